@@ -1,0 +1,324 @@
+// mcq_api.hip -- host side of libmcq.so: the C ABI declared in include/mcq.h.
+//
+// The handle owns one HIP stream and the per-batch device workspace ("slabs": band matrices, factor, vectors) on one
+// device; it is grown on demand and reused across calls.  One process per GPU creates one handle (bench.py,
+// engine.py); a multi-GPU job is N such processes, each solving a contiguous shard of the batch.
+#include <hip/hip_runtime.h>
+
+#include <stdio.h>
+#include <string.h>
+
+#include <string>
+#include <vector>
+
+#include "mcq_kernels.h"
+
+static thread_local std::string g_err;
+
+#define HIP_TRY(expr)                                                                                     \
+    do {                                                                                                  \
+        hipError_t e_ = (expr);                                                                           \
+        if (e_ != hipSuccess) {                                                                           \
+            char buf_[512];                                                                               \
+            snprintf(buf_, sizeof(buf_), "%s failed: %s (%s:%d)", #expr, hipGetErrorString(e_), __FILE__, \
+                     __LINE__);                                                                           \
+            g_err = buf_;                                                                                 \
+            return MCQ_E_DEVICE;                                                                          \
+        }                                                                                                 \
+    } while (0)
+
+struct mcq_handle {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    hipEvent_t ev[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};
+    bool timing_valid = false;
+    // workspace slabs
+    size_t cap_elems = 0;   // batch * nmax the slabs are sized for
+    size_t cap_batch = 0;
+    double *Eb = nullptr, *Et = nullptr, *Db = nullptr, *H = nullptr, *L = nullptr, *vec = nullptr;
+    signed char* state = nullptr;
+    // staging for the host-buffer entry point
+    double *d_ref = nullptr, *d_nv = nullptr, *d_sc = nullptr, *d_alpha = nullptr, *d_curv = nullptr, *d_kb = nullptr,
+           *d_wv = nullptr;
+    int *d_n = nullptr, *d_status = nullptr;
+    mcq_info* d_info = nullptr;
+    size_t stage_elems = 0, stage_batch = 0;
+    long long ws_bytes = 0;
+    bool smem_attr_set = false;
+};
+
+extern "C" const char* mcq_last_error(void) { return g_err.c_str(); }
+
+extern "C" void mcq_default_opts(mcq_opts* o)
+{
+    if (!o) return;
+    o->band_e = 32;
+    o->max_ipm_iter = 60;
+    o->max_as_iter = 60;
+    o->refine_steps = 2;
+    o->check_kappa = 1;
+}
+
+static mcq_opts resolve_opts(const mcq_opts* in)
+{
+    mcq_opts o;
+    mcq_default_opts(&o);
+    if (in) {
+        if (in->band_e > 0) o.band_e = in->band_e < MCQ_BE_MAX ? in->band_e : MCQ_BE_MAX;
+        if (in->max_ipm_iter > 0) o.max_ipm_iter = in->max_ipm_iter;
+        if (in->max_as_iter > 0) o.max_as_iter = in->max_as_iter;
+        if (in->refine_steps >= 0) o.refine_steps = in->refine_steps;
+        o.check_kappa = in->check_kappa;
+    }
+    return o;
+}
+
+extern "C" int mcq_create(int device_id, mcq_handle** out)
+{
+    if (!out) { g_err = "mcq_create: out is NULL"; return MCQ_E_ARG; }
+    *out = nullptr;
+    int ndev = 0;
+    HIP_TRY(hipGetDeviceCount(&ndev));
+    if (device_id < 0 || device_id >= ndev) { g_err = "mcq_create: no such device"; return MCQ_E_DEVICE; }
+    HIP_TRY(hipSetDevice(device_id));
+    mcq_handle* h = new mcq_handle();
+    h->device = device_id;
+    HIP_TRY(hipStreamCreate(&h->stream));
+    for (int k = 0; k < 5; ++k) HIP_TRY(hipEventCreate(&h->ev[k]));
+    *out = h;
+    return 0;
+}
+
+static void free_ws(mcq_handle* h)
+{
+    (void)hipFree(h->Eb); (void)hipFree(h->Et); (void)hipFree(h->Db); (void)hipFree(h->H); (void)hipFree(h->L); (void)hipFree(h->vec); (void)hipFree(h->state);
+    h->Eb = h->Et = h->Db = h->H = h->L = h->vec = nullptr;
+    h->state = nullptr;
+    h->cap_elems = h->cap_batch = 0;
+}
+
+static void free_stage(mcq_handle* h)
+{
+    (void)hipFree(h->d_ref); (void)hipFree(h->d_nv); (void)hipFree(h->d_sc); (void)hipFree(h->d_alpha); (void)hipFree(h->d_curv); (void)hipFree(h->d_kb);
+    (void)hipFree(h->d_wv); (void)hipFree(h->d_n); (void)hipFree(h->d_status); (void)hipFree(h->d_info);
+    h->d_ref = h->d_nv = h->d_sc = h->d_alpha = h->d_curv = h->d_kb = h->d_wv = nullptr;
+    h->d_n = h->d_status = nullptr;
+    h->d_info = nullptr;
+    h->stage_elems = h->stage_batch = 0;
+}
+
+extern "C" void mcq_destroy(mcq_handle* h)
+{
+    if (!h) return;
+    (void)hipSetDevice(h->device);
+    if (h->stream) (void)hipStreamSynchronize(h->stream);
+    free_ws(h);
+    free_stage(h);
+    for (int k = 0; k < 5; ++k) if (h->ev[k]) (void)hipEventDestroy(h->ev[k]);
+    if (h->stream) (void)hipStreamDestroy(h->stream);
+    delete h;
+}
+
+static int ensure_ws(mcq_handle* h, size_t batch, size_t nmax)
+{
+    const size_t elems = batch * nmax;
+    if (elems <= h->cap_elems && batch <= h->cap_batch) return 0;
+    HIP_TRY(hipStreamSynchronize(h->stream));
+    free_ws(h);
+    HIP_TRY(hipMalloc((void**)&h->Eb, elems * MCQ_ELD * sizeof(double)));
+    HIP_TRY(hipMalloc((void**)&h->Et, elems * MCQ_ELD * sizeof(double)));
+    HIP_TRY(hipMalloc((void**)&h->Db, elems * MCQ_ELD * sizeof(double)));
+    HIP_TRY(hipMalloc((void**)&h->H, elems * MCQ_HLD * sizeof(double)));
+    HIP_TRY(hipMalloc((void**)&h->L, elems * MCQ_HLD * sizeof(double)));
+    HIP_TRY(hipMalloc((void**)&h->vec, elems * MCQ_NVEC * sizeof(double)));
+    HIP_TRY(hipMalloc((void**)&h->state, elems));
+    h->cap_elems = elems;
+    h->cap_batch = batch;
+    h->ws_bytes = (long long)(elems * ((3 * MCQ_ELD + 2 * MCQ_HLD + MCQ_NVEC) * sizeof(double) + 1));
+    return 0;
+}
+
+static int ensure_stage(mcq_handle* h, size_t batch, size_t nmax)
+{
+    const size_t elems = batch * nmax;
+    if (elems <= h->stage_elems && batch <= h->stage_batch) return 0;
+    HIP_TRY(hipStreamSynchronize(h->stream));
+    free_stage(h);
+    HIP_TRY(hipMalloc((void**)&h->d_ref, elems * 4 * sizeof(double)));
+    HIP_TRY(hipMalloc((void**)&h->d_nv, elems * 2 * sizeof(double)));
+    HIP_TRY(hipMalloc((void**)&h->d_sc, elems * sizeof(double)));
+    HIP_TRY(hipMalloc((void**)&h->d_alpha, elems * sizeof(double)));
+    HIP_TRY(hipMalloc((void**)&h->d_curv, batch * sizeof(double)));
+    HIP_TRY(hipMalloc((void**)&h->d_kb, batch * sizeof(double)));
+    HIP_TRY(hipMalloc((void**)&h->d_wv, batch * sizeof(double)));
+    HIP_TRY(hipMalloc((void**)&h->d_n, batch * sizeof(int)));
+    HIP_TRY(hipMalloc((void**)&h->d_status, batch * sizeof(int)));
+    HIP_TRY(hipMalloc((void**)&h->d_info, batch * sizeof(mcq_info)));
+    h->stage_elems = elems;
+    h->stage_batch = batch;
+    return 0;
+}
+
+static int launch(mcq_handle* h, McqBatch& B, const mcq_opts& o)
+{
+    B.Eb = h->Eb; B.Et = h->Et; B.Db = h->Db; B.H = h->H; B.L = h->L; B.vec = h->vec; B.state = h->state;
+    B.band_e = o.band_e;
+    B.max_ipm_iter = o.max_ipm_iter;
+    B.max_as_iter = o.max_as_iter;
+    B.refine_steps = o.refine_steps;
+    B.check_kappa = o.check_kappa;
+    const size_t smem = mcq_solve_smem_bytes();
+    if (!h->smem_attr_set) {
+        HIP_TRY(hipFuncSetAttribute((const void*)mcq_solve_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
+        h->smem_attr_set = true;
+    }
+    HIP_TRY(hipEventRecord(h->ev[0], h->stream));
+    hipLaunchKernelGGL(mcq_assemble_kernel, dim3(B.batch), dim3(256), 0, h->stream, B);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipEventRecord(h->ev[1], h->stream));
+    hipLaunchKernelGGL(mcq_gram_kernel, dim3(B.batch, 8), dim3(256), 0, h->stream, B);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipEventRecord(h->ev[2], h->stream));
+    hipLaunchKernelGGL(mcq_solve_kernel, dim3(B.batch), dim3(256), smem, h->stream, B);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipEventRecord(h->ev[3], h->stream));
+    HIP_TRY(hipEventRecord(h->ev[4], h->stream));
+    h->timing_valid = true;
+    return 0;
+}
+
+extern "C" int mcq_solve_device(mcq_handle* h, int batch, int n, const double* reftrack, const double* normvec,
+                                const double* scaling, double kappa_bound, double w_veh, const mcq_opts* opts,
+                                double* alpha_out, double* curv_err_out, int* status_out, mcq_info* info_out)
+{
+    if (!h || batch <= 0 || n <= 0 || !reftrack || !normvec || !alpha_out || !curv_err_out || !status_out) {
+        g_err = "mcq_solve_device: bad argument";
+        return MCQ_E_ARG;
+    }
+    HIP_TRY(hipSetDevice(h->device));
+    const mcq_opts o = resolve_opts(opts);
+    int rc = ensure_ws(h, (size_t)batch, (size_t)n);
+    if (rc) return rc;
+    McqBatch B;
+    memset(&B, 0, sizeof(B));
+    B.batch = batch;
+    B.n = n;
+    B.nmax = n;
+    B.n_list = nullptr;
+    B.ref = reftrack;
+    B.nv = normvec;
+    B.sc = scaling;
+    B.alpha = alpha_out;
+    B.curv_err = curv_err_out;
+    B.status = status_out;
+    B.info = info_out;
+    B.kappa_bound = kappa_bound;
+    B.w_veh = w_veh;
+    return launch(h, B, o);
+}
+
+extern "C" int mcq_sync(mcq_handle* h)
+{
+    if (!h) { g_err = "mcq_sync: NULL handle"; return MCQ_E_ARG; }
+    HIP_TRY(hipSetDevice(h->device));
+    HIP_TRY(hipStreamSynchronize(h->stream));
+    return 0;
+}
+
+extern "C" void* mcq_stream(mcq_handle* h) { return h ? (void*)h->stream : nullptr; }
+
+extern "C" int mcq_last_timing(mcq_handle* h, float ms[5])
+{
+    if (!h || !ms || !h->timing_valid) { g_err = "mcq_last_timing: no timed launch"; return MCQ_E_ARG; }
+    HIP_TRY(hipSetDevice(h->device));
+    HIP_TRY(hipEventSynchronize(h->ev[4]));
+    HIP_TRY(hipEventElapsedTime(&ms[0], h->ev[0], h->ev[1]));
+    HIP_TRY(hipEventElapsedTime(&ms[1], h->ev[1], h->ev[2]));
+    HIP_TRY(hipEventElapsedTime(&ms[2], h->ev[2], h->ev[3]));
+    ms[3] = 0.0f;
+    HIP_TRY(hipEventElapsedTime(&ms[4], h->ev[0], h->ev[4]));
+    return 0;
+}
+
+extern "C" long long mcq_workspace_bytes(mcq_handle* h) { return h ? h->ws_bytes : 0; }
+
+extern "C" int mcq_solve_batch(mcq_handle* h, const mcq_problem* probs, int batch, const mcq_opts* opts,
+                               double* alpha_out, double* curv_err_out, int* status_out, mcq_info* info_out)
+{
+    if (!h || !probs || batch <= 0 || !alpha_out || !curv_err_out || !status_out) {
+        g_err = "mcq_solve_batch: bad argument";
+        return MCQ_E_ARG;
+    }
+    HIP_TRY(hipSetDevice(h->device));
+    const mcq_opts o = resolve_opts(opts);
+    size_t nmax = 3;
+    bool any_sc = false;
+    for (int b = 0; b < batch; ++b) {
+        if (!probs[b].reftrack || !probs[b].normvec || probs[b].n < 0) {
+            g_err = "mcq_solve_batch: problem with NULL buffers";
+            return MCQ_E_ARG;
+        }
+        if ((size_t)probs[b].n > nmax) nmax = (size_t)probs[b].n;
+        if (probs[b].scaling) any_sc = true;
+    }
+    int rc = ensure_ws(h, (size_t)batch, nmax);
+    if (rc) return rc;
+    rc = ensure_stage(h, (size_t)batch, nmax);
+    if (rc) return rc;
+
+    // pack [batch][nmax][*]
+    std::vector<double> ref((size_t)batch * nmax * 4, 0.0), nv((size_t)batch * nmax * 2, 0.0), sc;
+    std::vector<double> kb(batch), wv(batch);
+    std::vector<int> nl(batch);
+    if (any_sc) sc.assign((size_t)batch * nmax, 1.0);
+    for (int b = 0; b < batch; ++b) {
+        const size_t n = (size_t)probs[b].n;
+        memcpy(&ref[(size_t)b * nmax * 4], probs[b].reftrack, n * 4 * sizeof(double));
+        memcpy(&nv[(size_t)b * nmax * 2], probs[b].normvec, n * 2 * sizeof(double));
+        if (any_sc && probs[b].scaling) memcpy(&sc[(size_t)b * nmax], probs[b].scaling, n * sizeof(double));
+        kb[b] = probs[b].kappa_bound;
+        wv[b] = probs[b].w_veh;
+        nl[b] = probs[b].n;
+    }
+    HIP_TRY(hipMemcpyAsync(h->d_ref, ref.data(), ref.size() * sizeof(double), hipMemcpyHostToDevice, h->stream));
+    HIP_TRY(hipMemcpyAsync(h->d_nv, nv.data(), nv.size() * sizeof(double), hipMemcpyHostToDevice, h->stream));
+    if (any_sc)
+        HIP_TRY(hipMemcpyAsync(h->d_sc, sc.data(), sc.size() * sizeof(double), hipMemcpyHostToDevice, h->stream));
+    HIP_TRY(hipMemcpyAsync(h->d_kb, kb.data(), batch * sizeof(double), hipMemcpyHostToDevice, h->stream));
+    HIP_TRY(hipMemcpyAsync(h->d_wv, wv.data(), batch * sizeof(double), hipMemcpyHostToDevice, h->stream));
+    HIP_TRY(hipMemcpyAsync(h->d_n, nl.data(), batch * sizeof(int), hipMemcpyHostToDevice, h->stream));
+
+    McqBatch B;
+    memset(&B, 0, sizeof(B));
+    B.batch = batch;
+    B.n = (int)nmax;
+    B.nmax = (int)nmax;
+    B.n_list = h->d_n;
+    B.ref = h->d_ref;
+    B.nv = h->d_nv;
+    B.sc = any_sc ? h->d_sc : nullptr;
+    B.alpha = h->d_alpha;
+    B.curv_err = h->d_curv;
+    B.status = h->d_status;
+    B.info = h->d_info;
+    B.kappa_bound_list = h->d_kb;
+    B.w_veh_list = h->d_wv;
+    rc = launch(h, B, o);
+    if (rc) return rc;
+
+    std::vector<double> alpha((size_t)batch * nmax);
+    std::vector<mcq_info> info(batch);
+    HIP_TRY(hipMemcpyAsync(alpha.data(), h->d_alpha, alpha.size() * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+    HIP_TRY(hipMemcpyAsync(curv_err_out, h->d_curv, batch * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+    HIP_TRY(hipMemcpyAsync(status_out, h->d_status, batch * sizeof(int), hipMemcpyDeviceToHost, h->stream));
+    HIP_TRY(hipMemcpyAsync(info.data(), h->d_info, batch * sizeof(mcq_info), hipMemcpyDeviceToHost, h->stream));
+    HIP_TRY(hipStreamSynchronize(h->stream));
+    size_t off = 0;
+    for (int b = 0; b < batch; ++b) {
+        const size_t n = (size_t)probs[b].n;
+        memcpy(alpha_out + off, &alpha[(size_t)b * nmax], n * sizeof(double));
+        off += n;
+        if (info_out) info_out[b] = info[b];
+    }
+    return 0;
+}

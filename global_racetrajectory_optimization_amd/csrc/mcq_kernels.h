@@ -1,0 +1,111 @@
+// mcq_kernels.h -- hand-written HIP (gfx950 / CDNA4) kernels of the minimum-curvature raceline QP engine.
+//
+// One workgroup == one problem (one closed reference track); the batch is the grid.  Everything is fp64.
+// The maths follows SURVEY.md App. A (restating tph.opt_min_curv, call sites [REF main_globaltraj.py:264-271,
+// 344-350]); DESIGN.md sections 3-5 derive the structure-exploiting form used here:
+//
+//   K1 mcq_assemble_kernel : [x,y,w_r,w_l] rows, normals, spline scalings  ->  cyclic-banded E_kappa (and its
+//                            transpose band), D band, k_ref, x', y', box bounds.  The closed cubic-spline system
+//                            is a cyclic tridiagonal solve; rows of its inverse come from the periodic pivot
+//                            recurrences (exact to fp64 round-off: entries decay like 0.268^k).
+//   K2 mcq_gram_kernel     : H = E'E in "bordered band" storage (interior band + dense border that carries the
+//                            cyclic wrap-around), f = MCQ_F_SCALE * E' k_ref.
+//   K3 mcq_solve_kernel    : Mehrotra predictor-corrector interior point on the box QP (one bordered-band Cholesky
+//                            per iteration, LDS sliding window) -> active-set identification -> block-pivoting
+//                            active-set iterations on the identified vertex (exact KKT point, like the
+//                            Goldfarb-Idnani solver the reference uses returns) -> fp64 residual refinement through
+//                            E -> curvature-row check -> opt_min_curv's curvature-error post-check.
+//
+// Global-memory layout per problem (doubles, leading dimension in brackets):
+//   Eb/Db    [n][MCQ_ELD]  cyclic bands, entry [i][bE+o] = M[i, (i+o) mod n],  -bE <= o <= bR
+//   Et       [n][MCQ_ELD]  transpose band, entry [j][bR+o] = E[(j+o) mod n, j],  -bR <= o <= bE
+//   H, L     [n][MCQ_HLD]  interior rows i < ni: [0..b] band (H: H[i,i+k] upper / L: L[i,i-k] lower, L[.][0] = 1/L_ii),
+//                          [MCQ_HBO + jj] border coupling H[i, ni+jj] / W[i][jj];
+//                          border rows i = ni+j: [MCQ_HBO + jj] = D[j][jj] (H only; L_S stays in LDS)
+//   vectors  [n]           see Work struct
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include "../../include/mcq.h"
+
+#define MCQ_BE_MAX 32
+#define MCQ_BH_MAX 64
+#define MCQ_P_MAX 64
+#define MCQ_ELD 66                 /* 2*BE_MAX+1 = 65, padded */
+#define MCQ_GW (MCQ_BE_MAX + 2)    /* half-width of the T^-1 rows kept */
+#define MCQ_GLD 72                 /* 2*GW+1 = 69, padded */
+#define MCQ_HBO 66                 /* offset of the border part inside an H/L row */
+#define MCQ_HLD 130                /* BH_MAX+1 band | pad | P_MAX border */
+#define MCQ_NVEC 20
+#define MCQ_PIVOT_WARMUP 64
+
+// bE / bR: half-widths of the cyclic band of E_kappa to the left / right of the diagonal.  bR = bE except for small
+// even n, where the ring is fully covered by offsets [-bE, bE+1] (every column exactly once, E is then dense-exact).
+struct McqDims {
+    int n, bE, bR, ew, bH, p, ni, b;
+};
+
+__host__ __device__ inline McqDims mcq_dims(int n, int band_e)
+{
+    McqDims d;
+    d.n = n;
+    int bE = band_e < (n - 1) / 2 ? band_e : (n - 1) / 2;
+    if (bE < 1) bE = 1;
+    d.bE = bE;
+    d.bR = (n % 2 == 0 && band_e >= n / 2) ? bE + 1 : bE;
+    d.ew = d.bE + d.bR + 1;
+    d.bH = d.bE + d.bR < n / 2 ? d.bE + d.bR : n / 2;
+    if (d.bH < 1) d.bH = 1;
+    d.p = d.bH;
+    d.ni = n - d.p;
+    d.b = d.bH < d.ni - 1 ? d.bH : d.ni - 1;
+    if (d.b < 0) d.b = 0;
+    return d;
+}
+
+// Device workspace of ONE problem (pointers into the handle's slabs).
+struct McqWork {
+    const double* ref;   // [n][4]
+    const double* nv;    // [n][2]
+    const double* sc;    // [n] or nullptr
+    double* Eb;
+    double* Et;
+    double* Db;
+    double* H;
+    double* L;           // also scratch for the T^-1 rows during assembly
+    double* vec;         // MCQ_NVEC vectors of length nmax, see enum below
+    signed char* state;  // [n] 0 free, -1 at lower bound, +1 at upper bound, 2 fixed (lo == hi)
+    double* alpha;       // [n] output
+    double* curv_err;    // [1]
+    int* status;         // [1]
+    mcq_info* info;      // [1] or nullptr
+};
+
+enum {
+    V_XP = 0, V_YP, V_CP, V_KREF, V_XPP, V_YPP, V_F, V_LO, V_HI, V_X, V_G, V_ZL, V_ZU, V_SIG, V_RHS, V_DXA, V_T0, V_T1,
+    V_T2, V_T3
+};
+
+struct McqBatch {
+    int batch;
+    int n;          // uniform-n path (n_list == nullptr) or nmax
+    int nmax;
+    const int* n_list;      // per-problem n (device) or nullptr
+    const double* ref;      // [batch][nmax][4]
+    const double* nv;       // [batch][nmax][2]
+    const double* sc;       // [batch][nmax] or nullptr
+    double* Eb; double* Et; double* Db; double* H; double* L; double* vec;
+    signed char* state;
+    double* alpha;          // [batch][nmax]
+    double* curv_err; int* status; mcq_info* info;
+    double kappa_bound, w_veh;
+    const double* kappa_bound_list;  // per-problem overrides (device) or nullptr
+    const double* w_veh_list;
+    int band_e, max_ipm_iter, max_as_iter, refine_steps, check_kappa;
+};
+
+__global__ void mcq_assemble_kernel(McqBatch B);
+__global__ void mcq_gram_kernel(McqBatch B);
+__global__ void mcq_solve_kernel(McqBatch B);
+
+size_t mcq_solve_smem_bytes();

@@ -1,0 +1,195 @@
+"""
+ctypes host binding of libmcq.so (C ABI in include/mcq.h) -- the MI355X minimum-curvature QP engine.
+
+This is plumbing, not a fallback layer: the only implementation behind these calls is the hand-written HIP library
+built by csrc/build.sh for gfx950.  If it is missing or cannot be loaded the import of the engine fails loudly;
+there is no CPU path in the product (the CPU oracle lives in /oracle and is test infrastructure only).
+
+Mirrors the reference-side interface for the hot path:
+    solve_batch(problems)          -> what tph.opt_min_curv.opt_min_curv binds  [REF main_globaltraj.py:264-271]
+    Engine.solve_device(...)       -> device-resident batch entry (bench, IQP driver, multi-GPU shards)
+"""
+import ctypes
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+DEFAULT_LIB = os.path.join(_HERE, "csrc", "libmcq.so")
+
+STATUS_OK, STATUS_INFEASIBLE, STATUS_NOT_PD, STATUS_ITER_CAP, STATUS_BAD_INPUT, STATUS_KAPPA_INFEASIBLE, \
+    STATUS_KAPPA_ACTIVE = range(7)
+
+_dp = ctypes.POINTER(ctypes.c_double)
+_ip = ctypes.POINTER(ctypes.c_int)
+
+
+class McqProblem(ctypes.Structure):
+    _fields_ = [("n", ctypes.c_int), ("reftrack", _dp), ("normvec", _dp), ("scaling", _dp),
+                ("kappa_bound", ctypes.c_double), ("w_veh", ctypes.c_double)]
+
+
+class McqOpts(ctypes.Structure):
+    _fields_ = [("band_e", ctypes.c_int), ("max_ipm_iter", ctypes.c_int), ("max_as_iter", ctypes.c_int),
+                ("refine_steps", ctypes.c_int), ("check_kappa", ctypes.c_int)]
+
+
+class McqInfo(ctypes.Structure):
+    _fields_ = [("ipm_iters", ctypes.c_int), ("as_iters", ctypes.c_int), ("n_active_box", ctypes.c_int),
+                ("n_active_kappa", ctypes.c_int), ("kappa_max", ctypes.c_double), ("kkt_res", ctypes.c_double)]
+
+
+EXPORTED_SYMBOLS = ("mcq_create", "mcq_destroy", "mcq_last_error", "mcq_default_opts", "mcq_solve_batch",
+                    "mcq_solve_device", "mcq_sync", "mcq_stream", "mcq_last_timing", "mcq_workspace_bytes")
+
+
+class EngineError(RuntimeError):
+    pass
+
+
+def load_library(path=None):
+    """Load libmcq.so and declare the C ABI.  Raises EngineError if the HIP library is absent -- never falls back."""
+    path = path or os.environ.get("MCQ_LIB") or DEFAULT_LIB
+    if not os.path.exists(path):
+        raise EngineError("MI355X engine library not found at %s -- build it with "
+                          "global_racetrajectory_optimization_amd/csrc/build.sh (hipcc, gfx950)" % path)
+    lib = ctypes.CDLL(path)
+    vp = ctypes.c_void_p
+    lib.mcq_create.argtypes = [ctypes.c_int, ctypes.POINTER(vp)]
+    lib.mcq_create.restype = ctypes.c_int
+    lib.mcq_destroy.argtypes = [vp]
+    lib.mcq_destroy.restype = None
+    lib.mcq_last_error.argtypes = []
+    lib.mcq_last_error.restype = ctypes.c_char_p
+    lib.mcq_default_opts.argtypes = [ctypes.POINTER(McqOpts)]
+    lib.mcq_default_opts.restype = None
+    lib.mcq_solve_batch.argtypes = [vp, ctypes.POINTER(McqProblem), ctypes.c_int, ctypes.POINTER(McqOpts), _dp, _dp,
+                                    _ip, ctypes.POINTER(McqInfo)]
+    lib.mcq_solve_batch.restype = ctypes.c_int
+    lib.mcq_solve_device.argtypes = [vp, ctypes.c_int, ctypes.c_int, vp, vp, vp, ctypes.c_double, ctypes.c_double,
+                                     ctypes.POINTER(McqOpts), vp, vp, vp, vp]
+    lib.mcq_solve_device.restype = ctypes.c_int
+    lib.mcq_sync.argtypes = [vp]
+    lib.mcq_sync.restype = ctypes.c_int
+    lib.mcq_stream.argtypes = [vp]
+    lib.mcq_stream.restype = vp
+    lib.mcq_last_timing.argtypes = [vp, ctypes.POINTER(ctypes.c_float * 5)]
+    lib.mcq_last_timing.restype = ctypes.c_int
+    lib.mcq_workspace_bytes.argtypes = [vp]
+    lib.mcq_workspace_bytes.restype = ctypes.c_longlong
+    return lib
+
+
+def _as_dp(a):
+    return a.ctypes.data_as(_dp)
+
+
+class Engine:
+    """One handle == one GPU + one HIP stream + its device workspace.  One host thread at a time."""
+
+    def __init__(self, device_id=0, lib_path=None):
+        self.lib = load_library(lib_path)
+        h = ctypes.c_void_p()
+        rc = self.lib.mcq_create(int(device_id), ctypes.byref(h))
+        if rc != 0:
+            raise EngineError("mcq_create(%d) failed: %s" % (device_id, self.lib.mcq_last_error().decode()))
+        self.h = h
+        self.device_id = int(device_id)
+
+    def close(self):
+        if getattr(self, "h", None):
+            self.lib.mcq_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _opts(self, band_e=0, max_ipm_iter=0, max_as_iter=0, refine_steps=-1, check_kappa=1):
+        return McqOpts(int(band_e), int(max_ipm_iter), int(max_as_iter), int(refine_steps), int(check_kappa))
+
+    def _check(self, rc, what):
+        if rc != 0:
+            raise EngineError("%s failed (%d): %s" % (what, rc, self.lib.mcq_last_error().decode()))
+
+    # ------------------------------------------------------------------------------------------------------------------
+    def solve_batch(self, problems, **opt_kw):
+        """problems: list of dicts {reftrack [n,4], normvec [n,2], scaling [n] or None, kappa_bound, w_veh}.
+
+        Returns (alphas: list of [n] arrays, curv_err [B], status [B] int32, info: list of dicts).
+        """
+        bsz = len(problems)
+        keep = []
+        arr = (McqProblem * bsz)()
+        total = 0
+        for k, p in enumerate(problems):
+            ref = np.ascontiguousarray(p["reftrack"], dtype=np.float64)
+            nv = np.ascontiguousarray(p["normvec"], dtype=np.float64)
+            n = ref.shape[0]
+            if ref.ndim != 2 or ref.shape[1] != 4 or nv.shape != (n, 2):
+                raise ValueError("reftrack must be [n,4] and normvec [n,2]")
+            sc = p.get("scaling")
+            if sc is not None:
+                sc = np.ascontiguousarray(sc, dtype=np.float64)
+                if sc.shape != (n,):
+                    raise ValueError("scaling must be [n]")
+            keep.append((ref, nv, sc))
+            arr[k].n = n
+            arr[k].reftrack = _as_dp(ref)
+            arr[k].normvec = _as_dp(nv)
+            arr[k].scaling = _as_dp(sc) if sc is not None else None
+            arr[k].kappa_bound = float(p["kappa_bound"])
+            arr[k].w_veh = float(p["w_veh"])
+            total += n
+        alpha = np.zeros(total)
+        curv = np.zeros(bsz)
+        status = np.zeros(bsz, dtype=np.int32)
+        info = (McqInfo * bsz)()
+        opts = self._opts(**opt_kw)
+        rc = self.lib.mcq_solve_batch(self.h, arr, bsz, ctypes.byref(opts), _as_dp(alpha), _as_dp(curv),
+                                      status.ctypes.data_as(_ip), info)
+        self._check(rc, "mcq_solve_batch")
+        out, off = [], 0
+        for ref, _, _ in keep:
+            out.append(alpha[off:off + ref.shape[0]].copy())
+            off += ref.shape[0]
+        infos = [dict(ipm_iters=i.ipm_iters, as_iters=i.as_iters, n_active_box=i.n_active_box,
+                      n_active_kappa=i.n_active_kappa, kappa_max=i.kappa_max, kkt_res=i.kkt_res) for i in info]
+        return out, curv, status, infos
+
+    # ------------------------------------------------------------------------------------------------------------------
+    def solve_device(self, batch, n, d_reftrack, d_normvec, d_scaling, kappa_bound, w_veh, d_alpha, d_curv, d_status,
+                     d_info=None, **opt_kw):
+        """Device-resident batch (raw device pointers as ints, e.g. torch.Tensor.data_ptr()).  Asynchronous."""
+        opts = self._opts(**opt_kw)
+        rc = self.lib.mcq_solve_device(self.h, int(batch), int(n), d_reftrack, d_normvec, d_scaling or None,
+                                       float(kappa_bound), float(w_veh), ctypes.byref(opts), d_alpha, d_curv, d_status,
+                                       d_info or None)
+        self._check(rc, "mcq_solve_device")
+
+    def sync(self):
+        self._check(self.lib.mcq_sync(self.h), "mcq_sync")
+
+    def stream(self):
+        return self.lib.mcq_stream(self.h)
+
+    def last_timing_ms(self):
+        ms = (ctypes.c_float * 5)()
+        self._check(self.lib.mcq_last_timing(self.h, ctypes.byref(ms)), "mcq_last_timing")
+        return dict(assemble=ms[0], gram=ms[1], solve=ms[2], post=ms[3], total=ms[4])
+
+    def workspace_bytes(self):
+        return int(self.lib.mcq_workspace_bytes(self.h))
+
+
+_DEFAULT_ENGINE = None
+
+
+def default_engine():
+    """Process-wide engine on the device given by LOCAL_RANK (one process per GPU) or device 0."""
+    global _DEFAULT_ENGINE
+    if _DEFAULT_ENGINE is None:
+        _DEFAULT_ENGINE = Engine(int(os.environ.get("MCQ_DEVICE", os.environ.get("LOCAL_RANK", "0"))))
+    return _DEFAULT_ENGINE

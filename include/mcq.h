@@ -1,0 +1,117 @@
+/*
+ * mcq.h -- C ABI of the MI355X-native minimum-curvature raceline QP engine (libmcq.so).
+ *
+ * Drop-in boundary.  The reference has NO native interface for this path: it calls the
+ * third-party Python functions
+ *     trajectory_planning_helpers.opt_min_curv.opt_min_curv   [REF main_globaltraj.py:264-271, 344-350]
+ *     trajectory_planning_helpers.iqp_handler.iqp_handler     [REF main_globaltraj.py:273-284]
+ * which end in quadprog.solve_qp (C).  The entry points below are what a ctypes binding inside those two Python
+ * functions binds instead (INTEGRATION.md shows the stub).  Plain pointers and sizes only; no torch / numpy types.
+ *
+ * One "problem" = one closed reference track:
+ *     reftrack  [n][4] row-major double  = [x_m, y_m, w_tr_right_m, w_tr_left_m]   (producer [REF prep_track.py:39-45,104])
+ *     normvec   [n][2] row-major double  = unit normals pointing right             (producer [REF prep_track.py:50-51])
+ *     scaling   [n]    double            = s_i = l_i / l_{i+1}, the only information opt_min_curv needs from the
+ *                                          dense 4n x 4n matrix `A` the reference passes [REF main_globaltraj.py:267]
+ *                                          (s_i = -A[4i+2][4i+5], s_{n-1} = A[4n-2][1]); NULL => all ones
+ *                                          (calc_splines(use_dist_scaling=False), the iqp_handler re-spline).
+ * Result per problem: alpha[n] (lateral shift along the normal, metres; consumer [REF main_globaltraj.py:371-376]),
+ * curv_error_max (the opt_min_curv post-check that iqp_handler terminates on), status.
+ *
+ * The QP solved is exactly the one tph hands to quadprog:
+ *     minimise   1/2 a'Ha + f'a,   H = E'E,  f = MCQ_F_SCALE * E' k_ref
+ *     subject to -(w_l - w_veh/2) <= a <= (w_r - w_veh/2),     |k_ref + E a| <= kappa_bound
+ *
+ * Ownership: caller owns every buffer passed in; the library copies to / from device memory it owns inside the
+ * handle and retains no caller pointer after a call returns.  Threading: one host thread per handle at a time.
+ * Errors: functions return 0 on success or a negative MCQ_E_* code (mcq_last_error() gives text); per-problem
+ * outcomes are in status_out[].  The library never calls exit().
+ */
+#ifndef MCQ_H
+#define MCQ_H
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define MCQ_F_SCALE 2.0 /* the factor-2 quirk of tph's quadprog call -- reproduced, not fixed */
+
+/* per-problem status (status_out[]) */
+enum {
+    MCQ_OK = 0,
+    MCQ_INFEASIBLE = 1,      /* w_r + w_l < w_veh somewhere  -> tph raises RuntimeError("Problem not solvable, ...") */
+    MCQ_NOT_PD = 2,          /* Cholesky pivot <= 0            -> quadprog raises ValueError("matrix G is not positive definite") */
+    MCQ_ITER_CAP = 3,        /* iteration cap hit */
+    MCQ_BAD_INPUT = 4,       /* n < 3, non-finite input */
+    MCQ_KAPPA_INFEASIBLE = 5, /* curvature rows cannot be satisfied -> quadprog raises ValueError("constraints are inconsistent, no solution") */
+    MCQ_KAPPA_ACTIVE = 6      /* box-only optimum violates a curvature row and the curvature-row phase is disabled / failed */
+};
+
+/* library-level error codes (negative return values) */
+enum {
+    MCQ_E_ARG = -1,     /* NULL / out-of-range argument */
+    MCQ_E_DEVICE = -2,  /* HIP runtime error (no device, launch failure, out of memory) */
+    MCQ_E_TOO_LARGE = -3
+};
+
+typedef struct mcq_handle mcq_handle; /* opaque; owns device buffers + one HIP stream on one device */
+
+typedef struct {
+    int n;                  /* waypoints */
+    const double* reftrack; /* [n][4] */
+    const double* normvec;  /* [n][2] */
+    const double* scaling;  /* [n] or NULL */
+    double kappa_bound;     /* veh_params.curvlim  [REF params/racecar.ini:49] */
+    double w_veh;           /* optim_opts.width_opt [REF params/racecar.ini:72] */
+} mcq_problem;
+
+typedef struct {
+    int band_e;         /* cyclic half-bandwidth kept of E_kappa (<= 32; 0 => default 32; exact to fp64 round-off) */
+    int max_ipm_iter;   /* 0 => default 60 */
+    int max_as_iter;    /* 0 => default 60 */
+    int refine_steps;   /* fp64 residual-refinement rounds on the final active set; <0 => default 2 */
+    int check_kappa;    /* 0 => skip the curvature rows (box-only QP); default 1 */
+} mcq_opts;
+
+/* per-problem diagnostics (optional output) */
+typedef struct {
+    int ipm_iters;      /* interior-point iterations (one banded factorisation each) */
+    int as_iters;       /* active-set (block pivoting) iterations (one banded factorisation each) */
+    int n_active_box;   /* box rows active at the optimum */
+    int n_active_kappa; /* curvature rows active at the optimum */
+    double kappa_max;   /* max_i |k_ref_i + (E a)_i| at the returned a */
+    double kkt_res;     /* max free-gradient magnitude relative to max |f| */
+} mcq_info;
+
+int mcq_create(int device_id, mcq_handle** out);
+void mcq_destroy(mcq_handle* h);
+const char* mcq_last_error(void);
+void mcq_default_opts(mcq_opts* o);
+
+/* Host-buffer entry point == what opt_min_curv binds.  alpha_out is the concatenation of the per-problem alpha
+ * vectors (sum of n over the batch); curv_err_out/status_out/info_out have `batch` entries (info_out may be NULL). */
+int mcq_solve_batch(mcq_handle* h, const mcq_problem* probs, int batch, const mcq_opts* opts, double* alpha_out,
+                    double* curv_err_out, int* status_out, mcq_info* info_out);
+
+/* Device-resident entry points (uniform n, inputs already in HBM; used by bench.py, the IQP driver and the multi-GPU
+ * shard path).  All pointers are DEVICE pointers on the handle's device; layouts as above with a leading batch axis:
+ * reftrack [batch][n][4], normvec [batch][n][2], scaling [batch][n] or NULL, alpha_out [batch][n],
+ * curv_err_out [batch], status_out [batch], info_out [batch] or NULL.  Asynchronous on the handle's stream;
+ * mcq_sync() waits.  mcq_stream() returns the hipStream_t (as void*) so callers can record events on it. */
+int mcq_solve_device(mcq_handle* h, int batch, int n, const double* reftrack, const double* normvec,
+                     const double* scaling, double kappa_bound, double w_veh, const mcq_opts* opts, double* alpha_out,
+                     double* curv_err_out, int* status_out, mcq_info* info_out);
+int mcq_sync(mcq_handle* h);
+void* mcq_stream(mcq_handle* h);
+
+/* Timing of the last mcq_solve_device / mcq_solve_batch call, measured with HIP events on the handle's stream:
+ * ms[0] assembly kernel, ms[1] Gram kernel, ms[2] solver kernel, ms[3] post kernel, ms[4] whole launch sequence. */
+int mcq_last_timing(mcq_handle* h, float ms[5]);
+
+/* Bytes of device workspace the handle currently holds (for DESIGN.md / bench reporting). */
+long long mcq_workspace_bytes(mcq_handle* h);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MCQ_H */

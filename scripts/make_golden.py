@@ -1,0 +1,78 @@
+"""
+Generates tests/golden/*.npz -- run in the BUILD container only (it reads the reference's track CSVs under
+/root/reference/inputs/tracks, which do not exist on the GPU box).
+
+PARITY UNPINNED by the reference (it ships no tests / expected outputs and tph + quadprog are not installable here,
+SURVEY.md section 8c).  The vectors are therefore produced by OUR dense-faithful oracle (oracle/tph_ref.py +
+oracle/gi_dense.c) on the reference's own inputs at the reference's default parameters
+[REF params/racecar.ini:13-15,21-22,49,72-74], and pinned by an independent route (scipy BVLS on the least-squares
+form) plus a KKT certificate -- both recorded in the fixture.
+
+Inputs (reftrack_interp) come from the host shim's spline_approximation (FITPACK), i.e. what prep_track hands on
+[REF helper_funcs_glob/src/prep_track.py:39-51].
+"""
+import json
+import os
+import sys
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+from global_racetrajectory_optimization_amd.trajectory_planning_helpers import spline_approximation as sa  # noqa: E402
+from oracle import qp_ref, tph_ref  # noqa: E402
+
+REF_TRACKS = "/root/reference/inputs/tracks"
+OUT = os.path.join(ROOT, "tests", "golden")
+KAPPA_BOUND, W_VEH = 0.12, 3.4          # racecar.ini: veh_params.curvlim, optim_opts_mincurv.width_opt
+STEPSIZE_REG, ITERS_MIN, CURV_ERR_ALLOWED = 3.0, 3, 0.01
+
+
+def main():
+    os.makedirs(OUT, exist_ok=True)
+    summary = {}
+    for name in ("rounded_rectangle", "handling_track", "modena_2019", "berlin_2018"):
+        trk = np.loadtxt(os.path.join(REF_TRACKS, name + ".csv"), comments="#", delimiter=",")
+        reftrack = sa.spline_approximation(trk, k_reg=3, s_reg=10, stepsize_prep=1.0, stepsize_reg=STEPSIZE_REG)
+        n = reftrack.shape[0]
+        path_cl = np.vstack((reftrack[:, :2], reftrack[0, :2]))
+        _, _, A, normvec = tph_ref.calc_splines(path_cl)
+        idx = np.arange(n - 1)
+        scaling = np.empty(n)
+        scaling[:-1] = -A[4 * idx + 2, 4 * idx + 5]
+        scaling[-1] = A[4 * n - 2, 1]
+        info = {}
+        alpha, curv_err, I = tph_ref.opt_min_curv(reftrack, normvec, A, KAPPA_BOUND, W_VEH, return_internals=True,
+                                                  solver=lambda H, f, G, h: qp_ref.solve_qp_gi(H, f, G, h, info))
+        lo, hi = -(reftrack[:, 3] - W_VEH / 2), reftrack[:, 2] - W_VEH / 2
+        kkt = qp_ref.kkt_residuals(I["H"], I["f"], I["G"], I["h"], alpha)
+        rec = dict(n=n, gi_iters=[int(v) for v in info["iters"]], n_active=kkt["n_active"],
+                   kkt_stationarity=kkt["stationarity"], curv_error_max=curv_err,
+                   kappa_max=float(np.max(np.abs(I["k_ref"] + I["E"] @ alpha))))
+        bvls_diff = np.nan
+        if n <= 300:
+            a2 = qp_ref.solve_box_bvls(I["E"], I["k_ref"], lo, hi)
+            bvls_diff = float(np.max(np.abs(a2 - alpha)))
+        rec["bvls_max_diff"] = bvls_diff
+        out = dict(reftrack=reftrack, normvec=normvec, scaling=scaling, alpha=alpha, curv_error_max=curv_err,
+                   k_ref=I["k_ref"], f=I["f"], h_diag=np.diag(I["H"]).copy(), e_diag=np.diag(I["E"]).copy(),
+                   kappa_bound=KAPPA_BOUND, w_veh=W_VEH)
+        if n <= 300:   # IQP golden (dense re-linearisation every pass)
+            trace = []
+            a_iqp, ref_iqp, nv_iqp = tph_ref.iqp_handler(reftrack, normvec, A, KAPPA_BOUND, W_VEH, STEPSIZE_REG,
+                                                         ITERS_MIN, CURV_ERR_ALLOWED, trace=trace)
+            out.update(iqp_alpha=a_iqp, iqp_reftrack=ref_iqp, iqp_normvec=nv_iqp,
+                       iqp_n=np.array([t["n"] for t in trace]),
+                       iqp_curv_err=np.array([t["curv_error_max"] for t in trace]))
+            rec["iqp_n"] = [int(t["n"]) for t in trace]
+            rec["iqp_curv_err"] = [float(t["curv_error_max"]) for t in trace]
+        np.savez_compressed(os.path.join(OUT, name + ".npz"), **out)
+        summary[name] = rec
+        print(name, rec)
+    with open(os.path.join(OUT, "SUMMARY.json"), "w") as fh:
+        json.dump(summary, fh, indent=1)
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,109 @@
+"""CPU tests that pin the oracle against itself and against the committed golden vectors (PARITY UNPINNED by the
+reference: it has no tests; see oracle/tph_ref.py header and SURVEY.md section 8c)."""
+import numpy as np
+import pytest
+
+from oracle import qp_ref, tph_ref
+
+
+def _circle(n=120, radius=57.3, ccw=True):
+    th = np.linspace(0.0, 2 * np.pi, n, endpoint=False)
+    if not ccw:
+        th = -th
+    xy = radius * np.column_stack((np.cos(th), np.sin(th)))
+    return xy
+
+
+def _prep(xy, w_r, w_l):
+    path_cl = np.vstack((xy, xy[0]))
+    _, _, A, nv = tph_ref.calc_splines(path_cl)
+    ref = np.column_stack((xy, np.full(xy.shape[0], w_r), np.full(xy.shape[0], w_l)))
+    return ref, nv, A
+
+
+def test_gi_dense_against_bvls_and_kkt(golden):
+    for name in ("rounded_rectangle", "handling_track"):
+        g = golden[name]
+        path_cl = np.vstack((g["reftrack"][:, :2], g["reftrack"][0, :2]))
+        _, _, A, nv = tph_ref.calc_splines(path_cl)
+        assert np.max(np.abs(nv - g["normvec"])) < 1e-13
+        alpha, err, I = tph_ref.opt_min_curv(g["reftrack"], nv, A, 0.12, 3.4, return_internals=True)
+        assert np.max(np.abs(alpha - g["alpha"])) < 1e-10
+        assert abs(err - float(g["curv_error_max"])) < 1e-12
+        lo, hi = -(g["reftrack"][:, 3] - 1.7), g["reftrack"][:, 2] - 1.7
+        a2 = qp_ref.solve_box_bvls(I["E"], I["k_ref"], lo, hi)
+        assert np.max(np.abs(a2 - alpha)) < 1e-9          # two independent routes agree
+        k = qp_ref.kkt_residuals(I["H"], I["f"], I["G"], I["h"], alpha)
+        assert k["stationarity"] < 1e-10 and k["primal"] < 1e-10
+        # structural identities the GPU formulation relies on
+        assert np.max(np.abs(I["H"] - I["E"].T @ I["E"])) < 1e-14 * np.max(np.abs(I["H"])) * 100
+        assert np.max(np.abs(I["f"] - 2.0 * I["E"].T @ I["k_ref"])) < 1e-12 * np.max(np.abs(I["f"]))
+
+
+def test_factor_two_quirk_is_reproduced(golden):
+    """quadprog sees 1/2 a'Ha + f'a with f = 2 E'k_ref; F_SCALE = 1 gives a different alpha."""
+    g = golden["rounded_rectangle"]
+    path_cl = np.vstack((g["reftrack"][:, :2], g["reftrack"][0, :2]))
+    _, _, A, nv = tph_ref.calc_splines(path_cl)
+    H, f, E, k_ref, _ = tph_ref.assemble_dense(g["reftrack"], nv, A)
+    Gm, h = tph_ref.constraints_dense(g["reftrack"], E, k_ref, 0.12, 3.4)
+    a_two = qp_ref.solve_qp_gi(H, f, Gm, h)
+    a_one = qp_ref.solve_qp_gi(H, 0.5 * f, Gm, h)
+    assert np.max(np.abs(a_two - g["alpha"])) < 1e-10
+    assert np.max(np.abs(a_one - g["alpha"])) > 1e-3
+
+
+def test_known_answer_circle():
+    """Circle, uniform widths: by symmetry alpha is constant; the single-shot QP moves the line inward to the bound
+    (SURVEY.md section 8c known-answer tests)."""
+    xy = _circle()
+    ref, nv, A = _prep(xy, 5.0, 5.0)
+    alpha, _ = tph_ref.opt_min_curv(ref, nv, A, 0.12, 3.4)
+    assert np.max(np.abs(alpha - alpha[0])) < 1e-8
+    assert abs(abs(alpha[0]) - 3.3) < 1e-9
+
+
+def test_too_narrow_raises():
+    xy = _circle()
+    ref, nv, A = _prep(xy, 1.0, 1.0)
+    with pytest.raises(RuntimeError, match="Problem not solvable"):
+        tph_ref.opt_min_curv(ref, nv, A, 0.12, 3.4)
+
+
+def test_rotation_and_mirror_invariance(golden):
+    g = golden["rounded_rectangle"]
+    ref = g["reftrack"]
+    n = ref.shape[0]
+    # roll the start index
+    refr = np.roll(ref, 17, axis=0)
+    path_cl = np.vstack((refr[:, :2], refr[0, :2]))
+    _, _, A, nv = tph_ref.calc_splines(path_cl)
+    ar, _ = tph_ref.opt_min_curv(refr, nv, A, 0.12, 3.4)
+    assert np.max(np.abs(np.roll(ar, -17) - g["alpha"])) < 1e-8
+    # mirror y, swap widths -> alpha changes sign
+    refm = ref.copy()
+    refm[:, 1] *= -1.0
+    refm[:, [2, 3]] = refm[:, [3, 2]]
+    path_cl = np.vstack((refm[:, :2], refm[0, :2]))
+    _, _, A, nv = tph_ref.calc_splines(path_cl)
+    am, _ = tph_ref.opt_min_curv(refm, nv, A, 0.12, 3.4)
+    assert np.max(np.abs(am + g["alpha"])) < 1e-8
+    assert n == 105
+
+
+def test_gi_reports_infeasible_and_not_pd():
+    H = np.eye(2)
+    f = np.zeros(2)
+    G = np.array([[1.0, 0.0], [-1.0, 0.0]])
+    h = np.array([-1.0, -1.0])     # x <= -1 and x >= 1
+    with pytest.raises(ValueError, match="inconsistent"):
+        qp_ref.solve_qp_gi(H, f, G, h)
+    with pytest.raises(ValueError, match="positive definite"):
+        qp_ref.solve_qp_gi(np.array([[1.0, 2.0], [2.0, 1.0]]), f, G, np.array([1.0, 1.0]))
+
+
+def test_iqp_golden_shapes(golden):
+    g = golden["rounded_rectangle"]
+    assert list(g["iqp_n"]) == [105, 104, 103]
+    assert g["iqp_curv_err"][-1] <= 0.01 < g["iqp_curv_err"][-2]
+    assert g["iqp_alpha"].shape[0] == g["iqp_reftrack"].shape[0] == g["iqp_normvec"].shape[0] == 103
