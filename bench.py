@@ -1,0 +1,180 @@
+#!/usr/bin/env python
+"""
+bench.py -- headline benchmark of the MI355X minimum-curvature QP engine (contract: see the task statement).
+
+Metric (BASELINE.json): min-curv QP solves/sec at N = 2000 waypoints, batch = 1024 per GPU.
+A "step" = one pass of the hot path (assembly a1 + QP a2 + curvature-error post-check a3) over one
+batch of 1024 synthetic perturbed-oval reference tracks (BASELINE config 3 generator) whose inputs
+are already resident in HBM; with N > 1 GPUs every rank solves its own 1024 tracks (weak scaling, no data-path
+collective inside the solve) and ONE RCCL all-gather collects the alpha vectors (north_star) inside the timed region.
+
+  python bench.py [--gpus N] [--steps K] [--warmup W] [--batch B] [--n N_WAYPOINTS] [--no-cpu-baseline]
+
+Prints ONE JSON line on rank 0.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+INFO_DTYPE = np.dtype([("ipm_iters", "<i4"), ("as_iters", "<i4"), ("n_active_box", "<i4"), ("n_active_kappa", "<i4"),
+                       ("kappa_max", "<f8"), ("kkt_res", "<f8")])
+HBM_PEAK_GBS = 8000.0        # MI355X HBM3E spec peak, /opt/skills/guides/MI355X_MICROARCH.md
+KAPPA_BOUND, W_VEH = 0.12, 3.4
+
+
+def algorithmic_bytes(n, info, band_e=32, refine_steps=2):
+    """Algorithmic HBM bytes of mcq_solve_kernel for one launch ('banded-exact' mode).
+
+    Per problem with b = p = 2*band_e (interior band / border width), row = (b + 1 + p) doubles of H or L:
+      factorisation : read H rows + write L rows                      2 * n * row * 8
+      solve         : forward + backward sweep, each reads L rows     2 * n * row * 8
+      gradient      : E band + E' band, (2*band_e+1) doubles per row  2 * n * (2*band_e+1) * 8
+    IPM iteration = 1 factorisation + 2 solves + 1 gradient; active-set iteration = 1 factorisation + 1 solve +
+    2 gradients; refinement round = 1 solve + 1 gradient; + 1 initial gradient + 3 band products in the epilogue.
+    Iteration counts are the ones the solver reports (mcq_info).
+    """
+    row = (2 * band_e + 1 + 2 * band_e) * 8.0
+    fac = 2.0 * n * row
+    sol = 2.0 * n * row
+    grad = 2.0 * n * (2 * band_e + 1) * 8.0
+    ipm = info["ipm_iters"].astype(np.float64)
+    act = info["as_iters"].astype(np.float64)
+    per = ipm * (fac + 2 * sol + grad) + act * (fac + sol + 2 * grad) + refine_steps * (sol + grad) + grad + 1.5 * grad
+    return float(per.sum())
+
+
+def cpu_baseline(ref, nv, sc):
+    """Oracle ('port' of the reference's CPU path: dense-faithful numpy assembly + dense Goldfarb-Idnani in C) timed on
+    ONE problem of the same workload.  Test infrastructure used as the checker/baseline only, never shipped."""
+    from global_racetrajectory_optimization_amd.trajectory_planning_helpers import calc_splines as cs
+    from oracle import qp_ref, tph_ref
+    qp_ref.build()
+    n = ref.shape[0]
+    A = cs.build_les_matrix(n, sc)
+    t0 = time.perf_counter()
+    alpha, err = tph_ref.opt_min_curv(ref, nv, A, KAPPA_BOUND, W_VEH)
+    dt = time.perf_counter() - t0
+    return alpha, err, dt
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=3)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--batch", type=int, default=1024)
+    ap.add_argument("--n", type=int, default=2000)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    import torch
+    from global_racetrajectory_optimization_amd import engine, synthetic
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU (the engine has no CPU path)")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group(backend="nccl", rank=rank, world_size=world, device_id=dev)
+
+    B, n = args.batch, args.n
+    ref_h, nv_h, sc_h = synthetic.oval_batch(B, n=n, first=rank * B)
+    d_ref = torch.from_numpy(ref_h).to(dev)
+    d_nv = torch.from_numpy(nv_h).to(dev)
+    d_sc = torch.from_numpy(sc_h).to(dev)
+    d_alpha = torch.zeros((B, n), dtype=torch.float64, device=dev)
+    d_curv = torch.zeros((B,), dtype=torch.float64, device=dev)
+    d_status = torch.zeros((B,), dtype=torch.int32, device=dev)
+    d_info = torch.zeros((B, INFO_DTYPE.itemsize), dtype=torch.uint8, device=dev)
+    d_all = torch.zeros((world * B, n), dtype=torch.float64, device=dev) if world > 1 else None
+
+    eng = engine.Engine(local_rank)
+    solve_ms = []
+
+    def step(record):
+        eng.solve_device(B, n, d_ref.data_ptr(), d_nv.data_ptr(), d_sc.data_ptr(), KAPPA_BOUND, W_VEH,
+                         d_alpha.data_ptr(), d_curv.data_ptr(), d_status.data_ptr(), d_info.data_ptr())
+        eng.sync()
+        if record:
+            solve_ms.append(eng.last_timing_ms())
+        if world > 1:
+            dist.all_gather_into_tensor(d_all, d_alpha)
+
+    def fence():
+        eng.sync()
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+            torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step(False)
+    fence()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step(True)
+    fence()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([dt], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+
+    status = d_status.cpu().numpy()
+    info = d_info.cpu().numpy().view(INFO_DTYPE).reshape(B)
+    n_bad = int(np.count_nonzero(status))
+    alpha0 = d_alpha[0].cpu().numpy()
+    curv0 = float(d_curv[0].item())
+
+    if rank == 0:
+        value = world * B * args.steps / dt
+        k_ms = float(np.mean([m["solve"] for m in solve_ms]))
+        alg = algorithmic_bytes(n, info)
+        achieved = alg / (k_ms * 1e-3) / 1e9
+        out = {
+            "metric": "min-curv QP solves/sec, N=2000 waypoints, batch=1024 per GPU",
+            "value": value, "unit": "solves/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": 1e3 * dt / args.steps, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "f64", "data": "synthetic",
+            "config": {"workload": "BASELINE config 3 generator: perturbed 2:1 oval, perimeter 6000 m, N=%d, batch=%d "
+                                   "track-width perturbations per GPU, one opt_min_curv pass (assembly + QP + "
+                                   "curvature-error check) per track per step; kappa_bound=0.12, w_veh=3.4" % (n, B),
+                       "batch_per_gpu": B, "n_waypoints": n, "collective": "1 all-gather of alpha per step" if world > 1 else "none",
+                       "failed_problems": n_bad,
+                       "mean_ipm_iters": float(info["ipm_iters"].mean()), "mean_as_iters": float(info["as_iters"].mean()),
+                       "mean_active_box_rows": float(info["n_active_box"].mean()),
+                       "kernel_ms": {k: float(np.mean([m[k] for m in solve_ms])) for k in ("assemble", "gram", "solve", "total")},
+                       "workspace_GB": eng.workspace_bytes() / 1e9},
+            "roofline": {"bound": "hbm", "kernel": "mcq_solve_kernel", "achieved": achieved, "peak": HBM_PEAK_GBS,
+                         "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                         "algorithmic_bytes_per_launch": alg, "kernel_ms": k_ms},
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            a_cpu, err_cpu, t_cpu = cpu_baseline(ref_h[0], nv_h[0], sc_h[0])
+            out["cpu_baseline"] = {"value": 1.0 / t_cpu, "unit": "solves/s", "cores": os.cpu_count(), "kind": "port",
+                                   "sample": "1 of the %d N=%d problems: dense-faithful numpy assembly (BLAS on all "
+                                             "cores) + dense Goldfarb-Idnani in C (1 thread), %.1f s" % (B, n, t_cpu),
+                                   "max_abs_alpha_diff_vs_gpu_m": float(np.max(np.abs(a_cpu - alpha0))),
+                                   "curv_err_diff": abs(err_cpu - curv0)}
+        print(json.dumps(out))
+    if world > 1:
+        dist.destroy_process_group()
+    eng.close()
+
+
+if __name__ == "__main__":
+    main()
