@@ -167,11 +167,6 @@ static int launch(mcq_handle* h, McqBatch& B, const mcq_opts& o)
     B.max_as_iter = o.max_as_iter;
     B.refine_steps = o.refine_steps;
     B.check_kappa = o.check_kappa;
-    const size_t smem = mcq_solve_smem_bytes();
-    if (!h->smem_attr_set) {
-        HIP_TRY(hipFuncSetAttribute((const void*)mcq_solve_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
-        h->smem_attr_set = true;
-    }
     HIP_TRY(hipEventRecord(h->ev[0], h->stream));
     hipLaunchKernelGGL(mcq_assemble_kernel, dim3(B.batch), dim3(256), 0, h->stream, B);
     HIP_TRY(hipGetLastError());
@@ -179,7 +174,7 @@ static int launch(mcq_handle* h, McqBatch& B, const mcq_opts& o)
     hipLaunchKernelGGL(mcq_gram_kernel, dim3(B.batch, 8), dim3(256), 0, h->stream, B);
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipEventRecord(h->ev[2], h->stream));
-    hipLaunchKernelGGL(mcq_solve_kernel, dim3(B.batch), dim3(256), smem, h->stream, B);
+    hipLaunchKernelGGL(mcq_solve_kernel, dim3(B.batch), dim3(256), 0, h->stream, B);
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipEventRecord(h->ev[3], h->stream));
     HIP_TRY(hipEventRecord(h->ev[4], h->stream));

@@ -17,8 +17,10 @@
 //                            E -> curvature-row check -> opt_min_curv's curvature-error post-check.
 //
 // Global-memory layout per problem (doubles, leading dimension in brackets):
-//   Eb/Db    [n][MCQ_ELD]  cyclic bands, entry [i][bE+o] = M[i, (i+o) mod n],  -bE <= o <= bR
-//   Et       [n][MCQ_ELD]  transpose band, entry [j][bR+o] = E[(j+o) mod n, j],  -bR <= o <= bE
+//   Eb/Db    [MCQ_ELD][nmax]  cyclic bands, DIAGONAL-MAJOR: entry [(bE+o)*nmax + i] = M[i, (i+o) mod n], -bE <= o <= bR
+//   Et       [MCQ_ELD][nmax]  transpose band: entry [(bR+o)*nmax + j] = E[(j+o) mod n, j],  -bR <= o <= bE
+//                             (diagonal-major => a wave reading one diagonal for 64 consecutive rows reads 512 contiguous
+//                              bytes; band products need no cross-lane reduction)
 //   H, L     [n][MCQ_HLD]  interior rows i < ni: [0..b] band (H: H[i,i+k] upper / L: L[i,i-k] lower, L[.][0] = 1/L_ii),
 //                          [MCQ_HBO + jj] border coupling H[i, ni+jj] / W[i][jj];
 //                          border rows i = ni+j: [MCQ_HBO + jj] = D[j][jj] (H only; L_S stays in LDS)
@@ -63,22 +65,29 @@ __host__ __device__ inline McqDims mcq_dims(int n, int band_e)
     return d;
 }
 
+// Pointers into HBM carry the global address space in their type so that device functions that are not inlined still
+// compile to global_load / global_store (a generic pointer would become FLAT and serialise against LDS traffic).
+typedef __attribute__((address_space(1))) double gdouble;
+typedef __attribute__((address_space(1))) signed char gschar;
+typedef __attribute__((address_space(1))) int gint;
+typedef __attribute__((address_space(1))) mcq_info ginfo;
+
 // Device workspace of ONE problem (pointers into the handle's slabs).
 struct McqWork {
-    const double* ref;   // [n][4]
-    const double* nv;    // [n][2]
-    const double* sc;    // [n] or nullptr
-    double* Eb;
-    double* Et;
-    double* Db;
-    double* H;
-    double* L;           // also scratch for the T^-1 rows during assembly
-    double* vec;         // MCQ_NVEC vectors of length nmax, see enum below
-    signed char* state;  // [n] 0 free, -1 at lower bound, +1 at upper bound, 2 fixed (lo == hi)
-    double* alpha;       // [n] output
-    double* curv_err;    // [1]
-    int* status;         // [1]
-    mcq_info* info;      // [1] or nullptr
+    const gdouble* ref;   // [n][4]
+    const gdouble* nv;    // [n][2]
+    const gdouble* sc;    // [n] or nullptr
+    gdouble* Eb;
+    gdouble* Et;
+    gdouble* Db;
+    gdouble* H;
+    gdouble* L;           // also scratch for the T^-1 rows during assembly
+    gdouble* vec;         // MCQ_NVEC vectors of length nmax, see enum below
+    gschar* state;        // [n] 0 free, -1 at lower bound, +1 at upper bound, 2 fixed (lo == hi)
+    gdouble* alpha;       // [n] output
+    gdouble* curv_err;    // [1]
+    gint* status;         // [1]
+    ginfo* info;          // [1] or nullptr
 };
 
 enum {
@@ -108,4 +117,4 @@ __global__ void mcq_assemble_kernel(McqBatch B);
 __global__ void mcq_gram_kernel(McqBatch B);
 __global__ void mcq_solve_kernel(McqBatch B);
 
-size_t mcq_solve_smem_bytes();
+size_t mcq_solve_lds_bytes();   /* static LDS of the solver kernel (reporting only) */

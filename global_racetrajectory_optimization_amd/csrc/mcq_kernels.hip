@@ -5,13 +5,18 @@
 
 #define MCQ_NT 256
 #define MCQ_NW (MCQ_NT / 64)
-#define NSLOT (MCQ_BH_MAX + 2)
+#define PFB 16                          /* columns fetched per prefetch block of the factorisation */
+#define NSLOT (MCQ_BH_MAX + 2 + PFB)    /* sliding window of columns (b+2 live + one prefetch block) */
+#define LSLOT (MCQ_BH_MAX + 2)          /* row buffer in which finished rows of L are collected */
 #define WLD (MCQ_BH_MAX + 1)
 #define CLD MCQ_P_MAX
 #define SLD (MCQ_P_MAX + 1)
+#define CH 32                           /* rows per chunk of the triangular sweeps */
+#define NBUF 4                          /* chunk ring: 3 resident + 1 being filled */
+#define NRB 8                           /* right-hand-side ring (chunks) */
 
 // ---------------------------------------------------------------------------------------------------------------------
-// shared-memory carve-up of the solver kernel (doubles)
+// shared-memory carve-up of the solver kernel (doubles).  The triangular sweeps overlay the factorisation windows.
 // ---------------------------------------------------------------------------------------------------------------------
 #define SM_RED 0
 #define SM_XD (SM_RED + 64)
@@ -20,9 +25,15 @@
 #define SM_WIN (SM_S + MCQ_P_MAX * SLD)
 #define SM_CW (SM_WIN + NSLOT * WLD)
 #define SM_LRW (SM_CW + NSLOT * CLD)
-#define SM_TOTAL (SM_LRW + NSLOT * WLD)
+#define SM_TOTAL (SM_LRW + LSLOT * WLD)
+#define SM_CHUNK SM_WIN                          /* NBUF x CH x WLD */
+#define SM_RHS (SM_CHUNK + NBUF * CH * WLD)      /* NRB x CH */
 
-size_t mcq_solve_smem_bytes() { return sizeof(double) * SM_TOTAL; }
+size_t mcq_solve_lds_bytes() { return sizeof(double) * SM_TOTAL; }
+
+// The solver kernel's LDS: one statically sized array (address space 3 by type -> ds_read/ds_write in every device
+// function, inlined or not).  155 KiB of the CU's 160 KiB: one workgroup per CU.
+__shared__ double g_sm[SM_TOTAL];
 
 // ---------------------------------------------------------------------------------------------------------------------
 // small helpers
@@ -57,7 +68,7 @@ __device__ __forceinline__ double wave_max(double v)
 }
 
 // op: 0 sum, 1 min, 2 max.  All threads of the block must call; result returned to every thread.
-__device__ double block_reduce(double v, int op, double* red)
+__device__ double block_reduce_(double v, int op, double* red)
 {
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     v = op == 0 ? wave_sum(v) : (op == 1 ? wave_min(v) : wave_max(v));
@@ -76,38 +87,71 @@ __device__ McqWork mcq_work(const McqBatch& B, int pb, int& n, double& kb, doubl
     n = B.n_list ? B.n_list[pb] : B.n;
     kb = B.kappa_bound_list ? B.kappa_bound_list[pb] : B.kappa_bound;
     wv = B.w_veh_list ? B.w_veh_list[pb] : B.w_veh;
-    w.ref = B.ref + (size_t)pb * nm * 4;
-    w.nv = B.nv + (size_t)pb * nm * 2;
-    w.sc = B.sc ? B.sc + (size_t)pb * nm : nullptr;
-    w.Eb = B.Eb + (size_t)pb * nm * MCQ_ELD;
-    w.Et = B.Et + (size_t)pb * nm * MCQ_ELD;
-    w.Db = B.Db + (size_t)pb * nm * MCQ_ELD;
-    w.H = B.H + (size_t)pb * nm * MCQ_HLD;
-    w.L = B.L + (size_t)pb * nm * MCQ_HLD;
-    w.vec = B.vec + (size_t)pb * nm * MCQ_NVEC;
-    w.state = B.state + (size_t)pb * nm;
-    w.alpha = B.alpha + (size_t)pb * nm;
-    w.curv_err = B.curv_err + pb;
-    w.status = B.status + pb;
-    w.info = B.info ? B.info + pb : nullptr;
+    w.ref = (const gdouble*)(B.ref + (size_t)pb * nm * 4);
+    w.nv = (const gdouble*)(B.nv + (size_t)pb * nm * 2);
+    w.sc = B.sc ? (const gdouble*)(B.sc + (size_t)pb * nm) : nullptr;
+    w.Eb = (gdouble*)(B.Eb + (size_t)pb * nm * MCQ_ELD);
+    w.Et = (gdouble*)(B.Et + (size_t)pb * nm * MCQ_ELD);
+    w.Db = (gdouble*)(B.Db + (size_t)pb * nm * MCQ_ELD);
+    w.H = (gdouble*)(B.H + (size_t)pb * nm * MCQ_HLD);
+    w.L = (gdouble*)(B.L + (size_t)pb * nm * MCQ_HLD);
+    w.vec = (gdouble*)(B.vec + (size_t)pb * nm * MCQ_NVEC);
+    w.state = (gschar*)(B.state + (size_t)pb * nm);
+    w.alpha = (gdouble*)(B.alpha + (size_t)pb * nm);
+    w.curv_err = (gdouble*)(B.curv_err + pb);
+    w.status = (gint*)(B.status + pb);
+    w.info = B.info ? (ginfo*)(B.info + pb) : nullptr;
     return w;
 }
 
 #define VEC(w, nmax, id) ((w).vec + (size_t)(id) * (size_t)(nmax))
 
-// dst_i = sum_{o=-bl..br} Mb[i][bl+o] * src[(i+o) mod n] + addc * add_i      (one wave per row, coalesced row read)
-__device__ void band_matvec(const double* Mb, int bl, int br, int n, const double* src, const double* add, double addc,
-                            double* dst)
+// Workgroup barrier that orders LDS traffic only: global loads / stores issued before it stay in flight across it
+// (the "local" address-space fence lowers to s_waitcnt lgkmcnt(0); __syncthreads() would also drain vmcnt).
+__device__ __forceinline__ void lds_barrier()
 {
-    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local");
+    __builtin_amdgcn_s_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup", "local");
+}
+
+// broadcast of a double from a wave-uniform lane (two v_readlane_b32 instead of an LDS-crossbar shuffle)
+__device__ __forceinline__ double bcast_lane(double v, int src_lane)
+{
+    const int lo = __builtin_amdgcn_readlane(__double2loint(v), src_lane);
+    const int hi = __builtin_amdgcn_readlane(__double2hiint(v), src_lane);
+    return __hiloint2double(hi, lo);
+}
+
+// dst_i = sum_{o=-bl..br} Mb[(bl+o) * nm + i] * src[(i+o) mod n] + addc * add_i
+// Diagonal-major (DIA) band: thread per row, every load of a wave is one contiguous 512-byte segment, no reductions.
+#define MV_RU 8
+__device__ __noinline__ void band_matvec(const gdouble* Mb, int bl, int br, int n, int nm, const gdouble* src,
+                                         const gdouble* add, double addc, gdouble* dst)
+{
     const int ew = bl + br + 1;
-    for (int i = wv; i < n; i += MCQ_NW) {
-        const double* row = Mb + (size_t)i * MCQ_ELD;
-        double acc = 0.0;
-        if (lane < ew) acc = row[lane] * src[cyc(i + lane - bl, n)];
-        if (lane == 0 && ew > 64) acc += row[64] * src[cyc(i + 64 - bl, n)];
-        acc = wave_sum(acc);
-        if (lane == 0) dst[i] = acc + (add ? addc * add[i] : 0.0);
+    for (int i = threadIdx.x; i < n; i += MCQ_NT) {
+        double acc = add ? addc * add[i] : 0.0;
+        int j = i - bl;
+        if (j < 0) j += n;
+        if (j < 0) j = cyc(j, n);
+        int oo = 0;
+        for (; oo + MV_RU <= ew; oo += MV_RU) {
+            double m[MV_RU], x[MV_RU];
+#pragma unroll
+            for (int u = 0; u < MV_RU; ++u) {
+                m[u] = Mb[(size_t)(oo + u) * nm + i];
+                x[u] = src[j];
+                j = (j + 1 == n) ? 0 : j + 1;
+            }
+#pragma unroll
+            for (int u = 0; u < MV_RU; ++u) acc += m[u] * x[u];
+        }
+        for (; oo < ew; ++oo) {
+            acc += Mb[(size_t)oo * nm + i] * src[j];
+            j = (j + 1 == n) ? 0 : j + 1;
+        }
+        dst[i] = acc;
     }
 }
 
@@ -123,18 +167,18 @@ __global__ void __launch_bounds__(MCQ_NT) mcq_assemble_kernel(McqBatch B)
     const McqWork w = mcq_work(B, blockIdx.x, n, kb, wveh);
     const int nm = B.nmax;
     const McqDims d = mcq_dims(n < 3 ? 3 : n, B.band_e);
-    double* LO = VEC(w, nm, V_LO);
-    double* HI = VEC(w, nm, V_HI);
-    double* S = VEC(w, nm, V_T0);    // spline scalings
-    double* DE = VEC(w, nm, V_T1);   // periodic pivots, top-down
-    double* EP = VEC(w, nm, V_T2);   // periodic pivots, bottom-up
-    double* XP = VEC(w, nm, V_XP);
-    double* YP = VEC(w, nm, V_YP);
-    double* CP = VEC(w, nm, V_CP);
-    double* KRF = VEC(w, nm, V_KREF);
-    double* XPP = VEC(w, nm, V_XPP);
-    double* YPP = VEC(w, nm, V_YPP);
-    double* G = w.L;                 // T^-1 rows, leading dimension MCQ_GLD (scratch inside the L slab)
+    gdouble* LO = VEC(w, nm, V_LO);
+    gdouble* HI = VEC(w, nm, V_HI);
+    gdouble* S = VEC(w, nm, V_T0);    // spline scalings
+    gdouble* DE = VEC(w, nm, V_T1);   // periodic pivots, top-down
+    gdouble* EP = VEC(w, nm, V_T2);   // periodic pivots, bottom-up
+    gdouble* XP = VEC(w, nm, V_XP);
+    gdouble* YP = VEC(w, nm, V_YP);
+    gdouble* CP = VEC(w, nm, V_CP);
+    gdouble* KRF = VEC(w, nm, V_KREF);
+    gdouble* XPP = VEC(w, nm, V_XPP);
+    gdouble* YPP = VEC(w, nm, V_YPP);
+    gdouble* G = w.L;                 // T^-1 rows, diagonal-major [MCQ_GLD][nm] (scratch inside the L slab)
 
     // ---- phase 0: validate, box bounds  [-(w_l - w_veh/2), w_r - w_veh/2]   -----------------
     double flag_bad = 0.0, flag_inf = 0.0;
@@ -152,8 +196,8 @@ __global__ void __launch_bounds__(MCQ_NT) mcq_assemble_kernel(McqBatch B)
         HI[i] = hi;
         S[i] = s;
     }
-    flag_bad = block_reduce(flag_bad, 2, red);
-    flag_inf = block_reduce(flag_inf, 2, red);
+    flag_bad = block_reduce_(flag_bad, 2, red);
+    flag_inf = block_reduce_(flag_inf, 2, red);
     const int st = flag_bad > 0.0 ? MCQ_BAD_INPUT : (flag_inf > 0.0 ? MCQ_INFEASIBLE : MCQ_OK);
     if (tid == 0) {
         *w.status = st;
@@ -163,7 +207,8 @@ __global__ void __launch_bounds__(MCQ_NT) mcq_assemble_kernel(McqBatch B)
             z.ipm_iters = z.as_iters = z.n_active_box = z.n_active_kappa = 0;
             z.kappa_max = 0.0;
             z.kkt_res = 0.0;
-            *w.info = z;
+            z.ticks[0] = z.ticks[1] = z.ticks[2] = z.ticks[3] = 0;
+            *(mcq_info*)w.info = z;
         }
     }
     if (st != MCQ_OK) {
@@ -202,25 +247,25 @@ __global__ void __launch_bounds__(MCQ_NT) mcq_assemble_kernel(McqBatch B)
     // images of offset k land inside [-W, W] only if k >= n - W: run the recurrences further for short rings
     const int KR = (n - W > 96) ? W : 96;
     for (int i = tid; i < n; i += MCQ_NT) {
-        double* g = G + (size_t)i * MCQ_GLD;
-        for (int k = 0; k < MCQ_GLD; ++k) g[k] = 0.0;
+#define GG(k) G[(size_t)(MCQ_GW + (k)) * nm + i]
+        for (int k = -MCQ_GW; k <= MCQ_GW; ++k) GG(k) = 0.0;
         const double g0 = 1.0 / (DE[i] + EP[i] - TDIAG(i));
-        for (int o = -W; o <= W; ++o) if (cyc(o, n) == 0) g[MCQ_GW + o] += g0;
+        for (int o = -W; o <= W; ++o) if (cyc(o, n) == 0) GG(o) += g0;
         double cur = g0;
         for (int k = 1; k <= KR; ++k) {
             const int j = cyc(i + k - 1, n);
             cur = -(TSUP(j) / EP[cyc(j + 1, n)]) * cur;
-            if (k <= W) g[MCQ_GW + k] += cur;
+            if (k <= W) GG(k) += cur;
             if (k >= n - W)   // fold images: every offset o in [-W, W] with o == k (mod n), o != k
-                for (int o = k - n; o >= -W; o -= n) if (o <= W) g[MCQ_GW + o] += cur;
+                for (int o = k - n; o >= -W; o -= n) if (o <= W) GG(o) += cur;
         }
         cur = g0;
         for (int k = 1; k <= KR; ++k) {
             const int j = cyc(i - k + 1, n);
             cur = -cur / DE[cyc(j - 1, n)];
-            if (k <= W) g[MCQ_GW - k] += cur;
+            if (k <= W) GG(-k) += cur;
             if (k >= n - W)
-                for (int o = -k + n; o <= W; o += n) if (o >= -W) g[MCQ_GW + o] += cur;
+                for (int o = -k + n; o <= W; o += n) if (o >= -W) GG(o) += cur;
         }
         double cx = 0.0, cy = 0.0;
         const int klo = -((W < (n - 1) / 2) ? W : (n - 1) / 2), khi = (W < n / 2) ? W : n / 2;   // each column once
@@ -229,11 +274,12 @@ __global__ void __launch_bounds__(MCQ_NT) mcq_assemble_kernel(McqBatch B)
             const double sm1 = S[mm];
             const double rx = 3.0 * (sm1 * (w.ref[4 * mp] - w.ref[4 * m]) - (w.ref[4 * m] - w.ref[4 * mm]));
             const double ry = 3.0 * (sm1 * (w.ref[4 * mp + 1] - w.ref[4 * m + 1]) - (w.ref[4 * m + 1] - w.ref[4 * mm + 1]));
-            cx += g[MCQ_GW + k] * rx;
-            cy += g[MCQ_GW + k] * ry;
+            cx += GG(k) * rx;
+            cy += GG(k) * ry;
         }
         XPP[i] = 2.0 * cx;   // x''(0) of spline i
         YPP[i] = 2.0 * cy;
+#undef GG
     }
     __syncthreads();
 
@@ -252,21 +298,22 @@ __global__ void __launch_bounds__(MCQ_NT) mcq_assemble_kernel(McqBatch B)
     }
     __syncthreads();
 
-    // ---- phase 3b: D band (x'' = D x) and E_kappa band -----------------------------------------------------------------
+    // ---- phase 3b: D band (x'' = D x) and E_kappa band, diagonal-major -------------------------------------------------
     const int ew = d.ew;
     for (int idx = tid; idx < n * ew; idx += MCQ_NT) {
-        const int i = idx / ew, oo = idx - i * ew, o = oo - d.bE;
+        const int oo = idx / n, i = idx - oo * n, o = oo - d.bE;
         const int j = cyc(i + o, n);
-        const double* g = G + (size_t)i * MCQ_GLD + MCQ_GW + o;
-        const double dv = 6.0 * (g[1] - (1.0 + S[cyc(j - 1, n)]) * g[0] + S[cyc(j - 2, n)] * g[-1]);
-        w.Db[(size_t)i * MCQ_ELD + oo] = dv;
-        w.Eb[(size_t)i * MCQ_ELD + oo] = dv * CP[i] * (XP[i] * w.nv[2 * j + 1] - YP[i] * w.nv[2 * j]);
+        const double g1 = G[(size_t)(MCQ_GW + o + 1) * nm + i], g0 = G[(size_t)(MCQ_GW + o) * nm + i],
+                     gm = G[(size_t)(MCQ_GW + o - 1) * nm + i];
+        const double dv = 6.0 * (g1 - (1.0 + S[cyc(j - 1, n)]) * g0 + S[cyc(j - 2, n)] * gm);
+        w.Db[(size_t)oo * nm + i] = dv;
+        w.Eb[(size_t)oo * nm + i] = dv * CP[i] * (XP[i] * w.nv[2 * j + 1] - YP[i] * w.nv[2 * j]);
     }
     __syncthreads();
-    // ---- phase 3c: transpose band  Et[j][bR+o] = E[(j+o) mod n][j],  -bR <= o <= bE ---------------------------------
+    // ---- phase 3c: transpose band  Et[(bR+o) * nm + j] = E[(j+o) mod n][j],  -bR <= o <= bE --------------------------
     for (int idx = tid; idx < n * ew; idx += MCQ_NT) {
-        const int j = idx / ew, oo = idx - j * ew, o = oo - d.bR;
-        w.Et[(size_t)j * MCQ_ELD + oo] = w.Eb[(size_t)cyc(j + o, n) * MCQ_ELD + (d.bE - o)];
+        const int oo = idx / n, j = idx - oo * n, o = oo - d.bR;
+        w.Et[(size_t)oo * nm + j] = w.Eb[(size_t)(d.bE - o) * nm + cyc(j + o, n)];
     }
 #undef TDIAG
 #undef TSUP
@@ -275,20 +322,50 @@ __global__ void __launch_bounds__(MCQ_NT) mcq_assemble_kernel(McqBatch B)
 // =====================================================================================================================
 // K2: H = E'E (bordered band) and f
 // =====================================================================================================================
-// H[i,j] = sum_r E[r,i] E[r,j] = sum_o Et[i][bR+o] * Et[j][bR+o+dd],  r = i+o,  dd = cyclic (i - j);  -bR <= o <= bE
-__device__ __forceinline__ double h_entry(const double* Et, int bE, int bR, int n, int i, int j)
+// (E' diag(sg) E)[i,j] = sum_o Et[o][i] * sg[i+o] * Et[t][j],  r = i+o,  t = r - j (mod n) inside [-bR, bE];  sg == nullptr -> 1
+__device__ __forceinline__ double gram_entry(const gdouble* Et, const gdouble* sg, const McqDims& d, int nm, int i, int j)
 {
+    const int n = d.n, bE = d.bE, bR = d.bR;
     const int dd = sdiff(i, j, n);
-    const double* ri = Et + (size_t)i * MCQ_ELD + bR;
-    const double* rj = Et + (size_t)j * MCQ_ELD + bR;
     double acc = 0.0;
+    int r = i - bR;
+    if (r < 0) r += n;
+    if (r < 0) r = cyc(r, n);
     for (int o = -bR; o <= bE; ++o) {
-        int t = o + dd;          // r - j, defined modulo n; the band holds every column at most once
+        int t = o + dd;          // the band holds every column at most once: at most one of t, t -+ n is inside it
         if (t > bE) t -= n;
         else if (t < -bR) t += n;
-        if (t >= -bR && t <= bE) acc += ri[o] * rj[t];
+        if (t >= -bR && t <= bE) {
+            const double e = Et[(size_t)(bR + o) * nm + i] * Et[(size_t)(bR + t) * nm + j];
+            acc += sg ? e * sg[r] : e;
+        }
+        r = (r + 1 == n) ? 0 : r + 1;
     }
     return acc;
+}
+
+// Writes  E' diag(sg) E  in bordered-band storage (row-major rows of MCQ_HLD doubles, see mcq_kernels.h) into `out`.
+// Work items are ordered so that consecutive threads take consecutive rows i of the same diagonal / border column:
+// the Et[.][i] loads are contiguous 512-byte segments and the Et[.][j] loads hit a few L1-resident lines.
+__device__ void gram_bordered(const gdouble* Et, const gdouble* sg, const McqDims& d, int nm, gdouble* out, int t0, int nthreads)
+{
+    const int ni = d.ni, n = d.n;
+    const int bw = MCQ_BH_MAX + 1;
+    for (int idx = t0; idx < bw * ni; idx += nthreads) {
+        const int k = idx / ni, i = idx - k * ni;
+        double v = 0.0;
+        if (k <= d.b && i + k < ni) v = gram_entry(Et, sg, d, nm, i, i + k);
+        out[(size_t)i * MCQ_HLD + k] = v;
+    }
+    for (int idx = t0; idx < MCQ_P_MAX * n; idx += nthreads) {
+        const int jj = idx / n, i = idx - jj * n;
+        double v = 0.0;
+        if (jj < d.p) {
+            const int j = ni + jj;
+            if (abs(sdiff(i, j, n)) <= d.bH) v = gram_entry(Et, sg, d, nm, i, j);
+        }
+        out[(size_t)i * MCQ_HLD + MCQ_HBO + jj] = v;
+    }
 }
 
 __global__ void __launch_bounds__(MCQ_NT) mcq_gram_kernel(McqBatch B)
@@ -301,34 +378,19 @@ __global__ void __launch_bounds__(MCQ_NT) mcq_gram_kernel(McqBatch B)
     if (*w.status != MCQ_OK) return;
     const int nm = B.nmax;
     const McqDims d = mcq_dims(n, B.band_e);
-    const double* KR = VEC(w, nm, V_KREF);
-    double* F = VEC(w, nm, V_F);
+    const gdouble* KR = VEC(w, nm, V_KREF);
+    gdouble* F = VEC(w, nm, V_F);
 
-    for (int j = tid; j < n; j += nthreads) {
-        const double* r = w.Et + (size_t)j * MCQ_ELD + d.bR;
+    for (int j = tid; j < n; j += nthreads) {   // f = F_SCALE * E' k_ref
         double acc = 0.0;
-        for (int o = -d.bR; o <= d.bE; ++o) acc += r[o] * KR[cyc(j + o, n)];
+        int r = cyc(j - d.bR, n);
+        for (int oo = 0; oo < d.ew; ++oo) {
+            acc += w.Et[(size_t)oo * nm + j] * KR[r];
+            r = (r + 1 == n) ? 0 : r + 1;
+        }
         F[j] = MCQ_F_SCALE * acc;
     }
-    // interior rows: band part
-    const int bw = MCQ_BH_MAX + 1;
-    for (int idx = tid; idx < d.ni * bw; idx += nthreads) {
-        const int i = idx / bw, k = idx - i * bw;
-        double v = 0.0;
-        if (k <= d.b && i + k < d.ni) v = h_entry(w.Et, d.bE, d.bR, n, i, i + k);
-        w.H[(size_t)i * MCQ_HLD + k] = v;
-    }
-    // all rows: border part  H[i, ni+jj]
-    for (int idx = tid; idx < n * MCQ_P_MAX; idx += nthreads) {
-        const int i = idx / MCQ_P_MAX, jj = idx - i * MCQ_P_MAX;
-        double v = 0.0;
-        if (jj < d.p) {
-            const int j = d.ni + jj;
-            const int dist = abs(sdiff(i, j, n));
-            if (dist <= d.bH) v = h_entry(w.Et, d.bE, d.bR, n, i, j);
-        }
-        w.H[(size_t)i * MCQ_HLD + MCQ_HBO + jj] = v;
-    }
+    gram_bordered(w.Et, nullptr, d, nm, w.H, tid, nthreads);
 }
 
 // =====================================================================================================================
@@ -338,53 +400,68 @@ struct SolveCtx {
     McqDims d;
     McqWork w;
     int nm;
-    double* sm;
+    long long tk[4];   // phase timers (wall_clock64 ticks), meaningful on thread 0
 };
+#define TICK() ((long long)wall_clock64())
 
 // ---- bordered-band Cholesky of  M = H + diag(sig)  with rows/cols of pinned variables replaced by identity ----------
-// Right-looking, one column per step, LDS sliding window of b+2 columns (one __syncthreads per column).
+// Right-looking, one column per step, LDS sliding window.  Columns enter the window PFB at a time: the global loads of
+// block k+1 are issued at the first step of block k, stay in flight across the LDS-only barriers of the 16 column steps
+// and are written to LDS at the block's last step, so the HBM latency is paid once per PFB columns and overlapped.
 // Output: L rows in w.L (row i: [0] = 1/L_ii, [k] = L[i,i-k]; [HBO+jj] = W[i][jj]); L_S (p x p, lower) in LDS SM_S.
 // Returns 0 or MCQ_NOT_PD (uniform across the block).
-__device__ int factor(const SolveCtx& c, const double* sig, const signed char* mk)
+#define PF_ITEMS ((PFB * (WLD + CLD) + MCQ_NT - 1) / MCQ_NT)
+
+// element e of the (WLD + CLD)-wide "extended column" cc:  e < WLD -> band entry k = e, else border entry jj = e - WLD
+__device__ __forceinline__ double ext_col_load(const gdouble* H, const gdouble* sig, const gschar* mk, int ni, int b,
+                                               int p, int cc, int e)
+{
+    if (cc >= ni) return 0.0;
+    const bool pc = mk && mk[cc] != 0;
+    if (e < WLD) {
+        const int k = e, r = cc + k;
+        if (k > b || r >= ni) return 0.0;
+        if (pc || (mk && mk[r] != 0)) return k == 0 ? 1.0 : 0.0;
+        double v = H[(size_t)cc * MCQ_HLD + k];
+        if (k == 0 && sig) v += sig[cc];
+        return v;
+    }
+    const int jj = e - WLD;
+    if (jj >= p || pc || (mk && mk[ni + jj] != 0)) return 0.0;
+    return H[(size_t)cc * MCQ_HLD + MCQ_HBO + jj];
+}
+
+__device__ __forceinline__ void ext_col_store(double* win, double* cwn, int cc, int e, double v)
+{
+    if (e < WLD) win[(cc % NSLOT) * WLD + e] = v;
+    else cwn[(cc % NSLOT) * CLD + (e - WLD)] = v;
+}
+
+__device__ __noinline__ int factor(const SolveCtx& c, const gdouble* sig, const gschar* mk)
 {
     const int tid = threadIdx.x;
     const int b = c.d.b, p = c.d.p, ni = c.d.ni;
-    double* win = c.sm + SM_WIN;
-    double* cwn = c.sm + SM_CW;
-    double* lrw = c.sm + SM_LRW;
-    double* Sm = c.sm + SM_S;
-    const double* H = c.w.H;
-    double* L = c.w.L;
+    double* win = g_sm + SM_WIN;
+    double* cwn = g_sm + SM_CW;
+    double* lrw = g_sm + SM_LRW;
+    double* Sm = g_sm + SM_S;
+    const gdouble* H = c.w.H;
+    gdouble* L = c.w.L;
+    const int EXT = WLD + CLD;
 
     double sacc[16];
 #pragma unroll
     for (int m = 0; m < 16; ++m) sacc[m] = 0.0;
+    double pf[PF_ITEMS];
 
     __syncthreads();
-    for (int q = tid; q < NSLOT * WLD; q += MCQ_NT) lrw[q] = 0.0;
-    // preload columns 0..min(b, ni-1) (and their border rows)
-    const int npre = (b + 1 < ni ? b + 1 : ni);
-    for (int q = tid; q < npre * (WLD + CLD); q += MCQ_NT) {
-        const int cc = q / (WLD + CLD), e = q - cc * (WLD + CLD);
-        const bool pc = mk && mk[cc] != 0;
-        if (e < WLD) {
-            const int k = e, r = cc + k;
-            double v = 0.0;
-            if (k <= b && r < ni) {
-                v = H[(size_t)cc * MCQ_HLD + k];
-                const bool pr = mk && mk[r] != 0;
-                if (pc || pr) v = (k == 0) ? 1.0 : 0.0;
-                else if (k == 0 && sig) v += sig[cc];
-            }
-            win[(cc % NSLOT) * WLD + k] = v;
-        } else {
-            const int jj = e - WLD;
-            double v = 0.0;
-            if (jj < p) {
-                v = H[(size_t)cc * MCQ_HLD + MCQ_HBO + jj];
-                if (pc || (mk && mk[ni + jj] != 0)) v = 0.0;
-            }
-            cwn[(cc % NSLOT) * CLD + jj] = v;
+    for (int q = tid; q < LSLOT * WLD; q += MCQ_NT) lrw[q] = 0.0;
+    // prologue: columns 0 .. b + PFB (everything steps 0..PFB-1 touch)
+    {
+        const int npre = b + 1 + PFB;
+        for (int q = tid; q < npre * EXT; q += MCQ_NT) {
+            const int cc = q / EXT, e = q - cc * EXT;
+            ext_col_store(win, cwn, cc, e, ext_col_load(H, sig, mk, ni, b, p, cc, e));
         }
     }
     __syncthreads();
@@ -394,6 +471,16 @@ __device__ int factor(const SolveCtx& c, const double* sig, const signed char* m
         const int slot = i % NSLOT;
         const double* ci = win + slot * WLD;
         const double* cwi = cwn + slot * CLD;
+        const int ib = i % PFB;
+        const int cblk = i - ib + b + 1 + PFB;     // first column of the block fetched during this block of steps
+        if (ib == 0 && cblk < ni) {
+#pragma unroll
+            for (int u = 0; u < PF_ITEMS; ++u) {
+                const int q = tid + u * MCQ_NT;
+                const int cc = cblk + q / EXT, e = q % EXT;
+                pf[u] = (q < PFB * EXT) ? ext_col_load(H, sig, mk, ni, b, p, cc, e) : 0.0;
+            }
+        }
         const double piv = ci[0];
         if (!(piv > 0.0)) { fail = 1; break; }   // uniform: every thread reads the same LDS word
         const double rinv = 1.0 / piv;
@@ -424,49 +511,34 @@ __device__ int factor(const SolveCtx& c, const double* sig, const signed char* m
 #pragma unroll
             for (int m = 0; m < 16; ++m) sacc[m] -= cwi[(tid >> 6) + MCQ_NW * m] * cj;
         }
-        // (d) emit column i of L into the row buffer, W row to global, flush finished row i-1, load column i+b+1
+        // (d) emit column i of L into the row buffer, W row to global, flush the finished row i-1
         {
-            const int cn = i + b + 1;
-            const int nA = nrem + 1, nB = p, nC = (i > 0) ? b + 1 : 0, nD = (cn < ni) ? (WLD + CLD) : 0;
-            for (int q = tid; q < nA + nB + nC + nD; q += MCQ_NT) {
+            const int nA = nrem + 1, nB = p, nC = (i > 0) ? b + 1 : 0;
+            for (int q = tid; q < nA + nB + nC; q += MCQ_NT) {
                 if (q < nA) {
                     const int k = q;
-                    lrw[((i + k) % NSLOT) * WLD + k] = (k == 0) ? rs : ci[k] * rs;
+                    lrw[((i + k) % LSLOT) * WLD + k] = (k == 0) ? rs : ci[k] * rs;
                 } else if (q < nA + nB) {
                     const int jj = q - nA;
                     L[(size_t)i * MCQ_HLD + MCQ_HBO + jj] = cwi[jj] * rs;
-                } else if (q < nA + nB + nC) {
-                    const int k = q - nA - nB;
-                    L[(size_t)(i - 1) * MCQ_HLD + k] = lrw[((i - 1) % NSLOT) * WLD + k];
                 } else {
-                    const int e = q - nA - nB - nC;
-                    const bool pc = mk && mk[cn] != 0;
-                    if (e < WLD) {
-                        const int k = e, r = cn + k;
-                        double v = 0.0;
-                        if (k <= b && r < ni) {
-                            v = H[(size_t)cn * MCQ_HLD + k];
-                            const bool pr = mk && mk[r] != 0;
-                            if (pc || pr) v = (k == 0) ? 1.0 : 0.0;
-                            else if (k == 0 && sig) v += sig[cn];
-                        }
-                        win[(cn % NSLOT) * WLD + k] = v;
-                    } else {
-                        const int jj = e - WLD;
-                        double v = 0.0;
-                        if (jj < p) {
-                            v = H[(size_t)cn * MCQ_HLD + MCQ_HBO + jj];
-                            if (pc || (mk && mk[ni + jj] != 0)) v = 0.0;
-                        }
-                        cwn[(cn % NSLOT) * CLD + jj] = v;
-                    }
+                    const int k = q - nA - nB;
+                    L[(size_t)(i - 1) * MCQ_HLD + k] = lrw[((i - 1) % LSLOT) * WLD + k];
                 }
             }
         }
-        __syncthreads();
+        // (e) last step of the block: the prefetched block goes into the slots that were freed during this block
+        if (ib == PFB - 1 && cblk < ni) {
+#pragma unroll
+            for (int u = 0; u < PF_ITEMS; ++u) {
+                const int q = tid + u * MCQ_NT;
+                if (q < PFB * EXT) ext_col_store(win, cwn, cblk + q / EXT, q % EXT, pf[u]);
+            }
+        }
+        lds_barrier();
     }
     if (fail) return MCQ_NOT_PD;
-    for (int k = tid; k <= b; k += MCQ_NT) L[(size_t)(ni - 1) * MCQ_HLD + k] = lrw[((ni - 1) % NSLOT) * WLD + k];
+    for (int k = tid; k <= b; k += MCQ_NT) L[(size_t)(ni - 1) * MCQ_HLD + k] = lrw[((ni - 1) % LSLOT) * WLD + k];
 
     // ---- Schur complement of the border: S = D - W'W, dense Cholesky in LDS -------------------------------------------
     {
@@ -502,7 +574,7 @@ __device__ int factor(const SolveCtx& c, const double* sig, const signed char* m
             const int r = j + 1 + e / rem, cc = j + 1 + e % rem;
             if (cc <= r) Sm[r * SLD + cc] -= Sm[r * SLD + j] * Sm[cc * SLD + j] * rinv;
         }
-        __syncthreads();
+        lds_barrier();
         if (j > 0 && tid == 0) Sm[(j - 1) * SLD + (j - 1)] = sqrt(Sm[(j - 1) * SLD + (j - 1)]);
     }
     if (fail) return MCQ_NOT_PD;
@@ -513,49 +585,108 @@ __device__ int factor(const SolveCtx& c, const double* sig, const signed char* m
 }
 
 // ---- solve  M v = rhs  in place (v in global memory) with the factor produced by factor() ---------------------------
-__device__ void solve(const SolveCtx& c, double* v)
+// Interior triangular sweeps: wave 0 walks the rows in "axpy" form (lane l owns the pending row j == l mod 64, the newest
+// unknown is broadcast with v_readlane, one FMA per lane per row: no reductions on the critical path), reading L rows
+// and right-hand-side values from an LDS chunk ring that waves 1..3 keep filled two chunks ahead (register-staged).
+// A loader item is one double of a chunk: items [0, CH*WLD) = band part of the CH rows, [CH*WLD, CH*WLD+CH) = rhs values.
+#define LD_THREADS (MCQ_NT - 64)
+#define LD_ITEMS ((CH * WLD + CH + LD_THREADS - 1) / LD_THREADS)
+
+__device__ __forceinline__ void chunk_fetch(const gdouble* L, const gdouble* v, int ni, int b, int qL, int qR, int lt,
+                                            double* regs)
+{
+#pragma unroll
+    for (int u = 0; u < LD_ITEMS; ++u) {
+        const int e = lt + u * LD_THREADS;
+        double x = 0.0;
+        if (e < CH * WLD) {
+            const int r = qL * CH + e / WLD, k = e % WLD;
+            if (qL >= 0 && r < ni && k <= b) x = L[(size_t)r * MCQ_HLD + k];
+        } else if (e < CH * WLD + CH) {
+            const int r = qR * CH + (e - CH * WLD);
+            if (qR >= 0 && r >= 0 && r < ni) x = v[r];
+        }
+        regs[u] = x;
+    }
+}
+
+__device__ __forceinline__ void chunk_commit(double* chunk, double* rring, int qL, int qR, int lt, const double* regs)
+{
+#pragma unroll
+    for (int u = 0; u < LD_ITEMS; ++u) {
+        const int e = lt + u * LD_THREADS;
+        if (e < CH * WLD) { if (qL >= 0) chunk[(qL % NBUF) * CH * WLD + e] = regs[u]; }
+        else if (e < CH * WLD + CH) { if (qR >= 0) rring[(qR % NRB) * CH + (e - CH * WLD)] = regs[u]; }
+    }
+}
+
+#define LROW(r) (chunk + (((r) / CH) % NBUF) * CH * WLD + ((r) % CH) * WLD)
+#define RHSV(r) (rring[(((r) / CH) % NRB) * CH + ((r) % CH)])
+
+__device__ __noinline__ void solve(const SolveCtx& c, gdouble* v)
 {
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     const int b = c.d.b, p = c.d.p, ni = c.d.ni;
-    const double* L = c.w.L;
-    double* Sm = c.sm + SM_S;
-    double* xd = c.sm + SM_XD;
-    double* part = c.sm + SM_PART;
+    const gdouble* L = c.w.L;
+    double* Sm = g_sm + SM_S;
+    double* xd = g_sm + SM_XD;
+    double* part = g_sm + SM_PART;
+    double* chunk = g_sm + SM_CHUNK;
+    double* rring = g_sm + SM_RHS;
+    const int nch = (ni + CH - 1) / CH;
+    const int lt = tid - 64;      // loader thread id (waves 1..3)
+    double regs[LD_ITEMS];
 
     __syncthreads();
-    // forward substitution, interior rows (wave 0; lane l keeps the newest y_j with j == l mod 64)
-    if (wv == 0) {
-        double ycur = 0.0;
-        for (int i0 = 0; i0 < ni; i0 += 8) {
-            double lv[8], dg[8], rv[8];
-#pragma unroll
-            for (int u = 0; u < 8; ++u) {
-                const int i = i0 + u;
-                const int k = ((i - 1 - lane) & 63) + 1;
-                lv[u] = 0.0; dg[u] = 0.0; rv[u] = 0.0;
-                if (i < ni) {
-                    if (k <= b) lv[u] = L[(size_t)i * MCQ_HLD + k];
-                    dg[u] = L[(size_t)i * MCQ_HLD];
-                    rv[u] = v[i];
+    // ================= forward substitution, interior rows =================
+    // prologue: chunks 0,1,2 (rows + rhs) resident, chunk 3 staged in registers
+    if (wv > 0) {
+        for (int q = 0; q < 3; ++q) {
+            chunk_fetch(L, v, ni, b, q, q, lt, regs);
+            chunk_commit(chunk, rring, q, q, lt, regs);
+        }
+        chunk_fetch(L, v, ni, b, 3, 3, lt, regs);
+    }
+    __syncthreads();
+    {
+        double acc = (wv == 0 && lane < ni) ? RHSV(lane) : 0.0;     // lane l owns row l first
+        for (int cq = 0; cq < nch; ++cq) {
+            if (wv == 0) {
+                const int i1 = (cq + 1) * CH < ni ? (cq + 1) * CH : ni;
+                for (int i = cq * CH; i < i1; ++i) {
+                    const int owner = i & 63;
+                    const double yi = bcast_lane(acc, owner) * LROW(i)[0];
+                    if (lane == owner) {
+                        v[i] = yi;
+                        acc = (i + 64 < ni) ? RHSV(i + 64) : 0.0;
+                    }
+                    const int k = ((lane - i - 1) & 63) + 1;
+                    const int j = i + k;
+                    const double lv = (j < ni && k <= b) ? LROW(j)[k] : 0.0;
+                    acc -= lv * yi;
                 }
+            } else {
+                chunk_commit(chunk, rring, cq + 3, cq + 3, lt, regs);
+                chunk_fetch(L, v, ni, b, cq + 4, cq + 4, lt, regs);
             }
-#pragma unroll
-            for (int u = 0; u < 8; ++u) {
-                const int i = i0 + u;
-                if (i < ni) {
-                    const double s = wave_sum(lv[u] * ycur);
-                    const double yi = (rv[u] - s) * dg[u];
-                    if (lane == (i & 63)) { ycur = yi; v[i] = yi; }
-                }
-            }
+            lds_barrier();
         }
     }
     __syncthreads();
-    // border right-hand side  t = v_D - W' y_B
+    // ================= border:  t = v_D - W' y_B,  dense solves with L_S =================
     {
         double acc = 0.0;
-        if (lane < p)
-            for (int i = wv; i < ni; i += MCQ_NW) acc += L[(size_t)i * MCQ_HLD + MCQ_HBO + lane] * v[i];
+        if (lane < p) {
+            int i = wv;
+            for (; i + 3 * MCQ_NW < ni; i += 4 * MCQ_NW) {
+                const double w0 = L[(size_t)i * MCQ_HLD + MCQ_HBO + lane], y0 = v[i];
+                const double w1 = L[(size_t)(i + MCQ_NW) * MCQ_HLD + MCQ_HBO + lane], y1 = v[i + MCQ_NW];
+                const double w2 = L[(size_t)(i + 2 * MCQ_NW) * MCQ_HLD + MCQ_HBO + lane], y2 = v[i + 2 * MCQ_NW];
+                const double w3 = L[(size_t)(i + 3 * MCQ_NW) * MCQ_HLD + MCQ_HBO + lane], y3 = v[i + 3 * MCQ_NW];
+                acc += w0 * y0 + w1 * y1 + w2 * y2 + w3 * y3;
+            }
+            for (; i < ni; i += MCQ_NW) acc += L[(size_t)i * MCQ_HLD + MCQ_HBO + lane] * v[i];
+        }
         part[wv * 64 + lane] = acc;
     }
     __syncthreads();
@@ -565,79 +696,95 @@ __device__ void solve(const SolveCtx& c, double* v)
             t = v[ni + lane];
             for (int q = 0; q < MCQ_NW; ++q) t -= part[q * 64 + lane];
         }
-        // dense forward  L_S y = t
-        for (int j = 0; j < p; ++j) {
+        for (int j = 0; j < p; ++j) {      // dense forward  L_S y = t
             const double s = wave_sum(lane < j ? Sm[j * SLD + lane] * t : 0.0);
-            const double tj = (__shfl(t, j) - s) / Sm[j * SLD + j];
+            const double tj = (bcast_lane(t, j) - s) / Sm[j * SLD + j];
             if (lane == j) t = tj;
         }
-        // dense backward  L_S' x = y
-        for (int j = p - 1; j >= 0; --j) {
+        for (int j = p - 1; j >= 0; --j) { // dense backward  L_S' x = y
             const double s = wave_sum((lane > j && lane < p) ? Sm[lane * SLD + j] * t : 0.0);
-            const double xj = (__shfl(t, j) - s) / Sm[j * SLD + j];
+            const double xj = (bcast_lane(t, j) - s) / Sm[j * SLD + j];
             if (lane == j) t = xj;
         }
         if (lane < p) v[ni + lane] = t;
         xd[lane] = lane < p ? t : 0.0;
     }
     __syncthreads();
-    // y_B -= W x_D   (one wave per row)
-    for (int i = wv; i < ni; i += MCQ_NW) {
-        const double s = wave_sum(lane < p ? L[(size_t)i * MCQ_HLD + MCQ_HBO + lane] * xd[lane] : 0.0);
-        if (lane == 0) v[i] -= s;
+    // y_B -= W x_D   (one wave per row, MV_RU rows in flight)
+    for (int i0 = wv * MV_RU; i0 < ni; i0 += MCQ_NW * MV_RU) {
+        double a8[MV_RU];
+#pragma unroll
+        for (int u = 0; u < MV_RU; ++u) {
+            const int i = i0 + u;
+            a8[u] = (i < ni && lane < p) ? L[(size_t)i * MCQ_HLD + MCQ_HBO + lane] * xd[lane] : 0.0;
+        }
+#pragma unroll
+        for (int m = 32; m >= 1; m >>= 1) {
+#pragma unroll
+            for (int u = 0; u < MV_RU; ++u) a8[u] += __shfl_xor(a8[u], m);
+        }
+#pragma unroll
+        for (int u = 0; u < MV_RU; ++u) {
+            const int i = i0 + u;
+            if (i < ni && lane == 0) v[i] -= a8[u];
+        }
     }
     __syncthreads();
-    // backward substitution, interior rows (wave 0, axpy form; lane l owns the pending row j == l mod 64)
-    if (wv == 0 && ni > 0) {
-        int jown = ni - 1 - ((ni - 1 - lane) & 63);          // largest j <= ni-1 with j == lane (mod 64); may be < 0
-        double acc = jown >= 0 ? v[jown] : 0.0;
-        double vnext = jown - 64 >= 0 ? v[jown - 64] : 0.0;
-        for (int i0 = ni - 1; i0 >= 0; i0 -= 8) {
-            double lv[8], dg[8];
-#pragma unroll
-            for (int u = 0; u < 8; ++u) {
-                const int i = i0 - u;
-                const int k = ((i - 1 - lane) & 63) + 1;
-                lv[u] = 0.0; dg[u] = 0.0;
-                if (i >= 0) {
-                    if (k <= b && i - k >= 0) lv[u] = L[(size_t)i * MCQ_HLD + k];
-                    dg[u] = L[(size_t)i * MCQ_HLD];
-                }
-            }
-#pragma unroll
-            for (int u = 0; u < 8; ++u) {
-                const int i = i0 - u;
-                if (i >= 0) {
+    // ================= backward substitution, interior rows (descending) =================
+    // row i needs only its own L row; the owner of row i takes row i-64 next -> rhs chunks lead the row chunks by two
+    if (nch > 0) {
+        const int cl = nch - 1;
+        if (wv > 0) {
+            chunk_fetch(L, v, ni, b, cl, cl, lt, regs);
+            chunk_commit(chunk, rring, cl, cl, lt, regs);
+            chunk_fetch(L, v, ni, b, -1, cl - 1, lt, regs);
+            chunk_commit(chunk, rring, -1, cl - 1, lt, regs);
+            chunk_fetch(L, v, ni, b, -1, cl - 2, lt, regs);
+            chunk_commit(chunk, rring, -1, cl - 2, lt, regs);
+            chunk_fetch(L, v, ni, b, cl - 1, cl - 3, lt, regs);
+        }
+        __syncthreads();
+        // lane l first owns the largest row j <= ni-1 with j == l (mod 64)
+        const int j0 = ni - 1 - ((ni - 1 - lane) & 63);
+        double acc = (wv == 0 && j0 >= 0) ? RHSV(j0) : 0.0;
+        for (int cq = cl; cq >= 0; --cq) {
+            if (wv == 0) {
+                const int i1 = (cq + 1) * CH < ni ? (cq + 1) * CH : ni;
+                for (int i = i1 - 1; i >= cq * CH; --i) {
                     const int owner = i & 63;
-                    const double xi = __shfl(acc, owner) * dg[u];
+                    const double* lr = LROW(i);
+                    const double xi = bcast_lane(acc, owner) * lr[0];
                     if (lane == owner) {
                         v[i] = xi;
-                        acc = vnext;
-                        jown -= 64;
-                        vnext = jown - 64 >= 0 ? v[jown - 64] : 0.0;
+                        acc = (i - 64 >= 0) ? RHSV(i - 64) : 0.0;
                     }
-                    acc -= lv[u] * xi;
+                    const int k = ((i - 1 - lane) & 63) + 1;
+                    const double lv = (k <= b && i - k >= 0) ? lr[k] : 0.0;
+                    acc -= lv * xi;
                 }
+            } else {
+                chunk_commit(chunk, rring, cq - 1, cq - 3, lt, regs);
+                chunk_fetch(L, v, ni, b, cq - 2, cq - 4, lt, regs);
             }
+            lds_barrier();
         }
     }
     __syncthreads();
 }
 
 // gradient  g = E'(E x + F k_ref)   (tmp: scratch vector)
-__device__ void gradient(const SolveCtx& c, const double* x, double* tmp, double* g)
+__device__ __noinline__ void gradient(const SolveCtx& c, const gdouble* x, gdouble* tmp, gdouble* g)
 {
     const int n = c.d.n;
     __syncthreads();
-    band_matvec(c.w.Eb, c.d.bE, c.d.bR, n, x, VEC(c.w, c.nm, V_KREF), MCQ_F_SCALE, tmp);
+    band_matvec(c.w.Eb, c.d.bE, c.d.bR, n, c.nm, x, VEC(c.w, c.nm, V_KREF), MCQ_F_SCALE, tmp);
     __syncthreads();
-    band_matvec(c.w.Et, c.d.bR, c.d.bE, n, tmp, nullptr, 0.0, g);
+    band_matvec(c.w.Et, c.d.bR, c.d.bE, n, c.nm, tmp, nullptr, 0.0, g);
     __syncthreads();
 }
 
 __global__ void __launch_bounds__(MCQ_NT) mcq_solve_kernel(McqBatch B)
 {
-    HIP_DYNAMIC_SHARED(double, smem)   // the only LDS of this kernel: base is 16-byte aligned (guide, Guideline 17)
     const int tid = threadIdx.x;
     int n;
     double kbound, wveh;
@@ -646,25 +793,26 @@ __global__ void __launch_bounds__(MCQ_NT) mcq_solve_kernel(McqBatch B)
     if (*c.w.status != MCQ_OK) return;
     c.nm = B.nmax;
     c.d = mcq_dims(n, B.band_e);
-    c.sm = smem;
-    double* red = smem + SM_RED;
+    c.tk[0] = c.tk[1] = c.tk[2] = c.tk[3] = 0;
+    const long long t_kernel0 = TICK();
+    double* red = g_sm + SM_RED;
     const int nm = B.nmax;
 
-    const double* LO = VEC(c.w, nm, V_LO);
-    const double* HI = VEC(c.w, nm, V_HI);
-    const double* F = VEC(c.w, nm, V_F);
-    double* X = VEC(c.w, nm, V_X);
-    double* G = VEC(c.w, nm, V_G);
-    double* ZL = VEC(c.w, nm, V_ZL);
-    double* ZU = VEC(c.w, nm, V_ZU);
-    double* SIG = VEC(c.w, nm, V_SIG);
-    double* RHS = VEC(c.w, nm, V_RHS);
-    double* DXA = VEC(c.w, nm, V_DXA);
-    double* T0 = VEC(c.w, nm, V_T0);
-    double* T1 = VEC(c.w, nm, V_T1);
-    double* T2 = VEC(c.w, nm, V_T2);
-    double* T3 = VEC(c.w, nm, V_T3);
-    signed char* ST = c.w.state;
+    const gdouble* LO = VEC(c.w, nm, V_LO);
+    const gdouble* HI = VEC(c.w, nm, V_HI);
+    const gdouble* F = VEC(c.w, nm, V_F);
+    gdouble* X = VEC(c.w, nm, V_X);
+    gdouble* G = VEC(c.w, nm, V_G);
+    gdouble* ZL = VEC(c.w, nm, V_ZL);
+    gdouble* ZU = VEC(c.w, nm, V_ZU);
+    gdouble* SIG = VEC(c.w, nm, V_SIG);
+    gdouble* RHS = VEC(c.w, nm, V_RHS);
+    gdouble* DXA = VEC(c.w, nm, V_DXA);
+    gdouble* T0 = VEC(c.w, nm, V_T0);
+    gdouble* T1 = VEC(c.w, nm, V_T1);
+    gdouble* T2 = VEC(c.w, nm, V_T2);
+    gdouble* T3 = VEC(c.w, nm, V_T3);
+    gschar* ST = c.w.state;
 
     const double FIX_TOL = 1e-12;
     int status = MCQ_OK;
@@ -682,15 +830,15 @@ __global__ void __launch_bounds__(MCQ_NT) mcq_solve_kernel(McqBatch B)
         if (!fixed) { wsum += wdt; nfree_d += 1.0; }
         fmaxl = fmax(fmaxl, fabs(F[i]));
     }
-    wsum = block_reduce(wsum, 0, red);
-    nfree_d = block_reduce(nfree_d, 0, red);
-    const double fscale = block_reduce(fmaxl, 2, red);
+    wsum = block_reduce_(wsum, 0, red);
+    nfree_d = block_reduce_(nfree_d, 0, red);
+    const double fscale = block_reduce_(fmaxl, 2, red);
     const double wmean = nfree_d > 0.0 ? wsum / nfree_d : 1.0;
 
-    gradient(c, X, T0, G);
+    { long long t2_ = TICK(); gradient(c, X, T0, G); c.tk[2] += TICK() - t2_; }
     double gm = 0.0;
     for (int i = tid; i < n; i += MCQ_NT) if (ST[i] == 0) gm = fmax(gm, fabs(G[i]));
-    double zscale = block_reduce(gm, 2, red);
+    double zscale = block_reduce_(gm, 2, red);
     if (!(zscale > 0.0)) zscale = fscale > 0.0 ? fscale : 1.0;
     for (int i = tid; i < n; i += MCQ_NT) { ZL[i] = ST[i] == 0 ? zscale : 0.0; ZU[i] = ZL[i]; }
     __syncthreads();
@@ -707,17 +855,17 @@ __global__ void __launch_bounds__(MCQ_NT) mcq_solve_kernel(McqBatch B)
                 rdm = fmax(rdm, fabs(G[i] - ZL[i] + ZU[i]));
                 SIG[i] = ZL[i] / sl + ZU[i] / su;
             }
-            mu = block_reduce(mu, 0, red) / (2.0 * nfree_d);
-            rdm = block_reduce(rdm, 2, red);
+            mu = block_reduce_(mu, 0, red) / (2.0 * nfree_d);
+            rdm = block_reduce_(rdm, 2, red);
             if (mu < IPM_TOL * zscale * wmean && rdm < IPM_TOL * zscale) break;
             ipm_iters = it;
 
-            const int fs = factor(c, SIG, ST);
+            long long t0_ = TICK(); const int fs = factor(c, SIG, ST); c.tk[0] += TICK() - t0_;
             if (fs != 0) { status = fs; break; }
 
             // predictor
             for (int i = tid; i < n; i += MCQ_NT) RHS[i] = ST[i] == 0 ? -G[i] : 0.0;
-            solve(c, RHS);
+            { long long t1_ = TICK(); solve(c, RHS); c.tk[1] += TICK() - t1_; }
             double ap = 1.0, ad = 1.0;
             for (int i = tid; i < n; i += MCQ_NT) {
                 if (ST[i] != 0) { DXA[i] = 0.0; continue; }
@@ -730,8 +878,8 @@ __global__ void __launch_bounds__(MCQ_NT) mcq_solve_kernel(McqBatch B)
                 if (dzl < 0.0) ad = fmin(ad, -ZL[i] / dzl);
                 if (dzu < 0.0) ad = fmin(ad, -ZU[i] / dzu);
             }
-            ap = block_reduce(ap, 1, red);
-            ad = block_reduce(ad, 1, red);
+            ap = block_reduce_(ap, 1, red);
+            ad = block_reduce_(ad, 1, red);
             double mua = 0.0;
             for (int i = tid; i < n; i += MCQ_NT) {
                 if (ST[i] != 0) continue;
@@ -740,7 +888,7 @@ __global__ void __launch_bounds__(MCQ_NT) mcq_solve_kernel(McqBatch B)
                 const double dzl = -ZL[i] - ZL[i] * dx / sl, dzu = -ZU[i] + ZU[i] * dx / su;
                 mua += (sl + ap * dx) * (ZL[i] + ad * dzl) + (su - ap * dx) * (ZU[i] + ad * dzu);
             }
-            mua = block_reduce(mua, 0, red) / (2.0 * nfree_d);
+            mua = block_reduce_(mua, 0, red) / (2.0 * nfree_d);
             const double ratio = mua / mu;
             const double sigma = ratio * ratio * ratio;
             const double smu = sigma * mu;
@@ -753,7 +901,7 @@ __global__ void __launch_bounds__(MCQ_NT) mcq_solve_kernel(McqBatch B)
                 const double dzl = -ZL[i] - ZL[i] * dx / sl, dzu = -ZU[i] + ZU[i] * dx / su;
                 RHS[i] = -G[i] + (smu - dx * dzl) / sl - (smu + dx * dzu) / su;
             }
-            solve(c, RHS);
+            { long long t1_ = TICK(); solve(c, RHS); c.tk[1] += TICK() - t1_; }
             double amax = 1.0 / 0.995;
             for (int i = tid; i < n; i += MCQ_NT) {
                 if (ST[i] != 0) continue;
@@ -769,7 +917,7 @@ __global__ void __launch_bounds__(MCQ_NT) mcq_solve_kernel(McqBatch B)
                 if (dzl < 0.0) amax = fmin(amax, -ZL[i] / dzl);
                 if (dzu < 0.0) amax = fmin(amax, -ZU[i] / dzu);
             }
-            amax = block_reduce(amax, 1, red);
+            amax = block_reduce_(amax, 1, red);
             const double a = fmin(1.0, 0.995 * amax);
             for (int i = tid; i < n; i += MCQ_NT) {
                 if (ST[i] != 0) continue;
@@ -777,7 +925,7 @@ __global__ void __launch_bounds__(MCQ_NT) mcq_solve_kernel(McqBatch B)
                 ZL[i] += a * T1[i];
                 ZU[i] += a * T2[i];
             }
-            gradient(c, X, T0, G);
+            { long long t2_ = TICK(); gradient(c, X, T0, G); c.tk[2] += TICK() - t2_; }
         }
     }
 
@@ -806,13 +954,13 @@ __global__ void __launch_bounds__(MCQ_NT) mcq_solve_kernel(McqBatch B)
                 const signed char s = ST[i];
                 T1[i] = s == 0 ? 0.0 : (s < 0 ? LO[i] : (s == 1 ? HI[i] : 0.5 * (LO[i] + HI[i])));
             }
-            gradient(c, T1, T0, T2);       // T2 = H x_A + f
+            { long long t2_ = TICK(); gradient(c, T1, T0, T2); c.tk[2] += TICK() - t2_; }       // T2 = H x_A + f
             for (int i = tid; i < n; i += MCQ_NT) RHS[i] = ST[i] == 0 ? -T2[i] : T1[i];
-            const int fs = factor(c, nullptr, ST);
+            long long t0_ = TICK(); const int fs = factor(c, nullptr, ST); c.tk[0] += TICK() - t0_;
             if (fs != 0) { status = fs; break; }
-            solve(c, RHS);
+            { long long t1_ = TICK(); solve(c, RHS); c.tk[1] += TICK() - t1_; }
             for (int i = tid; i < n; i += MCQ_NT) X[i] = ST[i] == 0 ? RHS[i] : T1[i];
-            gradient(c, X, T0, G);
+            { long long t2_ = TICK(); gradient(c, X, T0, G); c.tk[2] += TICK() - t2_; }
             // infeasibilities
             double nv = 0.0, imax = -1.0, kk = 0.0;
             for (int i = tid; i < n; i += MCQ_NT) {
@@ -824,9 +972,9 @@ __global__ void __launch_bounds__(MCQ_NT) mcq_solve_kernel(McqBatch B)
                 T3[i] = (double)v;
                 if (v != 0) { nv += 1.0; imax = fmax(imax, (double)i); }
             }
-            nv = block_reduce(nv, 0, red);
-            imax = block_reduce(imax, 2, red);
-            kkt = block_reduce(kk, 2, red);
+            nv = block_reduce_(nv, 0, red);
+            imax = block_reduce_(imax, 2, red);
+            kkt = block_reduce_(kk, 2, red);
             const int nvi = (int)nv;
             if (nvi == 0) { converged = true; break; }
             bool full;
@@ -847,13 +995,13 @@ __global__ void __launch_bounds__(MCQ_NT) mcq_solve_kernel(McqBatch B)
         if (status == MCQ_OK) {
             for (int r = 0; r < B.refine_steps; ++r) {
                 for (int i = tid; i < n; i += MCQ_NT) RHS[i] = ST[i] == 0 ? -G[i] : 0.0;
-                solve(c, RHS);
+                { long long t1_ = TICK(); solve(c, RHS); c.tk[1] += TICK() - t1_; }
                 for (int i = tid; i < n; i += MCQ_NT) if (ST[i] == 0) X[i] += RHS[i];
-                gradient(c, X, T0, G);
+                { long long t2_ = TICK(); gradient(c, X, T0, G); c.tk[2] += TICK() - t2_; }
             }
             double kk = 0.0;
             for (int i = tid; i < n; i += MCQ_NT) if (ST[i] == 0) kk = fmax(kk, fabs(G[i]));
-            kkt = block_reduce(kk, 2, red);
+            kkt = block_reduce_(kk, 2, red);
         }
     }
 
@@ -868,25 +1016,25 @@ __global__ void __launch_bounds__(MCQ_NT) mcq_solve_kernel(McqBatch B)
         c.w.alpha[i] = a;
         if (ST[i] == -1 || ST[i] == 1) nact += 1.0;
     }
-    nact = block_reduce(nact, 0, red);
+    nact = block_reduce_(nact, 0, red);
     // kappa(alpha) = k_ref + E alpha
-    band_matvec(c.w.Eb, c.d.bE, c.d.bR, n, X, VEC(c.w, nm, V_KREF), 1.0, T0);
+    band_matvec(c.w.Eb, c.d.bE, c.d.bR, n, nm, X, VEC(c.w, nm, V_KREF), 1.0, T0);
     __syncthreads();
     double km = 0.0;
     for (int i = tid; i < n; i += MCQ_NT) km = fmax(km, fabs(T0[i]));
-    km = block_reduce(km, 2, red);
+    km = block_reduce_(km, 2, red);
     if (status == MCQ_OK && B.check_kappa && km > kbound * (1.0 + 1e-9)) status = MCQ_KAPPA_ACTIVE;
 
     // curvature error: derivatives re-linearised at the solution
     {
-        const double* XP = VEC(c.w, nm, V_XP);
-        const double* YP = VEC(c.w, nm, V_YP);
-        const double* XPP = VEC(c.w, nm, V_XPP);
-        const double* YPP = VEC(c.w, nm, V_YPP);
+        const gdouble* XP = VEC(c.w, nm, V_XP);
+        const gdouble* YP = VEC(c.w, nm, V_YP);
+        const gdouble* XPP = VEC(c.w, nm, V_XPP);
+        const gdouble* YPP = VEC(c.w, nm, V_YPP);
         for (int i = tid; i < n; i += MCQ_NT) { T1[i] = c.w.nv[2 * i] * X[i]; T2[i] = c.w.nv[2 * i + 1] * X[i]; }
         __syncthreads();
-        band_matvec(c.w.Db, c.d.bE, c.d.bR, n, T1, nullptr, 0.0, T0);   // D (n_x alpha)
-        band_matvec(c.w.Db, c.d.bE, c.d.bR, n, T2, nullptr, 0.0, T3);   // D (n_y alpha)
+        band_matvec(c.w.Db, c.d.bE, c.d.bR, n, nm, T1, nullptr, 0.0, T0);   // D (n_x alpha)
+        band_matvec(c.w.Db, c.d.bE, c.d.bR, n, nm, T2, nullptr, 0.0, T3);   // D (n_y alpha)
         __syncthreads();
         double em = 0.0;
         for (int i = tid; i < n; i += MCQ_NT) {
@@ -901,7 +1049,7 @@ __global__ void __launch_bounds__(MCQ_NT) mcq_solve_kernel(McqBatch B)
             const double k1 = (xpt * ypp - ypt * xpp) / pow(xpt * xpt + ypt * ypt, 1.5);
             em = fmax(em, fabs(k1 - k0));
         }
-        em = block_reduce(em, 2, red);
+        em = block_reduce_(em, 2, red);
         if (tid == 0) {
             *c.w.curv_err = em;
             *c.w.status = status;
@@ -913,7 +1061,9 @@ __global__ void __launch_bounds__(MCQ_NT) mcq_solve_kernel(McqBatch B)
                 o.n_active_kappa = 0;
                 o.kappa_max = km;
                 o.kkt_res = fscale > 0.0 ? kkt / fscale : kkt;
-                *c.w.info = o;
+                c.tk[3] = TICK() - t_kernel0;
+                for (int q = 0; q < 4; ++q) o.ticks[q] = c.tk[q];
+                *(mcq_info*)c.w.info = o;
             }
         }
     }

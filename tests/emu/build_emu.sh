@@ -4,4 +4,4 @@
 set -e
 cd "$(dirname "$0")"
 SRC=../../global_racetrajectory_optimization_amd/csrc
-g++ -O2 -std=c++17 -fPIC -shared -x c++ -I include -o libmcq_emu.so $SRC/mcq_kernels.hip $SRC/mcq_api.hip -Wno-unused-result
+g++ -O2 -std=c++17 -fPIC -shared -x c++ -I include -o libmcq_emu.so $SRC/mcq_kernels.hip $SRC/mcq_api.hip -Wno-unused-result -Wno-attributes

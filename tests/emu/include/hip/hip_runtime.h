@@ -13,6 +13,8 @@
 // instance (workgroups run one after another); dynamic LDS via HIP_DYNAMIC_SHARED.
 #pragma once
 #include <ucontext.h>
+#include <chrono>
+inline double hipemu_now() { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
 
 #include <chrono>
 #include <cmath>
@@ -182,6 +184,21 @@ inline double __shfl_xor(double v, int m)
     return __shfl(v, (s.cur ^ m) & 63);
 }
 inline int __shfl(int v, int src) { return (int)__shfl((double)v, src); }
+
+inline long long wall_clock64() { return (long long)(hipemu_now() * 1e5); }
+
+// AMDGCN builtins used by the kernels
+inline int hipemu_readlane(int v, int src) { return (int)__shfl((double)v, src); }
+#define __builtin_amdgcn_readlane(v, l) hipemu_readlane((v), (l))
+#define __builtin_amdgcn_s_barrier() hipemu::block_barrier()
+#define __builtin_amdgcn_fence(...) ((void)0)
+inline int __double2loint(double d) { long long b; memcpy(&b, &d, 8); return (int)(b & 0xffffffffLL); }
+inline int __double2hiint(double d) { long long b; memcpy(&b, &d, 8); return (int)((b >> 32) & 0xffffffffLL); }
+inline double __hiloint2double(int hi, int lo)
+{
+    long long b = ((long long)(unsigned)hi << 32) | (unsigned)lo;
+    double d; memcpy(&d, &b, 8); return d;
+}
 inline int __shfl_xor(int v, int m) { return (int)__shfl_xor((double)v, m); }
 
 // ---- host runtime subset -------------------------------------------------------------------------------------------
@@ -205,7 +222,7 @@ inline hipError_t hipFree(void* p) { free(p); return hipSuccess; }
 inline hipError_t hipMemcpyAsync(void* d, const void* s, size_t n, hipMemcpyKind, hipStream_t) { memcpy(d, s, n); return hipSuccess; }
 inline hipError_t hipMemcpy(void* d, const void* s, size_t n, hipMemcpyKind) { memcpy(d, s, n); return hipSuccess; }
 inline hipError_t hipFuncSetAttribute(const void*, hipFuncAttribute, int) { return hipSuccess; }
-inline double hipemu_now() { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
+inline double hipemu_now_() { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
 inline hipError_t hipEventCreate(hipEvent_t* e) { *e = new hipemu_event{0.0}; return hipSuccess; }
 inline hipError_t hipEventDestroy(hipEvent_t e) { delete e; return hipSuccess; }
 inline hipError_t hipEventRecord(hipEvent_t e, hipStream_t) { e->t = hipemu_now(); return hipSuccess; }
