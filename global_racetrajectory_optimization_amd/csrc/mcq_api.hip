@@ -35,7 +35,7 @@ struct mcq_handle {
     // workspace slabs
     size_t cap_elems = 0;   // batch * nmax the slabs are sized for
     size_t cap_batch = 0;
-    double *Eb = nullptr, *Et = nullptr, *Db = nullptr, *H = nullptr, *L = nullptr, *vec = nullptr;
+    double *Eb = nullptr, *Et = nullptr, *Db = nullptr, *H = nullptr, *L = nullptr, *vec = nullptr, *Z = nullptr;
     signed char* state = nullptr;
     // staging for the host-buffer entry point
     double *d_ref = nullptr, *d_nv = nullptr, *d_sc = nullptr, *d_alpha = nullptr, *d_curv = nullptr, *d_kb = nullptr,
@@ -91,8 +91,8 @@ extern "C" int mcq_create(int device_id, mcq_handle** out)
 
 static void free_ws(mcq_handle* h)
 {
-    (void)hipFree(h->Eb); (void)hipFree(h->Et); (void)hipFree(h->Db); (void)hipFree(h->H); (void)hipFree(h->L); (void)hipFree(h->vec); (void)hipFree(h->state);
-    h->Eb = h->Et = h->Db = h->H = h->L = h->vec = nullptr;
+    (void)hipFree(h->Eb); (void)hipFree(h->Et); (void)hipFree(h->Db); (void)hipFree(h->H); (void)hipFree(h->L); (void)hipFree(h->vec); (void)hipFree(h->Z); (void)hipFree(h->state);
+    h->Eb = h->Et = h->Db = h->H = h->L = h->vec = h->Z = nullptr;
     h->state = nullptr;
     h->cap_elems = h->cap_batch = 0;
 }
@@ -131,10 +131,11 @@ static int ensure_ws(mcq_handle* h, size_t batch, size_t nmax)
     HIP_TRY(hipMalloc((void**)&h->H, elems * MCQ_HLD * sizeof(double)));
     HIP_TRY(hipMalloc((void**)&h->L, elems * MCQ_HLD * sizeof(double)));
     HIP_TRY(hipMalloc((void**)&h->vec, elems * MCQ_NVEC * sizeof(double)));
+    HIP_TRY(hipMalloc((void**)&h->Z, elems * MCQ_KMAX * sizeof(double)));
     HIP_TRY(hipMalloc((void**)&h->state, elems));
     h->cap_elems = elems;
     h->cap_batch = batch;
-    h->ws_bytes = (long long)(elems * ((3 * MCQ_ELD + 2 * MCQ_HLD + MCQ_NVEC) * sizeof(double) + 1));
+    h->ws_bytes = (long long)(elems * ((3 * MCQ_ELD + 2 * MCQ_HLD + MCQ_NVEC + MCQ_KMAX) * sizeof(double) + 1));
     return 0;
 }
 
@@ -161,7 +162,7 @@ static int ensure_stage(mcq_handle* h, size_t batch, size_t nmax)
 
 static int launch(mcq_handle* h, McqBatch& B, const mcq_opts& o)
 {
-    B.Eb = h->Eb; B.Et = h->Et; B.Db = h->Db; B.H = h->H; B.L = h->L; B.vec = h->vec; B.state = h->state;
+    B.Eb = h->Eb; B.Et = h->Et; B.Db = h->Db; B.H = h->H; B.L = h->L; B.vec = h->vec; B.Z = h->Z; B.state = h->state;
     B.band_e = o.band_e;
     B.max_ipm_iter = o.max_ipm_iter;
     B.max_as_iter = o.max_as_iter;

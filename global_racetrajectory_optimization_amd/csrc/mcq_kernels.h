@@ -38,7 +38,8 @@
 #define MCQ_GLD 72                 /* 2*GW+1 = 69, padded */
 #define MCQ_HBO 66                 /* offset of the border part inside an H/L row */
 #define MCQ_HLD 130                /* BH_MAX+1 band | pad | P_MAX border */
-#define MCQ_NVEC 20
+#define MCQ_NVEC 27
+#define MCQ_KMAX 24                /* active curvature rows the Schur-complement path of the active-set phase holds */
 #define MCQ_PIVOT_WARMUP 64
 
 // bE / bR: half-widths of the cyclic band of E_kappa to the left / right of the diagonal.  bR = bE except for small
@@ -84,6 +85,7 @@ struct McqWork {
     gdouble* L;           // also scratch for the T^-1 rows during assembly
     gdouble* vec;         // MCQ_NVEC vectors of length nmax, see enum below
     gschar* state;        // [n] 0 free, -1 at lower bound, +1 at upper bound, 2 fixed (lo == hi)
+    gdouble* Z;           // [MCQ_KMAX][nmax] M^-1 E_K' columns of the curvature-row Schur complement
     gdouble* alpha;       // [n] output
     gdouble* curv_err;    // [1]
     gint* status;         // [1]
@@ -92,7 +94,7 @@ struct McqWork {
 
 enum {
     V_XP = 0, V_YP, V_CP, V_KREF, V_XPP, V_YPP, V_F, V_LO, V_HI, V_X, V_G, V_ZL, V_ZU, V_SIG, V_RHS, V_DXA, V_T0, V_T1,
-    V_T2, V_T3
+    V_T2, V_T3, V_TL, V_TU, V_YL, V_YU, V_SK, V_EDA, V_Q
 };
 
 struct McqBatch {
@@ -103,7 +105,7 @@ struct McqBatch {
     const double* ref;      // [batch][nmax][4]
     const double* nv;       // [batch][nmax][2]
     const double* sc;       // [batch][nmax] or nullptr
-    double* Eb; double* Et; double* Db; double* H; double* L; double* vec;
+    double* Eb; double* Et; double* Db; double* H; double* L; double* vec; double* Z;
     signed char* state;
     double* alpha;          // [batch][nmax]
     double* curv_err; int* status; mcq_info* info;

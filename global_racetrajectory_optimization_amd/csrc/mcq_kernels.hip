@@ -25,7 +25,10 @@
 #define SM_WIN (SM_S + MCQ_P_MAX * SLD)
 #define SM_CW (SM_WIN + NSLOT * WLD)
 #define SM_LRW (SM_CW + NSLOT * CLD)
-#define SM_TOTAL (SM_LRW + LSLOT * WLD)
+#define SM_KS (SM_LRW + LSLOT * WLD)              /* KMAX x KMAX Schur matrix of the active curvature rows */
+#define SM_KV (SM_KS + MCQ_KMAX * MCQ_KMAX)      /* 2 x KMAX: multipliers, right-hand side */
+#define SM_KI (SM_KV + 2 * MCQ_KMAX)             /* ints: nk, row index[KMAX], sign[KMAX] */
+#define SM_TOTAL (SM_KI + MCQ_KMAX + 2)
 #define SM_CHUNK SM_WIN                          /* NBUF x CH x WLD */
 #define SM_RHS (SM_CHUNK + NBUF * CH * WLD)      /* NRB x CH */
 
@@ -97,6 +100,7 @@ __device__ McqWork mcq_work(const McqBatch& B, int pb, int& n, double& kb, doubl
     w.L = (gdouble*)(B.L + (size_t)pb * nm * MCQ_HLD);
     w.vec = (gdouble*)(B.vec + (size_t)pb * nm * MCQ_NVEC);
     w.state = (gschar*)(B.state + (size_t)pb * nm);
+    w.Z = (gdouble*)(B.Z + (size_t)pb * nm * MCQ_KMAX);
     w.alpha = (gdouble*)(B.alpha + (size_t)pb * nm);
     w.curv_err = (gdouble*)(B.curv_err + pb);
     w.status = (gint*)(B.status + pb);
@@ -347,7 +351,8 @@ __device__ __forceinline__ double gram_entry(const gdouble* Et, const gdouble* s
 // Writes  E' diag(sg) E  in bordered-band storage (row-major rows of MCQ_HLD doubles, see mcq_kernels.h) into `out`.
 // Work items are ordered so that consecutive threads take consecutive rows i of the same diagonal / border column:
 // the Et[.][i] loads are contiguous 512-byte segments and the Et[.][j] loads hit a few L1-resident lines.
-__device__ void gram_bordered(const gdouble* Et, const gdouble* sg, const McqDims& d, int nm, gdouble* out, int t0, int nthreads)
+__device__ void gram_bordered(const gdouble* Et, const gdouble* sg, const McqDims& d, int nm, const gdouble* base, gdouble* out,
+                              int t0, int nthreads)
 {
     const int ni = d.ni, n = d.n;
     const int bw = MCQ_BH_MAX + 1;
@@ -355,7 +360,7 @@ __device__ void gram_bordered(const gdouble* Et, const gdouble* sg, const McqDim
         const int k = idx / ni, i = idx - k * ni;
         double v = 0.0;
         if (k <= d.b && i + k < ni) v = gram_entry(Et, sg, d, nm, i, i + k);
-        out[(size_t)i * MCQ_HLD + k] = v;
+        out[(size_t)i * MCQ_HLD + k] = v + (base ? base[(size_t)i * MCQ_HLD + k] : 0.0);
     }
     for (int idx = t0; idx < MCQ_P_MAX * n; idx += nthreads) {
         const int jj = idx / n, i = idx - jj * n;
@@ -364,7 +369,7 @@ __device__ void gram_bordered(const gdouble* Et, const gdouble* sg, const McqDim
             const int j = ni + jj;
             if (abs(sdiff(i, j, n)) <= d.bH) v = gram_entry(Et, sg, d, nm, i, j);
         }
-        out[(size_t)i * MCQ_HLD + MCQ_HBO + jj] = v;
+        out[(size_t)i * MCQ_HLD + MCQ_HBO + jj] = v + (base ? base[(size_t)i * MCQ_HLD + MCQ_HBO + jj] : 0.0);
     }
 }
 
@@ -390,7 +395,7 @@ __global__ void __launch_bounds__(MCQ_NT) mcq_gram_kernel(McqBatch B)
         }
         F[j] = MCQ_F_SCALE * acc;
     }
-    gram_bordered(w.Et, nullptr, d, nm, w.H, tid, nthreads);
+    gram_bordered(w.Et, nullptr, d, nm, nullptr, w.H, tid, nthreads);
 }
 
 // =====================================================================================================================
@@ -437,7 +442,7 @@ __device__ __forceinline__ void ext_col_store(double* win, double* cwn, int cc, 
     else cwn[(cc % NSLOT) * CLD + (e - WLD)] = v;
 }
 
-__device__ __noinline__ int factor(const SolveCtx& c, const gdouble* sig, const gschar* mk)
+__device__ __noinline__ int factor(const SolveCtx& c, const gdouble* Hsrc, const gdouble* sig, const gschar* mk)
 {
     const int tid = threadIdx.x;
     const int b = c.d.b, p = c.d.p, ni = c.d.ni;
@@ -445,7 +450,7 @@ __device__ __noinline__ int factor(const SolveCtx& c, const gdouble* sig, const 
     double* cwn = g_sm + SM_CW;
     double* lrw = g_sm + SM_LRW;
     double* Sm = g_sm + SM_S;
-    const gdouble* H = c.w.H;
+    const gdouble* H = Hsrc;   // c.w.H, or the L slab itself (in place: column cc is read before L row cc is written)
     gdouble* L = c.w.L;
     const int EXT = WLD + CLD;
 
@@ -772,15 +777,502 @@ __device__ __noinline__ void solve(const SolveCtx& c, gdouble* v)
     __syncthreads();
 }
 
-// gradient  g = E'(E x + F k_ref)   (tmp: scratch vector)
-__device__ __noinline__ void gradient(const SolveCtx& c, const gdouble* x, gdouble* tmp, gdouble* g)
+// g = E'(E x + F_SCALE k_ref + extra)      (tmp: scratch vector; extra may be nullptr)
+__device__ __noinline__ void gradient(SolveCtx& c, const gdouble* x, const gdouble* extra, gdouble* tmp, gdouble* g)
 {
     const int n = c.d.n;
+    const long long t0 = TICK();
     __syncthreads();
     band_matvec(c.w.Eb, c.d.bE, c.d.bR, n, c.nm, x, VEC(c.w, c.nm, V_KREF), MCQ_F_SCALE, tmp);
     __syncthreads();
+    if (extra) {
+        for (int i = threadIdx.x; i < n; i += MCQ_NT) tmp[i] += extra[i];
+        __syncthreads();
+    }
     band_matvec(c.w.Et, c.d.bR, c.d.bE, n, c.nm, tmp, nullptr, 0.0, g);
     __syncthreads();
+    c.tk[2] += TICK() - t0;
+}
+
+__device__ __forceinline__ int timed_factor(SolveCtx& c, const gdouble* src, const gdouble* sig, const gschar* mk)
+{
+    const long long t0 = TICK();
+    const int r = factor(c, src, sig, mk);
+    c.tk[0] += TICK() - t0;
+    return r;
+}
+__device__ __forceinline__ void timed_solve(SolveCtx& c, gdouble* v)
+{
+    const long long t0 = TICK();
+    solve(c, v);
+    c.tk[1] += TICK() - t0;
+}
+
+struct SolveScalars {
+    double zscale, fscale, wmean, nfree, kbound;
+};
+
+// ---------------------------------------------------------------------------------------------------------------------
+// Mehrotra predictor-corrector interior point on
+//     min 1/2 x'Hx + f'x   s.t.  lo <= x <= hi   [ and, with_kappa:  -kb <= E x + k_ref <= kb ]
+// Box pairs (sl, zl), (su, zu); curvature pairs (tl, yl), (tu, yu) with tl = kb + r, tu = kb - r, r = E x + k_ref
+// carried as infeasible-start slacks (residuals rho).  The reduced system is
+//     (H + diag(zl/sl + zu/su) + E' diag(yl/tl + yu/tu) E) dx = rhs
+// i.e. the same bordered band as H: one banded Cholesky per iteration, two solves.
+// ---------------------------------------------------------------------------------------------------------------------
+__device__ __noinline__ int ipm(SolveCtx& c, const McqBatch& B, bool with_kappa, const SolveScalars& sc, int& iters)
+{
+    const int tid = threadIdx.x, n = c.d.n, nm = c.nm;
+    double* red = g_sm + SM_RED;
+    const gdouble* LO = VEC(c.w, nm, V_LO);
+    const gdouble* HI = VEC(c.w, nm, V_HI);
+    const gdouble* KR = VEC(c.w, nm, V_KREF);
+    gdouble* X = VEC(c.w, nm, V_X);
+    gdouble* G = VEC(c.w, nm, V_G);
+    gdouble* ZL = VEC(c.w, nm, V_ZL);
+    gdouble* ZU = VEC(c.w, nm, V_ZU);
+    gdouble* SIG = VEC(c.w, nm, V_SIG);
+    gdouble* RHS = VEC(c.w, nm, V_RHS);
+    gdouble* DXA = VEC(c.w, nm, V_DXA);
+    gdouble* T0 = VEC(c.w, nm, V_T0);
+    gdouble* T1 = VEC(c.w, nm, V_T1);
+    gdouble* T2 = VEC(c.w, nm, V_T2);
+    gdouble* TL = VEC(c.w, nm, V_TL);
+    gdouble* TU = VEC(c.w, nm, V_TU);
+    gdouble* YL = VEC(c.w, nm, V_YL);
+    gdouble* YU = VEC(c.w, nm, V_YU);
+    gdouble* SK = VEC(c.w, nm, V_SK);
+    gdouble* EDA = VEC(c.w, nm, V_EDA);
+    gdouble* Q = VEC(c.w, nm, V_Q);
+    gschar* ST = c.w.state;
+    const double kb = sc.kbound, zscale = sc.zscale;
+    const double IPM_TOL = 1e-10;
+    iters = 0;
+
+    for (int i = tid; i < n; i += MCQ_NT) {
+        const bool fixed = !(HI[i] - LO[i] > 1e-12);
+        ST[i] = fixed ? 2 : 0;
+        X[i] = 0.5 * (LO[i] + HI[i]);
+        ZL[i] = fixed ? 0.0 : zscale;
+        ZU[i] = ZL[i];
+    }
+    __syncthreads();
+    if (with_kappa) {
+        band_matvec(c.w.Eb, c.d.bE, c.d.bR, n, nm, X, KR, 1.0, T0);     // r = E x + k_ref
+        __syncthreads();
+        const double mu0 = 0.5 * zscale * sc.wmean;
+        for (int i = tid; i < n; i += MCQ_NT) {
+            const double r = T0[i];
+            const double tl = fmax(kb + r, 0.1 * kb), tu = fmax(kb - r, 0.1 * kb);
+            TL[i] = tl; TU[i] = tu;
+            YL[i] = mu0 / tl; YU[i] = mu0 / tu;
+        }
+        __syncthreads();
+    }
+    const double npairs = 2.0 * sc.nfree + (with_kappa ? 2.0 * n : 0.0);
+    if (!(npairs > 0.0)) return MCQ_OK;
+
+    for (int it = 1; it <= B.max_ipm_iter; ++it) {
+        // ---- residuals: g = H x + f;  with kappa also r, rho and the dual residual needs E'(yu - yl) ---------------------
+        if (with_kappa) {
+            for (int i = tid; i < n; i += MCQ_NT) Q[i] = YU[i] - YL[i];
+            gradient(c, X, Q, T0, T1);                                   // T1 = g + E'(yu - yl)   (dual residual part)
+            gradient(c, X, nullptr, T0, G);                              // G  = g
+            band_matvec(c.w.Eb, c.d.bE, c.d.bR, n, nm, X, KR, 1.0, T0);  // T0 = r
+            __syncthreads();
+        } else {
+            gradient(c, X, nullptr, T0, G);
+        }
+        double mu = 0.0, rdm = 0.0, rhom = 0.0;
+        for (int i = tid; i < n; i += MCQ_NT) {
+            if (with_kappa) {
+                mu += TL[i] * YL[i] + TU[i] * YU[i];
+                rhom = fmax(rhom, fmax(fabs(TL[i] - (kb + T0[i])), fabs(TU[i] - (kb - T0[i]))));
+                SK[i] = YL[i] / TL[i] + YU[i] / TU[i];
+            }
+            if (ST[i] != 0) continue;
+            const double sl = X[i] - LO[i], su = HI[i] - X[i];
+            mu += sl * ZL[i] + su * ZU[i];
+            const double gg = with_kappa ? T1[i] : G[i];
+            rdm = fmax(rdm, fabs(gg - ZL[i] + ZU[i]));
+            SIG[i] = ZL[i] / sl + ZU[i] / su;
+        }
+        mu = block_reduce_(mu, 0, red) / npairs;
+        rdm = block_reduce_(rdm, 2, red);
+        rhom = block_reduce_(rhom, 2, red);
+        if (mu < IPM_TOL * zscale * sc.wmean && rdm < IPM_TOL * zscale && rhom <= 1e-9 * kb) return MCQ_OK;
+        iters = it;
+
+        // ---- factorisation of the reduced system ---------------------------------------------------------------------
+        int fs;
+        if (with_kappa) {
+            __syncthreads();
+            gram_bordered(c.w.Et, SK, c.d, nm, c.w.H, c.w.L, tid, MCQ_NT);   // L slab <- H + E' diag(SK) E
+            __syncthreads();
+            fs = timed_factor(c, c.w.L, SIG, ST);                            // in place
+        } else {
+            fs = timed_factor(c, c.w.H, SIG, ST);
+        }
+        if (fs != 0) return fs;
+
+        // ---- predictor -------------------------------------------------------------------------------------------------
+        if (with_kappa) {
+            // rhs = -g + E' q,  q = yl rho_l / tl - yu rho_u / tu
+            for (int i = tid; i < n; i += MCQ_NT) {
+                const double rl = TL[i] - (kb + T0[i]), ru = TU[i] - (kb - T0[i]);
+                Q[i] = YL[i] * rl / TL[i] - YU[i] * ru / TU[i];
+            }
+            __syncthreads();
+            band_matvec(c.w.Et, c.d.bR, c.d.bE, n, nm, Q, nullptr, 0.0, T2);
+            __syncthreads();
+            for (int i = tid; i < n; i += MCQ_NT) RHS[i] = ST[i] == 0 ? -G[i] + T2[i] : 0.0;
+        } else {
+            for (int i = tid; i < n; i += MCQ_NT) RHS[i] = ST[i] == 0 ? -G[i] : 0.0;
+        }
+        timed_solve(c, RHS);
+        if (with_kappa) {
+            band_matvec(c.w.Eb, c.d.bE, c.d.bR, n, nm, RHS, nullptr, 0.0, EDA);   // E dx_aff
+            __syncthreads();
+        }
+        double ap = 1.0, ad = 1.0;
+        for (int i = tid; i < n; i += MCQ_NT) {
+            if (with_kappa) {
+                const double rl = TL[i] - (kb + T0[i]), ru = TU[i] - (kb - T0[i]);
+                const double dtl = EDA[i] - rl, dtu = -EDA[i] - ru;
+                const double dyl = -YL[i] - YL[i] * dtl / TL[i], dyu = -YU[i] - YU[i] * dtu / TU[i];
+                if (dtl < 0.0) ap = fmin(ap, -TL[i] / dtl);
+                if (dtu < 0.0) ap = fmin(ap, -TU[i] / dtu);
+                if (dyl < 0.0) ad = fmin(ad, -YL[i] / dyl);
+                if (dyu < 0.0) ad = fmin(ad, -YU[i] / dyu);
+            }
+            if (ST[i] != 0) { DXA[i] = 0.0; continue; }
+            const double dx = RHS[i];
+            DXA[i] = dx;
+            const double sl = X[i] - LO[i], su = HI[i] - X[i];
+            const double dzl = -ZL[i] - ZL[i] * dx / sl, dzu = -ZU[i] + ZU[i] * dx / su;
+            if (dx < 0.0) ap = fmin(ap, -sl / dx);
+            if (dx > 0.0) ap = fmin(ap, su / dx);
+            if (dzl < 0.0) ad = fmin(ad, -ZL[i] / dzl);
+            if (dzu < 0.0) ad = fmin(ad, -ZU[i] / dzu);
+        }
+        ap = block_reduce_(ap, 1, red);
+        ad = block_reduce_(ad, 1, red);
+        double mua = 0.0;
+        for (int i = tid; i < n; i += MCQ_NT) {
+            if (with_kappa) {
+                const double rl = TL[i] - (kb + T0[i]), ru = TU[i] - (kb - T0[i]);
+                const double dtl = EDA[i] - rl, dtu = -EDA[i] - ru;
+                const double dyl = -YL[i] - YL[i] * dtl / TL[i], dyu = -YU[i] - YU[i] * dtu / TU[i];
+                mua += (TL[i] + ap * dtl) * (YL[i] + ad * dyl) + (TU[i] + ap * dtu) * (YU[i] + ad * dyu);
+            }
+            if (ST[i] != 0) continue;
+            const double dx = DXA[i];
+            const double sl = X[i] - LO[i], su = HI[i] - X[i];
+            const double dzl = -ZL[i] - ZL[i] * dx / sl, dzu = -ZU[i] + ZU[i] * dx / su;
+            mua += (sl + ap * dx) * (ZL[i] + ad * dzl) + (su - ap * dx) * (ZU[i] + ad * dzu);
+        }
+        mua = block_reduce_(mua, 0, red) / npairs;
+        const double ratio = mua / mu;
+        const double smu = ratio * ratio * ratio * mu;
+
+        // ---- corrector -------------------------------------------------------------------------------------------------
+        if (with_kappa) {
+            for (int i = tid; i < n; i += MCQ_NT) {
+                const double rl = TL[i] - (kb + T0[i]), ru = TU[i] - (kb - T0[i]);
+                const double dtl = EDA[i] - rl, dtu = -EDA[i] - ru;
+                const double dyl = -YL[i] - YL[i] * dtl / TL[i], dyu = -YU[i] - YU[i] * dtu / TU[i];
+                Q[i] = (smu - dtl * dyl + YL[i] * rl) / TL[i] - (smu - dtu * dyu + YU[i] * ru) / TU[i];
+            }
+            __syncthreads();
+            band_matvec(c.w.Et, c.d.bR, c.d.bE, n, nm, Q, nullptr, 0.0, T2);
+            __syncthreads();
+        }
+        for (int i = tid; i < n; i += MCQ_NT) {
+            if (ST[i] != 0) { RHS[i] = 0.0; continue; }
+            const double dx = DXA[i];
+            const double sl = X[i] - LO[i], su = HI[i] - X[i];
+            const double dzl = -ZL[i] - ZL[i] * dx / sl, dzu = -ZU[i] + ZU[i] * dx / su;
+            RHS[i] = -G[i] + (smu - dx * dzl) / sl - (smu + dx * dzu) / su + (with_kappa ? T2[i] : 0.0);
+        }
+        timed_solve(c, RHS);
+        if (with_kappa) {
+            band_matvec(c.w.Eb, c.d.bE, c.d.bR, n, nm, RHS, nullptr, 0.0, Q);     // Q = E dx
+            __syncthreads();
+        }
+        double amax = 1.0 / 0.995;
+        for (int i = tid; i < n; i += MCQ_NT) {
+            if (with_kappa) {
+                const double rl = TL[i] - (kb + T0[i]), ru = TU[i] - (kb - T0[i]);
+                const double dtla = EDA[i] - rl, dtua = -EDA[i] - ru;
+                const double dyla = -YL[i] - YL[i] * dtla / TL[i], dyua = -YU[i] - YU[i] * dtua / TU[i];
+                const double dtl = Q[i] - rl, dtu = -Q[i] - ru;
+                const double dyl = (-TL[i] * YL[i] + smu - dtla * dyla - YL[i] * dtl) / TL[i];
+                const double dyu = (-TU[i] * YU[i] + smu - dtua * dyua - YU[i] * dtu) / TU[i];
+                // stash the curvature-pair directions: EDA <- dyl, SK <- dyu (both are recomputed next iteration)
+                EDA[i] = dyl;
+                SK[i] = dyu;
+                if (dtl < 0.0) amax = fmin(amax, -TL[i] / dtl);
+                if (dtu < 0.0) amax = fmin(amax, -TU[i] / dtu);
+                if (dyl < 0.0) amax = fmin(amax, -YL[i] / dyl);
+                if (dyu < 0.0) amax = fmin(amax, -YU[i] / dyu);
+            }
+            if (ST[i] != 0) continue;
+            const double dx = RHS[i], da = DXA[i];
+            const double sl = X[i] - LO[i], su = HI[i] - X[i];
+            const double dzla = -ZL[i] - ZL[i] * da / sl, dzua = -ZU[i] + ZU[i] * da / su;
+            const double dzl = (-sl * ZL[i] + smu - da * dzla - ZL[i] * dx) / sl;
+            const double dzu = (-su * ZU[i] + smu + da * dzua + ZU[i] * dx) / su;
+            T1[i] = dzl;
+            T2[i] = dzu;
+            if (dx < 0.0) amax = fmin(amax, -sl / dx);
+            if (dx > 0.0) amax = fmin(amax, su / dx);
+            if (dzl < 0.0) amax = fmin(amax, -ZL[i] / dzl);
+            if (dzu < 0.0) amax = fmin(amax, -ZU[i] / dzu);
+        }
+        amax = block_reduce_(amax, 1, red);
+        const double a = fmin(1.0, 0.995 * amax);
+        for (int i = tid; i < n; i += MCQ_NT) {
+            if (with_kappa) {
+                const double rl = TL[i] - (kb + T0[i]), ru = TU[i] - (kb - T0[i]);
+                TL[i] += a * (Q[i] - rl);
+                TU[i] += a * (-Q[i] - ru);
+                YL[i] += a * EDA[i];
+                YU[i] += a * SK[i];
+            }
+            if (ST[i] != 0) continue;
+            X[i] += a * RHS[i];
+            ZL[i] += a * T1[i];
+            ZU[i] += a * T2[i];
+        }
+        __syncthreads();
+    }
+    return with_kappa ? MCQ_KAPPA_INFEASIBLE : MCQ_ITER_CAP;
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// Active-set identification from the interior-point pairs + block principal pivoting (Kim-Park / Judice-Pires rule
+// with single-pivot backup) on the vertex: every iterate solves the equality-constrained problem of its working set
+// exactly, so the returned point is an exact KKT vertex like the one a dual active-set (Goldfarb-Idnani) solver returns.
+// Working set = pinned box rows (masked banded Cholesky of H_FF) + at most MCQ_KMAX active curvature rows, the latter
+// through the Schur complement  S = E_K M^-1 E_K'  (|K| extra banded solves per iteration; rare path).
+// ---------------------------------------------------------------------------------------------------------------------
+__device__ __forceinline__ double erow_dot(const SolveCtx& c, int k, const gdouble* v)
+{
+    // (E v)_k, computed redundantly by every thread (short: ew terms)
+    const int n = c.d.n;
+    double acc = 0.0;
+    int j = cyc(k - c.d.bE, n);
+    for (int oo = 0; oo < c.d.ew; ++oo) {
+        acc += c.w.Eb[(size_t)oo * c.nm + k] * v[j];
+        j = (j + 1 == n) ? 0 : j + 1;
+    }
+    return acc;
+}
+
+__device__ __noinline__ int active_set(SolveCtx& c, const McqBatch& B, bool with_kappa, const SolveScalars& sc, int& iters,
+                                       double& kkt, int& nk_out)
+{
+    const int tid = threadIdx.x, n = c.d.n, nm = c.nm;
+    double* red = g_sm + SM_RED;
+    double* KS = g_sm + SM_KS;
+    double* KMU = g_sm + SM_KV;
+    double* KRH = g_sm + SM_KV + MCQ_KMAX;
+    int* KI = (int*)(g_sm + SM_KI);        // KI[0] = nk, KI[1+q] = row, KI[1+KMAX+q] = sign
+    const gdouble* LO = VEC(c.w, nm, V_LO);
+    const gdouble* HI = VEC(c.w, nm, V_HI);
+    const gdouble* KR = VEC(c.w, nm, V_KREF);
+    gdouble* X = VEC(c.w, nm, V_X);
+    gdouble* G = VEC(c.w, nm, V_G);
+    gdouble* ZL = VEC(c.w, nm, V_ZL);
+    gdouble* ZU = VEC(c.w, nm, V_ZU);
+    gdouble* RHS = VEC(c.w, nm, V_RHS);
+    gdouble* T0 = VEC(c.w, nm, V_T0);
+    gdouble* T1 = VEC(c.w, nm, V_T1);
+    gdouble* T2 = VEC(c.w, nm, V_T2);
+    gdouble* T3 = VEC(c.w, nm, V_T3);
+    gdouble* Q = VEC(c.w, nm, V_Q);
+    gdouble* KF = VEC(c.w, nm, V_SK);      // per-row flag of the curvature working set: 0, +1 (upper), -1 (lower)
+    gschar* ST = c.w.state;
+    const double zscale = sc.zscale, fscale = sc.fscale, kb = sc.kbound;
+    iters = 0;
+    kkt = 0.0;
+    nk_out = 0;
+
+    // ---- identification ---------------------------------------------------------------------------------------------------
+    for (int i = tid; i < n; i += MCQ_NT) {
+        if (ST[i] == 0) {
+            const double wdt = HI[i] - LO[i];
+            const double sl = X[i] - LO[i], su = HI[i] - X[i];
+            signed char st = 0;
+            if (sl * zscale < ZL[i] * wdt) st = -1;
+            else if (su * zscale < ZU[i] * wdt) st = 1;
+            ST[i] = st;
+        }
+        double kf = 0.0;
+        if (with_kappa) {
+            const gdouble* TL = VEC(c.w, nm, V_TL);
+            const gdouble* TU = VEC(c.w, nm, V_TU);
+            const gdouble* YL = VEC(c.w, nm, V_YL);
+            const gdouble* YU = VEC(c.w, nm, V_YU);
+            const double mu0 = 0.5 * zscale * sc.wmean;
+            if (TL[i] * mu0 < YL[i] * kb * kb) kf = -1.0;
+            else if (TU[i] * mu0 < YU[i] * kb * kb) kf = 1.0;
+        }
+        KF[i] = kf;
+    }
+    __syncthreads();
+    const double TOLX = 1e-10;
+    const double toly = 1e-10 * (fscale > 0.0 ? fscale : 1.0);
+    const double tolk = 1e-10 * kb;
+    int best = 2 * n + 1, pcnt = 3;
+    for (int it = 1; it <= B.max_as_iter; ++it) {
+        iters = it;
+        // ---- compact list of the curvature working set (thread 0; n is small relative to everything else here) ------------
+        if (tid == 0) {
+            int nk = 0;
+            if (with_kappa)
+                for (int i = 0; i < n; ++i)
+                    if (KF[i] != 0.0 && nk < MCQ_KMAX + 1) {
+                        if (nk < MCQ_KMAX) { KI[1 + nk] = i; KI[1 + MCQ_KMAX + nk] = KF[i] > 0.0 ? 1 : -1; }
+                        ++nk;
+                    }
+            KI[0] = nk;
+        }
+        __syncthreads();
+        const int nk = KI[0];
+        if (nk > MCQ_KMAX) return MCQ_KAPPA_ACTIVE;      // more active curvature rows than the Schur path holds
+        nk_out = nk;
+
+        for (int i = tid; i < n; i += MCQ_NT) {
+            const signed char st = ST[i];
+            T1[i] = st == 0 ? 0.0 : (st < 0 ? LO[i] : (st == 1 ? HI[i] : 0.5 * (LO[i] + HI[i])));
+        }
+        gradient(c, T1, nullptr, T0, T2);       // T2 = H x_A + f
+        for (int i = tid; i < n; i += MCQ_NT) RHS[i] = ST[i] == 0 ? -T2[i] : T1[i];
+        const int fs = timed_factor(c, c.w.H, nullptr, ST);
+        if (fs != 0) return fs;
+        timed_solve(c, RHS);                    // x0 (pinned rows carry their bounds)
+        if (nk > 0) {
+            // Z_q = M^-1 (E_kq' restricted to the free set)
+            for (int q = 0; q < nk; ++q) {
+                gdouble* Zq = c.w.Z + (size_t)q * nm;
+                const int k = KI[1 + q];
+                for (int i = tid; i < n; i += MCQ_NT) Zq[i] = 0.0;
+                __syncthreads();
+                for (int oo = tid; oo < c.d.ew; oo += MCQ_NT) {
+                    const int j = cyc(k + oo - c.d.bE, n);
+                    if (ST[j] == 0) Zq[j] = c.w.Eb[(size_t)oo * nm + k];
+                }
+                __syncthreads();
+                timed_solve(c, Zq);
+            }
+            // S = E_K Z,  rhs = E_K x0 + k_ref - s kb     (thread q handles row q: short band dot products)
+            for (int e = tid; e < nk * (nk + 1); e += MCQ_NT) {
+                const int q = e / (nk + 1), q2 = e - q * (nk + 1);
+                const int k = KI[1 + q];
+                if (q2 < nk) KS[q * MCQ_KMAX + q2] = erow_dot(c, k, c.w.Z + (size_t)q2 * nm);
+                else KRH[q] = erow_dot(c, k, RHS) + KR[k] - KI[1 + MCQ_KMAX + q] * kb;
+            }
+            __syncthreads();
+            if (tid == 0) {   // dense solve S mu = rhs, Gaussian elimination with partial pivoting (|K| <= MCQ_KMAX)
+                for (int cidx = 0; cidx < nk; ++cidx) {
+                    int pr = cidx;
+                    for (int r = cidx + 1; r < nk; ++r)
+                        if (fabs(KS[r * MCQ_KMAX + cidx]) > fabs(KS[pr * MCQ_KMAX + cidx])) pr = r;
+                    if (pr != cidx) {
+                        for (int cc = 0; cc < nk; ++cc) {
+                            const double t = KS[cidx * MCQ_KMAX + cc];
+                            KS[cidx * MCQ_KMAX + cc] = KS[pr * MCQ_KMAX + cc];
+                            KS[pr * MCQ_KMAX + cc] = t;
+                        }
+                        const double t = KRH[cidx]; KRH[cidx] = KRH[pr]; KRH[pr] = t;
+                    }
+                    const double pv = KS[cidx * MCQ_KMAX + cidx];
+                    for (int r = cidx + 1; r < nk; ++r) {
+                        const double m = pv != 0.0 ? KS[r * MCQ_KMAX + cidx] / pv : 0.0;
+                        for (int cc = cidx; cc < nk; ++cc) KS[r * MCQ_KMAX + cc] -= m * KS[cidx * MCQ_KMAX + cc];
+                        KRH[r] -= m * KRH[cidx];
+                    }
+                }
+                for (int r = nk - 1; r >= 0; --r) {
+                    double t = KRH[r];
+                    for (int cc = r + 1; cc < nk; ++cc) t -= KS[r * MCQ_KMAX + cc] * KMU[cc];
+                    const double pv = KS[r * MCQ_KMAX + r];
+                    KMU[r] = pv != 0.0 ? t / pv : 0.0;
+                }
+            }
+            __syncthreads();
+            for (int i = tid; i < n; i += MCQ_NT) {
+                double x = RHS[i];
+                for (int q = 0; q < nk; ++q) x -= KMU[q] * c.w.Z[(size_t)q * nm + i];
+                RHS[i] = x;
+                Q[i] = 0.0;
+            }
+            __syncthreads();
+            for (int q = tid; q < nk; q += MCQ_NT) Q[KI[1 + q]] = KMU[q];     // multipliers scattered onto their rows
+            __syncthreads();
+        }
+        for (int i = tid; i < n; i += MCQ_NT) X[i] = ST[i] == 0 ? RHS[i] : T1[i];
+        gradient(c, X, nk > 0 ? Q : nullptr, T0, G);      // Lagrangian gradient  H x + f + E_K' mu
+        if (with_kappa) {
+            band_matvec(c.w.Eb, c.d.bE, c.d.bR, n, nm, X, KR, 1.0, T2);      // r = E x + k_ref
+            __syncthreads();
+        }
+        double nv = 0.0, imax = -1.0, kk = 0.0;
+        for (int i = tid; i < n; i += MCQ_NT) {
+            const signed char st = ST[i];
+            int v = 0;
+            if (st == 0) {
+                if (X[i] < LO[i] - TOLX) v = -1;
+                else if (X[i] > HI[i] + TOLX) v = 1;
+                kk = fmax(kk, fabs(G[i]));
+            } else if (st == -1) { if (G[i] < -toly) v = 2; }
+            else if (st == 1) { if (G[i] > toly) v = 2; }
+            int vk = 0;
+            if (with_kappa) {
+                const double kf = KF[i];
+                if (kf == 0.0) {
+                    if (T2[i] > kb + tolk) vk = 1;
+                    else if (T2[i] < -kb - tolk) vk = -1;
+                } else if (kf * Q[i] < -toly) vk = 2;      // multiplier of an active row must push inward
+            }
+            T3[i] = (double)(v + 8 * vk);
+            if (v != 0) { nv += 1.0; imax = fmax(imax, (double)i); }
+            if (vk != 0) { nv += 1.0; imax = fmax(imax, (double)(n + i)); }
+        }
+        nv = block_reduce_(nv, 0, red);
+        imax = block_reduce_(imax, 2, red);
+        kkt = block_reduce_(kk, 2, red);
+        const int nvi = (int)nv;
+        if (nvi == 0) {
+            // fp64 residual refinement through E on the final working set (same factor); box-only working sets
+            for (int r = 0; r < (nk == 0 ? B.refine_steps : 0); ++r) {
+                for (int i = tid; i < n; i += MCQ_NT) RHS[i] = ST[i] == 0 ? -G[i] : 0.0;
+                timed_solve(c, RHS);
+                for (int i = tid; i < n; i += MCQ_NT) if (ST[i] == 0) X[i] += RHS[i];
+                gradient(c, X, nullptr, T0, G);
+            }
+            double k2 = 0.0;
+            for (int i = tid; i < n; i += MCQ_NT) if (ST[i] == 0) k2 = fmax(k2, fabs(G[i]));
+            kkt = block_reduce_(k2, 2, red);
+            return MCQ_OK;
+        }
+        bool full;
+        if (nvi < best) { best = nvi; pcnt = 3; full = true; }
+        else if (pcnt > 0) { --pcnt; full = true; }
+        else full = false;
+        for (int i = tid; i < n; i += MCQ_NT) {
+            const int code = (int)T3[i];
+            // decode v in {-1,0,1,2}, vk in {-1,0,1,2}:  code = v + 8 vk
+            int vk = (code + 20) / 8 - 2;
+            int v = code - 8 * vk;
+            if (v > 2) { v -= 8; vk += 1; }
+            if (v != 0 && (full || i == (int)imax)) ST[i] = v == 2 ? 0 : (signed char)v;
+            if (vk != 0 && (full || n + i == (int)imax)) KF[i] = vk == 2 ? 0.0 : (double)vk;
+        }
+        __syncthreads();
+    }
+    return MCQ_ITER_CAP;
 }
 
 __global__ void __launch_bounds__(MCQ_NT) mcq_solve_kernel(McqBatch B)
@@ -803,229 +1295,77 @@ __global__ void __launch_bounds__(MCQ_NT) mcq_solve_kernel(McqBatch B)
     const gdouble* F = VEC(c.w, nm, V_F);
     gdouble* X = VEC(c.w, nm, V_X);
     gdouble* G = VEC(c.w, nm, V_G);
-    gdouble* ZL = VEC(c.w, nm, V_ZL);
-    gdouble* ZU = VEC(c.w, nm, V_ZU);
-    gdouble* SIG = VEC(c.w, nm, V_SIG);
-    gdouble* RHS = VEC(c.w, nm, V_RHS);
-    gdouble* DXA = VEC(c.w, nm, V_DXA);
     gdouble* T0 = VEC(c.w, nm, V_T0);
     gdouble* T1 = VEC(c.w, nm, V_T1);
     gdouble* T2 = VEC(c.w, nm, V_T2);
     gdouble* T3 = VEC(c.w, nm, V_T3);
+    gdouble* Q = VEC(c.w, nm, V_Q);
     gschar* ST = c.w.state;
 
-    const double FIX_TOL = 1e-12;
-    int status = MCQ_OK;
-    int ipm_iters = 0, as_iters = 0;
-
-    // ---------------------------------------------------------------------------------------------------------------
-    // interior point (Mehrotra predictor-corrector) on   min 1/2 x'Hx + f'x,  lo <= x <= hi
-    // ---------------------------------------------------------------------------------------------------------------
+    // ---- scalars: scales for the tolerances, initial gradient at the box centre -----------------------------------------
+    SolveScalars sc;
+    sc.kbound = kbound;
     double wsum = 0.0, nfree_d = 0.0, fmaxl = 0.0;
     for (int i = tid; i < n; i += MCQ_NT) {
         const double wdt = HI[i] - LO[i];
-        const bool fixed = !(wdt > FIX_TOL);
+        const bool fixed = !(wdt > 1e-12);
         ST[i] = fixed ? 2 : 0;
         X[i] = 0.5 * (LO[i] + HI[i]);
         if (!fixed) { wsum += wdt; nfree_d += 1.0; }
         fmaxl = fmax(fmaxl, fabs(F[i]));
     }
     wsum = block_reduce_(wsum, 0, red);
-    nfree_d = block_reduce_(nfree_d, 0, red);
-    const double fscale = block_reduce_(fmaxl, 2, red);
-    const double wmean = nfree_d > 0.0 ? wsum / nfree_d : 1.0;
-
-    { long long t2_ = TICK(); gradient(c, X, T0, G); c.tk[2] += TICK() - t2_; }
+    sc.nfree = block_reduce_(nfree_d, 0, red);
+    sc.fscale = block_reduce_(fmaxl, 2, red);
+    sc.wmean = sc.nfree > 0.0 ? wsum / sc.nfree : 1.0;
+    gradient(c, X, nullptr, T0, G);
     double gm = 0.0;
     for (int i = tid; i < n; i += MCQ_NT) if (ST[i] == 0) gm = fmax(gm, fabs(G[i]));
-    double zscale = block_reduce_(gm, 2, red);
-    if (!(zscale > 0.0)) zscale = fscale > 0.0 ? fscale : 1.0;
-    for (int i = tid; i < n; i += MCQ_NT) { ZL[i] = ST[i] == 0 ? zscale : 0.0; ZU[i] = ZL[i]; }
-    __syncthreads();
+    sc.zscale = block_reduce_(gm, 2, red);
+    if (!(sc.zscale > 0.0)) sc.zscale = sc.fscale > 0.0 ? sc.fscale : 1.0;
 
-    const double IPM_TOL = 1e-10;
-    if (nfree_d > 0.0) {
-        for (int it = 1; it <= B.max_ipm_iter; ++it) {
-            // residuals / duality measure
-            double mu = 0.0, rdm = 0.0;
-            for (int i = tid; i < n; i += MCQ_NT) {
-                if (ST[i] != 0) continue;
-                const double sl = X[i] - LO[i], su = HI[i] - X[i];
-                mu += sl * ZL[i] + su * ZU[i];
-                rdm = fmax(rdm, fabs(G[i] - ZL[i] + ZU[i]));
-                SIG[i] = ZL[i] / sl + ZU[i] / su;
-            }
-            mu = block_reduce_(mu, 0, red) / (2.0 * nfree_d);
-            rdm = block_reduce_(rdm, 2, red);
-            if (mu < IPM_TOL * zscale * wmean && rdm < IPM_TOL * zscale) break;
-            ipm_iters = it;
-
-            long long t0_ = TICK(); const int fs = factor(c, SIG, ST); c.tk[0] += TICK() - t0_;
-            if (fs != 0) { status = fs; break; }
-
-            // predictor
-            for (int i = tid; i < n; i += MCQ_NT) RHS[i] = ST[i] == 0 ? -G[i] : 0.0;
-            { long long t1_ = TICK(); solve(c, RHS); c.tk[1] += TICK() - t1_; }
-            double ap = 1.0, ad = 1.0;
-            for (int i = tid; i < n; i += MCQ_NT) {
-                if (ST[i] != 0) { DXA[i] = 0.0; continue; }
-                const double dx = RHS[i];
-                DXA[i] = dx;
-                const double sl = X[i] - LO[i], su = HI[i] - X[i];
-                const double dzl = -ZL[i] - ZL[i] * dx / sl, dzu = -ZU[i] + ZU[i] * dx / su;
-                if (dx < 0.0) ap = fmin(ap, -sl / dx);
-                if (dx > 0.0) ap = fmin(ap, su / dx);
-                if (dzl < 0.0) ad = fmin(ad, -ZL[i] / dzl);
-                if (dzu < 0.0) ad = fmin(ad, -ZU[i] / dzu);
-            }
-            ap = block_reduce_(ap, 1, red);
-            ad = block_reduce_(ad, 1, red);
-            double mua = 0.0;
-            for (int i = tid; i < n; i += MCQ_NT) {
-                if (ST[i] != 0) continue;
-                const double dx = DXA[i];
-                const double sl = X[i] - LO[i], su = HI[i] - X[i];
-                const double dzl = -ZL[i] - ZL[i] * dx / sl, dzu = -ZU[i] + ZU[i] * dx / su;
-                mua += (sl + ap * dx) * (ZL[i] + ad * dzl) + (su - ap * dx) * (ZU[i] + ad * dzu);
-            }
-            mua = block_reduce_(mua, 0, red) / (2.0 * nfree_d);
-            const double ratio = mua / mu;
-            const double sigma = ratio * ratio * ratio;
-            const double smu = sigma * mu;
-
-            // corrector
-            for (int i = tid; i < n; i += MCQ_NT) {
-                if (ST[i] != 0) { RHS[i] = 0.0; continue; }
-                const double dx = DXA[i];
-                const double sl = X[i] - LO[i], su = HI[i] - X[i];
-                const double dzl = -ZL[i] - ZL[i] * dx / sl, dzu = -ZU[i] + ZU[i] * dx / su;
-                RHS[i] = -G[i] + (smu - dx * dzl) / sl - (smu + dx * dzu) / su;
-            }
-            { long long t1_ = TICK(); solve(c, RHS); c.tk[1] += TICK() - t1_; }
-            double amax = 1.0 / 0.995;
-            for (int i = tid; i < n; i += MCQ_NT) {
-                if (ST[i] != 0) continue;
-                const double dx = RHS[i], da = DXA[i];
-                const double sl = X[i] - LO[i], su = HI[i] - X[i];
-                const double dzla = -ZL[i] - ZL[i] * da / sl, dzua = -ZU[i] + ZU[i] * da / su;
-                const double dzl = (-sl * ZL[i] + smu - da * dzla - ZL[i] * dx) / sl;
-                const double dzu = (-su * ZU[i] + smu + da * dzua + ZU[i] * dx) / su;
-                T1[i] = dzl;
-                T2[i] = dzu;
-                if (dx < 0.0) amax = fmin(amax, -sl / dx);
-                if (dx > 0.0) amax = fmin(amax, su / dx);
-                if (dzl < 0.0) amax = fmin(amax, -ZL[i] / dzl);
-                if (dzu < 0.0) amax = fmin(amax, -ZU[i] / dzu);
-            }
-            amax = block_reduce_(amax, 1, red);
-            const double a = fmin(1.0, 0.995 * amax);
-            for (int i = tid; i < n; i += MCQ_NT) {
-                if (ST[i] != 0) continue;
-                X[i] += a * RHS[i];
-                ZL[i] += a * T1[i];
-                ZU[i] += a * T2[i];
-            }
-            { long long t2_ = TICK(); gradient(c, X, T0, G); c.tk[2] += TICK() - t2_; }
-        }
-    }
-
-    // ---------------------------------------------------------------------------------------------------------------
-    // active-set identification + block principal pivoting on the vertex (exact KKT point)
-    // ---------------------------------------------------------------------------------------------------------------
+    // ---- phase 1: box-constrained QP ---------------------------------------------------------------------------------------
+    int ipm_iters = 0, as_iters = 0, it2 = 0, nact_kappa = 0;
     double kkt = 0.0;
-    if (status == MCQ_OK) {
-        for (int i = tid; i < n; i += MCQ_NT) {
-            if (ST[i] != 0) continue;
-            const double wdt = HI[i] - LO[i];
-            const double sl = X[i] - LO[i], su = HI[i] - X[i];
-            signed char s = 0;
-            if (sl * zscale < ZL[i] * wdt) s = -1;
-            else if (su * zscale < ZU[i] * wdt) s = 1;
-            ST[i] = s;
-        }
-        __syncthreads();
-        const double TOLX = 1e-10;
-        const double toly = 1e-10 * (fscale > 0.0 ? fscale : 1.0);
-        int best = n + 1, pcnt = 3;
-        bool converged = false;
-        for (int it = 1; it <= B.max_as_iter; ++it) {
-            as_iters = it;
-            for (int i = tid; i < n; i += MCQ_NT) {
-                const signed char s = ST[i];
-                T1[i] = s == 0 ? 0.0 : (s < 0 ? LO[i] : (s == 1 ? HI[i] : 0.5 * (LO[i] + HI[i])));
-            }
-            { long long t2_ = TICK(); gradient(c, T1, T0, T2); c.tk[2] += TICK() - t2_; }       // T2 = H x_A + f
-            for (int i = tid; i < n; i += MCQ_NT) RHS[i] = ST[i] == 0 ? -T2[i] : T1[i];
-            long long t0_ = TICK(); const int fs = factor(c, nullptr, ST); c.tk[0] += TICK() - t0_;
-            if (fs != 0) { status = fs; break; }
-            { long long t1_ = TICK(); solve(c, RHS); c.tk[1] += TICK() - t1_; }
-            for (int i = tid; i < n; i += MCQ_NT) X[i] = ST[i] == 0 ? RHS[i] : T1[i];
-            { long long t2_ = TICK(); gradient(c, X, T0, G); c.tk[2] += TICK() - t2_; }
-            // infeasibilities
-            double nv = 0.0, imax = -1.0, kk = 0.0;
-            for (int i = tid; i < n; i += MCQ_NT) {
-                const signed char s = ST[i];
-                int v = 0;
-                if (s == 0) { if (X[i] < LO[i] - TOLX) v = -1; else if (X[i] > HI[i] + TOLX) v = 1; kk = fmax(kk, fabs(G[i])); }
-                else if (s == -1) { if (G[i] < -toly) v = 2; }
-                else if (s == 1) { if (G[i] > toly) v = 2; }
-                T3[i] = (double)v;
-                if (v != 0) { nv += 1.0; imax = fmax(imax, (double)i); }
-            }
-            nv = block_reduce_(nv, 0, red);
-            imax = block_reduce_(imax, 2, red);
-            kkt = block_reduce_(kk, 2, red);
-            const int nvi = (int)nv;
-            if (nvi == 0) { converged = true; break; }
-            bool full;
-            if (nvi < best) { best = nvi; pcnt = 3; full = true; }
-            else if (pcnt > 0) { --pcnt; full = true; }
-            else full = false;
-            for (int i = tid; i < n; i += MCQ_NT) {
-                const int v = (int)T3[i];
-                if (v == 0) continue;
-                if (!full && i != (int)imax) continue;
-                ST[i] = v == 2 ? 0 : (signed char)v;
-            }
-            __syncthreads();
-        }
-        if (status == MCQ_OK && !converged) status = MCQ_ITER_CAP;
+    int status = ipm(c, B, false, sc, ipm_iters);
+    int nk_dummy = 0;
+    if (status == MCQ_OK) status = active_set(c, B, false, sc, as_iters, kkt, nk_dummy);
 
-        // fp64 residual refinement through E on the final working set (same factor)
-        if (status == MCQ_OK) {
-            for (int r = 0; r < B.refine_steps; ++r) {
-                for (int i = tid; i < n; i += MCQ_NT) RHS[i] = ST[i] == 0 ? -G[i] : 0.0;
-                { long long t1_ = TICK(); solve(c, RHS); c.tk[1] += TICK() - t1_; }
-                for (int i = tid; i < n; i += MCQ_NT) if (ST[i] == 0) X[i] += RHS[i];
-                { long long t2_ = TICK(); gradient(c, X, T0, G); c.tk[2] += TICK() - t2_; }
-            }
-            double kk = 0.0;
-            for (int i = tid; i < n; i += MCQ_NT) if (ST[i] == 0) kk = fmax(kk, fabs(G[i]));
-            kkt = block_reduce_(kk, 2, red);
-        }
-    }
-
-    // ---------------------------------------------------------------------------------------------------------------
-    // outputs: alpha, curvature rows, opt_min_curv's curvature-error post-check
-    // ---------------------------------------------------------------------------------------------------------------
-    double nact = 0.0;
-    for (int i = tid; i < n; i += MCQ_NT) {
-        double a = X[i];
-        a = fmin(fmax(a, LO[i]), HI[i]);
-        X[i] = a;
-        c.w.alpha[i] = a;
-        if (ST[i] == -1 || ST[i] == 1) nact += 1.0;
-    }
-    nact = block_reduce_(nact, 0, red);
     // kappa(alpha) = k_ref + E alpha
+    for (int i = tid; i < n; i += MCQ_NT) X[i] = fmin(fmax(X[i], LO[i]), HI[i]);
+    __syncthreads();
     band_matvec(c.w.Eb, c.d.bE, c.d.bR, n, nm, X, VEC(c.w, nm, V_KREF), 1.0, T0);
     __syncthreads();
     double km = 0.0;
     for (int i = tid; i < n; i += MCQ_NT) km = fmax(km, fabs(T0[i]));
     km = block_reduce_(km, 2, red);
-    if (status == MCQ_OK && B.check_kappa && km > kbound * (1.0 + 1e-9)) status = MCQ_KAPPA_ACTIVE;
 
-    // curvature error: derivatives re-linearised at the solution
+    // ---- phase 2 (rare): a curvature-bound row is violated at the box optimum -> interior point with the curvature rows,
+    //      then the box active-set polish with the curvature multipliers frozen ---------------------------------------------
+    if (status == MCQ_OK && B.check_kappa && km > kbound * (1.0 + 1e-9)) {
+        status = ipm(c, B, true, sc, it2);
+        ipm_iters += it2;
+        if (status == MCQ_OK) {
+            status = active_set(c, B, true, sc, it2, kkt, nact_kappa);
+            as_iters += it2;
+        }
+        for (int i = tid; i < n; i += MCQ_NT) X[i] = fmin(fmax(X[i], LO[i]), HI[i]);
+        __syncthreads();
+        band_matvec(c.w.Eb, c.d.bE, c.d.bR, n, nm, X, VEC(c.w, nm, V_KREF), 1.0, T0);
+        __syncthreads();
+        double k2 = 0.0;
+        for (int i = tid; i < n; i += MCQ_NT) k2 = fmax(k2, fabs(T0[i]));
+        km = block_reduce_(k2, 2, red);
+        if (status == MCQ_OK && km > kbound * (1.0 + 1e-8)) status = MCQ_KAPPA_ACTIVE;
+    }
+
+    // ---- outputs: alpha, opt_min_curv's curvature-error post-check ------------------------------------
+    double nact = 0.0;
+    for (int i = tid; i < n; i += MCQ_NT) {
+        c.w.alpha[i] = X[i];
+        if (ST[i] == -1 || ST[i] == 1) nact += 1.0;
+    }
+    nact = block_reduce_(nact, 0, red);
     {
         const gdouble* XP = VEC(c.w, nm, V_XP);
         const gdouble* YP = VEC(c.w, nm, V_YP);
@@ -1058,9 +1398,9 @@ __global__ void __launch_bounds__(MCQ_NT) mcq_solve_kernel(McqBatch B)
                 o.ipm_iters = ipm_iters;
                 o.as_iters = as_iters;
                 o.n_active_box = (int)nact;
-                o.n_active_kappa = 0;
+                o.n_active_kappa = nact_kappa;
                 o.kappa_max = km;
-                o.kkt_res = fscale > 0.0 ? kkt / fscale : kkt;
+                o.kkt_res = sc.fscale > 0.0 ? kkt / sc.fscale : kkt;
                 c.tk[3] = TICK() - t_kernel0;
                 for (int q = 0; q < 4; ++q) o.ticks[q] = c.tk[q];
                 *(mcq_info*)c.w.info = o;

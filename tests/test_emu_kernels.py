@@ -73,3 +73,26 @@ def test_status_codes(emu, golden):
     bad["reftrack"][3, 0] = np.nan
     al, curv, st, _ = emu.solve_batch([narrow, bad])
     assert st[0] == engine.STATUS_INFEASIBLE and st[1] == engine.STATUS_BAD_INPUT
+
+
+def test_curvature_rows_active_and_infeasible(emu):
+    """Curvature-bound rows of the QP: active at the optimum -> exact vertex through the Schur
+    complement path; impossible to satisfy -> status 5 (quadprog: 'constraints are inconsistent, no solution')."""
+    from oracle import qp_ref
+    ref, nv, A, sc = _small_track(40, seed=5)
+    a_box, _, I = tph_ref.opt_min_curv(ref, nv, A, 10.0, 2.0, return_internals=True)
+    kmax = float(np.max(np.abs(I["k_ref"] + I["E"] @ a_box)))
+    kb = 0.9 * kmax
+    info = {}
+    a_ref, err_ref = tph_ref.opt_min_curv(ref, nv, A, kb, 2.0, solver=lambda H, f, G, h: qp_ref.solve_qp_gi(H, f, G, h, info))
+    n_act_kappa = int(np.sum(info["lagr"][2 * 40:] > 0))
+    assert n_act_kappa >= 1
+    with pytest.raises(ValueError, match="inconsistent"):
+        tph_ref.opt_min_curv(ref, nv, A, 1e-4, 2.0)
+    al, curv, st, inf = emu.solve_batch([dict(reftrack=ref, normvec=nv, scaling=sc, kappa_bound=kb, w_veh=2.0),
+                                         dict(reftrack=ref, normvec=nv, scaling=sc, kappa_bound=1e-4, w_veh=2.0)])
+    assert st[0] == 0 and st[1] == engine.STATUS_KAPPA_INFEASIBLE
+    assert inf[0]["n_active_kappa"] == n_act_kappa
+    assert np.max(np.abs(al[0] - a_ref)) < 1e-8
+    assert abs(curv[0] - err_ref) < 1e-9
+    assert abs(inf[0]["kappa_max"] - kb) < 1e-9

@@ -156,3 +156,31 @@ def test_ragged_batch_and_small_rings(gpu_engine, golden):
         assert np.max(np.abs(al[k] - a_ref)) < ALPHA_TOL
         assert abs(curv[k] - err_ref) < CURV_TOL
     assert np.max(np.abs(al[-1] - golden["handling_track"]["alpha"])) < ALPHA_TOL
+
+
+def test_curvature_rows_active_and_infeasible_gpu(gpu_engine):
+    from oracle import qp_ref, tph_ref
+    n = 150
+    rng = np.random.default_rng(11)
+    th = np.linspace(0.0, 2 * np.pi, n, endpoint=False)
+    r = 40.0 + 6.0 * np.sin(3 * th + 1.0) + 3.0 * np.cos(5 * th + 2.0)
+    xy = np.column_stack((r * np.cos(th), r * np.sin(th)))
+    path_cl = np.vstack((xy, xy[0]))
+    _, _, A, nv = tph_ref.calc_splines(path_cl)
+    ref = np.column_stack((xy, 3.0 + rng.uniform(0.0, 1.5, size=(n, 2))))
+    sc = tph.calc_splines.scalings_from_les_matrix(A)
+    a_box, _, I = tph_ref.opt_min_curv(ref, nv, A, 10.0, 2.0, return_internals=True)
+    kb = 0.9 * float(np.max(np.abs(I["k_ref"] + I["E"] @ a_box)))
+    info = {}
+    a_ref, err_ref = tph_ref.opt_min_curv(ref, nv, A, kb, 2.0,
+                                          solver=lambda H, f, G, h: qp_ref.solve_qp_gi(H, f, G, h, info))
+    n_act = int(np.sum(info["lagr"][2 * n:] > 0))
+    assert n_act >= 1
+    al, curv, st, inf = gpu_engine.solve_batch([dict(reftrack=ref, normvec=nv, scaling=sc, kappa_bound=kb, w_veh=2.0),
+                                                dict(reftrack=ref, normvec=nv, scaling=sc, kappa_bound=1e-4, w_veh=2.0)])
+    assert st[0] == 0 and st[1] == engine.STATUS_KAPPA_INFEASIBLE
+    assert inf[0]["n_active_kappa"] == n_act
+    assert np.max(np.abs(al[0] - a_ref)) < ALPHA_TOL
+    assert abs(curv[0] - err_ref) < CURV_TOL
+    with pytest.raises(ValueError, match="inconsistent"):
+        tph.opt_min_curv.opt_min_curv(ref, nv, A, 1e-4, 2.0)
