@@ -417,23 +417,32 @@ struct SolveCtx {
 // Returns 0 or MCQ_NOT_PD (uniform across the block).
 #define PF_ITEMS ((PFB * (WLD + CLD) + MCQ_NT - 1) / MCQ_NT)
 
-// element e of the (WLD + CLD)-wide "extended column" cc:  e < WLD -> band entry k = e, else border entry jj = e - WLD
+// element e of the (WLD + CLD)-wide "extended column" cc:  e < WLD -> band entry k = e, else border entry jj = e - WLD.
+// Branch-free: every load is issued unconditionally at a clamped (always valid) address, validity / pinning are selects.
+template <bool MK, bool SIG>
 __device__ __forceinline__ double ext_col_load(const gdouble* H, const gdouble* sig, const gschar* mk, int ni, int b,
                                                int p, int cc, int e)
 {
-    if (cc >= ni) return 0.0;
-    const bool pc = mk && mk[cc] != 0;
-    if (e < WLD) {
-        const int k = e, r = cc + k;
-        if (k > b || r >= ni) return 0.0;
-        if (pc || (mk && mk[r] != 0)) return k == 0 ? 1.0 : 0.0;
-        double v = H[(size_t)cc * MCQ_HLD + k];
-        if (k == 0 && sig) v += sig[cc];
-        return v;
-    }
+    const bool cin = cc < ni;
+    const int ccs = cin ? cc : 0;
+    const bool band = e < WLD;
     const int jj = e - WLD;
-    if (jj >= p || pc || (mk && mk[ni + jj] != 0)) return 0.0;
-    return H[(size_t)cc * MCQ_HLD + MCQ_HBO + jj];
+    const int off = band ? e : MCQ_HBO + jj;
+    const int r = band ? cc + e : ni + jj;
+    const bool valid = cin && (band ? (e <= b && r < ni) : (jj < p));
+    const int rs = valid ? r : 0;
+    double v = H[(size_t)ccs * MCQ_HLD + off];
+    v = valid ? v : 0.0;
+    bool pinned = false;
+    if (MK) {
+        pinned = (mk[ccs] != 0) | (mk[rs] != 0);
+        v = pinned ? ((e == 0 && valid) ? 1.0 : 0.0) : v;
+    }
+    if (SIG) {
+        const double sg = sig[ccs];
+        v += (e == 0 && valid && !pinned) ? sg : 0.0;
+    }
+    return v;
 }
 
 __device__ __forceinline__ void ext_col_store(double* win, double* cwn, int cc, int e, double v)
@@ -442,7 +451,8 @@ __device__ __forceinline__ void ext_col_store(double* win, double* cwn, int cc, 
     else cwn[(cc % NSLOT) * CLD + (e - WLD)] = v;
 }
 
-__device__ __noinline__ int factor(const SolveCtx& c, const gdouble* Hsrc, const gdouble* sig, const gschar* mk)
+template <bool MK, bool SIG>
+__device__ __forceinline__ int factor_t(const SolveCtx& c, const gdouble* Hsrc, const gdouble* sig, const gschar* mk)
 {
     const int tid = threadIdx.x;
     const int b = c.d.b, p = c.d.p, ni = c.d.ni;
@@ -453,6 +463,7 @@ __device__ __noinline__ int factor(const SolveCtx& c, const gdouble* Hsrc, const
     const gdouble* H = Hsrc;   // c.w.H, or the L slab itself (in place: column cc is read before L row cc is written)
     gdouble* L = c.w.L;
     const int EXT = WLD + CLD;
+    const int lane = tid & 63, w0 = tid >> 6;
 
     double sacc[16];
 #pragma unroll
@@ -461,79 +472,85 @@ __device__ __noinline__ int factor(const SolveCtx& c, const gdouble* Hsrc, const
 
     __syncthreads();
     for (int q = tid; q < LSLOT * WLD; q += MCQ_NT) lrw[q] = 0.0;
-    // prologue: columns 0 .. b + PFB (everything steps 0..PFB-1 touch)
+    // prologue: columns 0 .. b + PFB (everything steps 0..PFB-1 touch); columns >= ni load as zero
     {
-        const int npre = b + 1 + PFB;
+        const int npre = MCQ_BH_MAX + 1 + PFB;
         for (int q = tid; q < npre * EXT; q += MCQ_NT) {
             const int cc = q / EXT, e = q - cc * EXT;
-            ext_col_store(win, cwn, cc, e, ext_col_load(H, sig, mk, ni, b, p, cc, e));
+            ext_col_store(win, cwn, cc, e, ext_col_load<MK, SIG>(H, sig, mk, ni, b, p, cc, e));
         }
     }
     __syncthreads();
 
+    // Every step updates the full MCQ_BH_MAX-wide window with fixed trip counts and no predicates: entries that do not
+    // exist (rows >= ni, offsets beyond the band b) were loaded as exact zeros, so their updates are no-ops.
     int fail = 0;
     for (int i = 0; i < ni; ++i) {
         const int slot = i % NSLOT;
         const double* ci = win + slot * WLD;
         const double* cwi = cwn + slot * CLD;
         const int ib = i % PFB;
-        const int cblk = i - ib + b + 1 + PFB;     // first column of the block fetched during this block of steps
-        if (ib == 0 && cblk < ni) {
+        const int cblk = i - ib + MCQ_BH_MAX + 1 + PFB;   // first column of the block fetched during this block of steps
+        if (ib == 0) {
 #pragma unroll
             for (int u = 0; u < PF_ITEMS; ++u) {
                 const int q = tid + u * MCQ_NT;
-                const int cc = cblk + q / EXT, e = q % EXT;
-                pf[u] = (q < PFB * EXT) ? ext_col_load(H, sig, mk, ni, b, p, cc, e) : 0.0;
+                const int qq = q < PFB * EXT ? q : 0;
+                pf[u] = ext_col_load<MK, SIG>(H, sig, mk, ni, b, p, cblk + qq / EXT, qq % EXT);
             }
         }
         const double piv = ci[0];
         if (!(piv > 0.0)) { fail = 1; break; }   // uniform: every thread reads the same LDS word
         const double rinv = 1.0 / piv;
-        const double rs = 1.0 / sqrt(piv);
-        const int nrem = (b < ni - 1 - i) ? b : ni - 1 - i;
+        const double rs = rsqrt(piv);
 
-        // (a) band part of the trailing update: M[r,c] -= a_r a_c / piv,  i < c <= r <= i + nrem
+        // (a) band part of the trailing update: M[r,c] -= a_r a_c / piv,  i < c <= r <= i + 64
         {
-            const int dc = 1 + (tid & 63);
-            if (dc <= nrem) {
-                const double ac = ci[dc] * rinv;
-                double* colc = win + ((i + dc) % NSLOT) * WLD;
-                for (int dr = dc + (tid >> 6); dr <= nrem; dr += MCQ_NW) colc[dr - dc] -= ci[dr] * ac;
+            const int dc = 1 + lane;
+            double* colc = win + ((i + dc) % NSLOT) * WLD;
+            const double ac = ci[dc] * rinv;
+            double cv[16], av[16];
+#pragma unroll
+            for (int m = 0; m < 16; ++m) {
+                const int dr = dc + w0 + MCQ_NW * m;            // rows beyond i+64 get a_r = 0
+                const int drs = dr <= MCQ_BH_MAX ? dr : 0;
+                cv[m] = colc[w0 + MCQ_NW * m];
+                const double a = ci[drs];
+                av[m] = dr <= MCQ_BH_MAX ? a : 0.0;
             }
+#pragma unroll
+            for (int m = 0; m < 16; ++m) colc[w0 + MCQ_NW * m] = cv[m] - av[m] * ac;
         }
-        // (b) border coupling rows:  C[r][jj] -= a_r cw_i[jj] / piv
+        // (b) border coupling rows:  C[r][jj] -= a_r cw_i[jj] / piv,  r = i + 1 .. i + 64
         {
-            const int jj = tid & 63;
-            if (jj < p) {
-                const double cj = cwi[jj] * rinv;
-                for (int dr = 1 + (tid >> 6); dr <= nrem; dr += MCQ_NW) cwn[((i + dr) % NSLOT) * CLD + jj] -= ci[dr] * cj;
+            const double cj = cwi[lane] * rinv;
+            double cv[16], av[16];
+#pragma unroll
+            for (int m = 0; m < 16; ++m) {
+                const int dr = 1 + w0 + MCQ_NW * m;
+                cv[m] = cwn[((i + dr) % NSLOT) * CLD + lane];
+                av[m] = ci[dr];
+            }
+#pragma unroll
+            for (int m = 0; m < 16; ++m) {
+                const int dr = 1 + w0 + MCQ_NW * m;
+                cwn[((i + dr) % NSLOT) * CLD + lane] = cv[m] - av[m] * cj;
             }
         }
         // (c) Schur complement accumulators  S[j1][j2] -= cw_i[j1] cw_i[j2] / piv   (j2 = lane, j1 = wave + 4 m)
         {
-            const int j2 = tid & 63;
-            const double cj = cwi[j2] * rinv;
+            const double cj = cwi[lane] * rinv;
 #pragma unroll
-            for (int m = 0; m < 16; ++m) sacc[m] -= cwi[(tid >> 6) + MCQ_NW * m] * cj;
+            for (int m = 0; m < 16; ++m) sacc[m] -= cwi[w0 + MCQ_NW * m] * cj;
         }
-        // (d) emit column i of L into the row buffer, W row to global, flush the finished row i-1
-        {
-            const int nA = nrem + 1, nB = p, nC = (i > 0) ? b + 1 : 0;
-            for (int q = tid; q < nA + nB + nC; q += MCQ_NT) {
-                if (q < nA) {
-                    const int k = q;
-                    lrw[((i + k) % LSLOT) * WLD + k] = (k == 0) ? rs : ci[k] * rs;
-                } else if (q < nA + nB) {
-                    const int jj = q - nA;
-                    L[(size_t)i * MCQ_HLD + MCQ_HBO + jj] = cwi[jj] * rs;
-                } else {
-                    const int k = q - nA - nB;
-                    L[(size_t)(i - 1) * MCQ_HLD + k] = lrw[((i - 1) % LSLOT) * WLD + k];
-                }
-            }
-        }
+        // (d) emit column i of L into the row buffer (threads 0..64), W row to global (wave 1), flush the finished row
+        //     i-1 (threads 128..192)
+        if (tid <= MCQ_BH_MAX) lrw[((i + tid) % LSLOT) * WLD + tid] = (tid == 0) ? rs : ci[tid] * rs;
+        if (w0 == 1) L[(size_t)i * MCQ_HLD + MCQ_HBO + lane] = cwi[lane] * rs;
+        if (tid >= 128 && tid <= 128 + MCQ_BH_MAX && i > 0)
+            L[(size_t)(i - 1) * MCQ_HLD + (tid - 128)] = lrw[((i - 1) % LSLOT) * WLD + (tid - 128)];
         // (e) last step of the block: the prefetched block goes into the slots that were freed during this block
-        if (ib == PFB - 1 && cblk < ni) {
+        if (ib == PFB - 1) {
 #pragma unroll
             for (int u = 0; u < PF_ITEMS; ++u) {
                 const int q = tid + u * MCQ_NT;
@@ -553,11 +570,11 @@ __device__ __noinline__ int factor(const SolveCtx& c, const gdouble* Hsrc, const
             const int j1 = (tid >> 6) + MCQ_NW * m;
             double v = 0.0;
             if (j1 < p && j2 < p) {
-                const bool pj = mk && (mk[ni + j1] != 0 || mk[ni + j2] != 0);
+                const bool pj = MK && (mk[ni + j1] != 0 || mk[ni + j2] != 0);
                 if (pj) v = (j1 == j2) ? 1.0 : 0.0;
                 else {
                     v = H[(size_t)(ni + j1) * MCQ_HLD + MCQ_HBO + j2] + sacc[m];
-                    if (j1 == j2 && sig) v += sig[ni + j1];
+                    if (SIG && j1 == j2) v += sig[ni + j1];
                 }
             }
             Sm[j1 * SLD + j2] = v;
@@ -587,6 +604,13 @@ __device__ __noinline__ int factor(const SolveCtx& c, const gdouble* Hsrc, const
     if (tid == 0 && p > 0) Sm[(p - 1) * SLD + (p - 1)] = sqrt(Sm[(p - 1) * SLD + (p - 1)]);
     __syncthreads();
     return 0;
+}
+
+__device__ __noinline__ int factor(const SolveCtx& c, const gdouble* Hsrc, const gdouble* sig, const gschar* mk)
+{
+    // the two configurations the solver uses: interior point (diagonal added, fixed variables masked) and active set (mask only)
+    if (sig) return factor_t<true, true>(c, Hsrc, sig, mk);
+    return factor_t<true, false>(c, Hsrc, sig, mk);
 }
 
 // ---- solve  M v = rhs  in place (v in global memory) with the factor produced by factor() ---------------------------

@@ -26,6 +26,7 @@ inline double hipemu_now() { return std::chrono::duration<double, std::milli>(st
 #include <vector>
 
 using std::isfinite;
+inline double rsqrt(double x) { return 1.0 / std::sqrt(x); }
 
 #define __global__
 #define __device__
