@@ -1,0 +1,71 @@
+"""world_size = 2 gloo run of the sharded batch path on CPU (the per-rank solver is the SIMT-interpreted kernel library,
+test infrastructure only): ragged shards, one all-gather, every rank ends with the full batch."""
+import os
+import socket
+
+import numpy as np
+import pytest
+
+from global_racetrajectory_optimization_amd import parallel
+
+
+def test_shard_bounds_cover_batch():
+    for batch in (1, 2, 5, 1024, 16384):
+        for world in (1, 2, 3, 8):
+            spans = [parallel.shard_bounds(batch, world, r) for r in range(world)]
+            assert spans[0][0] == 0 and spans[-1][1] == batch
+            assert all(spans[r][1] == spans[r + 1][0] for r in range(world - 1))
+            sizes = [hi - lo for lo, hi in spans]
+            assert max(sizes) - min(sizes) <= 1
+
+
+def _problems():
+    from oracle import tph_ref
+    out = []
+    for n in (12, 16, 21):
+        rng = np.random.default_rng(n)
+        th = np.linspace(0.0, 2 * np.pi, n, endpoint=False)
+        r = 30.0 + 4.0 * np.sin(2 * th + 0.3)
+        xy = np.column_stack((r * np.cos(th), r * np.sin(th)))
+        _, _, _, nv = tph_ref.calc_splines(np.vstack((xy, xy[0])))
+        out.append(dict(reftrack=np.column_stack((xy, 3.0 + rng.uniform(0, 1, (n, 2)))), normvec=nv, scaling=None,
+                        kappa_bound=0.5, w_veh=2.0))
+    return out
+
+
+def _worker(rank, world, port, lib, q):
+    import torch.distributed as dist
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from global_racetrajectory_optimization_amd import engine
+    eng = engine.Engine(0, lib_path=lib)
+    a, c, s = parallel.solve_sharded(_problems(), eng, dist=dist)
+    q.put((rank, [x.tolist() for x in a], c.tolist(), s.tolist()))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.timeout(600)
+def test_two_rank_gloo_matches_single_process(emu_lib):
+    import torch.multiprocessing as mp
+    from global_racetrajectory_optimization_amd import engine
+    eng = engine.Engine(0, lib_path=emu_lib)
+    a_ref, c_ref, s_ref = parallel.solve_sharded(_problems(), eng)
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, emu_lib, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=500) for _ in range(2)]
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
+    for _, a, c, s in res:
+        assert s == s_ref.tolist() == [0, 0, 0]
+        for x, y in zip(a, a_ref):
+            assert np.array_equal(np.array(x), y)
+        assert np.allclose(c, c_ref, rtol=0, atol=0)

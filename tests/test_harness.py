@@ -1,0 +1,31 @@
+"""BASELINE config 1: the reference's main_globaltraj.py runs UNTOUCHED on top of the drop-in package (harness notes:
+SURVEY.md App. C).  Needs the reference checkout (/root/reference) -> skipped on the GPU box.  The engine behind
+opt_min_curv here is the SIMT-interpreted kernel library (test infrastructure); the `-m gpu` suite covers the real one."""
+import os
+
+import numpy as np
+import pytest
+
+REF = "/root/reference"
+
+
+@pytest.mark.skipif(not os.path.exists(os.path.join(REF, "main_globaltraj.py")), reason="reference checkout not present")
+@pytest.mark.parametrize("opt_type", ["mincurv"])
+def test_main_globaltraj_untouched(emu_lib, tmp_path, monkeypatch, opt_type):
+    from global_racetrajectory_optimization_amd import engine, harness
+    monkeypatch.setenv("MCQ_LIB", emu_lib)
+    monkeypatch.setattr(engine, "_DEFAULT_ENGINE", None)
+    res = harness.run(REF, opt_type=opt_type, track_name="rounded_rectangle", scratch=str(tmp_path), quiet=True)
+    monkeypatch.setattr(engine, "_DEFAULT_ENGINE", None)
+    assert "INFO: Estimated laptime:" in res["stdout"]
+    assert "Solver runtime opt_min_curv" in res["stdout"]
+    csv = res["outputs"]
+    assert os.path.exists(csv)
+    lines = open(csv).read().splitlines()
+    assert lines[2].replace(" ", "") == "#s_m;x_m;y_m;psi_rad;kappa_radpm;vx_mps;ax_mps2"
+    data = np.loadtxt(csv, comments="#", delimiter=";")
+    assert data.shape[1] == 7 and data.shape[0] > 100
+    assert np.allclose(data[0, 1:3], data[-1, 1:3])          # closed: last row repeats the first point
+    # the alpha the script got from the drop-in equals the golden single-shot solution
+    g = np.load(os.path.join(os.path.dirname(__file__), "golden", "rounded_rectangle.npz"))
+    assert np.max(np.abs(res["globals"]["alpha_opt"] - g["alpha"])) < 1e-8
