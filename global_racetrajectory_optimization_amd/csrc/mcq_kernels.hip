@@ -5,32 +5,36 @@
 
 #define MCQ_NT 256
 #define MCQ_NW (MCQ_NT / 64)
-#define PFB 16                          /* columns fetched per prefetch block of the factorisation */
-#define NSLOT (MCQ_BH_MAX + 2 + PFB)    /* sliding window of columns (b+2 live + one prefetch block) */
-#define LSLOT (MCQ_BH_MAX + 2)          /* row buffer in which finished rows of L are collected */
-#define WLD (MCQ_BH_MAX + 1)
-#define CLD MCQ_P_MAX
+typedef double v4d __attribute__((vector_size(32)));   /* accumulator fragment of v_mfma_f64_16x16x4_f64 */
+#define TB 16                           /* tile edge of the blocked factorisation (v_mfma_f64_16x16x4_f64) */
+#define TLD 17                          /* padded row stride of an LDS tile: conflict-free MFMA operand reads */
+#define TSZ (TB * TLD)
+#define NTR (MCQ_BH_MAX / TB + 1)       /* tile rows / cols of the sliding band window (5) */
+#define NCT (MCQ_P_MAX / TB)            /* tile columns of the border block (4) */
 #define SLD (MCQ_P_MAX + 1)
+#define WLD (MCQ_BH_MAX + 1)
 #define CH 32                           /* rows per chunk of the triangular sweeps */
 #define NBUF 4                          /* chunk ring: 3 resident + 1 being filled */
 #define NRB 8                           /* right-hand-side ring (chunks) */
 
 // ---------------------------------------------------------------------------------------------------------------------
-// shared-memory carve-up of the solver kernel (doubles).  The triangular sweeps overlay the factorisation windows.
+// shared-memory carve-up of the solver kernel (doubles).  The triangular sweeps overlay the factorisation window.
 // ---------------------------------------------------------------------------------------------------------------------
 #define SM_RED 0
 #define SM_XD (SM_RED + 64)
 #define SM_PART (SM_XD + 64)
 #define SM_S (SM_PART + MCQ_NW * 64)
-#define SM_WIN (SM_S + MCQ_P_MAX * SLD)
-#define SM_CW (SM_WIN + NSLOT * WLD)
-#define SM_LRW (SM_CW + NSLOT * CLD)
-#define SM_KS (SM_LRW + LSLOT * WLD)              /* KMAX x KMAX Schur matrix of the active curvature rows */
-#define SM_KV (SM_KS + MCQ_KMAX * MCQ_KMAX)      /* 2 x KMAX: multipliers, right-hand side */
-#define SM_KI (SM_KV + 2 * MCQ_KMAX)             /* ints: nk, row index[KMAX], sign[KMAX] */
+#define SM_OVL (SM_S + MCQ_P_MAX * SLD)          /* overlay region */
+#define OVL_SIZE (NTR * NTR * TSZ + NTR * NCT * TSZ + 32)
+#define SM_BT SM_OVL                              /* band tiles   (NTR x NTR) */
+#define SM_CT (SM_BT + NTR * NTR * TSZ)           /* border tiles (NTR x NCT) */
+#define SM_DINV (SM_CT + NTR * NCT * TSZ)         /* 16 reciprocal pivots of the current diagonal tile + fail flag */
+#define SM_CHUNK SM_OVL                           /* NBUF x CH x WLD */
+#define SM_RHS (SM_CHUNK + NBUF * CH * WLD)       /* NRB x CH */
+#define SM_KS (SM_OVL + OVL_SIZE)                 /* KMAX x KMAX Schur matrix of the active curvature rows */
+#define SM_KV (SM_KS + MCQ_KMAX * MCQ_KMAX)       /* 2 x KMAX: multipliers, right-hand side */
+#define SM_KI (SM_KV + 2 * MCQ_KMAX)              /* ints: nk, row index[KMAX], sign[KMAX] */
 #define SM_TOTAL (SM_KI + MCQ_KMAX + 2)
-#define SM_CHUNK SM_WIN                          /* NBUF x CH x WLD */
-#define SM_RHS (SM_CHUNK + NBUF * CH * WLD)      /* NRB x CH */
 
 size_t mcq_solve_lds_bytes() { return sizeof(double) * SM_TOTAL; }
 
@@ -410,45 +414,88 @@ struct SolveCtx {
 #define TICK() ((long long)wall_clock64())
 
 // ---- bordered-band Cholesky of  M = H + diag(sig)  with rows/cols of pinned variables replaced by identity ----------
-// Right-looking, one column per step, LDS sliding window.  Columns enter the window PFB at a time: the global loads of
-// block k+1 are issued at the first step of block k, stay in flight across the LDS-only barriers of the 16 column steps
-// and are written to LDS at the block's last step, so the HBM latency is paid once per PFB columns and overlapped.
+// Blocked right-looking factorisation, 16 columns per step, on an LDS window of 5 x 5 band tiles + 5 x 4 border tiles:
+//   phase 1  wave 0 factors the 16x16 diagonal tile in registers (left-looking, v_readlane broadcasts, no LDS trips);
+//   phase 2  128 lanes do the 16-step triangular solves of the panel: 64 rows of L below the diagonal tile and the 64
+//            columns of the border block row  W = L00^-1 C;
+//   phase 3  rank-16 trailing update on the fp64 matrix cores (v_mfma_f64_16x16x4_f64): 10 band tiles and 16 border
+//            tiles in LDS, the 16 tiles of the Schur complement S -= W'W in registers;  L / W rows go to HBM as
+//            128-byte segments, the next tile row (16 x 144 doubles) is fetched one step ahead through registers and
+//            stays in flight across the LDS-only barriers.
 // Output: L rows in w.L (row i: [0] = 1/L_ii, [k] = L[i,i-k]; [HBO+jj] = W[i][jj]); L_S (p x p, lower) in LDS SM_S.
 // Returns 0 or MCQ_NOT_PD (uniform across the block).
-#define PF_ITEMS ((PFB * (WLD + CLD) + MCQ_NT - 1) / MCQ_NT)
+#define BTILE(I, K) (bt + ((((I) % NTR) * NTR) + ((K) % NTR)) * TSZ)
+#define CTILE(I, a) (ct + ((((I) % NTR) * NCT) + (a)) * TSZ)
+#define ROW_ITEMS (TB * (NTR * TB + MCQ_P_MAX))            /* 16 x 144 doubles per tile row */
+#define PF_ITEMS ((ROW_ITEMS + MCQ_NT - 1) / MCQ_NT)
 
-// element e of the (WLD + CLD)-wide "extended column" cc:  e < WLD -> band entry k = e, else border entry jj = e - WLD.
-// Branch-free: every load is issued unconditionally at a clamped (always valid) address, validity / pinning are selects.
+// entry M[i][c] of the (identity-padded) interior matrix, i >= c; branch-free, loads at clamped addresses
 template <bool MK, bool SIG>
-__device__ __forceinline__ double ext_col_load(const gdouble* H, const gdouble* sig, const gschar* mk, int ni, int b,
-                                               int p, int cc, int e)
+__device__ __forceinline__ double m_entry(const gdouble* H, const gdouble* sig, const gschar* mk, int ni, int b, int i, int c)
 {
-    const bool cin = cc < ni;
-    const int ccs = cin ? cc : 0;
-    const bool band = e < WLD;
-    const int jj = e - WLD;
-    const int off = band ? e : MCQ_HBO + jj;
-    const int r = band ? cc + e : ni + jj;
-    const bool valid = cin && (band ? (e <= b && r < ni) : (jj < p));
-    const int rs = valid ? r : 0;
-    double v = H[(size_t)ccs * MCQ_HLD + off];
+    const bool in = (i < ni) & (c < ni) & (c >= 0);
+    const int k = i - c;
+    const bool valid = in & (k >= 0) & (k <= b);
+    const int cs = in ? c : 0, is = in ? i : 0;
+    double v = H[(size_t)cs * MCQ_HLD + (valid ? k : 0)];
     v = valid ? v : 0.0;
     bool pinned = false;
     if (MK) {
-        pinned = (mk[ccs] != 0) | (mk[rs] != 0);
-        v = pinned ? ((e == 0 && valid) ? 1.0 : 0.0) : v;
+        pinned = (mk[cs] != 0) | (mk[is] != 0);
+        v = pinned ? (k == 0 ? 1.0 : 0.0) : v;
     }
     if (SIG) {
-        const double sg = sig[ccs];
-        v += (e == 0 && valid && !pinned) ? sg : 0.0;
+        const double sg = sig[cs];
+        v += (k == 0 && !pinned) ? sg : 0.0;
     }
-    return v;
+    return in ? v : ((k == 0) ? 1.0 : 0.0);
 }
 
-__device__ __forceinline__ void ext_col_store(double* win, double* cwn, int cc, int e, double v)
+template <bool MK>
+__device__ __forceinline__ double c_entry(const gdouble* H, const gschar* mk, int ni, int p, int i, int jj)
 {
-    if (e < WLD) win[(cc % NSLOT) * WLD + e] = v;
-    else cwn[(cc % NSLOT) * CLD + (e - WLD)] = v;
+    const bool in = (i < ni) & (jj < p);
+    const int is = in ? i : 0, js = in ? jj : 0;
+    double v = H[(size_t)is * MCQ_HLD + MCQ_HBO + js];
+    if (MK) v = ((mk[is] != 0) | (mk[ni + js] != 0)) ? 0.0 : v;
+    return in ? v : 0.0;
+}
+
+// item q of tile row R: q < 16*80 -> band part, column-major inside the tile row (16 consecutive rows of one column
+// are 16 contiguous doubles of H); else border part, row-major (64 contiguous doubles of one H row)
+template <bool MK, bool SIG>
+__device__ __forceinline__ double tile_row_load(const gdouble* H, const gdouble* sig, const gschar* mk, int ni, int b, int p,
+                                                int R, int q)
+{
+    if (q < TB * NTR * TB) {
+        const int e = q / TB, rr = q - e * TB;
+        const int K = R - (NTR - 1) + e / TB, cc = e % TB;
+        return m_entry<MK, SIG>(H, sig, mk, ni, b, R * TB + rr, K * TB + cc);
+    }
+    const int q2 = q - TB * NTR * TB;
+    const int rr = q2 / MCQ_P_MAX, jj = q2 - rr * MCQ_P_MAX;
+    return c_entry<MK>(H, mk, ni, p, R * TB + rr, jj);
+}
+
+__device__ __forceinline__ void tile_row_store(double* bt, double* ct, int R, int q, double v)
+{
+    if (q < TB * NTR * TB) {
+        const int e = q / TB, rr = q - e * TB;
+        const int K = R - (NTR - 1) + e / TB, cc = e % TB;
+        if (K >= 0) BTILE(R, K)[rr * TLD + cc] = v;
+    } else if (q < ROW_ITEMS) {
+        const int q2 = q - TB * NTR * TB;
+        const int rr = q2 / MCQ_P_MAX, jj = q2 - rr * MCQ_P_MAX;
+        CTILE(R, jj / TB)[rr * TLD + (jj % TB)] = v;
+    }
+}
+
+// D(16x16) += A(16x16) B(16x16) as four K=4 matrix-core steps; a[kc], b[kc] are the per-lane operand values
+__device__ __forceinline__ v4d mfma16(const double a[4], const double b[4], v4d acc)
+{
+#pragma unroll
+    for (int kc = 0; kc < 4; ++kc) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a[kc], b[kc], acc, 0, 0, 0);
+    return acc;
 }
 
 template <bool MK, bool SIG>
@@ -456,124 +503,175 @@ __device__ __forceinline__ int factor_t(const SolveCtx& c, const gdouble* Hsrc, 
 {
     const int tid = threadIdx.x;
     const int b = c.d.b, p = c.d.p, ni = c.d.ni;
-    double* win = g_sm + SM_WIN;
-    double* cwn = g_sm + SM_CW;
-    double* lrw = g_sm + SM_LRW;
+    double* bt = g_sm + SM_BT;
+    double* ct = g_sm + SM_CT;
+    double* dinv = g_sm + SM_DINV;
     double* Sm = g_sm + SM_S;
-    const gdouble* H = Hsrc;   // c.w.H, or the L slab itself (in place: column cc is read before L row cc is written)
+    const gdouble* H = Hsrc;
     gdouble* L = c.w.L;
-    const int EXT = WLD + CLD;
     const int lane = tid & 63, w0 = tid >> 6;
+    const int l15 = lane & 15, l4 = lane >> 4;
+    const int nblk = (ni + TB - 1) / TB;
 
-    double sacc[16];
+    v4d sacc[NCT];
 #pragma unroll
-    for (int m = 0; m < 16; ++m) sacc[m] = 0.0;
+    for (int m = 0; m < NCT; ++m) sacc[m] = (v4d){0.0, 0.0, 0.0, 0.0};
     double pf[PF_ITEMS];
 
     __syncthreads();
-    for (int q = tid; q < LSLOT * WLD; q += MCQ_NT) lrw[q] = 0.0;
-    // prologue: columns 0 .. b + PFB (everything steps 0..PFB-1 touch); columns >= ni load as zero
-    {
-        const int npre = MCQ_BH_MAX + 1 + PFB;
-        for (int q = tid; q < npre * EXT; q += MCQ_NT) {
-            const int cc = q / EXT, e = q - cc * EXT;
-            ext_col_store(win, cwn, cc, e, ext_col_load<MK, SIG>(H, sig, mk, ni, b, p, cc, e));
-        }
-    }
+    // prologue: tile rows 0 .. NTR-1
+    for (int R = 0; R < NTR; ++R)
+        for (int q = tid; q < ROW_ITEMS; q += MCQ_NT)
+            tile_row_store(bt, ct, R, q, tile_row_load<MK, SIG>(H, sig, mk, ni, b, p, R, q));
+    if (tid == 0) dinv[TB] = 0.0;   // fail flag
     __syncthreads();
 
-    // Every step updates the full MCQ_BH_MAX-wide window with fixed trip counts and no predicates: entries that do not
-    // exist (rows >= ni, offsets beyond the band b) were loaded as exact zeros, so their updates are no-ops.
     int fail = 0;
-    for (int i = 0; i < ni; ++i) {
-        const int slot = i % NSLOT;
-        const double* ci = win + slot * WLD;
-        const double* cwi = cwn + slot * CLD;
-        const int ib = i % PFB;
-        const int cblk = i - ib + MCQ_BH_MAX + 1 + PFB;   // first column of the block fetched during this block of steps
-        if (ib == 0) {
+    for (int J = 0; J < nblk; ++J) {
+        // prefetch tile row J + NTR (stays in flight until the end of this step)
 #pragma unroll
-            for (int u = 0; u < PF_ITEMS; ++u) {
-                const int q = tid + u * MCQ_NT;
-                const int qq = q < PFB * EXT ? q : 0;
-                pf[u] = ext_col_load<MK, SIG>(H, sig, mk, ni, b, p, cblk + qq / EXT, qq % EXT);
+        for (int u = 0; u < PF_ITEMS; ++u) {
+            const int q = tid + u * MCQ_NT;
+            pf[u] = tile_row_load<MK, SIG>(H, sig, mk, ni, b, p, J + NTR, q < ROW_ITEMS ? q : 0);
+        }
+        // ---- phase 1: diagonal tile, wave 0; lane r (= lane & 15) keeps row r in 16 registers -------------------------
+        if (w0 == 0) {
+            double* d0 = BTILE(J, J);
+            double a[TB];
+#pragma unroll
+            for (int cc = 0; cc < TB; ++cc) a[cc] = d0[l15 * TLD + cc];
+            bool bad = false;
+#pragma unroll
+            for (int j = 0; j < TB; ++j) {
+#pragma unroll
+                for (int k = 0; k < j; ++k) a[j] -= a[k] * bcast_lane(a[k], j);
+                const double piv = bcast_lane(a[j], j);
+                bad |= !(piv > 0.0);
+                const double rs = rsqrt(piv);
+                a[j] = (l15 == j) ? piv * rs : a[j] * rs;
+                if (lane == j) dinv[j] = rs;
+            }
+            if (lane < TB) {
+#pragma unroll
+                for (int cc = 0; cc < TB; ++cc) d0[lane * TLD + cc] = (cc <= lane) ? a[cc] : 0.0;
+            }
+            if (bad && lane == 0) dinv[TB] = 1.0;
+        }
+        lds_barrier();
+        if (dinv[TB] != 0.0) { fail = 1; break; }
+        // ---- phase 2: panel.  lanes 0..63: rows of L below the diagonal tile; lanes 64..127: columns of W = L00^-1 C ----
+        if (tid < 128) {
+            const double* d0 = BTILE(J, J);
+            double* base;
+            int stride;
+            if (tid < 64) { base = BTILE(J + 1 + tid / TB, J) + (tid % TB) * TLD; stride = 1; }
+            else { const int jj = tid - 64; base = CTILE(J, jj / TB) + (jj % TB); stride = TLD; }
+            double x[TB];
+#pragma unroll
+            for (int cc = 0; cc < TB; ++cc) x[cc] = base[cc * stride];
+#pragma unroll
+            for (int cc = 0; cc < TB; ++cc) {
+                x[cc] *= dinv[cc];
+#pragma unroll
+                for (int c2 = cc + 1; c2 < TB; ++c2) x[c2] -= x[cc] * d0[c2 * TLD + cc];
+            }
+#pragma unroll
+            for (int cc = 0; cc < TB; ++cc) base[cc * stride] = x[cc];
+        }
+        lds_barrier();
+        // ---- emit block column J of L and block row J of W to HBM ----------------------------------------------------------
+        for (int q = tid; q < NTR * TB * TB; q += MCQ_NT) {
+            const int tI = q / (TB * TB), rem = q - tI * TB * TB;
+            const int rr = rem / TB, cc = rem - rr * TB;
+            const int i = (J + tI) * TB + rr;
+            const int k = tI * TB + rr - cc;
+            if (i < ni && k >= 0 && k <= MCQ_BH_MAX) {
+                const double v = BTILE(J + tI, J)[rr * TLD + cc];
+                L[(size_t)i * MCQ_HLD + k] = (k == 0) ? dinv[rr] : v;
             }
         }
-        const double piv = ci[0];
-        if (!(piv > 0.0)) { fail = 1; break; }   // uniform: every thread reads the same LDS word
-        const double rinv = 1.0 / piv;
-        const double rs = rsqrt(piv);
-
-        // (a) band part of the trailing update: M[r,c] -= a_r a_c / piv,  i < c <= r <= i + 64
+        for (int q = tid; q < TB * MCQ_P_MAX; q += MCQ_NT) {
+            const int rr = q / MCQ_P_MAX, jj = q - rr * MCQ_P_MAX;
+            const int i = J * TB + rr;
+            if (i < ni) L[(size_t)i * MCQ_HLD + MCQ_HBO + jj] = CTILE(J, jj / TB)[rr * TLD + (jj % TB)];
+        }
+        // ---- phase 3: rank-16 trailing update on the matrix cores ----------------------------------------------------------
         {
-            const int dc = 1 + lane;
-            double* colc = win + ((i + dc) % NSLOT) * WLD;
-            const double ac = ci[dc] * rinv;
-            double cv[16], av[16];
+            // operands of this wave's border column a = w0:  W_blk tile a in "direct" form  B[k][j] = W[k][16a + j]
+            const double* wa = CTILE(J, w0);
+            double wdir[4], wneg[4];
 #pragma unroll
-            for (int m = 0; m < 16; ++m) {
-                const int dr = dc + w0 + MCQ_NW * m;            // rows beyond i+64 get a_r = 0
-                const int drs = dr <= MCQ_BH_MAX ? dr : 0;
-                cv[m] = colc[w0 + MCQ_NW * m];
-                const double a = ci[drs];
-                av[m] = dr <= MCQ_BH_MAX ? a : 0.0;
+            for (int kc = 0; kc < 4; ++kc) { wdir[kc] = wa[(l4 + 4 * kc) * TLD + l15]; wneg[kc] = -wdir[kc]; }
+            // (c) Schur tiles  S[a][bb] -= W_a' W_bb
+#pragma unroll
+            for (int bb = 0; bb < NCT; ++bb) {
+                const double* wb = CTILE(J, bb);
+                double bv[4];
+#pragma unroll
+                for (int kc = 0; kc < 4; ++kc) bv[kc] = wb[(l4 + 4 * kc) * TLD + l15];
+                sacc[bb] = mfma16(wneg, bv, sacc[bb]);
             }
+            // (b) border tiles  C(I, a) -= L(I,J) W_a
 #pragma unroll
-            for (int m = 0; m < 16; ++m) colc[w0 + MCQ_NW * m] = cv[m] - av[m] * ac;
-        }
-        // (b) border coupling rows:  C[r][jj] -= a_r cw_i[jj] / piv,  r = i + 1 .. i + 64
-        {
-            const double cj = cwi[lane] * rinv;
-            double cv[16], av[16];
+            for (int dI = 1; dI < NTR; ++dI) {
+                const double* li = BTILE(J + dI, J);
+                double* ctile = CTILE(J + dI, w0);
+                double av[4];
 #pragma unroll
-            for (int m = 0; m < 16; ++m) {
-                const int dr = 1 + w0 + MCQ_NW * m;
-                cv[m] = cwn[((i + dr) % NSLOT) * CLD + lane];
-                av[m] = ci[dr];
+                for (int kc = 0; kc < 4; ++kc) av[kc] = -li[l15 * TLD + l4 + 4 * kc];
+                v4d acc;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) acc[r] = ctile[(l4 + 4 * r) * TLD + l15];
+                acc = mfma16(av, wdir, acc);
+#pragma unroll
+                for (int r = 0; r < 4; ++r) ctile[(l4 + 4 * r) * TLD + l15] = acc[r];
             }
+            // (a) band tiles  T(I,K) -= L(I,J) L(K,J)',  J < K <= I <= J+4: ten tiles dealt round-robin to the waves
+            int t = 0;
 #pragma unroll
-            for (int m = 0; m < 16; ++m) {
-                const int dr = 1 + w0 + MCQ_NW * m;
-                cwn[((i + dr) % NSLOT) * CLD + lane] = cv[m] - av[m] * cj;
-            }
-        }
-        // (c) Schur complement accumulators  S[j1][j2] -= cw_i[j1] cw_i[j2] / piv   (j2 = lane, j1 = wave + 4 m)
-        {
-            const double cj = cwi[lane] * rinv;
+            for (int dK = 1; dK < NTR; ++dK) {
 #pragma unroll
-            for (int m = 0; m < 16; ++m) sacc[m] -= cwi[w0 + MCQ_NW * m] * cj;
-        }
-        // (d) emit column i of L into the row buffer (threads 0..64), W row to global (wave 1), flush the finished row
-        //     i-1 (threads 128..192)
-        if (tid <= MCQ_BH_MAX) lrw[((i + tid) % LSLOT) * WLD + tid] = (tid == 0) ? rs : ci[tid] * rs;
-        if (w0 == 1) L[(size_t)i * MCQ_HLD + MCQ_HBO + lane] = cwi[lane] * rs;
-        if (tid >= 128 && tid <= 128 + MCQ_BH_MAX && i > 0)
-            L[(size_t)(i - 1) * MCQ_HLD + (tid - 128)] = lrw[((i - 1) % LSLOT) * WLD + (tid - 128)];
-        // (e) last step of the block: the prefetched block goes into the slots that were freed during this block
-        if (ib == PFB - 1) {
+                for (int dI = dK; dI < NTR; ++dI, ++t) {
+                    if ((t & (MCQ_NW - 1)) != w0) continue;
+                    const double* li = BTILE(J + dI, J);
+                    const double* lk = BTILE(J + dK, J);
+                    double* tt = BTILE(J + dI, J + dK);
+                    double av[4], bv[4];
 #pragma unroll
-            for (int u = 0; u < PF_ITEMS; ++u) {
-                const int q = tid + u * MCQ_NT;
-                if (q < PFB * EXT) ext_col_store(win, cwn, cblk + q / EXT, q % EXT, pf[u]);
+                    for (int kc = 0; kc < 4; ++kc) {
+                        av[kc] = -li[l15 * TLD + l4 + 4 * kc];
+                        bv[kc] = lk[l15 * TLD + l4 + 4 * kc];
+                    }
+                    v4d acc;
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) acc[r] = tt[(l4 + 4 * r) * TLD + l15];
+                    acc = mfma16(av, bv, acc);
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) tt[(l4 + 4 * r) * TLD + l15] = acc[r];
+                }
             }
         }
         lds_barrier();
+        // ---- the prefetched tile row takes the slots of tile row J (dead now) ------------------------------------------------
+#pragma unroll
+        for (int u = 0; u < PF_ITEMS; ++u) tile_row_store(bt, ct, J + NTR, tid + u * MCQ_NT, pf[u]);
+        lds_barrier();
     }
     if (fail) return MCQ_NOT_PD;
-    for (int k = tid; k <= b; k += MCQ_NT) L[(size_t)(ni - 1) * MCQ_HLD + k] = lrw[((ni - 1) % LSLOT) * WLD + k];
 
-    // ---- Schur complement of the border: S = D - W'W, dense Cholesky in LDS -------------------------------------------
-    {
-        const int j2 = tid & 63;
+    // ---- Schur complement of the border: S = D - W'W (accumulated above), dense Cholesky in LDS -----------------------
+    __syncthreads();
 #pragma unroll
-        for (int m = 0; m < 16; ++m) {
-            const int j1 = (tid >> 6) + MCQ_NW * m;
+    for (int bb = 0; bb < NCT; ++bb) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int j1 = TB * w0 + l4 + 4 * r, j2 = TB * bb + l15;
             double v = 0.0;
             if (j1 < p && j2 < p) {
                 const bool pj = MK && (mk[ni + j1] != 0 || mk[ni + j2] != 0);
                 if (pj) v = (j1 == j2) ? 1.0 : 0.0;
                 else {
-                    v = H[(size_t)(ni + j1) * MCQ_HLD + MCQ_HBO + j2] + sacc[m];
+                    v = H[(size_t)(ni + j1) * MCQ_HLD + MCQ_HBO + j2] + sacc[bb][r];
                     if (SIG && j1 == j2) v += sig[ni + j1];
                 }
             }
@@ -930,10 +1028,12 @@ __device__ __noinline__ int ipm(SolveCtx& c, const McqBatch& B, bool with_kappa,
         // ---- factorisation of the reduced system ---------------------------------------------------------------------
         int fs;
         if (with_kappa) {
+            // H slab <- E' (I + diag(SK)) E = H + E' diag(SK) E   (H = E'E is rebuilt by the caller after this phase)
+            for (int i = tid; i < n; i += MCQ_NT) EDA[i] = 1.0 + SK[i];
             __syncthreads();
-            gram_bordered(c.w.Et, SK, c.d, nm, c.w.H, c.w.L, tid, MCQ_NT);   // L slab <- H + E' diag(SK) E
+            gram_bordered(c.w.Et, EDA, c.d, nm, nullptr, c.w.H, tid, MCQ_NT);
             __syncthreads();
-            fs = timed_factor(c, c.w.L, SIG, ST);                            // in place
+            fs = timed_factor(c, c.w.H, SIG, ST);
         } else {
             fs = timed_factor(c, c.w.H, SIG, ST);
         }
@@ -1369,6 +1469,9 @@ __global__ void __launch_bounds__(MCQ_NT) mcq_solve_kernel(McqBatch B)
     if (status == MCQ_OK && B.check_kappa && km > kbound * (1.0 + 1e-9)) {
         status = ipm(c, B, true, sc, it2);
         ipm_iters += it2;
+        __syncthreads();
+        gram_bordered(c.w.Et, nullptr, c.d, nm, nullptr, c.w.H, tid, MCQ_NT);     // restore H = E'E
+        __syncthreads();
         if (status == MCQ_OK) {
             status = active_set(c, B, true, sc, it2, kkt, nact_kappa);
             as_iters += it2;

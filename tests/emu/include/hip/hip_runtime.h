@@ -59,7 +59,7 @@ struct State {
     unsigned bar_gen = 0;
     std::vector<int> wbar_count;
     std::vector<unsigned> wbar_gen;
-    std::vector<double> slot_d;
+    std::vector<double> slot_d, slot_e;
     std::vector<long long> slot_i;
     std::vector<char> dyn_smem;
     std::function<void()> body;
@@ -121,6 +121,7 @@ inline void run_block(F&& f, unsigned nt, size_t smem)
     s.wbar_count.assign((nt + 63) / 64, 0);
     s.wbar_gen.assign((nt + 63) / 64, 0);
     s.slot_d.assign(nt, 0.0);
+    s.slot_e.assign(nt, 0.0);
     s.slot_i.assign(nt, 0);
     if (s.dyn_smem.size() < smem + 64) s.dyn_smem.resize(smem + 64);
     s.body = f;
@@ -187,6 +188,27 @@ inline double __shfl_xor(double v, int m)
 inline int __shfl(int v, int src) { return (int)__shfl((double)v, src); }
 
 inline long long wall_clock64() { return (long long)(hipemu_now() * 1e5); }
+
+// v_mfma_f64_16x16x4_f64: D(16x16) = A(16x4) B(4x16) + C.  Lane l holds A[l&15][l>>4], B[l>>4][l&15]; C/D register r of lane l
+// is element (row (l>>4) + 4r, col l&15)   (/opt/skills/guides/cdna_hip_programming.md, section 3, f64 layout).
+typedef double hipemu_v4d __attribute__((vector_size(32)));
+inline hipemu_v4d hipemu_mfma_f64_16x16x4(double a, double b, hipemu_v4d c)
+{
+    hipemu::State& s = hipemu::st();
+    const int t = s.cur, base = t & ~63, l = t & 63;
+    s.slot_d[t] = a;
+    s.slot_e[t] = b;
+    hipemu::wave_barrier();
+    for (int r = 0; r < 4; ++r) {
+        const int row = (l >> 4) + 4 * r, col = l & 15;
+        double acc = 0.0;
+        for (int k = 0; k < 4; ++k) acc += s.slot_d[base + row + 16 * k] * s.slot_e[base + col + 16 * k];
+        c[r] += acc;
+    }
+    hipemu::wave_barrier();
+    return c;
+}
+#define __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, c, x, y, z) hipemu_mfma_f64_16x16x4((a), (b), (c))
 
 // AMDGCN builtins used by the kernels
 inline int hipemu_readlane(int v, int src) { return (int)__shfl((double)v, src); }
