@@ -766,7 +766,7 @@ __device__ __noinline__ void solve(const SolveCtx& c, gdouble* v)
 
     __syncthreads();
     // ================= forward substitution, interior rows =================
-    // prologue: chunks 0,1,2 (rows + rhs) resident, chunk 3 staged in registers
+    // prologue: chunks 0,1,2 (rows + rhs) resident, chunk 3 staged in registers.  Rows >= ni load as zeros (harmless).
     if (wv > 0) {
         for (int q = 0; q < 3; ++q) {
             chunk_fetch(L, v, ni, b, q, q, lt, regs);
@@ -779,19 +779,31 @@ __device__ __noinline__ void solve(const SolveCtx& c, gdouble* v)
         double acc = (wv == 0 && lane < ni) ? RHSV(lane) : 0.0;     // lane l owns row l first
         for (int cq = 0; cq < nch; ++cq) {
             if (wv == 0) {
-                const int i1 = (cq + 1) * CH < ni ? (cq + 1) * CH : ni;
-                for (int i = cq * CH; i < i1; ++i) {
-                    const int owner = i & 63;
-                    const double yi = bcast_lane(acc, owner) * LROW(i)[0];
-                    if (lane == owner) {
-                        v[i] = yi;
-                        acc = (i + 64 < ni) ? RHSV(i + 64) : 0.0;
+                double ysave = 0.0;
+                for (int i0 = cq * CH; i0 < (cq + 1) * CH; i0 += 4) {
+                    double dg[4], lv[4], nr[4];
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) {       // all LDS reads of four rows before the dependent chain
+                        const int i = i0 + u;
+                        const int k = ((lane - i - 1) & 63) + 1;
+                        dg[u] = LROW(i)[0];
+                        const double t = LROW(i + k)[k <= b ? k : 0];
+                        lv[u] = k <= b ? t : 0.0;
+                        nr[u] = RHSV(i + 64);
                     }
-                    const int k = ((lane - i - 1) & 63) + 1;
-                    const int j = i + k;
-                    const double lv = (j < ni && k <= b) ? LROW(j)[k] : 0.0;
-                    acc -= lv * yi;
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) {
+                        const int owner = (i0 + u) & 63;
+                        const double yi = bcast_lane(acc, owner) * dg[u];
+                        const bool own = lane == owner;
+                        ysave = own ? yi : ysave;
+                        acc = own ? nr[u] : acc;
+                        acc -= lv[u] * yi;
+                    }
                 }
+                // the 32 unknowns of this chunk sit in lanes (cq*32 .. cq*32+31) & 63: one coalesced store
+                const int li = cq * CH + ((lane - cq * CH) & 63);
+                if (((lane - cq * CH) & 63) < CH && li < ni) v[li] = ysave;
             } else {
                 chunk_commit(chunk, rring, cq + 3, cq + 3, lt, regs);
                 chunk_fetch(L, v, ni, b, cq + 4, cq + 4, lt, regs);
@@ -805,12 +817,15 @@ __device__ __noinline__ void solve(const SolveCtx& c, gdouble* v)
         double acc = 0.0;
         if (lane < p) {
             int i = wv;
-            for (; i + 3 * MCQ_NW < ni; i += 4 * MCQ_NW) {
-                const double w0 = L[(size_t)i * MCQ_HLD + MCQ_HBO + lane], y0 = v[i];
-                const double w1 = L[(size_t)(i + MCQ_NW) * MCQ_HLD + MCQ_HBO + lane], y1 = v[i + MCQ_NW];
-                const double w2 = L[(size_t)(i + 2 * MCQ_NW) * MCQ_HLD + MCQ_HBO + lane], y2 = v[i + 2 * MCQ_NW];
-                const double w3 = L[(size_t)(i + 3 * MCQ_NW) * MCQ_HLD + MCQ_HBO + lane], y3 = v[i + 3 * MCQ_NW];
-                acc += w0 * y0 + w1 * y1 + w2 * y2 + w3 * y3;
+            for (; i + 15 * MCQ_NW < ni; i += 16 * MCQ_NW) {
+                double wr[16], yr[16];
+#pragma unroll
+                for (int u = 0; u < 16; ++u) {
+                    wr[u] = L[(size_t)(i + u * MCQ_NW) * MCQ_HLD + MCQ_HBO + lane];
+                    yr[u] = v[i + u * MCQ_NW];
+                }
+#pragma unroll
+                for (int u = 0; u < 16; ++u) acc += wr[u] * yr[u];
             }
             for (; i < ni; i += MCQ_NW) acc += L[(size_t)i * MCQ_HLD + MCQ_HBO + lane] * v[i];
         }
@@ -837,24 +852,18 @@ __device__ __noinline__ void solve(const SolveCtx& c, gdouble* v)
         xd[lane] = lane < p ? t : 0.0;
     }
     __syncthreads();
-    // y_B -= W x_D   (one wave per row, MV_RU rows in flight)
-    for (int i0 = wv * MV_RU; i0 < ni; i0 += MCQ_NW * MV_RU) {
-        double a8[MV_RU];
-#pragma unroll
-        for (int u = 0; u < MV_RU; ++u) {
-            const int i = i0 + u;
-            a8[u] = (i < ni && lane < p) ? L[(size_t)i * MCQ_HLD + MCQ_HBO + lane] * xd[lane] : 0.0;
+    // y_B -= W x_D   (thread per row, 16-byte loads of the W row; x_D broadcast from LDS)
+    for (int i = tid; i < ni; i += MCQ_NT) {
+        typedef double d2 __attribute__((vector_size(16)));
+        const __attribute__((address_space(1))) d2* wr = (const __attribute__((address_space(1))) d2*)(L + (size_t)i * MCQ_HLD + MCQ_HBO);
+        double s0 = 0.0, s1 = 0.0;
+#pragma unroll 8
+        for (int q = 0; q < MCQ_P_MAX / 2; ++q) {
+            const d2 w2 = wr[q];
+            s0 += w2[0] * xd[2 * q];
+            s1 += w2[1] * xd[2 * q + 1];
         }
-#pragma unroll
-        for (int m = 32; m >= 1; m >>= 1) {
-#pragma unroll
-            for (int u = 0; u < MV_RU; ++u) a8[u] += __shfl_xor(a8[u], m);
-        }
-#pragma unroll
-        for (int u = 0; u < MV_RU; ++u) {
-            const int i = i0 + u;
-            if (i < ni && lane == 0) v[i] -= a8[u];
-        }
+        v[i] -= s0 + s1;
     }
     __syncthreads();
     // ================= backward substitution, interior rows (descending) =================
@@ -871,24 +880,40 @@ __device__ __noinline__ void solve(const SolveCtx& c, gdouble* v)
             chunk_fetch(L, v, ni, b, cl - 1, cl - 3, lt, regs);
         }
         __syncthreads();
-        // lane l first owns the largest row j <= ni-1 with j == l (mod 64)
-        const int j0 = ni - 1 - ((ni - 1 - lane) & 63);
+        // lane l first owns the largest row j <= nch*CH-1 with j == l (mod 64)  (rows >= ni are zero rows: x = 0)
+        const int top = nch * CH - 1;
+        const int j0 = top - ((top - lane) & 63);
         double acc = (wv == 0 && j0 >= 0) ? RHSV(j0) : 0.0;
         for (int cq = cl; cq >= 0; --cq) {
             if (wv == 0) {
-                const int i1 = (cq + 1) * CH < ni ? (cq + 1) * CH : ni;
-                for (int i = i1 - 1; i >= cq * CH; --i) {
-                    const int owner = i & 63;
-                    const double* lr = LROW(i);
-                    const double xi = bcast_lane(acc, owner) * lr[0];
-                    if (lane == owner) {
-                        v[i] = xi;
-                        acc = (i - 64 >= 0) ? RHSV(i - 64) : 0.0;
+                double xsave = 0.0;
+                for (int i0 = (cq + 1) * CH - 1; i0 >= cq * CH; i0 -= 4) {
+                    double dg[4], lv[4], nr[4];
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) {
+                        const int i = i0 - u;
+                        const double* lr = LROW(i);
+                        const int k = ((i - 1 - lane) & 63) + 1;
+                        const bool ok = (k <= b) & (k <= i);
+                        dg[u] = lr[0];
+                        const double t = lr[ok ? k : 0];
+                        lv[u] = ok ? t : 0.0;
+                        const int jn = i - 64;
+                        const double r = RHSV(jn >= 0 ? jn : 0);
+                        nr[u] = jn >= 0 ? r : 0.0;
                     }
-                    const int k = ((i - 1 - lane) & 63) + 1;
-                    const double lv = (k <= b && i - k >= 0) ? lr[k] : 0.0;
-                    acc -= lv * xi;
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) {
+                        const int owner = (i0 - u) & 63;
+                        const double xi = bcast_lane(acc, owner) * dg[u];
+                        const bool own = lane == owner;
+                        xsave = own ? xi : xsave;
+                        acc = own ? nr[u] : acc;
+                        acc -= lv[u] * xi;
+                    }
                 }
+                const int li = cq * CH + ((lane - cq * CH) & 63);
+                if (((lane - cq * CH) & 63) < CH && li < ni) v[li] = xsave;
             } else {
                 chunk_commit(chunk, rring, cq - 1, cq - 3, lt, regs);
                 chunk_fetch(L, v, ni, b, cq - 2, cq - 4, lt, regs);
