@@ -25,7 +25,7 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
 INFO_DTYPE = np.dtype([("ipm_iters", "<i4"), ("as_iters", "<i4"), ("n_active_box", "<i4"), ("n_active_kappa", "<i4"),
-                       ("kappa_max", "<f8"), ("kkt_res", "<f8"), ("ticks", "<i8", (4,))])
+                       ("kappa_max", "<f8"), ("kkt_res", "<f8"), ("ticks", "<i8", (8,))])
 HBM_PEAK_GBS = 8000.0        # MI355X HBM3E spec peak, /opt/skills/guides/MI355X_MICROARCH.md
 KAPPA_BOUND, W_VEH = 0.12, 3.4
 
@@ -160,7 +160,7 @@ def main():
                        "kernel_ms": {k: float(np.mean([m[k] for m in solve_ms])) for k in ("assemble", "gram", "solve", "total")},
                        "workspace_GB": eng.workspace_bytes() / 1e9,
                        "solver_phase_ms_per_problem": {k: float(info["ticks"][:, j].mean()) / 1e5 for j, k in
-                                                       enumerate(("factor", "solve", "gradient", "kernel"))}},
+                                                       enumerate(("factor", "solve", "gradient", "kernel", "f_diag", "f_panel", "f_emit", "f_trail"))}},
             "roofline": {"bound": "hbm", "kernel": "mcq_solve_kernel", "achieved": achieved, "peak": HBM_PEAK_GBS,
                          "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": None,
                          "algorithmic_bytes_per_launch": alg, "kernel_ms": k_ms},

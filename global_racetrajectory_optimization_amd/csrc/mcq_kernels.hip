@@ -215,7 +215,7 @@ __global__ void __launch_bounds__(MCQ_NT) mcq_assemble_kernel(McqBatch B)
             z.ipm_iters = z.as_iters = z.n_active_box = z.n_active_kappa = 0;
             z.kappa_max = 0.0;
             z.kkt_res = 0.0;
-            z.ticks[0] = z.ticks[1] = z.ticks[2] = z.ticks[3] = 0;
+            for (int q = 0; q < 8; ++q) z.ticks[q] = 0;
             *(mcq_info*)w.info = z;
         }
     }
@@ -409,7 +409,7 @@ struct SolveCtx {
     McqDims d;
     McqWork w;
     int nm;
-    long long tk[4];   // phase timers (wall_clock64 ticks), meaningful on thread 0
+    mutable long long tk[8];   // phase timers (wall_clock64 ticks), meaningful on thread 0
 };
 #define TICK() ((long long)wall_clock64())
 
@@ -429,52 +429,68 @@ struct SolveCtx {
 #define ROW_ITEMS (TB * (NTR * TB + MCQ_P_MAX))            /* 16 x 144 doubles per tile row */
 #define PF_ITEMS ((ROW_ITEMS + MCQ_NT - 1) / MCQ_NT)
 
-// entry M[i][c] of the (identity-padded) interior matrix, i >= c; branch-free, loads at clamped addresses
-template <bool MK, bool SIG>
-__device__ __forceinline__ double m_entry(const gdouble* H, const gdouble* sig, const gschar* mk, int ni, int b, int i, int c)
-{
-    const bool in = (i < ni) & (c < ni) & (c >= 0);
-    const int k = i - c;
-    const bool valid = in & (k >= 0) & (k <= b);
-    const int cs = in ? c : 0, is = in ? i : 0;
-    double v = H[(size_t)cs * MCQ_HLD + (valid ? k : 0)];
-    v = valid ? v : 0.0;
-    bool pinned = false;
-    if (MK) {
-        pinned = (mk[cs] != 0) | (mk[is] != 0);
-        v = pinned ? (k == 0 ? 1.0 : 0.0) : v;
-    }
-    if (SIG) {
-        const double sg = sig[cs];
-        v += (k == 0 && !pinned) ? sg : 0.0;
-    }
-    return in ? v : ((k == 0) ? 1.0 : 0.0);
-}
-
-template <bool MK>
-__device__ __forceinline__ double c_entry(const gdouble* H, const gschar* mk, int ni, int p, int i, int jj)
-{
-    const bool in = (i < ni) & (jj < p);
-    const int is = in ? i : 0, js = in ? jj : 0;
-    double v = H[(size_t)is * MCQ_HLD + MCQ_HBO + js];
-    if (MK) v = ((mk[is] != 0) | (mk[ni + js] != 0)) ? 0.0 : v;
-    return in ? v : 0.0;
-}
+// Raw (un-decoded) loads of one window entry: kept in registers while the loads are in flight, decoded when the entry is
+// committed to LDS -- nothing between fetch and commit depends on the loaded values, so no s_waitcnt is placed early.
+struct RawEntry {
+    double h, sg;
+    int m0, m1;
+};
 
 // item q of tile row R: q < 16*80 -> band part, column-major inside the tile row (16 consecutive rows of one column
 // are 16 contiguous doubles of H); else border part, row-major (64 contiguous doubles of one H row)
 template <bool MK, bool SIG>
-__device__ __forceinline__ double tile_row_load(const gdouble* H, const gdouble* sig, const gschar* mk, int ni, int b, int p,
-                                                int R, int q)
+__device__ __forceinline__ RawEntry tile_row_fetch(const gdouble* H, const gdouble* sig, const gschar* mk, int ni, int b, int p,
+                                                   int R, int q)
+{
+    RawEntry e;
+    e.sg = 0.0;
+    e.m0 = e.m1 = 0;
+    if (q < TB * NTR * TB) {
+        const int ee = q / TB, rr = q - ee * TB;
+        const int i = R * TB + rr, c = (R - (NTR - 1) + ee / TB) * TB + (ee % TB);
+        const bool in = (i < ni) & (c < ni) & (c >= 0);
+        const int k = i - c;
+        const bool valid = in & (k >= 0) & (k <= b);
+        const int cs = in ? c : 0, is = in ? i : 0;
+        e.h = H[(size_t)cs * MCQ_HLD + (valid ? k : 0)];
+        if (MK) { e.m0 = mk[cs]; e.m1 = mk[is]; }
+        if (SIG) e.sg = sig[cs];
+    } else {
+        const int q2 = q - TB * NTR * TB;
+        const int rr = q2 / MCQ_P_MAX, jj = q2 - rr * MCQ_P_MAX;
+        const int i = R * TB + rr;
+        const bool in = (i < ni) & (jj < p);
+        const int is = in ? i : 0, js = in ? jj : 0;
+        e.h = H[(size_t)is * MCQ_HLD + MCQ_HBO + js];
+        if (MK) { e.m0 = mk[is]; e.m1 = mk[ni + js]; }
+    }
+    return e;
+}
+
+template <bool MK, bool SIG>
+__device__ __forceinline__ double tile_row_decode(const RawEntry& e, int ni, int b, int p, int R, int q)
 {
     if (q < TB * NTR * TB) {
-        const int e = q / TB, rr = q - e * TB;
-        const int K = R - (NTR - 1) + e / TB, cc = e % TB;
-        return m_entry<MK, SIG>(H, sig, mk, ni, b, R * TB + rr, K * TB + cc);
+        const int ee = q / TB, rr = q - ee * TB;
+        const int i = R * TB + rr, c = (R - (NTR - 1) + ee / TB) * TB + (ee % TB);
+        const bool in = (i < ni) & (c < ni) & (c >= 0);
+        const int k = i - c;
+        const bool valid = in & (k >= 0) & (k <= b);
+        double v = valid ? e.h : 0.0;
+        bool pinned = false;
+        if (MK) {
+            pinned = (e.m0 != 0) | (e.m1 != 0);
+            v = pinned ? (k == 0 ? 1.0 : 0.0) : v;
+        }
+        if (SIG) v += (k == 0 && !pinned) ? e.sg : 0.0;
+        return in ? v : ((k == 0) ? 1.0 : 0.0);     // identity padding beyond the interior
     }
     const int q2 = q - TB * NTR * TB;
     const int rr = q2 / MCQ_P_MAX, jj = q2 - rr * MCQ_P_MAX;
-    return c_entry<MK>(H, mk, ni, p, R * TB + rr, jj);
+    const bool in = (R * TB + rr < ni) & (jj < p);
+    double v = e.h;
+    if (MK) v = ((e.m0 != 0) | (e.m1 != 0)) ? 0.0 : v;
+    return in ? v : 0.0;
 }
 
 __device__ __forceinline__ void tile_row_store(double* bt, double* ct, int R, int q, double v)
@@ -516,13 +532,13 @@ __device__ __forceinline__ int factor_t(const SolveCtx& c, const gdouble* Hsrc, 
     v4d sacc[NCT];
 #pragma unroll
     for (int m = 0; m < NCT; ++m) sacc[m] = (v4d){0.0, 0.0, 0.0, 0.0};
-    double pf[PF_ITEMS];
+    RawEntry pf[PF_ITEMS];
 
     __syncthreads();
     // prologue: tile rows 0 .. NTR-1
     for (int R = 0; R < NTR; ++R)
         for (int q = tid; q < ROW_ITEMS; q += MCQ_NT)
-            tile_row_store(bt, ct, R, q, tile_row_load<MK, SIG>(H, sig, mk, ni, b, p, R, q));
+            tile_row_store(bt, ct, R, q, tile_row_decode<MK, SIG>(tile_row_fetch<MK, SIG>(H, sig, mk, ni, b, p, R, q), ni, b, p, R, q));
     if (tid == 0) dinv[TB] = 0.0;   // fail flag
     __syncthreads();
 
@@ -532,8 +548,9 @@ __device__ __forceinline__ int factor_t(const SolveCtx& c, const gdouble* Hsrc, 
 #pragma unroll
         for (int u = 0; u < PF_ITEMS; ++u) {
             const int q = tid + u * MCQ_NT;
-            pf[u] = tile_row_load<MK, SIG>(H, sig, mk, ni, b, p, J + NTR, q < ROW_ITEMS ? q : 0);
+            pf[u] = tile_row_fetch<MK, SIG>(H, sig, mk, ni, b, p, J + NTR, q < ROW_ITEMS ? q : 0);
         }
+        long long tp = TICK();
         // ---- phase 1: diagonal tile, wave 0; lane r (= lane & 15) keeps row r in 16 registers -------------------------
         if (w0 == 0) {
             double* d0 = BTILE(J, J);
@@ -558,6 +575,7 @@ __device__ __forceinline__ int factor_t(const SolveCtx& c, const gdouble* Hsrc, 
             if (bad && lane == 0) dinv[TB] = 1.0;
         }
         lds_barrier();
+        c.tk[4] += TICK() - tp; tp = TICK();
         if (dinv[TB] != 0.0) { fail = 1; break; }
         // ---- phase 2: panel.  lanes 0..63: rows of L below the diagonal tile; lanes 64..127: columns of W = L00^-1 C ----
         if (tid < 128) {
@@ -579,6 +597,7 @@ __device__ __forceinline__ int factor_t(const SolveCtx& c, const gdouble* Hsrc, 
             for (int cc = 0; cc < TB; ++cc) base[cc * stride] = x[cc];
         }
         lds_barrier();
+        c.tk[5] += TICK() - tp; tp = TICK();
         // ---- emit block column J of L and block row J of W to HBM ----------------------------------------------------------
         for (int q = tid; q < NTR * TB * TB; q += MCQ_NT) {
             const int tI = q / (TB * TB), rem = q - tI * TB * TB;
@@ -595,6 +614,7 @@ __device__ __forceinline__ int factor_t(const SolveCtx& c, const gdouble* Hsrc, 
             const int i = J * TB + rr;
             if (i < ni) L[(size_t)i * MCQ_HLD + MCQ_HBO + jj] = CTILE(J, jj / TB)[rr * TLD + (jj % TB)];
         }
+        c.tk[6] += TICK() - tp; tp = TICK();
         // ---- phase 3: rank-16 trailing update on the matrix cores ----------------------------------------------------------
         {
             // operands of this wave's border column a = w0:  W_blk tile a in "direct" form  B[k][j] = W[k][16a + j]
@@ -654,8 +674,12 @@ __device__ __forceinline__ int factor_t(const SolveCtx& c, const gdouble* Hsrc, 
         lds_barrier();
         // ---- the prefetched tile row takes the slots of tile row J (dead now) ------------------------------------------------
 #pragma unroll
-        for (int u = 0; u < PF_ITEMS; ++u) tile_row_store(bt, ct, J + NTR, tid + u * MCQ_NT, pf[u]);
+        for (int u = 0; u < PF_ITEMS; ++u) {
+            const int q = tid + u * MCQ_NT;
+            tile_row_store(bt, ct, J + NTR, q, tile_row_decode<MK, SIG>(pf[u], ni, b, p, J + NTR, q < ROW_ITEMS ? q : 0));
+        }
         lds_barrier();
+        c.tk[7] += TICK() - tp;
     }
     if (fail) return MCQ_NOT_PD;
 
@@ -1434,7 +1458,7 @@ __global__ void __launch_bounds__(MCQ_NT) mcq_solve_kernel(McqBatch B)
     if (*c.w.status != MCQ_OK) return;
     c.nm = B.nmax;
     c.d = mcq_dims(n, B.band_e);
-    c.tk[0] = c.tk[1] = c.tk[2] = c.tk[3] = 0;
+    for (int q = 0; q < 8; ++q) c.tk[q] = 0;
     const long long t_kernel0 = TICK();
     double* red = g_sm + SM_RED;
     const int nm = B.nmax;
@@ -1554,7 +1578,7 @@ __global__ void __launch_bounds__(MCQ_NT) mcq_solve_kernel(McqBatch B)
                 o.kappa_max = km;
                 o.kkt_res = sc.fscale > 0.0 ? kkt / sc.fscale : kkt;
                 c.tk[3] = TICK() - t_kernel0;
-                for (int q = 0; q < 4; ++q) o.ticks[q] = c.tk[q];
+                for (int q = 0; q < 8; ++q) o.ticks[q] = c.tk[q];
                 *(mcq_info*)c.w.info = o;
             }
         }

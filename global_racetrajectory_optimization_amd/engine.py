@@ -37,7 +37,7 @@ class McqOpts(ctypes.Structure):
 class McqInfo(ctypes.Structure):
     _fields_ = [("ipm_iters", ctypes.c_int), ("as_iters", ctypes.c_int), ("n_active_box", ctypes.c_int),
                 ("n_active_kappa", ctypes.c_int), ("kappa_max", ctypes.c_double), ("kkt_res", ctypes.c_double),
-                ("ticks", ctypes.c_longlong * 4)]
+                ("ticks", ctypes.c_longlong * 8)]
 
 
 EXPORTED_SYMBOLS = ("mcq_create", "mcq_destroy", "mcq_last_error", "mcq_default_opts", "mcq_solve_batch",

@@ -82,8 +82,9 @@ typedef struct {
     double kappa_max;   /* max_i |k_ref_i + (E a)_i| at the returned a */
     double kkt_res;     /* max free-gradient magnitude relative to max |f| */
     /* device wall-clock (s_memrealtime, 100 MHz ticks) spent by this problem's workgroup in the phases of the solver
-     * kernel: [0] banded factorisations, [1] triangular solves, [2] gradient band products, [3] whole kernel */
-    long long ticks[4];
+     * kernel: [0] banded factorisations, [1] triangular solves, [2] gradient band products, [3] whole kernel,
+     * [4..7] inside the factorisation: diagonal tile, panel, write-out of L, trailing update + window refill */
+    long long ticks[8];
 } mcq_info;
 
 int mcq_create(int device_id, mcq_handle** out);
