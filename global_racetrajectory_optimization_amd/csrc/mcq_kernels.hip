@@ -13,8 +13,9 @@ typedef double v4d __attribute__((vector_size(32)));   /* accumulator fragment o
 #define NCT (MCQ_P_MAX / TB)            /* tile columns of the border block (4) */
 #define SLD (MCQ_P_MAX + 1)
 #define WLD (MCQ_BH_MAX + 1)
-#define CH 32                           /* rows per chunk of the triangular sweeps */
-#define NBUF 4                          /* chunk ring: 3 resident + 1 being filled */
+#define CH 64                           /* rows per chunk of the triangular sweeps */
+#define LA (64 / CH)                    /* chunks ahead of the current one that a sweep step touches (rows i .. i+64) */
+#define NBUF (LA + 2)                   /* chunk ring: LA + 1 resident + 1 being filled */
 #define NRB 8                           /* right-hand-side ring (chunks) */
 
 // ---------------------------------------------------------------------------------------------------------------------
@@ -25,7 +26,9 @@ typedef double v4d __attribute__((vector_size(32)));   /* accumulator fragment o
 #define SM_PART (SM_XD + 64)
 #define SM_S (SM_PART + MCQ_NW * 64)
 #define SM_OVL (SM_S + MCQ_P_MAX * SLD)          /* overlay region */
-#define OVL_SIZE (NTR * NTR * TSZ + NTR * NCT * TSZ + 32)
+#define OVL_SIZE_F (NTR * NTR * TSZ + NTR * NCT * TSZ + 32)
+#define OVL_SIZE_S (NBUF * CH * WLD + NRB * CH)
+#define OVL_SIZE (OVL_SIZE_F > OVL_SIZE_S ? OVL_SIZE_F : OVL_SIZE_S)
 #define SM_BT SM_OVL                              /* band tiles   (NTR x NTR) */
 #define SM_CT (SM_BT + NTR * NTR * TSZ)           /* border tiles (NTR x NCT) */
 #define SM_DINV (SM_CT + NTR * NCT * TSZ)         /* 16 reciprocal pivots of the current diagonal tile + fail flag */
@@ -792,11 +795,11 @@ __device__ __noinline__ void solve(const SolveCtx& c, gdouble* v)
     // ================= forward substitution, interior rows =================
     // prologue: chunks 0,1,2 (rows + rhs) resident, chunk 3 staged in registers.  Rows >= ni load as zeros (harmless).
     if (wv > 0) {
-        for (int q = 0; q < 3; ++q) {
+        for (int q = 0; q <= LA; ++q) {
             chunk_fetch(L, v, ni, b, q, q, lt, regs);
             chunk_commit(chunk, rring, q, q, lt, regs);
         }
-        chunk_fetch(L, v, ni, b, 3, 3, lt, regs);
+        chunk_fetch(L, v, ni, b, LA + 1, LA + 1, lt, regs);
     }
     __syncthreads();
     {
@@ -829,8 +832,8 @@ __device__ __noinline__ void solve(const SolveCtx& c, gdouble* v)
                 const int li = cq * CH + ((lane - cq * CH) & 63);
                 if (((lane - cq * CH) & 63) < CH && li < ni) v[li] = ysave;
             } else {
-                chunk_commit(chunk, rring, cq + 3, cq + 3, lt, regs);
-                chunk_fetch(L, v, ni, b, cq + 4, cq + 4, lt, regs);
+                chunk_commit(chunk, rring, cq + LA + 1, cq + LA + 1, lt, regs);
+                chunk_fetch(L, v, ni, b, cq + LA + 2, cq + LA + 2, lt, regs);
             }
             lds_barrier();
         }
