@@ -728,6 +728,25 @@ __device__ __forceinline__ int factor_t(const SolveCtx& c, const gdouble* Hsrc, 
     __syncthreads();
     if (tid == 0 && p > 0) Sm[(p - 1) * SLD + (p - 1)] = sqrt(Sm[(p - 1) * SLD + (p - 1)]);
     __syncthreads();
+    // explicit inverse of L_S (p <= 64): the border solves of every triangular solve become two LDS mat-vecs instead of
+    // 2 x 64 dependent wave reductions.  Thread c computes column c by forward substitution into the (now dead) tile area.
+    {
+        double* tmp = g_sm + SM_OVL;
+        for (int q = tid; q < MCQ_P_MAX * SLD; q += MCQ_NT) tmp[q] = 0.0;
+        __syncthreads();
+        if (tid < p) {
+            const int cc = tid;
+            tmp[cc * SLD + cc] = 1.0 / Sm[cc * SLD + cc];
+            for (int r = cc + 1; r < p; ++r) {
+                double acc = 0.0;
+                for (int k = cc; k < r; ++k) acc += Sm[r * SLD + k] * tmp[k * SLD + cc];
+                tmp[r * SLD + cc] = -acc / Sm[r * SLD + r];
+            }
+        }
+        __syncthreads();
+        for (int q = tid; q < MCQ_P_MAX * SLD; q += MCQ_NT) Sm[q] = tmp[q];
+        __syncthreads();
+    }
     return 0;
 }
 
@@ -777,12 +796,14 @@ __device__ __forceinline__ void chunk_commit(double* chunk, double* rring, int q
 #define LROW(r) (chunk + (((r) / CH) % NBUF) * CH * WLD + ((r) % CH) * WLD)
 #define RHSV(r) (rring[(((r) / CH) % NRB) * CH + ((r) % CH)])
 
+#define WROWS ((CH + 2) / 3)       /* W rows of a chunk handled by one loader wave (rows (wv-1) + 3m) */
+
 __device__ __noinline__ void solve(const SolveCtx& c, gdouble* v)
 {
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     const int b = c.d.b, p = c.d.p, ni = c.d.ni;
     const gdouble* L = c.w.L;
-    double* Sm = g_sm + SM_S;
+    double* Sm = g_sm + SM_S;      // L_S^-1 (lower triangular, upper part zero)
     double* xd = g_sm + SM_XD;
     double* part = g_sm + SM_PART;
     double* chunk = g_sm + SM_CHUNK;
@@ -790,10 +811,22 @@ __device__ __noinline__ void solve(const SolveCtx& c, gdouble* v)
     const int nch = (ni + CH - 1) / CH;
     const int lt = tid - 64;      // loader thread id (waves 1..3)
     double regs[LD_ITEMS];
+    double wreg[WROWS], vreg[WROWS];
+
+    // W rows (wv-1) + 3m of chunk q for this loader wave: raw loads at clamped addresses, masked when used
+#define WFETCH(q)                                                                                              \
+    _Pragma("unroll") for (int m = 0; m < WROWS; ++m) {                                                        \
+        const int r_ = (q) * CH + (wv - 1) + 3 * m;                                                            \
+        const int rs_ = (r_ >= 0 && r_ < ni) ? r_ : 0;                                                         \
+        wreg[m] = L[(size_t)rs_ * MCQ_HLD + MCQ_HBO + (lane < p ? lane : 0)];                                  \
+        vreg[m] = v[rs_];                                                                                      \
+    }
+#define WVALID(q, m) (((wv - 1) + 3 * (m) < CH) && ((q) * CH + (wv - 1) + 3 * (m) < ni) && ((q) >= 0) && lane < p)
 
     __syncthreads();
     // ================= forward substitution, interior rows =================
-    // prologue: chunks 0,1,2 (rows + rhs) resident, chunk 3 staged in registers.  Rows >= ni load as zeros (harmless).
+    // prologue: chunks 0..LA (rows + rhs) resident, chunk LA+1 staged in registers.  Rows >= ni load as zeros (harmless).
+    double tacc = 0.0;
     if (wv > 0) {
         for (int q = 0; q <= LA; ++q) {
             chunk_fetch(L, v, ni, b, q, q, lt, regs);
@@ -828,83 +861,82 @@ __device__ __noinline__ void solve(const SolveCtx& c, gdouble* v)
                         acc -= lv[u] * yi;
                     }
                 }
-                // the 32 unknowns of this chunk sit in lanes (cq*32 .. cq*32+31) & 63: one coalesced store
+                // the CH unknowns of this chunk sit in lanes (cq*CH .. cq*CH+CH-1) & 63: one coalesced store, and a copy in
+                // the rhs ring for the loader waves' W'y accumulation
                 const int li = cq * CH + ((lane - cq * CH) & 63);
-                if (((lane - cq * CH) & 63) < CH && li < ni) v[li] = ysave;
+                if (((lane - cq * CH) & 63) < CH) {
+                    RHSV(li) = ysave;
+                    if (li < ni) v[li] = ysave;
+                }
             } else {
                 chunk_commit(chunk, rring, cq + LA + 1, cq + LA + 1, lt, regs);
                 chunk_fetch(L, v, ni, b, cq + LA + 2, cq + LA + 2, lt, regs);
+                // border right-hand side, fused: t -= W' y for the rows solved in the previous step (W rows in registers)
+                if (cq >= 1) {
+#pragma unroll
+                    for (int m = 0; m < WROWS; ++m)
+                        if (WVALID(cq - 1, m)) tacc += wreg[m] * RHSV((cq - 1) * CH + (wv - 1) + 3 * m);
+                }
+                WFETCH(cq)
             }
             lds_barrier();
         }
-    }
-    __syncthreads();
-    // ================= border:  t = v_D - W' y_B,  dense solves with L_S =================
-    {
-        double acc = 0.0;
-        if (lane < p) {
-            int i = wv;
-            for (; i + 15 * MCQ_NW < ni; i += 16 * MCQ_NW) {
-                double wr[16], yr[16];
+        if (wv > 0 && nch >= 1) {
 #pragma unroll
-                for (int u = 0; u < 16; ++u) {
-                    wr[u] = L[(size_t)(i + u * MCQ_NW) * MCQ_HLD + MCQ_HBO + lane];
-                    yr[u] = v[i + u * MCQ_NW];
-                }
-#pragma unroll
-                for (int u = 0; u < 16; ++u) acc += wr[u] * yr[u];
-            }
-            for (; i < ni; i += MCQ_NW) acc += L[(size_t)i * MCQ_HLD + MCQ_HBO + lane] * v[i];
+            for (int m = 0; m < WROWS; ++m)
+                if (WVALID(nch - 1, m)) tacc += wreg[m] * RHSV((nch - 1) * CH + (wv - 1) + 3 * m);
         }
-        part[wv * 64 + lane] = acc;
     }
+    part[wv * 64 + lane] = tacc;
     __syncthreads();
+    // ================= border:  t = v_D - W' y_B,  x_D = L_S^-T (L_S^-1 t)  as two LDS mat-vecs =================
     if (wv == 0) {
         double t = 0.0;
         if (lane < p) {
             t = v[ni + lane];
-            for (int q = 0; q < MCQ_NW; ++q) t -= part[q * 64 + lane];
+            for (int q = 1; q < MCQ_NW; ++q) t -= part[q * 64 + lane];
         }
-        for (int j = 0; j < p; ++j) {      // dense forward  L_S y = t
-            const double s = wave_sum(lane < j ? Sm[j * SLD + lane] * t : 0.0);
-            const double tj = (bcast_lane(t, j) - s) / Sm[j * SLD + j];
-            if (lane == j) t = tj;
-        }
-        for (int j = p - 1; j >= 0; --j) { // dense backward  L_S' x = y
-            const double s = wave_sum((lane > j && lane < p) ? Sm[lane * SLD + j] * t : 0.0);
-            const double xj = (bcast_lane(t, j) - s) / Sm[j * SLD + j];
-            if (lane == j) t = xj;
-        }
-        if (lane < p) v[ni + lane] = t;
-        xd[lane] = lane < p ? t : 0.0;
-    }
-    __syncthreads();
-    // y_B -= W x_D   (thread per row, 16-byte loads of the W row; x_D broadcast from LDS)
-    for (int i = tid; i < ni; i += MCQ_NT) {
-        typedef double d2 __attribute__((vector_size(16)));
-        const __attribute__((address_space(1))) d2* wr = (const __attribute__((address_space(1))) d2*)(L + (size_t)i * MCQ_HLD + MCQ_HBO);
-        double s0 = 0.0, s1 = 0.0;
-#pragma unroll 8
-        for (int q = 0; q < MCQ_P_MAX / 2; ++q) {
-            const d2 w2 = wr[q];
-            s0 += w2[0] * xd[2 * q];
-            s1 += w2[1] * xd[2 * q + 1];
-        }
-        v[i] -= s0 + s1;
+        xd[lane] = t;
+        __builtin_amdgcn_wave_barrier();   // same-wave LDS write -> read (in-order on hardware; ordering point for the compiler)
+        double y = 0.0;
+        for (int cc = 0; cc < MCQ_P_MAX; ++cc) y += Sm[(lane < p ? lane : 0) * SLD + cc] * xd[cc];
+        __builtin_amdgcn_wave_barrier();
+        part[lane] = lane < p ? y : 0.0;
+        __builtin_amdgcn_wave_barrier();
+        double x = 0.0;
+        for (int r = 0; r < MCQ_P_MAX; ++r) x += Sm[r * SLD + lane] * part[r];
+        if (lane < p) v[ni + lane] = x;
+        xd[lane] = lane < p ? x : 0.0;
     }
     __syncthreads();
     // ================= backward substitution, interior rows (descending) =================
-    // row i needs only its own L row; the owner of row i takes row i-64 next -> rhs chunks lead the row chunks by two
+    // row i needs only its own L row; the owner of row i takes row i-64 next -> rhs chunks lead the row chunks by LA.
+    // The loader waves produce the right-hand side of a chunk as  y_B - W x_D  (W rows fetched one step ahead, 64-wide
+    // dot products reduced in the wave) and write it straight into the rhs ring.
+#define RHS_REDUCE_STORE(q)                                                                                    \
+    {                                                                                                          \
+        double a_[WROWS];                                                                                      \
+        _Pragma("unroll") for (int m = 0; m < WROWS; ++m) a_[m] = WVALID(q, m) ? wreg[m] * xd[lane] : 0.0;     \
+        _Pragma("unroll") for (int sh = 32; sh >= 1; sh >>= 1) {                                               \
+            _Pragma("unroll") for (int m = 0; m < WROWS; ++m) a_[m] += __shfl_xor(a_[m], sh);                  \
+        }                                                                                                      \
+        _Pragma("unroll") for (int m = 0; m < WROWS; ++m) {                                                    \
+            const int r_ = (q) * CH + (wv - 1) + 3 * m;                                                        \
+            if (lane == 0 && (wv - 1) + 3 * m < CH && (q) >= 0)                                                \
+                RHSV(r_) = (r_ < ni) ? vreg[m] - a_[m] : 0.0;                                                  \
+        }                                                                                                      \
+    }
     if (nch > 0) {
         const int cl = nch - 1;
         if (wv > 0) {
-            chunk_fetch(L, v, ni, b, cl, cl, lt, regs);
-            chunk_commit(chunk, rring, cl, cl, lt, regs);
-            chunk_fetch(L, v, ni, b, -1, cl - 1, lt, regs);
-            chunk_commit(chunk, rring, -1, cl - 1, lt, regs);
-            chunk_fetch(L, v, ni, b, -1, cl - 2, lt, regs);
-            chunk_commit(chunk, rring, -1, cl - 2, lt, regs);
-            chunk_fetch(L, v, ni, b, cl - 1, cl - 3, lt, regs);
+            chunk_fetch(L, v, ni, b, cl, -1, lt, regs);
+            chunk_commit(chunk, rring, cl, -1, lt, regs);
+            for (int q = cl; q >= cl - LA; --q) {
+                WFETCH(q)
+                RHS_REDUCE_STORE(q)
+            }
+            chunk_fetch(L, v, ni, b, cl - 1, -1, lt, regs);
+            WFETCH(cl - LA - 1)
         }
         __syncthreads();
         // lane l first owns the largest row j <= nch*CH-1 with j == l (mod 64)  (rows >= ni are zero rows: x = 0)
@@ -942,13 +974,18 @@ __device__ __noinline__ void solve(const SolveCtx& c, gdouble* v)
                 const int li = cq * CH + ((lane - cq * CH) & 63);
                 if (((lane - cq * CH) & 63) < CH && li < ni) v[li] = xsave;
             } else {
-                chunk_commit(chunk, rring, cq - 1, cq - 3, lt, regs);
-                chunk_fetch(L, v, ni, b, cq - 2, cq - 4, lt, regs);
+                chunk_commit(chunk, rring, cq - 1, -1, lt, regs);
+                chunk_fetch(L, v, ni, b, cq - 2, -1, lt, regs);
+                RHS_REDUCE_STORE(cq - LA - 1)
+                WFETCH(cq - LA - 2)
             }
             lds_barrier();
         }
     }
     __syncthreads();
+#undef WFETCH
+#undef WVALID
+#undef RHS_REDUCE_STORE
 }
 
 // g = E'(E x + F_SCALE k_ref + extra)      (tmp: scratch vector; extra may be nullptr)
