@@ -796,6 +796,7 @@ __device__ __forceinline__ void chunk_commit(double* chunk, double* rring, int q
 #define LROW(r) (chunk + (((r) / CH) % NBUF) * CH * WLD + ((r) % CH) * WLD)
 #define RHSV(r) (rring[(((r) / CH) % NRB) * CH + ((r) % CH)])
 
+#define SWG 8                      /* rows per group of a sweep: their LDS reads are issued together */
 #define WROWS ((CH + 2) / 3)       /* W rows of a chunk handled by one loader wave (rows (wv-1) + 3m) */
 
 __device__ __noinline__ void solve(const SolveCtx& c, gdouble* v)
@@ -840,10 +841,10 @@ __device__ __noinline__ void solve(const SolveCtx& c, gdouble* v)
         for (int cq = 0; cq < nch; ++cq) {
             if (wv == 0) {
                 double ysave = 0.0;
-                for (int i0 = cq * CH; i0 < (cq + 1) * CH; i0 += 4) {
-                    double dg[4], lv[4], nr[4];
+                for (int i0 = cq * CH; i0 < (cq + 1) * CH; i0 += SWG) {
+                    double dg[SWG], lv[SWG], nr[SWG];
 #pragma unroll
-                    for (int u = 0; u < 4; ++u) {       // all LDS reads of four rows before the dependent chain
+                    for (int u = 0; u < SWG; ++u) {     // all LDS reads of SWG rows before the dependent chain
                         const int i = i0 + u;
                         const int k = ((lane - i - 1) & 63) + 1;
                         dg[u] = LROW(i)[0];
@@ -852,7 +853,7 @@ __device__ __noinline__ void solve(const SolveCtx& c, gdouble* v)
                         nr[u] = RHSV(i + 64);
                     }
 #pragma unroll
-                    for (int u = 0; u < 4; ++u) {
+                    for (int u = 0; u < SWG; ++u) {
                         const int owner = (i0 + u) & 63;
                         const double yi = bcast_lane(acc, owner) * dg[u];
                         const bool own = lane == owner;
@@ -946,10 +947,10 @@ __device__ __noinline__ void solve(const SolveCtx& c, gdouble* v)
         for (int cq = cl; cq >= 0; --cq) {
             if (wv == 0) {
                 double xsave = 0.0;
-                for (int i0 = (cq + 1) * CH - 1; i0 >= cq * CH; i0 -= 4) {
-                    double dg[4], lv[4], nr[4];
+                for (int i0 = (cq + 1) * CH - 1; i0 >= cq * CH; i0 -= SWG) {
+                    double dg[SWG], lv[SWG], nr[SWG];
 #pragma unroll
-                    for (int u = 0; u < 4; ++u) {
+                    for (int u = 0; u < SWG; ++u) {
                         const int i = i0 - u;
                         const double* lr = LROW(i);
                         const int k = ((i - 1 - lane) & 63) + 1;
@@ -962,7 +963,7 @@ __device__ __noinline__ void solve(const SolveCtx& c, gdouble* v)
                         nr[u] = jn >= 0 ? r : 0.0;
                     }
 #pragma unroll
-                    for (int u = 0; u < 4; ++u) {
+                    for (int u = 0; u < SWG; ++u) {
                         const int owner = (i0 - u) & 63;
                         const double xi = bcast_lane(acc, owner) * dg[u];
                         const bool own = lane == owner;
