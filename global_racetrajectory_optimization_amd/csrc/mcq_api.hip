@@ -129,13 +129,13 @@ static int ensure_ws(mcq_handle* h, size_t batch, size_t nmax)
     HIP_TRY(hipMalloc((void**)&h->Et, elems * MCQ_ELD * sizeof(double)));
     HIP_TRY(hipMalloc((void**)&h->Db, elems * MCQ_ELD * sizeof(double)));
     HIP_TRY(hipMalloc((void**)&h->H, elems * MCQ_HLD * sizeof(double)));
-    HIP_TRY(hipMalloc((void**)&h->L, elems * MCQ_HLD * sizeof(double)));
+    HIP_TRY(hipMalloc((void**)&h->L, elems * MCQ_LLD * sizeof(double)));
     HIP_TRY(hipMalloc((void**)&h->vec, elems * MCQ_NVEC * sizeof(double)));
     HIP_TRY(hipMalloc((void**)&h->Z, elems * MCQ_KMAX * sizeof(double)));
     HIP_TRY(hipMalloc((void**)&h->state, elems));
     h->cap_elems = elems;
     h->cap_batch = batch;
-    h->ws_bytes = (long long)(elems * ((3 * MCQ_ELD + 2 * MCQ_HLD + MCQ_NVEC + MCQ_KMAX) * sizeof(double) + 1));
+    h->ws_bytes = (long long)(elems * ((3 * MCQ_ELD + MCQ_HLD + MCQ_LLD + MCQ_NVEC + MCQ_KMAX) * sizeof(double) + 1));
     return 0;
 }
 

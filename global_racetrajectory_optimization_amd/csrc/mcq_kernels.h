@@ -21,9 +21,11 @@
 //   Et       [MCQ_ELD][nmax]  transpose band: entry [(bR+o)*nmax + j] = E[(j+o) mod n, j],  -bR <= o <= bE
 //                             (diagonal-major => a wave reading one diagonal for 64 consecutive rows reads 512 contiguous
 //                              bytes; band products need no cross-lane reduction)
-//   H, L     [n][MCQ_HLD]  interior rows i < ni: [0..b] band (H: H[i,i+k] upper / L: L[i,i-k] lower, L[.][0] = 1/L_ii),
-//                          [MCQ_HBO + jj] border coupling H[i, ni+jj] / W[i][jj];
-//                          border rows i = ni+j: [MCQ_HBO + jj] = D[j][jj] (H only; L_S stays in LDS)
+//   H        [n][MCQ_HLD]  interior rows i < ni: [0..b] upper band H[i,i+k], [MCQ_HBO + jj] border coupling H[i, ni+jj];
+//                          border rows i = ni+j: [MCQ_HBO + jj] = D[j][jj]
+//   L        [n][MCQ_LLD]  interior rows i < ni: [m] = L[i, i-1-m] (m < 64), [MCQ_LBI + c] = row (i mod 16) of the inverse
+//                          of the 16x16 diagonal tile i/16, [MCQ_LBW + jj] = W[i][jj];  every piece 16-byte aligned.
+//                          (the inverse of the border factor L_S stays in LDS, packed lower-triangular)
 //   vectors  [n]           see Work struct
 #pragma once
 #include <hip/hip_runtime.h>
@@ -37,7 +39,10 @@
 #define MCQ_GW (MCQ_BE_MAX + 2)    /* half-width of the T^-1 rows kept */
 #define MCQ_GLD 72                 /* 2*GW+1 = 69, padded */
 #define MCQ_HBO 66                 /* offset of the border part inside an H/L row */
-#define MCQ_HLD 130                /* BH_MAX+1 band | pad | P_MAX border */
+#define MCQ_HLD 130                /* H rows: BH_MAX+1 band | pad | P_MAX border */
+#define MCQ_LLD 144                /* L rows: 64 band entries | 16 inverse-diagonal-tile entries | 64 border entries */
+#define MCQ_LBI 64                 /* offset of the inverse diagonal tile row inside an L row */
+#define MCQ_LBW 80                 /* offset of the border part W inside an L row */
 #define MCQ_NVEC 27
 #define MCQ_KMAX 24                /* active curvature rows the Schur-complement path of the active-set phase holds */
 #define MCQ_PIVOT_WARMUP 64

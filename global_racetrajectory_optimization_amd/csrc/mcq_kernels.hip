@@ -13,10 +13,12 @@ typedef double v4d __attribute__((vector_size(32)));   /* accumulator fragment o
 #define NCT (MCQ_P_MAX / TB)            /* tile columns of the border block (4) */
 #define SLD (MCQ_P_MAX + 1)
 #define WLD (MCQ_BH_MAX + 1)
-#define CH 64                           /* rows per chunk of the triangular sweeps */
-#define LA (64 / CH)                    /* chunks ahead of the current one that a sweep step touches (rows i .. i+64) */
-#define NBUF (LA + 2)                   /* chunk ring: LA + 1 resident + 1 being filled */
-#define NRB 8                           /* right-hand-side ring (chunks) */
+#define CH 64                           /* rows per chunk of the triangular sweeps (4 tiles) */
+#define CLD 80                          /* LDS row of a chunk: 64 band entries + 16 inverse-diagonal-tile entries */
+#define NBUF 3                          /* chunk ring: current, previous (backward sweep) / next, one being filled */
+#define NRB 4                           /* right-hand-side ring (chunks) */
+#define VRING 128                       /* ring of the most recent unknowns (the band reaches 64 back, tiles are 16 wide) */
+#define SPK (MCQ_P_MAX * (MCQ_P_MAX + 1) / 2)   /* packed lower triangle of the inverse border factor */
 
 // ---------------------------------------------------------------------------------------------------------------------
 // shared-memory carve-up of the solver kernel (doubles).  The triangular sweeps overlay the factorisation window.
@@ -24,16 +26,20 @@ typedef double v4d __attribute__((vector_size(32)));   /* accumulator fragment o
 #define SM_RED 0
 #define SM_XD (SM_RED + 64)
 #define SM_PART (SM_XD + 64)
-#define SM_S (SM_PART + MCQ_NW * 64)
-#define SM_OVL (SM_S + MCQ_P_MAX * SLD)          /* overlay region */
-#define OVL_SIZE_F (NTR * NTR * TSZ + NTR * NCT * TSZ + 32)
-#define OVL_SIZE_S (NBUF * CH * WLD + NRB * CH)
+#define SM_S (SM_PART + MCQ_NW * 64)              /* L_S^-1, packed rows: entry (r, c <= r) at r (r + 1) / 2 + c */
+#define SM_OVL (SM_S + SPK)                       /* overlay region */
+#define OVL_SIZE_F (NTR * NTR * TSZ + NTR * NCT * TSZ + TSZ + 32)
+#define OVL_SIZE_S (NBUF * CH * CLD + NRB * CH + VRING)
 #define OVL_SIZE (OVL_SIZE_F > OVL_SIZE_S ? OVL_SIZE_F : OVL_SIZE_S)
 #define SM_BT SM_OVL                              /* band tiles   (NTR x NTR) */
 #define SM_CT (SM_BT + NTR * NTR * TSZ)           /* border tiles (NTR x NCT) */
-#define SM_DINV (SM_CT + NTR * NCT * TSZ)         /* 16 reciprocal pivots of the current diagonal tile + fail flag */
-#define SM_CHUNK SM_OVL                           /* NBUF x CH x WLD */
-#define SM_RHS (SM_CHUNK + NBUF * CH * WLD)       /* NRB x CH */
+#define SM_LINV (SM_CT + NTR * NCT * TSZ)         /* inverse of the current diagonal tile */
+#define SM_DINV (SM_LINV + TSZ)                   /* 16 reciprocal pivots of the current diagonal tile + fail flag */
+#define SM_SFULL SM_OVL                           /* 64 x 65 work area of the dense border factorisation (tiles are dead then) */
+#define SM_STMP (SM_SFULL + MCQ_P_MAX * SLD)
+#define SM_CHUNK SM_OVL                           /* NBUF x CH x CLD */
+#define SM_RHS (SM_CHUNK + NBUF * CH * CLD)       /* NRB x CH */
+#define SM_VR (SM_RHS + NRB * CH)                 /* VRING */
 #define SM_KS (SM_OVL + OVL_SIZE)                 /* KMAX x KMAX Schur matrix of the active curvature rows */
 #define SM_KV (SM_KS + MCQ_KMAX * MCQ_KMAX)       /* 2 x KMAX: multipliers, right-hand side */
 #define SM_KI (SM_KV + 2 * MCQ_KMAX)              /* ints: nk, row index[KMAX], sign[KMAX] */
@@ -104,7 +110,7 @@ __device__ McqWork mcq_work(const McqBatch& B, int pb, int& n, double& kb, doubl
     w.Et = (gdouble*)(B.Et + (size_t)pb * nm * MCQ_ELD);
     w.Db = (gdouble*)(B.Db + (size_t)pb * nm * MCQ_ELD);
     w.H = (gdouble*)(B.H + (size_t)pb * nm * MCQ_HLD);
-    w.L = (gdouble*)(B.L + (size_t)pb * nm * MCQ_HLD);
+    w.L = (gdouble*)(B.L + (size_t)pb * nm * MCQ_LLD);
     w.vec = (gdouble*)(B.vec + (size_t)pb * nm * MCQ_NVEC);
     w.state = (gschar*)(B.state + (size_t)pb * nm);
     w.Z = (gdouble*)(B.Z + (size_t)pb * nm * MCQ_KMAX);
@@ -525,7 +531,8 @@ __device__ __forceinline__ int factor_t(const SolveCtx& c, const gdouble* Hsrc, 
     double* bt = g_sm + SM_BT;
     double* ct = g_sm + SM_CT;
     double* dinv = g_sm + SM_DINV;
-    double* Sm = g_sm + SM_S;
+    double* linv = g_sm + SM_LINV;
+    double* Sm = g_sm + SM_SFULL;     // dense 64 x 65 work area (valid once the block loop is done)
     const gdouble* H = Hsrc;
     gdouble* L = c.w.L;
     const int lane = tid & 63, w0 = tid >> 6;
@@ -580,16 +587,18 @@ __device__ __forceinline__ int factor_t(const SolveCtx& c, const gdouble* Hsrc, 
         lds_barrier();
         c.tk[4] += TICK() - tp; tp = TICK();
         if (dinv[TB] != 0.0) { fail = 1; break; }
-        // ---- phase 2: panel.  lanes 0..63: rows of L below the diagonal tile; lanes 64..127: columns of W = L00^-1 C ----
-        if (tid < 128) {
+        // ---- phase 2: panel.  lanes 0..63: rows of L below the diagonal tile; lanes 64..127: columns of W = L00^-1 C;
+        //      lanes 128..143: columns of L00^-1 itself (right-hand side e_c) -- the triangular sweeps multiply with it
+        if (tid < 128 + TB) {
             const double* d0 = BTILE(J, J);
             double* base;
             int stride;
-            if (tid < 64) { base = BTILE(J + 1 + tid / TB, J) + (tid % TB) * TLD; stride = 1; }
-            else { const int jj = tid - 64; base = CTILE(J, jj / TB) + (jj % TB); stride = TLD; }
             double x[TB];
+            if (tid < 64) { base = BTILE(J + 1 + tid / TB, J) + (tid % TB) * TLD; stride = 1; }
+            else if (tid < 128) { const int jj = tid - 64; base = CTILE(J, jj / TB) + (jj % TB); stride = TLD; }
+            else { base = linv + (tid - 128); stride = TLD; }
 #pragma unroll
-            for (int cc = 0; cc < TB; ++cc) x[cc] = base[cc * stride];
+            for (int cc = 0; cc < TB; ++cc) x[cc] = (tid < 128) ? base[cc * stride] : ((cc == tid - 128) ? 1.0 : 0.0);
 #pragma unroll
             for (int cc = 0; cc < TB; ++cc) {
                 x[cc] *= dinv[cc];
@@ -601,21 +610,21 @@ __device__ __forceinline__ int factor_t(const SolveCtx& c, const gdouble* Hsrc, 
         }
         lds_barrier();
         c.tk[5] += TICK() - tp; tp = TICK();
-        // ---- emit block column J of L and block row J of W to HBM ----------------------------------------------------------
+        // ---- emit block column J of L, the inverse diagonal tile and block row J of W to HBM --------------------------------
         for (int q = tid; q < NTR * TB * TB; q += MCQ_NT) {
             const int tI = q / (TB * TB), rem = q - tI * TB * TB;
             const int rr = rem / TB, cc = rem - rr * TB;
             const int i = (J + tI) * TB + rr;
             const int k = tI * TB + rr - cc;
-            if (i < ni && k >= 0 && k <= MCQ_BH_MAX) {
-                const double v = BTILE(J + tI, J)[rr * TLD + cc];
-                L[(size_t)i * MCQ_HLD + k] = (k == 0) ? dinv[rr] : v;
-            }
+            if (i < ni && k >= 1 && k <= MCQ_BH_MAX) L[(size_t)i * MCQ_LLD + (k - 1)] = BTILE(J + tI, J)[rr * TLD + cc];
         }
-        for (int q = tid; q < TB * MCQ_P_MAX; q += MCQ_NT) {
-            const int rr = q / MCQ_P_MAX, jj = q - rr * MCQ_P_MAX;
+        for (int q = tid; q < TB * (TB + MCQ_P_MAX); q += MCQ_NT) {
+            const int rr = q / (TB + MCQ_P_MAX), e = q - rr * (TB + MCQ_P_MAX);
             const int i = J * TB + rr;
-            if (i < ni) L[(size_t)i * MCQ_HLD + MCQ_HBO + jj] = CTILE(J, jj / TB)[rr * TLD + (jj % TB)];
+            if (i < ni) {
+                const double v = (e < TB) ? linv[rr * TLD + e] : CTILE(J, (e - TB) / TB)[rr * TLD + ((e - TB) % TB)];
+                L[(size_t)i * MCQ_LLD + MCQ_LBI + e] = v;      // [LBI .. LBI+15] inverse tile row, [LBW ..] = LBI + 16 + jj
+            }
         }
         c.tk[6] += TICK() - tp; tp = TICK();
         // ---- phase 3: rank-16 trailing update on the matrix cores ----------------------------------------------------------
@@ -729,9 +738,11 @@ __device__ __forceinline__ int factor_t(const SolveCtx& c, const gdouble* Hsrc, 
     if (tid == 0 && p > 0) Sm[(p - 1) * SLD + (p - 1)] = sqrt(Sm[(p - 1) * SLD + (p - 1)]);
     __syncthreads();
     // explicit inverse of L_S (p <= 64): the border solves of every triangular solve become two LDS mat-vecs instead of
-    // 2 x 64 dependent wave reductions.  Thread c computes column c by forward substitution into the (now dead) tile area.
+    // 2 x 64 dependent wave reductions.  Thread c computes column c by forward substitution; the result is kept packed
+    // (lower triangle by rows) in SM_S, outside the overlay, for the triangular solves that follow.
     {
-        double* tmp = g_sm + SM_OVL;
+        double* tmp = g_sm + SM_STMP;
+        double* spk = g_sm + SM_S;
         for (int q = tid; q < MCQ_P_MAX * SLD; q += MCQ_NT) tmp[q] = 0.0;
         __syncthreads();
         if (tid < p) {
@@ -744,7 +755,10 @@ __device__ __forceinline__ int factor_t(const SolveCtx& c, const gdouble* Hsrc, 
             }
         }
         __syncthreads();
-        for (int q = tid; q < MCQ_P_MAX * SLD; q += MCQ_NT) Sm[q] = tmp[q];
+        for (int q = tid; q < MCQ_P_MAX * MCQ_P_MAX; q += MCQ_NT) {
+            const int r = q / MCQ_P_MAX, cc = q - r * MCQ_P_MAX;
+            if (cc <= r) spk[r * (r + 1) / 2 + cc] = tmp[r * SLD + cc];
+        }
         __syncthreads();
     }
     return 0;
@@ -758,13 +772,18 @@ __device__ __noinline__ int factor(const SolveCtx& c, const gdouble* Hsrc, const
 }
 
 // ---- solve  M v = rhs  in place (v in global memory) with the factor produced by factor() ---------------------------
-// Interior triangular sweeps: wave 0 walks the rows in "axpy" form (lane l owns the pending row j == l mod 64, the newest
-// unknown is broadcast with v_readlane, one FMA per lane per row: no reductions on the critical path), reading L rows
-// and right-hand-side values from an LDS chunk ring that waves 1..3 keep filled two chunks ahead (register-staged).
-// A loader item is one double of a chunk: items [0, CH*WLD) = band part of the CH rows, [CH*WLD, CH*WLD+CH) = rhs values.
+// Interior triangular sweeps, one 16-row tile per step on wave 0, no serial per-row chain:
+//   s    = rhs_tile - sum over the 4 previous (next) tiles of L-tile x unknowns      64 lanes = 16 rows x 4 tiles, 16 FMAs
+//          each, two cross-lane adds;
+//   tile = Linv_tile s   (Linv_tile' s backward)                                       16 independent FMAs per lane, operands
+//          broadcast with v_readlane.
+// L rows (64 band entries + the 16 entries of the inverse diagonal tile) and right-hand sides come from an LDS chunk ring
+// (64 rows per chunk) that waves 1..3 keep filled ahead through registers; the same waves fold the border block in:
+// forward they accumulate W'y for t = v_D - W'y, backward they produce the right-hand side y_B - W x_D.
 #define LD_THREADS (MCQ_NT - 64)
-#define LD_ITEMS ((CH * WLD + CH + LD_THREADS - 1) / LD_THREADS)
+#define LD_ITEMS ((CH * CLD + CH + LD_THREADS - 1) / LD_THREADS)
 
+// items [0, CH*CLD): entry m of row r of chunk qL (band entries masked to the band / the matrix), [CH*CLD, +CH): rhs of chunk qR
 __device__ __forceinline__ void chunk_fetch(const gdouble* L, const gdouble* v, int ni, int b, int qL, int qR, int lt,
                                             double* regs)
 {
@@ -772,11 +791,12 @@ __device__ __forceinline__ void chunk_fetch(const gdouble* L, const gdouble* v, 
     for (int u = 0; u < LD_ITEMS; ++u) {
         const int e = lt + u * LD_THREADS;
         double x = 0.0;
-        if (e < CH * WLD) {
-            const int r = qL * CH + e / WLD, k = e % WLD;
-            if (qL >= 0 && r < ni && k <= b) x = L[(size_t)r * MCQ_HLD + k];
-        } else if (e < CH * WLD + CH) {
-            const int r = qR * CH + (e - CH * WLD);
+        if (e < CH * CLD) {
+            const int r = qL * CH + e / CLD, m = e % CLD;
+            const bool ok = (qL >= 0) & (r < ni) & ((m >= MCQ_BH_MAX) | ((m < b) & (m < r)));
+            if (ok) x = L[(size_t)r * MCQ_LLD + m];
+        } else if (e < CH * CLD + CH) {
+            const int r = qR * CH + (e - CH * CLD);
             if (qR >= 0 && r >= 0 && r < ni) x = v[r];
         }
         regs[u] = x;
@@ -788,27 +808,27 @@ __device__ __forceinline__ void chunk_commit(double* chunk, double* rring, int q
 #pragma unroll
     for (int u = 0; u < LD_ITEMS; ++u) {
         const int e = lt + u * LD_THREADS;
-        if (e < CH * WLD) { if (qL >= 0) chunk[(qL % NBUF) * CH * WLD + e] = regs[u]; }
-        else if (e < CH * WLD + CH) { if (qR >= 0) rring[(qR % NRB) * CH + (e - CH * WLD)] = regs[u]; }
+        if (e < CH * CLD) { if (qL >= 0) chunk[(qL % NBUF) * CH * CLD + e] = regs[u]; }
+        else if (e < CH * CLD + CH) { if (qR >= 0) rring[(qR % NRB) * CH + (e - CH * CLD)] = regs[u]; }
     }
 }
 
-#define LROW(r) (chunk + (((r) / CH) % NBUF) * CH * WLD + ((r) % CH) * WLD)
+#define LROW(r) (chunk + (((r) / CH) % NBUF) * CH * CLD + ((r) % CH) * CLD)
 #define RHSV(r) (rring[(((r) / CH) % NRB) * CH + ((r) % CH)])
-
-#define SWG 8                      /* rows per group of a sweep: their LDS reads are issued together */
 #define WROWS ((CH + 2) / 3)       /* W rows of a chunk handled by one loader wave (rows (wv-1) + 3m) */
 
 __device__ __noinline__ void solve(const SolveCtx& c, gdouble* v)
 {
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const int l15 = lane & 15, l4 = lane >> 4;
     const int b = c.d.b, p = c.d.p, ni = c.d.ni;
     const gdouble* L = c.w.L;
-    double* Sm = g_sm + SM_S;      // L_S^-1 (lower triangular, upper part zero)
+    const double* spk = g_sm + SM_S;      // L_S^-1 packed lower triangle
     double* xd = g_sm + SM_XD;
     double* part = g_sm + SM_PART;
     double* chunk = g_sm + SM_CHUNK;
     double* rring = g_sm + SM_RHS;
+    double* vring = g_sm + SM_VR;
     const int nch = (ni + CH - 1) / CH;
     const int lt = tid - 64;      // loader thread id (waves 1..3)
     double regs[LD_ITEMS];
@@ -819,74 +839,70 @@ __device__ __noinline__ void solve(const SolveCtx& c, gdouble* v)
     _Pragma("unroll") for (int m = 0; m < WROWS; ++m) {                                                        \
         const int r_ = (q) * CH + (wv - 1) + 3 * m;                                                            \
         const int rs_ = (r_ >= 0 && r_ < ni) ? r_ : 0;                                                         \
-        wreg[m] = L[(size_t)rs_ * MCQ_HLD + MCQ_HBO + (lane < p ? lane : 0)];                                  \
+        wreg[m] = L[(size_t)rs_ * MCQ_LLD + MCQ_LBW + (lane < p ? lane : 0)];                                  \
         vreg[m] = v[rs_];                                                                                      \
     }
 #define WVALID(q, m) (((wv - 1) + 3 * (m) < CH) && ((q) * CH + (wv - 1) + 3 * (m) < ni) && ((q) >= 0) && lane < p)
 
     __syncthreads();
+    for (int q = tid; q < VRING; q += MCQ_NT) vring[q] = 0.0;
     // ================= forward substitution, interior rows =================
-    // prologue: chunks 0..LA (rows + rhs) resident, chunk LA+1 staged in registers.  Rows >= ni load as zeros (harmless).
+    // a tile needs only its own rows: chunk cq resident, cq+1 committed one step ahead, cq+2 committed during step cq.
     double tacc = 0.0;
     if (wv > 0) {
-        for (int q = 0; q <= LA; ++q) {
+        for (int q = 0; q <= 1; ++q) {
             chunk_fetch(L, v, ni, b, q, q, lt, regs);
             chunk_commit(chunk, rring, q, q, lt, regs);
         }
-        chunk_fetch(L, v, ni, b, LA + 1, LA + 1, lt, regs);
+        chunk_fetch(L, v, ni, b, 2, 2, lt, regs);
     }
     __syncthreads();
-    {
-        double acc = (wv == 0 && lane < ni) ? RHSV(lane) : 0.0;     // lane l owns row l first
-        for (int cq = 0; cq < nch; ++cq) {
-            if (wv == 0) {
-                double ysave = 0.0;
-                for (int i0 = cq * CH; i0 < (cq + 1) * CH; i0 += SWG) {
-                    double dg[SWG], lv[SWG], nr[SWG];
+    for (int cq = 0; cq < nch; ++cq) {
+        if (wv == 0) {
+            for (int J = cq * (CH / TB); J < (cq + 1) * (CH / TB); ++J) {
+                const int i = J * TB + l15;
+                const double* lr = LROW(i);
+                // lane (row l15, group l4) covers source tile K = J - 4 + l4: columns 16K + cc, band offset k = i - column
+                double acc = 0.0;
+                const int kb = TB * (4 - l4) + l15;          // k for cc = 0
+                const int c0 = (J - 4 + l4) * TB;            // first source column (may be negative: entries are masked zeros)
 #pragma unroll
-                    for (int u = 0; u < SWG; ++u) {     // all LDS reads of SWG rows before the dependent chain
-                        const int i = i0 + u;
-                        const int k = ((lane - i - 1) & 63) + 1;
-                        dg[u] = LROW(i)[0];
-                        const double t = LROW(i + k)[k <= b ? k : 0];
-                        lv[u] = k <= b ? t : 0.0;
-                        nr[u] = RHSV(i + 64);
-                    }
+                for (int cc = 0; cc < TB; ++cc) {
+                    const int k = kb - cc;
+                    const double lv = lr[(k <= MCQ_BH_MAX ? k : 1) - 1];
+                    acc += (k <= MCQ_BH_MAX ? lv : 0.0) * vring[(c0 + cc) & (VRING - 1)];
+                }
+                acc += __shfl_xor(acc, 16);
+                acc += __shfl_xor(acc, 32);
+                const double sv = RHSV(i) - acc;
+                double y = 0.0;
 #pragma unroll
-                    for (int u = 0; u < SWG; ++u) {
-                        const int owner = (i0 + u) & 63;
-                        const double yi = bcast_lane(acc, owner) * dg[u];
-                        const bool own = lane == owner;
-                        ysave = own ? yi : ysave;
-                        acc = own ? nr[u] : acc;
-                        acc -= lv[u] * yi;
-                    }
+                for (int cc = 0; cc < TB; ++cc) y += lr[MCQ_BH_MAX + cc] * bcast_lane(sv, cc);     // row l15 of the inverse tile
+                __builtin_amdgcn_wave_barrier();
+                if (l4 == 0) {
+                    vring[i & (VRING - 1)] = y;
+                    RHSV(i) = y;
+                    if (i < ni) v[i] = y;
                 }
-                // the CH unknowns of this chunk sit in lanes (cq*CH .. cq*CH+CH-1) & 63: one coalesced store, and a copy in
-                // the rhs ring for the loader waves' W'y accumulation
-                const int li = cq * CH + ((lane - cq * CH) & 63);
-                if (((lane - cq * CH) & 63) < CH) {
-                    RHSV(li) = ysave;
-                    if (li < ni) v[li] = ysave;
-                }
-            } else {
-                chunk_commit(chunk, rring, cq + LA + 1, cq + LA + 1, lt, regs);
-                chunk_fetch(L, v, ni, b, cq + LA + 2, cq + LA + 2, lt, regs);
-                // border right-hand side, fused: t -= W' y for the rows solved in the previous step (W rows in registers)
-                if (cq >= 1) {
-#pragma unroll
-                    for (int m = 0; m < WROWS; ++m)
-                        if (WVALID(cq - 1, m)) tacc += wreg[m] * RHSV((cq - 1) * CH + (wv - 1) + 3 * m);
-                }
-                WFETCH(cq)
+                __builtin_amdgcn_wave_barrier();
             }
-            lds_barrier();
-        }
-        if (wv > 0 && nch >= 1) {
+        } else {
+            chunk_commit(chunk, rring, cq + 2, cq + 2, lt, regs);
+            chunk_fetch(L, v, ni, b, cq + 3, cq + 3, lt, regs);
+            // border right-hand side, fused: t -= W' y for the rows solved in the previous step (W rows in registers)
+            if (cq >= 1) {
 #pragma unroll
-            for (int m = 0; m < WROWS; ++m)
-                if (WVALID(nch - 1, m)) tacc += wreg[m] * RHSV((nch - 1) * CH + (wv - 1) + 3 * m);
+                for (int m = 0; m < WROWS; ++m)
+                    if (WVALID(cq - 1, m)) tacc += wreg[m] * RHSV((cq - 1) * CH + (wv - 1) + 3 * m);
+            }
+            WFETCH(cq)
         }
+        lds_barrier();
+    }
+    if (wv > 0 && nch >= 1) {
+#pragma unroll
+        for (int m = 0; m < WROWS; ++m)
+            if (WVALID(nch - 1, m)) tacc += wreg[m] * RHSV((nch - 1) * CH + (wv - 1) + 3 * m);
     }
     part[wv * 64 + lane] = tacc;
     __syncthreads();
@@ -900,18 +916,25 @@ __device__ __noinline__ void solve(const SolveCtx& c, gdouble* v)
         xd[lane] = t;
         __builtin_amdgcn_wave_barrier();   // same-wave LDS write -> read (in-order on hardware; ordering point for the compiler)
         double y = 0.0;
-        for (int cc = 0; cc < MCQ_P_MAX; ++cc) y += Sm[(lane < p ? lane : 0) * SLD + cc] * xd[cc];
+        for (int cc = 0; cc < MCQ_P_MAX; ++cc) {
+            const double a = spk[lane * (lane + 1) / 2 + (cc <= lane ? cc : 0)];
+            y += (cc <= lane ? a : 0.0) * xd[cc];
+        }
         __builtin_amdgcn_wave_barrier();
         part[lane] = lane < p ? y : 0.0;
         __builtin_amdgcn_wave_barrier();
         double x = 0.0;
-        for (int r = 0; r < MCQ_P_MAX; ++r) x += Sm[r * SLD + lane] * part[r];
+        for (int r = 0; r < MCQ_P_MAX; ++r) {
+            const double a = spk[r * (r + 1) / 2 + (lane <= r ? lane : 0)];
+            x += (lane <= r ? a : 0.0) * part[r];
+        }
         if (lane < p) v[ni + lane] = x;
         xd[lane] = lane < p ? x : 0.0;
     }
     __syncthreads();
+    for (int q = tid; q < VRING; q += MCQ_NT) vring[q] = 0.0;
     // ================= backward substitution, interior rows (descending) =================
-    // row i needs only its own L row; the owner of row i takes row i-64 next -> rhs chunks lead the row chunks by LA.
+    // tile J needs the band entries of the rows of tiles J+1..J+4 (the chunk processed before) and its own inverse tile.
     // The loader waves produce the right-hand side of a chunk as  y_B - W x_D  (W rows fetched one step ahead, 64-wide
     // dot products reduced in the wave) and write it straight into the rhs ring.
 #define RHS_REDUCE_STORE(q)                                                                                    \
@@ -932,53 +955,44 @@ __device__ __noinline__ void solve(const SolveCtx& c, gdouble* v)
         if (wv > 0) {
             chunk_fetch(L, v, ni, b, cl, -1, lt, regs);
             chunk_commit(chunk, rring, cl, -1, lt, regs);
-            for (int q = cl; q >= cl - LA; --q) {
-                WFETCH(q)
-                RHS_REDUCE_STORE(q)
-            }
+            WFETCH(cl)
+            RHS_REDUCE_STORE(cl)
             chunk_fetch(L, v, ni, b, cl - 1, -1, lt, regs);
-            WFETCH(cl - LA - 1)
+            WFETCH(cl - 1)
         }
         __syncthreads();
-        // lane l first owns the largest row j <= nch*CH-1 with j == l (mod 64)  (rows >= ni are zero rows: x = 0)
-        const int top = nch * CH - 1;
-        const int j0 = top - ((top - lane) & 63);
-        double acc = (wv == 0 && j0 >= 0) ? RHSV(j0) : 0.0;
         for (int cq = cl; cq >= 0; --cq) {
             if (wv == 0) {
-                double xsave = 0.0;
-                for (int i0 = (cq + 1) * CH - 1; i0 >= cq * CH; i0 -= SWG) {
-                    double dg[SWG], lv[SWG], nr[SWG];
+                for (int J = (cq + 1) * (CH / TB) - 1; J >= cq * (CH / TB); --J) {
+                    const int j = J * TB + l15;               // unknown handled by this lane's row group
+                    // lane (column l15, group l4) covers the rows of tile K = J + 1 + l4: i = 16K + rr, offset k = i - j
+                    double acc = 0.0;
+                    const int i0 = (J + 1 + l4) * TB;
+                    const int kb = TB * (l4 + 1) - l15;       // k for rr = 0
 #pragma unroll
-                    for (int u = 0; u < SWG; ++u) {
-                        const int i = i0 - u;
-                        const double* lr = LROW(i);
-                        const int k = ((i - 1 - lane) & 63) + 1;
-                        const bool ok = (k <= b) & (k <= i);
-                        dg[u] = lr[0];
-                        const double t = lr[ok ? k : 0];
-                        lv[u] = ok ? t : 0.0;
-                        const int jn = i - 64;
-                        const double r = RHSV(jn >= 0 ? jn : 0);
-                        nr[u] = jn >= 0 ? r : 0.0;
+                    for (int rr = 0; rr < TB; ++rr) {
+                        const int k = kb + rr;
+                        const double lv = LROW(i0 + rr)[(k <= MCQ_BH_MAX ? k : 1) - 1];
+                        acc += (k <= MCQ_BH_MAX ? lv : 0.0) * vring[(i0 + rr) & (VRING - 1)];
                     }
+                    acc += __shfl_xor(acc, 16);
+                    acc += __shfl_xor(acc, 32);
+                    const double sv = RHSV(j) - acc;
+                    double x = 0.0;
 #pragma unroll
-                    for (int u = 0; u < SWG; ++u) {
-                        const int owner = (i0 - u) & 63;
-                        const double xi = bcast_lane(acc, owner) * dg[u];
-                        const bool own = lane == owner;
-                        xsave = own ? xi : xsave;
-                        acc = own ? nr[u] : acc;
-                        acc -= lv[u] * xi;
+                    for (int rr = 0; rr < TB; ++rr) x += LROW(J * TB + rr)[MCQ_BH_MAX + l15] * bcast_lane(sv, rr);   // column l15 of the inverse tile
+                    __builtin_amdgcn_wave_barrier();
+                    if (l4 == 0) {
+                        vring[j & (VRING - 1)] = x;
+                        if (j < ni) v[j] = x;
                     }
+                    __builtin_amdgcn_wave_barrier();
                 }
-                const int li = cq * CH + ((lane - cq * CH) & 63);
-                if (((lane - cq * CH) & 63) < CH && li < ni) v[li] = xsave;
             } else {
                 chunk_commit(chunk, rring, cq - 1, -1, lt, regs);
                 chunk_fetch(L, v, ni, b, cq - 2, -1, lt, regs);
-                RHS_REDUCE_STORE(cq - LA - 1)
-                WFETCH(cq - LA - 2)
+                RHS_REDUCE_STORE(cq - 1)
+                WFETCH(cq - 2)
             }
             lds_barrier();
         }
