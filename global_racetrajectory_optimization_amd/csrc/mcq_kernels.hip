@@ -781,36 +781,63 @@ __device__ __noinline__ int factor(const SolveCtx& c, const gdouble* Hsrc, const
 // (64 rows per chunk) that waves 1..3 keep filled ahead through registers; the same waves fold the border block in:
 // forward they accumulate W'y for t = v_D - W'y, backward they produce the right-hand side y_B - W x_D.
 #define LD_THREADS (MCQ_NT - 64)
-#define LD_ITEMS ((CH * CLD + CH + LD_THREADS - 1) / LD_THREADS)
+#define LD_PAIRS (CH * CLD / 2)                                 /* 16-byte items of a chunk's L rows */
+#define LD_ITEMS ((LD_PAIRS + LD_THREADS - 1) / LD_THREADS)
+typedef double d2 __attribute__((vector_size(16)));
+typedef __attribute__((address_space(1))) d2 gd2;
 
-// items [0, CH*CLD): entry m of row r of chunk qL (band entries masked to the band / the matrix), [CH*CLD, +CH): rhs of chunk qR
+// Loader item u of thread lt: the 16-byte pair e2 = lt + u * LD_THREADS of the chunk image (row e2 / 40, doubles
+// 2 (e2 % 40) ..+1 of the 80-double LDS row); the chunk image in LDS is the linear array of these pairs.  `goff[u]` (row *
+// MCQ_LLD + column, precomputed once per solve) makes the steady-state fetch one add + one global_load_dwordx4 per item.
+// Generic path (first chunk, last chunk, narrow bands): band entries that do not exist (column < 0, beyond the band,
+// rows >= ni) are zeroed.
 __device__ __forceinline__ void chunk_fetch(const gdouble* L, const gdouble* v, int ni, int b, int qL, int qR, int lt,
-                                            double* regs)
+                                            const int* goff, d2* regs, double& rreg)
 {
+    const bool fast = (qL >= 1) & ((qL + 1) * CH <= ni) & (b == MCQ_BH_MAX);
+    if (fast) {
+        const gdouble* base = L + (size_t)qL * CH * MCQ_LLD;
 #pragma unroll
-    for (int u = 0; u < LD_ITEMS; ++u) {
-        const int e = lt + u * LD_THREADS;
-        double x = 0.0;
-        if (e < CH * CLD) {
-            const int r = qL * CH + e / CLD, m = e % CLD;
-            const bool ok = (qL >= 0) & (r < ni) & ((m >= MCQ_BH_MAX) | ((m < b) & (m < r)));
-            if (ok) x = L[(size_t)r * MCQ_LLD + m];
-        } else if (e < CH * CLD + CH) {
-            const int r = qR * CH + (e - CH * CLD);
-            if (qR >= 0 && r >= 0 && r < ni) x = v[r];
+        for (int u = 0; u < LD_ITEMS; ++u) {
+            const int e2 = lt + u * LD_THREADS;
+            regs[u] = (e2 < LD_PAIRS) ? *(const gd2*)(base + goff[u]) : (d2){0.0, 0.0};
         }
-        regs[u] = x;
+    } else {
+#pragma unroll
+        for (int u = 0; u < LD_ITEMS; ++u) {
+            const int e2 = lt + u * LD_THREADS;
+            d2 x = {0.0, 0.0};
+            if (e2 < LD_PAIRS && qL >= 0) {
+                const int r = qL * CH + e2 / (CLD / 2), m = 2 * (e2 % (CLD / 2));
+                if (r < ni) {
+                    x = *(const gd2*)(L + (size_t)r * MCQ_LLD + m);
+                    if (m < MCQ_BH_MAX) {
+                        if (!((m < b) & (m < r))) x[0] = 0.0;
+                        if (!((m + 1 < b) & (m + 1 < r))) x[1] = 0.0;
+                    }
+                }
+            }
+            regs[u] = x;
+        }
+    }
+    rreg = 0.0;
+    if (lt < CH && qR >= 0) {
+        const int r = qR * CH + lt;
+        if (r < ni) rreg = v[r];
     }
 }
 
-__device__ __forceinline__ void chunk_commit(double* chunk, double* rring, int qL, int qR, int lt, const double* regs)
+__device__ __forceinline__ void chunk_commit(double* chunk, double* rring, int qL, int qR, int lt, const d2* regs, double rreg)
 {
+    if (qL >= 0) {
+        d2* dst = (d2*)(chunk + (qL % NBUF) * CH * CLD);
 #pragma unroll
-    for (int u = 0; u < LD_ITEMS; ++u) {
-        const int e = lt + u * LD_THREADS;
-        if (e < CH * CLD) { if (qL >= 0) chunk[(qL % NBUF) * CH * CLD + e] = regs[u]; }
-        else if (e < CH * CLD + CH) { if (qR >= 0) rring[(qR % NRB) * CH + (e - CH * CLD)] = regs[u]; }
+        for (int u = 0; u < LD_ITEMS; ++u) {
+            const int e2 = lt + u * LD_THREADS;
+            if (e2 < LD_PAIRS) dst[e2] = regs[u];
+        }
     }
+    if (lt < CH && qR >= 0) rring[(qR % NRB) * CH + lt] = rreg;
 }
 
 #define LROW(r) (chunk + (((r) / CH) % NBUF) * CH * CLD + ((r) % CH) * CLD)
@@ -831,16 +858,33 @@ __device__ __noinline__ void solve(const SolveCtx& c, gdouble* v)
     double* vring = g_sm + SM_VR;
     const int nch = (ni + CH - 1) / CH;
     const int lt = tid - 64;      // loader thread id (waves 1..3)
-    double regs[LD_ITEMS];
+    d2 regs[LD_ITEMS];
+    double rreg = 0.0;
+    int goff[LD_ITEMS];
+#pragma unroll
+    for (int u = 0; u < LD_ITEMS; ++u) {
+        const int e2 = (lt >= 0 ? lt : 0) + u * LD_THREADS;
+        goff[u] = (e2 / (CLD / 2)) * MCQ_LLD + 2 * (e2 % (CLD / 2));
+    }
     double wreg[WROWS], vreg[WROWS];
 
     // W rows (wv-1) + 3m of chunk q for this loader wave: raw loads at clamped addresses, masked when used
 #define WFETCH(q)                                                                                              \
-    _Pragma("unroll") for (int m = 0; m < WROWS; ++m) {                                                        \
-        const int r_ = (q) * CH + (wv - 1) + 3 * m;                                                            \
-        const int rs_ = (r_ >= 0 && r_ < ni) ? r_ : 0;                                                         \
-        wreg[m] = L[(size_t)rs_ * MCQ_LLD + MCQ_LBW + (lane < p ? lane : 0)];                                  \
-        vreg[m] = v[rs_];                                                                                      \
+    if ((q) >= 0 && ((q) + 1) * CH <= ni && p == MCQ_P_MAX) {                                                  \
+        const gdouble* wb_ = L + ((size_t)(q) * CH + (wv - 1)) * MCQ_LLD + MCQ_LBW + lane;                     \
+        const gdouble* vb_ = v + (q) * CH + (wv - 1);                                                          \
+        _Pragma("unroll") for (int m = 0; m < WROWS; ++m) {                                                    \
+            const int ms_ = ((wv - 1) + 3 * m < CH) ? m : 0;                                                   \
+            wreg[m] = wb_[(size_t)ms_ * 3 * MCQ_LLD];                                                          \
+            vreg[m] = vb_[ms_ * 3];                                                                            \
+        }                                                                                                      \
+    } else {                                                                                                   \
+        _Pragma("unroll") for (int m = 0; m < WROWS; ++m) {                                                    \
+            const int r_ = (q) * CH + (wv - 1) + 3 * m;                                                        \
+            const int rs_ = (r_ >= 0 && r_ < ni) ? r_ : 0;                                                     \
+            wreg[m] = L[(size_t)rs_ * MCQ_LLD + MCQ_LBW + (lane < p ? lane : 0)];                              \
+            vreg[m] = v[rs_];                                                                                  \
+        }                                                                                                      \
     }
 #define WVALID(q, m) (((wv - 1) + 3 * (m) < CH) && ((q) * CH + (wv - 1) + 3 * (m) < ni) && ((q) >= 0) && lane < p)
 
@@ -851,10 +895,10 @@ __device__ __noinline__ void solve(const SolveCtx& c, gdouble* v)
     double tacc = 0.0;
     if (wv > 0) {
         for (int q = 0; q <= 1; ++q) {
-            chunk_fetch(L, v, ni, b, q, q, lt, regs);
-            chunk_commit(chunk, rring, q, q, lt, regs);
+            chunk_fetch(L, v, ni, b, q, q, lt, goff, regs, rreg);
+            chunk_commit(chunk, rring, q, q, lt, regs, rreg);
         }
-        chunk_fetch(L, v, ni, b, 2, 2, lt, regs);
+        chunk_fetch(L, v, ni, b, 2, 2, lt, goff, regs, rreg);
     }
     __syncthreads();
     for (int cq = 0; cq < nch; ++cq) {
@@ -887,8 +931,8 @@ __device__ __noinline__ void solve(const SolveCtx& c, gdouble* v)
                 __builtin_amdgcn_wave_barrier();
             }
         } else {
-            chunk_commit(chunk, rring, cq + 2, cq + 2, lt, regs);
-            chunk_fetch(L, v, ni, b, cq + 3, cq + 3, lt, regs);
+            chunk_commit(chunk, rring, cq + 2, cq + 2, lt, regs, rreg);
+            chunk_fetch(L, v, ni, b, cq + 3, cq + 3, lt, goff, regs, rreg);
             // border right-hand side, fused: t -= W' y for the rows solved in the previous step (W rows in registers)
             if (cq >= 1) {
 #pragma unroll
@@ -953,11 +997,11 @@ __device__ __noinline__ void solve(const SolveCtx& c, gdouble* v)
     if (nch > 0) {
         const int cl = nch - 1;
         if (wv > 0) {
-            chunk_fetch(L, v, ni, b, cl, -1, lt, regs);
-            chunk_commit(chunk, rring, cl, -1, lt, regs);
+            chunk_fetch(L, v, ni, b, cl, -1, lt, goff, regs, rreg);
+            chunk_commit(chunk, rring, cl, -1, lt, regs, rreg);
             WFETCH(cl)
             RHS_REDUCE_STORE(cl)
-            chunk_fetch(L, v, ni, b, cl - 1, -1, lt, regs);
+            chunk_fetch(L, v, ni, b, cl - 1, -1, lt, goff, regs, rreg);
             WFETCH(cl - 1)
         }
         __syncthreads();
@@ -989,8 +1033,8 @@ __device__ __noinline__ void solve(const SolveCtx& c, gdouble* v)
                     __builtin_amdgcn_wave_barrier();
                 }
             } else {
-                chunk_commit(chunk, rring, cq - 1, -1, lt, regs);
-                chunk_fetch(L, v, ni, b, cq - 2, -1, lt, regs);
+                chunk_commit(chunk, rring, cq - 1, -1, lt, regs, rreg);
+                chunk_fetch(L, v, ni, b, cq - 2, -1, lt, goff, regs, rreg);
                 RHS_REDUCE_STORE(cq - 1)
                 WFETCH(cq - 2)
             }
