@@ -437,6 +437,7 @@ struct SolveCtx {
 #define CTILE(I, a) (ct + ((((I) % NTR) * NCT) + (a)) * TSZ)
 #define ROW_ITEMS (TB * (NTR * TB + MCQ_P_MAX))            /* 16 x 144 doubles per tile row */
 #define PF_ITEMS ((ROW_ITEMS + MCQ_NT - 1) / MCQ_NT)
+#define PF_BAND_ITEMS ((TB * NTR * TB) / MCQ_NT)          /* 1280 / 256 = 5: the band entries are exactly items u < 5 */
 
 // Raw (un-decoded) loads of one window entry: kept in registers while the loads are in flight, decoded when the entry is
 // committed to LDS -- nothing between fetch and commit depends on the loaded values, so no s_waitcnt is placed early.
@@ -552,16 +553,110 @@ __device__ __forceinline__ int factor_t(const SolveCtx& c, const gdouble* Hsrc, 
     if (tid == 0) dinv[TB] = 0.0;   // fail flag
     __syncthreads();
 
+    // Software-pipelined block loop.  The critical path of one step is  diag(J) -> panel(J) -> update of block column J+1;
+    // everything else that step J-1 owes (16 border tiles, 10 Schur tiles, 6 band tiles, the write-out of L / W / the
+    // inverse tile) runs on waves 1..3 WHILE wave 0 factors the next diagonal tile:
+    //   phase 1   wave 0: diag(J)                         | waves 1..3: lag(J-1) = border/Schur/band updates + write-out
+    //   phase 2   waves 0,1: panel(J) (L rows, W columns)  | wave 2 (16 lanes): inverse of the diagonal tile | all: commit
+    //             the tile row that was fetched during the previous step into the slots lag(J-1) just released
+    //   phase 3   all waves: the four tiles of block column J+1
     int fail = 0;
+    const int wl = w0 - 1;           // lag-worker index of waves 1..3
+#define LAG_WORK(P)                                                                                                    \
+    {                                                                                                                  \
+        /* border tiles  C(P+dI, a) -= L(P+dI, P) W_P(a) */                                                            \
+        _Pragma("unroll") for (int t_ = 0; t_ < 16; ++t_) {                                                            \
+            if (t_ % 3 != wl) continue;                                                                                \
+            const int dI_ = 1 + t_ / NCT, a_ = t_ % NCT;                                                               \
+            const double* li_ = BTILE((P) + dI_, (P));                                                                 \
+            const double* wa_ = CTILE((P), a_);                                                                        \
+            double* ct_ = CTILE((P) + dI_, a_);                                                                        \
+            double av_[4], bv_[4];                                                                                     \
+            _Pragma("unroll") for (int kc = 0; kc < 4; ++kc) {                                                         \
+                av_[kc] = -li_[l15 * TLD + l4 + 4 * kc];                                                               \
+                bv_[kc] = wa_[(l4 + 4 * kc) * TLD + l15];                                                              \
+            }                                                                                                          \
+            v4d acc_;                                                                                                  \
+            _Pragma("unroll") for (int r = 0; r < 4; ++r) acc_[r] = ct_[(l4 + 4 * r) * TLD + l15];                     \
+            acc_ = mfma16(av_, bv_, acc_);                                                                             \
+            _Pragma("unroll") for (int r = 0; r < 4; ++r) ct_[(l4 + 4 * r) * TLD + l15] = acc_[r];                     \
+        }                                                                                                              \
+        /* Schur tiles (lower)  S(a, bb) -= W_P(a)' W_P(bb),  kept in registers */                                    \
+        {                                                                                                              \
+            int t_ = 0;                                                                                                \
+            _Pragma("unroll") for (int a_ = 0; a_ < NCT; ++a_) {                                                       \
+                _Pragma("unroll") for (int bb_ = 0; bb_ <= a_; ++bb_, ++t_) {                                          \
+                    if (t_ % 3 != wl) continue;                                                                        \
+                    const double* wa_ = CTILE((P), a_);                                                                \
+                    const double* wb_ = CTILE((P), bb_);                                                               \
+                    double av_[4], bv_[4];                                                                             \
+                    _Pragma("unroll") for (int kc = 0; kc < 4; ++kc) {                                                 \
+                        av_[kc] = -wa_[(l4 + 4 * kc) * TLD + l15];                                                     \
+                        bv_[kc] = wb_[(l4 + 4 * kc) * TLD + l15];                                                      \
+                    }                                                                                                  \
+                    sacc[t_ / 3] = mfma16(av_, bv_, sacc[t_ / 3]);                                                     \
+                }                                                                                                      \
+            }                                                                                                          \
+        }                                                                                                              \
+        /* band tiles not in block column P+1:  T(P+dI, P+dK) -= L(P+dI,P) L(P+dK,P)',  2 <= dK <= dI <= 4 */          \
+        {                                                                                                              \
+            int t_ = 0;                                                                                                \
+            _Pragma("unroll") for (int dK_ = 2; dK_ < NTR; ++dK_) {                                                    \
+                _Pragma("unroll") for (int dI_ = dK_; dI_ < NTR; ++dI_, ++t_) {                                        \
+                    if (t_ % 3 != wl) continue;                                                                        \
+                    const double* li_ = BTILE((P) + dI_, (P));                                                         \
+                    const double* lk_ = BTILE((P) + dK_, (P));                                                         \
+                    double* tt_ = BTILE((P) + dI_, (P) + dK_);                                                         \
+                    double av_[4], bv_[4];                                                                             \
+                    _Pragma("unroll") for (int kc = 0; kc < 4; ++kc) {                                                 \
+                        av_[kc] = -li_[l15 * TLD + l4 + 4 * kc];                                                       \
+                        bv_[kc] = lk_[l15 * TLD + l4 + 4 * kc];                                                        \
+                    }                                                                                                  \
+                    v4d acc_;                                                                                          \
+                    _Pragma("unroll") for (int r = 0; r < 4; ++r) acc_[r] = tt_[(l4 + 4 * r) * TLD + l15];             \
+                    acc_ = mfma16(av_, bv_, acc_);                                                                     \
+                    _Pragma("unroll") for (int r = 0; r < 4; ++r) tt_[(l4 + 4 * r) * TLD + l15] = acc_[r];             \
+                }                                                                                                      \
+            }                                                                                                          \
+        }                                                                                                              \
+        /* write-out of block column P of L, the inverse diagonal tile and block row P of W (192 threads) */           \
+        for (int q = tid - 64; q < NTR * TB * TB; q += MCQ_NT - 64) {                                                  \
+            const int tI = q / (TB * TB), rem = q - tI * TB * TB;                                                      \
+            const int rr = rem / TB, cc = rem - rr * TB;                                                               \
+            const int i = ((P) + tI) * TB + rr;                                                                        \
+            const int k = tI * TB + rr - cc;                                                                           \
+            /* tI = 0 (entries inside the diagonal tile) is skipped: the sweeps use the inverse tile instead */       \
+            if (tI >= 1 && i < ni && k <= MCQ_BH_MAX) L[(size_t)i * MCQ_LLD + (k - 1)] = BTILE((P) + tI, (P))[rr * TLD + cc]; \
+        }                                                                                                              \
+        for (int q = tid - 64; q < TB * (TB + MCQ_P_MAX); q += MCQ_NT - 64) {                                          \
+            const int rr = q / (TB + MCQ_P_MAX), e = q - rr * (TB + MCQ_P_MAX);                                        \
+            const int i = (P) * TB + rr;                                                                               \
+            if (i < ni) {                                                                                              \
+                const double v_ = (e < TB) ? linv[rr * TLD + e] : CTILE((P), (e - TB) / TB)[rr * TLD + ((e - TB) % TB)]; \
+                L[(size_t)i * MCQ_LLD + MCQ_LBI + e] = v_;                                                             \
+            }                                                                                                          \
+        }                                                                                                              \
+    }
+
     for (int J = 0; J < nblk; ++J) {
-        // prefetch tile row J + NTR (stays in flight until the end of this step)
+        // fetch tile row J + NTR (committed in phase 2 of the NEXT step: a full step in flight)
+        RawEntry pfn[PF_ITEMS];
 #pragma unroll
         for (int u = 0; u < PF_ITEMS; ++u) {
             const int q = tid + u * MCQ_NT;
-            pf[u] = tile_row_fetch<MK, SIG>(H, sig, mk, ni, b, p, J + NTR, q < ROW_ITEMS ? q : 0);
+            pfn[u] = tile_row_fetch<MK, SIG>(H, sig, mk, ni, b, p, J + NTR, q < ROW_ITEMS ? q : 0);
         }
         long long tp = TICK();
-        // ---- phase 1: diagonal tile, wave 0; lane r (= lane & 15) keeps row r in 16 registers -------------------------
+        // ---- phase 1 --------------------------------------------------------------------------------------------------------
+        // band part of tile row J-1+NTR (fetched during the previous step; items u < 5 are exactly the 16 x 80 band entries):
+        // its slots -- tile row J-1 of the band window -- were last read by panel(J-1); panel(J) needs tile (J+4, J).
+        if (J > 0) {
+#pragma unroll
+            for (int u = 0; u < PF_BAND_ITEMS; ++u) {
+                const int q = tid + u * MCQ_NT;
+                tile_row_store(bt, ct, J - 1 + NTR, q, tile_row_decode<MK, SIG>(pf[u], ni, b, p, J - 1 + NTR, q));
+            }
+        }
         if (w0 == 0) {
             double* d0 = BTILE(J, J);
             double a[TB];
@@ -583,12 +678,23 @@ __device__ __forceinline__ int factor_t(const SolveCtx& c, const gdouble* Hsrc, 
                 for (int cc = 0; cc < TB; ++cc) d0[lane * TLD + cc] = (cc <= lane) ? a[cc] : 0.0;
             }
             if (bad && lane == 0) dinv[TB] = 1.0;
+        } else if (J > 0) {
+            LAG_WORK(J - 1)
         }
         lds_barrier();
         c.tk[4] += TICK() - tp; tp = TICK();
         if (dinv[TB] != 0.0) { fail = 1; break; }
-        // ---- phase 2: panel.  lanes 0..63: rows of L below the diagonal tile; lanes 64..127: columns of W = L00^-1 C;
-        //      lanes 128..143: columns of L00^-1 itself (right-hand side e_c) -- the triangular sweeps multiply with it
+        // ---- phase 2 --------------------------------------------------------------------------------------------------------
+        // border part of that tile row: its slots held W_(J-1), released by lag(J-1) in phase 1
+        if (J > 0) {
+#pragma unroll
+            for (int u = PF_BAND_ITEMS; u < PF_ITEMS; ++u) {
+                const int q = tid + u * MCQ_NT;
+                tile_row_store(bt, ct, J - 1 + NTR, q, tile_row_decode<MK, SIG>(pf[u], ni, b, p, J - 1 + NTR, q < ROW_ITEMS ? q : 0));
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < PF_ITEMS; ++u) pf[u] = pfn[u];
         if (tid < 128 + TB) {
             const double* d0 = BTILE(J, J);
             double* base;
@@ -610,108 +716,59 @@ __device__ __forceinline__ int factor_t(const SolveCtx& c, const gdouble* Hsrc, 
         }
         lds_barrier();
         c.tk[5] += TICK() - tp; tp = TICK();
-        // ---- emit block column J of L, the inverse diagonal tile and block row J of W to HBM --------------------------------
-        for (int q = tid; q < NTR * TB * TB; q += MCQ_NT) {
-            const int tI = q / (TB * TB), rem = q - tI * TB * TB;
-            const int rr = rem / TB, cc = rem - rr * TB;
-            const int i = (J + tI) * TB + rr;
-            const int k = tI * TB + rr - cc;
-            if (i < ni && k >= 1 && k <= MCQ_BH_MAX) L[(size_t)i * MCQ_LLD + (k - 1)] = BTILE(J + tI, J)[rr * TLD + cc];
-        }
-        for (int q = tid; q < TB * (TB + MCQ_P_MAX); q += MCQ_NT) {
-            const int rr = q / (TB + MCQ_P_MAX), e = q - rr * (TB + MCQ_P_MAX);
-            const int i = J * TB + rr;
-            if (i < ni) {
-                const double v = (e < TB) ? linv[rr * TLD + e] : CTILE(J, (e - TB) / TB)[rr * TLD + ((e - TB) % TB)];
-                L[(size_t)i * MCQ_LLD + MCQ_LBI + e] = v;      // [LBI .. LBI+15] inverse tile row, [LBW ..] = LBI + 16 + jj
-            }
-        }
-        c.tk[6] += TICK() - tp; tp = TICK();
-        // ---- phase 3: rank-16 trailing update on the matrix cores ----------------------------------------------------------
+        // ---- phase 3: block column J+1, one tile per wave:  T(J+1+w, J+1) -= L(J+1+w, J) L(J+1, J)' ---------------------------
         {
-            // operands of this wave's border column a = w0:  W_blk tile a in "direct" form  B[k][j] = W[k][16a + j]
-            const double* wa = CTILE(J, w0);
-            double wdir[4], wneg[4];
+            const double* li = BTILE(J + 1 + w0, J);
+            const double* lk = BTILE(J + 1, J);
+            double* tt = BTILE(J + 1 + w0, J + 1);
+            double av[4], bv[4];
 #pragma unroll
-            for (int kc = 0; kc < 4; ++kc) { wdir[kc] = wa[(l4 + 4 * kc) * TLD + l15]; wneg[kc] = -wdir[kc]; }
-            // (c) Schur tiles  S[a][bb] -= W_a' W_bb
-#pragma unroll
-            for (int bb = 0; bb < NCT; ++bb) {
-                const double* wb = CTILE(J, bb);
-                double bv[4];
-#pragma unroll
-                for (int kc = 0; kc < 4; ++kc) bv[kc] = wb[(l4 + 4 * kc) * TLD + l15];
-                sacc[bb] = mfma16(wneg, bv, sacc[bb]);
+            for (int kc = 0; kc < 4; ++kc) {
+                av[kc] = -li[l15 * TLD + l4 + 4 * kc];
+                bv[kc] = lk[l15 * TLD + l4 + 4 * kc];
             }
-            // (b) border tiles  C(I, a) -= L(I,J) W_a
+            v4d acc;
 #pragma unroll
-            for (int dI = 1; dI < NTR; ++dI) {
-                const double* li = BTILE(J + dI, J);
-                double* ctile = CTILE(J + dI, w0);
-                double av[4];
+            for (int r = 0; r < 4; ++r) acc[r] = tt[(l4 + 4 * r) * TLD + l15];
+            acc = mfma16(av, bv, acc);
 #pragma unroll
-                for (int kc = 0; kc < 4; ++kc) av[kc] = -li[l15 * TLD + l4 + 4 * kc];
-                v4d acc;
-#pragma unroll
-                for (int r = 0; r < 4; ++r) acc[r] = ctile[(l4 + 4 * r) * TLD + l15];
-                acc = mfma16(av, wdir, acc);
-#pragma unroll
-                for (int r = 0; r < 4; ++r) ctile[(l4 + 4 * r) * TLD + l15] = acc[r];
-            }
-            // (a) band tiles  T(I,K) -= L(I,J) L(K,J)',  J < K <= I <= J+4: ten tiles dealt round-robin to the waves
-            int t = 0;
-#pragma unroll
-            for (int dK = 1; dK < NTR; ++dK) {
-#pragma unroll
-                for (int dI = dK; dI < NTR; ++dI, ++t) {
-                    if ((t & (MCQ_NW - 1)) != w0) continue;
-                    const double* li = BTILE(J + dI, J);
-                    const double* lk = BTILE(J + dK, J);
-                    double* tt = BTILE(J + dI, J + dK);
-                    double av[4], bv[4];
-#pragma unroll
-                    for (int kc = 0; kc < 4; ++kc) {
-                        av[kc] = -li[l15 * TLD + l4 + 4 * kc];
-                        bv[kc] = lk[l15 * TLD + l4 + 4 * kc];
-                    }
-                    v4d acc;
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) acc[r] = tt[(l4 + 4 * r) * TLD + l15];
-                    acc = mfma16(av, bv, acc);
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) tt[(l4 + 4 * r) * TLD + l15] = acc[r];
-                }
-            }
-        }
-        lds_barrier();
-        // ---- the prefetched tile row takes the slots of tile row J (dead now) ------------------------------------------------
-#pragma unroll
-        for (int u = 0; u < PF_ITEMS; ++u) {
-            const int q = tid + u * MCQ_NT;
-            tile_row_store(bt, ct, J + NTR, q, tile_row_decode<MK, SIG>(pf[u], ni, b, p, J + NTR, q < ROW_ITEMS ? q : 0));
+            for (int r = 0; r < 4; ++r) tt[(l4 + 4 * r) * TLD + l15] = acc[r];
         }
         lds_barrier();
         c.tk[7] += TICK() - tp;
     }
     if (fail) return MCQ_NOT_PD;
+    // drain: what the last step still owes
+    if (w0 > 0 && nblk > 0) LAG_WORK(nblk - 1)
+#undef LAG_WORK
+    lds_barrier();
 
     // ---- Schur complement of the border: S = D - W'W (accumulated above), dense Cholesky in LDS -----------------------
     __syncthreads();
+    for (int q = tid; q < MCQ_P_MAX * SLD; q += MCQ_NT) Sm[q] = 0.0;
+    __syncthreads();
+    if (w0 > 0) {
+        int t = 0;
 #pragma unroll
-    for (int bb = 0; bb < NCT; ++bb) {
+        for (int a = 0; a < NCT; ++a) {
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            const int j1 = TB * w0 + l4 + 4 * r, j2 = TB * bb + l15;
-            double v = 0.0;
-            if (j1 < p && j2 < p) {
-                const bool pj = MK && (mk[ni + j1] != 0 || mk[ni + j2] != 0);
-                if (pj) v = (j1 == j2) ? 1.0 : 0.0;
-                else {
-                    v = H[(size_t)(ni + j1) * MCQ_HLD + MCQ_HBO + j2] + sacc[bb][r];
-                    if (SIG && j1 == j2) v += sig[ni + j1];
+            for (int bb = 0; bb <= a; ++bb, ++t) {
+                if (t % 3 != wl) continue;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int j1 = TB * a + l4 + 4 * r, j2 = TB * bb + l15;
+                    double v = 0.0;
+                    if (j1 < p && j2 < p) {
+                        const bool pj = MK && (mk[ni + j1] != 0 || mk[ni + j2] != 0);
+                        if (pj) v = (j1 == j2) ? 1.0 : 0.0;
+                        else {
+                            v = H[(size_t)(ni + j1) * MCQ_HLD + MCQ_HBO + j2] + sacc[t / 3][r];
+                            if (SIG && j1 == j2) v += sig[ni + j1];
+                        }
+                    }
+                    Sm[j1 * SLD + j2] = v;
                 }
             }
-            Sm[j1 * SLD + j2] = v;
         }
     }
     __syncthreads();
