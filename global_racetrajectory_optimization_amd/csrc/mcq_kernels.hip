@@ -562,78 +562,134 @@ __device__ __forceinline__ int factor_t(const SolveCtx& c, const gdouble* Hsrc, 
     //   phase 3   all waves: the four tiles of block column J+1
     int fail = 0;
     const int wl = w0 - 1;           // lag-worker index of waves 1..3
+    // Tile ownership of the three lag waves (wl = 0..2):
+    //   border tiles C(P+dI, a): column a = wl for dI = 1..4, plus one tile of column 3 (dI = wl + 1); wave 0 also (4, 3)
+    //   Schur tiles (lower, 10): t % 3 == wl;    band tiles (6): t % 3 == wl
+    // All LDS operand / accumulator reads of a group are issued before its MFMAs, all writes after them.
 #define LAG_WORK(P)                                                                                                    \
     {                                                                                                                  \
-        /* border tiles  C(P+dI, a) -= L(P+dI, P) W_P(a) */                                                            \
-        _Pragma("unroll") for (int t_ = 0; t_ < 16; ++t_) {                                                            \
-            if (t_ % 3 != wl) continue;                                                                                \
-            const int dI_ = 1 + t_ / NCT, a_ = t_ % NCT;                                                               \
-            const double* li_ = BTILE((P) + dI_, (P));                                                                 \
-            const double* wa_ = CTILE((P), a_);                                                                        \
-            double* ct_ = CTILE((P) + dI_, a_);                                                                        \
-            double av_[4], bv_[4];                                                                                     \
-            _Pragma("unroll") for (int kc = 0; kc < 4; ++kc) {                                                         \
-                av_[kc] = -li_[l15 * TLD + l4 + 4 * kc];                                                               \
-                bv_[kc] = wa_[(l4 + 4 * kc) * TLD + l15];                                                              \
-            }                                                                                                          \
-            v4d acc_;                                                                                                  \
-            _Pragma("unroll") for (int r = 0; r < 4; ++r) acc_[r] = ct_[(l4 + 4 * r) * TLD + l15];                     \
-            acc_ = mfma16(av_, bv_, acc_);                                                                             \
-            _Pragma("unroll") for (int r = 0; r < 4; ++r) ct_[(l4 + 4 * r) * TLD + l15] = acc_[r];                     \
-        }                                                                                                              \
-        /* Schur tiles (lower)  S(a, bb) -= W_P(a)' W_P(bb),  kept in registers */                                    \
+        /* ---- border tiles: C(P+dI, a) -= L(P+dI, P) W_P(a) ---- */                                                  \
         {                                                                                                              \
+            double la_[4][4], wa_[4], w3_[4];                                                                          \
+            v4d cacc_[4], c3a_, c3b_;                                                                                  \
+            const double* wt_ = CTILE((P), wl);                                                                        \
+            const double* w3t_ = CTILE((P), 3);                                                                        \
+            _Pragma("unroll") for (int kc = 0; kc < 4; ++kc) {                                                         \
+                wa_[kc] = wt_[(l4 + 4 * kc) * TLD + l15];                                                              \
+                w3_[kc] = w3t_[(l4 + 4 * kc) * TLD + l15];                                                             \
+            }                                                                                                          \
+            _Pragma("unroll") for (int dI_ = 1; dI_ < NTR; ++dI_) {                                                    \
+                const double* li_ = BTILE((P) + dI_, (P));                                                             \
+                const double* ctl_ = CTILE((P) + dI_, wl);                                                             \
+                _Pragma("unroll") for (int kc = 0; kc < 4; ++kc) la_[dI_ - 1][kc] = -li_[l15 * TLD + l4 + 4 * kc];     \
+                _Pragma("unroll") for (int r = 0; r < 4; ++r) cacc_[dI_ - 1][r] = ctl_[(l4 + 4 * r) * TLD + l15];      \
+            }                                                                                                          \
+            {                                                                                                          \
+                const double* c3p_ = CTILE((P) + wl + 1, 3);                                                           \
+                const double* c3q_ = CTILE((P) + 4, 3);                                                                \
+                _Pragma("unroll") for (int r = 0; r < 4; ++r) {                                                        \
+                    c3a_[r] = c3p_[(l4 + 4 * r) * TLD + l15];                                                          \
+                    c3b_[r] = c3q_[(l4 + 4 * r) * TLD + l15];                                                          \
+                }                                                                                                      \
+            }                                                                                                          \
+            _Pragma("unroll") for (int dI_ = 1; dI_ < NTR; ++dI_) cacc_[dI_ - 1] = mfma16(la_[dI_ - 1], wa_, cacc_[dI_ - 1]); \
+            c3a_ = mfma16(la_[wl], w3_, c3a_);                                                                         \
+            if (wl == 0) c3b_ = mfma16(la_[3], w3_, c3b_);                                                             \
+            _Pragma("unroll") for (int dI_ = 1; dI_ < NTR; ++dI_) {                                                    \
+                double* ctl_ = CTILE((P) + dI_, wl);                                                                   \
+                _Pragma("unroll") for (int r = 0; r < 4; ++r) ctl_[(l4 + 4 * r) * TLD + l15] = cacc_[dI_ - 1][r];      \
+            }                                                                                                          \
+            {                                                                                                          \
+                double* c3p_ = CTILE((P) + wl + 1, 3);                                                                 \
+                double* c3q_ = CTILE((P) + 4, 3);                                                                      \
+                _Pragma("unroll") for (int r = 0; r < 4; ++r) {                                                        \
+                    c3p_[(l4 + 4 * r) * TLD + l15] = c3a_[r];                                                          \
+                    if (wl == 0) c3q_[(l4 + 4 * r) * TLD + l15] = c3b_[r];                                             \
+                }                                                                                                      \
+            }                                                                                                          \
+            /* ---- band tiles not in block column P+1:  T(P+dI, P+dK) -= L(P+dI,P) L(P+dK,P)',  2 <= dK <= dI <= 4; the   \
+                    row-form operand of L(P+dI, P) is la_[dI-1] (negated), the column-form operand of L(P+dK, P) is the    \
+                    same register pattern un-negated ---- */                                                              \
+            {                                                                                                          \
+                v4d bacc_[2];                                                                                          \
+                int t_ = 0, s_ = 0;                                                                                    \
+                _Pragma("unroll") for (int dK_ = 2; dK_ < NTR; ++dK_) {                                                \
+                    _Pragma("unroll") for (int dI_ = dK_; dI_ < NTR; ++dI_, ++t_) {                                    \
+                        if (t_ % 3 != wl) continue;                                                                    \
+                        const double* tt_ = BTILE((P) + dI_, (P) + dK_);                                               \
+                        _Pragma("unroll") for (int r = 0; r < 4; ++r) bacc_[s_][r] = tt_[(l4 + 4 * r) * TLD + l15];    \
+                        ++s_;                                                                                          \
+                    }                                                                                                  \
+                }                                                                                                      \
+                t_ = 0; s_ = 0;                                                                                        \
+                _Pragma("unroll") for (int dK_ = 2; dK_ < NTR; ++dK_) {                                                \
+                    _Pragma("unroll") for (int dI_ = dK_; dI_ < NTR; ++dI_, ++t_) {                                    \
+                        if (t_ % 3 != wl) continue;                                                                    \
+                        double bv_[4];                                                                                 \
+                        _Pragma("unroll") for (int kc = 0; kc < 4; ++kc) bv_[kc] = -la_[dK_ - 1][kc];                  \
+                        bacc_[s_] = mfma16(la_[dI_ - 1], bv_, bacc_[s_]);                                              \
+                        ++s_;                                                                                          \
+                    }                                                                                                  \
+                }                                                                                                      \
+                t_ = 0; s_ = 0;                                                                                        \
+                _Pragma("unroll") for (int dK_ = 2; dK_ < NTR; ++dK_) {                                                \
+                    _Pragma("unroll") for (int dI_ = dK_; dI_ < NTR; ++dI_, ++t_) {                                    \
+                        if (t_ % 3 != wl) continue;                                                                    \
+                        double* tt_ = BTILE((P) + dI_, (P) + dK_);                                                     \
+                        _Pragma("unroll") for (int r = 0; r < 4; ++r) tt_[(l4 + 4 * r) * TLD + l15] = bacc_[s_][r];    \
+                        ++s_;                                                                                          \
+                    }                                                                                                  \
+                }                                                                                                      \
+            }                                                                                                          \
+        }                                                                                                              \
+        /* ---- Schur tiles (lower)  S(a, bb) -= W_P(a)' W_P(bb),  kept in registers ---- */                           \
+        {                                                                                                              \
+            double wv_[NCT][4];                                                                                        \
+            _Pragma("unroll") for (int a_ = 0; a_ < NCT; ++a_) {                                                       \
+                const double* wa2_ = CTILE((P), a_);                                                                   \
+                _Pragma("unroll") for (int kc = 0; kc < 4; ++kc) wv_[a_][kc] = wa2_[(l4 + 4 * kc) * TLD + l15];        \
+            }                                                                                                          \
             int t_ = 0;                                                                                                \
             _Pragma("unroll") for (int a_ = 0; a_ < NCT; ++a_) {                                                       \
                 _Pragma("unroll") for (int bb_ = 0; bb_ <= a_; ++bb_, ++t_) {                                          \
                     if (t_ % 3 != wl) continue;                                                                        \
-                    const double* wa_ = CTILE((P), a_);                                                                \
-                    const double* wb_ = CTILE((P), bb_);                                                               \
-                    double av_[4], bv_[4];                                                                             \
-                    _Pragma("unroll") for (int kc = 0; kc < 4; ++kc) {                                                 \
-                        av_[kc] = -wa_[(l4 + 4 * kc) * TLD + l15];                                                     \
-                        bv_[kc] = wb_[(l4 + 4 * kc) * TLD + l15];                                                      \
-                    }                                                                                                  \
-                    sacc[t_ / 3] = mfma16(av_, bv_, sacc[t_ / 3]);                                                     \
+                    double av_[4];                                                                                     \
+                    _Pragma("unroll") for (int kc = 0; kc < 4; ++kc) av_[kc] = -wv_[a_][kc];                           \
+                    sacc[t_ / 3] = mfma16(av_, wv_[bb_], sacc[t_ / 3]);                                                \
                 }                                                                                                      \
             }                                                                                                          \
         }                                                                                                              \
-        /* band tiles not in block column P+1:  T(P+dI, P+dK) -= L(P+dI,P) L(P+dK,P)',  2 <= dK <= dI <= 4 */          \
+        /* ---- write-out of block column P of L (tiles below the diagonal one), the inverse diagonal tile and block row P  \
+                of W: 192 threads, fixed trip counts, LDS reads batched before the stores ---- */                         \
         {                                                                                                              \
-            int t_ = 0;                                                                                                \
-            _Pragma("unroll") for (int dK_ = 2; dK_ < NTR; ++dK_) {                                                    \
-                _Pragma("unroll") for (int dI_ = dK_; dI_ < NTR; ++dI_, ++t_) {                                        \
-                    if (t_ % 3 != wl) continue;                                                                        \
-                    const double* li_ = BTILE((P) + dI_, (P));                                                         \
-                    const double* lk_ = BTILE((P) + dK_, (P));                                                         \
-                    double* tt_ = BTILE((P) + dI_, (P) + dK_);                                                         \
-                    double av_[4], bv_[4];                                                                             \
-                    _Pragma("unroll") for (int kc = 0; kc < 4; ++kc) {                                                 \
-                        av_[kc] = -li_[l15 * TLD + l4 + 4 * kc];                                                       \
-                        bv_[kc] = lk_[l15 * TLD + l4 + 4 * kc];                                                        \
-                    }                                                                                                  \
-                    v4d acc_;                                                                                          \
-                    _Pragma("unroll") for (int r = 0; r < 4; ++r) acc_[r] = tt_[(l4 + 4 * r) * TLD + l15];             \
-                    acc_ = mfma16(av_, bv_, acc_);                                                                     \
-                    _Pragma("unroll") for (int r = 0; r < 4; ++r) tt_[(l4 + 4 * r) * TLD + l15] = acc_[r];             \
-                }                                                                                                      \
+            const int lt_ = tid - 64;                                                                                  \
+            double ev_[6];                                                                                             \
+            _Pragma("unroll") for (int m_ = 0; m_ < 6; ++m_) {                                                         \
+                const int q = lt_ + m_ * (MCQ_NT - 64);                                                                \
+                const int qs = q < 4 * TB * TB ? q : 0;                                                                \
+                ev_[m_] = BTILE((P) + 1 + qs / (TB * TB), (P))[((qs / TB) % TB) * TLD + (qs % TB)];                    \
             }                                                                                                          \
-        }                                                                                                              \
-        /* write-out of block column P of L, the inverse diagonal tile and block row P of W (192 threads) */           \
-        for (int q = tid - 64; q < NTR * TB * TB; q += MCQ_NT - 64) {                                                  \
-            const int tI = q / (TB * TB), rem = q - tI * TB * TB;                                                      \
-            const int rr = rem / TB, cc = rem - rr * TB;                                                               \
-            const int i = ((P) + tI) * TB + rr;                                                                        \
-            const int k = tI * TB + rr - cc;                                                                           \
-            /* tI = 0 (entries inside the diagonal tile) is skipped: the sweeps use the inverse tile instead */       \
-            if (tI >= 1 && i < ni && k <= MCQ_BH_MAX) L[(size_t)i * MCQ_LLD + (k - 1)] = BTILE((P) + tI, (P))[rr * TLD + cc]; \
-        }                                                                                                              \
-        for (int q = tid - 64; q < TB * (TB + MCQ_P_MAX); q += MCQ_NT - 64) {                                          \
-            const int rr = q / (TB + MCQ_P_MAX), e = q - rr * (TB + MCQ_P_MAX);                                        \
-            const int i = (P) * TB + rr;                                                                               \
-            if (i < ni) {                                                                                              \
-                const double v_ = (e < TB) ? linv[rr * TLD + e] : CTILE((P), (e - TB) / TB)[rr * TLD + ((e - TB) % TB)]; \
-                L[(size_t)i * MCQ_LLD + MCQ_LBI + e] = v_;                                                             \
+            _Pragma("unroll") for (int m_ = 0; m_ < 6; ++m_) {                                                         \
+                const int q = lt_ + m_ * (MCQ_NT - 64);                                                                \
+                const int tI = 1 + q / (TB * TB), rr = (q / TB) % TB, cc = q % TB;                                     \
+                const int i = ((P) + tI) * TB + rr, k = tI * TB + rr - cc;                                             \
+                if (q < 4 * TB * TB && i < ni && k <= MCQ_BH_MAX) L[(size_t)i * MCQ_LLD + (k - 1)] = ev_[m_];          \
+            }                                                                                                          \
+            double fv_[7];                                                                                             \
+            _Pragma("unroll") for (int m_ = 0; m_ < 7; ++m_) {                                                         \
+                const int q = lt_ + m_ * (MCQ_NT - 64);                                                                \
+                const int qs = q < TB * (TB + MCQ_P_MAX) ? q : 0;                                                      \
+                const int rr = qs / (TB + MCQ_P_MAX), e = qs - rr * (TB + MCQ_P_MAX);                                  \
+                const int es = e < TB ? 0 : e - TB;                                                                    \
+                const double a1_ = linv[rr * TLD + (e < TB ? e : 0)];                                                  \
+                const double a2_ = CTILE((P), es / TB)[rr * TLD + (es % TB)];                                          \
+                fv_[m_] = e < TB ? a1_ : a2_;                                                                          \
+            }                                                                                                          \
+            _Pragma("unroll") for (int m_ = 0; m_ < 7; ++m_) {                                                         \
+                const int q = lt_ + m_ * (MCQ_NT - 64);                                                                \
+                const int rr = q / (TB + MCQ_P_MAX), e = q - rr * (TB + MCQ_P_MAX);                                    \
+                const int i = (P) * TB + rr;                                                                           \
+                if (q < TB * (TB + MCQ_P_MAX) && i < ni) L[(size_t)i * MCQ_LLD + MCQ_LBI + e] = fv_[m_];               \
             }                                                                                                          \
         }                                                                                                              \
     }
