@@ -33,22 +33,35 @@ KAPPA_BOUND, W_VEH = 0.12, 3.4
 def algorithmic_bytes(n, info, band_e=32, refine_steps=2):
     """Algorithmic HBM bytes of mcq_solve_kernel for one launch ('banded-exact' mode).
 
-    Per problem with b = p = 2*band_e (interior band / border width), row = (b + 1 + p) doubles of H or L:
-      factorisation : read H rows + write L rows                      2 * n * row * 8
-      solve         : forward + backward sweep, each reads L rows     2 * n * row * 8
-      gradient      : E band + E' band, (2*band_e+1) doubles per row  2 * n * (2*band_e+1) * 8
+    Row sizes as stored (csrc/mcq_kernels.h): H row 130 doubles (65 band | pad | 64 border), L row 144 doubles
+    (64 band | 16 inverse-diagonal-tile | 64 border W), E / E' bands 65 doubles per row.
+      factorisation : read the H rows + write the L rows               n * (1040 + 1152) B
+      solve         : forward + backward sweep, each reads the L rows  2 * n * 1152 B
+      gradient      : E band + E' band                                 2 * n * 65 * 8 B
     IPM iteration = 1 factorisation + 2 solves + 1 gradient; active-set iteration = 1 factorisation + 1 solve +
     2 gradients; refinement round = 1 solve + 1 gradient; + 1 initial gradient + 3 band products in the epilogue.
     Iteration counts are the ones the solver reports (mcq_info).
     """
-    row = (2 * band_e + 1 + 2 * band_e) * 8.0
-    fac = 2.0 * n * row
-    sol = 2.0 * n * row
+    fac = n * (130.0 + 144.0) * 8.0
+    sol = 2.0 * n * 144.0 * 8.0
     grad = 2.0 * n * (2 * band_e + 1) * 8.0
     ipm = info["ipm_iters"].astype(np.float64)
     act = info["as_iters"].astype(np.float64)
     per = ipm * (fac + 2 * sol + grad) + act * (fac + sol + 2 * grad) + refine_steps * (sol + grad) + grad + 1.5 * grad
     return float(per.sum())
+
+
+def measured_traffic():
+    """HBM traffic of mcq_solve_kernel per launch from the committed rocprofv3 PMC passes (profiles/latest_pmc.json,
+    written by scripts/pmc_summary.py: separate --pmc FETCH_SIZE / WRITE_SIZE runs of this same command, KiB units,
+    FETCH_SIZE doubled per the gfx950 note of MI355X_MICROARCH.md).  None if no profile is committed."""
+    path = os.path.join(ROOT, "profiles", "latest_pmc.json")
+    try:
+        with open(path) as fh:
+            k = json.load(fh)["kernels"]["mcq_solve_kernel"]
+        return float(k["traffic_bytes"])
+    except Exception:
+        return None
 
 
 def cpu_baseline(ref, nv, sc):
@@ -162,7 +175,7 @@ def main():
                        "solver_phase_ms_per_problem": {k: float(info["ticks"][:, j].mean()) / 1e5 for j, k in
                                                        enumerate(("factor", "solve", "gradient", "kernel", "f_diag", "f_panel", "f_emit", "f_trail"))}},
             "roofline": {"bound": "hbm", "kernel": "mcq_solve_kernel", "achieved": achieved, "peak": HBM_PEAK_GBS,
-                         "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                         "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": measured_traffic(),
                          "algorithmic_bytes_per_launch": alg, "kernel_ms": k_ms},
         }
         if world == 1 and not args.no_cpu_baseline:
