@@ -28,13 +28,13 @@ typedef double v4d __attribute__((vector_size(32)));   /* accumulator fragment o
 #define SM_PART (SM_XD + 64)
 #define SM_S (SM_PART + MCQ_NW * 64)              /* L_S^-1, packed rows: entry (r, c <= r) at r (r + 1) / 2 + c */
 #define SM_OVL (SM_S + SPK)                       /* overlay region */
-#define OVL_SIZE_F (NTR * NTR * TSZ + NTR * NCT * TSZ + TSZ + 32)
+#define OVL_SIZE_F (NTR * NTR * TSZ + NTR * NCT * TSZ + 2 * TSZ + 32)
 #define OVL_SIZE_S (NBUF * CH * CLD + NRB * CH + VRING)
 #define OVL_SIZE (OVL_SIZE_F > OVL_SIZE_S ? OVL_SIZE_F : OVL_SIZE_S)
 #define SM_BT SM_OVL                              /* band tiles   (NTR x NTR) */
 #define SM_CT (SM_BT + NTR * NTR * TSZ)           /* border tiles (NTR x NCT) */
-#define SM_LINV (SM_CT + NTR * NCT * TSZ)         /* inverse of the current diagonal tile */
-#define SM_DINV (SM_LINV + TSZ)                   /* 16 reciprocal pivots of the current diagonal tile + fail flag */
+#define SM_LINV (SM_CT + NTR * NCT * TSZ)         /* inverses of the current and the previous diagonal tile (by step parity) */
+#define SM_DINV (SM_LINV + 2 * TSZ)                   /* 16 reciprocal pivots of the current diagonal tile + fail flag */
 #define SM_SFULL SM_OVL                           /* 64 x 65 work area of the dense border factorisation (tiles are dead then) */
 #define SM_STMP (SM_SFULL + MCQ_P_MAX * SLD)
 #define SM_CHUNK SM_OVL                           /* NBUF x CH x CLD */
@@ -566,6 +566,23 @@ __device__ __forceinline__ int factor_t(const SolveCtx& c, const gdouble* Hsrc, 
     //   border tiles C(P+dI, a): column a = wl for dI = 1..4, plus one tile of column 3 (dI = wl + 1); wave 0 also (4, 3)
     //   Schur tiles (lower, 10): t % 3 == wl;    band tiles (6): t % 3 == wl
     // All LDS operand / accumulator reads of a group are issued before its MFMAs, all writes after them.
+#define S_HEAD(P)                                                                                                      \
+    {                                                                                                                  \
+        double wv_[3][4];                                                                                              \
+        _Pragma("unroll") for (int a_ = 0; a_ < 3; ++a_) {                                                             \
+            const double* wa2_ = CTILE((P), a_);                                                                       \
+            _Pragma("unroll") for (int kc = 0; kc < 4; ++kc) wv_[a_][kc] = wa2_[(l4 + 4 * kc) * TLD + l15];            \
+        }                                                                                                              \
+        int t_ = 0;                                                                                                    \
+        _Pragma("unroll") for (int a_ = 0; a_ < 3; ++a_) {                                                             \
+            _Pragma("unroll") for (int bb_ = 0; bb_ <= a_; ++bb_, ++t_) {                                              \
+                if (t_ >= 4) continue;                                                                                 \
+                double av_[4];                                                                                         \
+                _Pragma("unroll") for (int kc = 0; kc < 4; ++kc) av_[kc] = -wv_[a_][kc];                               \
+                sacc[t_] = mfma16(av_, wv_[bb_], sacc[t_]);                                                            \
+            }                                                                                                          \
+        }                                                                                                              \
+    }
 #define LAG_WORK(P)                                                                                                    \
     {                                                                                                                  \
         /* ---- border tiles: C(P+dI, a) -= L(P+dI, P) W_P(a) ---- */                                                  \
@@ -652,44 +669,54 @@ __device__ __forceinline__ int factor_t(const SolveCtx& c, const gdouble* Hsrc, 
             int t_ = 0;                                                                                                \
             _Pragma("unroll") for (int a_ = 0; a_ < NCT; ++a_) {                                                       \
                 _Pragma("unroll") for (int bb_ = 0; bb_ <= a_; ++bb_, ++t_) {                                          \
-                    if (t_ % 3 != wl) continue;                                                                        \
+                    if (t_ < 4 || (t_ - 4) % 3 != wl) continue;                                                        \
                     double av_[4];                                                                                     \
                     _Pragma("unroll") for (int kc = 0; kc < 4; ++kc) av_[kc] = -wv_[a_][kc];                           \
-                    sacc[t_ / 3] = mfma16(av_, wv_[bb_], sacc[t_ / 3]);                                                \
+                    sacc[(t_ - 4) / 3] = mfma16(av_, wv_[bb_], sacc[(t_ - 4) / 3]);                                    \
                 }                                                                                                      \
             }                                                                                                          \
         }                                                                                                              \
-        /* ---- write-out of block column P of L (tiles below the diagonal one), the inverse diagonal tile and block row P  \
-                of W: 192 threads, fixed trip counts, LDS reads batched before the stores ---- */                         \
-        {                                                                                                              \
-            const int lt_ = tid - 64;                                                                                  \
-            double ev_[6];                                                                                             \
-            _Pragma("unroll") for (int m_ = 0; m_ < 6; ++m_) {                                                         \
-                const int q = lt_ + m_ * (MCQ_NT - 64);                                                                \
-                const int qs = q < 4 * TB * TB ? q : 0;                                                                \
-                ev_[m_] = BTILE((P) + 1 + qs / (TB * TB), (P))[((qs / TB) % TB) * TLD + (qs % TB)];                    \
+    }
+
+    // Write-out of block column P of L (tiles below the diagonal one; the sweeps use the inverse tile instead of the
+    // entries inside the diagonal tile), of the inverse diagonal tile and of block row P of W: 64 threads (the wave that is
+    // idle during the panel phase), fixed trip counts, LDS reads batched before the stores.  Reads the inverse tile of step P
+    // from its own buffer (linv is double-buffered by step parity).
+#define WO_T 64
+#define WO_L ((4 * TB * TB) / WO_T)
+#define WO_W ((TB * (TB + MCQ_P_MAX)) / WO_T)
+#define WRITE_OUT(P)                                                                                                   \
+    {                                                                                                                  \
+        const double* lv_ = linv + ((P) & 1) * TSZ;                                                                    \
+        const int lt_ = lane;                                                                                          \
+        _Pragma("unroll") for (int h_ = 0; h_ < 2; ++h_) {                                                             \
+            double ev_[WO_L / 2];                                                                                      \
+            _Pragma("unroll") for (int m_ = 0; m_ < WO_L / 2; ++m_) {                                                  \
+                const int q = lt_ + (m_ + h_ * (WO_L / 2)) * WO_T;                                                     \
+                ev_[m_] = BTILE((P) + 1 + q / (TB * TB), (P))[((q / TB) % TB) * TLD + (q % TB)];                       \
             }                                                                                                          \
-            _Pragma("unroll") for (int m_ = 0; m_ < 6; ++m_) {                                                         \
-                const int q = lt_ + m_ * (MCQ_NT - 64);                                                                \
+            _Pragma("unroll") for (int m_ = 0; m_ < WO_L / 2; ++m_) {                                                  \
+                const int q = lt_ + (m_ + h_ * (WO_L / 2)) * WO_T;                                                     \
                 const int tI = 1 + q / (TB * TB), rr = (q / TB) % TB, cc = q % TB;                                     \
                 const int i = ((P) + tI) * TB + rr, k = tI * TB + rr - cc;                                             \
-                if (q < 4 * TB * TB && i < ni && k <= MCQ_BH_MAX) L[(size_t)i * MCQ_LLD + (k - 1)] = ev_[m_];          \
+                if (i < ni && k <= MCQ_BH_MAX) L[(size_t)i * MCQ_LLD + (k - 1)] = ev_[m_];                             \
             }                                                                                                          \
-            double fv_[7];                                                                                             \
-            _Pragma("unroll") for (int m_ = 0; m_ < 7; ++m_) {                                                         \
-                const int q = lt_ + m_ * (MCQ_NT - 64);                                                                \
-                const int qs = q < TB * (TB + MCQ_P_MAX) ? q : 0;                                                      \
-                const int rr = qs / (TB + MCQ_P_MAX), e = qs - rr * (TB + MCQ_P_MAX);                                  \
+        }                                                                                                              \
+        _Pragma("unroll") for (int h_ = 0; h_ < 2; ++h_) {                                                             \
+            double fv_[WO_W / 2];                                                                                      \
+            _Pragma("unroll") for (int m_ = 0; m_ < WO_W / 2; ++m_) {                                                  \
+                const int q = lt_ + (m_ + h_ * (WO_W / 2)) * WO_T;                                                     \
+                const int rr = q / (TB + MCQ_P_MAX), e = q - rr * (TB + MCQ_P_MAX);                                    \
                 const int es = e < TB ? 0 : e - TB;                                                                    \
-                const double a1_ = linv[rr * TLD + (e < TB ? e : 0)];                                                  \
+                const double a1_ = lv_[rr * TLD + (e < TB ? e : 0)];                                                   \
                 const double a2_ = CTILE((P), es / TB)[rr * TLD + (es % TB)];                                          \
                 fv_[m_] = e < TB ? a1_ : a2_;                                                                          \
             }                                                                                                          \
-            _Pragma("unroll") for (int m_ = 0; m_ < 7; ++m_) {                                                         \
-                const int q = lt_ + m_ * (MCQ_NT - 64);                                                                \
+            _Pragma("unroll") for (int m_ = 0; m_ < WO_W / 2; ++m_) {                                                  \
+                const int q = lt_ + (m_ + h_ * (WO_W / 2)) * WO_T;                                                     \
                 const int rr = q / (TB + MCQ_P_MAX), e = q - rr * (TB + MCQ_P_MAX);                                    \
                 const int i = (P) * TB + rr;                                                                           \
-                if (q < TB * (TB + MCQ_P_MAX) && i < ni) L[(size_t)i * MCQ_LLD + MCQ_LBI + e] = fv_[m_];               \
+                if (i < ni) L[(size_t)i * MCQ_LLD + MCQ_LBI + e] = fv_[m_];                                            \
             }                                                                                                          \
         }                                                                                                              \
     }
@@ -734,6 +761,7 @@ __device__ __forceinline__ int factor_t(const SolveCtx& c, const gdouble* Hsrc, 
                 for (int cc = 0; cc < TB; ++cc) d0[lane * TLD + cc] = (cc <= lane) ? a[cc] : 0.0;
             }
             if (bad && lane == 0) dinv[TB] = 1.0;
+            if (J > 0) { S_HEAD(J - 1) }      // wave 0's share of the lag work: four Schur tiles
         } else if (J > 0) {
             LAG_WORK(J - 1)
         }
@@ -741,16 +769,7 @@ __device__ __forceinline__ int factor_t(const SolveCtx& c, const gdouble* Hsrc, 
         c.tk[4] += TICK() - tp; tp = TICK();
         if (dinv[TB] != 0.0) { fail = 1; break; }
         // ---- phase 2 --------------------------------------------------------------------------------------------------------
-        // border part of that tile row: its slots held W_(J-1), released by lag(J-1) in phase 1
-        if (J > 0) {
-#pragma unroll
-            for (int u = PF_BAND_ITEMS; u < PF_ITEMS; ++u) {
-                const int q = tid + u * MCQ_NT;
-                tile_row_store(bt, ct, J - 1 + NTR, q, tile_row_decode<MK, SIG>(pf[u], ni, b, p, J - 1 + NTR, q < ROW_ITEMS ? q : 0));
-            }
-        }
-#pragma unroll
-        for (int u = 0; u < PF_ITEMS; ++u) pf[u] = pfn[u];
+        if (w0 == MCQ_NW - 1 && J > 0) { WRITE_OUT(J - 1) }     // the wave that has no panel work writes step J-1 out
         if (tid < 128 + TB) {
             const double* d0 = BTILE(J, J);
             double* base;
@@ -758,7 +777,7 @@ __device__ __forceinline__ int factor_t(const SolveCtx& c, const gdouble* Hsrc, 
             double x[TB];
             if (tid < 64) { base = BTILE(J + 1 + tid / TB, J) + (tid % TB) * TLD; stride = 1; }
             else if (tid < 128) { const int jj = tid - 64; base = CTILE(J, jj / TB) + (jj % TB); stride = TLD; }
-            else { base = linv + (tid - 128); stride = TLD; }
+            else { base = linv + (J & 1) * TSZ + (tid - 128); stride = TLD; }
 #pragma unroll
             for (int cc = 0; cc < TB; ++cc) x[cc] = (tid < 128) ? base[cc * stride] : ((cc == tid - 128) ? 1.0 : 0.0);
 #pragma unroll
@@ -790,26 +809,46 @@ __device__ __forceinline__ int factor_t(const SolveCtx& c, const gdouble* Hsrc, 
 #pragma unroll
             for (int r = 0; r < 4; ++r) tt[(l4 + 4 * r) * TLD + l15] = acc[r];
         }
+        // border part of the tile row fetched during the previous step: its slots held W_(J-1), which lag(J-1) (phase 1)
+        // and the write-out of step J-1 (phase 2) have released; first used by lag(J) in the next step
+        if (J > 0) {
+#pragma unroll
+            for (int u = PF_BAND_ITEMS; u < PF_ITEMS; ++u) {
+                const int q = tid + u * MCQ_NT;
+                tile_row_store(bt, ct, J - 1 + NTR, q, tile_row_decode<MK, SIG>(pf[u], ni, b, p, J - 1 + NTR, q < ROW_ITEMS ? q : 0));
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < PF_ITEMS; ++u) pf[u] = pfn[u];
         lds_barrier();
         c.tk[7] += TICK() - tp;
     }
     if (fail) return MCQ_NOT_PD;
     // drain: what the last step still owes
-    if (w0 > 0 && nblk > 0) LAG_WORK(nblk - 1)
+    if (nblk > 0) {
+        if (w0 == 0) { S_HEAD(nblk - 1) }
+        else { LAG_WORK(nblk - 1) }
+        if (w0 == MCQ_NW - 1) { WRITE_OUT(nblk - 1) }
+    }
 #undef LAG_WORK
+#undef S_HEAD
+#undef WRITE_OUT
     lds_barrier();
 
     // ---- Schur complement of the border: S = D - W'W (accumulated above), dense Cholesky in LDS -----------------------
     __syncthreads();
     for (int q = tid; q < MCQ_P_MAX * SLD; q += MCQ_NT) Sm[q] = 0.0;
     __syncthreads();
-    if (w0 > 0) {
+    {
         int t = 0;
 #pragma unroll
         for (int a = 0; a < NCT; ++a) {
 #pragma unroll
             for (int bb = 0; bb <= a; ++bb, ++t) {
-                if (t % 3 != wl) continue;
+                // tiles 0..3 live in wave 0, tile t >= 4 in lag wave (t - 4) % 3, register slot (t - 4) / 3
+                const bool mine = (t < 4) ? (w0 == 0) : (w0 > 0 && (t - 4) % 3 == wl);
+                if (!mine) continue;
+                const int slot = t < 4 ? t : (t - 4) / 3;
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
                     const int j1 = TB * a + l4 + 4 * r, j2 = TB * bb + l15;
@@ -818,7 +857,7 @@ __device__ __forceinline__ int factor_t(const SolveCtx& c, const gdouble* Hsrc, 
                         const bool pj = MK && (mk[ni + j1] != 0 || mk[ni + j2] != 0);
                         if (pj) v = (j1 == j2) ? 1.0 : 0.0;
                         else {
-                            v = H[(size_t)(ni + j1) * MCQ_HLD + MCQ_HBO + j2] + sacc[t / 3][r];
+                            v = H[(size_t)(ni + j1) * MCQ_HLD + MCQ_HBO + j2] + sacc[slot][r];
                             if (SIG && j1 == j2) v += sig[ni + j1];
                         }
                     }
