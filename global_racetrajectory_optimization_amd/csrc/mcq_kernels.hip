@@ -421,6 +421,11 @@ struct SolveCtx {
     mutable long long tk[8];   // phase timers (wall_clock64 ticks), meaningful on thread 0
 };
 #define TICK() ((long long)wall_clock64())
+// fine-grained timers inside the factorisation (ticks[4..7]) cost an s_waitcnt per sample in the hot loop: off by default
+#ifndef MCQ_FINE_TIMERS
+#define MCQ_FINE_TIMERS 0
+#endif
+#define FTICK() (MCQ_FINE_TIMERS ? TICK() : 0LL)
 
 // ---- bordered-band Cholesky of  M = H + diag(sig)  with rows/cols of pinned variables replaced by identity ----------
 // Blocked right-looking factorisation, 16 columns per step, on an LDS window of 5 x 5 band tiles + 5 x 4 border tiles:
@@ -464,7 +469,7 @@ __device__ __forceinline__ RawEntry tile_row_fetch(const gdouble* H, const gdoub
         const int cs = in ? c : 0, is = in ? i : 0;
         e.h = H[(size_t)cs * MCQ_HLD + (valid ? k : 0)];
         if (MK) { e.m0 = mk[cs]; e.m1 = mk[is]; }
-        if (SIG) e.sg = sig[cs];
+        if (SIG && k == 0) e.sg = sig[cs];      // the diagonal shift only touches the 16 diagonal entries of a tile row
     } else {
         const int q2 = q - TB * NTR * TB;
         const int rr = q2 / MCQ_P_MAX, jj = q2 - rr * MCQ_P_MAX;
@@ -547,9 +552,19 @@ __device__ __forceinline__ int factor_t(const SolveCtx& c, const gdouble* Hsrc, 
 
     __syncthreads();
     // prologue: tile rows 0 .. NTR-1
-    for (int R = 0; R < NTR; ++R)
-        for (int q = tid; q < ROW_ITEMS; q += MCQ_NT)
-            tile_row_store(bt, ct, R, q, tile_row_decode<MK, SIG>(tile_row_fetch<MK, SIG>(H, sig, mk, ni, b, p, R, q), ni, b, p, R, q));
+    for (int R = 0; R < NTR; ++R) {
+        // all loads of a tile row are issued before the first decode (one HBM round trip per tile row, not per item)
+#pragma unroll
+        for (int u = 0; u < PF_ITEMS; ++u) {
+            const int q = tid + u * MCQ_NT;
+            pf[u] = tile_row_fetch<MK, SIG>(H, sig, mk, ni, b, p, R, q < ROW_ITEMS ? q : 0);
+        }
+#pragma unroll
+        for (int u = 0; u < PF_ITEMS; ++u) {
+            const int q = tid + u * MCQ_NT;
+            tile_row_store(bt, ct, R, q, tile_row_decode<MK, SIG>(pf[u], ni, b, p, R, q < ROW_ITEMS ? q : 0));
+        }
+    }
     if (tid == 0) dinv[TB] = 0.0;   // fail flag
     __syncthreads();
 
@@ -729,7 +744,7 @@ __device__ __forceinline__ int factor_t(const SolveCtx& c, const gdouble* Hsrc, 
             const int q = tid + u * MCQ_NT;
             pfn[u] = tile_row_fetch<MK, SIG>(H, sig, mk, ni, b, p, J + NTR, q < ROW_ITEMS ? q : 0);
         }
-        long long tp = TICK();
+        long long tp = FTICK();
         // ---- phase 1 --------------------------------------------------------------------------------------------------------
         // band part of tile row J-1+NTR (fetched during the previous step; items u < 5 are exactly the 16 x 80 band entries):
         // its slots -- tile row J-1 of the band window -- were last read by panel(J-1); panel(J) needs tile (J+4, J).
@@ -766,7 +781,7 @@ __device__ __forceinline__ int factor_t(const SolveCtx& c, const gdouble* Hsrc, 
             LAG_WORK(J - 1)
         }
         lds_barrier();
-        c.tk[4] += TICK() - tp; tp = TICK();
+        c.tk[4] += FTICK() - tp; tp = FTICK();
         if (dinv[TB] != 0.0) { fail = 1; break; }
         // ---- phase 2 --------------------------------------------------------------------------------------------------------
         if (w0 == MCQ_NW - 1 && J > 0) { WRITE_OUT(J - 1) }     // the wave that has no panel work writes step J-1 out
@@ -790,7 +805,7 @@ __device__ __forceinline__ int factor_t(const SolveCtx& c, const gdouble* Hsrc, 
             for (int cc = 0; cc < TB; ++cc) base[cc * stride] = x[cc];
         }
         lds_barrier();
-        c.tk[5] += TICK() - tp; tp = TICK();
+        c.tk[5] += FTICK() - tp; tp = FTICK();
         // ---- phase 3: block column J+1, one tile per wave:  T(J+1+w, J+1) -= L(J+1+w, J) L(J+1, J)' ---------------------------
         {
             const double* li = BTILE(J + 1 + w0, J);
@@ -821,9 +836,10 @@ __device__ __forceinline__ int factor_t(const SolveCtx& c, const gdouble* Hsrc, 
 #pragma unroll
         for (int u = 0; u < PF_ITEMS; ++u) pf[u] = pfn[u];
         lds_barrier();
-        c.tk[7] += TICK() - tp;
+        c.tk[7] += FTICK() - tp;
     }
     if (fail) return MCQ_NOT_PD;
+    const long long t_tail = FTICK();
     // drain: what the last step still owes
     if (nblk > 0) {
         if (w0 == 0) { S_HEAD(nblk - 1) }
@@ -913,13 +929,15 @@ __device__ __forceinline__ int factor_t(const SolveCtx& c, const gdouble* Hsrc, 
         }
         __syncthreads();
     }
+    c.tk[6] += FTICK() - t_tail;    // drain + border factor + its inverse
     return 0;
 }
 
 __device__ __noinline__ int factor(const SolveCtx& c, const gdouble* Hsrc, const gdouble* sig, const gschar* mk)
 {
-    // the two configurations the solver uses: interior point (diagonal added, fixed variables masked) and active set (mask only)
-    if (sig) return factor_t<true, true>(c, Hsrc, sig, mk);
+    // the configurations the solver uses: interior point (diagonal added; variables with lo == hi masked -- usually there are
+    // none, then no mask bytes are fetched at all) and active set (mask only)
+    if (sig) return mk ? factor_t<true, true>(c, Hsrc, sig, mk) : factor_t<false, true>(c, Hsrc, sig, mk);
     return factor_t<true, false>(c, Hsrc, sig, mk);
 }
 
@@ -1292,6 +1310,9 @@ __device__ __noinline__ int ipm(SolveCtx& c, const McqBatch& B, bool with_kappa,
         __syncthreads();
     }
     const double npairs = 2.0 * sc.nfree + (with_kappa ? 2.0 * n : 0.0);
+    const gschar* const no_mask = nullptr;
+    const bool any_fixed = sc.nfree < (double)n;
+    (void)no_mask;
     if (!(npairs > 0.0)) return MCQ_OK;
 
     for (int it = 1; it <= B.max_ipm_iter; ++it) {
@@ -1333,9 +1354,9 @@ __device__ __noinline__ int ipm(SolveCtx& c, const McqBatch& B, bool with_kappa,
             __syncthreads();
             gram_bordered(c.w.Et, EDA, c.d, nm, nullptr, c.w.H, tid, MCQ_NT);
             __syncthreads();
-            fs = timed_factor(c, c.w.H, SIG, ST);
+            fs = timed_factor(c, c.w.H, SIG, any_fixed ? ST : nullptr);
         } else {
-            fs = timed_factor(c, c.w.H, SIG, ST);
+            fs = timed_factor(c, c.w.H, SIG, any_fixed ? ST : nullptr);
         }
         if (fs != 0) return fs;
 
