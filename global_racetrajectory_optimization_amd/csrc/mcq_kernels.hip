@@ -26,7 +26,7 @@ typedef double v4d __attribute__((vector_size(32)));   /* accumulator fragment o
 #define SM_RED 0
 #define SM_XD (SM_RED + 64)
 #define SM_PART (SM_XD + 64)
-#define SM_S (SM_PART + MCQ_NW * 64)              /* L_S^-1, packed rows: entry (r, c <= r) at r (r + 1) / 2 + c */
+#define SM_S (SM_PART + MCQ_NW * 128)             /* L_S^-1, packed rows: entry (r, c <= r) at r (r + 1) / 2 + c */
 #define SM_OVL (SM_S + SPK)                       /* overlay region */
 #define OVL_SIZE_F (NTR * NTR * TSZ + NTR * NCT * TSZ + 2 * TSZ + 32)
 #define OVL_SIZE_S (NBUF * CH * CLD + NRB * CH + VRING)
@@ -1012,7 +1012,8 @@ __device__ __forceinline__ void chunk_commit(double* chunk, double* rring, int q
 
 #define LROW(r) (chunk + (((r) / CH) % NBUF) * CH * CLD + ((r) % CH) * CLD)
 #define RHSV(r) (rring[(((r) / CH) % NRB) * CH + ((r) % CH)])
-#define WROWS ((CH + 2) / 3)       /* W rows of a chunk handled by one loader wave (rows (wv-1) + 3m) */
+#define NLW (MCQ_NW - 1)                        /* loader waves */
+#define WPAIRS ((CH / 2 + NLW - 1) / NLW)       /* row pairs of a chunk handled by one loader wave */
 
 __device__ __noinline__ void solve(const SolveCtx& c, gdouble* v)
 {
@@ -1036,33 +1037,24 @@ __device__ __noinline__ void solve(const SolveCtx& c, gdouble* v)
         const int e2 = (lt >= 0 ? lt : 0) + u * LD_THREADS;
         goff[u] = (e2 / (CLD / 2)) * MCQ_LLD + 2 * (e2 % (CLD / 2));
     }
-    double wreg[WROWS], vreg[WROWS];
-
-    // W rows (wv-1) + 3m of chunk q for this loader wave: raw loads at clamped addresses, masked when used
+    // Border block W (64 doubles per row): a loader wave reads TWO rows per 16-byte load instruction -- lanes 0..31 the
+    // pairs (2 jp, 2 jp + 1) of row 2 pr, lanes 32..63 those of row 2 pr + 1, pr = (wv - 1) + NLW m.
+    const int hf = lane >> 5, jp = lane & 31;
+    d2 wreg[WPAIRS];
+#define WROW(q, m) ((q) * CH + 2 * ((wv - 1) + NLW * (m)) + hf)
+#define WOK(q, m) (((wv - 1) + NLW * (m) < CH / 2) && (q) >= 0 && WROW(q, m) < ni && 2 * jp < p)
 #define WFETCH(q)                                                                                              \
-    if ((q) >= 0 && ((q) + 1) * CH <= ni && p == MCQ_P_MAX) {                                                  \
-        const gdouble* wb_ = L + ((size_t)(q) * CH + (wv - 1)) * MCQ_LLD + MCQ_LBW + lane;                     \
-        const gdouble* vb_ = v + (q) * CH + (wv - 1);                                                          \
-        _Pragma("unroll") for (int m = 0; m < WROWS; ++m) {                                                    \
-            const int ms_ = ((wv - 1) + 3 * m < CH) ? m : 0;                                                   \
-            wreg[m] = wb_[(size_t)ms_ * 3 * MCQ_LLD];                                                          \
-            vreg[m] = vb_[ms_ * 3];                                                                            \
-        }                                                                                                      \
-    } else {                                                                                                   \
-        _Pragma("unroll") for (int m = 0; m < WROWS; ++m) {                                                    \
-            const int r_ = (q) * CH + (wv - 1) + 3 * m;                                                        \
-            const int rs_ = (r_ >= 0 && r_ < ni) ? r_ : 0;                                                     \
-            wreg[m] = L[(size_t)rs_ * MCQ_LLD + MCQ_LBW + (lane < p ? lane : 0)];                              \
-            vreg[m] = v[rs_];                                                                                  \
-        }                                                                                                      \
+    _Pragma("unroll") for (int m = 0; m < WPAIRS; ++m) {                                                       \
+        const int r_ = WROW(q, m);                                                                             \
+        const int rs_ = ((q) >= 0 && r_ < ni) ? r_ : 0;                                                        \
+        wreg[m] = *(const gd2*)(L + (size_t)rs_ * MCQ_LLD + MCQ_LBW + 2 * jp);                                 \
     }
-#define WVALID(q, m) (((wv - 1) + 3 * (m) < CH) && ((q) * CH + (wv - 1) + 3 * (m) < ni) && ((q) >= 0) && lane < p)
 
     __syncthreads();
     for (int q = tid; q < VRING; q += MCQ_NT) vring[q] = 0.0;
     // ================= forward substitution, interior rows =================
     // a tile needs only its own rows: chunk cq resident, cq+1 committed one step ahead, cq+2 committed during step cq.
-    double tacc = 0.0;
+    d2 tacc = {0.0, 0.0};
     if (wv > 0) {
         for (int q = 0; q <= 1; ++q) {
             chunk_fetch(L, v, ni, b, q, q, lt, goff, regs, rreg);
@@ -1106,8 +1098,10 @@ __device__ __noinline__ void solve(const SolveCtx& c, gdouble* v)
             // border right-hand side, fused: t -= W' y for the rows solved in the previous step (W rows in registers)
             if (cq >= 1) {
 #pragma unroll
-                for (int m = 0; m < WROWS; ++m)
-                    if (WVALID(cq - 1, m)) tacc += wreg[m] * RHSV((cq - 1) * CH + (wv - 1) + 3 * m);
+                for (int m = 0; m < WPAIRS; ++m) {
+                    const double yr = WOK(cq - 1, m) ? RHSV(WOK(cq - 1, m) ? WROW(cq - 1, m) : 0) : 0.0;
+                    tacc += wreg[m] * yr;
+                }
             }
             WFETCH(cq)
         }
@@ -1115,18 +1109,23 @@ __device__ __noinline__ void solve(const SolveCtx& c, gdouble* v)
     }
     if (wv > 0 && nch >= 1) {
 #pragma unroll
-        for (int m = 0; m < WROWS; ++m)
-            if (WVALID(nch - 1, m)) tacc += wreg[m] * RHSV((nch - 1) * CH + (wv - 1) + 3 * m);
+        for (int m = 0; m < WPAIRS; ++m) {
+            const double yr = WOK(nch - 1, m) ? RHSV(WOK(nch - 1, m) ? WROW(nch - 1, m) : 0) : 0.0;
+            tacc += wreg[m] * yr;
+        }
     }
-    part[wv * 64 + lane] = tacc;
+    // part[wave][half][jj]: partial sums of W'y
+    part[(wv * 2 + hf) * 64 + 2 * jp] = tacc[0];
+    part[(wv * 2 + hf) * 64 + 2 * jp + 1] = tacc[1];
     __syncthreads();
     // ================= border:  t = v_D - W' y_B,  x_D = L_S^-T (L_S^-1 t)  as two LDS mat-vecs =================
     if (wv == 0) {
         double t = 0.0;
         if (lane < p) {
             t = v[ni + lane];
-            for (int q = 1; q < MCQ_NW; ++q) t -= part[q * 64 + lane];
+            for (int q = 2; q < 2 * MCQ_NW; ++q) t -= part[q * 64 + lane];
         }
+        __builtin_amdgcn_wave_barrier();
         xd[lane] = t;
         __builtin_amdgcn_wave_barrier();   // same-wave LDS write -> read (in-order on hardware; ordering point for the compiler)
         double y = 0.0;
@@ -1149,29 +1148,35 @@ __device__ __noinline__ void solve(const SolveCtx& c, gdouble* v)
     for (int q = tid; q < VRING; q += MCQ_NT) vring[q] = 0.0;
     // ================= backward substitution, interior rows (descending) =================
     // tile J needs the band entries of the rows of tiles J+1..J+4 (the chunk processed before) and its own inverse tile.
-    // The loader waves produce the right-hand side of a chunk as  y_B - W x_D  (W rows fetched one step ahead, 64-wide
-    // dot products reduced in the wave) and write it straight into the rhs ring.
-#define RHS_REDUCE_STORE(q)                                                                                    \
+    // Right-hand side of a chunk = y_B - W x_D: the raw y_B values are committed to the rhs ring two steps ahead, the
+    // loader waves subtract the 64-wide dot products W[r] . x_D (W rows fetched one step ahead, reduced inside each
+    // 32-lane half) one step ahead.
+#define RHS_SUB(q)                                                                                             \
     {                                                                                                          \
-        double a_[WROWS];                                                                                      \
-        _Pragma("unroll") for (int m = 0; m < WROWS; ++m) a_[m] = WVALID(q, m) ? wreg[m] * xd[lane] : 0.0;     \
-        _Pragma("unroll") for (int sh = 32; sh >= 1; sh >>= 1) {                                               \
-            _Pragma("unroll") for (int m = 0; m < WROWS; ++m) a_[m] += __shfl_xor(a_[m], sh);                  \
+        double a_[WPAIRS];                                                                                     \
+        _Pragma("unroll") for (int m = 0; m < WPAIRS; ++m)                                                     \
+            a_[m] = WOK(q, m) ? wreg[m][0] * xd[2 * jp] + wreg[m][1] * xd[2 * jp + 1] : 0.0;                   \
+        _Pragma("unroll") for (int sh = 16; sh >= 1; sh >>= 1) {                                               \
+            _Pragma("unroll") for (int m = 0; m < WPAIRS; ++m) a_[m] += __shfl_xor(a_[m], sh);                 \
         }                                                                                                      \
-        _Pragma("unroll") for (int m = 0; m < WROWS; ++m) {                                                    \
-            const int r_ = (q) * CH + (wv - 1) + 3 * m;                                                        \
-            if (lane == 0 && (wv - 1) + 3 * m < CH && (q) >= 0)                                                \
-                RHSV(r_) = (r_ < ni) ? vreg[m] - a_[m] : 0.0;                                                  \
+        _Pragma("unroll") for (int m = 0; m < WPAIRS; ++m) {                                                   \
+            const int r_ = WROW(q, m);                                                                         \
+            if (jp == 0 && (wv - 1) + NLW * m < CH / 2 && (q) >= 0 && r_ < ni) RHSV(r_) -= a_[m];              \
         }                                                                                                      \
     }
     if (nch > 0) {
         const int cl = nch - 1;
         if (wv > 0) {
-            chunk_fetch(L, v, ni, b, cl, -1, lt, goff, regs, rreg);
-            chunk_commit(chunk, rring, cl, -1, lt, regs, rreg);
+            chunk_fetch(L, v, ni, b, cl, cl, lt, goff, regs, rreg);
+            chunk_commit(chunk, rring, cl, cl, lt, regs, rreg);
+            chunk_fetch(L, v, ni, b, -1, cl - 1, lt, goff, regs, rreg);
+            chunk_commit(chunk, rring, -1, cl - 1, lt, regs, rreg);
             WFETCH(cl)
-            RHS_REDUCE_STORE(cl)
-            chunk_fetch(L, v, ni, b, cl - 1, -1, lt, goff, regs, rreg);
+        }
+        __syncthreads();
+        if (wv > 0) {
+            RHS_SUB(cl)
+            chunk_fetch(L, v, ni, b, cl - 1, cl - 2, lt, goff, regs, rreg);
             WFETCH(cl - 1)
         }
         __syncthreads();
@@ -1203,9 +1208,9 @@ __device__ __noinline__ void solve(const SolveCtx& c, gdouble* v)
                     __builtin_amdgcn_wave_barrier();
                 }
             } else {
-                chunk_commit(chunk, rring, cq - 1, -1, lt, regs, rreg);
-                chunk_fetch(L, v, ni, b, cq - 2, -1, lt, goff, regs, rreg);
-                RHS_REDUCE_STORE(cq - 1)
+                chunk_commit(chunk, rring, cq - 1, cq - 2, lt, regs, rreg);
+                chunk_fetch(L, v, ni, b, cq - 2, cq - 3, lt, goff, regs, rreg);
+                RHS_SUB(cq - 1)
                 WFETCH(cq - 2)
             }
             lds_barrier();
@@ -1213,8 +1218,9 @@ __device__ __noinline__ void solve(const SolveCtx& c, gdouble* v)
     }
     __syncthreads();
 #undef WFETCH
-#undef WVALID
-#undef RHS_REDUCE_STORE
+#undef WOK
+#undef WROW
+#undef RHS_SUB
 }
 
 // g = E'(E x + F_SCALE k_ref + extra)      (tmp: scratch vector; extra may be nullptr)
