@@ -174,6 +174,8 @@ static int launch(mcq_handle* h, McqBatch& B, const mcq_opts& o)
     HIP_TRY(hipEventRecord(h->ev[1], h->stream));
     hipLaunchKernelGGL(mcq_gram_kernel, dim3(B.batch, 8), dim3(256), 0, h->stream, B);
     HIP_TRY(hipGetLastError());
+    hipLaunchKernelGGL(mcq_gram_tile_kernel, dim3(B.batch, (B.nmax + 63) / 64), dim3(256), 0, h->stream, B);
+    HIP_TRY(hipGetLastError());
     HIP_TRY(hipEventRecord(h->ev[2], h->stream));
     hipLaunchKernelGGL(mcq_solve_kernel, dim3(B.batch), dim3(256), 0, h->stream, B);
     HIP_TRY(hipGetLastError());

@@ -122,6 +122,7 @@ struct McqBatch {
 
 __global__ void mcq_assemble_kernel(McqBatch B);
 __global__ void mcq_gram_kernel(McqBatch B);
+__global__ void mcq_gram_tile_kernel(McqBatch B);
 __global__ void mcq_solve_kernel(McqBatch B);
 
 size_t mcq_solve_lds_bytes();   /* static LDS of the solver kernel (reporting only) */

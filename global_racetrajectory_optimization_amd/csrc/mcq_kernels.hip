@@ -365,12 +365,13 @@ __device__ __forceinline__ double gram_entry(const gdouble* Et, const gdouble* s
 // Work items are ordered so that consecutive threads take consecutive rows i of the same diagonal / border column:
 // the Et[.][i] loads are contiguous 512-byte segments and the Et[.][j] loads hit a few L1-resident lines.
 __device__ void gram_bordered(const gdouble* Et, const gdouble* sg, const McqDims& d, int nm, const gdouble* base, gdouble* out,
-                              int t0, int nthreads)
+                              int t0, int nthreads, int skip0 = 0, int skip1 = 0)
 {
     const int ni = d.ni, n = d.n;
     const int bw = MCQ_BH_MAX + 1;
     for (int idx = t0; idx < bw * ni; idx += nthreads) {
         const int k = idx / ni, i = idx - k * ni;
+        if (i >= skip0 && i < skip1) continue;     // rows done by mcq_gram_tile_kernel
         double v = 0.0;
         if (k <= d.b && i + k < ni) v = gram_entry(Et, sg, d, nm, i, i + k);
         out[(size_t)i * MCQ_HLD + k] = v + (base ? base[(size_t)i * MCQ_HLD + k] : 0.0);
@@ -383,6 +384,76 @@ __device__ void gram_bordered(const gdouble* Et, const gdouble* sg, const McqDim
             if (abs(sdiff(i, j, n)) <= d.bH) v = gram_entry(Et, sg, d, nm, i, j);
         }
         out[(size_t)i * MCQ_HLD + MCQ_HBO + jj] = v + (base ? base[(size_t)i * MCQ_HLD + MCQ_HBO + jj] : 0.0);
+    }
+}
+
+// Rows [f0, f1) of the band part of H whose 65 entries involve no wrap-around and no truncation: the LDS-tiled fast path.
+#define GT_ROWS 64
+__device__ __forceinline__ void gram_fast_range(const McqDims& d, int& f0, int& f1)
+{
+    f0 = f1 = 0;
+    if (d.bE == MCQ_BE_MAX && d.bR == MCQ_BE_MAX && d.b == MCQ_BH_MAX) {
+        f0 = MCQ_BE_MAX;
+        const int last = d.ni - MCQ_BH_MAX;                 // exclusive: rows i with i + 64 < ni
+        if (last > f0) f1 = f0 + ((last - f0) / GT_ROWS) * GT_ROWS;
+        if (f1 < f0) f1 = f0;
+    }
+}
+
+// H[i, i+k] = sum_{o >= k} E'[o][i] E'[o-k][i+k]  (o, o-k = 0-based diagonal indices of the 65-wide E' band).
+// One workgroup per tile of 64 rows: the 65 x 128 block of E' it touches (columns i0 .. i0+127) is staged once in LDS
+// (66.5 KB, two workgroups per CU); thread (row r, group g) keeps its column of E in 65 registers and produces the entries
+// k == g (mod 4): one LDS read per FMA, conflict-free (consecutive lanes = consecutive columns).
+__global__ void __launch_bounds__(MCQ_NT) mcq_gram_tile_kernel(McqBatch B)
+{
+    __shared__ double S[(2 * MCQ_BE_MAX + 1) * 2 * GT_ROWS];
+    int n;
+    double kb, wveh;
+    const McqWork w = mcq_work(B, blockIdx.x, n, kb, wveh);
+    if (*w.status != MCQ_OK) return;
+    const int nm = B.nmax;
+    const McqDims d = mcq_dims(n, B.band_e);
+    int f0, f1;
+    gram_fast_range(d, f0, f1);
+    const int i0 = f0 + blockIdx.y * GT_ROWS;
+    if (i0 >= f1) return;
+    const int tid = threadIdx.x;
+    const int NO = 2 * MCQ_BE_MAX + 1, NC = 2 * GT_ROWS;
+    // 65 x 128 doubles = 32.5 loads per thread: issued in batches of 11 independent loads (one HBM round trip per batch)
+    {
+        const int cc = tid & (NC - 1), o0 = tid / NC;              // 256 threads = 2 diagonals x 128 columns per pass
+        const gdouble* src = w.Et + (size_t)i0 + cc;                // i0 + cc <= f1 - 1 + 64 + 63 < n
+#pragma unroll
+        for (int pass = 0; pass < 3; ++pass) {
+            double t[11];
+#pragma unroll
+            for (int u = 0; u < 11; ++u) {
+                const int o = o0 + 2 * (pass * 11 + u);
+                t[u] = src[(size_t)(o < NO ? o : 0) * nm];
+            }
+#pragma unroll
+            for (int u = 0; u < 11; ++u) {
+                const int o = o0 + 2 * (pass * 11 + u);
+                if (o < NO) S[o * NC + cc] = t[u];
+            }
+        }
+    }
+    __syncthreads();
+    const int r = tid & (GT_ROWS - 1), g = tid / GT_ROWS;
+    double a[2 * MCQ_BE_MAX + 1];
+#pragma unroll
+    for (int o = 0; o < NO; ++o) a[o] = S[o * NC + r];
+    gdouble* orow = w.H + (size_t)(i0 + r) * MCQ_HLD;
+    for (int k = g; k <= MCQ_BH_MAX; k += MCQ_NT / GT_ROWS) {
+        const double* bcol = S + r + k;
+        double acc = 0.0;
+#pragma unroll
+        for (int o = 0; o < NO; ++o) {
+            const int tt = o - k;
+            const double bv = bcol[(tt >= 0 ? tt : 0) * NC];
+            acc += a[o] * (tt >= 0 ? bv : 0.0);
+        }
+        orow[k] = acc;
     }
 }
 
@@ -408,7 +479,9 @@ __global__ void __launch_bounds__(MCQ_NT) mcq_gram_kernel(McqBatch B)
         }
         F[j] = MCQ_F_SCALE * acc;
     }
-    gram_bordered(w.Et, nullptr, d, nm, nullptr, w.H, tid, nthreads);
+    int f0, f1;
+    gram_fast_range(d, f0, f1);
+    gram_bordered(w.Et, nullptr, d, nm, nullptr, w.H, tid, nthreads, f0, f1);
 }
 
 // =====================================================================================================================
