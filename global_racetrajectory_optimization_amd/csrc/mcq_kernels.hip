@@ -651,33 +651,17 @@ __device__ __forceinline__ int factor_t(const SolveCtx& c, const gdouble* Hsrc, 
     int fail = 0;
     const int wl = w0 - 1;           // lag-worker index of waves 1..3
     // Tile ownership of the three lag waves (wl = 0..2):
-    //   border tiles C(P+dI, a): column a = wl for dI = 1..4, plus one tile of column 3 (dI = wl + 1); wave 0 also (4, 3)
-    //   Schur tiles (lower, 10): t % 3 == wl;    band tiles (6): t % 3 == wl
+    //   border tiles C(P+dI, a): column a = wl for dI = 1..4, plus one tile of column 3 (dI = wl + 1); wl = 0 also (4, 3)
+    //   Schur tiles (lower, 10): (t + 1) % 3 == wl, register slot t / 3;    band tiles (6): t % 3 == wl
+    // wl is a literal inside LAG_WORK (three-way dispatch) so that every register array is indexed statically.
     // All LDS operand / accumulator reads of a group are issued before its MFMAs, all writes after them.
-#define S_HEAD(P)                                                                                                      \
-    {                                                                                                                  \
-        double wv_[3][4];                                                                                              \
-        _Pragma("unroll") for (int a_ = 0; a_ < 3; ++a_) {                                                             \
-            const double* wa2_ = CTILE((P), a_);                                                                       \
-            _Pragma("unroll") for (int kc = 0; kc < 4; ++kc) wv_[a_][kc] = wa2_[(l4 + 4 * kc) * TLD + l15];            \
-        }                                                                                                              \
-        int t_ = 0;                                                                                                    \
-        _Pragma("unroll") for (int a_ = 0; a_ < 3; ++a_) {                                                             \
-            _Pragma("unroll") for (int bb_ = 0; bb_ <= a_; ++bb_, ++t_) {                                              \
-                if (t_ >= 4) continue;                                                                                 \
-                double av_[4];                                                                                         \
-                _Pragma("unroll") for (int kc = 0; kc < 4; ++kc) av_[kc] = -wv_[a_][kc];                               \
-                sacc[t_] = mfma16(av_, wv_[bb_], sacc[t_]);                                                            \
-            }                                                                                                          \
-        }                                                                                                              \
-    }
-#define LAG_WORK(P)                                                                                                    \
+#define LAG_WORK(P, WL)                                                                                                    \
     {                                                                                                                  \
         /* ---- border tiles: C(P+dI, a) -= L(P+dI, P) W_P(a) ---- */                                                  \
         {                                                                                                              \
             double la_[4][4], wa_[4], w3_[4];                                                                          \
             v4d cacc_[4], c3a_, c3b_;                                                                                  \
-            const double* wt_ = CTILE((P), wl);                                                                        \
+            const double* wt_ = CTILE((P), (WL));                                                                        \
             const double* w3t_ = CTILE((P), 3);                                                                        \
             _Pragma("unroll") for (int kc = 0; kc < 4; ++kc) {                                                         \
                 wa_[kc] = wt_[(l4 + 4 * kc) * TLD + l15];                                                              \
@@ -685,12 +669,12 @@ __device__ __forceinline__ int factor_t(const SolveCtx& c, const gdouble* Hsrc, 
             }                                                                                                          \
             _Pragma("unroll") for (int dI_ = 1; dI_ < NTR; ++dI_) {                                                    \
                 const double* li_ = BTILE((P) + dI_, (P));                                                             \
-                const double* ctl_ = CTILE((P) + dI_, wl);                                                             \
+                const double* ctl_ = CTILE((P) + dI_, (WL));                                                             \
                 _Pragma("unroll") for (int kc = 0; kc < 4; ++kc) la_[dI_ - 1][kc] = -li_[l15 * TLD + l4 + 4 * kc];     \
                 _Pragma("unroll") for (int r = 0; r < 4; ++r) cacc_[dI_ - 1][r] = ctl_[(l4 + 4 * r) * TLD + l15];      \
             }                                                                                                          \
             {                                                                                                          \
-                const double* c3p_ = CTILE((P) + wl + 1, 3);                                                           \
+                const double* c3p_ = CTILE((P) + (WL) + 1, 3);                                                           \
                 const double* c3q_ = CTILE((P) + 4, 3);                                                                \
                 _Pragma("unroll") for (int r = 0; r < 4; ++r) {                                                        \
                     c3a_[r] = c3p_[(l4 + 4 * r) * TLD + l15];                                                          \
@@ -698,18 +682,18 @@ __device__ __forceinline__ int factor_t(const SolveCtx& c, const gdouble* Hsrc, 
                 }                                                                                                      \
             }                                                                                                          \
             _Pragma("unroll") for (int dI_ = 1; dI_ < NTR; ++dI_) cacc_[dI_ - 1] = mfma16(la_[dI_ - 1], wa_, cacc_[dI_ - 1]); \
-            c3a_ = mfma16(la_[wl], w3_, c3a_);                                                                         \
-            if (wl == 0) c3b_ = mfma16(la_[3], w3_, c3b_);                                                             \
+            c3a_ = mfma16(la_[(WL)], w3_, c3a_);                                                                         \
+            if ((WL) == 0) c3b_ = mfma16(la_[3], w3_, c3b_);                                                             \
             _Pragma("unroll") for (int dI_ = 1; dI_ < NTR; ++dI_) {                                                    \
-                double* ctl_ = CTILE((P) + dI_, wl);                                                                   \
+                double* ctl_ = CTILE((P) + dI_, (WL));                                                                   \
                 _Pragma("unroll") for (int r = 0; r < 4; ++r) ctl_[(l4 + 4 * r) * TLD + l15] = cacc_[dI_ - 1][r];      \
             }                                                                                                          \
             {                                                                                                          \
-                double* c3p_ = CTILE((P) + wl + 1, 3);                                                                 \
+                double* c3p_ = CTILE((P) + (WL) + 1, 3);                                                                 \
                 double* c3q_ = CTILE((P) + 4, 3);                                                                      \
                 _Pragma("unroll") for (int r = 0; r < 4; ++r) {                                                        \
                     c3p_[(l4 + 4 * r) * TLD + l15] = c3a_[r];                                                          \
-                    if (wl == 0) c3q_[(l4 + 4 * r) * TLD + l15] = c3b_[r];                                             \
+                    if ((WL) == 0) c3q_[(l4 + 4 * r) * TLD + l15] = c3b_[r];                                             \
                 }                                                                                                      \
             }                                                                                                          \
             /* ---- band tiles not in block column P+1:  T(P+dI, P+dK) -= L(P+dI,P) L(P+dK,P)',  2 <= dK <= dI <= 4; the   \
@@ -720,7 +704,7 @@ __device__ __forceinline__ int factor_t(const SolveCtx& c, const gdouble* Hsrc, 
                 int t_ = 0, s_ = 0;                                                                                    \
                 _Pragma("unroll") for (int dK_ = 2; dK_ < NTR; ++dK_) {                                                \
                     _Pragma("unroll") for (int dI_ = dK_; dI_ < NTR; ++dI_, ++t_) {                                    \
-                        if (t_ % 3 != wl) continue;                                                                    \
+                        if (t_ % 3 != (WL)) continue;                                                                    \
                         const double* tt_ = BTILE((P) + dI_, (P) + dK_);                                               \
                         _Pragma("unroll") for (int r = 0; r < 4; ++r) bacc_[s_][r] = tt_[(l4 + 4 * r) * TLD + l15];    \
                         ++s_;                                                                                          \
@@ -729,7 +713,7 @@ __device__ __forceinline__ int factor_t(const SolveCtx& c, const gdouble* Hsrc, 
                 t_ = 0; s_ = 0;                                                                                        \
                 _Pragma("unroll") for (int dK_ = 2; dK_ < NTR; ++dK_) {                                                \
                     _Pragma("unroll") for (int dI_ = dK_; dI_ < NTR; ++dI_, ++t_) {                                    \
-                        if (t_ % 3 != wl) continue;                                                                    \
+                        if (t_ % 3 != (WL)) continue;                                                                    \
                         double bv_[4];                                                                                 \
                         _Pragma("unroll") for (int kc = 0; kc < 4; ++kc) bv_[kc] = -la_[dK_ - 1][kc];                  \
                         bacc_[s_] = mfma16(la_[dI_ - 1], bv_, bacc_[s_]);                                              \
@@ -739,7 +723,7 @@ __device__ __forceinline__ int factor_t(const SolveCtx& c, const gdouble* Hsrc, 
                 t_ = 0; s_ = 0;                                                                                        \
                 _Pragma("unroll") for (int dK_ = 2; dK_ < NTR; ++dK_) {                                                \
                     _Pragma("unroll") for (int dI_ = dK_; dI_ < NTR; ++dI_, ++t_) {                                    \
-                        if (t_ % 3 != wl) continue;                                                                    \
+                        if (t_ % 3 != (WL)) continue;                                                                    \
                         double* tt_ = BTILE((P) + dI_, (P) + dK_);                                                     \
                         _Pragma("unroll") for (int r = 0; r < 4; ++r) tt_[(l4 + 4 * r) * TLD + l15] = bacc_[s_][r];    \
                         ++s_;                                                                                          \
@@ -757,15 +741,21 @@ __device__ __forceinline__ int factor_t(const SolveCtx& c, const gdouble* Hsrc, 
             int t_ = 0;                                                                                                \
             _Pragma("unroll") for (int a_ = 0; a_ < NCT; ++a_) {                                                       \
                 _Pragma("unroll") for (int bb_ = 0; bb_ <= a_; ++bb_, ++t_) {                                          \
-                    if (t_ < 4 || (t_ - 4) % 3 != wl) continue;                                                        \
+                    if ((t_ + 1) % 3 != (WL)) continue;                                                                \
                     double av_[4];                                                                                     \
                     _Pragma("unroll") for (int kc = 0; kc < 4; ++kc) av_[kc] = -wv_[a_][kc];                           \
-                    sacc[(t_ - 4) / 3] = mfma16(av_, wv_[bb_], sacc[(t_ - 4) / 3]);                                    \
+                    sacc[t_ / 3] = mfma16(av_, wv_[bb_], sacc[t_ / 3]);                                                \
                 }                                                                                                      \
             }                                                                                                          \
         }                                                                                                              \
     }
 
+#define LAG_DISPATCH(P)                                                                                                \
+    {                                                                                                                  \
+        if (wl == 0) { LAG_WORK((P), 0) }                                                                              \
+        else if (wl == 1) { LAG_WORK((P), 1) }                                                                         \
+        else { LAG_WORK((P), 2) }                                                                                      \
+    }
     // Write-out of block column P of L (tiles below the diagonal one; the sweeps use the inverse tile instead of the
     // entries inside the diagonal tile), of the inverse diagonal tile and of block row P of W: 64 threads (the wave that is
     // idle during the panel phase), fixed trip counts, LDS reads batched before the stores.  Reads the inverse tile of step P
@@ -849,9 +839,8 @@ __device__ __forceinline__ int factor_t(const SolveCtx& c, const gdouble* Hsrc, 
                 for (int cc = 0; cc < TB; ++cc) d0[lane * TLD + cc] = (cc <= lane) ? a[cc] : 0.0;
             }
             if (bad && lane == 0) dinv[TB] = 1.0;
-            if (J > 0) { S_HEAD(J - 1) }      // wave 0's share of the lag work: four Schur tiles
         } else if (J > 0) {
-            LAG_WORK(J - 1)
+            LAG_DISPATCH(J - 1)
         }
         lds_barrier();
         c.tk[4] += FTICK() - tp; tp = FTICK();
@@ -915,12 +904,11 @@ __device__ __forceinline__ int factor_t(const SolveCtx& c, const gdouble* Hsrc, 
     const long long t_tail = FTICK();
     // drain: what the last step still owes
     if (nblk > 0) {
-        if (w0 == 0) { S_HEAD(nblk - 1) }
-        else { LAG_WORK(nblk - 1) }
+        if (w0 > 0) { LAG_DISPATCH(nblk - 1) }
         if (w0 == MCQ_NW - 1) { WRITE_OUT(nblk - 1) }
     }
 #undef LAG_WORK
-#undef S_HEAD
+#undef LAG_DISPATCH
 #undef WRITE_OUT
     lds_barrier();
 
@@ -934,10 +922,9 @@ __device__ __forceinline__ int factor_t(const SolveCtx& c, const gdouble* Hsrc, 
         for (int a = 0; a < NCT; ++a) {
 #pragma unroll
             for (int bb = 0; bb <= a; ++bb, ++t) {
-                // tiles 0..3 live in wave 0, tile t >= 4 in lag wave (t - 4) % 3, register slot (t - 4) / 3
-                const bool mine = (t < 4) ? (w0 == 0) : (w0 > 0 && (t - 4) % 3 == wl);
-                if (!mine) continue;
-                const int slot = t < 4 ? t : (t - 4) / 3;
+                // tile t lives in lag wave (t + 1) % 3, register slot t / 3
+                if (w0 == 0 || (t + 1) % 3 != wl) continue;
+                const int slot = t / 3;
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
                     const int j1 = TB * a + l4 + 4 * r, j2 = TB * bb + l15;
