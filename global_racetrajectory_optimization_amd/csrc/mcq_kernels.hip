@@ -513,6 +513,9 @@ struct SolveCtx {
 // Returns 0 or MCQ_NOT_PD (uniform across the block).
 #define BTILE(I, K) (bt + ((((I) % NTR) * NTR) + ((K) % NTR)) * TSZ)
 #define CTILE(I, a) (ct + ((((I) % NTR) * NCT) + (a)) * TSZ)
+// L(P+dI, P), dI = 1..4, once the panel of step P is done: in place, except the first sub-diagonal tile, which every wave
+// still reads as T(P+1, P) while wave 0 produces it -- that one goes to the dead upper-triangle slot (P+1, P+2)
+#define LTILE(dI, P) ((dI) == 1 ? BTILE((P) + 1, (P) + 2) : BTILE((P) + (dI), (P)))
 #define ROW_ITEMS (TB * (NTR * TB + MCQ_P_MAX))            /* 16 x 144 doubles per tile row */
 #define PF_ITEMS ((ROW_ITEMS + MCQ_NT - 1) / MCQ_NT)
 #define PF_BAND_ITEMS ((TB * NTR * TB) / MCQ_NT)          /* 1280 / 256 = 5: the band entries are exactly items u < 5 */
@@ -641,13 +644,14 @@ __device__ __forceinline__ int factor_t(const SolveCtx& c, const gdouble* Hsrc, 
     if (tid == 0) dinv[TB] = 0.0;   // fail flag
     __syncthreads();
 
-    // Software-pipelined block loop.  The critical path of one step is  diag(J) -> panel(J) -> update of block column J+1;
+    // Software-pipelined block loop, two LDS barriers per step.  The critical path of one step is
+    //   diag(J) [+ its inverse M_J]  ->  panel(J) = products with M_J  ->  update of block column J+1;
     // everything else that step J-1 owes (16 border tiles, 10 Schur tiles, 6 band tiles, the write-out of L / W / the
     // inverse tile) runs on waves 1..3 WHILE wave 0 factors the next diagonal tile:
-    //   phase 1   wave 0: diag(J)                         | waves 1..3: lag(J-1) = border/Schur/band updates + write-out
-    //   phase 2   waves 0,1: panel(J) (L rows, W columns)  | wave 2 (16 lanes): inverse of the diagonal tile | all: commit
-    //             the tile row that was fetched during the previous step into the slots lag(J-1) just released
-    //   phase 3   all waves: the four tiles of block column J+1
+    //   phase 1   wave 0: diag(J) and M_J = L_JJ^-1 (registers, v_readlane)   | waves 1..3: lag(J-1) + write-out(J-1)
+    //             all: commit the band part of the tile row fetched during the previous step
+    //   phase 2   wave w: L(J+1+w, J) = T M_J',  W_J(w) = M_J C(J, w),  T(J+1+w, J+1) -= L(J+1+w, J) L(J+1, J)'   (MFMA)
+    //             all: commit the border part of that tile row into the slots lag(J-1) just released
     int fail = 0;
     const int wl = w0 - 1;           // lag-worker index of waves 1..3
     // Tile ownership of the three lag waves (wl = 0..2):
@@ -668,7 +672,7 @@ __device__ __forceinline__ int factor_t(const SolveCtx& c, const gdouble* Hsrc, 
                 w3_[kc] = w3t_[(l4 + 4 * kc) * TLD + l15];                                                             \
             }                                                                                                          \
             _Pragma("unroll") for (int dI_ = 1; dI_ < NTR; ++dI_) {                                                    \
-                const double* li_ = BTILE((P) + dI_, (P));                                                             \
+                const double* li_ = LTILE(dI_, (P));                                                                       \
                 const double* ctl_ = CTILE((P) + dI_, (WL));                                                             \
                 _Pragma("unroll") for (int kc = 0; kc < 4; ++kc) la_[dI_ - 1][kc] = -li_[l15 * TLD + l4 + 4 * kc];     \
                 _Pragma("unroll") for (int r = 0; r < 4; ++r) cacc_[dI_ - 1][r] = ctl_[(l4 + 4 * r) * TLD + l15];      \
@@ -752,50 +756,51 @@ __device__ __forceinline__ int factor_t(const SolveCtx& c, const gdouble* Hsrc, 
 
 #define LAG_DISPATCH(P)                                                                                                \
     {                                                                                                                  \
-        if (wl == 0) { LAG_WORK((P), 0) }                                                                              \
-        else if (wl == 1) { LAG_WORK((P), 1) }                                                                         \
-        else { LAG_WORK((P), 2) }                                                                                      \
+        if (wl == 0) { LAG_WORK((P), 0) WRITE_OUT_W((P), 1) }                                                          \
+        else if (wl == 1) { LAG_WORK((P), 1) WRITE_OUT_W((P), 0) }                                                     \
+        else { LAG_WORK((P), 2) WRITE_OUT_L((P)) }                                                                     \
     }
     // Write-out of block column P of L (tiles below the diagonal one; the sweeps use the inverse tile instead of the
-    // entries inside the diagonal tile), of the inverse diagonal tile and of block row P of W: 64 threads (the wave that is
-    // idle during the panel phase), fixed trip counts, LDS reads batched before the stores.  Reads the inverse tile of step P
-    // from its own buffer (linv is double-buffered by step parity).
+    // entries inside the diagonal tile), of the inverse diagonal tile and of block row P of W.  Shared by the three lag waves
+    // (64 lanes each): wl = 2 writes the four L tiles, wl = 1 / wl = 0 one half each of the [inverse tile | W] rows.  Fixed
+    // trip counts, LDS reads batched before the stores.  The inverse tile of step P is read from its own buffer (linv is
+    // double-buffered by step parity).
 #define WO_T 64
 #define WO_L ((4 * TB * TB) / WO_T)
 #define WO_W ((TB * (TB + MCQ_P_MAX)) / WO_T)
-#define WRITE_OUT(P)                                                                                                   \
+#define WRITE_OUT_L(P)                                                                                                 \
     {                                                                                                                  \
-        const double* lv_ = linv + ((P) & 1) * TSZ;                                                                    \
-        const int lt_ = lane;                                                                                          \
         _Pragma("unroll") for (int h_ = 0; h_ < 2; ++h_) {                                                             \
             double ev_[WO_L / 2];                                                                                      \
             _Pragma("unroll") for (int m_ = 0; m_ < WO_L / 2; ++m_) {                                                  \
-                const int q = lt_ + (m_ + h_ * (WO_L / 2)) * WO_T;                                                     \
-                ev_[m_] = BTILE((P) + 1 + q / (TB * TB), (P))[((q / TB) % TB) * TLD + (q % TB)];                       \
+                const int q = lane + (m_ + h_ * (WO_L / 2)) * WO_T;                                                    \
+                ev_[m_] = LTILE(1 + (m_ + h_ * (WO_L / 2)) / 4, (P))[((q / TB) % TB) * TLD + (q % TB)];                \
             }                                                                                                          \
             _Pragma("unroll") for (int m_ = 0; m_ < WO_L / 2; ++m_) {                                                  \
-                const int q = lt_ + (m_ + h_ * (WO_L / 2)) * WO_T;                                                     \
+                const int q = lane + (m_ + h_ * (WO_L / 2)) * WO_T;                                                    \
                 const int tI = 1 + q / (TB * TB), rr = (q / TB) % TB, cc = q % TB;                                     \
                 const int i = ((P) + tI) * TB + rr, k = tI * TB + rr - cc;                                             \
                 if (i < ni && k <= MCQ_BH_MAX) L[(size_t)i * MCQ_LLD + (k - 1)] = ev_[m_];                             \
             }                                                                                                          \
         }                                                                                                              \
-        _Pragma("unroll") for (int h_ = 0; h_ < 2; ++h_) {                                                             \
-            double fv_[WO_W / 2];                                                                                      \
-            _Pragma("unroll") for (int m_ = 0; m_ < WO_W / 2; ++m_) {                                                  \
-                const int q = lt_ + (m_ + h_ * (WO_W / 2)) * WO_T;                                                     \
-                const int rr = q / (TB + MCQ_P_MAX), e = q - rr * (TB + MCQ_P_MAX);                                    \
-                const int es = e < TB ? 0 : e - TB;                                                                    \
-                const double a1_ = lv_[rr * TLD + (e < TB ? e : 0)];                                                   \
-                const double a2_ = CTILE((P), es / TB)[rr * TLD + (es % TB)];                                          \
-                fv_[m_] = e < TB ? a1_ : a2_;                                                                          \
-            }                                                                                                          \
-            _Pragma("unroll") for (int m_ = 0; m_ < WO_W / 2; ++m_) {                                                  \
-                const int q = lt_ + (m_ + h_ * (WO_W / 2)) * WO_T;                                                     \
-                const int rr = q / (TB + MCQ_P_MAX), e = q - rr * (TB + MCQ_P_MAX);                                    \
-                const int i = (P) * TB + rr;                                                                           \
-                if (i < ni) L[(size_t)i * MCQ_LLD + MCQ_LBI + e] = fv_[m_];                                            \
-            }                                                                                                          \
+    }
+#define WRITE_OUT_W(P, HALF)                                                                                           \
+    {                                                                                                                  \
+        const double* lv_ = linv + ((P) & 1) * TSZ;                                                                    \
+        double fv_[WO_W / 2];                                                                                          \
+        _Pragma("unroll") for (int m_ = 0; m_ < WO_W / 2; ++m_) {                                                      \
+            const int q = lane + (m_ + (HALF) * (WO_W / 2)) * WO_T;                                                    \
+            const int rr = q / (TB + MCQ_P_MAX), e = q - rr * (TB + MCQ_P_MAX);                                        \
+            const int es = e < TB ? 0 : e - TB;                                                                        \
+            const double a1_ = lv_[rr * TLD + (e < TB ? e : 0)];                                                       \
+            const double a2_ = CTILE((P), es / TB)[rr * TLD + (es % TB)];                                              \
+            fv_[m_] = e < TB ? a1_ : a2_;                                                                              \
+        }                                                                                                              \
+        _Pragma("unroll") for (int m_ = 0; m_ < WO_W / 2; ++m_) {                                                      \
+            const int q = lane + (m_ + (HALF) * (WO_W / 2)) * WO_T;                                                    \
+            const int rr = q / (TB + MCQ_P_MAX), e = q - rr * (TB + MCQ_P_MAX);                                        \
+            const int i = (P) * TB + rr;                                                                               \
+            if (i < ni) L[(size_t)i * MCQ_LLD + MCQ_LBI + e] = fv_[m_];                                                \
         }                                                                                                              \
     }
 
@@ -819,24 +824,33 @@ __device__ __forceinline__ int factor_t(const SolveCtx& c, const gdouble* Hsrc, 
             }
         }
         if (w0 == 0) {
-            double* d0 = BTILE(J, J);
-            double a[TB];
+            // Diagonal tile: lane i (mod 16) holds row i of L (a[k] = L[i][k]); left-looking by columns, the multipliers
+            // L[j][k] are v_readlane broadcasts.  The same multipliers give the inverse M = L^-1 by rows for free: lane c holds
+            // column c of M,  M[j][c] = rs_j ( [j == c] - sum_{k<j} L[j][k] M[k][c] ).
+            const double* d0 = BTILE(J, J);
+            double a[TB], m[TB];
 #pragma unroll
             for (int cc = 0; cc < TB; ++cc) a[cc] = d0[l15 * TLD + cc];
             bool bad = false;
 #pragma unroll
             for (int j = 0; j < TB; ++j) {
+                double mm = (l15 == j) ? 1.0 : 0.0;
 #pragma unroll
-                for (int k = 0; k < j; ++k) a[j] -= a[k] * bcast_lane(a[k], j);
+                for (int k = 0; k < j; ++k) {
+                    const double s = bcast_lane(a[k], j);
+                    a[j] -= a[k] * s;
+                    mm -= m[k] * s;
+                }
                 const double piv = bcast_lane(a[j], j);
                 bad |= !(piv > 0.0);
                 const double rs = rsqrt(piv);
-                a[j] = (l15 == j) ? piv * rs : a[j] * rs;
-                if (lane == j) dinv[j] = rs;
+                a[j] *= rs;
+                m[j] = mm * rs;
             }
             if (lane < TB) {
+                double* lv = linv + (J & 1) * TSZ;
 #pragma unroll
-                for (int cc = 0; cc < TB; ++cc) d0[lane * TLD + cc] = (cc <= lane) ? a[cc] : 0.0;
+                for (int j = 0; j < TB; ++j) lv[j * TLD + lane] = m[j];
             }
             if (bad && lane == 0) dinv[TB] = 1.0;
         } else if (J > 0) {
@@ -845,49 +859,45 @@ __device__ __forceinline__ int factor_t(const SolveCtx& c, const gdouble* Hsrc, 
         lds_barrier();
         c.tk[4] += FTICK() - tp; tp = FTICK();
         if (dinv[TB] != 0.0) { fail = 1; break; }
-        // ---- phase 2 --------------------------------------------------------------------------------------------------------
-        if (w0 == MCQ_NW - 1 && J > 0) { WRITE_OUT(J - 1) }     // the wave that has no panel work writes step J-1 out
-        if (tid < 128 + TB) {
-            const double* d0 = BTILE(J, J);
-            double* base;
-            int stride;
-            double x[TB];
-            if (tid < 64) { base = BTILE(J + 1 + tid / TB, J) + (tid % TB) * TLD; stride = 1; }
-            else if (tid < 128) { const int jj = tid - 64; base = CTILE(J, jj / TB) + (jj % TB); stride = TLD; }
-            else { base = linv + (J & 1) * TSZ + (tid - 128); stride = TLD; }
-#pragma unroll
-            for (int cc = 0; cc < TB; ++cc) x[cc] = (tid < 128) ? base[cc * stride] : ((cc == tid - 128) ? 1.0 : 0.0);
-#pragma unroll
-            for (int cc = 0; cc < TB; ++cc) {
-                x[cc] *= dinv[cc];
-#pragma unroll
-                for (int c2 = cc + 1; c2 < TB; ++c2) x[c2] -= x[cc] * d0[c2 * TLD + cc];
-            }
-#pragma unroll
-            for (int cc = 0; cc < TB; ++cc) base[cc * stride] = x[cc];
-        }
-        lds_barrier();
-        c.tk[5] += FTICK() - tp; tp = FTICK();
-        // ---- phase 3: block column J+1, one tile per wave:  T(J+1+w, J+1) -= L(J+1+w, J) L(J+1, J)' ---------------------------
+        // ---- phase 2: panel + block column J+1, all on the matrix cores, one tile row per wave ---------------------------------
+        //   X1' = M T(J+1,J)'  (every wave: the column-form operand of the update),   Xw' = M T(J+1+w,J)'  (L(J+1+w, J) = Xw),
+        //   W_w = M C(J, w),   T(J+1+w, J+1) -= Xw X1'.
+        // The transposed products leave X in exactly the per-lane layout the update's operands need: no LDS round trip.
         {
-            const double* li = BTILE(J + 1 + w0, J);
-            const double* lk = BTILE(J + 1, J);
-            double* tt = BTILE(J + 1 + w0, J + 1);
-            double av[4], bv[4];
+            const double* lv = linv + (J & 1) * TSZ;
+            const double* t1 = BTILE(J + 1, J);
+            const double* tw = BTILE(J + 1 + w0, J);
+            double* cw = CTILE(J, w0);
+            double* tu = BTILE(J + 1 + w0, J + 1);
+            double mv[4], b1[4], bw[4], bc[4];
+            v4d accu;
 #pragma unroll
             for (int kc = 0; kc < 4; ++kc) {
-                av[kc] = -li[l15 * TLD + l4 + 4 * kc];
-                bv[kc] = lk[l15 * TLD + l4 + 4 * kc];
+                mv[kc] = lv[l15 * TLD + l4 + 4 * kc];
+                b1[kc] = t1[l15 * TLD + l4 + 4 * kc];
+                bw[kc] = tw[l15 * TLD + l4 + 4 * kc];
+                bc[kc] = cw[(l4 + 4 * kc) * TLD + l15];
             }
-            v4d acc;
 #pragma unroll
-            for (int r = 0; r < 4; ++r) acc[r] = tt[(l4 + 4 * r) * TLD + l15];
-            acc = mfma16(av, bv, acc);
+            for (int r = 0; r < 4; ++r) accu[r] = tu[(l4 + 4 * r) * TLD + l15];
+            const v4d z4 = {0.0, 0.0, 0.0, 0.0};
+            const v4d x1 = mfma16(mv, b1, z4);
+            const v4d xw = mfma16(mv, bw, z4);
+            const v4d ww = mfma16(mv, bc, z4);
+            double av[4], bv[4];
 #pragma unroll
-            for (int r = 0; r < 4; ++r) tt[(l4 + 4 * r) * TLD + l15] = acc[r];
+            for (int kc = 0; kc < 4; ++kc) { av[kc] = -xw[kc]; bv[kc] = x1[kc]; }
+            accu = mfma16(av, bv, accu);
+            double* lo = (w0 == 0) ? BTILE(J + 1, J + 2) : BTILE(J + 1 + w0, J);      // LTILE(1 + w0, J)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                lo[l15 * TLD + l4 + 4 * r] = xw[r];
+                cw[(l4 + 4 * r) * TLD + l15] = ww[r];
+                tu[(l4 + 4 * r) * TLD + l15] = accu[r];
+            }
         }
-        // border part of the tile row fetched during the previous step: its slots held W_(J-1), which lag(J-1) (phase 1)
-        // and the write-out of step J-1 (phase 2) have released; first used by lag(J) in the next step
+        // border part of the tile row fetched during the previous step: its slots held W_(J-1), which lag(J-1) and the
+        // write-out of step J-1 (phase 1) have released; first used by lag(J) in the next step
         if (J > 0) {
 #pragma unroll
             for (int u = PF_BAND_ITEMS; u < PF_ITEMS; ++u) {
@@ -898,18 +908,18 @@ __device__ __forceinline__ int factor_t(const SolveCtx& c, const gdouble* Hsrc, 
 #pragma unroll
         for (int u = 0; u < PF_ITEMS; ++u) pf[u] = pfn[u];
         lds_barrier();
-        c.tk[7] += FTICK() - tp;
+        c.tk[5] += FTICK() - tp;
     }
     if (fail) return MCQ_NOT_PD;
     const long long t_tail = FTICK();
     // drain: what the last step still owes
     if (nblk > 0) {
         if (w0 > 0) { LAG_DISPATCH(nblk - 1) }
-        if (w0 == MCQ_NW - 1) { WRITE_OUT(nblk - 1) }
     }
 #undef LAG_WORK
 #undef LAG_DISPATCH
-#undef WRITE_OUT
+#undef WRITE_OUT_L
+#undef WRITE_OUT_W
     lds_barrier();
 
     // ---- Schur complement of the border: S = D - W'W (accumulated above), dense Cholesky in LDS -----------------------
