@@ -132,6 +132,12 @@ __device__ __forceinline__ void lds_barrier()
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup", "local");
 }
 
+// Scheduling pin: an empty asm that "rewrites" a scalar and a vector register, i.e. ties the uses of the scalar that
+// follow to the point where the vector value is final (the SIMT emulator of tests/emu predefines it as a no-op).
+#ifndef MCQ_PIN_SV
+#define MCQ_PIN_SV(sreg, vreg) asm volatile("" : "+s"(sreg), "+v"(vreg))
+#endif
+
 // broadcast of a double from a wave-uniform lane (two v_readlane_b32 instead of an LDS-crossbar shuffle)
 __device__ __forceinline__ double bcast_lane(double v, int src_lane)
 {
@@ -834,23 +840,30 @@ __device__ __forceinline__ int factor_t(const SolveCtx& c, const gdouble* Hsrc, 
             bool bad = false;
 #pragma unroll
             for (int j = 0; j < TB; ++j) {
+                // The broadcast lane is passed through an opaque register tied to the column finished last: without it the
+                // compiler hoists all 120 multiplier broadcasts to where their source column becomes final and parks them in
+                // SGPRs (spilled to VGPR lanes and reloaded) -- with it at most one column's multipliers are live.
+                int jv = j;
+                if (j > 0) MCQ_PIN_SV(jv, a[j - 1]);
                 double mm = (l15 == j) ? 1.0 : 0.0;
 #pragma unroll
                 for (int k = 0; k < j; ++k) {
-                    const double s = bcast_lane(a[k], j);
+                    const double s = bcast_lane(a[k], jv);
                     a[j] -= a[k] * s;
                     mm -= m[k] * s;
                 }
-                const double piv = bcast_lane(a[j], j);
+                const double piv = bcast_lane(a[j], jv);
                 bad |= !(piv > 0.0);
                 const double rs = rsqrt(piv);
                 a[j] *= rs;
                 m[j] = mm * rs;
             }
-            if (lane < TB) {
+            {
+                // all four 16-lane groups hold the same columns and store them (same values, same addresses): a store under
+                // "lane < 16" lets the compiler sink the whole M chain behind the L chain and spill its 120 multipliers
                 double* lv = linv + (J & 1) * TSZ;
 #pragma unroll
-                for (int j = 0; j < TB; ++j) lv[j * TLD + lane] = m[j];
+                for (int j = 0; j < TB; ++j) lv[j * TLD + l15] = m[j];
             }
             if (bad && lane == 0) dinv[TB] = 1.0;
         } else if (J > 0) {
