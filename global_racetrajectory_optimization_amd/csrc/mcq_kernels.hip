@@ -35,8 +35,6 @@ typedef double v4d __attribute__((vector_size(32)));   /* accumulator fragment o
 #define SM_CT (SM_BT + NTR * NTR * TSZ)           /* border tiles (NTR x NCT) */
 #define SM_LINV (SM_CT + NTR * NCT * TSZ)         /* inverses of the current and the previous diagonal tile (by step parity) */
 #define SM_DINV (SM_LINV + 2 * TSZ)                   /* 16 reciprocal pivots of the current diagonal tile + fail flag */
-#define SM_SFULL SM_OVL                           /* 64 x 65 work area of the dense border factorisation (tiles are dead then) */
-#define SM_STMP (SM_SFULL + MCQ_P_MAX * SLD)
 #define SM_CHUNK SM_OVL                           /* NBUF x CH x CLD */
 #define SM_RHS (SM_CHUNK + NBUF * CH * CLD)       /* NRB x CH */
 #define SM_VR (SM_RHS + NRB * CH)                 /* VRING */
@@ -132,10 +130,10 @@ __device__ __forceinline__ void lds_barrier()
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup", "local");
 }
 
-// Scheduling pin: an empty asm that "rewrites" a scalar and a vector register, i.e. ties the uses of the scalar that
-// follow to the point where the vector value is final (the SIMT emulator of tests/emu predefines it as a no-op).
-#ifndef MCQ_PIN_SV
-#define MCQ_PIN_SV(sreg, vreg) asm volatile("" : "+s"(sreg), "+v"(vreg))
+// Scheduling pin: an empty asm that "rewrites" a scalar and two vector registers, i.e. ties the uses of the scalar that
+// follow to the point where the vector values are final (the SIMT emulator of tests/emu predefines it as a no-op).
+#ifndef MCQ_PIN_SVV
+#define MCQ_PIN_SVV(sreg, vreg0, vreg1) asm volatile("" : "+s"(sreg), "+v"(vreg0), "+v"(vreg1))
 #endif
 
 // broadcast of a double from a wave-uniform lane (two v_readlane_b32 instead of an LDS-crossbar shuffle)
@@ -611,6 +609,44 @@ __device__ __forceinline__ v4d mfma16(const double a[4], const double b[4], v4d 
     return acc;
 }
 
+// Cholesky factor AND its inverse of one 16x16 LDS tile on ONE wave, in registers.  Lane i (mod 16) holds row i of L
+// (a[k] = L[i][k]); left-looking by columns, the multipliers L[j][k] are v_readlane broadcasts.  The same multipliers give
+// the inverse M = L^-1 by rows for free: lane c holds column c of M,  M[j][c] = rs_j ( [j == c] - sum_{k<j} L[j][k] M[k][c] ).
+// Writes M (row-major, upper part zero) to `lv`; returns true if a pivot is not positive.
+__device__ __forceinline__ bool diag_tile_inv(const double* d0, double* lv, int l15)
+{
+    double a[TB], m[TB];
+#pragma unroll
+    for (int cc = 0; cc < TB; ++cc) a[cc] = d0[l15 * TLD + cc];
+    bool bad = false;
+#pragma unroll
+    for (int j = 0; j < TB; ++j) {
+        // The broadcast lane is passed through an opaque register tied to the column of L and the row of M finished last:
+        // without it the compiler hoists all 120 multiplier broadcasts to where their source column becomes final, runs
+        // the M chain after the L chain and parks the multipliers in SGPRs (spilled to VGPR lanes and reloaded) -- with it
+        // at most one column's multipliers are live.
+        int jv = j;
+        if (j > 0) MCQ_PIN_SVV(jv, a[j - 1], m[j - 1]);
+        double mm = (l15 == j) ? 1.0 : 0.0;
+#pragma unroll
+        for (int k = 0; k < j; ++k) {
+            const double s = bcast_lane(a[k], jv);
+            a[j] -= a[k] * s;
+            mm -= m[k] * s;
+        }
+        const double piv = bcast_lane(a[j], jv);
+        bad |= !(piv > 0.0);
+        const double rs = rsqrt(piv);
+        a[j] *= rs;
+        m[j] = mm * rs;
+    }
+    // all four 16-lane groups hold the same columns and store them (same values, same addresses): a store under
+    // "lane < 16" lets the compiler sink the whole M chain behind the L chain and spill its 120 multipliers
+#pragma unroll
+    for (int j = 0; j < TB; ++j) lv[j * TLD + l15] = m[j];
+    return bad;
+}
+
 template <bool MK, bool SIG>
 __device__ __forceinline__ int factor_t(const SolveCtx& c, const gdouble* Hsrc, const gdouble* sig, const gschar* mk)
 {
@@ -620,7 +656,6 @@ __device__ __forceinline__ int factor_t(const SolveCtx& c, const gdouble* Hsrc, 
     double* ct = g_sm + SM_CT;
     double* dinv = g_sm + SM_DINV;
     double* linv = g_sm + SM_LINV;
-    double* Sm = g_sm + SM_SFULL;     // dense 64 x 65 work area (valid once the block loop is done)
     const gdouble* H = Hsrc;
     gdouble* L = c.w.L;
     const int lane = tid & 63, w0 = tid >> 6;
@@ -830,41 +865,7 @@ __device__ __forceinline__ int factor_t(const SolveCtx& c, const gdouble* Hsrc, 
             }
         }
         if (w0 == 0) {
-            // Diagonal tile: lane i (mod 16) holds row i of L (a[k] = L[i][k]); left-looking by columns, the multipliers
-            // L[j][k] are v_readlane broadcasts.  The same multipliers give the inverse M = L^-1 by rows for free: lane c holds
-            // column c of M,  M[j][c] = rs_j ( [j == c] - sum_{k<j} L[j][k] M[k][c] ).
-            const double* d0 = BTILE(J, J);
-            double a[TB], m[TB];
-#pragma unroll
-            for (int cc = 0; cc < TB; ++cc) a[cc] = d0[l15 * TLD + cc];
-            bool bad = false;
-#pragma unroll
-            for (int j = 0; j < TB; ++j) {
-                // The broadcast lane is passed through an opaque register tied to the column finished last: without it the
-                // compiler hoists all 120 multiplier broadcasts to where their source column becomes final and parks them in
-                // SGPRs (spilled to VGPR lanes and reloaded) -- with it at most one column's multipliers are live.
-                int jv = j;
-                if (j > 0) MCQ_PIN_SV(jv, a[j - 1]);
-                double mm = (l15 == j) ? 1.0 : 0.0;
-#pragma unroll
-                for (int k = 0; k < j; ++k) {
-                    const double s = bcast_lane(a[k], jv);
-                    a[j] -= a[k] * s;
-                    mm -= m[k] * s;
-                }
-                const double piv = bcast_lane(a[j], jv);
-                bad |= !(piv > 0.0);
-                const double rs = rsqrt(piv);
-                a[j] *= rs;
-                m[j] = mm * rs;
-            }
-            {
-                // all four 16-lane groups hold the same columns and store them (same values, same addresses): a store under
-                // "lane < 16" lets the compiler sink the whole M chain behind the L chain and spill its 120 multipliers
-                double* lv = linv + (J & 1) * TSZ;
-#pragma unroll
-                for (int j = 0; j < TB; ++j) lv[j * TLD + l15] = m[j];
-            }
+            const bool bad = diag_tile_inv(BTILE(J, J), linv + (J & 1) * TSZ, l15);
             if (bad && lane == 0) dinv[TB] = 1.0;
         } else if (J > 0) {
             LAG_DISPATCH(J - 1)
@@ -935,9 +936,12 @@ __device__ __forceinline__ int factor_t(const SolveCtx& c, const gdouble* Hsrc, 
 #undef WRITE_OUT_W
     lds_barrier();
 
-    // ---- Schur complement of the border: S = D - W'W (accumulated above), dense Cholesky in LDS -----------------------
-    __syncthreads();
-    for (int q = tid; q < MCQ_P_MAX * SLD; q += MCQ_NT) Sm[q] = 0.0;
+    // ---- Schur complement of the border: S = D - W'W (accumulated above) as 4 x 4 LDS tiles; wave 0 factors it with the same
+    //      tile kernels as the band (diagonal tile + inverse in registers, panel / trailing update / block inverse as MFMA
+    //      products) -- no block barriers, ~15 us instead of 64 barrier-separated column steps + a serial substitution ------
+#define STILE(I, K) (bt + ((I) * NCT + (K)) * TSZ)              /* S, then L_S (lower tiles, row-major) */
+#define MTILE(I) (bt + (NCT * NCT + (I)) * TSZ)                 /* inverses of the diagonal tiles of L_S */
+#define ITILE(I, K) (ct + ((I) * NCT + (K)) * TSZ)              /* off-diagonal tiles of L_S^-1 */
     __syncthreads();
     {
         int t = 0;
@@ -951,67 +955,117 @@ __device__ __forceinline__ int factor_t(const SolveCtx& c, const gdouble* Hsrc, 
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
                     const int j1 = TB * a + l4 + 4 * r, j2 = TB * bb + l15;
-                    double v = 0.0;
+                    double v = (j1 == j2) ? 1.0 : 0.0;          // identity padding beyond p, identity rows of pinned variables
                     if (j1 < p && j2 < p) {
                         const bool pj = MK && (mk[ni + j1] != 0 || mk[ni + j2] != 0);
-                        if (pj) v = (j1 == j2) ? 1.0 : 0.0;
-                        else {
+                        if (!pj) {
                             v = H[(size_t)(ni + j1) * MCQ_HLD + MCQ_HBO + j2] + sacc[slot][r];
                             if (SIG && j1 == j2) v += sig[ni + j1];
                         }
                     }
-                    Sm[j1 * SLD + j2] = v;
+                    STILE(a, bb)[(l4 + 4 * r) * TLD + l15] = v;
                 }
             }
         }
     }
     __syncthreads();
-    for (int j = 0; j < p; ++j) {
-        const double piv = Sm[j * SLD + j];
-        if (!(piv > 0.0)) { fail = 1; break; }
-        const double rinv = 1.0 / piv;
-        const int rem = p - 1 - j;
-        // finalise column j-1 (scaled) while updating with column j (unscaled): disjoint elements
-        if (j > 0) {
-            const double pv = Sm[(j - 1) * SLD + (j - 1)];
-            const double rs = 1.0 / sqrt(pv);
-            for (int r = j + tid; r < p; r += MCQ_NT) Sm[r * SLD + (j - 1)] *= rs;
+    if (w0 == 0) {
+        bool bad = false;
+        const v4d z4 = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll 1
+        for (int a = 0; a < NCT; ++a) {
+            bad |= diag_tile_inv(STILE(a, a), MTILE(a), l15);
+            __builtin_amdgcn_wave_barrier();
+            double mv[4];
+#pragma unroll
+            for (int kc = 0; kc < 4; ++kc) mv[kc] = MTILE(a)[l15 * TLD + l4 + 4 * kc];
+            // panel: L_S(i, a) = S(i, a) M_a'  (computed transposed: the result lands in row-major operand layout)
+#pragma unroll 1
+            for (int i = a + 1; i < NCT; ++i) {
+                double* ti = STILE(i, a);
+                double bi[4];
+#pragma unroll
+                for (int kc = 0; kc < 4; ++kc) bi[kc] = ti[l15 * TLD + l4 + 4 * kc];
+                const v4d x = mfma16(mv, bi, z4);
+                __builtin_amdgcn_wave_barrier();
+#pragma unroll
+                for (int r = 0; r < 4; ++r) ti[l15 * TLD + l4 + 4 * r] = x[r];
+            }
+            __builtin_amdgcn_wave_barrier();
+            // trailing update: S(i, k) -= L_S(i, a) L_S(k, a)',  a < k <= i
+#pragma unroll 1
+            for (int i = a + 1; i < NCT; ++i) {
+                double av[4];
+#pragma unroll
+                for (int kc = 0; kc < 4; ++kc) av[kc] = -STILE(i, a)[l15 * TLD + l4 + 4 * kc];
+#pragma unroll 1
+                for (int k = a + 1; k <= i; ++k) {
+                    double bv[4];
+                    v4d acc;
+                    double* tk = STILE(i, k);
+#pragma unroll
+                    for (int kc = 0; kc < 4; ++kc) bv[kc] = STILE(k, a)[l15 * TLD + l4 + 4 * kc];
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) acc[r] = tk[(l4 + 4 * r) * TLD + l15];
+                    acc = mfma16(av, bv, acc);
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) tk[(l4 + 4 * r) * TLD + l15] = acc[r];
+                }
+            }
+            __builtin_amdgcn_wave_barrier();
         }
-        for (int e = tid; e < rem * rem; e += MCQ_NT) {
-            const int r = j + 1 + e / rem, cc = j + 1 + e % rem;
-            if (cc <= r) Sm[r * SLD + cc] -= Sm[r * SLD + j] * Sm[cc * SLD + j] * rinv;
+        // block inverse of L_S:  Inv(j, j) = M_j,   Inv(i, j) = -M_i sum_{k=j}^{i-1} L_S(i, k) Inv(k, j)   (i > j)
+#pragma unroll 1
+        for (int j = 0; j < NCT - 1; ++j) {
+#pragma unroll 1
+            for (int i = j + 1; i < NCT; ++i) {
+                v4d acc = z4;
+#pragma unroll 1
+                for (int k = j; k < i; ++k) {
+                    const double* lik = STILE(i, k);
+                    const double* ikj = (k == j) ? MTILE(j) : ITILE(k, j);
+                    double av[4], bv[4];
+#pragma unroll
+                    for (int kc = 0; kc < 4; ++kc) {
+                        av[kc] = lik[l15 * TLD + l4 + 4 * kc];
+                        bv[kc] = ikj[(l4 + 4 * kc) * TLD + l15];
+                    }
+                    acc = mfma16(av, bv, acc);
+                }
+                double mi[4], sb[4];
+#pragma unroll
+                for (int kc = 0; kc < 4; ++kc) {
+                    mi[kc] = -MTILE(i)[l15 * TLD + l4 + 4 * kc];
+                    sb[kc] = acc[kc];                         // accumulator layout == column-operand layout
+                }
+                const v4d res = mfma16(mi, sb, z4);
+                double* o = ITILE(i, j);
+#pragma unroll
+                for (int r = 0; r < 4; ++r) o[(l4 + 4 * r) * TLD + l15] = res[r];
+                __builtin_amdgcn_wave_barrier();
+            }
         }
-        lds_barrier();
-        if (j > 0 && tid == 0) Sm[(j - 1) * SLD + (j - 1)] = sqrt(Sm[(j - 1) * SLD + (j - 1)]);
+        if (bad && lane == 0) dinv[TB] = 1.0;
     }
-    if (fail) return MCQ_NOT_PD;
     __syncthreads();
-    if (tid == 0 && p > 0) Sm[(p - 1) * SLD + (p - 1)] = sqrt(Sm[(p - 1) * SLD + (p - 1)]);
-    __syncthreads();
-    // explicit inverse of L_S (p <= 64): the border solves of every triangular solve become two LDS mat-vecs instead of
-    // 2 x 64 dependent wave reductions.  Thread c computes column c by forward substitution; the result is kept packed
-    // (lower triangle by rows) in SM_S, outside the overlay, for the triangular solves that follow.
+    if (dinv[TB] != 0.0) return MCQ_NOT_PD;
+    // L_S^-1 packed (lower triangle by rows) into SM_S, outside the overlay, for the triangular solves that follow: the
+    // border solves of every sweep are two LDS mat-vecs.
     {
-        double* tmp = g_sm + SM_STMP;
         double* spk = g_sm + SM_S;
-        for (int q = tid; q < MCQ_P_MAX * SLD; q += MCQ_NT) tmp[q] = 0.0;
-        __syncthreads();
-        if (tid < p) {
-            const int cc = tid;
-            tmp[cc * SLD + cc] = 1.0 / Sm[cc * SLD + cc];
-            for (int r = cc + 1; r < p; ++r) {
-                double acc = 0.0;
-                for (int k = cc; k < r; ++k) acc += Sm[r * SLD + k] * tmp[k * SLD + cc];
-                tmp[r * SLD + cc] = -acc / Sm[r * SLD + r];
+        for (int q = tid; q < MCQ_P_MAX * MCQ_P_MAX; q += MCQ_NT) {
+            const int r = q / MCQ_P_MAX, cc = q - r * MCQ_P_MAX;
+            if (cc <= r) {
+                const int tr = r / TB, tc = cc / TB;
+                const double* src = (tr == tc) ? MTILE(tr) : ITILE(tr, tc);
+                spk[r * (r + 1) / 2 + cc] = src[(r % TB) * TLD + (cc % TB)];
             }
         }
         __syncthreads();
-        for (int q = tid; q < MCQ_P_MAX * MCQ_P_MAX; q += MCQ_NT) {
-            const int r = q / MCQ_P_MAX, cc = q - r * MCQ_P_MAX;
-            if (cc <= r) spk[r * (r + 1) / 2 + cc] = tmp[r * SLD + cc];
-        }
-        __syncthreads();
     }
+#undef STILE
+#undef MTILE
+#undef ITILE
     c.tk[6] += FTICK() - t_tail;    // drain + border factor + its inverse
     return 0;
 }

@@ -215,7 +215,7 @@ inline int hipemu_readlane(int v, int src) { return (int)__shfl((double)v, src);
 #define __builtin_amdgcn_readlane(v, l) hipemu_readlane((v), (l))
 #define __builtin_amdgcn_s_barrier() hipemu::block_barrier()
 #define __builtin_amdgcn_sched_barrier(mask) ((void)0)
-#define MCQ_PIN_SV(sreg, vreg) ((void)0)
+#define MCQ_PIN_SVV(sreg, vreg0, vreg1) ((void)0)
 #define __builtin_amdgcn_wave_barrier() hipemu::wave_barrier()
 #define __builtin_amdgcn_fence(...) ((void)0)
 inline int __double2loint(double d) { long long b; memcpy(&b, &d, 8); return (int)(b & 0xffffffffLL); }
