@@ -28,12 +28,13 @@ typedef double v4d __attribute__((vector_size(32)));   /* accumulator fragment o
 #define SM_PART (SM_XD + 64)
 #define SM_S (SM_PART + MCQ_NW * 128)             /* L_S^-1, packed rows: entry (r, c <= r) at r (r + 1) / 2 + c */
 #define SM_OVL (SM_S + SPK)                       /* overlay region */
-#define OVL_SIZE_F (NTR * NTR * TSZ + NTR * NCT * TSZ + 2 * TSZ + 32)
+#define NTRC (NTR + 1)                   /* tile rows of the border window: one more than the band (committed a phase earlier) */
+#define OVL_SIZE_F (NTR * NTR * TSZ + NTRC * NCT * TSZ + 2 * TSZ + 32)
 #define OVL_SIZE_S (NBUF * CH * CLD + NRB * CH + VRING)
 #define OVL_SIZE (OVL_SIZE_F > OVL_SIZE_S ? OVL_SIZE_F : OVL_SIZE_S)
 #define SM_BT SM_OVL                              /* band tiles   (NTR x NTR) */
-#define SM_CT (SM_BT + NTR * NTR * TSZ)           /* border tiles (NTR x NCT) */
-#define SM_LINV (SM_CT + NTR * NCT * TSZ)         /* inverses of the current and the previous diagonal tile (by step parity) */
+#define SM_CT (SM_BT + NTR * NTR * TSZ)           /* border tiles (NTRC x NCT) */
+#define SM_LINV (SM_CT + NTRC * NCT * TSZ)        /* inverses of the current and the previous diagonal tile (by step parity) */
 #define SM_DINV (SM_LINV + 2 * TSZ)                   /* 16 reciprocal pivots of the current diagonal tile + fail flag */
 #define SM_CHUNK SM_OVL                           /* NBUF x CH x CLD */
 #define SM_RHS (SM_CHUNK + NBUF * CH * CLD)       /* NRB x CH */
@@ -505,7 +506,7 @@ struct SolveCtx {
 #define FTICK() (MCQ_FINE_TIMERS ? TICK() : 0LL)
 
 // ---- bordered-band Cholesky of  M = H + diag(sig)  with rows/cols of pinned variables replaced by identity ----------
-// Blocked right-looking factorisation, 16 columns per step, on an LDS window of 5 x 5 band tiles + 5 x 4 border tiles:
+// Blocked right-looking factorisation, 16 columns per step, on an LDS window of 5 x 5 band tiles + 6 x 4 border tiles:
 //   phase 1  wave 0 factors the 16x16 diagonal tile in registers (left-looking, v_readlane broadcasts, no LDS trips);
 //   phase 2  128 lanes do the 16-step triangular solves of the panel: 64 rows of L below the diagonal tile and the 64
 //            columns of the border block row  W = L00^-1 C;
@@ -516,13 +517,13 @@ struct SolveCtx {
 // Output: L rows in w.L (row i: [0] = 1/L_ii, [k] = L[i,i-k]; [HBO+jj] = W[i][jj]); L_S (p x p, lower) in LDS SM_S.
 // Returns 0 or MCQ_NOT_PD (uniform across the block).
 #define BTILE(I, K) (bt + ((((I) % NTR) * NTR) + ((K) % NTR)) * TSZ)
-#define CTILE(I, a) (ct + ((((I) % NTR) * NCT) + (a)) * TSZ)
+#define CTILE(I, a) (ct + ((((I) % NTRC) * NCT) + (a)) * TSZ)
 // L(P+dI, P), dI = 1..4, once the panel of step P is done: in place, except the first sub-diagonal tile, which every wave
 // still reads as T(P+1, P) while wave 0 produces it -- that one goes to the dead upper-triangle slot (P+1, P+2)
 #define LTILE(dI, P) ((dI) == 1 ? BTILE((P) + 1, (P) + 2) : BTILE((P) + (dI), (P)))
 #define ROW_ITEMS (TB * (NTR * TB + MCQ_P_MAX))            /* 16 x 144 doubles per tile row */
-#define PF_ITEMS ((ROW_ITEMS + MCQ_NT - 1) / MCQ_NT)
-#define PF_BAND_ITEMS ((TB * NTR * TB) / MCQ_NT)          /* 1280 / 256 = 5: the band entries are exactly items u < 5 */
+#define PF_THREADS (MCQ_NT - 64)                           /* waves 1..3 fetch and commit; wave 0 only runs the critical path */
+#define PF_ITEMS (ROW_ITEMS / PF_THREADS)                 /* 2304 / 192 = 12 */
 
 // Raw (un-decoded) loads of one window entry: kept in registers while the loads are in flight, decoded when the entry is
 // committed to LDS -- nothing between fetch and commit depends on the loaded values, so no s_waitcnt is placed early.
@@ -601,6 +602,82 @@ __device__ __forceinline__ void tile_row_store(double* bt, double* ct, int R, in
     }
 }
 
+// Steady-state fetch / commit of a tile row: for tile rows that lie completely inside the interior (R >= NTR-1 and
+// 16 (R+1) <= ni) every index of an item is its per-thread constant plus a multiple of R, so the per-step address
+// arithmetic of the generic functions above (divisions, bounds, band limits: ~40 integer instructions per item, twice per
+// step) shrinks to a handful.  Constants are derived once per factorisation from the same item numbering.
+struct PfConst {
+    int goff;      // H offset relative to row block R:  + R * TB * MCQ_HLD
+    int loff;      // LDS offset inside the tile slot (band) / inside the border tile row (border)
+    int flags;     // bit 0 band item, bit 1 entry exists (inside the band / column < p), bit 2 diagonal entry; bits 8.. 1 + tile column
+    int m0, m1;    // mask byte indices: relative to R * TB (band: column, row; border: row), absolute (border: ni + column)
+};
+
+__device__ __forceinline__ PfConst pf_const(int q, int ni, int b, int p)
+{
+    PfConst k;
+    if (q < TB * NTR * TB) {
+        const int ee = q / TB, rr = q - ee * TB;
+        const int tcol = ee / TB, cc = ee % TB;
+        const int kk = (NTR - 1 - tcol) * TB + rr - cc;
+        const bool valid = (kk >= 0) & (kk <= b);
+        k.goff = ((tcol - (NTR - 1)) * TB + cc) * MCQ_HLD + (valid ? kk : 0);
+        k.loff = rr * TLD + cc;
+        k.flags = 1 | (valid ? 2 : 0) | (kk == 0 ? 4 : 0) | ((1 + tcol) << 8);
+        k.m0 = (tcol - (NTR - 1)) * TB + cc;
+        k.m1 = rr;
+    } else {
+        const int q2 = q - TB * NTR * TB;
+        const int rr = q2 / MCQ_P_MAX, jj = q2 - rr * MCQ_P_MAX;
+        const bool ok = jj < p;
+        k.goff = rr * MCQ_HLD + MCQ_HBO + (ok ? jj : 0);
+        k.loff = (jj / TB) * TSZ + rr * TLD + (jj % TB);
+        k.flags = ok ? 2 : 0;
+        k.m0 = rr;
+        k.m1 = ni + (ok ? jj : 0);
+    }
+    return k;
+}
+
+// BAND (band / border item) is a compile-time property of an item slot: with 192 fetch threads, slots 0..5 are band items,
+// slots 7..11 border items for every thread, slot 6 is a band item on waves 1 and 2 and a border item on wave 3 (a scalar
+// branch on the wave index).  Diagonal entries (the only ones that take the sig shift) occur in slots 5 and 6 only.
+template <bool MK, bool SIG>
+__device__ __forceinline__ RawEntry tile_row_fetch_fast(const gdouble* H, const gdouble* sig, const gschar* mk, int R, const PfConst& k,
+                                                        const bool BAND, const bool MAYDIAG)
+{
+    RawEntry e;
+    e.sg = 0.0;
+    e.m0 = e.m1 = 0;
+    e.h = H[(size_t)R * (TB * MCQ_HLD) + k.goff];
+    if (MK) {
+        e.m0 = mk[R * TB + k.m0];
+        e.m1 = mk[BAND ? R * TB + k.m1 : k.m1];
+    }
+    if (SIG && BAND && MAYDIAG) e.sg = sig[R * TB + k.m0];      // column index: valid for every band item, used by the diagonal ones
+    return e;
+}
+
+template <bool MK, bool SIG>
+__device__ __forceinline__ void tile_row_commit_fast(double* bt, double* ct, const RawEntry& e, int R, const PfConst& k,
+                                                     const bool BAND, const bool MAYDIAG)
+{
+    const bool pinned = MK && ((e.m0 != 0) | (e.m1 != 0));
+    double v = (k.flags & 2) ? e.h : 0.0;
+    if (BAND) {
+        const bool dg = MAYDIAG && (k.flags & 4);
+        if (MK) v = pinned ? (dg ? 1.0 : 0.0) : v;
+        if (SIG && MAYDIAG) v += (dg && !pinned) ? e.sg : 0.0;
+        const int r5 = R % NTR;
+        int kc = r5 + (k.flags >> 8);               // (R - (NTR-1) + tcol) mod NTR
+        kc = kc >= NTR ? kc - NTR : kc;
+        bt[(r5 * NTR + kc) * TSZ + k.loff] = v;
+    } else {
+        if (MK) v = pinned ? 0.0 : v;
+        ct[(R % NTRC) * (NCT * TSZ) + k.loff] = v;
+    }
+}
+
 // D(16x16) += A(16x16) B(16x16) as four K=4 matrix-core steps; a[kc], b[kc] are the per-lane operand values
 __device__ __forceinline__ v4d mfma16(const double a[4], const double b[4], v4d acc)
 {
@@ -667,19 +744,24 @@ __device__ __forceinline__ int factor_t(const SolveCtx& c, const gdouble* Hsrc, 
     for (int m = 0; m < NCT; ++m) sacc[m] = (v4d){0.0, 0.0, 0.0, 0.0};
     RawEntry pf[PF_ITEMS];
 
+    const int lt = tid - 64;         // fetch / commit thread of waves 1..3
+    PfConst pc[PF_ITEMS];
+#pragma unroll
+    for (int u = 0; u < PF_ITEMS; ++u) pc[u] = pf_const((lt >= 0 ? lt : 0) + u * PF_THREADS, ni, b, p);
+#define PF_FAST(R) ((R) >= NTR - 1 && ((R) + 1) * TB <= ni)
+    const bool wave3 = __builtin_amdgcn_readfirstlane(w0) == 3;      // scalar: slot 6 is a border item on wave 3 only
     __syncthreads();
     // prologue: tile rows 0 .. NTR-1
-    for (int R = 0; R < NTR; ++R) {
-        // all loads of a tile row are issued before the first decode (one HBM round trip per tile row, not per item)
+    if (lt >= 0) {
+        for (int R = 0; R < NTR; ++R) {
+            // all loads of a tile row are issued before the first decode (one HBM round trip per tile row, not per item)
 #pragma unroll
-        for (int u = 0; u < PF_ITEMS; ++u) {
-            const int q = tid + u * MCQ_NT;
-            pf[u] = tile_row_fetch<MK, SIG>(H, sig, mk, ni, b, p, R, q < ROW_ITEMS ? q : 0);
-        }
+            for (int u = 0; u < PF_ITEMS; ++u) pf[u] = tile_row_fetch<MK, SIG>(H, sig, mk, ni, b, p, R, lt + u * PF_THREADS);
 #pragma unroll
-        for (int u = 0; u < PF_ITEMS; ++u) {
-            const int q = tid + u * MCQ_NT;
-            tile_row_store(bt, ct, R, q, tile_row_decode<MK, SIG>(pf[u], ni, b, p, R, q < ROW_ITEMS ? q : 0));
+            for (int u = 0; u < PF_ITEMS; ++u) {
+                const int q = lt + u * PF_THREADS;
+                tile_row_store(bt, ct, R, q, tile_row_decode<MK, SIG>(pf[u], ni, b, p, R, q));
+            }
         }
     }
     if (tid == 0) dinv[TB] = 0.0;   // fail flag
@@ -689,10 +771,10 @@ __device__ __forceinline__ int factor_t(const SolveCtx& c, const gdouble* Hsrc, 
     //   diag(J) [+ its inverse M_J]  ->  panel(J) = products with M_J  ->  update of block column J+1;
     // everything else that step J-1 owes (16 border tiles, 10 Schur tiles, 6 band tiles, the write-out of L / W / the
     // inverse tile) runs on waves 1..3 WHILE wave 0 factors the next diagonal tile:
-    //   phase 1   wave 0: diag(J) and M_J = L_JJ^-1 (registers, v_readlane)   | waves 1..3: lag(J-1) + write-out(J-1)
-    //             all: commit the band part of the tile row fetched during the previous step
+    //   phase 1   wave 0: diag(J) and M_J = L_JJ^-1 (registers, v_readlane), nothing else
+    //             waves 1..3: commit the tile row fetched during the previous step, put the next one in flight,
+    //                         lag(J-1) + write-out(J-1)
     //   phase 2   wave w: L(J+1+w, J) = T M_J',  W_J(w) = M_J C(J, w),  T(J+1+w, J+1) -= L(J+1+w, J) L(J+1, J)'   (MFMA)
-    //             all: commit the border part of that tile row into the slots lag(J-1) just released
     int fail = 0;
     const int wl = w0 - 1;           // lag-worker index of waves 1..3
     // Tile ownership of the three lag waves (wl = 0..2):
@@ -797,9 +879,15 @@ __device__ __forceinline__ int factor_t(const SolveCtx& c, const gdouble* Hsrc, 
 
 #define LAG_DISPATCH(P)                                                                                                \
     {                                                                                                                  \
-        if (wl == 0) { LAG_WORK((P), 0) WRITE_OUT_W((P), 1) }                                                          \
-        else if (wl == 1) { LAG_WORK((P), 1) WRITE_OUT_W((P), 0) }                                                     \
-        else { LAG_WORK((P), 2) WRITE_OUT_L((P)) }                                                                     \
+        if (wl == 0) { LAG_WORK((P), 0) }                                                                              \
+        else if (wl == 1) { LAG_WORK((P), 1) }                                                                         \
+        else { LAG_WORK((P), 2) }                                                                                      \
+    }
+#define WRITE_OUT_DISPATCH(P)                                                                                          \
+    {                                                                                                                  \
+        if (wl == 0) { WRITE_OUT_W((P), 1) }                                                                           \
+        else if (wl == 1) { WRITE_OUT_W((P), 0) }                                                                      \
+        else { WRITE_OUT_L((P)) }                                                                                      \
     }
     // Write-out of block column P of L (tiles below the diagonal one; the sweeps use the inverse tile instead of the
     // entries inside the diagonal tile), of the inverse diagonal tile and of block row P of W.  Shared by the three lag waves
@@ -846,29 +934,49 @@ __device__ __forceinline__ int factor_t(const SolveCtx& c, const gdouble* Hsrc, 
     }
 
     for (int J = 0; J < nblk; ++J) {
-        // fetch tile row J + NTR (committed in phase 2 of the NEXT step: a full step in flight)
-        RawEntry pfn[PF_ITEMS];
-#pragma unroll
-        for (int u = 0; u < PF_ITEMS; ++u) {
-            const int q = tid + u * MCQ_NT;
-            pfn[u] = tile_row_fetch<MK, SIG>(H, sig, mk, ni, b, p, J + NTR, q < ROW_ITEMS ? q : 0);
-        }
         long long tp = FTICK();
         // ---- phase 1 --------------------------------------------------------------------------------------------------------
-        // band part of tile row J-1+NTR (fetched during the previous step; items u < 5 are exactly the 16 x 80 band entries):
-        // its slots -- tile row J-1 of the band window -- were last read by panel(J-1); panel(J) needs tile (J+4, J).
-        if (J > 0) {
-#pragma unroll
-            for (int u = 0; u < PF_BAND_ITEMS; ++u) {
-                const int q = tid + u * MCQ_NT;
-                tile_row_store(bt, ct, J - 1 + NTR, q, tile_row_decode<MK, SIG>(pf[u], ni, b, p, J - 1 + NTR, q));
-            }
-        }
         if (w0 == 0) {
             const bool bad = diag_tile_inv(BTILE(J, J), linv + (J & 1) * TSZ, l15);
             if (bad && lane == 0) dinv[TB] = 1.0;
-        } else if (J > 0) {
-            LAG_DISPATCH(J - 1)
+        } else {
+            // Tile row J-1+NTR (fetched during the previous step) enters the window: its band slots -- tile row J-1 -- were
+            // last read by panel(J-1), its border slots -- tile row J-2 of the 6-row border window -- by lag(J-2) in the
+            // previous step; panel(J) needs tile (J+4, J).  Then tile row J+NTR goes in flight: a full step ahead.
+            if (J > 0) {
+                const int R = J - 1 + NTR;
+                if (PF_FAST(R)) {
+#pragma unroll
+                    for (int u = 0; u < PF_ITEMS; ++u) {
+                        if (u < 6) tile_row_commit_fast<MK, SIG>(bt, ct, pf[u], R, pc[u], true, u == 5);
+                        else if (u > 6) tile_row_commit_fast<MK, SIG>(bt, ct, pf[u], R, pc[u], false, false);
+                        else if (wave3) tile_row_commit_fast<MK, SIG>(bt, ct, pf[u], R, pc[u], false, false);
+                        else tile_row_commit_fast<MK, SIG>(bt, ct, pf[u], R, pc[u], true, true);
+                    }
+                } else {
+#pragma unroll
+                    for (int u = 0; u < PF_ITEMS; ++u) {
+                        const int q = lt + u * PF_THREADS;
+                        tile_row_store(bt, ct, R, q, tile_row_decode<MK, SIG>(pf[u], ni, b, p, R, q));
+                    }
+                }
+            }
+            {
+                const int R = J + NTR;
+                if (PF_FAST(R)) {
+#pragma unroll
+                    for (int u = 0; u < PF_ITEMS; ++u) {
+                        if (u < 6) pf[u] = tile_row_fetch_fast<MK, SIG>(H, sig, mk, R, pc[u], true, u == 5);
+                        else if (u > 6) pf[u] = tile_row_fetch_fast<MK, SIG>(H, sig, mk, R, pc[u], false, false);
+                        else if (wave3) pf[u] = tile_row_fetch_fast<MK, SIG>(H, sig, mk, R, pc[u], false, false);
+                        else pf[u] = tile_row_fetch_fast<MK, SIG>(H, sig, mk, R, pc[u], true, true);
+                    }
+                } else {
+#pragma unroll
+                    for (int u = 0; u < PF_ITEMS; ++u) pf[u] = tile_row_fetch<MK, SIG>(H, sig, mk, ni, b, p, R, lt + u * PF_THREADS);
+                }
+            }
+            if (J > 0) { LAG_DISPATCH(J - 1) WRITE_OUT_DISPATCH(J - 1) }
         }
         lds_barrier();
         c.tk[4] += FTICK() - tp; tp = FTICK();
@@ -910,17 +1018,6 @@ __device__ __forceinline__ int factor_t(const SolveCtx& c, const gdouble* Hsrc, 
                 tu[(l4 + 4 * r) * TLD + l15] = accu[r];
             }
         }
-        // border part of the tile row fetched during the previous step: its slots held W_(J-1), which lag(J-1) and the
-        // write-out of step J-1 (phase 1) have released; first used by lag(J) in the next step
-        if (J > 0) {
-#pragma unroll
-            for (int u = PF_BAND_ITEMS; u < PF_ITEMS; ++u) {
-                const int q = tid + u * MCQ_NT;
-                tile_row_store(bt, ct, J - 1 + NTR, q, tile_row_decode<MK, SIG>(pf[u], ni, b, p, J - 1 + NTR, q < ROW_ITEMS ? q : 0));
-            }
-        }
-#pragma unroll
-        for (int u = 0; u < PF_ITEMS; ++u) pf[u] = pfn[u];
         lds_barrier();
         c.tk[5] += FTICK() - tp;
     }
@@ -928,10 +1025,12 @@ __device__ __forceinline__ int factor_t(const SolveCtx& c, const gdouble* Hsrc, 
     const long long t_tail = FTICK();
     // drain: what the last step still owes
     if (nblk > 0) {
-        if (w0 > 0) { LAG_DISPATCH(nblk - 1) }
+        if (w0 > 0) { LAG_DISPATCH(nblk - 1) WRITE_OUT_DISPATCH(nblk - 1) }
     }
 #undef LAG_WORK
+#undef PF_FAST
 #undef LAG_DISPATCH
+#undef WRITE_OUT_DISPATCH
 #undef WRITE_OUT_L
 #undef WRITE_OUT_W
     lds_barrier();

@@ -214,6 +214,7 @@ inline hipemu_v4d hipemu_mfma_f64_16x16x4(double a, double b, hipemu_v4d c)
 inline int hipemu_readlane(int v, int src) { return (int)__shfl((double)v, src); }
 #define __builtin_amdgcn_readlane(v, l) hipemu_readlane((v), (l))
 #define __builtin_amdgcn_s_barrier() hipemu::block_barrier()
+#define __builtin_amdgcn_readfirstlane(v) (v)     /* only used on wave-uniform values */
 #define __builtin_amdgcn_sched_barrier(mask) ((void)0)
 #define MCQ_PIN_SVV(sreg, vreg0, vreg1) ((void)0)
 #define __builtin_amdgcn_wave_barrier() hipemu::wave_barrier()
