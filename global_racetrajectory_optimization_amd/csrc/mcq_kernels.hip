@@ -1304,22 +1304,30 @@ __device__ __noinline__ void solve(const SolveCtx& c, gdouble* v)
             for (int J = cq * (CH / TB); J < (cq + 1) * (CH / TB); ++J) {
                 const int i = J * TB + l15;
                 const double* lr = LROW(i);
-                // lane (row l15, group l4) covers source tile K = J - 4 + l4: columns 16K + cc, band offset k = i - column
-                double acc = 0.0;
+                // lane (row l15, group l4) covers source tile K = J - 4 + l4: columns 16K + cc, band offset k = i - column.
+                // Entries beyond the band (k > 64, group 0 only) are read from the row's inverse-tile slots and masked;
+                // first-chunk columns < 0 hit masked zeros.  All LDS offsets are compile-time constants off two bases.
                 const int kb = TB * (4 - l4) + l15;          // k for cc = 0
-                const int c0 = (J - 4 + l4) * TB;            // first source column (may be negative: entries are masked zeros)
+                const double* lk = lr + kb - 1;              // lk[-cc] = L[i, i - (kb - cc)]
+                const double* vs = vring + (((J - 4 + l4) * TB) & (VRING - 1));      // 16 consecutive ring slots (no wrap inside)
+                double a0 = 0.0, a1 = 0.0;
 #pragma unroll
-                for (int cc = 0; cc < TB; ++cc) {
-                    const int k = kb - cc;
-                    const double lv = lr[(k <= MCQ_BH_MAX ? k : 1) - 1];
-                    acc += (k <= MCQ_BH_MAX ? lv : 0.0) * vring[(c0 + cc) & (VRING - 1)];
+                for (int cc = 0; cc < TB; cc += 2) {
+                    const double l0 = lk[-cc], l1 = lk[-cc - 1];
+                    a0 += (kb - cc <= MCQ_BH_MAX ? l0 : 0.0) * vs[cc];
+                    a1 += (kb - cc - 1 <= MCQ_BH_MAX ? l1 : 0.0) * vs[cc + 1];
                 }
+                double acc = a0 + a1;
                 acc += __shfl_xor(acc, 16);
                 acc += __shfl_xor(acc, 32);
                 const double sv = RHSV(i) - acc;
-                double y = 0.0;
+                double y0 = 0.0, y1 = 0.0;
 #pragma unroll
-                for (int cc = 0; cc < TB; ++cc) y += lr[MCQ_BH_MAX + cc] * bcast_lane(sv, cc);     // row l15 of the inverse tile
+                for (int cc = 0; cc < TB; cc += 2) {         // row l15 of the inverse tile
+                    y0 += lr[MCQ_BH_MAX + cc] * bcast_lane(sv, cc);
+                    y1 += lr[MCQ_BH_MAX + cc + 1] * bcast_lane(sv, cc + 1);
+                }
+                const double y = y0 + y1;
                 __builtin_amdgcn_wave_barrier();
                 if (l4 == 0) {
                     vring[i & (VRING - 1)] = y;
@@ -1420,22 +1428,32 @@ __device__ __noinline__ void solve(const SolveCtx& c, gdouble* v)
             if (wv == 0) {
                 for (int J = (cq + 1) * (CH / TB) - 1; J >= cq * (CH / TB); --J) {
                     const int j = J * TB + l15;               // unknown handled by this lane's row group
-                    // lane (column l15, group l4) covers the rows of tile K = J + 1 + l4: i = 16K + rr, offset k = i - j
-                    double acc = 0.0;
+                    // lane (column l15, group l4) covers the rows of tile K = J + 1 + l4: i = 16K + rr, offset k = i - j.
+                    // A tile never straddles a chunk: its 16 rows are 16 consecutive LDS rows, so every offset below is a
+                    // compile-time constant off one base (entries with k > 64 land in inverse-tile slots and are masked).
                     const int i0 = (J + 1 + l4) * TB;
                     const int kb = TB * (l4 + 1) - l15;       // k for rr = 0
+                    const double* lk = LROW(i0) + kb - 1;     // lk[rr (CLD + 1)] = L[i0 + rr, j]
+                    const double* vs = vring + (i0 & (VRING - 1));
+                    double a0 = 0.0, a1 = 0.0;
 #pragma unroll
-                    for (int rr = 0; rr < TB; ++rr) {
-                        const int k = kb + rr;
-                        const double lv = LROW(i0 + rr)[(k <= MCQ_BH_MAX ? k : 1) - 1];
-                        acc += (k <= MCQ_BH_MAX ? lv : 0.0) * vring[(i0 + rr) & (VRING - 1)];
+                    for (int rr = 0; rr < TB; rr += 2) {
+                        const double l0 = lk[rr * (CLD + 1)], l1 = lk[(rr + 1) * (CLD + 1)];
+                        a0 += (kb + rr <= MCQ_BH_MAX ? l0 : 0.0) * vs[rr];
+                        a1 += (kb + rr + 1 <= MCQ_BH_MAX ? l1 : 0.0) * vs[rr + 1];
                     }
+                    double acc = a0 + a1;
                     acc += __shfl_xor(acc, 16);
                     acc += __shfl_xor(acc, 32);
                     const double sv = RHSV(j) - acc;
-                    double x = 0.0;
+                    const double* mi = LROW(J * TB) + MCQ_BH_MAX + l15;       // column l15 of the inverse tile, row stride CLD
+                    double x0 = 0.0, x1 = 0.0;
 #pragma unroll
-                    for (int rr = 0; rr < TB; ++rr) x += LROW(J * TB + rr)[MCQ_BH_MAX + l15] * bcast_lane(sv, rr);   // column l15 of the inverse tile
+                    for (int rr = 0; rr < TB; rr += 2) {
+                        x0 += mi[rr * CLD] * bcast_lane(sv, rr);
+                        x1 += mi[(rr + 1) * CLD] * bcast_lane(sv, rr + 1);
+                    }
+                    const double x = x0 + x1;
                     __builtin_amdgcn_wave_barrier();
                     if (l4 == 0) {
                         vring[j & (VRING - 1)] = x;
