@@ -1249,7 +1249,7 @@ __device__ __forceinline__ void chunk_commit(double* chunk, double* rring, int q
 #define LROW(r) (chunk + (((r) / CH) % NBUF) * CH * CLD + ((r) % CH) * CLD)
 #define RHSV(r) (rring[(((r) / CH) % NRB) * CH + ((r) % CH)])
 #define NLW (MCQ_NW - 1)                        /* loader waves */
-#define WPAIRS ((CH / 2 + NLW - 1) / NLW)       /* row pairs of a chunk handled by one loader wave */
+#define WGRP ((CH / 8 + NLW - 1) / NLW)         /* 8-row groups of a chunk handled by one loader wave */
 
 __device__ __noinline__ void solve(const SolveCtx& c, gdouble* v)
 {
@@ -1273,24 +1273,34 @@ __device__ __noinline__ void solve(const SolveCtx& c, gdouble* v)
         const int e2 = (lt >= 0 ? lt : 0) + u * LD_THREADS;
         goff[u] = (e2 / (CLD / 2)) * MCQ_LLD + 2 * (e2 % (CLD / 2));
     }
-    // Border block W (64 doubles per row): a loader wave reads TWO rows per 16-byte load instruction -- lanes 0..31 the
-    // pairs (2 jp, 2 jp + 1) of row 2 pr, lanes 32..63 those of row 2 pr + 1, pr = (wv - 1) + NLW m.
-    const int hf = lane >> 5, jp = lane & 31;
-    d2 wreg[WPAIRS];
-#define WROW(q, m) ((q) * CH + 2 * ((wv - 1) + NLW * (m)) + hf)
-#define WOK(q, m) (((wv - 1) + NLW * (m) < CH / 2) && (q) >= 0 && WROW(q, m) < ni && 2 * jp < p)
+    // Border block W (64 doubles per row): a loader wave reads EIGHT rows per 16-byte load instruction -- lane (g8, c8) =
+    // (lane >> 3, lane & 7) takes the pair (16 u + 2 c8, +1) of row 8 grp + g8 in load u = 0..3 (128 contiguous bytes per row
+    // and instruction), row groups grp = (wv - 1) + NLW m.  A row's dot product with x_D then reduces over 8 lanes only.
+    const int g8 = lane >> 3, c8 = lane & 7;
+    d2 wreg[WGRP][4];
+#define WGOK(m) ((wv - 1) + NLW * (m) < CH / 8)
+#define WROW(q, m) ((q) * CH + 8 * ((wv - 1) + NLW * (m)) + g8)
+#define WOK(q, m) (WGOK(m) && (q) >= 0 && WROW(q, m) < ni)
 #define WFETCH(q)                                                                                              \
-    _Pragma("unroll") for (int m = 0; m < WPAIRS; ++m) {                                                       \
-        const int r_ = WROW(q, m);                                                                             \
-        const int rs_ = ((q) >= 0 && r_ < ni) ? r_ : 0;                                                        \
-        wreg[m] = *(const gd2*)(L + (size_t)rs_ * MCQ_LLD + MCQ_LBW + 2 * jp);                                 \
+    _Pragma("unroll") for (int m = 0; m < WGRP; ++m) {                                                         \
+        const int rs_ = WOK(q, m) ? WROW(q, m) : 0;                                                            \
+        const gdouble* wr_ = L + (size_t)rs_ * MCQ_LLD + MCQ_LBW + 2 * c8;                                     \
+        _Pragma("unroll") for (int u = 0; u < 4; ++u) wreg[m][u] = *(const gd2*)(wr_ + 16 * u);                \
+    }
+#define TACC_ADD(q)                                                                                            \
+    _Pragma("unroll") for (int m = 0; m < WGRP; ++m) {                                                         \
+        const bool ok_ = WOK(q, m);                                                                            \
+        const double yr_ = ok_ ? RHSV(ok_ ? WROW(q, m) : 0) : 0.0;                                             \
+        _Pragma("unroll") for (int u = 0; u < 4; ++u) tacc[u] += wreg[m][u] * yr_;                             \
     }
 
     __syncthreads();
     for (int q = tid; q < VRING; q += MCQ_NT) vring[q] = 0.0;
     // ================= forward substitution, interior rows =================
     // a tile needs only its own rows: chunk cq resident, cq+1 committed one step ahead, cq+2 committed during step cq.
-    d2 tacc = {0.0, 0.0};
+    d2 tacc[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) tacc[u] = (d2){0.0, 0.0};
     if (wv > 0) {
         for (int q = 0; q <= 1; ++q) {
             chunk_fetch(L, v, ni, b, q, q, lt, goff, regs, rreg);
@@ -1340,34 +1350,32 @@ __device__ __noinline__ void solve(const SolveCtx& c, gdouble* v)
             chunk_commit(chunk, rring, cq + 2, cq + 2, lt, regs, rreg);
             chunk_fetch(L, v, ni, b, cq + 3, cq + 3, lt, goff, regs, rreg);
             // border right-hand side, fused: t -= W' y for the rows solved in the previous step (W rows in registers)
-            if (cq >= 1) {
-#pragma unroll
-                for (int m = 0; m < WPAIRS; ++m) {
-                    const double yr = WOK(cq - 1, m) ? RHSV(WOK(cq - 1, m) ? WROW(cq - 1, m) : 0) : 0.0;
-                    tacc += wreg[m] * yr;
-                }
-            }
+            if (cq >= 1) { TACC_ADD(cq - 1) }
             WFETCH(cq)
         }
         lds_barrier();
     }
-    if (wv > 0 && nch >= 1) {
+    if (wv > 0 && nch >= 1) { TACC_ADD(nch - 1) }
+    // part[wave][jj]: partial sums of W'y (summed over the wave's rows: the 8 row lanes of every column pair, then LDS)
 #pragma unroll
-        for (int m = 0; m < WPAIRS; ++m) {
-            const double yr = WOK(nch - 1, m) ? RHSV(WOK(nch - 1, m) ? WROW(nch - 1, m) : 0) : 0.0;
-            tacc += wreg[m] * yr;
+    for (int u = 0; u < 4; ++u) {
+#pragma unroll
+        for (int sh = 8; sh <= 32; sh <<= 1) {
+            tacc[u][0] += __shfl_xor(tacc[u][0], sh);
+            tacc[u][1] += __shfl_xor(tacc[u][1], sh);
+        }
+        if (g8 == 0) {
+            part[wv * 64 + 16 * u + 2 * c8] = tacc[u][0];
+            part[wv * 64 + 16 * u + 2 * c8 + 1] = tacc[u][1];
         }
     }
-    // part[wave][half][jj]: partial sums of W'y
-    part[(wv * 2 + hf) * 64 + 2 * jp] = tacc[0];
-    part[(wv * 2 + hf) * 64 + 2 * jp + 1] = tacc[1];
     __syncthreads();
     // ================= border:  t = v_D - W' y_B,  x_D = L_S^-T (L_S^-1 t)  as two LDS mat-vecs =================
     if (wv == 0) {
         double t = 0.0;
         if (lane < p) {
             t = v[ni + lane];
-            for (int q = 2; q < 2 * MCQ_NW; ++q) t -= part[q * 64 + lane];
+            for (int q = 1; q < MCQ_NW; ++q) t -= part[q * 64 + lane];
         }
         __builtin_amdgcn_wave_barrier();
         xd[lane] = t;
@@ -1394,20 +1402,26 @@ __device__ __noinline__ void solve(const SolveCtx& c, gdouble* v)
     // tile J needs the band entries of the rows of tiles J+1..J+4 (the chunk processed before) and its own inverse tile.
     // Right-hand side of a chunk = y_B - W x_D: the raw y_B values are committed to the rhs ring two steps ahead, the
     // loader waves subtract the 64-wide dot products W[r] . x_D (W rows fetched one step ahead, reduced inside each
-    // 32-lane half) one step ahead.
+    // 8-lane row group) one step ahead.
 #define RHS_SUB(q)                                                                                             \
     {                                                                                                          \
-        double a_[WPAIRS];                                                                                     \
-        _Pragma("unroll") for (int m = 0; m < WPAIRS; ++m)                                                     \
-            a_[m] = WOK(q, m) ? wreg[m][0] * xd[2 * jp] + wreg[m][1] * xd[2 * jp + 1] : 0.0;                   \
-        _Pragma("unroll") for (int sh = 16; sh >= 1; sh >>= 1) {                                               \
-            _Pragma("unroll") for (int m = 0; m < WPAIRS; ++m) a_[m] += __shfl_xor(a_[m], sh);                 \
+        double a_[WGRP];                                                                                       \
+        _Pragma("unroll") for (int m = 0; m < WGRP; ++m) {                                                     \
+            d2 s_ = wreg[m][0] * xdr[0];                                                                       \
+            _Pragma("unroll") for (int u = 1; u < 4; ++u) s_ += wreg[m][u] * xdr[u];                           \
+            a_[m] = s_[0] + s_[1];                                                                             \
         }                                                                                                      \
-        _Pragma("unroll") for (int m = 0; m < WPAIRS; ++m) {                                                   \
-            const int r_ = WROW(q, m);                                                                         \
-            if (jp == 0 && (wv - 1) + NLW * m < CH / 2 && (q) >= 0 && r_ < ni) RHSV(r_) -= a_[m];              \
+        _Pragma("unroll") for (int sh = 4; sh >= 1; sh >>= 1) {                                                \
+            _Pragma("unroll") for (int m = 0; m < WGRP; ++m) a_[m] += __shfl_xor(a_[m], sh);                   \
+        }                                                                                                      \
+        _Pragma("unroll") for (int m = 0; m < WGRP; ++m) {                                                     \
+            const bool ok_ = WOK(q, m);                                                                        \
+            if (c8 == 0 && ok_) RHSV(WROW(q, m)) -= a_[m];                                                     \
         }                                                                                                      \
     }
+    d2 xdr[4];      // this lane's slice of x_D (constant over the sweep)
+#pragma unroll
+    for (int u = 0; u < 4; ++u) xdr[u] = (d2){xd[16 * u + 2 * c8], xd[16 * u + 2 * c8 + 1]};
     if (nch > 0) {
         const int cl = nch - 1;
         if (wv > 0) {
@@ -1472,6 +1486,8 @@ __device__ __noinline__ void solve(const SolveCtx& c, gdouble* v)
     }
     __syncthreads();
 #undef WFETCH
+#undef TACC_ADD
+#undef WGOK
 #undef WOK
 #undef WROW
 #undef RHS_SUB
