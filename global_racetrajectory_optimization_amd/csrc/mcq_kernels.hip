@@ -349,19 +349,36 @@ __device__ __forceinline__ double gram_entry(const gdouble* Et, const gdouble* s
 {
     const int n = d.n, bE = d.bE, bR = d.bR;
     const int dd = sdiff(i, j, n);
+    int r0 = i - bR;
+    if (r0 < 0) r0 += n;
+    if (r0 < 0) r0 = cyc(r0, n);
+    // fixed trip count, branch-free body, loads of a batch issued together: the chain of 2 x 65 dependent L2 round trips
+    // of a data-dependent loop is what this routine costs otherwise
+    constexpr int EW = MCQ_BE_MAX + (MCQ_BE_MAX + 1) + 1;       // bE + bR + 1 <= 66
+    constexpr int GB = 11;
+    const int ew = bR + bE + 1;
     double acc = 0.0;
-    int r = i - bR;
-    if (r < 0) r += n;
-    if (r < 0) r = cyc(r, n);
-    for (int o = -bR; o <= bE; ++o) {
-        int t = o + dd;          // the band holds every column at most once: at most one of t, t -+ n is inside it
-        if (t > bE) t -= n;
-        else if (t < -bR) t += n;
-        if (t >= -bR && t <= bE) {
-            const double e = Et[(size_t)(bR + o) * nm + i] * Et[(size_t)(bR + t) * nm + j];
-            acc += sg ? e * sg[r] : e;
+#pragma unroll 1
+    for (int o0 = 0; o0 < EW; o0 += GB) {
+        double ea[GB], eb[GB], es[GB];
+        bool ok[GB];
+#pragma unroll
+        for (int u = 0; u < GB; ++u) {
+            const int oo = o0 + u;                 // 0-based diagonal of the first factor: o = oo - bR
+            int t = oo - bR + dd;                  // the band holds every column at most once: at most one of t, t -+ n is inside it
+            if (t > bE) t -= n;
+            else if (t < -bR) t += n;
+            ok[u] = (oo < ew) & (t >= -bR) & (t <= bE);
+            const int oa = ok[u] ? oo : 0, ob = ok[u] ? bR + t : 0;
+            int r = r0 + oo;
+            r = r >= n ? r - n : r;
+            r = r >= n ? r - n : r;
+            ea[u] = Et[(size_t)oa * nm + i];
+            eb[u] = Et[(size_t)ob * nm + j];
+            es[u] = sg ? sg[ok[u] ? r : 0] : 1.0;
         }
-        r = (r + 1 == n) ? 0 : r + 1;
+#pragma unroll
+        for (int u = 0; u < GB; ++u) acc += ok[u] ? ea[u] * eb[u] * es[u] : 0.0;
     }
     return acc;
 }
