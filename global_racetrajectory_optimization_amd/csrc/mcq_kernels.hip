@@ -384,22 +384,25 @@ __device__ __forceinline__ double gram_entry(const gdouble* Et, const gdouble* s
 }
 
 // Writes  E' diag(sg) E  in bordered-band storage (row-major rows of MCQ_HLD doubles, see mcq_kernels.h) into `out`.
-// Work items are ordered so that consecutive threads take consecutive rows i of the same diagonal / border column:
-// the Et[.][i] loads are contiguous 512-byte segments and the Et[.][j] loads hit a few L1-resident lines.
+// Work items are ordered so that consecutive threads take consecutive entries of ONE row of `out`: the stores (most of
+// them zeros of the border part) are contiguous segments instead of 8-byte pieces 1040 bytes apart, and the second
+// factor's loads of the few entries that need arithmetic are contiguous too.  Rows [skip0, skip1) of the band part are
+// left to mcq_gram_tile_kernel.
 __device__ void gram_bordered(const gdouble* Et, const gdouble* sg, const McqDims& d, int nm, const gdouble* base, gdouble* out,
                               int t0, int nthreads, int skip0 = 0, int skip1 = 0)
 {
     const int ni = d.ni, n = d.n;
     const int bw = MCQ_BH_MAX + 1;
-    for (int idx = t0; idx < bw * ni; idx += nthreads) {
-        const int k = idx / ni, i = idx - k * ni;
-        if (i >= skip0 && i < skip1) continue;     // rows done by mcq_gram_tile_kernel
+    const int nskip = skip1 - skip0;
+    for (int idx = t0; idx < bw * (ni - nskip); idx += nthreads) {
+        const int rix = idx / bw, k = idx - rix * bw;
+        const int i = rix < skip0 ? rix : rix + nskip;
         double v = 0.0;
         if (k <= d.b && i + k < ni) v = gram_entry(Et, sg, d, nm, i, i + k);
         out[(size_t)i * MCQ_HLD + k] = v + (base ? base[(size_t)i * MCQ_HLD + k] : 0.0);
     }
     for (int idx = t0; idx < MCQ_P_MAX * n; idx += nthreads) {
-        const int jj = idx / n, i = idx - jj * n;
+        const int i = idx / MCQ_P_MAX, jj = idx - i * MCQ_P_MAX;
         double v = 0.0;
         if (jj < d.p) {
             const int j = ni + jj;
@@ -422,10 +425,31 @@ __device__ __forceinline__ void gram_fast_range(const McqDims& d, int& f0, int& 
     }
 }
 
+// Entries k == G (mod 4) of one row of the band of H for mcq_gram_tile_kernel: k is a literal, so every LDS offset is an
+// immediate and only the 65 - k products that exist are formed.  a[o] = E'[o][row]; sc = tile base + row.
+template <int G>
+__device__ __forceinline__ void gram_tile_class(const double* a, const double* sc, double* res)
+{
+    constexpr int NO = 2 * MCQ_BE_MAX + 1, NC = 2 * GT_ROWS;
+#pragma unroll
+    for (int m = 0; m < (MCQ_BH_MAX + 4) / 4; ++m) {
+        const int k = G + 4 * m;
+        double acc0 = 0.0, acc1 = 0.0;
+        if (k <= MCQ_BH_MAX) {
+#pragma unroll
+            for (int o = k; o < NO; o += 2) {
+                acc0 += a[o] * sc[(o - k) * NC + k];
+                if (o + 1 < NO) acc1 += a[o + 1] * sc[(o + 1 - k) * NC + k];
+            }
+        }
+        res[m] = acc0 + acc1;
+    }
+}
+
 // H[i, i+k] = sum_{o >= k} E'[o][i] E'[o-k][i+k]  (o, o-k = 0-based diagonal indices of the 65-wide E' band).
 // One workgroup per tile of 64 rows: the 65 x 128 block of E' it touches (columns i0 .. i0+127) is staged once in LDS
-// (66.5 KB, two workgroups per CU); thread (row r, group g) keeps its column of E in 65 registers and produces the entries
-// k == g (mod 4): one LDS read per FMA, conflict-free (consecutive lanes = consecutive columns).
+// (66.5 KB, two workgroups per CU); thread (row r, wave g) keeps its column of E in 65 registers and produces the entries
+// k == g (mod 4): one LDS read per FMA, conflict-free (consecutive lanes = consecutive columns), immediate offsets.
 __global__ void __launch_bounds__(MCQ_NT) mcq_gram_tile_kernel(McqBatch B)
 {
     __shared__ double S[(2 * MCQ_BE_MAX + 1) * 2 * GT_ROWS];
@@ -461,21 +485,28 @@ __global__ void __launch_bounds__(MCQ_NT) mcq_gram_tile_kernel(McqBatch B)
         }
     }
     __syncthreads();
-    const int r = tid & (GT_ROWS - 1), g = tid / GT_ROWS;
+    const int r = tid & (GT_ROWS - 1);
+    const int g = __builtin_amdgcn_readfirstlane(tid / GT_ROWS);       // wave-uniform: a scalar branch picks the k class
     double a[2 * MCQ_BE_MAX + 1];
 #pragma unroll
     for (int o = 0; o < NO; ++o) a[o] = S[o * NC + r];
-    gdouble* orow = w.H + (size_t)(i0 + r) * MCQ_HLD;
-    for (int k = g; k <= MCQ_BH_MAX; k += MCQ_NT / GT_ROWS) {
-        const double* bcol = S + r + k;
-        double acc = 0.0;
+    double res[(MCQ_BH_MAX + 4) / 4];
+    if (g == 0) gram_tile_class<0>(a, S + r, res);
+    else if (g == 1) gram_tile_class<1>(a, S + r, res);
+    else if (g == 2) gram_tile_class<2>(a, S + r, res);
+    else gram_tile_class<3>(a, S + r, res);
+    // results through LDS (the E' block is dead): rows leave as contiguous 520-byte runs instead of 8-byte pieces
+    __syncthreads();
+    const int OW = MCQ_BH_MAX + 1;
 #pragma unroll
-        for (int o = 0; o < NO; ++o) {
-            const int tt = o - k;
-            const double bv = bcol[(tt >= 0 ? tt : 0) * NC];
-            acc += a[o] * (tt >= 0 ? bv : 0.0);
-        }
-        orow[k] = acc;
+    for (int m = 0; m < (MCQ_BH_MAX + 4) / 4; ++m) {
+        const int k = g + 4 * m;
+        if (k <= MCQ_BH_MAX) S[r * OW + k] = res[m];
+    }
+    __syncthreads();
+    for (int q = tid; q < GT_ROWS * OW; q += MCQ_NT) {
+        const int row = q / OW, k = q - row * OW;
+        w.H[(size_t)(i0 + row) * MCQ_HLD + k] = S[q];
     }
 }
 
