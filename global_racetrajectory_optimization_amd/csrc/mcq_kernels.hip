@@ -53,6 +53,13 @@ __shared__ double g_sm[SM_TOTAL];
 // ---------------------------------------------------------------------------------------------------------------------
 // small helpers
 // ---------------------------------------------------------------------------------------------------------------------
+// i mod n for i in [-n, 2n): two compares instead of an integer division (indices one band width around the ring)
+__device__ __forceinline__ int cyc1(int i, int n)
+{
+    i = i < 0 ? i + n : i;
+    return i >= n ? i - n : i;
+}
+
 __device__ __forceinline__ int cyc(int i, int n)
 {
     i %= n;
@@ -241,8 +248,8 @@ __global__ void __launch_bounds__(MCQ_NT) mcq_assemble_kernel(McqBatch B)
 
     // ---- phase 1: periodic pivots of the cyclic tridiagonal system in the c-coefficients -----------------------------
     // centre m:  1*c_{m-1} + (2 s_{m-1}^2 + 2 s_{m-1}) c_m + (s_{m-1} s_m^2) c_{m+1} = 3 (s_{m-1} D_m - D_{m-1})
-#define TDIAG(m) (2.0 * S[cyc((m) - 1, n)] * S[cyc((m) - 1, n)] + 2.0 * S[cyc((m) - 1, n)])
-#define TSUP(m) (S[cyc((m) - 1, n)] * S[(m)] * S[(m)])
+#define TDIAG(m) (2.0 * S[cyc1((m) - 1, n)] * S[cyc1((m) - 1, n)] + 2.0 * S[cyc1((m) - 1, n)])
+#define TSUP(m) (S[cyc1((m) - 1, n)] * S[(m)] * S[(m)])
     {
         const int chunk = (n + MCQ_NT - 1) / MCQ_NT;
         const int m0 = tid * chunk;
@@ -268,6 +275,44 @@ __global__ void __launch_bounds__(MCQ_NT) mcq_assemble_kernel(McqBatch B)
     const int W = d.bE + 2;
     // images of offset k land inside [-W, W] only if k >= n - W: run the recurrences further for short rings
     const int KR = (n - W > 96) ? W : 96;
+    // Long rings (no image folding, full band): nothing of T^-1 goes through memory.  A row of T^-1 is two geometric-like
+    // recurrences away from its diagonal entry,  g[k+1] = RU[i+k] g[k]  (upwards),  g[-k-1] = RD[i-k] g[-k]  (downwards), with
+    // per-index ratios computed once; phase 2 consumes the entries as they are produced (c-coefficients = T^-1 rhs), phase 3b
+    // produces them again with a three-entry window.  A handful of registers per row: several workgroups per CU hide the
+    // L2 latency of the ratio / right-hand-side loads.
+    const bool long_ring = (d.bE == MCQ_BE_MAX) && (n - W > 96) && (W < (n - 1) / 2);
+    gdouble* RU = VEC(w, nm, V_RHS);
+    gdouble* RD = VEC(w, nm, V_DXA);
+    gdouble* RX = VEC(w, nm, V_SK);
+    gdouble* RY = VEC(w, nm, V_EDA);
+    if (long_ring) {
+        for (int m = tid; m < n; m += MCQ_NT) {
+            const int mp = cyc1(m + 1, n), mm = cyc1(m - 1, n);
+            const double sm1 = S[mm];
+            RX[m] = 3.0 * (sm1 * (w.ref[4 * mp] - w.ref[4 * m]) - (w.ref[4 * m] - w.ref[4 * mm]));
+            RY[m] = 3.0 * (sm1 * (w.ref[4 * mp + 1] - w.ref[4 * m + 1]) - (w.ref[4 * m + 1] - w.ref[4 * mm + 1]));
+            RU[m] = -(TSUP(m) / EP[mp]);          // g[k+1] = RU[j] g[k],  j = i + k
+            RD[m] = -1.0 / DE[mm];                // g[-k-1] = RD[j] g[-k],  j = i - k
+        }
+        __syncthreads();
+        for (int i = tid; i < n; i += MCQ_NT) {
+            const double g0 = 1.0 / (DE[i] + EP[i] - TDIAG(i));
+            double cx = g0 * RX[i], cy = g0 * RY[i];
+            double cu = g0, cd = g0;
+            int ju = i, jd = i;                    // index of the entry last produced on either side
+#pragma unroll 2
+            for (int k = 1; k <= MCQ_GW; ++k) {
+                cu *= RU[ju];
+                cd *= RD[jd];
+                ju = ju + 1 == n ? 0 : ju + 1;
+                jd = jd == 0 ? n - 1 : jd - 1;
+                cx += cu * RX[ju] + cd * RX[jd];
+                cy += cu * RY[ju] + cd * RY[jd];
+            }
+            XPP[i] = 2.0 * cx;   // x''(0) of spline i
+            YPP[i] = 2.0 * cy;
+        }
+    } else
     for (int i = tid; i < n; i += MCQ_NT) {
 #define GG(k) G[(size_t)(MCQ_GW + (k)) * nm + i]
         for (int k = -MCQ_GW; k <= MCQ_GW; ++k) GG(k) = 0.0;
@@ -322,6 +367,55 @@ __global__ void __launch_bounds__(MCQ_NT) mcq_assemble_kernel(McqBatch B)
 
     // ---- phase 3b: D band (x'' = D x) and E_kappa band, diagonal-major -------------------------------------------------
     const int ew = d.ew;
+    if (long_ring) {
+        // D[i, i+o] = 6 (g[o+1] - (1 + s_{j-1}) g[o] + s_{j-2} g[o-1]),  j = i + o:  a three-entry window walks up from the
+        // diagonal and down from it; stores are diagonal-major (consecutive threads = consecutive rows)
+        for (int i = tid; i < n; i += MCQ_NT) {
+            const double g0 = 1.0 / (DE[i] + EP[i] - TDIAG(i));
+            const double cpx = CP[i] * XP[i], cpy = CP[i] * YP[i];
+            const int im = i == 0 ? n - 1 : i - 1, imm = im == 0 ? n - 1 : im - 1;
+            const double gu1 = g0 * RU[i], gd1 = g0 * RD[i];
+            {
+                const double dv = 6.0 * (gu1 - (1.0 + S[im]) * g0 + S[imm] * gd1);
+                w.Db[(size_t)MCQ_BE_MAX * nm + i] = dv;
+                w.Eb[(size_t)MCQ_BE_MAX * nm + i] = dv * (cpx * w.nv[2 * i + 1] - cpy * w.nv[2 * i]);
+            }
+            // upwards: prev = g[o-1], cur = g[o], j = i + o
+            {
+                double prev = g0, cur = gu1;
+                int j = i + 1 == n ? 0 : i + 1, jm1 = i, jm2 = im;
+#pragma unroll 2
+                for (int o = 1; o <= MCQ_BE_MAX; ++o) {
+                    const double nxt = cur * RU[j];
+                    const double dv = 6.0 * (nxt - (1.0 + S[jm1]) * cur + S[jm2] * prev);
+                    w.Db[(size_t)(MCQ_BE_MAX + o) * nm + i] = dv;
+                    w.Eb[(size_t)(MCQ_BE_MAX + o) * nm + i] = dv * (cpx * w.nv[2 * j + 1] - cpy * w.nv[2 * j]);
+                    prev = cur;
+                    cur = nxt;
+                    jm2 = jm1;
+                    jm1 = j;
+                    j = j + 1 == n ? 0 : j + 1;
+                }
+            }
+            // downwards: nxt = g[o+1], cur = g[o], j = i + o  (o < 0)
+            {
+                double nxt = g0, cur = gd1;
+                int j = im, jm1 = imm, jm2 = imm == 0 ? n - 1 : imm - 1;
+#pragma unroll 2
+                for (int o = -1; o >= -MCQ_BE_MAX; --o) {
+                    const double prv = cur * RD[j];            // g[o-1]
+                    const double dv = 6.0 * (nxt - (1.0 + S[jm1]) * cur + S[jm2] * prv);
+                    w.Db[(size_t)(MCQ_BE_MAX + o) * nm + i] = dv;
+                    w.Eb[(size_t)(MCQ_BE_MAX + o) * nm + i] = dv * (cpx * w.nv[2 * j + 1] - cpy * w.nv[2 * j]);
+                    nxt = cur;
+                    cur = prv;
+                    j = jm1;
+                    jm1 = jm2;
+                    jm2 = jm2 == 0 ? n - 1 : jm2 - 1;
+                }
+            }
+        }
+    } else
     for (int idx = tid; idx < n * ew; idx += MCQ_NT) {
         const int oo = idx / n, i = idx - oo * n, o = oo - d.bE;
         const int j = cyc(i + o, n);
