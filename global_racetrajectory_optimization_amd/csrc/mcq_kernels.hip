@@ -154,7 +154,9 @@ __device__ __forceinline__ double bcast_lane(double v, int src_lane)
 
 // dst_i = sum_{o=-bl..br} Mb[(bl+o) * nm + i] * src[(i+o) mod n] + addc * add_i
 // Diagonal-major (DIA) band: thread per row, every load of a wave is one contiguous 512-byte segment, no reductions.
-#define MV_RU 8
+// Loads are issued in batches of MV_RU diagonals (three batches cover the 65/66-wide bands): with one wave per SIMD the
+// only way to keep enough bytes in flight is per-thread batching (22 x 8 B x 256 threads = 45 KB per round trip).
+#define MV_RU 22
 __device__ __noinline__ void band_matvec(const gdouble* Mb, int bl, int br, int n, int nm, const gdouble* src,
                                          const gdouble* add, double addc, gdouble* dst)
 {
@@ -164,21 +166,17 @@ __device__ __noinline__ void band_matvec(const gdouble* Mb, int bl, int br, int 
         int j = i - bl;
         if (j < 0) j += n;
         if (j < 0) j = cyc(j, n);
-        int oo = 0;
-        for (; oo + MV_RU <= ew; oo += MV_RU) {
+        for (int oo = 0; oo < ew; oo += MV_RU) {
             double m[MV_RU], x[MV_RU];
 #pragma unroll
             for (int u = 0; u < MV_RU; ++u) {
-                m[u] = Mb[(size_t)(oo + u) * nm + i];
-                x[u] = src[j];
+                const bool ok = oo + u < ew;
+                m[u] = Mb[(size_t)(ok ? oo + u : 0) * nm + i];
+                x[u] = ok ? src[j] : 0.0;
                 j = (j + 1 == n) ? 0 : j + 1;
             }
 #pragma unroll
             for (int u = 0; u < MV_RU; ++u) acc += m[u] * x[u];
-        }
-        for (; oo < ew; ++oo) {
-            acc += Mb[(size_t)oo * nm + i] * src[j];
-            j = (j + 1 == n) ? 0 : j + 1;
         }
         dst[i] = acc;
     }
