@@ -38,8 +38,9 @@ def algorithmic_bytes(n, info, band_e=32, refine_steps=2):
       factorisation : read the H rows + write the L rows               n * (1040 + 1152) B
       solve         : forward + backward sweep, each reads the L rows  2 * n * 1152 B
       gradient      : E band + E' band                                 2 * n * 65 * 8 B
-    IPM iteration = 1 factorisation + 2 solves + 1 gradient; active-set iteration = 1 factorisation + 1 solve +
-    2 gradients; refinement round = 1 solve + 1 gradient; + 1 initial gradient + 3 band products in the epilogue.
+    IPM iteration = 1 factorisation + 2 solves (the gradient is carried through the reduced system; one exact gradient
+    confirms convergence); active-set iteration = 1 factorisation + 1 solve + 2 gradients; refinement round = 1 solve +
+    1 gradient; + 1 initial gradient + 3 band products in the epilogue.
     Iteration counts are the ones the solver reports (mcq_info).
     """
     fac = n * (130.0 + 144.0) * 8.0
@@ -47,7 +48,7 @@ def algorithmic_bytes(n, info, band_e=32, refine_steps=2):
     grad = 2.0 * n * (2 * band_e + 1) * 8.0
     ipm = info["ipm_iters"].astype(np.float64)
     act = info["as_iters"].astype(np.float64)
-    per = ipm * (fac + 2 * sol + grad) + act * (fac + sol + 2 * grad) + refine_steps * (sol + grad) + grad + 1.5 * grad
+    per = ipm * (fac + 2 * sol) + grad + act * (fac + sol + 2 * grad) + refine_steps * (sol + grad) + grad + 1.5 * grad
     return float(per.sum())
 
 

@@ -1731,6 +1731,12 @@ __device__ __noinline__ int ipm(SolveCtx& c, const McqBatch& B, bool with_kappa,
     (void)no_mask;
     if (!(npairs > 0.0)) return MCQ_OK;
 
+    // Box-only phase: the gradient g = H x + f is carried along instead of recomputed.  The reduced system gives
+    //   H dx = rhs - diag(sig) dx   on the free rows (pinned rows have dx = 0 and their g is never read),
+    // so  g(x + a dx) = g + a (rhs - sig dx)  costs a vector pass where two band products (2 MB of E / E') were; the error
+    // it carries is the residual of the banded solve.  Convergence is only declared on an exactly recomputed gradient.
+    // On entry G holds the exact gradient at the box centre (computed by the caller for the scaling).
+    bool g_exact = true;
     for (int it = 1; it <= B.max_ipm_iter; ++it) {
         // ---- residuals: g = H x + f;  with kappa also r, rho and the dual residual needs E'(yu - yl) ---------------------
         if (with_kappa) {
@@ -1739,27 +1745,32 @@ __device__ __noinline__ int ipm(SolveCtx& c, const McqBatch& B, bool with_kappa,
             gradient(c, X, nullptr, T0, G);                              // G  = g
             band_matvec(c.w.Eb, c.d.bE, c.d.bR, n, nm, X, KR, 1.0, T0);  // T0 = r
             __syncthreads();
-        } else {
-            gradient(c, X, nullptr, T0, G);
         }
-        double mu = 0.0, rdm = 0.0, rhom = 0.0;
-        for (int i = tid; i < n; i += MCQ_NT) {
-            if (with_kappa) {
-                mu += TL[i] * YL[i] + TU[i] * YU[i];
-                rhom = fmax(rhom, fmax(fabs(TL[i] - (kb + T0[i])), fabs(TU[i] - (kb - T0[i]))));
-                SK[i] = YL[i] / TL[i] + YU[i] / TU[i];
+        double mu, rdm, rhom;
+        for (;;) {
+            mu = 0.0; rdm = 0.0; rhom = 0.0;
+            for (int i = tid; i < n; i += MCQ_NT) {
+                if (with_kappa) {
+                    mu += TL[i] * YL[i] + TU[i] * YU[i];
+                    rhom = fmax(rhom, fmax(fabs(TL[i] - (kb + T0[i])), fabs(TU[i] - (kb - T0[i]))));
+                    SK[i] = YL[i] / TL[i] + YU[i] / TU[i];
+                }
+                if (ST[i] != 0) continue;
+                const double sl = X[i] - LO[i], su = HI[i] - X[i];
+                mu += sl * ZL[i] + su * ZU[i];
+                const double gg = with_kappa ? T1[i] : G[i];
+                rdm = fmax(rdm, fabs(gg - ZL[i] + ZU[i]));
+                SIG[i] = ZL[i] / sl + ZU[i] / su;
             }
-            if (ST[i] != 0) continue;
-            const double sl = X[i] - LO[i], su = HI[i] - X[i];
-            mu += sl * ZL[i] + su * ZU[i];
-            const double gg = with_kappa ? T1[i] : G[i];
-            rdm = fmax(rdm, fabs(gg - ZL[i] + ZU[i]));
-            SIG[i] = ZL[i] / sl + ZU[i] / su;
+            mu = block_reduce_(mu, 0, red) / npairs;
+            rdm = block_reduce_(rdm, 2, red);
+            rhom = block_reduce_(rhom, 2, red);
+            const bool conv = mu < IPM_TOL * zscale * sc.wmean && rdm < IPM_TOL * zscale && rhom <= 1e-9 * kb;
+            if (conv && (with_kappa || g_exact)) return MCQ_OK;
+            if (!conv) break;
+            gradient(c, X, nullptr, T0, G);          // looks converged on the carried gradient: confirm on the exact one
+            g_exact = true;
         }
-        mu = block_reduce_(mu, 0, red) / npairs;
-        rdm = block_reduce_(rdm, 2, red);
-        rhom = block_reduce_(rhom, 2, red);
-        if (mu < IPM_TOL * zscale * sc.wmean && rdm < IPM_TOL * zscale && rhom <= 1e-9 * kb) return MCQ_OK;
         iters = it;
 
         // ---- factorisation of the reduced system ---------------------------------------------------------------------
@@ -1901,10 +1912,19 @@ __device__ __noinline__ int ipm(SolveCtx& c, const McqBatch& B, bool with_kappa,
                 YU[i] += a * SK[i];
             }
             if (ST[i] != 0) continue;
+            if (!with_kappa) {
+                // g += a H dx,  H dx = (corrector right-hand side) - sig dx
+                const double dxa = DXA[i], dx = RHS[i];
+                const double sl = X[i] - LO[i], su = HI[i] - X[i];
+                const double dzla = -ZL[i] - ZL[i] * dxa / sl, dzua = -ZU[i] + ZU[i] * dxa / su;
+                const double rc = -G[i] + (smu - dxa * dzla) / sl - (smu + dxa * dzua) / su;
+                G[i] += a * (rc - SIG[i] * dx);
+            }
             X[i] += a * RHS[i];
             ZL[i] += a * T1[i];
             ZU[i] += a * T2[i];
         }
+        g_exact = false;
         __syncthreads();
     }
     return with_kappa ? MCQ_KAPPA_INFEASIBLE : MCQ_ITER_CAP;
