@@ -152,6 +152,18 @@ __device__ __forceinline__ double bcast_lane(double v, int src_lane)
     return __hiloint2double(hi, lo);
 }
 
+// Lanes 0..15: sum of x over the four 16-lane rows (lane, lane+16, lane+32, lane+48); other lanes: unspecified.
+// v_permlane32_swap / v_permlane16_swap (gfx950) are VALU lane exchanges: no LDS-crossbar round trip like ds_bpermute.
+__device__ __forceinline__ double row4_sum_low16(double x)
+{
+    const auto a0 = __builtin_amdgcn_permlane32_swap(__double2loint(x), __double2loint(x), false, false);
+    const auto a1 = __builtin_amdgcn_permlane32_swap(__double2hiint(x), __double2hiint(x), false, false);
+    const double y = x + __hiloint2double((int)a1[1], (int)a0[1]);            // lanes 0..31: + lane 32 above
+    const auto b0 = __builtin_amdgcn_permlane16_swap(__double2loint(y), __double2loint(y), false, false);
+    const auto b1 = __builtin_amdgcn_permlane16_swap(__double2hiint(y), __double2hiint(y), false, false);
+    return y + __hiloint2double((int)b1[1], (int)b0[1]);                      // lanes 0..15: + lane 16 above
+}
+
 // dst_i = sum_{o=-bl..br} Mb[(bl+o) * nm + i] * src[(i+o) mod n] + addc * add_i
 // Diagonal-major (DIA) band: thread per row, every load of a wave is one contiguous 512-byte segment, no reductions.
 // Loads are issued in batches of MV_RU diagonals (three batches cover the 65/66-wide bands): with one wave per SIMD the
@@ -1467,10 +1479,7 @@ __device__ __noinline__ void solve(const SolveCtx& c, gdouble* v)
                     a0 += (kb - cc <= MCQ_BH_MAX ? l0 : 0.0) * vs[cc];
                     a1 += (kb - cc - 1 <= MCQ_BH_MAX ? l1 : 0.0) * vs[cc + 1];
                 }
-                double acc = a0 + a1;
-                acc += __shfl_xor(acc, 16);
-                acc += __shfl_xor(acc, 32);
-                const double sv = RHSV(i) - acc;
+                const double sv = RHSV(i) - row4_sum_low16(a0 + a1);       // valid in lanes 0..15: the ones the broadcasts read
                 double y0 = 0.0, y1 = 0.0;
 #pragma unroll
                 for (int cc = 0; cc < TB; cc += 2) {         // row l15 of the inverse tile
@@ -1596,10 +1605,7 @@ __device__ __noinline__ void solve(const SolveCtx& c, gdouble* v)
                         a0 += (kb + rr <= MCQ_BH_MAX ? l0 : 0.0) * vs[rr];
                         a1 += (kb + rr + 1 <= MCQ_BH_MAX ? l1 : 0.0) * vs[rr + 1];
                     }
-                    double acc = a0 + a1;
-                    acc += __shfl_xor(acc, 16);
-                    acc += __shfl_xor(acc, 32);
-                    const double sv = RHSV(j) - acc;
+                    const double sv = RHSV(j) - row4_sum_low16(a0 + a1);   // valid in lanes 0..15: the ones the broadcasts read
                     const double* mi = LROW(J * TB) + MCQ_BH_MAX + l15;       // column l15 of the inverse tile, row stride CLD
                     double x0 = 0.0, x1 = 0.0;
 #pragma unroll

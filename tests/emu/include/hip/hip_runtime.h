@@ -187,6 +187,28 @@ inline double __shfl_xor(double v, int m)
 }
 inline int __shfl(int v, int src) { return (int)__shfl((double)v, src); }
 
+
+// v_permlane32_swap / v_permlane16_swap (gfx950): [0] = new vdst, [1] = new src0.
+//   32: vdst lanes 32..63 <-> src0 lanes 0..31;   16: vdst rows 1,3 (lanes 16..31, 48..63) <-> src0 rows 0,2
+struct hipemu_u2 {
+    unsigned v[2];
+    unsigned operator[](int i) const { return v[i]; }
+};
+inline hipemu_u2 hipemu_permlane_swap(unsigned d, unsigned s, int width)
+{
+    const int lane = hipemu::st().cur & 63;
+    // the partner lane of the *other* operand
+    const unsigned s_from = (unsigned)(long long)__shfl((double)s, lane - width);   // src0[lane - width] (meaningful for the upper half)
+    const unsigned d_from = (unsigned)(long long)__shfl((double)d, lane + width);   // vdst[lane + width] (meaningful for the lower half)
+    const bool upper = (lane & width) != 0;
+    hipemu_u2 r;
+    r.v[0] = upper ? s_from : d;
+    r.v[1] = upper ? s : d_from;
+    return r;
+}
+#define __builtin_amdgcn_permlane32_swap(d, s, fi, bc) hipemu_permlane_swap((unsigned)(d), (unsigned)(s), 32)
+#define __builtin_amdgcn_permlane16_swap(d, s, fi, bc) hipemu_permlane_swap((unsigned)(d), (unsigned)(s), 16)
+
 inline long long wall_clock64() { return (long long)(hipemu_now() * 1e5); }
 
 // v_mfma_f64_16x16x4_f64: D(16x16) = A(16x4) B(4x16) + C.  Lane l holds A[l&15][l>>4], B[l>>4][l&15]; C/D register r of lane l
