@@ -184,3 +184,29 @@ def test_curvature_rows_active_and_infeasible_gpu(gpu_engine):
     assert abs(curv[0] - err_ref) < CURV_TOL
     with pytest.raises(ValueError, match="inconsistent"):
         tph.opt_min_curv.opt_min_curv(ref, nv, A, 1e-4, 2.0)
+
+
+def test_vehicle_width_sweep_mixed_tracks(gpu_engine, golden):
+    """BASELINE config 4 in miniature: one ragged launch over (track x vehicle-width) variants of the reference tracks
+    (re-sampled to N ~ 250 so that the dense oracle finishes in seconds), every variant against the live dense oracle."""
+    from oracle import tph_ref
+    probs, refs = [], []
+    for name in ("berlin_2018", "modena_2019", "rounded_rectangle"):
+        full = golden[name]["reftrack"]
+        n_sub = min(250, full.shape[0])
+        idx = np.round(np.linspace(0, full.shape[0], n_sub, endpoint=False)).astype(int)
+        ref = full[idx]
+        path_cl = np.vstack((ref[:, :2], ref[0, :2]))
+        _, _, A, nv = tph_ref.calc_splines(path_cl)
+        sc = tph.calc_splines.scalings_from_les_matrix(A)
+        for w_veh in (2.0, 2.8, 3.4):
+            if np.any(ref[:, 2] + ref[:, 3] < w_veh):
+                continue                                  # infeasible variant: covered by the status-code test
+            probs.append(dict(reftrack=ref, normvec=nv, scaling=sc, kappa_bound=0.12, w_veh=w_veh))
+            refs.append(tph_ref.opt_min_curv(ref, nv, A, 0.12, w_veh))
+    assert len(probs) >= 6
+    al, curv, st, info = gpu_engine.solve_batch(probs)
+    for k, (a_ref, err_ref) in enumerate(refs):
+        assert st[k] == 0, (k, st[k])
+        assert np.max(np.abs(al[k] - a_ref)) < ALPHA_TOL, k
+        assert abs(curv[k] - err_ref) < CURV_TOL, k
