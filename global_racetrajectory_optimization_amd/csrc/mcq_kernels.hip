@@ -102,6 +102,27 @@ __device__ double block_reduce_(double v, int op, double* red)
     return r;
 }
 
+// Two reductions (ops as above) for the price of one barrier pair; the wave-level butterflies interleave.
+__device__ void block_reduce2_(double& a, int opa, double& b, int opb, double* red)
+{
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    for (int m = 32; m >= 1; m >>= 1) {
+        const double oa = __shfl_xor(a, m), ob = __shfl_xor(b, m);
+        a = opa == 0 ? a + oa : (opa == 1 ? fmin(a, oa) : fmax(a, oa));
+        b = opb == 0 ? b + ob : (opb == 1 ? fmin(b, ob) : fmax(b, ob));
+    }
+    __syncthreads();
+    if (lane == 0) { red[wv] = a; red[MCQ_NW + wv] = b; }
+    __syncthreads();
+    double ra = red[0], rb = red[MCQ_NW];
+    for (int k = 1; k < MCQ_NW; ++k) {
+        ra = opa == 0 ? ra + red[k] : (opa == 1 ? fmin(ra, red[k]) : fmax(ra, red[k]));
+        rb = opb == 0 ? rb + red[MCQ_NW + k] : (opb == 1 ? fmin(rb, red[MCQ_NW + k]) : fmax(rb, red[MCQ_NW + k]));
+    }
+    a = ra;
+    b = rb;
+}
+
 __device__ McqWork mcq_work(const McqBatch& B, int pb, int& n, double& kb, double& wv)
 {
     McqWork w;
@@ -1937,6 +1958,195 @@ __device__ __noinline__ int ipm(SolveCtx& c, const McqBatch& B, bool with_kappa,
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
+// The same Mehrotra iteration for the box-only phase of rings with n <= 8 x 256, with the vector work restructured for a
+// workgroup that runs one wave per SIMD: every thread owns its (up to) eight entries i = tid + 256 u, ALL loads of a pass
+// are issued before the first use (one L2 round trip per pass instead of one per entry), and what a pass loaded stays in
+// registers across the block reductions that follow it -- three load phases and six reductions per iteration where the
+// generic routine above does seven dependent passes.  Arithmetic and summation order are those of ipm().
+// ---------------------------------------------------------------------------------------------------------------------
+#define IPB_E 8
+__device__ __noinline__ int ipm_box(SolveCtx& c, const McqBatch& B, const SolveScalars& sc, int& iters)
+{
+    // Pointers and the per-thread index set are re-derived at the top of every pass: nothing but a few scalars is live
+    // across the (non-inlined) factorisation / solve calls, so nothing is spilled to scratch and reloaded around them.
+#define IPB_SETUP                                                                                                      \
+    const int tid = threadIdx.x, n = c.d.n, nm = c.nm;                                                                 \
+    double* red = g_sm + SM_RED;                                                                                       \
+    const gdouble* LO = VEC(c.w, nm, V_LO);                                                                            \
+    const gdouble* HI = VEC(c.w, nm, V_HI);                                                                            \
+    gdouble* X = VEC(c.w, nm, V_X);                                                                                    \
+    gdouble* G = VEC(c.w, nm, V_G);                                                                                    \
+    gdouble* ZL = VEC(c.w, nm, V_ZL);                                                                                  \
+    gdouble* ZU = VEC(c.w, nm, V_ZU);                                                                                  \
+    gdouble* SIG = VEC(c.w, nm, V_SIG);                                                                                \
+    gdouble* RHS = VEC(c.w, nm, V_RHS);                                                                                \
+    gdouble* DXA = VEC(c.w, nm, V_DXA);                                                                                \
+    gschar* ST = c.w.state;                                                                                            \
+    (void)red; (void)LO; (void)HI; (void)X; (void)G; (void)ZL; (void)ZU; (void)SIG; (void)RHS; (void)DXA; (void)ST;    \
+    int idx[IPB_E];                                                                                                    \
+    bool ok[IPB_E];                                                                                                    \
+    _Pragma("unroll") for (int u = 0; u < IPB_E; ++u) {                                                                \
+        ok[u] = tid + u * MCQ_NT < n;                                                                                  \
+        idx[u] = ok[u] ? tid + u * MCQ_NT : 0;          /* entry 0 stands in for the absent ones (loaded, never stored) */ \
+    }
+    const double zscale = sc.zscale;
+    const double IPM_TOL = 1e-10;
+    iters = 0;
+    {
+    IPB_SETUP
+#pragma unroll
+    for (int u = 0; u < IPB_E; ++u) {
+        if (!ok[u]) continue;
+        const int i = idx[u];
+        const bool fixed = !(HI[i] - LO[i] > 1e-12);
+        ST[i] = fixed ? 2 : 0;
+        X[i] = 0.5 * (LO[i] + HI[i]);
+        ZL[i] = fixed ? 0.0 : zscale;
+        ZU[i] = ZL[i];
+    }
+    }
+    __syncthreads();
+    const double npairs = 2.0 * sc.nfree;
+    const bool any_fixed = sc.nfree < (double)c.d.n;
+    if (!(npairs > 0.0)) return MCQ_OK;
+
+    // g = H x + f is carried along (see ipm()): exact on entry, exact again before convergence is declared
+    bool g_exact = true;
+    for (int it = 1; it <= B.max_ipm_iter; ++it) {
+        // ---- pass 1: complementarity, dual residual, sig, predictor right-hand side ----------------------------------------
+        double mu;
+        for (;;) {
+            IPB_SETUP
+            double x[IPB_E], lo[IPB_E], hi[IPB_E], zl[IPB_E], zu[IPB_E], g[IPB_E];
+            int st[IPB_E];
+#pragma unroll
+            for (int u = 0; u < IPB_E; ++u) {
+                const int i = idx[u];
+                st[u] = ST[i]; x[u] = X[i]; lo[u] = LO[i]; hi[u] = HI[i]; zl[u] = ZL[i]; zu[u] = ZU[i]; g[u] = G[i];
+            }
+            double rdm = 0.0;
+            mu = 0.0;
+#pragma unroll
+            for (int u = 0; u < IPB_E; ++u) {
+                if (!ok[u]) continue;
+                const int i = idx[u];
+                if (st[u] != 0) { RHS[i] = 0.0; continue; }
+                const double sl = x[u] - lo[u], su = hi[u] - x[u];
+                mu += sl * zl[u] + su * zu[u];
+                rdm = fmax(rdm, fabs(g[u] - zl[u] + zu[u]));
+                SIG[i] = zl[u] / sl + zu[u] / su;
+                RHS[i] = -g[u];
+            }
+            block_reduce2_(mu, 0, rdm, 2, red);
+            mu /= npairs;
+            const bool conv = mu < IPM_TOL * zscale * sc.wmean && rdm < IPM_TOL * zscale;
+            if (conv && g_exact) return MCQ_OK;
+            if (!conv) break;
+            gradient(c, X, nullptr, VEC(c.w, nm, V_T0), G);     // looks converged on the carried gradient: confirm on the exact one
+            g_exact = true;
+        }
+        iters = it;
+
+        // ---- factorisation, predictor solve -----------------------------------------------------------------------------
+        const int fs = timed_factor(c, c.w.H, VEC(c.w, c.nm, V_SIG), any_fixed ? c.w.state : nullptr);
+        if (fs != 0) return fs;
+        timed_solve(c, VEC(c.w, c.nm, V_RHS));
+
+        // ---- pass 2: affine step lengths, centring parameter, corrector right-hand side (one load phase) --------------
+        double smu;
+        {
+            IPB_SETUP
+            double dxa[IPB_E], sl[IPB_E], su[IPB_E], zl[IPB_E], zu[IPB_E], g[IPB_E];
+            bool act[IPB_E];
+#pragma unroll
+            for (int u = 0; u < IPB_E; ++u) {
+                const int i = idx[u];
+                const double x = X[i];
+                act[u] = ok[u] && ST[i] == 0;
+                dxa[u] = RHS[i]; sl[u] = x - LO[i]; su[u] = HI[i] - x; zl[u] = ZL[i]; zu[u] = ZU[i]; g[u] = G[i];
+            }
+            double ap = 1.0, ad = 1.0;
+            double dzla[IPB_E], dzua[IPB_E];
+#pragma unroll
+            for (int u = 0; u < IPB_E; ++u) {
+                if (!ok[u]) continue;
+                if (!act[u]) { DXA[idx[u]] = 0.0; continue; }
+                const double dx = dxa[u];
+                DXA[idx[u]] = dx;
+                dzla[u] = -zl[u] - zl[u] * dx / sl[u];
+                dzua[u] = -zu[u] + zu[u] * dx / su[u];
+                if (dx < 0.0) ap = fmin(ap, -sl[u] / dx);
+                if (dx > 0.0) ap = fmin(ap, su[u] / dx);
+                if (dzla[u] < 0.0) ad = fmin(ad, -zl[u] / dzla[u]);
+                if (dzua[u] < 0.0) ad = fmin(ad, -zu[u] / dzua[u]);
+            }
+            block_reduce2_(ap, 1, ad, 1, red);
+            double mua = 0.0;
+#pragma unroll
+            for (int u = 0; u < IPB_E; ++u) {
+                if (!act[u]) continue;
+                mua += (sl[u] + ap * dxa[u]) * (zl[u] + ad * dzla[u]) + (su[u] - ap * dxa[u]) * (zu[u] + ad * dzua[u]);
+            }
+            mua = block_reduce_(mua, 0, red) / npairs;
+            const double ratio = mua / mu;
+            smu = ratio * ratio * ratio * mu;
+#pragma unroll
+            for (int u = 0; u < IPB_E; ++u) {
+                if (!ok[u]) continue;
+                RHS[idx[u]] = act[u] ? -g[u] + (smu - dxa[u] * dzla[u]) / sl[u] - (smu + dxa[u] * dzua[u]) / su[u] : 0.0;
+            }
+        }
+        timed_solve(c, VEC(c.w, c.nm, V_RHS));
+
+        // ---- pass 3: step length of the combined direction, update (one load phase) -------------------------------------
+        {
+            IPB_SETUP
+            double dx[IPB_E], x[IPB_E], zl[IPB_E], zu[IPB_E], g[IPB_E], dzl[IPB_E], dzu[IPB_E], hdx[IPB_E];
+            bool act[IPB_E];
+            double amax = 1.0 / 0.995;
+            double da[IPB_E], lo[IPB_E], hi[IPB_E], sg[IPB_E];
+#pragma unroll
+            for (int u = 0; u < IPB_E; ++u) {
+                const int i = idx[u];
+                act[u] = ok[u] && ST[i] == 0;
+                dx[u] = RHS[i]; da[u] = DXA[i]; x[u] = X[i]; lo[u] = LO[i]; hi[u] = HI[i]; zl[u] = ZL[i]; zu[u] = ZU[i];
+                g[u] = G[i]; sg[u] = SIG[i];
+            }
+#pragma unroll
+            for (int u = 0; u < IPB_E; ++u) {
+                if (!act[u]) continue;
+                const double sl = x[u] - lo[u], su = hi[u] - x[u];
+                const double dzla = -zl[u] - zl[u] * da[u] / sl, dzua = -zu[u] + zu[u] * da[u] / su;
+                dzl[u] = (-sl * zl[u] + smu - da[u] * dzla - zl[u] * dx[u]) / sl;
+                dzu[u] = (-su * zu[u] + smu + da[u] * dzua + zu[u] * dx[u]) / su;
+                // H dx = (corrector right-hand side) - sig dx
+                const double rc = -g[u] + (smu - da[u] * dzla) / sl - (smu + da[u] * dzua) / su;
+                hdx[u] = rc - sg[u] * dx[u];
+                if (dx[u] < 0.0) amax = fmin(amax, -sl / dx[u]);
+                if (dx[u] > 0.0) amax = fmin(amax, su / dx[u]);
+                if (dzl[u] < 0.0) amax = fmin(amax, -zl[u] / dzl[u]);
+                if (dzu[u] < 0.0) amax = fmin(amax, -zu[u] / dzu[u]);
+            }
+            amax = block_reduce_(amax, 1, red);
+            const double a = fmin(1.0, 0.995 * amax);
+#pragma unroll
+            for (int u = 0; u < IPB_E; ++u) {
+                if (!act[u]) continue;
+                const int i = idx[u];
+                G[i] = g[u] + a * hdx[u];
+                X[i] = x[u] + a * dx[u];
+                ZL[i] = zl[u] + a * dzl[u];
+                ZU[i] = zu[u] + a * dzu[u];
+            }
+        }
+        g_exact = false;
+        __syncthreads();
+    }
+    return MCQ_ITER_CAP;
+#undef IPB_SETUP
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
 // Active-set identification from the interior-point pairs + block principal pivoting (Kim-Park / Judice-Pires rule
 // with single-pivot backup) on the vertex: every iterate solves the equality-constrained problem of its working set
 // exactly, so the returned point is an exact KKT vertex like the one a dual active-set (Goldfarb-Idnani) solver returns.
@@ -2214,7 +2424,7 @@ __global__ void __launch_bounds__(MCQ_NT) mcq_solve_kernel(McqBatch B)
     // ---- phase 1: box-constrained QP ---------------------------------------------------------------------------------------
     int ipm_iters = 0, as_iters = 0, it2 = 0, nact_kappa = 0;
     double kkt = 0.0;
-    int status = ipm(c, B, false, sc, ipm_iters);
+    int status = n <= IPB_E * MCQ_NT ? ipm_box(c, B, sc, ipm_iters) : ipm(c, B, false, sc, ipm_iters);
     int nk_dummy = 0;
     if (status == MCQ_OK) status = active_set(c, B, false, sc, as_iters, kkt, nk_dummy);
 
