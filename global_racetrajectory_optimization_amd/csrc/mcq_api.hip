@@ -5,6 +5,7 @@
 // engine.py); a multi-GPU job is N such processes, each solving a contiguous shard of the batch.
 #include <hip/hip_runtime.h>
 
+#include <stddef.h>
 #include <stdio.h>
 #include <string.h>
 
@@ -213,6 +214,110 @@ extern "C" int mcq_solve_device(mcq_handle* h, int batch, int n, const double* r
     B.kappa_bound = kappa_bound;
     B.w_veh = w_veh;
     return launch(h, B, o);
+}
+
+extern "C" int mcq_solve_device_ragged(mcq_handle* h, int batch, int nmax, const int* n_list, const double* reftrack,
+                                       const double* normvec, const double* scaling, double kappa_bound, double w_veh,
+                                       const mcq_opts* opts, double* alpha_out, double* curv_err_out, int* status_out,
+                                       mcq_info* info_out)
+{
+    if (!h || batch <= 0 || nmax <= 0 || !n_list || !reftrack || !normvec || !alpha_out || !curv_err_out || !status_out) {
+        g_err = "mcq_solve_device_ragged: bad argument";
+        return MCQ_E_ARG;
+    }
+    HIP_TRY(hipSetDevice(h->device));
+    const mcq_opts o = resolve_opts(opts);
+    int rc = ensure_ws(h, (size_t)batch, (size_t)nmax);
+    if (rc) return rc;
+    McqBatch B;
+    memset(&B, 0, sizeof(B));
+    B.batch = batch;
+    B.n = nmax;
+    B.nmax = nmax;
+    B.n_list = n_list;
+    B.ref = reftrack;
+    B.nv = normvec;
+    B.sc = scaling;
+    B.alpha = alpha_out;
+    B.curv_err = curv_err_out;
+    B.status = status_out;
+    B.info = info_out;
+    B.kappa_bound = kappa_bound;
+    B.w_veh = w_veh;
+    return launch(h, B, o);
+}
+
+extern "C" int mcq_relinearise_device(mcq_handle* h, int batch, int nmax, const int* n_in, const double* reftrack_in,
+                                      const double* normvec_in, const double* alpha, const int* live, double alpha_scale,
+                                      double stepsize, double* reftrack_out, double* normvec_out, int* n_out,
+                                      int* status_out)
+{
+    if (!h || batch <= 0 || nmax <= 0 || !n_in || !reftrack_in || !normvec_in || !alpha || !reftrack_out || !normvec_out ||
+        !n_out || !status_out || !(stepsize > 0.0) || reftrack_in == reftrack_out || normvec_in == normvec_out) {
+        g_err = "mcq_relinearise_device: bad argument";
+        return MCQ_E_ARG;
+    }
+    HIP_TRY(hipSetDevice(h->device));
+    int rc = ensure_ws(h, (size_t)batch, (size_t)nmax);
+    if (rc) return rc;
+    McqRelin R;
+    memset(&R, 0, sizeof(R));
+    R.batch = batch;
+    R.nmax = nmax;
+    R.n_in = n_in;
+    R.ref_in = reftrack_in;
+    R.nv_in = normvec_in;
+    R.alpha = alpha;
+    R.live = live;
+    R.alpha_scale = alpha_scale;
+    R.stepsize = stepsize;
+    R.ref_out = reftrack_out;
+    R.nv_out = normvec_out;
+    R.n_out = n_out;
+    R.status = status_out;
+    R.vec = h->vec;
+    hipLaunchKernelGGL(mcq_relinearise_kernel, dim3(batch), dim3(256), 0, h->stream, R);
+    HIP_TRY(hipGetLastError());
+    return 0;
+}
+
+// ---- device memory plumbing for callers that keep data resident between calls without a second HIP runtime in the
+//      process (the Python IQP driver): plain allocate / free / copy on the handle's device and stream ------------------
+extern "C" int mcq_device_alloc(mcq_handle* h, size_t bytes, void** out)
+{
+    if (!h || !out || bytes == 0) { g_err = "mcq_device_alloc: bad argument"; return MCQ_E_ARG; }
+    HIP_TRY(hipSetDevice(h->device));
+    HIP_TRY(hipMalloc(out, bytes));
+    HIP_TRY(hipMemsetAsync(*out, 0, bytes, h->stream));
+    return 0;
+}
+
+extern "C" int mcq_device_free(mcq_handle* h, void* ptr)
+{
+    if (!h) { g_err = "mcq_device_free: NULL handle"; return MCQ_E_ARG; }
+    if (!ptr) return 0;
+    HIP_TRY(hipSetDevice(h->device));
+    HIP_TRY(hipStreamSynchronize(h->stream));
+    HIP_TRY(hipFree(ptr));
+    return 0;
+}
+
+extern "C" int mcq_copy_to_device(mcq_handle* h, void* dst, const void* src, size_t bytes)
+{
+    if (!h || !dst || !src) { g_err = "mcq_copy_to_device: bad argument"; return MCQ_E_ARG; }
+    HIP_TRY(hipSetDevice(h->device));
+    HIP_TRY(hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, h->stream));
+    HIP_TRY(hipStreamSynchronize(h->stream));          // the host buffer may be reused on return
+    return 0;
+}
+
+extern "C" int mcq_copy_to_host(mcq_handle* h, void* dst, const void* src, size_t bytes)
+{
+    if (!h || !dst || !src) { g_err = "mcq_copy_to_host: bad argument"; return MCQ_E_ARG; }
+    HIP_TRY(hipSetDevice(h->device));
+    HIP_TRY(hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToHost, h->stream));
+    HIP_TRY(hipStreamSynchronize(h->stream));
+    return 0;
 }
 
 extern "C" int mcq_sync(mcq_handle* h)

@@ -126,3 +126,24 @@ __global__ void mcq_gram_tile_kernel(McqBatch B);
 __global__ void mcq_solve_kernel(McqBatch B);
 
 size_t mcq_solve_lds_bytes();   /* static LDS of the solver kernel (reporting only) */
+
+/* ---- IQP glue on the device: raceline = refline + alpha * normal, closed spline through it
+ *      (unit scalings), arclength re-sampling at ~stepsize, track widths carried over, normals of the re-sampled ring.
+ *      One workgroup per track; mirrors tph.create_raceline / interp_track_widths / calc_splines(use_dist_scaling=False)
+ *      as iqp_handler chains them. ---- */
+struct McqRelin {
+    int batch, nmax;
+    const int* n_in;        // [batch] waypoints of each track
+    const double* ref_in;   // [batch][nmax][4]
+    const double* nv_in;    // [batch][nmax][2]
+    const double* alpha;    // [batch][nmax]
+    const int* live;        // [batch] (0: leave this track alone) or nullptr
+    double alpha_scale;     // damping of the early IQP iterations (iter / iters_min), 1 afterwards
+    double stepsize;        // stepsize_interp
+    double* ref_out;        // [batch][nmax][4]
+    double* nv_out;         // [batch][nmax][2]
+    int* n_out;             // [batch]
+    int* status;            // [batch]: MCQ_OK, or MCQ_BAD_INPUT if the re-sampled ring has < 3 or > nmax points
+    double* vec;            // workspace, [batch][MCQ_NVEC][nmax] (the solver's vector slab)
+};
+__global__ void mcq_relinearise_kernel(McqRelin R);

@@ -2533,3 +2533,194 @@ __global__ void __launch_bounds__(MCQ_NT) mcq_solve_kernel(McqBatch B)
         }
     }
 }
+
+// =====================================================================================================================
+// K4: IQP glue -- re-linearisation on the device
+// =====================================================================================================================
+// Closed cubic spline with unit scalings through n points: the c-coefficients solve  circ(1, 4, 1) c = rhs,
+// rhs_m = 3 (P_{m+1} - 2 P_m + P_{m-1}).  The inverse of circ(1,4,1) is known in closed form -- g_k = A lam^|k| with
+// lam = sqrt(3) - 2, A = 1 / (4 + 2 lam), plus its periodic images -- so c is a short convolution: 0.268^48 ~ 4e-28, rings
+// with more than 2 x 48 points use the truncated kernel, shorter rings the exact periodic one
+// g_k = A (lam^k + lam^(n-k)) / (1 - lam^n).  RX / RY hold rhs; all threads of the block call.
+#define RL_KW 48
+__device__ void relin_spline_c(const gdouble* RX, const gdouble* RY, int n, gdouble* CX, gdouble* CY)
+{
+    const double lam = sqrt(3.0) - 2.0, A = 1.0 / (4.0 + 2.0 * lam);
+    for (int i = threadIdx.x; i < n; i += MCQ_NT) {
+        double cx, cy;
+        if (n > 2 * RL_KW) {
+            cx = A * RX[i];
+            cy = A * RY[i];
+            double g = A;
+            int ju = i, jd = i;
+            for (int k = 1; k <= RL_KW; ++k) {
+                g *= lam;
+                ju = ju + 1 == n ? 0 : ju + 1;
+                jd = jd == 0 ? n - 1 : jd - 1;
+                cx += g * (RX[ju] + RX[jd]);
+                cy += g * (RY[ju] + RY[jd]);
+            }
+        } else {
+            double ln = 1.0;
+            for (int k = 0; k < n; ++k) ln *= lam;                       // lam^n
+            const double sc = A / (1.0 - ln), il = 1.0 / lam;
+            double pk = 1.0, qk = ln;                                    // lam^k, lam^(n-k)
+            cx = 0.0;
+            cy = 0.0;
+            int j = i;
+            for (int k = 0; k < n; ++k) {
+                const double g = sc * (pk + qk);
+                cx += g * RX[j];
+                cy += g * RY[j];
+                pk *= lam;
+                qk *= il;
+                j = j + 1 == n ? 0 : j + 1;
+            }
+        }
+        CX[i] = cx;
+        CY[i] = cy;
+    }
+}
+
+// rhs of the c-system from the points
+__device__ void relin_spline_rhs(const gdouble* PX, const gdouble* PY, int n, gdouble* RX, gdouble* RY)
+{
+    for (int i = threadIdx.x; i < n; i += MCQ_NT) {
+        const int ip = i + 1 == n ? 0 : i + 1, im = i == 0 ? n - 1 : i - 1;
+        RX[i] = 3.0 * ((PX[ip] - PX[i]) - (PX[i] - PX[im]));
+        RY[i] = 3.0 * ((PY[ip] - PY[i]) - (PY[i] - PY[im]));
+    }
+}
+
+__global__ void __launch_bounds__(MCQ_NT) mcq_relinearise_kernel(McqRelin R)
+{
+    __shared__ double sbuf[2048];
+    __shared__ double s_carry;
+    __shared__ int s_m;
+    const int tid = threadIdx.x, pb = blockIdx.x;
+    if (R.live && R.live[pb] == 0) return;
+    const size_t nm = (size_t)R.nmax;
+    const int n = R.n_in[pb];
+    const gdouble* ref = (const gdouble*)(R.ref_in + (size_t)pb * nm * 4);
+    const gdouble* nv = (const gdouble*)(R.nv_in + (size_t)pb * nm * 2);
+    const gdouble* al = (const gdouble*)(R.alpha + (size_t)pb * nm);
+    gdouble* refo = (gdouble*)(R.ref_out + (size_t)pb * nm * 4);
+    gdouble* nvo = (gdouble*)(R.nv_out + (size_t)pb * nm * 2);
+    gdouble* vec = (gdouble*)(R.vec + (size_t)pb * nm * MCQ_NVEC);
+    gdouble* PX = vec + 0 * nm;   gdouble* PY = vec + 1 * nm;    // raceline points (a-coefficients)
+    gdouble* RX = vec + 2 * nm;   gdouble* RY = vec + 3 * nm;    // rhs, later the new points
+    gdouble* CX = vec + 4 * nm;   gdouble* CY = vec + 5 * nm;    // c-coefficients
+    gdouble* LEN = vec + 6 * nm;  gdouble* CUM = vec + 7 * nm;   // spline lengths, their running sum
+    gdouble* WR = vec + 8 * nm;   gdouble* WL = vec + 9 * nm;    // shifted track widths
+    gdouble* QX = vec + 10 * nm;  gdouble* QY = vec + 11 * nm;   // re-sampled points
+    gint* n_out = (gint*)(R.n_out + pb);
+    gint* status = (gint*)(R.status + pb);
+    if (n < 3) {
+        if (tid == 0) { *status = MCQ_BAD_INPUT; *n_out = n; }
+        return;
+    }
+
+    // ---- raceline and shifted widths:  p + a n,  w_right - a,  w_left + a   (a = damped alpha) --------------------------
+    for (int i = tid; i < n; i += MCQ_NT) {
+        const double a = R.alpha_scale * al[i];
+        PX[i] = ref[4 * i] + a * nv[2 * i];
+        PY[i] = ref[4 * i + 1] + a * nv[2 * i + 1];
+        WR[i] = ref[4 * i + 2] - a;
+        WL[i] = ref[4 * i + 3] + a;
+    }
+    __syncthreads();
+    relin_spline_rhs(PX, PY, n, RX, RY);
+    __syncthreads();
+    relin_spline_c(RX, RY, n, CX, CY);
+    __syncthreads();
+
+    // ---- spline lengths: 15 points per segment, sum of the 14 chords (tph.calc_spline_lengths) --------------------------
+    for (int i = tid; i < n; i += MCQ_NT) {
+        const int ip = i + 1 == n ? 0 : i + 1;
+        const double ax = PX[i], ay = PY[i], cx = CX[i], cy = CY[i];
+        const double dlx = PX[ip] - ax, dly = PY[ip] - ay;
+        const double bx = dlx - (2.0 * cx + CX[ip]) / 3.0, by = dly - (2.0 * cy + CY[ip]) / 3.0;
+        const double dx = (CX[ip] - cx) / 3.0, dy = (CY[ip] - cy) / 3.0;
+        double len = 0.0, x0 = ax, y0 = ay;
+        for (int k = 1; k < 15; ++k) {
+            const double t = (double)k / 14.0;
+            const double x1 = ax + bx * t + cx * t * t + dx * t * t * t;
+            const double y1 = ay + by * t + cy * t * t + dy * t * t * t;
+            len += hypot(x1 - x0, y1 - y0);
+            x0 = x1;
+            y0 = y1;
+        }
+        LEN[i] = len;
+    }
+    __syncthreads();
+    // ---- running sum, in the summation order of numpy.cumsum (the point count below is a ceil() of its last entry):
+    //      2048-entry chunks through LDS, one thread adds sequentially ---------------------------------------------------
+    if (tid == 0) s_carry = 0.0;
+    for (int c0 = 0; c0 < n; c0 += 2048) {
+        const int cn = n - c0 < 2048 ? n - c0 : 2048;
+        __syncthreads();
+        for (int q = tid; q < cn; q += MCQ_NT) sbuf[q] = LEN[c0 + q];
+        __syncthreads();
+        if (tid == 0) {
+            double acc = s_carry;
+            for (int q = 0; q < cn; ++q) { acc += sbuf[q]; sbuf[q] = acc; }
+            s_carry = acc;
+        }
+        __syncthreads();
+        for (int q = tid; q < cn; q += MCQ_NT) CUM[c0 + q] = sbuf[q];
+    }
+    __syncthreads();
+    const double total = s_carry;
+    if (tid == 0) {
+        const double cnt = ceil(total / R.stepsize) + 1.0;       // no_interp_points of tph.interp_splines
+        s_m = (cnt >= 2.0 && cnt <= 2.0e9) ? (int)cnt - 1 : -1;  // points kept (incl_last_point = False)
+    }
+    __syncthreads();
+    const int m = s_m;
+    if (m < 3 || m > R.nmax) {
+        if (tid == 0) { *status = MCQ_BAD_INPUT; *n_out = n; }
+        return;
+    }
+
+    // ---- re-sampling: numpy.linspace(0, total, m + 1)[:m], searchsorted(cum, q, side='right'), Horner evaluation;
+    //      widths linearly between the segment's end points (closed) ---------------------------------------------------------
+    const double step = total / (double)m;
+    for (int j = tid; j < m; j += MCQ_NT) {
+        const double q = (double)j * step;
+        int lo = 0, hi = n;                                      // first index with CUM[idx] > q
+        while (lo < hi) {
+            const int mid = (lo + hi) >> 1;
+            if (CUM[mid] > q) hi = mid; else lo = mid + 1;
+        }
+        const int s = lo < n - 1 ? lo : n - 1;
+        const int sp = s + 1 == n ? 0 : s + 1;
+        const double start = s > 0 ? CUM[s - 1] : 0.0;
+        const double t = (q - start) / LEN[s];
+        const double ax = PX[s], ay = PY[s], cx = CX[s], cy = CY[s];
+        const double bx = (PX[sp] - ax) - (2.0 * cx + CX[sp]) / 3.0, by = (PY[sp] - ay) - (2.0 * cy + CY[sp]) / 3.0;
+        const double dx = (CX[sp] - cx) / 3.0, dy = (CY[sp] - cy) / 3.0;
+        QX[j] = ax + t * (bx + t * (cx + t * dx));
+        QY[j] = ay + t * (by + t * (cy + t * dy));
+        refo[4 * j + 2] = WR[s] + (WR[sp] - WR[s]) * t;
+        refo[4 * j + 3] = WL[s] + (WL[sp] - WL[s]) * t;
+    }
+    __syncthreads();
+    for (int j = tid; j < m; j += MCQ_NT) {
+        refo[4 * j] = QX[j];
+        refo[4 * j + 1] = QY[j];
+    }
+    // ---- normals of the closed unit-scaling spline through the new ring:  (b_y, -b_x) / |b| ------------------------------
+    relin_spline_rhs(QX, QY, m, PX, PY);                         // PX / PY reused as rhs
+    __syncthreads();
+    relin_spline_c(PX, PY, m, CX, CY);
+    __syncthreads();
+    for (int j = tid; j < m; j += MCQ_NT) {
+        const int jp = j + 1 == m ? 0 : j + 1;
+        const double bx = (QX[jp] - QX[j]) - (2.0 * CX[j] + CX[jp]) / 3.0;
+        const double by = (QY[jp] - QY[j]) - (2.0 * CY[j] + CY[jp]) / 3.0;
+        const double nrm = sqrt(by * by + bx * bx);
+        nvo[2 * j] = by / nrm;
+        nvo[2 * j + 1] = -bx / nrm;
+    }
+    if (tid == 0) { *status = MCQ_OK; *n_out = m; }
+}

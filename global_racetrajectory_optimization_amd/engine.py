@@ -41,7 +41,9 @@ class McqInfo(ctypes.Structure):
 
 
 EXPORTED_SYMBOLS = ("mcq_create", "mcq_destroy", "mcq_last_error", "mcq_default_opts", "mcq_solve_batch",
-                    "mcq_solve_device", "mcq_sync", "mcq_stream", "mcq_last_timing", "mcq_workspace_bytes")
+                    "mcq_solve_device", "mcq_solve_device_ragged", "mcq_relinearise_device", "mcq_device_alloc",
+                    "mcq_device_free", "mcq_copy_to_device", "mcq_copy_to_host", "mcq_sync", "mcq_stream",
+                    "mcq_last_timing", "mcq_workspace_bytes")
 
 
 class EngineError(RuntimeError):
@@ -70,6 +72,20 @@ def load_library(path=None):
     lib.mcq_solve_device.argtypes = [vp, ctypes.c_int, ctypes.c_int, vp, vp, vp, ctypes.c_double, ctypes.c_double,
                                      ctypes.POINTER(McqOpts), vp, vp, vp, vp]
     lib.mcq_solve_device.restype = ctypes.c_int
+    lib.mcq_solve_device_ragged.argtypes = [vp, ctypes.c_int, ctypes.c_int, vp, vp, vp, vp, ctypes.c_double,
+                                            ctypes.c_double, ctypes.POINTER(McqOpts), vp, vp, vp, vp]
+    lib.mcq_solve_device_ragged.restype = ctypes.c_int
+    lib.mcq_relinearise_device.argtypes = [vp, ctypes.c_int, ctypes.c_int, vp, vp, vp, vp, vp, ctypes.c_double,
+                                           ctypes.c_double, vp, vp, vp, vp]
+    lib.mcq_relinearise_device.restype = ctypes.c_int
+    lib.mcq_device_alloc.argtypes = [vp, ctypes.c_size_t, ctypes.POINTER(vp)]
+    lib.mcq_device_alloc.restype = ctypes.c_int
+    lib.mcq_device_free.argtypes = [vp, vp]
+    lib.mcq_device_free.restype = ctypes.c_int
+    lib.mcq_copy_to_device.argtypes = [vp, vp, vp, ctypes.c_size_t]
+    lib.mcq_copy_to_device.restype = ctypes.c_int
+    lib.mcq_copy_to_host.argtypes = [vp, vp, vp, ctypes.c_size_t]
+    lib.mcq_copy_to_host.restype = ctypes.c_int
     lib.mcq_sync.argtypes = [vp]
     lib.mcq_sync.restype = ctypes.c_int
     lib.mcq_stream.argtypes = [vp]
@@ -170,6 +186,41 @@ class Engine:
                                        float(kappa_bound), float(w_veh), ctypes.byref(opts), d_alpha, d_curv, d_status,
                                        d_info or None)
         self._check(rc, "mcq_solve_device")
+
+    def solve_device_ragged(self, batch, nmax, d_n, d_reftrack, d_normvec, d_scaling, kappa_bound, w_veh, d_alpha,
+                            d_curv, d_status, d_info=None, **opt_kw):
+        """Device-resident batch with per-problem waypoint counts d_n [batch] (int32, device); arrays strided by nmax."""
+        opts = self._opts(**opt_kw)
+        rc = self.lib.mcq_solve_device_ragged(self.h, int(batch), int(nmax), d_n, d_reftrack, d_normvec,
+                                              d_scaling or None, float(kappa_bound), float(w_veh), ctypes.byref(opts),
+                                              d_alpha, d_curv, d_status, d_info or None)
+        self._check(rc, "mcq_solve_device_ragged")
+
+    def relinearise_device(self, batch, nmax, d_n_in, d_ref_in, d_nv_in, d_alpha, d_live, alpha_scale, stepsize,
+                           d_ref_out, d_nv_out, d_n_out, d_status):
+        """IQP glue between two passes, on the device (mcq_relinearise_device in include/mcq.h).  Asynchronous."""
+        rc = self.lib.mcq_relinearise_device(self.h, int(batch), int(nmax), d_n_in, d_ref_in, d_nv_in, d_alpha,
+                                             d_live or None, float(alpha_scale), float(stepsize), d_ref_out, d_nv_out,
+                                             d_n_out, d_status)
+        self._check(rc, "mcq_relinearise_device")
+
+    # ---- device memory plumbing (mcq_device_alloc & co): numpy in, numpy out, raw device pointers as ints ----------------
+    def alloc(self, nbytes):
+        p = ctypes.c_void_p()
+        self._check(self.lib.mcq_device_alloc(self.h, int(nbytes), ctypes.byref(p)), "mcq_device_alloc")
+        return p.value
+
+    def free(self, ptr):
+        self._check(self.lib.mcq_device_free(self.h, ptr), "mcq_device_free")
+
+    def upload(self, ptr, arr, offset_bytes=0):
+        arr = np.ascontiguousarray(arr)
+        self._check(self.lib.mcq_copy_to_device(self.h, int(ptr) + int(offset_bytes), arr.ctypes.data, arr.nbytes), "mcq_copy_to_device")
+
+    def download(self, ptr, shape, dtype, offset_bytes=0):
+        out = np.empty(shape, dtype=dtype)
+        self._check(self.lib.mcq_copy_to_host(self.h, out.ctypes.data, int(ptr) + int(offset_bytes), out.nbytes), "mcq_copy_to_host")
+        return out
 
     def sync(self):
         self._check(self.lib.mcq_sync(self.h), "mcq_sync")

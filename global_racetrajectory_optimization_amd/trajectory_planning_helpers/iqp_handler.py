@@ -34,15 +34,113 @@ def _relinearise(reftrack_tmp, normvec_tmp, alpha, stepsize_interp):
     return reftrack_new, _respline_normals(reftrack_new[:, :2])
 
 
+def _iqp_batch_device(eng, tracks, kappa_bound, w_veh, stepsize_interp, iters_min, curv_error_allowed, print_debug,
+                      max_rounds, stats):
+    """The lock-step IQP rounds with everything but a few scalars per track resident in HBM: the QP pass is
+    mcq_solve_device_ragged, the glue between passes mcq_relinearise_device.  Per round the host
+    reads back curv_error / status / N per track and, for the tracks that finish, their final alpha / reftrack /
+    normals.  Device memory through the engine's own C ABI (no second HIP runtime in the process)."""
+    bsz = len(tracks)
+    refs = [np.ascontiguousarray(t["reftrack"], dtype=np.float64) for t in tracks]
+    nvs = [np.ascontiguousarray(t["normvectors"], dtype=np.float64) for t in tracks]
+    n_host = np.array([r.shape[0] for r in refs], dtype=np.int32)
+    # capacity for the re-sampled rings: the raceline is never much longer than the polygon through the reference points;
+    # 30 % + 16 points of headroom, reported (not truncated) if it ever is not enough
+    nmax = 0
+    for r in refs:
+        closed = np.vstack((r[:, :2], r[:1, :2]))
+        length = float(np.sum(np.sqrt(np.sum(np.diff(closed, axis=0) ** 2, axis=1))))
+        nmax = max(nmax, r.shape[0], int(np.ceil(1.3 * length / stepsize_interp)) + 16)
+    ref_h = np.zeros((bsz, nmax, 4))
+    nv_h = np.zeros((bsz, nmax, 2))
+    sc_h = np.ones((bsz, nmax))
+    for k in range(bsz):
+        ref_h[k, :n_host[k]] = refs[k]
+        nv_h[k, :n_host[k]] = nvs[k]
+        if tracks[k].get("scaling") is not None:
+            sc_h[k, :n_host[k]] = tracks[k]["scaling"]
+    f8, i4 = 8, 4
+    bufs = []
+
+    def dalloc(nbytes, init=None):
+        p = eng.alloc(nbytes)
+        bufs.append(p)
+        if init is not None:
+            eng.upload(p, init)
+        return p
+
+    try:
+        d_ref = [dalloc(ref_h.nbytes, ref_h), dalloc(ref_h.nbytes)]
+        d_nv = [dalloc(nv_h.nbytes, nv_h), dalloc(nv_h.nbytes)]
+        d_sc = dalloc(sc_h.nbytes, sc_h)
+        d_alpha = dalloc(bsz * nmax * f8)
+        d_curv = dalloc(bsz * f8)
+        d_status = dalloc(bsz * i4)
+        d_n = [dalloc(bsz * i4, n_host), dalloc(bsz * i4)]
+        d_nsolve = dalloc(bsz * i4)
+        d_live = dalloc(bsz * i4)
+        d_rst = dalloc(bsz * i4)
+        live = np.ones(bsz, dtype=bool)
+        out = [None] * bsz
+        cur, n_solves, it = 0, 0, 0
+        while live.any():
+            it += 1
+            if it > max_rounds:
+                raise RuntimeError("iqp_handler: no convergence within %d rounds" % max_rounds)
+            # finished tracks keep their buffers but are skipped: n = 0 makes the assembly kernel flag them, the solver returns
+            eng.upload(d_nsolve, (n_host * live).astype(np.int32))
+            eng.solve_device_ragged(bsz, nmax, d_nsolve, d_ref[cur], d_nv[cur], d_sc if it == 1 else None, kappa_bound,
+                                    w_veh, d_alpha, d_curv, d_status)
+            n_solves += int(live.sum())
+            curv = eng.download(d_curv, (bsz,), np.float64)
+            status = eng.download(d_status, (bsz,), np.int32)
+            scale = it * 1.0 / iters_min if it < iters_min else 1.0
+            for k in np.nonzero(live)[0]:
+                _omc.raise_for_status(int(status[k]))
+                if print_debug:
+                    print("Minimum curvature IQP: iteration %i, curv_error_max: %.4frad/m" % (it, curv[k]))
+                if it >= iters_min and curv[k] <= curv_error_allowed:
+                    if print_debug:
+                        print("Finished IQP!")
+                    nk = int(n_host[k])
+                    out[k] = (eng.download(d_alpha, (nk,), np.float64, k * nmax * f8),
+                              eng.download(d_ref[cur], (nk, 4), np.float64, k * nmax * 4 * f8),
+                              eng.download(d_nv[cur], (nk, 2), np.float64, k * nmax * 2 * f8))
+                    live[k] = False
+            if not live.any():
+                break
+            eng.upload(d_live, live.astype(np.int32))
+            eng.relinearise_device(bsz, nmax, d_n[cur], d_ref[cur], d_nv[cur], d_alpha, d_live, scale, stepsize_interp,
+                                   d_ref[1 - cur], d_nv[1 - cur], d_n[1 - cur], d_rst)
+            rst = eng.download(d_rst, (bsz,), np.int32)
+            n_new = eng.download(d_n[1 - cur], (bsz,), np.int32)
+            for k in np.nonzero(live)[0]:
+                if rst[k] != 0:
+                    raise RuntimeError("iqp_handler: re-sampled raceline of track %d does not fit the device buffers "
+                                       "(nmax = %d)" % (k, nmax))
+                n_host[k] = n_new[k]
+            cur = 1 - cur
+    finally:
+        for p in bufs:
+            eng.free(p)
+    if stats is not None:
+        stats.update(rounds=it, qp_solves=n_solves, device_resident=True, nmax=nmax)
+    return out
+
+
 def iqp_handler_batch(tracks: list, kappa_bound: float, w_veh: float, stepsize_interp: float, iters_min: int = 3,
                       curv_error_allowed: float = 0.01, print_debug: bool = False, engine=None, max_rounds: int = 50,
-                      stats: dict = None) -> list:
+                      stats: dict = None, device_resident: bool = False) -> list:
     """tracks: list of dicts {reftrack [N,4], normvectors [N,2], scaling [N] or None}.
 
     Returns a list of (alpha, reftrack, normvectors) like iqp_handler.  `stats` (optional dict) receives
-    {'rounds', 'qp_solves'}.
+    {'rounds', 'qp_solves'}.  device_resident=True keeps the tracks in HBM between the passes (the glue runs as a HIP
+    kernel, mcq_relinearise_device); the default runs the glue on the host exactly as upstream chains it.
     """
     eng = engine or _engine.default_engine()
+    if device_resident:
+        return _iqp_batch_device(eng, tracks, kappa_bound, w_veh, stepsize_interp, iters_min, curv_error_allowed,
+                                 print_debug, max_rounds, stats)
     state = [dict(ref=np.array(t["reftrack"], dtype=np.float64), nv=np.array(t["normvectors"], dtype=np.float64),
                   sc=None if t.get("scaling") is None else np.array(t["scaling"], dtype=np.float64), done=False,
                   alpha=None) for t in tracks]

@@ -30,6 +30,8 @@
 #ifndef MCQ_H
 #define MCQ_H
 
+#include <stddef.h>
+
 #ifdef __cplusplus
 extern "C" {
 #endif
@@ -105,6 +107,32 @@ int mcq_solve_batch(mcq_handle* h, const mcq_problem* probs, int batch, const mc
 int mcq_solve_device(mcq_handle* h, int batch, int n, const double* reftrack, const double* normvec,
                      const double* scaling, double kappa_bound, double w_veh, const mcq_opts* opts, double* alpha_out,
                      double* curv_err_out, int* status_out, mcq_info* info_out);
+/* The same with per-problem sizes: n_list [batch] (device) waypoints per problem, every array strided by nmax
+ * (reftrack [batch][nmax][4], ...).  This is what a batch of IQP runs needs: N changes from pass to pass and differs
+ * between tracks [REF main_globaltraj.py:273-284]. */
+int mcq_solve_device_ragged(mcq_handle* h, int batch, int nmax, const int* n_list, const double* reftrack,
+                            const double* normvec, const double* scaling, double kappa_bound, double w_veh,
+                            const mcq_opts* opts, double* alpha_out, double* curv_err_out, int* status_out,
+                            mcq_info* info_out);
+
+/* Device-side glue of tph.iqp_handler between two passes (what upstream does on the host with two dense 4N x 4N spline
+ * solves per pass): raceline = refline + alpha_scale * alpha * normal; closed spline through it (unit scalings);
+ * arclength re-sampling at ~stepsize (tph.create_raceline); track widths shifted by -/+ alpha and carried over linearly
+ * (tph.interp_track_widths); unit normals of the closed spline through the re-sampled ring
+ * (tph.calc_splines(use_dist_scaling=False)).  All pointers DEVICE pointers, arrays strided by nmax; `live` [batch] or
+ * NULL selects the tracks to process; n_out [batch] receives the new waypoint counts; status_out [batch] MCQ_OK or
+ * MCQ_BAD_INPUT (new ring would have < 3 or > nmax points).  Input and output buffers must differ.  Asynchronous on
+ * the handle's stream. */
+int mcq_relinearise_device(mcq_handle* h, int batch, int nmax, const int* n_in, const double* reftrack_in,
+                           const double* normvec_in, const double* alpha, const int* live, double alpha_scale,
+                           double stepsize, double* reftrack_out, double* normvec_out, int* n_out, int* status_out);
+/* Device memory plumbing on the handle's device and stream, for callers that keep data resident between calls (the
+ * Python IQP driver) without loading a second HIP runtime into the process: allocate (zero-filled) / free / blocking
+ * copies.  A reference-side binding would use these exactly where a CUDA/HIP-aware caller uses its own allocator. */
+int mcq_device_alloc(mcq_handle* h, size_t bytes, void** out);
+int mcq_device_free(mcq_handle* h, void* ptr);
+int mcq_copy_to_device(mcq_handle* h, void* dst, const void* src, size_t bytes);
+int mcq_copy_to_host(mcq_handle* h, void* dst, const void* src, size_t bytes);
 int mcq_sync(mcq_handle* h);
 void* mcq_stream(mcq_handle* h);
 

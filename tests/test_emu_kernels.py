@@ -96,3 +96,48 @@ def test_curvature_rows_active_and_infeasible(emu):
     assert np.max(np.abs(al[0] - a_ref)) < 1e-8
     assert abs(curv[0] - err_ref) < 1e-9
     assert abs(inf[0]["kappa_max"] - kb) < 1e-9
+
+
+def _relin_device(eng, tracks, alphas, alpha_scale, stepsize, nmax):
+    """Drives mcq_relinearise_device with plain host arrays (the interpreter's "device" memory is host memory)."""
+    bsz = len(tracks)
+    n_in = np.array([t[0].shape[0] for t in tracks], dtype=np.int32)
+    ref_in = np.zeros((bsz, nmax, 4))
+    nv_in = np.zeros((bsz, nmax, 2))
+    al = np.zeros((bsz, nmax))
+    for k, (ref, nv) in enumerate(tracks):
+        ref_in[k, :n_in[k]] = ref
+        nv_in[k, :n_in[k]] = nv
+        al[k, :n_in[k]] = alphas[k]
+    ref_out = np.zeros_like(ref_in)
+    nv_out = np.zeros_like(nv_in)
+    n_out = np.zeros(bsz, dtype=np.int32)
+    st = np.full(bsz, -1, dtype=np.int32)
+    eng.relinearise_device(bsz, nmax, n_in.ctypes.data, ref_in.ctypes.data, nv_in.ctypes.data, al.ctypes.data, None,
+                           alpha_scale, stepsize, ref_out.ctypes.data, nv_out.ctypes.data, n_out.ctypes.data,
+                           st.ctypes.data)
+    eng.sync()
+    return ref_out, nv_out, n_out, st
+
+
+def test_relinearise_kernel_matches_host_glue(emu, golden):
+    """Row f-1: the device-side IQP glue (raceline, re-sampling, widths, normals) against the host chain
+    create_raceline -> interp_track_widths -> calc_splines(use_dist_scaling=False), long and short rings in one launch."""
+    from global_racetrajectory_optimization_amd.trajectory_planning_helpers import iqp_handler as iqp
+    g = golden["rounded_rectangle"]
+    ref_s, nv_s, _, _ = _small_track(40, 3)                      # short ring: exact periodic spline kernel
+    rng = np.random.default_rng(0)
+    tracks = [(g["reftrack"], g["normvec"]), (ref_s, nv_s)]
+    alphas = [g["alpha"], 0.3 * rng.uniform(-1.0, 1.0, size=40)]
+    for scale, step in ((1.0 / 3.0, 3.0), (1.0, 2.0)):
+        ref_d, nv_d, n_d, st = _relin_device(emu, tracks, alphas, scale, step, nmax=512)
+        for k, (ref, nv) in enumerate(tracks):
+            ref_h, nv_h = iqp._relinearise(np.array(ref), np.array(nv), scale * alphas[k], step)
+            assert st[k] == 0
+            assert n_d[k] == ref_h.shape[0]
+            m = n_d[k]
+            assert np.max(np.abs(ref_d[k, :m] - ref_h)) < 1e-9
+            assert np.max(np.abs(nv_d[k, :m] - nv_h)) < 1e-9
+    # a ring that does not fit the output stride is reported, not truncated
+    _, _, _, st = _relin_device(emu, tracks[:1], alphas[:1], 1.0, 0.5, nmax=512)
+    assert st[0] == engine.STATUS_BAD_INPUT

@@ -210,3 +210,24 @@ def test_vehicle_width_sweep_mixed_tracks(gpu_engine, golden):
         assert st[k] == 0, (k, st[k])
         assert np.max(np.abs(al[k] - a_ref)) < ALPHA_TOL, k
         assert abs(curv[k] - err_ref) < CURV_TOL, k
+
+
+def test_iqp_device_resident_matches_golden(gpu_engine, golden):
+    """Row f-1: a batch of IQP runs with the tracks resident in HBM between the passes (mcq_solve_device_ragged +
+    mcq_relinearise_device) against the golden IQP end states of the oracle's host chain; ragged N, tracks finishing in
+    different rounds."""
+    names = ("rounded_rectangle", "handling_track", "rounded_rectangle")
+    tracks = []
+    for name in names:
+        g = golden[name]
+        tracks.append(dict(reftrack=g["reftrack"].copy(), normvectors=g["normvec"], scaling=g["scaling"]))
+    stats = {}
+    out = tph.iqp_handler.iqp_handler_batch(tracks, kappa_bound=0.12, w_veh=3.4, stepsize_interp=3.0, iters_min=3,
+                                            curv_error_allowed=0.01, engine=gpu_engine, stats=stats, device_resident=True)
+    assert stats["device_resident"] and stats["rounds"] >= 3
+    for name, (a, ref_out, nv_out) in zip(names, out):
+        g = golden[name]
+        assert a.shape == g["iqp_alpha"].shape
+        assert np.max(np.abs(a - g["iqp_alpha"])) < ALPHA_TOL
+        assert np.max(np.abs(ref_out - g["iqp_reftrack"])) < 1e-6
+        assert np.max(np.abs(nv_out - g["iqp_normvec"])) < 1e-8
