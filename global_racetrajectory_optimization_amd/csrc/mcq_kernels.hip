@@ -1974,7 +1974,9 @@ __device__ __noinline__ int ipm(SolveCtx& c, const McqBatch& B, bool with_kappa,
 // generic routine above does seven dependent passes.  Arithmetic and summation order are those of ipm().
 // ---------------------------------------------------------------------------------------------------------------------
 #define IPB_E 8
-__device__ __noinline__ int ipm_box(SolveCtx& c, const McqBatch& B, const SolveScalars& sc, int& iters)
+// `resume`: continue from the pairs (X, ZL, ZU) already in memory to the tighter tolerance `tol` -- the second attempt on
+// degenerate / very ill-conditioned instances (see the driver in mcq_solve_kernel).
+__device__ __noinline__ int ipm_box(SolveCtx& c, const McqBatch& B, const SolveScalars& sc, int& iters, double tol, bool resume)
 {
     // Pointers and the per-thread index set are re-derived at the top of every pass: nothing but a few scalars is live
     // across the (non-inlined) factorisation / solve calls, so nothing is spilled to scratch and reloaded around them.
@@ -2000,7 +2002,7 @@ __device__ __noinline__ int ipm_box(SolveCtx& c, const McqBatch& B, const SolveS
         idx[u] = ok[u] ? tid + u * MCQ_NT : 0;          /* entry 0 stands in for the absent ones (loaded, never stored) */ \
     }
     const double zscale = sc.zscale;
-    const double IPM_TOL = 1e-10;
+    const double IPM_TOL = tol;
     iters = 0;
     {
     IPB_SETUP
@@ -2010,18 +2012,23 @@ __device__ __noinline__ int ipm_box(SolveCtx& c, const McqBatch& B, const SolveS
         const int i = idx[u];
         const bool fixed = !(HI[i] - LO[i] > 1e-12);
         ST[i] = fixed ? 2 : 0;
-        X[i] = 0.5 * (LO[i] + HI[i]);
-        ZL[i] = fixed ? 0.0 : zscale;
-        ZU[i] = ZL[i];
+        if (!resume) {
+            X[i] = 0.5 * (LO[i] + HI[i]);
+            ZL[i] = fixed ? 0.0 : zscale;
+            ZU[i] = ZL[i];
+        }
     }
     }
     __syncthreads();
+    if (resume) gradient(c, VEC(c.w, c.nm, V_X), nullptr, VEC(c.w, c.nm, V_T0), VEC(c.w, c.nm, V_G));
     const double npairs = 2.0 * sc.nfree;
     const bool any_fixed = sc.nfree < (double)c.d.n;
     if (!(npairs > 0.0)) return MCQ_OK;
 
     // g = H x + f is carried along (see ipm()): exact on entry, exact again before convergence is declared
     bool g_exact = true;
+    double mu_prev = 1e300;
+    int stalled = 0;
     for (int it = 1; it <= B.max_ipm_iter; ++it) {
         // ---- pass 1: complementarity, dual residual, sig, predictor right-hand side ----------------------------------------
         double mu;
@@ -2056,6 +2063,13 @@ __device__ __noinline__ int ipm_box(SolveCtx& c, const McqBatch& B, const SolveS
             g_exact = true;
         }
         iters = it;
+        if (resume) {
+            // at the tighter tolerance round-off can stop the complementarity from shrinking: three rounds without a 10 %
+            // reduction end the attempt (the active-set phase then decides)
+            stalled = mu > 0.9 * mu_prev ? stalled + 1 : 0;
+            mu_prev = mu;
+            if (stalled >= 3) return MCQ_OK;
+        }
 
         // ---- factorisation, predictor solve -----------------------------------------------------------------------------
         const int fs = timed_factor(c, c.w.H, VEC(c.w, c.nm, V_SIG), any_fixed ? c.w.state : nullptr);
@@ -2183,7 +2197,7 @@ __device__ __forceinline__ double erow_dot(const SolveCtx& c, int k, const gdoub
     return acc;
 }
 
-__device__ __noinline__ int active_set(SolveCtx& c, const McqBatch& B, bool with_kappa, bool tapia, const SolveScalars& sc, int& iters,
+__device__ __noinline__ int active_set(SolveCtx& c, const McqBatch& B, bool with_kappa, bool tapia, int cap, const SolveScalars& sc, int& iters,
                                        double& kkt, int& nk_out)
 {
     const int tid = threadIdx.x, n = c.d.n, nm = c.nm;
@@ -2246,7 +2260,7 @@ __device__ __noinline__ int active_set(SolveCtx& c, const McqBatch& B, bool with
     const double toly = 1e-10 * (fscale > 0.0 ? fscale : 1.0);
     const double tolk = 1e-10 * kb;
     int best = 2 * n + 1, pcnt = 3;
-    for (int it = 1; it <= B.max_as_iter; ++it) {
+    for (int it = 1; it <= cap; ++it) {
         iters = it;
         // ---- compact list of the curvature working set (thread 0; n is small relative to everything else here) ------------
         if (tid == 0) {
@@ -2449,9 +2463,32 @@ __global__ void __launch_bounds__(MCQ_NT) mcq_solve_kernel(McqBatch B)
     // ---- phase 1: box-constrained QP ---------------------------------------------------------------------------------------
     int ipm_iters = 0, as_iters = 0, it2 = 0, nact_kappa = 0;
     double kkt = 0.0;
-    int status = n <= IPB_E * MCQ_NT ? ipm_box(c, B, sc, ipm_iters) : ipm(c, B, false, sc, ipm_iters);
+    const bool small = n <= IPB_E * MCQ_NT;
+    int status = small ? ipm_box(c, B, sc, ipm_iters, 1e-10, false) : ipm(c, B, false, sc, ipm_iters);
     int nk_dummy = 0;
-    if (status == MCQ_OK) status = active_set(c, B, false, ipm_iters >= 1 && c.last_step >= 0.9, sc, as_iters, kkt, nk_dummy);
+    if (status == MCQ_OK && small) {
+        // Two attempts.  The pairs at mu = 1e-10 identify the active set of all but the degenerate / extremely
+        // ill-conditioned instances (IQP passes on an already optimised raceline: dozens of bounds touched with multipliers
+        // down to 1e-7 of the gradient scale, |x_ipm - x*| ~ 5 mm at that mu); there block pivoting from a guess that is off
+        // by a few rows does not settle.  So the first active-set attempt is capped at a few rounds; if it runs out, the
+        // interior point resumes from its own pairs down to mu = 1e-13 -- where the magnitude test separates those rows --
+        // and the active-set phase starts again with the full budget.
+        gdouble* XS = VEC(c.w, nm, V_TL);
+        for (int i = tid; i < n; i += MCQ_NT) XS[i] = X[i];
+        const int cap1 = B.max_as_iter < 4 ? B.max_as_iter : 4;
+        status = active_set(c, B, false, ipm_iters >= 1 && c.last_step >= 0.9, cap1, sc, as_iters, kkt, nk_dummy);
+        if (status == MCQ_ITER_CAP && B.max_as_iter > cap1) {
+            for (int i = tid; i < n; i += MCQ_NT) X[i] = XS[i];
+            __syncthreads();
+            int it_more = 0, as_more = 0;
+            status = ipm_box(c, B, sc, it_more, 1e-13, true);
+            ipm_iters += it_more;
+            if (status == MCQ_OK) status = active_set(c, B, false, false, B.max_as_iter, sc, as_more, kkt, nk_dummy);
+            as_iters += as_more;
+        }
+    } else if (status == MCQ_OK) {
+        status = active_set(c, B, false, ipm_iters >= 1 && c.last_step >= 0.9, B.max_as_iter, sc, as_iters, kkt, nk_dummy);
+    }
 
     // kappa(alpha) = k_ref + E alpha
     for (int i = tid; i < n; i += MCQ_NT) X[i] = fmin(fmax(X[i], LO[i]), HI[i]);
@@ -2471,7 +2508,7 @@ __global__ void __launch_bounds__(MCQ_NT) mcq_solve_kernel(McqBatch B)
         gram_bordered(c.w.Et, nullptr, c.d, nm, nullptr, c.w.H, tid, MCQ_NT);     // restore H = E'E
         __syncthreads();
         if (status == MCQ_OK) {
-            status = active_set(c, B, true, false, sc, it2, kkt, nact_kappa);
+            status = active_set(c, B, true, false, B.max_as_iter, sc, it2, kkt, nact_kappa);
             as_iters += it2;
         }
         for (int i = tid; i < n; i += MCQ_NT) X[i] = fmin(fmax(X[i], LO[i]), HI[i]);

@@ -1,0 +1,40 @@
+#!/usr/bin/env python
+"""Fixture of a degenerate / very ill-conditioned instance: the QP of the THIRD IQP pass on a synthetic N = 2000 oval
+(BASELINE config 3 generator, track 3) -- the raceline of two oracle passes re-sampled, so dozens of box rows are touched
+with multipliers down to 1e-7 of the gradient scale.  Solved by the dense Goldfarb-Idnani oracle.  The interior-point
+pairs at mu = 1e-10 are 5 mm from the optimum on it and block pivoting from their active-set guess does not settle
+ -- this is the regression instance of the two-attempt driver.
+
+  python scripts/make_degenerate_fixture.py        # ~2 minutes on CPU, writes tests/golden/iqp_pass3_oval3.npz
+"""
+import os
+import sys
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+from global_racetrajectory_optimization_amd import synthetic                                                   # noqa: E402
+from global_racetrajectory_optimization_amd.trajectory_planning_helpers import calc_splines as cs, iqp_handler as iq   # noqa: E402
+from oracle import qp_ref, tph_ref                                                                               # noqa: E402
+
+
+def main():
+    qp_ref.build()
+    ref_b, nv_b, sc_b = synthetic.oval_batch(1, n=2000, first=3)
+    ref, nv, sc = ref_b[0].copy(), nv_b[0].copy(), sc_b[0]
+    for it in (1, 2):
+        A = cs.build_les_matrix(ref.shape[0], sc if sc is not None else np.ones(ref.shape[0]))
+        al, _ = tph_ref.opt_min_curv(ref, nv, A, 0.12, 3.4)
+        ref, nv = iq._relinearise(ref, nv, al * it / 3.0, 3.0)
+        sc = None
+    A = cs.build_les_matrix(ref.shape[0], np.ones(ref.shape[0]))
+    alpha, err = tph_ref.opt_min_curv(ref, nv, A, 0.12, 3.4)
+    out = os.path.join(ROOT, "tests", "golden", "iqp_pass3_oval3.npz")
+    np.savez_compressed(out, reftrack=ref, normvec=nv, alpha=alpha, curv_error_max=err, kappa_bound=0.12, w_veh=3.4)
+    print("wrote", out, "N =", ref.shape[0], "active rows:",
+          int(np.sum((np.abs(alpha + (ref[:, 3] - 1.7)) < 1e-9) | (np.abs(alpha - (ref[:, 2] - 1.7)) < 1e-9))))
+
+
+if __name__ == "__main__":
+    main()

@@ -231,3 +231,19 @@ def test_iqp_device_resident_matches_golden(gpu_engine, golden):
         assert np.max(np.abs(a - g["iqp_alpha"])) < ALPHA_TOL
         assert np.max(np.abs(ref_out - g["iqp_reftrack"])) < 1e-6
         assert np.max(np.abs(nv_out - g["iqp_normvec"])) < 1e-8
+
+
+def test_degenerate_iqp_pass_two_attempt_driver(gpu_engine):
+    """The QP of the third IQP pass on a synthetic N = 2000 oval (tests/golden/iqp_pass3_oval3.npz, made by
+    scripts/make_degenerate_fixture.py with the dense oracle): 42 touched bounds with multipliers down to 1e-7 of the
+    gradient scale.  The interior point at mu = 1e-10 is 5 mm from the optimum here and block pivoting from its guess does
+    not settle; the driver's second attempt (interior point resumed to mu = 1e-13) must return the oracle's vertex."""
+    from conftest import load_golden
+    g = load_golden("iqp_pass3_oval3")
+    al, curv, st, info = gpu_engine.solve_batch([dict(reftrack=g["reftrack"], normvec=g["normvec"], scaling=None,
+                                                      kappa_bound=float(g["kappa_bound"]), w_veh=float(g["w_veh"]))])
+    assert st[0] == 0
+    assert np.max(np.abs(al[0] - g["alpha"])) < ALPHA_TOL
+    assert abs(curv[0] - float(g["curv_error_max"])) < CURV_TOL
+    assert info[0]["kkt_res"] < 1e-9
+    assert info[0]["as_iters"] <= 12
