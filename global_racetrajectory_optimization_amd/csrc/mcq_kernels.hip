@@ -1425,6 +1425,104 @@ __device__ __forceinline__ void chunk_commit(double* chunk, double* rring, int q
 #define NLW (MCQ_NW - 1)                        /* loader waves */
 #define WGRP ((CH / 8 + NLW - 1) / NLW)         /* 8-row groups of a chunk handled by one loader wave */
 
+// The interior sweeps of solve() as seen by wave 0, each in a function of its own: compiled separately from the loader
+// waves' code they are free of its register state (16-byte staging registers of a whole chunk, W rows, accumulators -- 150
+// VGPRs that otherwise sit live across the tile chain and make the allocator serialise the LDS reads of a tile through two
+// address / data registers).  One LDS barrier per chunk, matched by the loaders' loop in solve().
+__device__ __noinline__ void sweep_fwd_wave0(const SolveCtx& c, gdouble* v)
+{
+    const int lane = threadIdx.x & 63;
+    const int l15 = lane & 15, l4 = lane >> 4;
+    const int ni = c.d.ni;
+    double* chunk = g_sm + SM_CHUNK;
+    double* rring = g_sm + SM_RHS;
+    double* vring = g_sm + SM_VR;
+    const int nch = (ni + CH - 1) / CH;
+    for (int cq = 0; cq < nch; ++cq) {
+            for (int J = cq * (CH / TB); J < (cq + 1) * (CH / TB); ++J) {
+                const int i = J * TB + l15;
+                const double* lr = LROW(i);
+                // lane (row l15, group l4) covers source tile K = J - 4 + l4: columns 16K + cc, band offset k = i - column.
+                // Entries beyond the band (k > 64, group 0 only) are read from the row's inverse-tile slots and masked;
+                // first-chunk columns < 0 hit masked zeros.  All LDS offsets are compile-time constants off two bases.
+                const int kb = TB * (4 - l4) + l15;          // k for cc = 0
+                // base at the LOWEST address of the 16 entries: ds_read offsets are unsigned immediates, so only then do all
+                // 16 reads hang off one address register and issue back to back
+                const double* lk = lr + kb - TB;             // lk[TB - 1 - cc] = L[i, i - (kb - cc)]
+                const double* vs = vring + (((J - 4 + l4) * TB) & (VRING - 1));      // 16 consecutive ring slots (no wrap inside)
+                double a0 = 0.0, a1 = 0.0;
+#pragma unroll
+                for (int cc = 0; cc < TB; cc += 2) {
+                    const double l0 = lk[TB - 1 - cc], l1 = lk[TB - 2 - cc];
+                    a0 += (kb - cc <= MCQ_BH_MAX ? l0 : 0.0) * vs[cc];
+                    a1 += (kb - cc - 1 <= MCQ_BH_MAX ? l1 : 0.0) * vs[cc + 1];
+                }
+                const double sv = RHSV(i) - row4_sum_low16(a0 + a1);       // valid in lanes 0..15: the ones the broadcasts read
+                double y0 = 0.0, y1 = 0.0;
+#pragma unroll
+                for (int cc = 0; cc < TB; cc += 2) {         // row l15 of the inverse tile
+                    y0 += lr[MCQ_BH_MAX + cc] * bcast_lane(sv, cc);
+                    y1 += lr[MCQ_BH_MAX + cc + 1] * bcast_lane(sv, cc + 1);
+                }
+                const double y = y0 + y1;
+                __builtin_amdgcn_wave_barrier();
+                if (l4 == 0) {
+                    vring[i & (VRING - 1)] = y;
+                    RHSV(i) = y;
+                    if (i < ni) v[i] = y;
+                }
+                __builtin_amdgcn_wave_barrier();
+            }
+        lds_barrier();
+    }
+}
+
+__device__ __noinline__ void sweep_bwd_wave0(const SolveCtx& c, gdouble* v)
+{
+    const int lane = threadIdx.x & 63;
+    const int l15 = lane & 15, l4 = lane >> 4;
+    const int ni = c.d.ni;
+    double* chunk = g_sm + SM_CHUNK;
+    double* rring = g_sm + SM_RHS;
+    double* vring = g_sm + SM_VR;
+    const int nch = (ni + CH - 1) / CH;
+    for (int cq = nch - 1; cq >= 0; --cq) {
+                for (int J = (cq + 1) * (CH / TB) - 1; J >= cq * (CH / TB); --J) {
+                const int j = J * TB + l15;               // unknown handled by this lane's row group
+                // lane (column l15, group l4) covers the rows of tile K = J + 1 + l4: i = 16K + rr, offset k = i - j.
+                // A tile never straddles a chunk: its 16 rows are 16 consecutive LDS rows, so every offset below is a
+                // compile-time constant off one base (entries with k > 64 land in inverse-tile slots and are masked).
+                const int i0 = (J + 1 + l4) * TB;
+                const int kb = TB * (l4 + 1) - l15;       // k for rr = 0
+                const double* lk = LROW(i0) + kb - 1;     // lk[rr (CLD + 1)] = L[i0 + rr, j]
+                const double* vs = vring + (i0 & (VRING - 1));
+                double a0 = 0.0, a1 = 0.0;
+#pragma unroll
+                for (int rr = 0; rr < TB; rr += 2) {
+                    const double l0 = lk[rr * (CLD + 1)], l1 = lk[(rr + 1) * (CLD + 1)];
+                    a0 += (kb + rr <= MCQ_BH_MAX ? l0 : 0.0) * vs[rr];
+                    a1 += (kb + rr + 1 <= MCQ_BH_MAX ? l1 : 0.0) * vs[rr + 1];
+                }
+                const double sv = RHSV(j) - row4_sum_low16(a0 + a1);   // valid in lanes 0..15: the ones the broadcasts read
+                const double* mi = LROW(J * TB) + MCQ_BH_MAX + l15;       // column l15 of the inverse tile, row stride CLD
+                double x0 = 0.0, x1 = 0.0;
+#pragma unroll
+                for (int rr = 0; rr < TB; rr += 2) {
+                    x0 += mi[rr * CLD] * bcast_lane(sv, rr);
+                    x1 += mi[(rr + 1) * CLD] * bcast_lane(sv, rr + 1);
+                }
+                const double x = x0 + x1;
+                __builtin_amdgcn_wave_barrier();
+                if (l4 == 0) {
+                    vring[j & (VRING - 1)] = x;
+                    if (j < ni) v[j] = x;
+                }
+                __builtin_amdgcn_wave_barrier();
+            }
+        lds_barrier();
+    }
+}
+
 __device__ __noinline__ void solve(const SolveCtx& c, gdouble* v)
 {
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
@@ -1483,48 +1581,16 @@ __device__ __noinline__ void solve(const SolveCtx& c, gdouble* v)
         chunk_fetch(L, v, ni, b, 2, 2, lt, goff, regs, rreg);
     }
     __syncthreads();
-    for (int cq = 0; cq < nch; ++cq) {
-        if (wv == 0) {
-            for (int J = cq * (CH / TB); J < (cq + 1) * (CH / TB); ++J) {
-                const int i = J * TB + l15;
-                const double* lr = LROW(i);
-                // lane (row l15, group l4) covers source tile K = J - 4 + l4: columns 16K + cc, band offset k = i - column.
-                // Entries beyond the band (k > 64, group 0 only) are read from the row's inverse-tile slots and masked;
-                // first-chunk columns < 0 hit masked zeros.  All LDS offsets are compile-time constants off two bases.
-                const int kb = TB * (4 - l4) + l15;          // k for cc = 0
-                const double* lk = lr + kb - 1;              // lk[-cc] = L[i, i - (kb - cc)]
-                const double* vs = vring + (((J - 4 + l4) * TB) & (VRING - 1));      // 16 consecutive ring slots (no wrap inside)
-                double a0 = 0.0, a1 = 0.0;
-#pragma unroll
-                for (int cc = 0; cc < TB; cc += 2) {
-                    const double l0 = lk[-cc], l1 = lk[-cc - 1];
-                    a0 += (kb - cc <= MCQ_BH_MAX ? l0 : 0.0) * vs[cc];
-                    a1 += (kb - cc - 1 <= MCQ_BH_MAX ? l1 : 0.0) * vs[cc + 1];
-                }
-                const double sv = RHSV(i) - row4_sum_low16(a0 + a1);       // valid in lanes 0..15: the ones the broadcasts read
-                double y0 = 0.0, y1 = 0.0;
-#pragma unroll
-                for (int cc = 0; cc < TB; cc += 2) {         // row l15 of the inverse tile
-                    y0 += lr[MCQ_BH_MAX + cc] * bcast_lane(sv, cc);
-                    y1 += lr[MCQ_BH_MAX + cc + 1] * bcast_lane(sv, cc + 1);
-                }
-                const double y = y0 + y1;
-                __builtin_amdgcn_wave_barrier();
-                if (l4 == 0) {
-                    vring[i & (VRING - 1)] = y;
-                    RHSV(i) = y;
-                    if (i < ni) v[i] = y;
-                }
-                __builtin_amdgcn_wave_barrier();
-            }
-        } else {
+    if (wv == 0) sweep_fwd_wave0(c, v);
+    else {
+        for (int cq = 0; cq < nch; ++cq) {
             chunk_commit(chunk, rring, cq + 2, cq + 2, lt, regs, rreg);
             chunk_fetch(L, v, ni, b, cq + 3, cq + 3, lt, goff, regs, rreg);
             // border right-hand side, fused: t -= W' y for the rows solved in the previous step (W rows in registers)
             if (cq >= 1) { TACC_ADD(cq - 1) }
             WFETCH(cq)
+            lds_barrier();
         }
-        lds_barrier();
     }
     if (wv > 0 && nch >= 1) { TACC_ADD(nch - 1) }
     // part[wave][jj]: partial sums of W'y (summed over the wave's rows: the 8 row lanes of every column pair, then LDS)
@@ -1609,47 +1675,15 @@ __device__ __noinline__ void solve(const SolveCtx& c, gdouble* v)
             WFETCH(cl - 1)
         }
         __syncthreads();
-        for (int cq = cl; cq >= 0; --cq) {
-            if (wv == 0) {
-                for (int J = (cq + 1) * (CH / TB) - 1; J >= cq * (CH / TB); --J) {
-                    const int j = J * TB + l15;               // unknown handled by this lane's row group
-                    // lane (column l15, group l4) covers the rows of tile K = J + 1 + l4: i = 16K + rr, offset k = i - j.
-                    // A tile never straddles a chunk: its 16 rows are 16 consecutive LDS rows, so every offset below is a
-                    // compile-time constant off one base (entries with k > 64 land in inverse-tile slots and are masked).
-                    const int i0 = (J + 1 + l4) * TB;
-                    const int kb = TB * (l4 + 1) - l15;       // k for rr = 0
-                    const double* lk = LROW(i0) + kb - 1;     // lk[rr (CLD + 1)] = L[i0 + rr, j]
-                    const double* vs = vring + (i0 & (VRING - 1));
-                    double a0 = 0.0, a1 = 0.0;
-#pragma unroll
-                    for (int rr = 0; rr < TB; rr += 2) {
-                        const double l0 = lk[rr * (CLD + 1)], l1 = lk[(rr + 1) * (CLD + 1)];
-                        a0 += (kb + rr <= MCQ_BH_MAX ? l0 : 0.0) * vs[rr];
-                        a1 += (kb + rr + 1 <= MCQ_BH_MAX ? l1 : 0.0) * vs[rr + 1];
-                    }
-                    const double sv = RHSV(j) - row4_sum_low16(a0 + a1);   // valid in lanes 0..15: the ones the broadcasts read
-                    const double* mi = LROW(J * TB) + MCQ_BH_MAX + l15;       // column l15 of the inverse tile, row stride CLD
-                    double x0 = 0.0, x1 = 0.0;
-#pragma unroll
-                    for (int rr = 0; rr < TB; rr += 2) {
-                        x0 += mi[rr * CLD] * bcast_lane(sv, rr);
-                        x1 += mi[(rr + 1) * CLD] * bcast_lane(sv, rr + 1);
-                    }
-                    const double x = x0 + x1;
-                    __builtin_amdgcn_wave_barrier();
-                    if (l4 == 0) {
-                        vring[j & (VRING - 1)] = x;
-                        if (j < ni) v[j] = x;
-                    }
-                    __builtin_amdgcn_wave_barrier();
-                }
-            } else {
+        if (wv == 0) sweep_bwd_wave0(c, v);
+        else {
+            for (int cq = cl; cq >= 0; --cq) {
                 chunk_commit(chunk, rring, cq - 1, cq - 2, lt, regs, rreg);
                 chunk_fetch(L, v, ni, b, cq - 2, cq - 3, lt, goff, regs, rreg);
                 RHS_SUB(cq - 1)
                 WFETCH(cq - 2)
+                lds_barrier();
             }
-            lds_barrier();
         }
     }
     __syncthreads();
