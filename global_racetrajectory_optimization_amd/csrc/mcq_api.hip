@@ -172,6 +172,7 @@ static int launch(mcq_handle* h, McqBatch& B, const mcq_opts& o)
     HIP_TRY(hipEventRecord(h->ev[0], h->stream));
     hipLaunchKernelGGL(mcq_assemble_kernel, dim3(B.batch), dim3(256), 0, h->stream, B);
     HIP_TRY(hipGetLastError());
+    if (B.prep_only) return 0;
     HIP_TRY(hipEventRecord(h->ev[1], h->stream));
     hipLaunchKernelGGL(mcq_gram_kernel, dim3(B.batch, 8), dim3(256), 0, h->stream, B);
     HIP_TRY(hipGetLastError());
@@ -190,7 +191,7 @@ extern "C" int mcq_solve_device(mcq_handle* h, int batch, int n, const double* r
                                 const double* scaling, double kappa_bound, double w_veh, const mcq_opts* opts,
                                 double* alpha_out, double* curv_err_out, int* status_out, mcq_info* info_out)
 {
-    if (!h || batch <= 0 || n <= 0 || !reftrack || !normvec || !alpha_out || !curv_err_out || !status_out) {
+    if (!h || batch <= 0 || n <= 0 || !reftrack || !alpha_out || !curv_err_out || !status_out) {
         g_err = "mcq_solve_device: bad argument";
         return MCQ_E_ARG;
     }
@@ -221,7 +222,7 @@ extern "C" int mcq_solve_device_ragged(mcq_handle* h, int batch, int nmax, const
                                        const mcq_opts* opts, double* alpha_out, double* curv_err_out, int* status_out,
                                        mcq_info* info_out)
 {
-    if (!h || batch <= 0 || nmax <= 0 || !n_list || !reftrack || !normvec || !alpha_out || !curv_err_out || !status_out) {
+    if (!h || batch <= 0 || nmax <= 0 || !n_list || !reftrack || !alpha_out || !curv_err_out || !status_out) {
         g_err = "mcq_solve_device_ragged: bad argument";
         return MCQ_E_ARG;
     }
@@ -244,6 +245,33 @@ extern "C" int mcq_solve_device_ragged(mcq_handle* h, int batch, int nmax, const
     B.info = info_out;
     B.kappa_bound = kappa_bound;
     B.w_veh = w_veh;
+    return launch(h, B, o);
+}
+
+extern "C" int mcq_prep_device(mcq_handle* h, int batch, int nmax, const int* n_list, const double* reftrack,
+                               double* normvec_out, double* scaling_out, int* status_out)
+{
+    if (!h || batch <= 0 || nmax <= 0 || !reftrack || !status_out || (!normvec_out && !scaling_out)) {
+        g_err = "mcq_prep_device: bad argument";
+        return MCQ_E_ARG;
+    }
+    HIP_TRY(hipSetDevice(h->device));
+    const mcq_opts o = resolve_opts(nullptr);
+    int rc = ensure_ws(h, (size_t)batch, (size_t)nmax);
+    if (rc) return rc;
+    McqBatch B;
+    memset(&B, 0, sizeof(B));
+    B.batch = batch;
+    B.n = nmax;
+    B.nmax = nmax;
+    B.n_list = n_list;
+    B.ref = reftrack;
+    B.status = status_out;
+    B.nv_out = normvec_out;
+    B.sc_out = scaling_out;
+    B.prep_only = 1;
+    B.w_veh = 0.0;              // the bounds computed along the way are not used: any widths are "feasible"
+    B.kappa_bound = 1.0;
     return launch(h, B, o);
 }
 
@@ -357,8 +385,8 @@ extern "C" int mcq_solve_batch(mcq_handle* h, const mcq_problem* probs, int batc
     size_t nmax = 3;
     bool any_sc = false;
     for (int b = 0; b < batch; ++b) {
-        if (!probs[b].reftrack || !probs[b].normvec || probs[b].n < 0) {
-            g_err = "mcq_solve_batch: problem with NULL buffers";
+        if (!probs[b].reftrack || probs[b].n < 0 || (probs[b].normvec == nullptr) != (probs[0].normvec == nullptr)) {
+            g_err = "mcq_solve_batch: problem with NULL buffers (normvec must be given for all problems or for none)";
             return MCQ_E_ARG;
         }
         if ((size_t)probs[b].n > nmax) nmax = (size_t)probs[b].n;
@@ -377,7 +405,7 @@ extern "C" int mcq_solve_batch(mcq_handle* h, const mcq_problem* probs, int batc
     for (int b = 0; b < batch; ++b) {
         const size_t n = (size_t)probs[b].n;
         memcpy(&ref[(size_t)b * nmax * 4], probs[b].reftrack, n * 4 * sizeof(double));
-        memcpy(&nv[(size_t)b * nmax * 2], probs[b].normvec, n * 2 * sizeof(double));
+        if (probs[b].normvec) memcpy(&nv[(size_t)b * nmax * 2], probs[b].normvec, n * 2 * sizeof(double));
         if (any_sc && probs[b].scaling) memcpy(&sc[(size_t)b * nmax], probs[b].scaling, n * sizeof(double));
         kb[b] = probs[b].kappa_bound;
         wv[b] = probs[b].w_veh;
@@ -398,7 +426,7 @@ extern "C" int mcq_solve_batch(mcq_handle* h, const mcq_problem* probs, int batc
     B.nmax = (int)nmax;
     B.n_list = h->d_n;
     B.ref = h->d_ref;
-    B.nv = h->d_nv;
+    B.nv = probs[0].normvec ? h->d_nv : nullptr;      // none given: derived on the device (scalings too)
     B.sc = any_sc ? h->d_sc : nullptr;
     B.alpha = h->d_alpha;
     B.curv_err = h->d_curv;

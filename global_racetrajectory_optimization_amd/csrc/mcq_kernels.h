@@ -43,7 +43,7 @@
 #define MCQ_LLD 144                /* L rows: 64 band entries | 16 inverse-diagonal-tile entries | 64 border entries */
 #define MCQ_LBI 64                 /* offset of the inverse diagonal tile row inside an L row */
 #define MCQ_LBW 80                 /* offset of the border part W inside an L row */
-#define MCQ_NVEC 27
+#define MCQ_NVEC 30
 #define MCQ_KMAX 24                /* active curvature rows the Schur-complement path of the active-set phase holds */
 #define MCQ_PIVOT_WARMUP 64
 
@@ -99,7 +99,7 @@ struct McqWork {
 
 enum {
     V_XP = 0, V_YP, V_CP, V_KREF, V_XPP, V_YPP, V_F, V_LO, V_HI, V_X, V_G, V_ZL, V_ZU, V_SIG, V_RHS, V_DXA, V_T0, V_T1,
-    V_T2, V_T3, V_TL, V_TU, V_YL, V_YU, V_SK, V_EDA, V_Q
+    V_T2, V_T3, V_TL, V_TU, V_YL, V_YU, V_SK, V_EDA, V_Q, V_NX, V_NY, V_SC    /* unit normals and spline scalings as used (given or derived) */
 };
 
 struct McqBatch {
@@ -108,8 +108,12 @@ struct McqBatch {
     int nmax;
     const int* n_list;      // per-problem n (device) or nullptr
     const double* ref;      // [batch][nmax][4]
-    const double* nv;       // [batch][nmax][2]
-    const double* sc;       // [batch][nmax] or nullptr
+    const double* nv;       // [batch][nmax][2], or nullptr: normals AND scalings are derived from the closed distance-scaled
+                            // spline through the reference line (what prep_track does with calc_splines), `sc` is ignored
+    const double* sc;       // [batch][nmax] or nullptr (unit scalings)
+    double* nv_out;         // optional outputs of the assembly: normals [batch][nmax][2], scalings [batch][nmax]
+    double* sc_out;
+    int prep_only;          // assembly kernel stops after the spline quantities (mcq_prep_device)
     double* Eb; double* Et; double* Db; double* H; double* L; double* vec; double* Z;
     signed char* state;
     double* alpha;          // [batch][nmax]

@@ -131,7 +131,7 @@ __device__ McqWork mcq_work(const McqBatch& B, int pb, int& n, double& kb, doubl
     kb = B.kappa_bound_list ? B.kappa_bound_list[pb] : B.kappa_bound;
     wv = B.w_veh_list ? B.w_veh_list[pb] : B.w_veh;
     w.ref = (const gdouble*)(B.ref + (size_t)pb * nm * 4);
-    w.nv = (const gdouble*)(B.nv + (size_t)pb * nm * 2);
+    w.nv = B.nv ? (const gdouble*)(B.nv + (size_t)pb * nm * 2) : nullptr;
     w.sc = B.sc ? (const gdouble*)(B.sc + (size_t)pb * nm) : nullptr;
     w.Eb = (gdouble*)(B.Eb + (size_t)pb * nm * MCQ_ELD);
     w.Et = (gdouble*)(B.Et + (size_t)pb * nm * MCQ_ELD);
@@ -141,8 +141,8 @@ __device__ McqWork mcq_work(const McqBatch& B, int pb, int& n, double& kb, doubl
     w.vec = (gdouble*)(B.vec + (size_t)pb * nm * MCQ_NVEC);
     w.state = (gschar*)(B.state + (size_t)pb * nm);
     w.Z = (gdouble*)(B.Z + (size_t)pb * nm * MCQ_KMAX);
-    w.alpha = (gdouble*)(B.alpha + (size_t)pb * nm);
-    w.curv_err = (gdouble*)(B.curv_err + pb);
+    w.alpha = B.alpha ? (gdouble*)(B.alpha + (size_t)pb * nm) : nullptr;
+    w.curv_err = B.curv_err ? (gdouble*)(B.curv_err + pb) : nullptr;
     w.status = (gint*)(B.status + pb);
     w.info = B.info ? (ginfo*)(B.info + pb) : nullptr;
     return w;
@@ -243,10 +243,23 @@ __global__ void __launch_bounds__(MCQ_NT) mcq_assemble_kernel(McqBatch B)
     // ---- phase 0: validate, box bounds  [-(w_l - w_veh/2), w_r - w_veh/2]   -----------------
     double flag_bad = 0.0, flag_inf = 0.0;
     if (n < 3) flag_bad = 1.0;
+    gdouble* NX = VEC(w, nm, V_NX);
+    gdouble* NY = VEC(w, nm, V_NY);
+    const bool derive = w.nv == nullptr;      // normals and scalings from the distance-scaled spline through the line itself
     for (int i = tid; i < n; i += MCQ_NT) {
         const double x = w.ref[4 * i], y = w.ref[4 * i + 1], wr = w.ref[4 * i + 2], wl = w.ref[4 * i + 3];
-        const double nx = w.nv[2 * i], ny = w.nv[2 * i + 1];
-        const double s = w.sc ? w.sc[i] : 1.0;
+        const double nx = derive ? 0.0 : w.nv[2 * i], ny = derive ? 1.0 : w.nv[2 * i + 1];
+        double s = w.sc ? w.sc[i] : 1.0;
+        if (derive) {
+            // s_i = l_i / l_{i+1},  l_i = |p_{i+1} - p_i|  (tph.calc_splines, use_dist_scaling=True, closed)
+            const int i1 = i + 1 >= n ? i + 1 - n : i + 1, i2 = i1 + 1 >= n ? i1 + 1 - n : i1 + 1;
+            const double l0 = hypot(w.ref[4 * i1] - x, w.ref[4 * i1 + 1] - y);
+            const double l1 = hypot(w.ref[4 * i2] - w.ref[4 * i1], w.ref[4 * i2 + 1] - w.ref[4 * i1 + 1]);
+            s = l0 / l1;
+        } else {
+            NX[i] = nx;
+            NY[i] = ny;
+        }
         if (!(isfinite(x) && isfinite(y) && isfinite(wr) && isfinite(wl) && isfinite(nx) && isfinite(ny) && isfinite(s)
               && s > 0.0))
             flag_bad = 1.0;
@@ -255,13 +268,14 @@ __global__ void __launch_bounds__(MCQ_NT) mcq_assemble_kernel(McqBatch B)
         LO[i] = lo;
         HI[i] = hi;
         S[i] = s;
+        VEC(w, nm, V_SC)[i] = s;          // S is a scratch slot; the solver's curvature-error post-check needs s again
     }
     flag_bad = block_reduce_(flag_bad, 2, red);
     flag_inf = block_reduce_(flag_inf, 2, red);
     const int st = flag_bad > 0.0 ? MCQ_BAD_INPUT : (flag_inf > 0.0 ? MCQ_INFEASIBLE : MCQ_OK);
     if (tid == 0) {
         *w.status = st;
-        *w.curv_err = 0.0;
+        if (w.curv_err) *w.curv_err = 0.0;
         if (w.info) {
             mcq_info z;
             z.ipm_iters = z.as_iters = z.n_active_box = z.n_active_kappa = 0;
@@ -272,7 +286,7 @@ __global__ void __launch_bounds__(MCQ_NT) mcq_assemble_kernel(McqBatch B)
         }
     }
     if (st != MCQ_OK) {
-        for (int i = tid; i < n; i += MCQ_NT) w.alpha[i] = 0.0;
+        if (w.alpha) for (int i = tid; i < n; i += MCQ_NT) w.alpha[i] = 0.0;
         return;
     }
     __syncthreads();
@@ -393,8 +407,21 @@ __global__ void __launch_bounds__(MCQ_NT) mcq_assemble_kernel(McqBatch B)
         YP[i] = yp;
         CP[i] = cp;
         KRF[i] = cp * (xp * YPP[i] - yp * XPP[i]);
+        if (derive) {
+            // unit normal to the right of the spline's tangent (b-coefficients):  (y', -x') / |.|   (tph.calc_splines)
+            const double nrm = sqrt(xp * xp + yp * yp);
+            NX[i] = yp / nrm;
+            NY[i] = -xp / nrm;
+        }
+        if (B.nv_out) {
+            gdouble* no = (gdouble*)(B.nv_out + ((size_t)blockIdx.x * nm + i) * 2);
+            no[0] = NX[i];
+            no[1] = NY[i];
+        }
+        if (B.sc_out) ((gdouble*)(B.sc_out + (size_t)blockIdx.x * nm))[i] = S[i];
     }
     __syncthreads();
+    if (B.prep_only) return;
 
     // ---- phase 3b: D band (x'' = D x) and E_kappa band, diagonal-major -------------------------------------------------
     const int ew = d.ew;
@@ -409,7 +436,7 @@ __global__ void __launch_bounds__(MCQ_NT) mcq_assemble_kernel(McqBatch B)
             {
                 const double dv = 6.0 * (gu1 - (1.0 + S[im]) * g0 + S[imm] * gd1);
                 w.Db[(size_t)MCQ_BE_MAX * nm + i] = dv;
-                w.Eb[(size_t)MCQ_BE_MAX * nm + i] = dv * (cpx * w.nv[2 * i + 1] - cpy * w.nv[2 * i]);
+                w.Eb[(size_t)MCQ_BE_MAX * nm + i] = dv * (cpx * NY[i] - cpy * NX[i]);
             }
             // upwards: prev = g[o-1], cur = g[o], j = i + o
             {
@@ -420,7 +447,7 @@ __global__ void __launch_bounds__(MCQ_NT) mcq_assemble_kernel(McqBatch B)
                     const double nxt = cur * RU[j];
                     const double dv = 6.0 * (nxt - (1.0 + S[jm1]) * cur + S[jm2] * prev);
                     w.Db[(size_t)(MCQ_BE_MAX + o) * nm + i] = dv;
-                    w.Eb[(size_t)(MCQ_BE_MAX + o) * nm + i] = dv * (cpx * w.nv[2 * j + 1] - cpy * w.nv[2 * j]);
+                    w.Eb[(size_t)(MCQ_BE_MAX + o) * nm + i] = dv * (cpx * NY[j] - cpy * NX[j]);
                     prev = cur;
                     cur = nxt;
                     jm2 = jm1;
@@ -437,7 +464,7 @@ __global__ void __launch_bounds__(MCQ_NT) mcq_assemble_kernel(McqBatch B)
                     const double prv = cur * RD[j];            // g[o-1]
                     const double dv = 6.0 * (nxt - (1.0 + S[jm1]) * cur + S[jm2] * prv);
                     w.Db[(size_t)(MCQ_BE_MAX + o) * nm + i] = dv;
-                    w.Eb[(size_t)(MCQ_BE_MAX + o) * nm + i] = dv * (cpx * w.nv[2 * j + 1] - cpy * w.nv[2 * j]);
+                    w.Eb[(size_t)(MCQ_BE_MAX + o) * nm + i] = dv * (cpx * NY[j] - cpy * NX[j]);
                     nxt = cur;
                     cur = prv;
                     j = jm1;
@@ -454,7 +481,7 @@ __global__ void __launch_bounds__(MCQ_NT) mcq_assemble_kernel(McqBatch B)
                      gm = G[(size_t)(MCQ_GW + o - 1) * nm + i];
         const double dv = 6.0 * (g1 - (1.0 + S[cyc(j - 1, n)]) * g0 + S[cyc(j - 2, n)] * gm);
         w.Db[(size_t)oo * nm + i] = dv;
-        w.Eb[(size_t)oo * nm + i] = dv * CP[i] * (XP[i] * w.nv[2 * j + 1] - YP[i] * w.nv[2 * j]);
+        w.Eb[(size_t)oo * nm + i] = dv * CP[i] * (XP[i] * NY[j] - YP[i] * NX[j]);
     }
     __syncthreads();
     // ---- phase 3c: transpose band  Et[(bR+o) * nm + j] = E[(j+o) mod n][j],  -bR <= o <= bE --------------------------
@@ -2567,7 +2594,7 @@ __global__ void __launch_bounds__(MCQ_NT) mcq_solve_kernel(McqBatch B)
         const gdouble* YP = VEC(c.w, nm, V_YP);
         const gdouble* XPP = VEC(c.w, nm, V_XPP);
         const gdouble* YPP = VEC(c.w, nm, V_YPP);
-        for (int i = tid; i < n; i += MCQ_NT) { T1[i] = c.w.nv[2 * i] * X[i]; T2[i] = c.w.nv[2 * i + 1] * X[i]; }
+        for (int i = tid; i < n; i += MCQ_NT) { T1[i] = VEC(c.w, nm, V_NX)[i] * X[i]; T2[i] = VEC(c.w, nm, V_NY)[i] * X[i]; }
         __syncthreads();
         band_matvec(c.w.Db, c.d.bE, c.d.bR, n, nm, T1, nullptr, 0.0, T0);   // D (n_x alpha)
         band_matvec(c.w.Db, c.d.bE, c.d.bR, n, nm, T2, nullptr, 0.0, T3);   // D (n_y alpha)
@@ -2575,7 +2602,7 @@ __global__ void __launch_bounds__(MCQ_NT) mcq_solve_kernel(McqBatch B)
         double em = 0.0;
         for (int i = tid; i < n; i += MCQ_NT) {
             const int ip = cyc(i + 1, n);
-            const double s = c.w.sc ? c.w.sc[i] : 1.0;
+            const double s = VEC(c.w, nm, V_SC)[i];
             const double s2 = s * s;
             const double xpt = XP[i] + (T1[ip] - T1[i]) - (T0[i] + 0.5 * s2 * T0[ip]) / 3.0;
             const double ypt = YP[i] + (T2[ip] - T2[i]) - (T3[i] + 0.5 * s2 * T3[ip]) / 3.0;

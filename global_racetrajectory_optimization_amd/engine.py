@@ -41,7 +41,7 @@ class McqInfo(ctypes.Structure):
 
 
 EXPORTED_SYMBOLS = ("mcq_create", "mcq_destroy", "mcq_last_error", "mcq_default_opts", "mcq_solve_batch",
-                    "mcq_solve_device", "mcq_solve_device_ragged", "mcq_relinearise_device", "mcq_device_alloc",
+                    "mcq_solve_device", "mcq_solve_device_ragged", "mcq_prep_device", "mcq_relinearise_device", "mcq_device_alloc",
                     "mcq_device_free", "mcq_copy_to_device", "mcq_copy_to_host", "mcq_sync", "mcq_stream",
                     "mcq_last_timing", "mcq_workspace_bytes")
 
@@ -75,6 +75,8 @@ def load_library(path=None):
     lib.mcq_solve_device_ragged.argtypes = [vp, ctypes.c_int, ctypes.c_int, vp, vp, vp, vp, ctypes.c_double,
                                             ctypes.c_double, ctypes.POINTER(McqOpts), vp, vp, vp, vp]
     lib.mcq_solve_device_ragged.restype = ctypes.c_int
+    lib.mcq_prep_device.argtypes = [vp, ctypes.c_int, ctypes.c_int, vp, vp, vp, vp, vp]
+    lib.mcq_prep_device.restype = ctypes.c_int
     lib.mcq_relinearise_device.argtypes = [vp, ctypes.c_int, ctypes.c_int, vp, vp, vp, vp, vp, ctypes.c_double,
                                            ctypes.c_double, vp, vp, vp, vp]
     lib.mcq_relinearise_device.restype = ctypes.c_int
@@ -143,9 +145,9 @@ class Engine:
         total = 0
         for k, p in enumerate(problems):
             ref = np.ascontiguousarray(p["reftrack"], dtype=np.float64)
-            nv = np.ascontiguousarray(p["normvec"], dtype=np.float64)
+            nv = None if p.get("normvec") is None else np.ascontiguousarray(p["normvec"], dtype=np.float64)
             n = ref.shape[0]
-            if ref.ndim != 2 or ref.shape[1] != 4 or nv.shape != (n, 2):
+            if ref.ndim != 2 or ref.shape[1] != 4 or (nv is not None and nv.shape != (n, 2)):
                 raise ValueError("reftrack must be [n,4] and normvec [n,2]")
             sc = p.get("scaling")
             if sc is not None:
@@ -155,7 +157,7 @@ class Engine:
             keep.append((ref, nv, sc))
             arr[k].n = n
             arr[k].reftrack = _as_dp(ref)
-            arr[k].normvec = _as_dp(nv)
+            arr[k].normvec = _as_dp(nv) if nv is not None else None
             arr[k].scaling = _as_dp(sc) if sc is not None else None
             arr[k].kappa_bound = float(p["kappa_bound"])
             arr[k].w_veh = float(p["w_veh"])
@@ -195,6 +197,31 @@ class Engine:
                                               d_scaling or None, float(kappa_bound), float(w_veh), ctypes.byref(opts),
                                               d_alpha, d_curv, d_status, d_info or None)
         self._check(rc, "mcq_solve_device_ragged")
+
+    def prep_batch(self, reftracks):
+        """Unit normals and spline scalings of the closed distance-scaled splines through a list of reference lines
+        ([n,>=2] arrays), computed on the device (mcq_prep_device).  Returns (list of [n,2], list of [n])."""
+        bsz = len(reftracks)
+        ns = np.array([r.shape[0] for r in reftracks], dtype=np.int32)
+        nmax = int(ns.max())
+        ref = np.zeros((bsz, nmax, 4))
+        for k, r in enumerate(reftracks):
+            ref[k, :ns[k], :min(4, r.shape[1])] = np.asarray(r, dtype=np.float64)[:, :4]
+        d_ref, d_n = self.alloc(ref.nbytes), self.alloc(ns.nbytes)
+        d_nv, d_sc, d_st = self.alloc(bsz * nmax * 16), self.alloc(bsz * nmax * 8), self.alloc(bsz * 4)
+        try:
+            self.upload(d_ref, ref)
+            self.upload(d_n, ns)
+            self._check(self.lib.mcq_prep_device(self.h, bsz, nmax, d_n, d_ref, d_nv, d_sc, d_st), "mcq_prep_device")
+            st = self.download(d_st, (bsz,), np.int32)
+            nv = self.download(d_nv, (bsz, nmax, 2), np.float64)
+            sc = self.download(d_sc, (bsz, nmax), np.float64)
+        finally:
+            for p in (d_ref, d_n, d_nv, d_sc, d_st):
+                self.free(p)
+        if np.any(st != 0):
+            raise EngineError("mcq_prep_device: bad input in problem(s) %s" % np.nonzero(st)[0].tolist())
+        return [nv[k, :ns[k]].copy() for k in range(bsz)], [sc[k, :ns[k]].copy() for k in range(bsz)]
 
     def relinearise_device(self, batch, nmax, d_n_in, d_ref_in, d_nv_in, d_alpha, d_live, alpha_scale, stepsize,
                            d_ref_out, d_nv_out, d_n_out, d_status):

@@ -61,7 +61,7 @@ typedef struct mcq_handle mcq_handle; /* opaque; owns device buffers + one HIP s
 typedef struct {
     int n;                  /* waypoints */
     const double* reftrack; /* [n][4] */
-    const double* normvec;  /* [n][2] */
+    const double* normvec;  /* [n][2], or NULL for every problem of a batch: derived on the device (with the scalings) */
     const double* scaling;  /* [n] or NULL */
     double kappa_bound;     /* veh_params.curvlim  [REF params/racecar.ini:49] */
     double w_veh;           /* optim_opts.width_opt [REF params/racecar.ini:72] */
@@ -114,6 +114,15 @@ int mcq_solve_device_ragged(mcq_handle* h, int batch, int nmax, const int* n_lis
                             const double* normvec, const double* scaling, double kappa_bound, double w_veh,
                             const mcq_opts* opts, double* alpha_out, double* curv_err_out, int* status_out,
                             mcq_info* info_out);
+
+/* The front half of prep_track on the device [REF helper_funcs_glob/src/prep_track.py:48-51]: unit normals (pointing
+ * right) and spline scalings s_i = l_i / l_{i+1} of the closed distance-scaled cubic spline through the reference line --
+ * what tph.calc_splines(path) returns as normvec_normalized and encodes in its matrix.  reftrack [batch][nmax][4],
+ * n_list [batch] or NULL (all nmax); outputs normvec_out [batch][nmax][2] and / or scaling_out [batch][nmax] (either may
+ * be NULL); status_out [batch].  The solve entry points derive the same quantities themselves when they are called with
+ * normvec == NULL (then `scaling` is ignored).  Asynchronous on the handle's stream. */
+int mcq_prep_device(mcq_handle* h, int batch, int nmax, const int* n_list, const double* reftrack, double* normvec_out,
+                    double* scaling_out, int* status_out);
 
 /* Device-side glue of tph.iqp_handler between two passes (what upstream does on the host with two dense 4N x 4N spline
  * solves per pass): raceline = refline + alpha_scale * alpha * normal; closed spline through it (unit scalings);

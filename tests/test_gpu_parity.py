@@ -247,3 +247,21 @@ def test_degenerate_iqp_pass_two_attempt_driver(gpu_engine):
     assert abs(curv[0] - float(g["curv_error_max"])) < CURV_TOL
     assert info[0]["kkt_res"] < 1e-9
     assert info[0]["as_iters"] <= 12
+
+
+def test_prep_on_device_and_solve_without_normals(gpu_engine, golden):
+    """Row f-2: normals / scalings derived on the device against tph.calc_splines (as prep_track calls it), and the
+    reference tracks solved from [x, y, w_right, w_left] rows alone against the golden alpha."""
+    names = list(golden)
+    nvs, scs = gpu_engine.prep_batch([golden[k]["reftrack"] for k in names])
+    for k, name in enumerate(names):
+        g = golden[name]
+        assert np.max(np.abs(nvs[k] - g["normvec"])) < 1e-10, name
+        assert np.max(np.abs(scs[k] - g["scaling"])) < 1e-12, name
+    al, curv, st, _ = gpu_engine.solve_batch([dict(reftrack=golden[k]["reftrack"], normvec=None, scaling=None,
+                                                   kappa_bound=float(golden[k]["kappa_bound"]), w_veh=float(golden[k]["w_veh"]))
+                                              for k in names])
+    for k, name in enumerate(names):
+        assert st[k] == 0
+        assert np.max(np.abs(al[k] - golden[name]["alpha"])) < ALPHA_TOL, name
+        assert abs(curv[k] - float(golden[name]["curv_error_max"])) < CURV_TOL, name
