@@ -90,7 +90,8 @@ def test_curvature_rows_active_and_infeasible(emu):
     with pytest.raises(ValueError, match="inconsistent"):
         tph_ref.opt_min_curv(ref, nv, A, 1e-4, 2.0)
     al, curv, st, inf = emu.solve_batch([dict(reftrack=ref, normvec=nv, scaling=sc, kappa_bound=kb, w_veh=2.0),
-                                         dict(reftrack=ref, normvec=nv, scaling=sc, kappa_bound=1e-4, w_veh=2.0)])
+                                         dict(reftrack=ref, normvec=nv, scaling=sc, kappa_bound=1e-4, w_veh=2.0)],
+                                        max_ipm_iter=30)       # the infeasible one runs into the cap: keep the interpreter's bill down
     assert st[0] == 0 and st[1] == engine.STATUS_KAPPA_INFEASIBLE
     assert inf[0]["n_active_kappa"] == n_act_kappa
     assert np.max(np.abs(al[0] - a_ref)) < 1e-8
