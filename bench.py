@@ -30,7 +30,7 @@ HBM_PEAK_GBS = 8000.0        # MI355X HBM3E spec peak, /opt/skills/guides/MI355X
 KAPPA_BOUND, W_VEH = 0.12, 3.4
 
 
-def algorithmic_bytes(n, info, band_e=32, refine_steps=2):
+def algorithmic_bytes(n, info, band_e=32, refine_steps=1):
     """Algorithmic HBM bytes of mcq_solve_kernel for one launch ('banded-exact' mode).
 
     Row sizes as stored (csrc/mcq_kernels.h): H row 130 doubles (65 band | pad | 64 border), L row 144 doubles
@@ -40,7 +40,9 @@ def algorithmic_bytes(n, info, band_e=32, refine_steps=2):
       gradient      : E band + E' band                                 2 * n * 65 * 8 B
     IPM iteration = 1 factorisation + 2 solves (the gradient is carried through the reduced system; one exact gradient
     confirms convergence); active-set iteration = 1 factorisation + 1 solve + 2 gradients; refinement round = 1 solve +
-    1 gradient; + 1 initial gradient + 3 band products in the epilogue.
+    1 gradient, ONE round counted (the second of the two allowed runs only when the first correction exceeds 1e-8 m and
+    is not reported per problem: counting it never would overstate nothing); + 1 initial gradient + 3 band products in
+    the epilogue.
     Iteration counts are the ones the solver reports (mcq_info).
     """
     fac = n * (130.0 + 144.0) * 8.0

@@ -2442,11 +2442,16 @@ __device__ __noinline__ int active_set(SolveCtx& c, const McqBatch& B, bool with
         const int nvi = (int)nv;
         if (nvi == 0) {
             // fp64 residual refinement through E on the final working set (same factor); box-only working sets
+            // A round whose correction is already below 1e-8 m is the last one: the next would move alpha by (cond * eps)
+            // times that, i.e. far below the 1e-9 m at which the dense oracle itself is known.
             for (int r = 0; r < (nk == 0 ? B.refine_steps : 0); ++r) {
                 for (int i = tid; i < n; i += MCQ_NT) RHS[i] = ST[i] == 0 ? -G[i] : 0.0;
                 timed_solve(c, RHS);
-                for (int i = tid; i < n; i += MCQ_NT) if (ST[i] == 0) X[i] += RHS[i];
+                double dm = 0.0;
+                for (int i = tid; i < n; i += MCQ_NT) if (ST[i] == 0) { X[i] += RHS[i]; dm = fmax(dm, fabs(RHS[i])); }
+                dm = block_reduce_(dm, 2, red);
                 gradient(c, X, nullptr, T0, G);
+                if (!(dm > 1e-8)) break;
             }
             double k2 = 0.0;
             for (int i = tid; i < n; i += MCQ_NT) if (ST[i] == 0) k2 = fmax(k2, fabs(G[i]));
