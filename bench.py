@@ -25,12 +25,13 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
 INFO_DTYPE = np.dtype([("ipm_iters", "<i4"), ("as_iters", "<i4"), ("n_active_box", "<i4"), ("n_active_kappa", "<i4"),
-                       ("kappa_max", "<f8"), ("kkt_res", "<f8"), ("ticks", "<i8", (8,))])
+                       ("kappa_max", "<f8"), ("kkt_res", "<f8"), ("ticks", "<i8", (8,)),
+                       ("refine_rounds", "<i4"), ("second_attempt", "<i4")])
 HBM_PEAK_GBS = 8000.0        # MI355X HBM3E spec peak, /opt/skills/guides/MI355X_MICROARCH.md
 KAPPA_BOUND, W_VEH = 0.12, 3.4
 
 
-def algorithmic_bytes(n, info, band_e=32, refine_steps=1):
+def algorithmic_bytes(n, info, band_e=32):
     """Algorithmic HBM bytes of mcq_solve_kernel for one launch ('banded-exact' mode).
 
     Row sizes as stored (csrc/mcq_kernels.h): H row 130 doubles (65 band | pad | 64 border), L row 144 doubles
@@ -40,9 +41,7 @@ def algorithmic_bytes(n, info, band_e=32, refine_steps=1):
       gradient      : E band + E' band                                 2 * n * 65 * 8 B
     IPM iteration = 1 factorisation + 2 solves (the gradient is carried through the reduced system; one exact gradient
     confirms convergence); active-set iteration = 1 factorisation + 1 solve + 2 gradients; refinement round = 1 solve +
-    1 gradient, ONE round counted (the second of the two allowed runs only when the first correction exceeds 1e-8 m and
-    is not reported per problem: counting it never would overstate nothing); + 1 initial gradient + 3 band products in
-    the epilogue.
+    1 gradient (the rounds actually run: mcq_info.refine_rounds); + 1 initial gradient + 3 band products in the epilogue.
     Iteration counts are the ones the solver reports (mcq_info).
     """
     fac = n * (130.0 + 144.0) * 8.0
@@ -50,7 +49,8 @@ def algorithmic_bytes(n, info, band_e=32, refine_steps=1):
     grad = 2.0 * n * (2 * band_e + 1) * 8.0
     ipm = info["ipm_iters"].astype(np.float64)
     act = info["as_iters"].astype(np.float64)
-    per = ipm * (fac + 2 * sol) + grad + act * (fac + sol + 2 * grad) + refine_steps * (sol + grad) + grad + 1.5 * grad
+    ref = info["refine_rounds"].astype(np.float64)
+    per = ipm * (fac + 2 * sol) + grad + act * (fac + sol + 2 * grad) + ref * (sol + grad) + grad + 1.5 * grad
     return float(per.sum())
 
 
@@ -181,6 +181,8 @@ def main():
                        "failed_problems": n_bad,
                        "mean_ipm_iters": float(info["ipm_iters"].mean()), "mean_as_iters": float(info["as_iters"].mean()),
                        "mean_active_box_rows": float(info["n_active_box"].mean()),
+                       "mean_refine_rounds": float(info["refine_rounds"].mean()),
+                       "second_attempts": int(info["second_attempt"].sum()),
                        "kernel_ms": {k: float(np.mean([m[k] for m in solve_ms])) for k in ("assemble", "gram", "solve", "total")},
                        "workspace_GB": eng.workspace_bytes() / 1e9,
                        "solver_phase_ms_per_problem": {k: float(info["ticks"][:, j].mean()) / 1e5 for j, k in

@@ -281,6 +281,7 @@ __global__ void __launch_bounds__(MCQ_NT) mcq_assemble_kernel(McqBatch B)
             z.ipm_iters = z.as_iters = z.n_active_box = z.n_active_kappa = 0;
             z.kappa_max = 0.0;
             z.kkt_res = 0.0;
+            z.refine_rounds = z.second_attempt = 0;
             for (int q = 0; q < 8; ++q) z.ticks[q] = 0;
             *(mcq_info*)w.info = z;
         }
@@ -697,6 +698,7 @@ struct SolveCtx {
     McqWork w;
     int nm;
     mutable long long tk[8];   // phase timers (wall_clock64 ticks), meaningful on thread 0
+    mutable int refine_rounds, second_attempt;   // diagnostics for mcq_info
     mutable double last_step;  // length of the last interior-point step (the Tapia indicators are only trusted after a near-full one)
 };
 #define TICK() ((long long)wall_clock64())
@@ -2451,6 +2453,7 @@ __device__ __noinline__ int active_set(SolveCtx& c, const McqBatch& B, bool with
                 for (int i = tid; i < n; i += MCQ_NT) if (ST[i] == 0) { X[i] += RHS[i]; dm = fmax(dm, fabs(RHS[i])); }
                 dm = block_reduce_(dm, 2, red);
                 gradient(c, X, nullptr, T0, G);
+                c.refine_rounds = r + 1;
                 if (!(dm > 1e-8)) break;
             }
             double k2 = 0.0;
@@ -2488,6 +2491,7 @@ __global__ void __launch_bounds__(MCQ_NT) mcq_solve_kernel(McqBatch B)
     c.d = mcq_dims(n, B.band_e);
     for (int q = 0; q < 8; ++q) c.tk[q] = 0;
     c.last_step = 0.0;
+    c.refine_rounds = c.second_attempt = 0;
     const long long t_kernel0 = TICK();
     double* red = g_sm + SM_RED;
     const int nm = B.nmax;
@@ -2544,6 +2548,7 @@ __global__ void __launch_bounds__(MCQ_NT) mcq_solve_kernel(McqBatch B)
         const int cap1 = B.max_as_iter < 4 ? B.max_as_iter : 4;
         status = active_set(c, B, false, ipm_iters >= 1 && c.last_step >= 0.9, cap1, sc, as_iters, kkt, nk_dummy);
         if (status == MCQ_ITER_CAP && B.max_as_iter > cap1) {
+            c.second_attempt = 1;
             for (int i = tid; i < n; i += MCQ_NT) X[i] = XS[i];
             __syncthreads();
             int it_more = 0, as_more = 0;
@@ -2629,6 +2634,8 @@ __global__ void __launch_bounds__(MCQ_NT) mcq_solve_kernel(McqBatch B)
                 o.n_active_kappa = nact_kappa;
                 o.kappa_max = km;
                 o.kkt_res = sc.fscale > 0.0 ? kkt / sc.fscale : kkt;
+                o.refine_rounds = c.refine_rounds;
+                o.second_attempt = c.second_attempt;
                 c.tk[3] = TICK() - t_kernel0;
                 for (int q = 0; q < 8; ++q) o.ticks[q] = c.tk[q];
                 *(mcq_info*)c.w.info = o;

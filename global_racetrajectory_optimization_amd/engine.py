@@ -37,7 +37,7 @@ class McqOpts(ctypes.Structure):
 class McqInfo(ctypes.Structure):
     _fields_ = [("ipm_iters", ctypes.c_int), ("as_iters", ctypes.c_int), ("n_active_box", ctypes.c_int),
                 ("n_active_kappa", ctypes.c_int), ("kappa_max", ctypes.c_double), ("kkt_res", ctypes.c_double),
-                ("ticks", ctypes.c_longlong * 8)]
+                ("ticks", ctypes.c_longlong * 8), ("refine_rounds", ctypes.c_int), ("second_attempt", ctypes.c_int)]
 
 
 EXPORTED_SYMBOLS = ("mcq_create", "mcq_destroy", "mcq_last_error", "mcq_default_opts", "mcq_solve_batch",
@@ -176,7 +176,7 @@ class Engine:
             off += ref.shape[0]
         infos = [dict(ipm_iters=i.ipm_iters, as_iters=i.as_iters, n_active_box=i.n_active_box,
                       n_active_kappa=i.n_active_kappa, kappa_max=i.kappa_max, kkt_res=i.kkt_res,
-                      ticks=list(i.ticks)) for i in info]
+                      ticks=list(i.ticks), refine_rounds=i.refine_rounds, second_attempt=i.second_attempt) for i in info]
         return out, curv, status, infos
 
     # ------------------------------------------------------------------------------------------------------------------

@@ -87,6 +87,9 @@ typedef struct {
      * kernel: [0] banded factorisations, [1] triangular solves, [2] gradient band products, [3] whole kernel,
      * [4..7] inside the factorisation: diagonal tile, panel, write-out of L, trailing update + window refill */
     long long ticks[8];
+    int refine_rounds;  /* fp64 refinement rounds run on the final working set (<= opts.refine_steps) */
+    int second_attempt; /* 1 if the active-set phase ran out of its first budget and the interior point was resumed to
+                           mu = 1e-13 (degenerate / very ill-conditioned instance) */
 } mcq_info;
 
 int mcq_create(int device_id, mcq_handle** out);
