@@ -46,6 +46,8 @@ struct mcq_handle {
     size_t stage_elems = 0, stage_batch = 0;
     long long ws_bytes = 0;
     bool smem_attr_set = false;
+    double* vel_scratch = nullptr;      // lap-doubled profiles of mcq_vel_profile_device, [2 nmax][batch]
+    size_t vel_scratch_bytes = 0;
 };
 
 extern "C" const char* mcq_last_error(void) { return g_err.c_str(); }
@@ -115,6 +117,7 @@ extern "C" void mcq_destroy(mcq_handle* h)
     if (h->stream) (void)hipStreamSynchronize(h->stream);
     free_ws(h);
     free_stage(h);
+    (void)hipFree(h->vel_scratch);
     for (int k = 0; k < 5; ++k) if (h->ev[k]) (void)hipEventDestroy(h->ev[k]);
     if (h->stream) (void)hipStreamDestroy(h->stream);
     delete h;
@@ -305,6 +308,38 @@ extern "C" int mcq_relinearise_device(mcq_handle* h, int batch, int nmax, const 
     R.status = status_out;
     R.vec = h->vec;
     hipLaunchKernelGGL(mcq_relinearise_kernel, dim3(batch), dim3(256), 0, h->stream, R);
+    HIP_TRY(hipGetLastError());
+    return 0;
+}
+
+extern "C" int mcq_vel_profile_device(mcq_handle* h, int batch, int n, int nmax, const int* track_of, const double* kappa,
+                                      const double* el_lengths, const double* ggv, int n_ggv, const double* ax_max_machines,
+                                      int n_machines, const double* drag_coeff, const double* m_veh, const double* v_max,
+                                      double dyn_model_exp, double* vx_out, double* lap_time_out)
+{
+    if (!h || batch <= 0 || n < 2 || nmax < n || !kappa || !el_lengths || !ggv || n_ggv < 1 || !ax_max_machines ||
+        n_machines < 1 || !drag_coeff || !m_veh || !v_max || !vx_out || !lap_time_out || !(dyn_model_exp > 0.0)) {
+        g_err = "mcq_vel_profile_device: bad argument";
+        return MCQ_E_ARG;
+    }
+    HIP_TRY(hipSetDevice(h->device));
+    const size_t need = (size_t)2 * nmax * batch * sizeof(double);
+    if (need > h->vel_scratch_bytes) {
+        HIP_TRY(hipStreamSynchronize(h->stream));
+        (void)hipFree(h->vel_scratch);
+        h->vel_scratch = nullptr;
+        h->vel_scratch_bytes = 0;
+        HIP_TRY(hipMalloc((void**)&h->vel_scratch, need));
+        h->vel_scratch_bytes = need;
+    }
+    McqVel V;
+    memset(&V, 0, sizeof(V));
+    V.batch = batch; V.n = n; V.nmax = nmax;
+    V.track_of = track_of; V.kappa = kappa; V.el = el_lengths;
+    V.ggv = ggv; V.ng = n_ggv; V.axm = ax_max_machines; V.nam = n_machines;
+    V.drag = drag_coeff; V.mass = m_veh; V.vmax = v_max; V.dyn_exp = dyn_model_exp;
+    V.scratch = h->vel_scratch; V.vx_out = vx_out; V.lap_time = lap_time_out;
+    hipLaunchKernelGGL(mcq_vel_profile_kernel, dim3((batch + 63) / 64), dim3(64), 0, h->stream, V);
     HIP_TRY(hipGetLastError());
     return 0;
 }

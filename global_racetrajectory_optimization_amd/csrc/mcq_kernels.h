@@ -151,3 +151,25 @@ struct McqRelin {
     double* vec;            // workspace, [batch][MCQ_NVEC][nmax] (the solver's vector slab)
 };
 __global__ void mcq_relinearise_kernel(McqRelin R);
+
+/* ---- ggv velocity profile + lap time of many (track, vehicle) variants: the forward /
+ *      backward quasi-steady-state sweeps of tph.calc_vel_profile (closed track, global ggv) followed by
+ *      tph.calc_ax_profile / calc_t_profile, one thread per variant. ---- */
+struct McqVel {
+    int batch, n, nmax;
+    const int* track_of;     // [batch] row of kappa / el a variant uses, or nullptr (row = variant)
+    const double* kappa;     // [tracks][nmax]
+    const double* el;        // [tracks][nmax] element lengths (closed: n of them)
+    const double* ggv;       // [batch][ng][3]  (v, ax_max, ay_max)
+    int ng;
+    const double* axm;       // [batch][nam][2] (v, ax_max of the machines)
+    int nam;
+    const double* drag;      // [batch] drag coefficient
+    const double* mass;      // [batch]
+    const double* vmax;      // [batch]
+    double dyn_exp;
+    double* scratch;         // [2 nmax][batch]: the lap-doubled profile, variant-minor (coalesced across threads)
+    double* vx_out;          // [batch][nmax]
+    double* lap_time;        // [batch]
+};
+__global__ void mcq_vel_profile_kernel(McqVel V);

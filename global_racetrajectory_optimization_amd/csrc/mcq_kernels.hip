@@ -2834,3 +2834,123 @@ __global__ void __launch_bounds__(MCQ_NT) mcq_relinearise_kernel(McqRelin R)
     }
     if (tid == 0) { *status = MCQ_OK; *n_out = m; }
 }
+
+// =====================================================================================================================
+// K5: ggv velocity profile and lap time of many variants
+// =====================================================================================================================
+// numpy.interp: piecewise linear, clamped at both ends; xs ascending, stride 3 (ggv rows) or 2 (machine rows)
+__device__ __forceinline__ double vp_interp(double x, const gdouble* tab, int cnt, int stride, int col)
+{
+    if (x <= tab[0]) return tab[col];
+    if (x >= tab[(size_t)(cnt - 1) * stride]) return tab[(size_t)(cnt - 1) * stride + col];
+    int k = 1;
+    while (k < cnt - 1 && tab[(size_t)k * stride] <= x) ++k;                 // tab[k-1].x <= x < tab[k].x
+    const double x0 = tab[(size_t)(k - 1) * stride], x1 = tab[(size_t)k * stride];
+    const double y0 = tab[(size_t)(k - 1) * stride + col], y1 = tab[(size_t)k * stride + col];
+    return y0 + (y1 - y0) * (x - x0) / (x1 - x0);
+}
+
+// longitudinal acceleration still available at speed v on radius `rad` (friction ellipse of exponent e, drag)
+__device__ __forceinline__ double vp_ax_possible(double v, double rad, const gdouble* ggv, int ng, const gdouble* axm, int nam,
+                                                 bool accel, double e, double drag_over_m)
+{
+    const double ax_t = vp_interp(v, ggv, ng, 3, 1), ay_t = vp_interp(v, ggv, ng, 3, 2);
+    const double ay_used = v * v / rad;
+    const double radicand = ay_t > 0.0 ? 1.0 - pow(ay_used / ay_t, e) : 0.0;
+    const double ax_tires = radicand > 0.0 ? ax_t * pow(radicand, 1.0 / e) : 0.0;
+    const double ax_drag = -v * v * drag_over_m;
+    if (accel) return fmin(ax_tires, vp_interp(v, axm, nam, 2, 1)) + ax_drag;
+    return ax_tires - ax_drag;                 // braking, integrated backwards
+}
+
+__global__ void __launch_bounds__(64) mcq_vel_profile_kernel(McqVel V)
+{
+    const int v = blockIdx.x * 64 + threadIdx.x;
+    if (v >= V.batch) return;
+    const int n = V.n, bt = V.batch;
+    const size_t row = (size_t)(V.track_of ? V.track_of[v] : v) * V.nmax;
+    const gdouble* kap = (const gdouble*)(V.kappa + row);
+    const gdouble* el = (const gdouble*)(V.el + row);
+    const gdouble* ggv_all = (const gdouble*)(V.ggv + (size_t)v * V.ng * 3);
+    const gdouble* axm = (const gdouble*)(V.axm + (size_t)v * V.nam * 2);
+    gdouble* S = (gdouble*)V.scratch + v;       // S[j * bt]
+    const double vmax = V.vmax[v], e = V.dyn_exp, dom = V.drag[v] / V.mass[v];
+    // rows of the ggv diagram up to v_max (tph drops the rest)
+    int ng = V.ng;
+    if (ng > 1) {
+        const double lim = fmax(vmax, ggv_all[0]) + 1e-9;
+        int c = 0;
+        while (c < ng && ggv_all[(size_t)c * 3] <= lim) ++c;
+        ng = c;
+    }
+    const gdouble* ggv = ggv_all;
+    double aymin = ggv[2];
+    for (int k = 1; k < ng; ++k) aymin = fmin(aymin, ggv[(size_t)k * 3 + 2]);
+
+    // ---- lateral limit  v = sqrt(ay_max(v) R)  by fixed-point iteration -----------------------------------------------------
+    for (int i = 0; i < n; ++i) {
+        const double k = kap[i];
+        const double rad = k != 0.0 ? fabs(1.0 / k) : INFINITY;
+        S[(size_t)i * bt] = sqrt(aymin * rad);
+    }
+    for (int it = 0; it < 100; ++it) {
+        double worst = 0.0;
+        for (int i = 0; i < n; ++i) {
+            const double k = kap[i];
+            const double rad = k != 0.0 ? fabs(1.0 / k) : INFINITY;
+            const double vx = S[(size_t)i * bt];
+            const double vn = sqrt(vp_interp(fmin(vx, vmax), ggv, ng, 3, 2) * rad);
+            if (isfinite(vn)) worst = fmax(worst, fabs(vx / (vn > 0.0 ? vn : 1.0) - 1.0));
+            S[(size_t)i * bt] = vn;
+        }
+        if (worst < 0.005) break;
+    }
+    // ---- two laps: acceleration-limited forward sweep, deceleration-limited backward sweep -------------------------------------
+    for (int i = 0; i < n; ++i) {
+        const double vx = fmin(S[(size_t)i * bt], vmax);
+        S[(size_t)i * bt] = vx;
+        S[(size_t)(n + i) * bt] = vx;
+    }
+    {
+        double cur = S[0];
+        for (int j = 0; j < 2 * n - 1; ++j) {
+            const int i = j < n ? j : j - n;
+            const double k = kap[i];
+            const double rad = k != 0.0 ? fabs(1.0 / k) : INFINITY;
+            const double ax = vp_ax_possible(cur, rad, ggv, ng, axm, V.nam, true, e, dom);
+            const double vnext = sqrt(fmax(cur * cur + 2.0 * ax * el[i], 0.0));
+            double nxt = S[(size_t)(j + 1) * bt];
+            if (vnext < nxt) { nxt = vnext; S[(size_t)(j + 1) * bt] = nxt; }
+            cur = nxt;
+        }
+    }
+    {
+        double cur = S[(size_t)(2 * n - 1) * bt];
+        for (int j = 2 * n - 1; j >= 1; --j) {
+            const int i = j < n ? j : j - n;
+            const int im = (j - 1) < n ? j - 1 : j - 1 - n;
+            const double k = kap[i];
+            const double rad = k != 0.0 ? fabs(1.0 / k) : INFINITY;
+            const double ax = vp_ax_possible(cur, rad, ggv, ng, axm, V.nam, false, e, dom);
+            const double vprev = sqrt(fmax(cur * cur + 2.0 * ax * el[im], 0.0));
+            double prv = S[(size_t)(j - 1) * bt];
+            if (vprev < prv) { prv = vprev; S[(size_t)(j - 1) * bt] = prv; }
+            cur = prv;
+        }
+    }
+    // ---- second lap out; lap time from the piecewise-constant accelerations (tph.calc_ax_profile / calc_t_profile) -----------
+    gdouble* out = (gdouble*)(V.vx_out + (size_t)v * V.nmax);
+    double t = 0.0;
+    const double v0 = S[(size_t)n * bt];
+    double va = v0;
+    for (int i = 0; i < n; ++i) {
+        const double vb = i + 1 < n ? S[(size_t)(n + i + 1) * bt] : v0;
+        out[i] = va;
+        // constant acceleration over the element: t = 2 l / (v_a + v_b).  Algebraically tph.calc_t_profile's
+        // (-v_a + sqrt(v_a^2 + 2 a l)) / a with a = (v_b^2 - v_a^2) / (2 l), which cancels catastrophically as a -> 0 (a 1e-15
+        // ripple on a speed-limited stretch moves that expression by 0.1 s per element); this form has no such case.
+        t += 2.0 * el[i] / (va + vb);
+        va = vb;
+    }
+    V.lap_time[v] = t;
+}

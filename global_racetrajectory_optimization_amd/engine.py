@@ -41,7 +41,8 @@ class McqInfo(ctypes.Structure):
 
 
 EXPORTED_SYMBOLS = ("mcq_create", "mcq_destroy", "mcq_last_error", "mcq_default_opts", "mcq_solve_batch",
-                    "mcq_solve_device", "mcq_solve_device_ragged", "mcq_prep_device", "mcq_relinearise_device", "mcq_device_alloc",
+                    "mcq_solve_device", "mcq_solve_device_ragged", "mcq_prep_device", "mcq_relinearise_device",
+                    "mcq_vel_profile_device", "mcq_device_alloc",
                     "mcq_device_free", "mcq_copy_to_device", "mcq_copy_to_host", "mcq_sync", "mcq_stream",
                     "mcq_last_timing", "mcq_workspace_bytes")
 
@@ -80,6 +81,9 @@ def load_library(path=None):
     lib.mcq_relinearise_device.argtypes = [vp, ctypes.c_int, ctypes.c_int, vp, vp, vp, vp, vp, ctypes.c_double,
                                            ctypes.c_double, vp, vp, vp, vp]
     lib.mcq_relinearise_device.restype = ctypes.c_int
+    lib.mcq_vel_profile_device.argtypes = [vp, ctypes.c_int, ctypes.c_int, ctypes.c_int, vp, vp, vp, vp, ctypes.c_int, vp,
+                                           ctypes.c_int, vp, vp, vp, ctypes.c_double, vp, vp]
+    lib.mcq_vel_profile_device.restype = ctypes.c_int
     lib.mcq_device_alloc.argtypes = [vp, ctypes.c_size_t, ctypes.POINTER(vp)]
     lib.mcq_device_alloc.restype = ctypes.c_int
     lib.mcq_device_free.argtypes = [vp, vp]
@@ -222,6 +226,41 @@ class Engine:
         if np.any(st != 0):
             raise EngineError("mcq_prep_device: bad input in problem(s) %s" % np.nonzero(st)[0].tolist())
         return [nv[k, :ns[k]].copy() for k in range(bsz)], [sc[k, :ns[k]].copy() for k in range(bsz)]
+
+    def vel_profile_batch(self, kappa, el_lengths, ggv, ax_max_machines, drag_coeff, m_veh, v_max, dyn_model_exp=1.0,
+                          track_of=None):
+        """ggv velocity profiles and lap times of a batch of variants on the device (mcq_vel_profile_device).
+
+        kappa, el_lengths: [tracks, n]; ggv: [batch, g, 3]; ax_max_machines: [batch, m, 2]; drag_coeff, m_veh, v_max: [batch];
+        track_of: [batch] ints (row of kappa / el per variant) or None when tracks == batch.  Returns (vx [batch, n], lap_time
+        [batch])."""
+        kappa = np.ascontiguousarray(kappa, dtype=np.float64)
+        el = np.ascontiguousarray(el_lengths, dtype=np.float64)
+        ggv = np.ascontiguousarray(ggv, dtype=np.float64)
+        axm = np.ascontiguousarray(ax_max_machines, dtype=np.float64)
+        bsz, n = ggv.shape[0], kappa.shape[1]
+        scal = [np.ascontiguousarray(np.broadcast_to(np.asarray(a, dtype=np.float64), (bsz,))) for a in (drag_coeff, m_veh, v_max)]
+        tr = None if track_of is None else np.ascontiguousarray(track_of, dtype=np.int32)
+        ptrs = []
+
+        def up(a):
+            p = self.alloc(a.nbytes)
+            ptrs.append(p)
+            self.upload(p, a)
+            return p
+        try:
+            d_k, d_e, d_g, d_a = up(kappa), up(el), up(ggv), up(axm)
+            d_s = [up(a) for a in scal]
+            d_t = up(tr) if tr is not None else None
+            d_vx = self.alloc(bsz * n * 8); ptrs.append(d_vx)
+            d_lt = self.alloc(bsz * 8); ptrs.append(d_lt)
+            rc = self.lib.mcq_vel_profile_device(self.h, bsz, n, n, d_t, d_k, d_e, d_g, ggv.shape[1], d_a, axm.shape[1],
+                                                 d_s[0], d_s[1], d_s[2], float(dyn_model_exp), d_vx, d_lt)
+            self._check(rc, "mcq_vel_profile_device")
+            return self.download(d_vx, (bsz, n), np.float64), self.download(d_lt, (bsz,), np.float64)
+        finally:
+            for p in ptrs:
+                self.free(p)
 
     def relinearise_device(self, batch, nmax, d_n_in, d_ref_in, d_nv_in, d_alpha, d_live, alpha_scale, stepsize,
                            d_ref_out, d_nv_out, d_n_out, d_status):

@@ -138,6 +138,17 @@ int mcq_prep_device(mcq_handle* h, int batch, int nmax, const int* n_list, const
 int mcq_relinearise_device(mcq_handle* h, int batch, int nmax, const int* n_in, const double* reftrack_in,
                            const double* normvec_in, const double* alpha, const int* live, double alpha_scale,
                            double stepsize, double* reftrack_out, double* normvec_out, int* n_out, int* status_out);
+/* ggv velocity profile and lap time of a batch of (track, vehicle) variants -- what the lap-time-matrix sweep of the
+ * reference runs per cell [REF main_globaltraj.py:400-422, 460-493]: tph.calc_vel_profile (closed track, global ggv, no
+ * filter) followed by calc_ax_profile / calc_t_profile.  One device thread per variant.  All pointers DEVICE pointers:
+ * kappa / el_lengths [tracks][nmax] (n valid entries each), track_of [batch] (row used by a variant) or NULL (row =
+ * variant), ggv [batch][n_ggv][3] (v, ax_max, ay_max), ax_max_machines [batch][n_machines][2], drag_coeff / m_veh / v_max
+ * [batch]; outputs vx_out [batch][nmax], lap_time_out [batch].  Asynchronous on the handle's stream. */
+int mcq_vel_profile_device(mcq_handle* h, int batch, int n, int nmax, const int* track_of, const double* kappa,
+                           const double* el_lengths, const double* ggv, int n_ggv, const double* ax_max_machines,
+                           int n_machines, const double* drag_coeff, const double* m_veh, const double* v_max,
+                           double dyn_model_exp, double* vx_out, double* lap_time_out);
+
 /* Device memory plumbing on the handle's device and stream, for callers that keep data resident between calls (the
  * Python IQP driver) without loading a second HIP runtime into the process: allocate (zero-filled) / free / blocking
  * copies.  A reference-side binding would use these exactly where a CUDA/HIP-aware caller uses its own allocator. */
