@@ -307,3 +307,29 @@ def test_velocity_profile_lap_time_sweep(gpu_engine, golden):
             assert abs(lt_d[k] - float(np.sum(2.0 * el / (vx_cl[:-1] + vx_cl[1:])))) < 1e-9, k
             assert abs(lt_d[k] - t_h[-1]) < 0.5, k
     assert nmax > 0
+
+
+def test_pinned_variables_and_bad_input(gpu_engine, golden):
+    """Edge cases of the boundary: waypoints whose box is a single point (w_right + w_left == w_veh: the interior point
+    carries them as pinned rows, the masked factorisation path) against the dense oracle, and non-finite input flagged
+    per problem (status 4) without disturbing its batch neighbours."""
+    from oracle import tph_ref
+    g = golden["rounded_rectangle"]
+    ref = g["reftrack"].copy()
+    for i, shift in ((5, 0.2), (40, -0.35), (41, 0.1)):
+        ref[i, 2] = 1.7 + shift          # hi =  shift
+        ref[i, 3] = 1.7 - shift          # lo =  shift
+    path_cl = np.vstack((ref[:, :2], ref[0, :2]))
+    _, _, A, nv = tph_ref.calc_splines(path_cl)
+    a_ref, err_ref = tph_ref.opt_min_curv(ref, nv, A, 0.12, 3.4)
+    bad = g["reftrack"].copy()
+    bad[7, 0] = np.nan
+    sc = tph.calc_splines.scalings_from_les_matrix(A)
+    al, curv, st, _ = gpu_engine.solve_batch([dict(reftrack=ref, normvec=nv, scaling=sc, kappa_bound=0.12, w_veh=3.4),
+                                              dict(reftrack=bad, normvec=g["normvec"], scaling=g["scaling"], kappa_bound=0.12, w_veh=3.4),
+                                              dict(reftrack=g["reftrack"], normvec=g["normvec"], scaling=g["scaling"], kappa_bound=0.12, w_veh=3.4)])
+    assert list(st) == [0, engine.STATUS_BAD_INPUT, 0]
+    assert np.max(np.abs(al[0] - a_ref)) < ALPHA_TOL
+    assert abs(al[0][5] - 0.2) < 1e-12 and abs(al[0][40] + 0.35) < 1e-12
+    assert abs(curv[0] - err_ref) < CURV_TOL
+    assert np.max(np.abs(al[2] - g["alpha"])) < ALPHA_TOL
