@@ -1143,9 +1143,28 @@ __device__ __forceinline__ int factor_t(const SolveCtx& c, const gdouble* Hsrc, 
             const bool bad = diag_tile_inv(BTILE(J, J), linv + (J & 1) * TSZ, l15);
             if (bad && lane == 0) dinv[TB] = 1.0;
         } else {
-            // Tile row J-1+NTR (fetched during the previous step) enters the window: its band slots -- tile row J-1 -- were
-            // last read by panel(J-1), its border slots -- tile row J-2 of the 6-row border window -- by lag(J-2) in the
-            // previous step; panel(J) needs tile (J+4, J).  Then tile row J+NTR goes in flight: a full step ahead.
+            // Tile row J+NTR goes in flight first; the lag work and the write-out of step J-1 follow; only then is tile row
+            // J-1+NTR -- fetched at the top of the PREVIOUS step, i.e. one and a half steps ago: the commit never waits on
+            // HBM -- decoded into the window: its band slots -- tile row J-1 -- were last read by panel(J-1), its border slots
+            // -- tile row J-2 of the 6-row border window -- by lag(J-2); lag(J-1) does not touch either, panel(J) needs
+            // tile (J+4, J).
+            RawEntry pfn[PF_ITEMS];
+            {
+                const int R = J + NTR;
+                if (PF_FAST(R)) {
+#pragma unroll
+                    for (int u = 0; u < PF_ITEMS; ++u) {
+                        if (u < 6) pfn[u] = tile_row_fetch_fast<MK, SIG>(H, sig, mk, R, pc[u], true, u == 5);
+                        else if (u > 6) pfn[u] = tile_row_fetch_fast<MK, SIG>(H, sig, mk, R, pc[u], false, false);
+                        else if (wave3) pfn[u] = tile_row_fetch_fast<MK, SIG>(H, sig, mk, R, pc[u], false, false);
+                        else pfn[u] = tile_row_fetch_fast<MK, SIG>(H, sig, mk, R, pc[u], true, true);
+                    }
+                } else {
+#pragma unroll
+                    for (int u = 0; u < PF_ITEMS; ++u) pfn[u] = tile_row_fetch<MK, SIG>(H, sig, mk, ni, b, p, R, lt + u * PF_THREADS);
+                }
+            }
+            if (J > 0) { LAG_DISPATCH(J - 1) WRITE_OUT_DISPATCH(J - 1) }
             if (J > 0) {
                 const int R = J - 1 + NTR;
                 if (PF_FAST(R)) {
@@ -1164,22 +1183,8 @@ __device__ __forceinline__ int factor_t(const SolveCtx& c, const gdouble* Hsrc, 
                     }
                 }
             }
-            {
-                const int R = J + NTR;
-                if (PF_FAST(R)) {
 #pragma unroll
-                    for (int u = 0; u < PF_ITEMS; ++u) {
-                        if (u < 6) pf[u] = tile_row_fetch_fast<MK, SIG>(H, sig, mk, R, pc[u], true, u == 5);
-                        else if (u > 6) pf[u] = tile_row_fetch_fast<MK, SIG>(H, sig, mk, R, pc[u], false, false);
-                        else if (wave3) pf[u] = tile_row_fetch_fast<MK, SIG>(H, sig, mk, R, pc[u], false, false);
-                        else pf[u] = tile_row_fetch_fast<MK, SIG>(H, sig, mk, R, pc[u], true, true);
-                    }
-                } else {
-#pragma unroll
-                    for (int u = 0; u < PF_ITEMS; ++u) pf[u] = tile_row_fetch<MK, SIG>(H, sig, mk, ni, b, p, R, lt + u * PF_THREADS);
-                }
-            }
-            if (J > 0) { LAG_DISPATCH(J - 1) WRITE_OUT_DISPATCH(J - 1) }
+            for (int u = 0; u < PF_ITEMS; ++u) pf[u] = pfn[u];
         }
         lds_barrier();
         c.tk[4] += FTICK() - tp; tp = FTICK();
