@@ -60,6 +60,7 @@ extern "C" void mcq_default_opts(mcq_opts* o)
     o->max_as_iter = 60;
     o->refine_steps = 2;
     o->check_kappa = 1;
+    o->objective = MCQ_OBJ_MIN_CURV;
 }
 
 static mcq_opts resolve_opts(const mcq_opts* in)
@@ -72,6 +73,7 @@ static mcq_opts resolve_opts(const mcq_opts* in)
         if (in->max_as_iter > 0) o.max_as_iter = in->max_as_iter;
         if (in->refine_steps >= 0) o.refine_steps = in->refine_steps;
         o.check_kappa = in->check_kappa;
+        o.objective = in->objective == MCQ_OBJ_SHORTEST_PATH ? MCQ_OBJ_SHORTEST_PATH : MCQ_OBJ_MIN_CURV;
     }
     return o;
 }
@@ -172,6 +174,22 @@ static int launch(mcq_handle* h, McqBatch& B, const mcq_opts& o)
     B.max_as_iter = o.max_as_iter;
     B.refine_steps = o.refine_steps;
     B.check_kappa = o.check_kappa;
+    B.objective = o.objective;
+    if (B.objective == MCQ_OBJ_SHORTEST_PATH && !B.prep_only) {
+        if (!B.nv) { g_err = "shortest-path objective: normvec is required"; return MCQ_E_ARG; }
+        B.check_kappa = 0;
+        HIP_TRY(hipEventRecord(h->ev[0], h->stream));
+        hipLaunchKernelGGL(mcq_assemble_sp_kernel, dim3(B.batch), dim3(256), 0, h->stream, B);
+        HIP_TRY(hipGetLastError());
+        HIP_TRY(hipEventRecord(h->ev[1], h->stream));
+        HIP_TRY(hipEventRecord(h->ev[2], h->stream));
+        hipLaunchKernelGGL(mcq_solve_kernel, dim3(B.batch), dim3(256), 0, h->stream, B);
+        HIP_TRY(hipGetLastError());
+        HIP_TRY(hipEventRecord(h->ev[3], h->stream));
+        HIP_TRY(hipEventRecord(h->ev[4], h->stream));
+        h->timing_valid = true;
+        return 0;
+    }
     HIP_TRY(hipEventRecord(h->ev[0], h->stream));
     hipLaunchKernelGGL(mcq_assemble_kernel, dim3(B.batch), dim3(256), 0, h->stream, B);
     HIP_TRY(hipGetLastError());

@@ -122,9 +122,12 @@ struct McqBatch {
     const double* kappa_bound_list;  // per-problem overrides (device) or nullptr
     const double* w_veh_list;
     int band_e, max_ipm_iter, max_as_iter, refine_steps, check_kappa;
+    int objective;          // MCQ_OBJ_*: shortest path = H and f written directly by mcq_assemble_sp_kernel (Eb holds the three
+                            // diagonals of H, the gradient is H x + f), no curvature rows, no curvature-error post-check
 };
 
 __global__ void mcq_assemble_kernel(McqBatch B);
+__global__ void mcq_assemble_sp_kernel(McqBatch B);
 __global__ void mcq_gram_kernel(McqBatch B);
 __global__ void mcq_gram_tile_kernel(McqBatch B);
 __global__ void mcq_solve_kernel(McqBatch B);

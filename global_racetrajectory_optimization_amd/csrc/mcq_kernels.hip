@@ -693,6 +693,96 @@ __global__ void __launch_bounds__(MCQ_NT) mcq_gram_kernel(McqBatch B)
 // =====================================================================================================================
 // K3: solver
 // =====================================================================================================================
+// =====================================================================================================================
+// K1': assembly of the shortest-path QP (tph.opt_shortest_path, call site
+//      [REF main_globaltraj.py:286-290]):   minimise  sum_i |p_{i+1} + a_{i+1} n_{i+1} - p_i - a_i n_i|^2   over the ring,
+//      i.e.  1/2 a'Ha + f'a  with  H_ii = 4 |n_i|^2,  H_{i,i+1} = -2 n_i . n_{i+1},  f_i = 2 n_i . (2 p_i - p_{i-1} - p_{i+1}),
+//      on the box  -max(w_l - w_veh/2, 0.001) <= a_i <= max(w_r - w_veh/2, 0.001).
+//      H goes straight into the bordered-band storage the factorisation reads (a cyclic tridiagonal: diagonal, one
+//      off-diagonal, two wrap-around entries in the border); Eb holds its three diagonals for the gradient H x + f.
+// =====================================================================================================================
+__global__ void __launch_bounds__(MCQ_NT) mcq_assemble_sp_kernel(McqBatch B)
+{
+    __shared__ double red[64];
+    const int tid = threadIdx.x;
+    int n;
+    double kb, wveh;
+    const McqWork w = mcq_work(B, blockIdx.x, n, kb, wveh);
+    const int nm = B.nmax;
+    const McqDims d = mcq_dims(n < 3 ? 3 : n, B.band_e);
+    gdouble* LO = VEC(w, nm, V_LO);
+    gdouble* HI = VEC(w, nm, V_HI);
+    gdouble* NX = VEC(w, nm, V_NX);
+    gdouble* NY = VEC(w, nm, V_NY);
+    gdouble* F = VEC(w, nm, V_F);
+    gdouble* KRF = VEC(w, nm, V_KREF);
+
+    double flag_bad = n < 3 ? 1.0 : 0.0;
+    for (int i = tid; i < n; i += MCQ_NT) {
+        const double x = w.ref[4 * i], y = w.ref[4 * i + 1], wr = w.ref[4 * i + 2], wl = w.ref[4 * i + 3];
+        const double nx = w.nv[2 * i], ny = w.nv[2 * i + 1];
+        if (!(isfinite(x) && isfinite(y) && isfinite(wr) && isfinite(wl) && isfinite(nx) && isfinite(ny))) flag_bad = 1.0;
+        NX[i] = nx;
+        NY[i] = ny;
+        LO[i] = -fmax(wl - 0.5 * wveh, 0.001);
+        HI[i] = fmax(wr - 0.5 * wveh, 0.001);
+        KRF[i] = 0.0;
+    }
+    flag_bad = block_reduce_(flag_bad, 2, red);
+    const int st = flag_bad > 0.0 ? MCQ_BAD_INPUT : MCQ_OK;
+    if (tid == 0) {
+        *w.status = st;
+        if (w.curv_err) *w.curv_err = 0.0;
+        if (w.info) {
+            mcq_info z;
+            z.ipm_iters = z.as_iters = z.n_active_box = z.n_active_kappa = 0;
+            z.kappa_max = 0.0;
+            z.kkt_res = 0.0;
+            z.refine_rounds = z.second_attempt = 0;
+            for (int q = 0; q < 8; ++q) z.ticks[q] = 0;
+            *(mcq_info*)w.info = z;
+        }
+    }
+    if (st != MCQ_OK) {
+        if (w.alpha) for (int i = tid; i < n; i += MCQ_NT) w.alpha[i] = 0.0;
+        return;
+    }
+
+    // entries of the cyclic tridiagonal (n >= 3: the two neighbours of a point are distinct)
+#define SP_DIAG(i) (4.0 * (w.nv[2 * (i)] * w.nv[2 * (i)] + w.nv[2 * (i) + 1] * w.nv[2 * (i) + 1]))
+#define SP_OFF(i, j) (-2.0 * (w.nv[2 * (i)] * w.nv[2 * (j)] + w.nv[2 * (i) + 1] * w.nv[2 * (j) + 1]))
+    const int ni = d.ni;
+    for (int i = tid; i < n; i += MCQ_NT) {
+        const int ip = i + 1 == n ? 0 : i + 1, im = i == 0 ? n - 1 : i - 1;
+        const double hd = SP_DIAG(i), hu = SP_OFF(i, ip), hl = SP_OFF(i, im);
+        w.Eb[(size_t)0 * nm + i] = hl;
+        w.Eb[(size_t)1 * nm + i] = hd;
+        w.Eb[(size_t)2 * nm + i] = hu;
+        const double px = w.ref[4 * i], py = w.ref[4 * i + 1];
+        F[i] = 2.0 * (w.nv[2 * i] * ((px - w.ref[4 * im]) - (w.ref[4 * ip] - px))
+                      + w.nv[2 * i + 1] * ((py - w.ref[4 * im + 1]) - (w.ref[4 * ip + 1] - py)));
+    }
+    // rows of the bordered band: consecutive threads write consecutive entries of one row
+    for (int idx = tid; idx < MCQ_HLD * n; idx += MCQ_NT) {
+        const int i = idx / MCQ_HLD, k = idx - i * MCQ_HLD;
+        double v = 0.0;
+        if (k < MCQ_HBO) {
+            if (i < ni) {
+                if (k == 0) v = SP_DIAG(i);
+                else if (k == 1 && d.b >= 1 && i + 1 < ni) v = SP_OFF(i, i + 1);
+            }
+        } else if (k - MCQ_HBO < d.p) {
+            const int j = ni + (k - MCQ_HBO);
+            const int df = sdiff(i, j, n);
+            if (df == 0) v = SP_DIAG(i);
+            else if (df == 1 || df == -1) v = SP_OFF(i, j);
+        }
+        w.H[(size_t)i * MCQ_HLD + k] = v;
+    }
+#undef SP_DIAG
+#undef SP_OFF
+}
+
 struct SolveCtx {
     McqDims d;
     McqWork w;
@@ -700,6 +790,7 @@ struct SolveCtx {
     mutable long long tk[8];   // phase timers (wall_clock64 ticks), meaningful on thread 0
     mutable int refine_rounds, second_attempt;   // diagnostics for mcq_info
     mutable double last_step;  // length of the last interior-point step (the Tapia indicators are only trusted after a near-full one)
+    int direct;                // 1: Eb holds the three diagonals of H itself and V_F holds f (shortest-path objective)
 };
 #define TICK() ((long long)wall_clock64())
 // fine-grained timers inside the factorisation (ticks[4..7]) cost an s_waitcnt per sample in the hot loop: off by default
@@ -1735,6 +1826,12 @@ __device__ __noinline__ void gradient(SolveCtx& c, const gdouble* x, const gdoub
     const int n = c.d.n;
     const long long t0 = TICK();
     __syncthreads();
+    if (c.direct) {          // g = H x + f, H a cyclic tridiagonal given entry by entry: nothing to gain from a factored form
+        band_matvec(c.w.Eb, 1, 1, n, c.nm, x, VEC(c.w, c.nm, V_F), 1.0, g);
+        __syncthreads();
+        c.tk[2] += TICK() - t0;
+        return;
+    }
     band_matvec(c.w.Eb, c.d.bE, c.d.bR, n, c.nm, x, VEC(c.w, c.nm, V_KREF), MCQ_F_SCALE, tmp);
     __syncthreads();
     if (extra) {
@@ -2497,6 +2594,7 @@ __global__ void __launch_bounds__(MCQ_NT) mcq_solve_kernel(McqBatch B)
     for (int q = 0; q < 8; ++q) c.tk[q] = 0;
     c.last_step = 0.0;
     c.refine_rounds = c.second_attempt = 0;
+    c.direct = B.objective == MCQ_OBJ_SHORTEST_PATH;
     const long long t_kernel0 = TICK();
     double* red = g_sm + SM_RED;
     const int nm = B.nmax;
@@ -2569,15 +2667,17 @@ __global__ void __launch_bounds__(MCQ_NT) mcq_solve_kernel(McqBatch B)
     // kappa(alpha) = k_ref + E alpha
     for (int i = tid; i < n; i += MCQ_NT) X[i] = fmin(fmax(X[i], LO[i]), HI[i]);
     __syncthreads();
-    band_matvec(c.w.Eb, c.d.bE, c.d.bR, n, nm, X, VEC(c.w, nm, V_KREF), 1.0, T0);
-    __syncthreads();
     double km = 0.0;
-    for (int i = tid; i < n; i += MCQ_NT) km = fmax(km, fabs(T0[i]));
-    km = block_reduce_(km, 2, red);
+    if (!c.direct) {
+        band_matvec(c.w.Eb, c.d.bE, c.d.bR, n, nm, X, VEC(c.w, nm, V_KREF), 1.0, T0);
+        __syncthreads();
+        for (int i = tid; i < n; i += MCQ_NT) km = fmax(km, fabs(T0[i]));
+        km = block_reduce_(km, 2, red);
+    }
 
     // ---- phase 2 (rare): a curvature-bound row is violated at the box optimum -> interior point with the curvature rows,
     //      then the box active-set polish with the curvature multipliers frozen ---------------------------------------------
-    if (status == MCQ_OK && B.check_kappa && km > kbound * (1.0 + 1e-9)) {
+    if (status == MCQ_OK && B.check_kappa && !c.direct && km > kbound * (1.0 + 1e-9)) {
         status = ipm(c, B, true, sc, it2);
         ipm_iters += it2;
         __syncthreads();
@@ -2609,13 +2709,15 @@ __global__ void __launch_bounds__(MCQ_NT) mcq_solve_kernel(McqBatch B)
         const gdouble* YP = VEC(c.w, nm, V_YP);
         const gdouble* XPP = VEC(c.w, nm, V_XPP);
         const gdouble* YPP = VEC(c.w, nm, V_YPP);
-        for (int i = tid; i < n; i += MCQ_NT) { T1[i] = VEC(c.w, nm, V_NX)[i] * X[i]; T2[i] = VEC(c.w, nm, V_NY)[i] * X[i]; }
-        __syncthreads();
-        band_matvec(c.w.Db, c.d.bE, c.d.bR, n, nm, T1, nullptr, 0.0, T0);   // D (n_x alpha)
-        band_matvec(c.w.Db, c.d.bE, c.d.bR, n, nm, T2, nullptr, 0.0, T3);   // D (n_y alpha)
-        __syncthreads();
+        if (!c.direct) {
+            for (int i = tid; i < n; i += MCQ_NT) { T1[i] = VEC(c.w, nm, V_NX)[i] * X[i]; T2[i] = VEC(c.w, nm, V_NY)[i] * X[i]; }
+            __syncthreads();
+            band_matvec(c.w.Db, c.d.bE, c.d.bR, n, nm, T1, nullptr, 0.0, T0);   // D (n_x alpha)
+            band_matvec(c.w.Db, c.d.bE, c.d.bR, n, nm, T2, nullptr, 0.0, T3);   // D (n_y alpha)
+            __syncthreads();
+        }
         double em = 0.0;
-        for (int i = tid; i < n; i += MCQ_NT) {
+        for (int i = tid; i < (c.direct ? 0 : n); i += MCQ_NT) {
             const int ip = cyc(i + 1, n);
             const double s = VEC(c.w, nm, V_SC)[i];
             const double s2 = s * s;

@@ -73,7 +73,14 @@ typedef struct {
     int max_as_iter;    /* 0 => default 60 */
     int refine_steps;   /* fp64 residual-refinement rounds on the final active set; <0 => default 2 */
     int check_kappa;    /* 0 => skip the curvature rows (box-only QP); default 1 */
+    int objective;      /* MCQ_OBJ_MIN_CURV (0, default) or MCQ_OBJ_SHORTEST_PATH: the QP of tph.opt_shortest_path
+                         * [REF main_globaltraj.py:286-290] on the same box rows -- H = cyclic tridiagonal
+                         * (4 |n_i|^2 on the diagonal, -2 n_i.n_{i+1} beside it), f_i = 2 n_i.(2 p_i - p_{i-1} - p_{i+1}),
+                         * deviations clipped at 0.001 m instead of rejected.  normvec is required; scaling, kappa_bound
+                         * and the curvature rows are ignored and curv_err_out is 0. */
 } mcq_opts;
+#define MCQ_OBJ_MIN_CURV 0
+#define MCQ_OBJ_SHORTEST_PATH 1
 
 /* per-problem diagnostics (optional output) */
 typedef struct {

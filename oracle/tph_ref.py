@@ -17,6 +17,7 @@ anchored on the reference's own call sites:
   iqp_handler    <- [REF main_globaltraj.py:273-284]
   calc_splines   <- [REF helper_funcs_glob/src/prep_track.py:48-51]
   create_raceline<- [REF main_globaltraj.py:371-376]
+  opt_shortest_path <- [REF main_globaltraj.py:286-290]
 
 "Dense-faithful" means: no structure is exploited.  The 4N x 4N spline system is built and
 inverted densely, H/f/E_kappa are formed with dense products, and the QP is handed with all 4N
@@ -189,6 +190,58 @@ def opt_min_curv(reftrack, normvectors, A, kappa_bound, w_veh, solver=None, retu
     if return_internals:
         return alpha, err, dict(H=H, f=f, E=E_kappa, k_ref=k_ref, G=G, h=h)
     return alpha, err
+
+
+# ----------------------------------------------------------------------------------------------------------------------
+# shortest path
+# ----------------------------------------------------------------------------------------------------------------------
+
+def shortest_path_dense(reftrack, normvectors, w_veh):
+    """Dense H, f, G, h of tph.opt_shortest_path (trajectory_planning_helpers==0.76, not vendored; restated from its
+    published form, call site [REF main_globaltraj.py:286-290]).  Point by point as upstream accumulates it: every
+    segment i -> i+1 (the last one closing the ring) adds the square of its shifted length
+    |p_{i+1} + a_{i+1} n_{i+1} - p_i - a_i n_i|^2 to the cost 1/2 a'Ha + f'a (+ const)."""
+    reftrack = np.asarray(reftrack, dtype=np.float64)
+    nv = np.asarray(normvectors, dtype=np.float64)
+    n = reftrack.shape[0]
+    H = np.zeros((n, n))
+    f = np.zeros(n)
+    for i in range(n):
+        j = i + 1 if i < n - 1 else 0
+        H[i, i] += 2.0 * (nv[i, 0] ** 2 + nv[i, 1] ** 2)
+        H[j, j] += 2.0 * (nv[j, 0] ** 2 + nv[j, 1] ** 2)
+        hij = -2.0 * (nv[i, 0] * nv[j, 0] + nv[i, 1] * nv[j, 1])
+        H[i, j] += hij
+        H[j, i] += hij
+        f[i] += 2.0 * (nv[i, 0] * (reftrack[i, 0] - reftrack[j, 0]) + nv[i, 1] * (reftrack[i, 1] - reftrack[j, 1]))
+        f[j] += 2.0 * (nv[j, 0] * (reftrack[j, 0] - reftrack[i, 0]) + nv[j, 1] * (reftrack[j, 1] - reftrack[i, 1]))
+    dev_max_right = reftrack[:, 2] - w_veh / 2.0
+    dev_max_left = reftrack[:, 3] - w_veh / 2.0
+    dev_max_right[dev_max_right < 0.001] = 0.001       # upstream clips instead of rejecting
+    dev_max_left[dev_max_left < 0.001] = 0.001
+    G = np.vstack((np.eye(n), -np.eye(n)))
+    h = np.append(dev_max_right, dev_max_left)
+    return H, f, G, h
+
+
+def opt_shortest_path(reftrack, normvectors, w_veh, solver=None, return_internals=False):
+    """Restatement of tph.opt_shortest_path.opt_shortest_path: alpha [N] from the dense QP, solved by the dense
+    Goldfarb-Idnani stand-in for quadprog (oracle/gi_dense.c)."""
+    H, f, G, h = shortest_path_dense(reftrack, normvectors, w_veh)
+    if solver is None:
+        from oracle import qp_ref
+        solver = qp_ref.solve_qp_gi
+    alpha = solver(H, f, G, h)
+    if return_internals:
+        return alpha, dict(H=H, f=f, G=G, h=h)
+    return alpha
+
+
+def path_length_sq(reftrack, normvectors, alpha):
+    """Sum of squared segment lengths of the closed polygon through p_i + alpha_i n_i (what shortest_path_dense encodes)."""
+    p = np.asarray(reftrack, dtype=np.float64)[:, :2] + np.asarray(alpha)[:, None] * np.asarray(normvectors, dtype=np.float64)
+    dp = np.roll(p, -1, axis=0) - p
+    return float(np.sum(dp * dp))
 
 
 # ----------------------------------------------------------------------------------------------------------------------

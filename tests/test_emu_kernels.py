@@ -2,6 +2,8 @@
 only -- see the header of tests/emu/include/hip/hip_runtime.h).  Exercises every kernel's index arithmetic, barrier
 placement and wave-level data flow against the golden vectors without a GPU; the `-m gpu` suite repeats the parity
 checks on real hardware through the real libmcq.so."""
+import os
+
 import numpy as np
 import pytest
 
@@ -207,3 +209,40 @@ def test_velocity_profile_kernel_matches_host_shim(emu, golden):
         assert np.max(np.abs(vx_d[k] - vx_h)) < 1e-9
         assert abs(lt_d[k] - float(np.sum(2.0 * el / (vx_cl[:-1] + vx_cl[1:])))) < 1e-9      # stable form of calc_t_profile's sum
         assert abs(lt_d[k] - t_h[-1]) < 0.5
+
+
+@pytest.mark.parametrize("n", [7, 33, 70])
+def test_shortest_path_objective_matches_dense_oracle(emu, n):
+    """Row f-4 through the unchanged kernels: the cyclic tridiagonal H written straight into the bordered band (band,
+    wrap-around entries in the border, border block), the H x + f gradient, the 1 mm clipping of the deviations and a
+    ragged batch; against the dense Goldfarb-Idnani oracle."""
+    ref, nv, _, _ = _small_track(n, seed=n)
+    ref2, nv2, _, _ = _small_track(n + 3, seed=n + 100)
+    ref2[: n // 2, 2] = 0.9                  # w_r - w_veh/2 < 0: clipped to 0.001
+    a1 = tph_ref.opt_shortest_path(ref, nv, 2.0)
+    a2 = tph_ref.opt_shortest_path(ref2, nv2, 2.0)
+    al, curv, st, info = emu.solve_batch([dict(reftrack=ref, normvec=nv, scaling=None, kappa_bound=1.0, w_veh=2.0),
+                                          dict(reftrack=ref2, normvec=nv2, scaling=None, kappa_bound=1.0, w_veh=2.0)],
+                                         objective=engine.OBJ_SHORTEST_PATH)
+    assert list(st) == [0, 0] and np.all(curv == 0.0)
+    assert np.max(np.abs(al[0] - a1)) < 1e-9
+    assert np.max(np.abs(al[1] - a2)) < 1e-9
+    assert np.all(al[1][: n // 2] <= 0.001 + 1e-15)
+    assert info[0]["kkt_res"] < 1e-10 and info[0]["n_active_box"] > 0
+
+
+def test_shortest_path_golden_and_errors(emu, golden):
+    z = np.load(os.path.join(os.path.dirname(__file__), "golden", "shortest_path.npz"))
+    g = golden["rounded_rectangle"]
+    al, _, st, _ = emu.solve_batch([dict(reftrack=g["reftrack"], normvec=g["normvec"], scaling=None, kappa_bound=1.0,
+                                         w_veh=float(z["w_veh"]))], objective=engine.OBJ_SHORTEST_PATH)
+    assert st[0] == 0
+    assert np.max(np.abs(al[0] - z["rounded_rectangle_alpha"])) < 1e-9
+    bad = g["reftrack"].copy()
+    bad[3, 0] = np.nan
+    _, _, st, _ = emu.solve_batch([dict(reftrack=bad, normvec=g["normvec"], scaling=None, kappa_bound=1.0, w_veh=3.4)],
+                                  objective=engine.OBJ_SHORTEST_PATH)
+    assert st[0] == engine.STATUS_BAD_INPUT
+    with pytest.raises(engine.EngineError, match="normvec is required"):
+        emu.solve_batch([dict(reftrack=g["reftrack"], normvec=None, scaling=None, kappa_bound=1.0, w_veh=3.4)],
+                        objective=engine.OBJ_SHORTEST_PATH)

@@ -333,3 +333,57 @@ def test_pinned_variables_and_bad_input(gpu_engine, golden):
     assert abs(al[0][5] - 0.2) < 1e-12 and abs(al[0][40] + 0.35) < 1e-12
     assert abs(curv[0] - err_ref) < CURV_TOL
     assert np.max(np.abs(al[2] - g["alpha"])) < ALPHA_TOL
+
+
+def _sp_kkt(ref, nv, w_veh, alpha):
+    """Projected-gradient certificate of the shortest-path QP from its tridiagonal form (numpy, O(n))."""
+    p = ref[:, :2]
+    hd = 4.0 * np.sum(nv * nv, axis=1)
+    ho = -2.0 * np.sum(nv * np.roll(nv, -1, axis=0), axis=1)
+    g = hd * alpha + ho * np.roll(alpha, -1) + np.roll(ho, 1) * np.roll(alpha, 1) \
+        + 2.0 * np.sum(nv * (2 * p - np.roll(p, 1, axis=0) - np.roll(p, -1, axis=0)), axis=1)
+    lo, hi = -np.maximum(ref[:, 3] - w_veh / 2, 0.001), np.maximum(ref[:, 2] - w_veh / 2, 0.001)
+    at_lo, at_hi = alpha <= lo + 1e-12, alpha >= hi - 1e-12
+    free = ~(at_lo | at_hi)
+    viol = max(float(np.max(np.abs(g[free]), initial=0.0)), float(np.max(-g[at_lo], initial=0.0)),
+               float(np.max(g[at_hi], initial=0.0)))
+    feas = max(float(np.max(lo - alpha)), float(np.max(alpha - hi)))
+    return viol, feas, int(np.count_nonzero(~free))
+
+
+def test_shortest_path_drop_in_matches_golden(golden):
+    """Row f-4: tph.opt_shortest_path drop-in [REF main_globaltraj.py:286-290] on the four reference tracks."""
+    import os
+    z = np.load(os.path.join(os.path.dirname(__file__), "golden", "shortest_path.npz"))
+    for name in ("rounded_rectangle", "handling_track", "modena_2019", "berlin_2018"):
+        g = golden[name]
+        a = tph.opt_shortest_path.opt_shortest_path(reftrack=g["reftrack"], normvectors=g["normvec"],
+                                                    w_veh=float(z["w_veh"]), print_debug=False)
+        assert a.shape == (g["reftrack"].shape[0],)
+        assert np.max(np.abs(a - z[name + "_alpha"])) < ALPHA_TOL
+    with pytest.raises(RuntimeError, match="same as normvectors"):
+        tph.opt_shortest_path.opt_shortest_path(g["reftrack"], g["normvec"][:-1], 3.4)
+
+
+def test_shortest_path_full_size_properties_and_oracle(gpu_engine):
+    """N = 2000 ovals: KKT certificate (numpy, tridiagonal form), feasibility, shorter polygon, batch-order independence;
+    one N = 1000 problem against the dense Goldfarb-Idnani oracle."""
+    from oracle import tph_ref
+    ref, nv, _ = synthetic.oval_batch(8, n=2000, perturb_centreline=True)
+    probs = [dict(reftrack=ref[b], normvec=nv[b], scaling=None, kappa_bound=1.0, w_veh=3.4) for b in range(8)]
+    al, curv, st, info = gpu_engine.solve_batch(probs, objective=engine.OBJ_SHORTEST_PATH)
+    assert np.all(st == 0) and np.all(curv == 0.0)
+    for b in range(8):
+        viol, feas, nact = _sp_kkt(ref[b], nv[b], 3.4, al[b])
+        assert viol < 1e-8 and feas < 1e-12
+        assert nact == info[b]["n_active_box"] and 0 < nact < 2000
+        assert tph_ref.path_length_sq(ref[b], nv[b], al[b]) < tph_ref.path_length_sq(ref[b], nv[b], np.zeros(2000))
+    al2, _, _, _ = gpu_engine.solve_batch(probs[::-1], objective=engine.OBJ_SHORTEST_PATH)
+    for b in range(8):
+        assert np.array_equal(al[b], al2[7 - b])
+    ref1, nv1, _ = synthetic.oval_batch(1, n=1000, first=3, perturb_centreline=True)
+    a_ref = tph_ref.opt_shortest_path(ref1[0], nv1[0], 3.4)
+    a, _, st1, _ = gpu_engine.solve_batch([dict(reftrack=ref1[0], normvec=nv1[0], scaling=None, kappa_bound=1.0,
+                                                w_veh=3.4)], objective=engine.OBJ_SHORTEST_PATH)
+    assert st1[0] == 0
+    assert np.max(np.abs(a[0] - a_ref)) < ALPHA_TOL

@@ -1,5 +1,7 @@
 """CPU tests that pin the oracle against itself and against the committed golden vectors (PARITY UNPINNED by the
 reference: it has no tests; see oracle/tph_ref.py header and SURVEY.md section 8c)."""
+import os
+
 import numpy as np
 import pytest
 
@@ -107,3 +109,36 @@ def test_iqp_golden_shapes(golden):
     assert list(g["iqp_n"]) == [105, 104, 103]
     assert g["iqp_curv_err"][-1] <= 0.01 < g["iqp_curv_err"][-2]
     assert g["iqp_alpha"].shape[0] == g["iqp_reftrack"].shape[0] == g["iqp_normvec"].shape[0] == 103
+
+
+def test_shortest_path_oracle_encodes_the_polygon_length(golden):
+    """Row f-4: the restated H, f of tph.opt_shortest_path are the quadratic form of the sum of squared segment lengths
+    (checked at random shifts), H is the cyclic tridiagonal the device kernel writes entry by entry, and the committed
+    alphas are the oracle's own (KKT certificate) and shorten the polygon."""
+    g = golden["handling_track"]
+    ref, nv = g["reftrack"], g["normvec"]
+    n = ref.shape[0]
+    H, f, G, h = tph_ref.shortest_path_dense(ref, nv, 3.4)
+    rng = np.random.default_rng(5)
+    c0 = tph_ref.path_length_sq(ref, nv, np.zeros(n))
+    for _ in range(3):
+        a = rng.uniform(-2.0, 2.0, n)
+        assert abs(0.5 * a @ H @ a + f @ a + c0 - tph_ref.path_length_sq(ref, nv, a)) < 1e-9 * c0
+    i = np.arange(n)
+    T = np.zeros((n, n))
+    T[i, i] = 4.0 * np.sum(nv * nv, axis=1)
+    off = -2.0 * np.sum(nv * np.roll(nv, -1, axis=0), axis=1)
+    T[i, (i + 1) % n] = off
+    T[(i + 1) % n, i] = off
+    assert np.max(np.abs(H - T)) < 1e-14
+    p = ref[:, :2]
+    assert np.max(np.abs(f - 2.0 * np.sum(nv * (2 * p - np.roll(p, 1, axis=0) - np.roll(p, -1, axis=0)), axis=1))) < 1e-11
+    # narrow stretches are clipped to 1 mm, not rejected
+    _, _, _, h_wide = tph_ref.shortest_path_dense(ref, nv, 50.0)
+    assert np.all(h_wide == 0.001)
+    z = np.load(os.path.join(os.path.dirname(__file__), "golden", "shortest_path.npz"))
+    alpha = tph_ref.opt_shortest_path(ref, nv, float(z["w_veh"]))
+    assert np.max(np.abs(alpha - z["handling_track_alpha"])) < 1e-10
+    kkt = qp_ref.kkt_residuals(H, f, G, h, alpha)
+    assert kkt["stationarity"] < 1e-12 and kkt["primal"] < 1e-12
+    assert tph_ref.path_length_sq(ref, nv, alpha) < c0
