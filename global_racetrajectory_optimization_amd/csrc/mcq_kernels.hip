@@ -783,6 +783,9 @@ __global__ void __launch_bounds__(MCQ_NT) mcq_assemble_sp_kernel(McqBatch B)
 #undef SP_OFF
 }
 
+#ifndef MCQ_IPM_TOL
+#define MCQ_IPM_TOL 1e-10
+#endif
 struct SolveCtx {
     McqDims d;
     McqWork w;
@@ -1485,6 +1488,9 @@ __device__ __noinline__ int factor(const SolveCtx& c, const gdouble* Hsrc, const
 // L rows (64 band entries + the 16 entries of the inverse diagonal tile) and right-hand sides come from an LDS chunk ring
 // (64 rows per chunk) that waves 1..3 keep filled ahead through registers; the same waves fold the border block in:
 // forward they accumulate W'y for t = v_D - W'y, backward they produce the right-hand side y_B - W x_D.
+// Band mask of the sweeps: an entry beyond the band keeps its low dword and loses its high one -- a denormal (< 2.3e-308)
+// stands in for the zero, one v_cndmask_b32 per entry instead of two on wave 0's serial chain.
+#define BAND_MASK(cond, val) __hiloint2double((cond) ? __double2hiint(val) : 0, __double2loint(val))
 #define LD_THREADS (MCQ_NT - 64)
 #define LD_PAIRS (CH * CLD / 2)                                 /* 16-byte items of a chunk's L rows */
 #define LD_ITEMS ((LD_PAIRS + LD_THREADS - 1) / LD_THREADS)
@@ -1563,43 +1569,65 @@ __device__ __noinline__ void sweep_fwd_wave0(const SolveCtx& c, gdouble* v)
     double* rring = g_sm + SM_RHS;
     double* vring = g_sm + SM_VR;
     const int nch = (ni + CH - 1) / CH;
+    // lane (row l15, group l4) of tile J covers source tile K = J - 4 + l4: columns 16K + cc, band offset k = i - column.
+    // Entries beyond the band (k > 64, group 0 only) are read from the row's inverse-tile slots and masked; first-chunk
+    // columns < 0 hit masked zeros.  All LDS offsets are compile-time constants off two bases.
+    const int kb = TB * (4 - l4) + l15;          // k for cc = 0
+    // The 32 LDS reads of a tile that do not depend on the tile before it -- its band entries and its row of the inverse
+    // tile -- are issued one tile ahead into a second register set (FW_LOAD of tile J + 1 before the chain of tile J: the
+    // next chunk is resident one step ahead), so that a step's chain starts at the reads of the unknowns just produced.
+    // base at the LOWEST address of the 16 entries: ds_read offsets are unsigned immediates, so only then do all 16 reads
+    // hang off one address register and issue back to back:  lk[TB - 1 - cc] = L[i, i - (kb - cc)]
+#define FW_LOAD(J_, LB_, MB_)                                                                                  \
+    {                                                                                                          \
+        const double* lr_ = LROW((J_) * TB + l15);                                                             \
+        const double* lk_ = lr_ + kb - TB;                                                                     \
+        _Pragma("unroll") for (int cc = 0; cc < TB; ++cc) {                                                    \
+            LB_[cc] = lk_[TB - 1 - cc];                                                                        \
+            MB_[cc] = lr_[MCQ_BH_MAX + cc];                                                                    \
+        }                                                                                                      \
+    }
+#define FW_STEP(J_, LB_, MB_)                                                                                  \
+    {                                                                                                          \
+        const int i = (J_) * TB + l15;                                                                         \
+        const double* vs = vring + ((((J_) - 4 + l4) * TB) & (VRING - 1));   /* 16 consecutive ring slots */    \
+        double a0 = 0.0, a1 = 0.0;                                                                             \
+        _Pragma("unroll") for (int cc = 0; cc < TB; cc += 2) {                                                 \
+            a0 += BAND_MASK(kb - cc <= MCQ_BH_MAX, LB_[cc]) * vs[cc];                                       \
+            a1 += BAND_MASK(kb - cc - 1 <= MCQ_BH_MAX, LB_[cc + 1]) * vs[cc + 1];                           \
+        }                                                                                                      \
+        const double sv = RHSV(i) - row4_sum_low16(a0 + a1);   /* valid in lanes 0..15: the ones the broadcasts read */ \
+        double y0 = 0.0, y1 = 0.0;                                                                             \
+        _Pragma("unroll") for (int cc = 0; cc < TB; cc += 2) {   /* row l15 of the inverse tile */              \
+            y0 += MB_[cc] * bcast_lane(sv, cc);                                                                \
+            y1 += MB_[cc + 1] * bcast_lane(sv, cc + 1);                                                        \
+        }                                                                                                      \
+        const double y = y0 + y1;                                                                              \
+        __builtin_amdgcn_wave_barrier();                                                                       \
+        if (l4 == 0) {                                                                                         \
+            vring[i & (VRING - 1)] = y;                                                                        \
+            RHSV(i) = y;                                                                                       \
+            if (i < ni) v[i] = y;                                                                              \
+        }                                                                                                      \
+        __builtin_amdgcn_wave_barrier();                                                                       \
+    }
+    double la[TB], ma[TB], lb[TB], mb[TB];
+    static_assert(CH / TB == 4, "the sweeps are unrolled over the four tiles of a chunk");
+    FW_LOAD(0, la, ma)
     for (int cq = 0; cq < nch; ++cq) {
-            for (int J = cq * (CH / TB); J < (cq + 1) * (CH / TB); ++J) {
-                const int i = J * TB + l15;
-                const double* lr = LROW(i);
-                // lane (row l15, group l4) covers source tile K = J - 4 + l4: columns 16K + cc, band offset k = i - column.
-                // Entries beyond the band (k > 64, group 0 only) are read from the row's inverse-tile slots and masked;
-                // first-chunk columns < 0 hit masked zeros.  All LDS offsets are compile-time constants off two bases.
-                const int kb = TB * (4 - l4) + l15;          // k for cc = 0
-                // base at the LOWEST address of the 16 entries: ds_read offsets are unsigned immediates, so only then do all
-                // 16 reads hang off one address register and issue back to back
-                const double* lk = lr + kb - TB;             // lk[TB - 1 - cc] = L[i, i - (kb - cc)]
-                const double* vs = vring + (((J - 4 + l4) * TB) & (VRING - 1));      // 16 consecutive ring slots (no wrap inside)
-                double a0 = 0.0, a1 = 0.0;
-#pragma unroll
-                for (int cc = 0; cc < TB; cc += 2) {
-                    const double l0 = lk[TB - 1 - cc], l1 = lk[TB - 2 - cc];
-                    a0 += (kb - cc <= MCQ_BH_MAX ? l0 : 0.0) * vs[cc];
-                    a1 += (kb - cc - 1 <= MCQ_BH_MAX ? l1 : 0.0) * vs[cc + 1];
-                }
-                const double sv = RHSV(i) - row4_sum_low16(a0 + a1);       // valid in lanes 0..15: the ones the broadcasts read
-                double y0 = 0.0, y1 = 0.0;
-#pragma unroll
-                for (int cc = 0; cc < TB; cc += 2) {         // row l15 of the inverse tile
-                    y0 += lr[MCQ_BH_MAX + cc] * bcast_lane(sv, cc);
-                    y1 += lr[MCQ_BH_MAX + cc + 1] * bcast_lane(sv, cc + 1);
-                }
-                const double y = y0 + y1;
-                __builtin_amdgcn_wave_barrier();
-                if (l4 == 0) {
-                    vring[i & (VRING - 1)] = y;
-                    RHSV(i) = y;
-                    if (i < ni) v[i] = y;
-                }
-                __builtin_amdgcn_wave_barrier();
-            }
+        const int J0 = cq * (CH / TB);
+        FW_LOAD(J0 + 1, lb, mb)
+        FW_STEP(J0, la, ma)
+        FW_LOAD(J0 + 2, la, ma)
+        FW_STEP(J0 + 1, lb, mb)
+        FW_LOAD(J0 + 3, lb, mb)
+        FW_STEP(J0 + 2, la, ma)
+        FW_LOAD(J0 + 4, la, ma)          // first tile of the next chunk (resident; past the end: unused ring contents)
+        FW_STEP(J0 + 3, lb, mb)
         lds_barrier();
     }
+#undef FW_LOAD
+#undef FW_STEP
 }
 
 __device__ __noinline__ void sweep_bwd_wave0(const SolveCtx& c, gdouble* v)
@@ -1611,41 +1639,71 @@ __device__ __noinline__ void sweep_bwd_wave0(const SolveCtx& c, gdouble* v)
     double* rring = g_sm + SM_RHS;
     double* vring = g_sm + SM_VR;
     const int nch = (ni + CH - 1) / CH;
-    for (int cq = nch - 1; cq >= 0; --cq) {
-                for (int J = (cq + 1) * (CH / TB) - 1; J >= cq * (CH / TB); --J) {
-                const int j = J * TB + l15;               // unknown handled by this lane's row group
-                // lane (column l15, group l4) covers the rows of tile K = J + 1 + l4: i = 16K + rr, offset k = i - j.
-                // A tile never straddles a chunk: its 16 rows are 16 consecutive LDS rows, so every offset below is a
-                // compile-time constant off one base (entries with k > 64 land in inverse-tile slots and are masked).
-                const int i0 = (J + 1 + l4) * TB;
-                const int kb = TB * (l4 + 1) - l15;       // k for rr = 0
-                const double* lk = LROW(i0) + kb - 1;     // lk[rr (CLD + 1)] = L[i0 + rr, j]
-                const double* vs = vring + (i0 & (VRING - 1));
-                double a0 = 0.0, a1 = 0.0;
-#pragma unroll
-                for (int rr = 0; rr < TB; rr += 2) {
-                    const double l0 = lk[rr * (CLD + 1)], l1 = lk[(rr + 1) * (CLD + 1)];
-                    a0 += (kb + rr <= MCQ_BH_MAX ? l0 : 0.0) * vs[rr];
-                    a1 += (kb + rr + 1 <= MCQ_BH_MAX ? l1 : 0.0) * vs[rr + 1];
-                }
-                const double sv = RHSV(j) - row4_sum_low16(a0 + a1);   // valid in lanes 0..15: the ones the broadcasts read
-                const double* mi = LROW(J * TB) + MCQ_BH_MAX + l15;       // column l15 of the inverse tile, row stride CLD
-                double x0 = 0.0, x1 = 0.0;
-#pragma unroll
-                for (int rr = 0; rr < TB; rr += 2) {
-                    x0 += mi[rr * CLD] * bcast_lane(sv, rr);
-                    x1 += mi[(rr + 1) * CLD] * bcast_lane(sv, rr + 1);
-                }
-                const double x = x0 + x1;
-                __builtin_amdgcn_wave_barrier();
-                if (l4 == 0) {
-                    vring[j & (VRING - 1)] = x;
-                    if (j < ni) v[j] = x;
-                }
-                __builtin_amdgcn_wave_barrier();
-            }
-        lds_barrier();
+    // lane (column l15, group l4) of tile J covers the rows of tile K = J + 1 + l4: i = 16K + rr, offset k = i - j.
+    // A tile never straddles a chunk: its 16 rows are 16 consecutive LDS rows, so every offset below is a compile-time
+    // constant off one base (entries with k > 64 land in inverse-tile slots and are masked).
+    const int kb = TB * (l4 + 1) - l15;       // k for rr = 0
+    // As forward, the reads that do not depend on the tile solved just before are issued one tile ahead: the band entries
+    // (rows of tiles already solved: resident) always, the tile's own inverse only inside a chunk -- the chunk below is still
+    // being committed by the loader waves until the barrier.
+#define BW_LOADL(J_, LB_)                                                                                      \
+    {                                                                                                          \
+        const double* lk_ = LROW(((J_) + 1 + l4) * TB) + kb - 1;     /* lk[rr (CLD + 1)] = L[i0 + rr, j] */      \
+        _Pragma("unroll") for (int rr = 0; rr < TB; ++rr) LB_[rr] = lk_[rr * (CLD + 1)];                       \
     }
+#define BW_LOADM(J_, MB_)                                                                                      \
+    {                                                                                                          \
+        const double* mi_ = LROW((J_) * TB) + MCQ_BH_MAX + l15;      /* column l15 of the inverse tile */        \
+        _Pragma("unroll") for (int rr = 0; rr < TB; ++rr) MB_[rr] = mi_[rr * CLD];                             \
+    }
+#define BW_STEP(J_, LB_, MB_)                                                                                  \
+    {                                                                                                          \
+        const int j = (J_) * TB + l15;               /* unknown handled by this lane's row group */             \
+        const double* vs = vring + ((((J_) + 1 + l4) * TB) & (VRING - 1));                                     \
+        double a0 = 0.0, a1 = 0.0;                                                                             \
+        _Pragma("unroll") for (int rr = 0; rr < TB; rr += 2) {                                                 \
+            a0 += BAND_MASK(kb + rr <= MCQ_BH_MAX, LB_[rr]) * vs[rr];                                       \
+            a1 += BAND_MASK(kb + rr + 1 <= MCQ_BH_MAX, LB_[rr + 1]) * vs[rr + 1];                           \
+        }                                                                                                      \
+        const double sv = RHSV(j) - row4_sum_low16(a0 + a1);   /* valid in lanes 0..15 */                       \
+        double x0 = 0.0, x1 = 0.0;                                                                             \
+        _Pragma("unroll") for (int rr = 0; rr < TB; rr += 2) {                                                 \
+            x0 += MB_[rr] * bcast_lane(sv, rr);                                                                \
+            x1 += MB_[rr + 1] * bcast_lane(sv, rr + 1);                                                        \
+        }                                                                                                      \
+        const double x = x0 + x1;                                                                              \
+        __builtin_amdgcn_wave_barrier();                                                                       \
+        if (l4 == 0) {                                                                                         \
+            vring[j & (VRING - 1)] = x;                                                                        \
+            if (j < ni) v[j] = x;                                                                              \
+        }                                                                                                      \
+        __builtin_amdgcn_wave_barrier();                                                                       \
+    }
+    double la[TB], ma[TB], lb[TB], mb[TB];
+    if (nch > 0) {
+        const int Jt = nch * (CH / TB) - 1;
+        BW_LOADL(Jt, la)
+        BW_LOADM(Jt, ma)
+    }
+    for (int cq = nch - 1; cq >= 0; --cq) {
+        const int J3 = cq * (CH / TB) + 3;
+        BW_LOADL(J3 - 1, lb)
+        BW_LOADM(J3 - 1, mb)
+        BW_STEP(J3, la, ma)
+        BW_LOADL(J3 - 2, la)
+        BW_LOADM(J3 - 2, ma)
+        BW_STEP(J3 - 1, lb, mb)
+        BW_LOADL(J3 - 3, lb)
+        BW_LOADM(J3 - 3, mb)
+        BW_STEP(J3 - 2, la, ma)
+        if (cq > 0) BW_LOADL(J3 - 4, la)
+        BW_STEP(J3 - 3, lb, mb)
+        lds_barrier();
+        if (cq > 0) BW_LOADM(J3 - 4, ma)
+    }
+#undef BW_LOADL
+#undef BW_LOADM
+#undef BW_STEP
 }
 
 __device__ __noinline__ void solve(const SolveCtx& c, gdouble* v)
@@ -2637,7 +2695,7 @@ __global__ void __launch_bounds__(MCQ_NT) mcq_solve_kernel(McqBatch B)
     int ipm_iters = 0, as_iters = 0, it2 = 0, nact_kappa = 0;
     double kkt = 0.0;
     const bool small = n <= IPB_E * MCQ_NT;
-    int status = small ? ipm_box(c, B, sc, ipm_iters, 1e-10, false) : ipm(c, B, false, sc, ipm_iters);
+    int status = small ? ipm_box(c, B, sc, ipm_iters, MCQ_IPM_TOL, false) : ipm(c, B, false, sc, ipm_iters);
     int nk_dummy = 0;
     if (status == MCQ_OK && small) {
         // Two attempts.  The pairs at mu = 1e-10 identify the active set of all but the degenerate / extremely
