@@ -186,7 +186,7 @@ def main():
                        "kernel_ms": {k: float(np.mean([m[k] for m in solve_ms])) for k in ("assemble", "gram", "solve", "total")},
                        "workspace_GB": eng.workspace_bytes() / 1e9,
                        "solver_phase_ms_per_problem": {k: float(info["ticks"][:, j].mean()) / 1e5 for j, k in
-                                                       enumerate(("factor", "solve", "gradient", "kernel", "f_diag", "f_panel", "f_emit", "f_trail"))}},
+                                                       enumerate(("factor", "solve", "gradient", "kernel", "sweep_fwd", "sweep_bwd"))}},
             "roofline": {"bound": "hbm", "kernel": "mcq_solve_kernel", "achieved": achieved, "peak": HBM_PEAK_GBS,
                          "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": measured_traffic(),
                          "algorithmic_bytes_per_launch": alg, "kernel_ms": k_ms},

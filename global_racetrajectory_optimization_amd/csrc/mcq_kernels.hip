@@ -801,6 +801,8 @@ struct SolveCtx {
 #define MCQ_FINE_TIMERS 0
 #endif
 #define FTICK() (MCQ_FINE_TIMERS ? TICK() : 0LL)
+// default build: ticks[4] / ticks[5] = wave 0's forward / backward interior sweeps (part of ticks[1]), two samples per solve
+#define STICK() (MCQ_FINE_TIMERS ? 0LL : TICK())
 
 // ---- bordered-band Cholesky of  M = H + diag(sig)  with rows/cols of pinned variables replaced by identity ----------
 // Blocked right-looking factorisation, 16 columns per step, on an LDS window of 5 x 5 band tiles + 6 x 4 border tiles:
@@ -1582,10 +1584,8 @@ __device__ __noinline__ void sweep_fwd_wave0(const SolveCtx& c, gdouble* v)
     {                                                                                                          \
         const double* lr_ = LROW((J_) * TB + l15);                                                             \
         const double* lk_ = lr_ + kb - TB;                                                                     \
-        _Pragma("unroll") for (int cc = 0; cc < TB; ++cc) {                                                    \
-            LB_[cc] = lk_[TB - 1 - cc];                                                                        \
-            MB_[cc] = lr_[MCQ_BH_MAX + cc];                                                                    \
-        }                                                                                                      \
+        _Pragma("unroll") for (int cc = 0; cc < TB; ++cc) LB_[cc] = lk_[TB - 1 - cc];                          \
+        _Pragma("unroll") for (int k = 0; k < 4; ++k) MB_[k] = lr_[MCQ_BH_MAX + 4 * l4 + k];                   \
     }
 #define FW_STEP(J_, LB_, MB_)                                                                                  \
     {                                                                                                          \
@@ -1596,13 +1596,15 @@ __device__ __noinline__ void sweep_fwd_wave0(const SolveCtx& c, gdouble* v)
             a0 += BAND_MASK(kb - cc <= MCQ_BH_MAX, LB_[cc]) * vs[cc];                                       \
             a1 += BAND_MASK(kb - cc - 1 <= MCQ_BH_MAX, LB_[cc + 1]) * vs[cc + 1];                           \
         }                                                                                                      \
-        const double sv = RHSV(i) - row4_sum_low16(a0 + a1);   /* valid in lanes 0..15: the ones the broadcasts read */ \
-        double y0 = 0.0, y1 = 0.0;                                                                             \
-        _Pragma("unroll") for (int cc = 0; cc < TB; cc += 2) {   /* row l15 of the inverse tile */              \
-            y0 += MB_[cc] * bcast_lane(sv, cc);                                                                \
-            y1 += MB_[cc + 1] * bcast_lane(sv, cc + 1);                                                        \
-        }                                                                                                      \
-        const double y = y0 + y1;                                                                              \
+        const double sv = RHSV(i) - row4_sum_low16(a0 + a1);   /* valid in lanes 0..15 */                       \
+        /* y = M_J sv, all 64 lanes: group l4 takes columns 4 l4 .. 4 l4 + 3 of row l15 (sv through a 16-double LDS slot,   \
+           read back as one group-uniform 32-byte piece), a second four-way sum -- 21 instructions where 32 v_readlane     \
+           broadcasts and 16 FMAs on a quarter of the lanes were: the sweeps are bound by wave 0's instruction issue */     \
+        __builtin_amdgcn_wave_barrier();                                                                       \
+        if (lane < TB) svx[lane] = sv;                                                                         \
+        __builtin_amdgcn_wave_barrier();                                                                       \
+        const double y = row4_sum_low16((MB_[0] * svx[4 * l4] + MB_[1] * svx[4 * l4 + 1])                      \
+                                        + (MB_[2] * svx[4 * l4 + 2] + MB_[3] * svx[4 * l4 + 3]));              \
         __builtin_amdgcn_wave_barrier();                                                                       \
         if (l4 == 0) {                                                                                         \
             vring[i & (VRING - 1)] = y;                                                                        \
@@ -1611,7 +1613,8 @@ __device__ __noinline__ void sweep_fwd_wave0(const SolveCtx& c, gdouble* v)
         }                                                                                                      \
         __builtin_amdgcn_wave_barrier();                                                                       \
     }
-    double la[TB], ma[TB], lb[TB], mb[TB];
+    double la[TB], ma[4], lb[TB], mb[4];
+    double* svx = g_sm + SM_RED;                 // 16 doubles: the tile's right-hand side on its way to all four lane groups
     static_assert(CH / TB == 4, "the sweeps are unrolled over the four tiles of a chunk");
     FW_LOAD(0, la, ma)
     for (int cq = 0; cq < nch; ++cq) {
@@ -1654,7 +1657,7 @@ __device__ __noinline__ void sweep_bwd_wave0(const SolveCtx& c, gdouble* v)
 #define BW_LOADM(J_, MB_)                                                                                      \
     {                                                                                                          \
         const double* mi_ = LROW((J_) * TB) + MCQ_BH_MAX + l15;      /* column l15 of the inverse tile */        \
-        _Pragma("unroll") for (int rr = 0; rr < TB; ++rr) MB_[rr] = mi_[rr * CLD];                             \
+        _Pragma("unroll") for (int k = 0; k < 4; ++k) MB_[k] = mi_[(4 * l4 + k) * CLD];                        \
     }
 #define BW_STEP(J_, LB_, MB_)                                                                                  \
     {                                                                                                          \
@@ -1666,12 +1669,12 @@ __device__ __noinline__ void sweep_bwd_wave0(const SolveCtx& c, gdouble* v)
             a1 += BAND_MASK(kb + rr + 1 <= MCQ_BH_MAX, LB_[rr + 1]) * vs[rr + 1];                           \
         }                                                                                                      \
         const double sv = RHSV(j) - row4_sum_low16(a0 + a1);   /* valid in lanes 0..15 */                       \
-        double x0 = 0.0, x1 = 0.0;                                                                             \
-        _Pragma("unroll") for (int rr = 0; rr < TB; rr += 2) {                                                 \
-            x0 += MB_[rr] * bcast_lane(sv, rr);                                                                \
-            x1 += MB_[rr + 1] * bcast_lane(sv, rr + 1);                                                        \
-        }                                                                                                      \
-        const double x = x0 + x1;                                                                              \
+        /* x = M_J' sv over all 64 lanes: group l4 takes rows 4 l4 .. 4 l4 + 3 of column l15 (see the forward sweep) */    \
+        __builtin_amdgcn_wave_barrier();                                                                       \
+        if (lane < TB) svx[lane] = sv;                                                                         \
+        __builtin_amdgcn_wave_barrier();                                                                       \
+        const double x = row4_sum_low16((MB_[0] * svx[4 * l4] + MB_[1] * svx[4 * l4 + 1])                      \
+                                        + (MB_[2] * svx[4 * l4 + 2] + MB_[3] * svx[4 * l4 + 3]));              \
         __builtin_amdgcn_wave_barrier();                                                                       \
         if (l4 == 0) {                                                                                         \
             vring[j & (VRING - 1)] = x;                                                                        \
@@ -1679,7 +1682,8 @@ __device__ __noinline__ void sweep_bwd_wave0(const SolveCtx& c, gdouble* v)
         }                                                                                                      \
         __builtin_amdgcn_wave_barrier();                                                                       \
     }
-    double la[TB], ma[TB], lb[TB], mb[TB];
+    double la[TB], ma[4], lb[TB], mb[4];
+    double* svx = g_sm + SM_RED;
     if (nch > 0) {
         const int Jt = nch * (CH / TB) - 1;
         BW_LOADL(Jt, la)
@@ -1764,7 +1768,7 @@ __device__ __noinline__ void solve(const SolveCtx& c, gdouble* v)
         chunk_fetch(L, v, ni, b, 2, 2, lt, goff, regs, rreg);
     }
     __syncthreads();
-    if (wv == 0) sweep_fwd_wave0(c, v);
+    if (wv == 0) { const long long ts_ = STICK(); sweep_fwd_wave0(c, v); c.tk[4] += STICK() - ts_; }
     else {
         for (int cq = 0; cq < nch; ++cq) {
             chunk_commit(chunk, rring, cq + 2, cq + 2, lt, regs, rreg);
@@ -1858,7 +1862,7 @@ __device__ __noinline__ void solve(const SolveCtx& c, gdouble* v)
             WFETCH(cl - 1)
         }
         __syncthreads();
-        if (wv == 0) sweep_bwd_wave0(c, v);
+        if (wv == 0) { const long long ts_ = STICK(); sweep_bwd_wave0(c, v); c.tk[5] += STICK() - ts_; }
         else {
             for (int cq = cl; cq >= 0; --cq) {
                 chunk_commit(chunk, rring, cq - 1, cq - 2, lt, regs, rreg);

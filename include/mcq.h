@@ -92,7 +92,8 @@ typedef struct {
     double kkt_res;     /* max free-gradient magnitude relative to max |f| */
     /* device wall-clock (s_memrealtime, 100 MHz ticks) spent by this problem's workgroup in the phases of the solver
      * kernel: [0] banded factorisations, [1] triangular solves, [2] gradient band products, [3] whole kernel,
-     * [4..7] inside the factorisation: diagonal tile, panel, write-out of L, trailing update + window refill */
+     * [4] / [5] forward / backward interior sweeps of the triangular solves as wave 0 sees them (part of [1]);
+     * a -DMCQ_FINE_TIMERS build reports the inside of the factorisation in [4..6] instead (phase 1, phase 2, tail) */
     long long ticks[8];
     int refine_rounds;  /* fp64 refinement rounds run on the final working set (<= opts.refine_steps) */
     int second_attempt; /* 1 if the active-set phase ran out of its first budget and the interior point was resumed to
