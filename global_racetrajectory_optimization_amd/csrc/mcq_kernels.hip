@@ -1770,10 +1770,10 @@ __device__ __noinline__ void solve(const SolveCtx& c, gdouble* v)
     __syncthreads();
     if (wv == 0) { const long long ts_ = STICK(); sweep_fwd_wave0(c, v); c.tk[4] += STICK() - ts_; }
     else {
+        // border right-hand side, fused: t -= W' y for the rows solved in the previous step (W rows in registers)
         for (int cq = 0; cq < nch; ++cq) {
             chunk_commit(chunk, rring, cq + 2, cq + 2, lt, regs, rreg);
             chunk_fetch(L, v, ni, b, cq + 3, cq + 3, lt, goff, regs, rreg);
-            // border right-hand side, fused: t -= W' y for the rows solved in the previous step (W rows in registers)
             if (cq >= 1) { TACC_ADD(cq - 1) }
             WFETCH(cq)
             lds_barrier();
@@ -1864,11 +1864,13 @@ __device__ __noinline__ void solve(const SolveCtx& c, gdouble* v)
         __syncthreads();
         if (wv == 0) { const long long ts_ = STICK(); sweep_bwd_wave0(c, v); c.tk[5] += STICK() - ts_; }
         else {
+            // W rows first: fetched at the top of the previous step, consumed at the top of this one and re-fetched at once, they
+            // get a whole step in flight like the L rows (behind the commit they had half of one; forward the same order loses)
             for (int cq = cl; cq >= 0; --cq) {
-                chunk_commit(chunk, rring, cq - 1, cq - 2, lt, regs, rreg);
-                chunk_fetch(L, v, ni, b, cq - 2, cq - 3, lt, goff, regs, rreg);
                 RHS_SUB(cq - 1)
                 WFETCH(cq - 2)
+                chunk_commit(chunk, rring, cq - 1, cq - 2, lt, regs, rreg);
+                chunk_fetch(L, v, ni, b, cq - 2, cq - 3, lt, goff, regs, rreg);
                 lds_barrier();
             }
         }
