@@ -8,7 +8,12 @@ batch of 1024 synthetic perturbed-oval reference tracks (BASELINE config 3 gener
 are already resident in HBM; with N > 1 GPUs every rank solves its own 1024 tracks (weak scaling, no data-path
 collective inside the solve) and ONE RCCL all-gather collects the alpha vectors (north_star) inside the timed region.
 
-  python bench.py [--gpus N] [--steps K] [--warmup W] [--batch B] [--n N_WAYPOINTS] [--no-cpu-baseline]
+  python bench.py [--gpus N] [--steps K] [--warmup W] [--batch B] [--n N_WAYPOINTS] [--io f64|f32] [--perturb-centreline]
+                  [--no-cpu-baseline]
+
+--io f32 (BASELINE config 5's boundary): tracks and alpha live in HBM as float and the all-gather moves float alpha; the
+arithmetic stays fp64 (`dtype` in the JSON line is the arithmetic type).  Config 5 on one node of 8 GPUs is
+`--gpus 8 --batch 8192 --io f32 --perturb-centreline` (65536 synthetic reference tracks, 69 GB of workspace per GPU).
 
 Prints ONE JSON line on rank 0.
 """
@@ -96,6 +101,8 @@ def main():
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--batch", type=int, default=1024)
     ap.add_argument("--n", type=int, default=2000)
+    ap.add_argument("--io", choices=("f64", "f32"), default="f64")
+    ap.add_argument("--perturb-centreline", action="store_true")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
 
@@ -116,22 +123,28 @@ def main():
         dist.init_process_group(backend="nccl", rank=rank, world_size=world, device_id=dev)
 
     B, n = args.batch, args.n
-    ref_h, nv_h, sc_h = synthetic.oval_batch(B, n=n, first=rank * B)
-    d_ref = torch.from_numpy(ref_h).to(dev)
-    d_nv = torch.from_numpy(nv_h).to(dev)
-    d_sc = torch.from_numpy(sc_h).to(dev)
-    d_alpha = torch.zeros((B, n), dtype=torch.float64, device=dev)
+    ref_h, nv_h, sc_h = synthetic.oval_batch(B, n=n, first=rank * B, perturb_centreline=args.perturb_centreline)
+    f32 = args.io == "f32"
+    io_t = torch.float32 if f32 else torch.float64
+    d_ref = torch.from_numpy(ref_h).to(dev).to(io_t)
+    d_nv = torch.from_numpy(nv_h).to(dev).to(io_t)
+    d_sc = torch.from_numpy(sc_h).to(dev).to(io_t)
+    d_alpha = torch.zeros((B, n), dtype=io_t, device=dev)
     d_curv = torch.zeros((B,), dtype=torch.float64, device=dev)
     d_status = torch.zeros((B,), dtype=torch.int32, device=dev)
     d_info = torch.zeros((B, INFO_DTYPE.itemsize), dtype=torch.uint8, device=dev)
-    d_all = torch.zeros((world * B, n), dtype=torch.float64, device=dev) if world > 1 else None
+    d_all = torch.zeros((world * B, n), dtype=io_t, device=dev) if world > 1 else None
 
     eng = engine.Engine(local_rank)
     solve_ms = []
 
     def step(record):
-        eng.solve_device(B, n, d_ref.data_ptr(), d_nv.data_ptr(), d_sc.data_ptr(), KAPPA_BOUND, W_VEH,
-                         d_alpha.data_ptr(), d_curv.data_ptr(), d_status.data_ptr(), d_info.data_ptr())
+        if f32:     # float normals are unit vectors only to 6e-8: let the engine derive them (and the scalings) in fp64
+            eng.solve_device_f32(B, n, d_ref.data_ptr(), None, None, KAPPA_BOUND, W_VEH,
+                                 d_alpha.data_ptr(), d_curv.data_ptr(), d_status.data_ptr(), d_info.data_ptr())
+        else:
+            eng.solve_device(B, n, d_ref.data_ptr(), d_nv.data_ptr(), d_sc.data_ptr(), KAPPA_BOUND, W_VEH,
+                             d_alpha.data_ptr(), d_curv.data_ptr(), d_status.data_ptr(), d_info.data_ptr())
         eng.sync()
         if record:
             solve_ms.append(eng.last_timing_ms())
@@ -161,7 +174,7 @@ def main():
     status = d_status.cpu().numpy()
     info = d_info.cpu().numpy().view(INFO_DTYPE).reshape(B)
     n_bad = int(np.count_nonzero(status))
-    alpha0 = d_alpha[0].cpu().numpy()
+    alpha0 = d_alpha[0].cpu().numpy().astype(np.float64)
     curv0 = float(d_curv[0].item())
 
     if rank == 0:
@@ -177,7 +190,9 @@ def main():
             "config": {"workload": "BASELINE config 3 generator: perturbed 2:1 oval, perimeter 6000 m, N=%d, batch=%d "
                                    "track-width perturbations per GPU, one opt_min_curv pass (assembly + QP + "
                                    "curvature-error check) per track per step; kappa_bound=0.12, w_veh=3.4" % (n, B),
-                       "batch_per_gpu": B, "n_waypoints": n, "collective": "1 all-gather of alpha per step" if world > 1 else "none",
+                       "batch_per_gpu": B, "n_waypoints": n, "io": args.io + (" rows / alpha in HBM, fp64 arithmetic" if f32 else ""),
+                       "centrelines": "perturbed per track" if args.perturb_centreline else "shared",
+                       "collective": "1 all-gather of alpha per step" if world > 1 else "none",
                        "failed_problems": n_bad,
                        "mean_ipm_iters": float(info["ipm_iters"].mean()), "mean_as_iters": float(info["as_iters"].mean()),
                        "mean_active_box_rows": float(info["n_active_box"].mean()),
@@ -192,6 +207,8 @@ def main():
                          "algorithmic_bytes_per_launch": alg, "kernel_ms": k_ms},
         }
         if world == 1 and not args.no_cpu_baseline:
+            if f32:     # the baseline solves the rows the engine saw
+                ref_h = ref_h.astype(np.float32).astype(np.float64)
             a_cpu, err_cpu, t_cpu, k_cpu = cpu_baseline(ref_h, nv_h, sc_h)
             out["cpu_baseline"] = {"value": k_cpu / t_cpu, "unit": "solves/s", "cores": os.cpu_count(), "kind": "port",
                                    "sample": "%d of the %d N=%d problems: dense-faithful numpy assembly (BLAS on all "

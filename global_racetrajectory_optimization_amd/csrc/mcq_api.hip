@@ -238,6 +238,58 @@ extern "C" int mcq_solve_device(mcq_handle* h, int batch, int n, const double* r
     return launch(h, B, o);
 }
 
+static int convert_launch(mcq_handle* h, const float* src, double* dst, size_t count)
+{
+    const unsigned blocks = (unsigned)((count / 4 + 255) / 256 < 4096 ? (count / 4 + 255) / 256 + 1 : 4096);
+    hipLaunchKernelGGL(mcq_widen_kernel, dim3(blocks), dim3(256), 0, h->stream, src, dst, count);
+    HIP_TRY(hipGetLastError());
+    return 0;
+}
+
+// fp32 at the boundary, fp64 inside (BASELINE config 5): the float rows are widened into the handle's staging buffers, the
+// fp64 engine runs unchanged, alpha is narrowed on the way out.  The conversions stream 28 + 12 bytes per waypoint next
+// to the ~93 KB per waypoint the solver moves: not measurable.
+extern "C" int mcq_solve_device_f32(mcq_handle* h, int batch, int n, const float* reftrack, const float* normvec,
+                                    const float* scaling, double kappa_bound, double w_veh, const mcq_opts* opts,
+                                    float* alpha_out, double* curv_err_out, int* status_out, mcq_info* info_out)
+{
+    if (!h || batch <= 0 || n <= 0 || !reftrack || !alpha_out || !curv_err_out || !status_out) {
+        g_err = "mcq_solve_device_f32: bad argument";
+        return MCQ_E_ARG;
+    }
+    HIP_TRY(hipSetDevice(h->device));
+    const mcq_opts o = resolve_opts(opts);
+    int rc = ensure_ws(h, (size_t)batch, (size_t)n);
+    if (rc) return rc;
+    rc = ensure_stage(h, (size_t)batch, (size_t)n);
+    if (rc) return rc;
+    const size_t elems = (size_t)batch * n;
+    rc = convert_launch(h, reftrack, h->d_ref, elems * 4);
+    if (rc) return rc;
+    if (normvec) { rc = convert_launch(h, normvec, h->d_nv, elems * 2); if (rc) return rc; }
+    if (scaling) { rc = convert_launch(h, scaling, h->d_sc, elems); if (rc) return rc; }
+    McqBatch B;
+    memset(&B, 0, sizeof(B));
+    B.batch = batch;
+    B.n = n;
+    B.nmax = n;
+    B.ref = h->d_ref;
+    B.nv = normvec ? h->d_nv : nullptr;
+    B.sc = scaling ? h->d_sc : nullptr;
+    B.alpha = h->d_alpha;
+    B.curv_err = curv_err_out;
+    B.status = status_out;
+    B.info = info_out;
+    B.kappa_bound = kappa_bound;
+    B.w_veh = w_veh;
+    rc = launch(h, B, o);
+    if (rc) return rc;
+    const unsigned blocks = (unsigned)((elems / 4 + 255) / 256 < 4096 ? (elems / 4 + 255) / 256 + 1 : 4096);
+    hipLaunchKernelGGL(mcq_narrow_kernel, dim3(blocks), dim3(256), 0, h->stream, (const double*)h->d_alpha, alpha_out, elems);
+    HIP_TRY(hipGetLastError());
+    return 0;
+}
+
 extern "C" int mcq_solve_device_ragged(mcq_handle* h, int batch, int nmax, const int* n_list, const double* reftrack,
                                        const double* normvec, const double* scaling, double kappa_bound, double w_veh,
                                        const mcq_opts* opts, double* alpha_out, double* curv_err_out, int* status_out,

@@ -132,6 +132,10 @@ __global__ void mcq_gram_kernel(McqBatch B);
 __global__ void mcq_gram_tile_kernel(McqBatch B);
 __global__ void mcq_solve_kernel(McqBatch B);
 
+/* fp32 boundary (BASELINE config 5): float <-> double streaming conversions around the fp64 engine */
+__global__ void mcq_widen_kernel(const float* src, double* dst, size_t count);
+__global__ void mcq_narrow_kernel(const double* src, float* dst, size_t count);
+
 size_t mcq_solve_lds_bytes();   /* static LDS of the solver kernel (reporting only) */
 
 /* ---- IQP glue on the device: raceline = refline + alpha * normal, closed spline through it

@@ -3125,3 +3125,35 @@ __global__ void __launch_bounds__(64) mcq_vel_profile_kernel(McqVel V)
     }
     V.lap_time[v] = t;
 }
+
+// ---- fp32 boundary (BASELINE config 5): tracks and results stored as float in HBM, every bit of arithmetic still fp64.
+//      cond(H) = 1e9...1e12 rules out fp32 factors; what fp32 buys is half the bytes at the
+//      boundary -- the rows coming in and, above all, the alpha vectors that go through the all-gather.  Plain streaming
+//      kernels: 16-byte loads on the narrow side, grid-stride. ----
+__global__ void mcq_widen_kernel(const float* src, double* dst, size_t count)
+{
+    const size_t stride = (size_t)gridDim.x * blockDim.x;
+    const size_t quads = count / 4;
+    for (size_t q = (size_t)blockIdx.x * blockDim.x + threadIdx.x; q < quads; q += stride) {
+        const float a = src[4 * q], b = src[4 * q + 1], c = src[4 * q + 2], d = src[4 * q + 3];
+        dst[4 * q] = (double)a;
+        dst[4 * q + 1] = (double)b;
+        dst[4 * q + 2] = (double)c;
+        dst[4 * q + 3] = (double)d;
+    }
+    for (size_t i = 4 * quads + (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < count; i += stride) dst[i] = (double)src[i];
+}
+
+__global__ void mcq_narrow_kernel(const double* src, float* dst, size_t count)
+{
+    const size_t stride = (size_t)gridDim.x * blockDim.x;
+    const size_t quads = count / 4;
+    for (size_t q = (size_t)blockIdx.x * blockDim.x + threadIdx.x; q < quads; q += stride) {
+        const double a = src[4 * q], b = src[4 * q + 1], c = src[4 * q + 2], d = src[4 * q + 3];
+        dst[4 * q] = (float)a;
+        dst[4 * q + 1] = (float)b;
+        dst[4 * q + 2] = (float)c;
+        dst[4 * q + 3] = (float)d;
+    }
+    for (size_t i = 4 * quads + (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < count; i += stride) dst[i] = (float)src[i];
+}

@@ -44,7 +44,7 @@ class McqInfo(ctypes.Structure):
 
 
 EXPORTED_SYMBOLS = ("mcq_create", "mcq_destroy", "mcq_last_error", "mcq_default_opts", "mcq_solve_batch",
-                    "mcq_solve_device", "mcq_solve_device_ragged", "mcq_prep_device", "mcq_relinearise_device",
+                    "mcq_solve_device", "mcq_solve_device_f32", "mcq_solve_device_ragged", "mcq_prep_device", "mcq_relinearise_device",
                     "mcq_vel_profile_device", "mcq_device_alloc",
                     "mcq_device_free", "mcq_copy_to_device", "mcq_copy_to_host", "mcq_sync", "mcq_stream",
                     "mcq_last_timing", "mcq_workspace_bytes")
@@ -76,6 +76,8 @@ def load_library(path=None):
     lib.mcq_solve_device.argtypes = [vp, ctypes.c_int, ctypes.c_int, vp, vp, vp, ctypes.c_double, ctypes.c_double,
                                      ctypes.POINTER(McqOpts), vp, vp, vp, vp]
     lib.mcq_solve_device.restype = ctypes.c_int
+    lib.mcq_solve_device_f32.argtypes = lib.mcq_solve_device.argtypes
+    lib.mcq_solve_device_f32.restype = ctypes.c_int
     lib.mcq_solve_device_ragged.argtypes = [vp, ctypes.c_int, ctypes.c_int, vp, vp, vp, vp, ctypes.c_double,
                                             ctypes.c_double, ctypes.POINTER(McqOpts), vp, vp, vp, vp]
     lib.mcq_solve_device_ragged.restype = ctypes.c_int
@@ -196,6 +198,54 @@ class Engine:
                                        float(kappa_bound), float(w_veh), ctypes.byref(opts), d_alpha, d_curv, d_status,
                                        d_info or None)
         self._check(rc, "mcq_solve_device")
+
+    def solve_device_f32(self, batch, n, d_reftrack, d_normvec, d_scaling, kappa_bound, w_veh, d_alpha, d_curv, d_status,
+                         d_info=None, **opt_kw):
+        """As solve_device with float32 tracks and float32 alpha in HBM (mcq_solve_device_f32: fp32 at the boundary, fp64
+        arithmetic inside; d_curv stays float64).  d_normvec / d_scaling may be None."""
+        opts = self._opts(**opt_kw)
+        rc = self.lib.mcq_solve_device_f32(self.h, int(batch), int(n), d_reftrack, d_normvec or None, d_scaling or None,
+                                           float(kappa_bound), float(w_veh), ctypes.byref(opts), d_alpha, d_curv, d_status,
+                                           d_info or None)
+        self._check(rc, "mcq_solve_device_f32")
+
+    def solve_uniform_f32(self, reftrack, normvec, scaling, kappa_bound, w_veh, **opt_kw):
+        """Host convenience around solve_device_f32 for a uniform-n batch: reftrack [B,n,4] (cast to float32), normvec
+        [B,n,2] or None (derived on the device), scaling [B,n] or None.  Returns (alpha float32 [B,n], curv_err [B],
+        status [B], info [B])."""
+        ref = np.ascontiguousarray(reftrack, dtype=np.float32)
+        bsz, n = ref.shape[0], ref.shape[1]
+        nv = None if normvec is None else np.ascontiguousarray(normvec, dtype=np.float32)
+        sc = None if scaling is None else np.ascontiguousarray(scaling, dtype=np.float32)
+        bufs = []
+
+        def up(a):
+            p = self.alloc(a.nbytes)
+            bufs.append(p)
+            self.upload(p, a)
+            return p
+
+        try:
+            d_ref = up(ref)
+            d_nv = up(nv) if nv is not None else None
+            d_sc = up(sc) if sc is not None else None
+            d_alpha = self.alloc(bsz * n * 4); bufs.append(d_alpha)
+            d_curv = self.alloc(bsz * 8); bufs.append(d_curv)
+            d_status = self.alloc(bsz * 4); bufs.append(d_status)
+            d_info = self.alloc(bsz * ctypes.sizeof(McqInfo)); bufs.append(d_info)
+            self.solve_device_f32(bsz, n, d_ref, d_nv, d_sc, kappa_bound, w_veh, d_alpha, d_curv, d_status, d_info, **opt_kw)
+            self.sync()
+            alpha = self.download(d_alpha, (bsz, n), np.float32)
+            curv = self.download(d_curv, (bsz,), np.float64)
+            status = self.download(d_status, (bsz,), np.int32)
+            raw = self.download(d_info, (bsz * ctypes.sizeof(McqInfo),), np.uint8)
+        finally:
+            for p in bufs:
+                self.free(p)
+        infos = (McqInfo * bsz).from_buffer_copy(raw.tobytes())
+        info = [dict(ipm_iters=i.ipm_iters, as_iters=i.as_iters, n_active_box=i.n_active_box,
+                     n_active_kappa=i.n_active_kappa, kappa_max=i.kappa_max, kkt_res=i.kkt_res) for i in infos]
+        return alpha, curv, status, info
 
     def solve_device_ragged(self, batch, nmax, d_n, d_reftrack, d_normvec, d_scaling, kappa_bound, w_veh, d_alpha,
                             d_curv, d_status, d_info=None, **opt_kw):

@@ -14,18 +14,34 @@ import numpy as np
 from .trajectory_planning_helpers import calc_splines as _cs
 
 
-def oval_centreline(n=2000, perimeter=6000.0, ratio=2.0, amp1=8.0, k1=7, amp2=3.0, k2=23, centre_seed=None):
-    m = 200 * n
-    th = np.linspace(0.0, 2.0 * np.pi, m, endpoint=False)
-    # clockwise or counter-clockwise does not matter to the QP; use counter-clockwise
-    ex, ey = ratio * np.cos(th), np.sin(th)
-    seg = np.hypot(np.diff(np.append(ex, ex[0])), np.diff(np.append(ey, ey[0])))
-    scale = perimeter / float(np.sum(seg))
-    ex, ey, seg = ex * scale, ey * scale, seg * scale
-    s = np.concatenate(([0.0], np.cumsum(seg)[:-1]))
-    tx, ty = np.gradient(ex), np.gradient(ey)
-    tn = np.hypot(tx, ty)
-    nx, ny = ty / tn, -tx / tn
+_BASE = {}
+
+
+def _base_oval(n, perimeter, ratio, fine=200):
+    """Finely sampled 2:1 ellipse scaled to the perimeter, its arclength stations and right-pointing normals (the part
+    of oval_centreline that does not depend on the track; cached)."""
+    key = (int(n), float(perimeter), float(ratio), int(fine))
+    if key not in _BASE:
+        m = fine * n
+        th = np.linspace(0.0, 2.0 * np.pi, m, endpoint=False)
+        # clockwise or counter-clockwise does not matter to the QP; use counter-clockwise
+        ex, ey = ratio * np.cos(th), np.sin(th)
+        seg = np.hypot(np.diff(np.append(ex, ex[0])), np.diff(np.append(ey, ey[0])))
+        scale = perimeter / float(np.sum(seg))
+        ex, ey, seg = ex * scale, ey * scale, seg * scale
+        s = np.concatenate(([0.0], np.cumsum(seg)[:-1]))
+        tx, ty = np.gradient(ex), np.gradient(ey)
+        tn = np.hypot(tx, ty)
+        if len(_BASE) > 3:
+            _BASE.clear()
+        _BASE[key] = (ex, ey, s, ty / tn, -tx / tn)
+    return _BASE[key]
+
+
+def oval_centreline(n=2000, perimeter=6000.0, ratio=2.0, amp1=8.0, k1=7, amp2=3.0, k2=23, centre_seed=None, fine=200):
+    """fine: samples of the underlying curve per waypoint (200 for the shared centreline of configs 3; oval_batch uses 20
+    for per-track centrelines -- config 5 generates 8192 of them per rank -- which moves a waypoint by < 1e-3 m)."""
+    ex, ey, s, nx, ny = _base_oval(n, perimeter, ratio, fine)
     off = amp1 * np.sin(2.0 * np.pi * k1 * s / perimeter) + amp2 * np.sin(2.0 * np.pi * k2 * s / perimeter)
     if centre_seed is not None:
         rng = np.random.default_rng(centre_seed)
@@ -74,7 +90,7 @@ def oval_batch(batch, n=2000, first=0, perturb_centreline=False):
     for i in range(batch):
         b = first + i
         if perturb_centreline:
-            xy0 = oval_centreline(n, centre_seed=b)
+            xy0 = oval_centreline(n, centre_seed=b, fine=20)
             nv0, s0 = prepared_track(xy0)
         ref[i, :, :2] = xy0
         ref[i, :, 2:] = widths(n, b)

@@ -126,6 +126,17 @@ int mcq_solve_device_ragged(mcq_handle* h, int batch, int nmax, const int* n_lis
                             const mcq_opts* opts, double* alpha_out, double* curv_err_out, int* status_out,
                             mcq_info* info_out);
 
+/* fp32 at the boundary (BASELINE config 5: 65536 tracks, alpha collected with one all-gather): as mcq_solve_device, with
+ * the tracks stored as float in HBM (reftrack [batch][n][4], normvec [batch][n][2] or NULL, scaling [batch][n] or NULL) and
+ * alpha_out [batch][n] written as float.  The arithmetic in between is the fp64 engine, unchanged -- cond(H) = 1e9..1e12
+ * leaves no room for fp32 factors -- so the result is the exact QP solution OF THE ROUNDED INPUTS, rounded once more on
+ * the way out (|alpha| < 2^3 m => 2.4e-7 m); how far the rounded inputs move the solution is a property of the QP, not of
+ * the engine (measured in tests/test_gpu_parity.py).  With normvec == NULL the normals and scalings are derived in fp64 from
+ * the float x, y (preferred: float normals are unit vectors only to 6e-8).  curv_err_out stays double. */
+int mcq_solve_device_f32(mcq_handle* h, int batch, int n, const float* reftrack, const float* normvec,
+                         const float* scaling, double kappa_bound, double w_veh, const mcq_opts* opts, float* alpha_out,
+                         double* curv_err_out, int* status_out, mcq_info* info_out);
+
 /* The front half of prep_track on the device [REF helper_funcs_glob/src/prep_track.py:48-51]: unit normals (pointing
  * right) and spline scalings s_i = l_i / l_{i+1} of the closed distance-scaled cubic spline through the reference line --
  * what tph.calc_splines(path) returns as normvec_normalized and encodes in its matrix.  reftrack [batch][nmax][4],

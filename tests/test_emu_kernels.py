@@ -246,3 +246,22 @@ def test_shortest_path_golden_and_errors(emu, golden):
     with pytest.raises(engine.EngineError, match="normvec is required"):
         emu.solve_batch([dict(reftrack=g["reftrack"], normvec=None, scaling=None, kappa_bound=1.0, w_veh=3.4)],
                         objective=engine.OBJ_SHORTEST_PATH)
+
+
+def test_fp32_boundary_is_exact_on_the_rounded_inputs(emu, golden):
+    """mcq_solve_device_f32 (BASELINE config 5's boundary): float tracks in, float alpha out, fp64 arithmetic inside --
+    the result must be the dense oracle's solution OF THE ROUNDED ROWS to one float rounding of alpha; the distance to
+    the fp64-input golden alpha is the QP's sensitivity to the input rounding, far larger and not the engine's."""
+    g = golden["rounded_rectangle"]
+    ref32 = g["reftrack"].astype(np.float32)
+    a32, curv, st, info = emu.solve_uniform_f32(ref32[None], None, None, 0.12, 3.4)
+    assert a32.dtype == np.float32 and st[0] == 0
+    r64 = ref32.astype(np.float64)
+    _, _, A, nv_d = tph_ref.calc_splines(np.vstack((r64[:, :2], r64[0, :2])))
+    a_ref, err_ref = tph_ref.opt_min_curv(r64, nv_d, A, 0.12, 3.4)
+    assert np.max(np.abs(a32[0] - a_ref)) <= np.max(np.abs(a_ref)) * 2.0 ** -24 + 1e-9
+    assert abs(curv[0] - err_ref) < 1e-10
+    assert 1e-7 < np.max(np.abs(a32[0] - g["alpha"])) < 1e-4       # input rounding at |x|, |y| ~ 100 m
+    # float normals / scalings handed over instead of derived: same solution to the input-rounding level
+    b32, _, stb, _ = emu.solve_uniform_f32(ref32[None], g["normvec"][None], g["scaling"][None], 0.12, 3.4)
+    assert stb[0] == 0 and np.max(np.abs(b32[0] - g["alpha"])) < 1e-4

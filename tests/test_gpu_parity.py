@@ -135,6 +135,32 @@ def test_oval_n2000_against_dense_gi_oracle(gpu_engine):
     assert qp_ref is not None
 
 
+def test_fp32_boundary_full_size(gpu_engine):
+    """BASELINE config 5's boundary at N = 2000: float tracks / float alpha in HBM, fp64 arithmetic inside
+    (mcq_solve_device_f32).  Exact on the rounded rows: against the fp64 entry fed the same rounded rows the only
+    difference is the final rounding of alpha.  The distance to the solution of the unrounded rows is the QP's
+    sensitivity to 1e-4 m of coordinate rounding (|x| up to 1.9 km) -- the stated fp32 tolerance of this config, 5e-2 m."""
+    ref, nv, sc = synthetic.oval_batch(4, n=2000)
+    ref32 = ref.astype(np.float32)
+    a32, curv32, st32, info32 = gpu_engine.solve_uniform_f32(ref32, None, None, 0.12, 3.4)
+    assert a32.dtype == np.float32 and np.all(st32 == 0)
+    r64 = ref32.astype(np.float64)
+    probs = [dict(reftrack=r64[b], normvec=None, scaling=None, kappa_bound=0.12, w_veh=3.4) for b in range(4)]
+    a64, curv64, st64, _ = gpu_engine.solve_batch(probs)
+    assert np.all(st64 == 0)
+    for b in range(4):
+        assert np.max(np.abs(a32[b] - a64[b])) <= np.max(np.abs(a64[b])) * 2.0 ** -24 + 1e-12   # one rounding of alpha
+        assert abs(curv32[b] - curv64[b]) < 1e-12
+        lo, hi = -(r64[b, :, 3] - 1.7), r64[b, :, 2] - 1.7
+        assert np.all(a32[b] >= lo - 3e-7) and np.all(a32[b] <= hi + 3e-7)
+        assert info32[b]["kkt_res"] < 1e-9
+    full = [dict(reftrack=ref[b], normvec=nv[b], scaling=sc[b], kappa_bound=0.12, w_veh=3.4) for b in range(4)]
+    a_full, _, _, _ = gpu_engine.solve_batch(full)
+    dev = max(float(np.max(np.abs(a32[b] - a_full[b]))) for b in range(4))
+    print("fp32 boundary, N=2000: max |alpha(f32 rows) - alpha(f64 rows)| = %.3e m" % dev)
+    assert dev < 5e-2
+
+
 def test_ragged_batch_and_small_rings(gpu_engine, golden):
     from oracle import tph_ref
     probs, refs = [], []
