@@ -382,13 +382,14 @@ extern "C" int mcq_relinearise_device(mcq_handle* h, int batch, int nmax, const 
     return 0;
 }
 
-extern "C" int mcq_vel_profile_device(mcq_handle* h, int batch, int n, int nmax, const int* track_of, const double* kappa,
-                                      const double* el_lengths, const double* ggv, int n_ggv, const double* ax_max_machines,
-                                      int n_machines, const double* drag_coeff, const double* m_veh, const double* v_max,
-                                      double dyn_model_exp, double* vx_out, double* lap_time_out)
+static int vel_profile_launch(mcq_handle* h, int batch, int n, int nmax, const int* n_of_track, const int* track_of,
+                              const double* kappa, const double* el_lengths, const double* ggv, int n_ggv,
+                              const double* ax_max_machines, int n_machines, const double* drag_coeff, const double* m_veh,
+                              const double* v_max, double dyn_model_exp, double* vx_out, double* lap_time_out)
 {
-    if (!h || batch <= 0 || n < 2 || nmax < n || !kappa || !el_lengths || !ggv || n_ggv < 1 || !ax_max_machines ||
-        n_machines < 1 || !drag_coeff || !m_veh || !v_max || !vx_out || !lap_time_out || !(dyn_model_exp > 0.0)) {
+    if (!h || batch <= 0 || (!n_of_track && n < 2) || nmax < n || nmax < 2 || !kappa || !el_lengths || !ggv || n_ggv < 1 ||
+        !ax_max_machines || n_machines < 1 || !drag_coeff || !m_veh || !v_max || !vx_out || !lap_time_out ||
+        !(dyn_model_exp > 0.0)) {
         g_err = "mcq_vel_profile_device: bad argument";
         return MCQ_E_ARG;
     }
@@ -405,11 +406,57 @@ extern "C" int mcq_vel_profile_device(mcq_handle* h, int batch, int n, int nmax,
     McqVel V;
     memset(&V, 0, sizeof(V));
     V.batch = batch; V.n = n; V.nmax = nmax;
+    V.n_of_track = n_of_track;
     V.track_of = track_of; V.kappa = kappa; V.el = el_lengths;
     V.ggv = ggv; V.ng = n_ggv; V.axm = ax_max_machines; V.nam = n_machines;
     V.drag = drag_coeff; V.mass = m_veh; V.vmax = v_max; V.dyn_exp = dyn_model_exp;
     V.scratch = h->vel_scratch; V.vx_out = vx_out; V.lap_time = lap_time_out;
     hipLaunchKernelGGL(mcq_vel_profile_kernel, dim3((batch + 63) / 64), dim3(64), 0, h->stream, V);
+    HIP_TRY(hipGetLastError());
+    return 0;
+}
+
+extern "C" int mcq_vel_profile_device(mcq_handle* h, int batch, int n, int nmax, const int* track_of, const double* kappa,
+                                      const double* el_lengths, const double* ggv, int n_ggv, const double* ax_max_machines,
+                                      int n_machines, const double* drag_coeff, const double* m_veh, const double* v_max,
+                                      double dyn_model_exp, double* vx_out, double* lap_time_out)
+{
+    return vel_profile_launch(h, batch, n, nmax, nullptr, track_of, kappa, el_lengths, ggv, n_ggv, ax_max_machines,
+                              n_machines, drag_coeff, m_veh, v_max, dyn_model_exp, vx_out, lap_time_out);
+}
+
+extern "C" int mcq_vel_profile_device_ragged(mcq_handle* h, int batch, int nmax, const int* n_of_track, const int* track_of,
+                                             const double* kappa, const double* el_lengths, const double* ggv, int n_ggv,
+                                             const double* ax_max_machines, int n_machines, const double* drag_coeff,
+                                             const double* m_veh, const double* v_max, double dyn_model_exp, double* vx_out,
+                                             double* lap_time_out)
+{
+    if (!n_of_track) { g_err = "mcq_vel_profile_device_ragged: n_of_track is NULL"; return MCQ_E_ARG; }
+    return vel_profile_launch(h, batch, 0, nmax, n_of_track, track_of, kappa, el_lengths, ggv, n_ggv, ax_max_machines,
+                              n_machines, drag_coeff, m_veh, v_max, dyn_model_exp, vx_out, lap_time_out);
+}
+
+extern "C" int mcq_raceline_device(mcq_handle* h, int batch, int nmax, const int* n_in, const double* reftrack,
+                                   const double* normvec, const double* alpha, double stepsize, int mmax,
+                                   double* raceline_out, double* psi_out, double* kappa_out, double* el_lengths_out,
+                                   int* m_out, int* status_out)
+{
+    if (!h || batch <= 0 || nmax < 3 || mmax < 2 || !reftrack || !normvec || !alpha || !(stepsize > 0.0) || !kappa_out ||
+        !el_lengths_out || !m_out || !status_out) {
+        g_err = "mcq_raceline_device: bad argument";
+        return MCQ_E_ARG;
+    }
+    HIP_TRY(hipSetDevice(h->device));
+    int rc = ensure_ws(h, (size_t)batch, (size_t)nmax);
+    if (rc) return rc;
+    McqRace Q;
+    memset(&Q, 0, sizeof(Q));
+    Q.batch = batch; Q.nmax = nmax; Q.mmax = mmax;
+    Q.n_in = n_in; Q.ref = reftrack; Q.nv = normvec; Q.alpha = alpha; Q.stepsize = stepsize;
+    Q.xy_out = raceline_out; Q.psi_out = psi_out; Q.kappa_out = kappa_out; Q.el_out = el_lengths_out;
+    Q.m_out = m_out; Q.status = status_out;
+    Q.vec = h->vec;
+    hipLaunchKernelGGL(mcq_raceline_kernel, dim3(batch), dim3(256), 0, h->stream, Q);
     HIP_TRY(hipGetLastError());
     return 0;
 }

@@ -159,11 +159,31 @@ struct McqRelin {
 };
 __global__ void mcq_relinearise_kernel(McqRelin R);
 
+/* ---- raceline at the output resolution + heading / curvature (what main_globaltraj.py runs between the QP and the velocity
+ *      profile [REF main_globaltraj.py:371-387]: tph.create_raceline + tph.calc_head_curv_an).  One workgroup per track. ---- */
+struct McqRace {
+    int batch, nmax, mmax;
+    const int* n_in;        // [batch] waypoints of each track, or nullptr (all nmax)
+    const double* ref;      // [batch][nmax][4]
+    const double* nv;       // [batch][nmax][2]
+    const double* alpha;    // [batch][nmax]
+    double stepsize;        // stepsize_interp_after_opt
+    double* xy_out;         // [batch][mmax][2] raceline_interp, or nullptr
+    double* psi_out;        // [batch][mmax] heading (0 = north), or nullptr
+    double* kappa_out;      // [batch][mmax]
+    double* el_out;         // [batch][mmax] element lengths (closed: m of them)
+    int* m_out;             // [batch] points of the interpolated raceline
+    int* status;            // [batch] MCQ_OK, or MCQ_BAD_INPUT (n < 3, or the raceline needs more than mmax points)
+    double* vec;            // workspace, [batch][MCQ_NVEC][nmax] (the solver's vector slab)
+};
+__global__ void mcq_raceline_kernel(McqRace Q);
+
 /* ---- ggv velocity profile + lap time of many (track, vehicle) variants: the forward /
  *      backward quasi-steady-state sweeps of tph.calc_vel_profile (closed track, global ggv) followed by
  *      tph.calc_ax_profile / calc_t_profile, one thread per variant. ---- */
 struct McqVel {
     int batch, n, nmax;
+    const int* n_of_track;   // [tracks] valid entries of each kappa / el row, or nullptr (all rows: n)
     const int* track_of;     // [batch] row of kappa / el a variant uses, or nullptr (row = variant)
     const double* kappa;     // [tracks][nmax]
     const double* el;        // [tracks][nmax] element lengths (closed: n of them)

@@ -2873,37 +2873,26 @@ __device__ void relin_spline_rhs(const gdouble* PX, const gdouble* PY, int n, gd
     }
 }
 
-__global__ void __launch_bounds__(MCQ_NT) mcq_relinearise_kernel(McqRelin R)
+// Front half of the glue, shared by mcq_relinearise_kernel and mcq_raceline_kernel: raceline p + a n (and the shifted
+// widths), closed unit-scaling spline through it, spline lengths and their running sum, point count of the re-sampled ring.
+// vec slots: 0/1 raceline points (a-coefficients), 2/3 rhs, 4/5 c-coefficients, 6 lengths, 7 running sum, 8/9 widths.
+// Returns the number of points kept (tph.interp_splines, incl_last_point = False) or -1; `total` = length of the raceline.
+__device__ __forceinline__ int relin_front(const gdouble* ref, const gdouble* nv, const gdouble* al, int n, double alpha_scale,
+                                           double stepsize, gdouble* vec, size_t nm, double& total)
 {
     __shared__ double sbuf[2048];
     __shared__ double s_carry;
     __shared__ int s_m;
-    const int tid = threadIdx.x, pb = blockIdx.x;
-    if (R.live && R.live[pb] == 0) return;
-    const size_t nm = (size_t)R.nmax;
-    const int n = R.n_in[pb];
-    const gdouble* ref = (const gdouble*)(R.ref_in + (size_t)pb * nm * 4);
-    const gdouble* nv = (const gdouble*)(R.nv_in + (size_t)pb * nm * 2);
-    const gdouble* al = (const gdouble*)(R.alpha + (size_t)pb * nm);
-    gdouble* refo = (gdouble*)(R.ref_out + (size_t)pb * nm * 4);
-    gdouble* nvo = (gdouble*)(R.nv_out + (size_t)pb * nm * 2);
-    gdouble* vec = (gdouble*)(R.vec + (size_t)pb * nm * MCQ_NVEC);
+    const int tid = threadIdx.x;
     gdouble* PX = vec + 0 * nm;   gdouble* PY = vec + 1 * nm;    // raceline points (a-coefficients)
     gdouble* RX = vec + 2 * nm;   gdouble* RY = vec + 3 * nm;    // rhs, later the new points
     gdouble* CX = vec + 4 * nm;   gdouble* CY = vec + 5 * nm;    // c-coefficients
     gdouble* LEN = vec + 6 * nm;  gdouble* CUM = vec + 7 * nm;   // spline lengths, their running sum
     gdouble* WR = vec + 8 * nm;   gdouble* WL = vec + 9 * nm;    // shifted track widths
-    gdouble* QX = vec + 10 * nm;  gdouble* QY = vec + 11 * nm;   // re-sampled points
-    gint* n_out = (gint*)(R.n_out + pb);
-    gint* status = (gint*)(R.status + pb);
-    if (n < 3) {
-        if (tid == 0) { *status = MCQ_BAD_INPUT; *n_out = n; }
-        return;
-    }
 
     // ---- raceline and shifted widths:  p + a n,  w_right - a,  w_left + a   (a = damped alpha) --------------------------
     for (int i = tid; i < n; i += MCQ_NT) {
-        const double a = R.alpha_scale * al[i];
+        const double a = alpha_scale * al[i];
         PX[i] = ref[4 * i] + a * nv[2 * i];
         PY[i] = ref[4 * i + 1] + a * nv[2 * i + 1];
         WR[i] = ref[4 * i + 2] - a;
@@ -2951,13 +2940,40 @@ __global__ void __launch_bounds__(MCQ_NT) mcq_relinearise_kernel(McqRelin R)
         for (int q = tid; q < cn; q += MCQ_NT) CUM[c0 + q] = sbuf[q];
     }
     __syncthreads();
-    const double total = s_carry;
+    total = s_carry;
     if (tid == 0) {
-        const double cnt = ceil(total / R.stepsize) + 1.0;       // no_interp_points of tph.interp_splines
+        const double cnt = ceil(total / stepsize) + 1.0;         // no_interp_points of tph.interp_splines
         s_m = (cnt >= 2.0 && cnt <= 2.0e9) ? (int)cnt - 1 : -1;  // points kept (incl_last_point = False)
     }
     __syncthreads();
-    const int m = s_m;
+    return s_m;
+}
+
+__global__ void __launch_bounds__(MCQ_NT) mcq_relinearise_kernel(McqRelin R)
+{
+    const int tid = threadIdx.x, pb = blockIdx.x;
+    if (R.live && R.live[pb] == 0) return;
+    const size_t nm = (size_t)R.nmax;
+    const int n = R.n_in[pb];
+    const gdouble* ref = (const gdouble*)(R.ref_in + (size_t)pb * nm * 4);
+    const gdouble* nv = (const gdouble*)(R.nv_in + (size_t)pb * nm * 2);
+    const gdouble* al = (const gdouble*)(R.alpha + (size_t)pb * nm);
+    gdouble* refo = (gdouble*)(R.ref_out + (size_t)pb * nm * 4);
+    gdouble* nvo = (gdouble*)(R.nv_out + (size_t)pb * nm * 2);
+    gdouble* vec = (gdouble*)(R.vec + (size_t)pb * nm * MCQ_NVEC);
+    gdouble* PX = vec + 0 * nm;   gdouble* PY = vec + 1 * nm;    // raceline points (a-coefficients)
+    gdouble* CX = vec + 4 * nm;   gdouble* CY = vec + 5 * nm;    // c-coefficients
+    gdouble* LEN = vec + 6 * nm;  gdouble* CUM = vec + 7 * nm;   // spline lengths, their running sum
+    gdouble* WR = vec + 8 * nm;   gdouble* WL = vec + 9 * nm;    // shifted track widths
+    gdouble* QX = vec + 10 * nm;  gdouble* QY = vec + 11 * nm;   // re-sampled points
+    gint* n_out = (gint*)(R.n_out + pb);
+    gint* status = (gint*)(R.status + pb);
+    if (n < 3) {
+        if (tid == 0) { *status = MCQ_BAD_INPUT; *n_out = n; }
+        return;
+    }
+    double total;
+    const int m = relin_front(ref, nv, al, n, R.alpha_scale, R.stepsize, vec, nm, total);
     if (m < 3 || m > R.nmax) {
         if (tid == 0) { *status = MCQ_BAD_INPUT; *n_out = n; }
         return;
@@ -3038,8 +3054,11 @@ __global__ void __launch_bounds__(64) mcq_vel_profile_kernel(McqVel V)
 {
     const int v = blockIdx.x * 64 + threadIdx.x;
     if (v >= V.batch) return;
-    const int n = V.n, bt = V.batch;
-    const size_t row = (size_t)(V.track_of ? V.track_of[v] : v) * V.nmax;
+    const int bt = V.batch;
+    const int trk = V.track_of ? V.track_of[v] : v;
+    const int n = V.n_of_track ? V.n_of_track[trk] : V.n;        // ragged tracks: per-row waypoint counts
+    if (n < 2 || n > V.nmax) { V.lap_time[v] = NAN; return; }
+    const size_t row = (size_t)trk * V.nmax;
     const gdouble* kap = (const gdouble*)(V.kappa + row);
     const gdouble* el = (const gdouble*)(V.el + row);
     const gdouble* ggv_all = (const gdouble*)(V.ggv + (size_t)v * V.ng * 3);
@@ -3124,6 +3143,73 @@ __global__ void __launch_bounds__(64) mcq_vel_profile_kernel(McqVel V)
         va = vb;
     }
     V.lap_time[v] = t;
+}
+
+// ---- what main_globaltraj.py does with alpha before the velocity profile [REF main_globaltraj.py:371-387]: tph.create_raceline
+//      (raceline p + alpha n, closed unit-scaling spline, re-sampling at ~stepsize_interp_after_opt) followed by
+//      tph.calc_head_curv_an (heading and curvature from the spline's derivatives, analytically) -- one workgroup per track,
+//      outputs strided by mmax: exactly what mcq_vel_profile_kernel consumes (kappa, el_lengths). ----
+__global__ void __launch_bounds__(MCQ_NT) mcq_raceline_kernel(McqRace Q)
+{
+    const int tid = threadIdx.x, pb = blockIdx.x;
+    const size_t nm = (size_t)Q.nmax, mm = (size_t)Q.mmax;
+    const int n = Q.n_in ? Q.n_in[pb] : Q.nmax;
+    const gdouble* ref = (const gdouble*)(Q.ref + (size_t)pb * nm * 4);
+    const gdouble* nv = (const gdouble*)(Q.nv + (size_t)pb * nm * 2);
+    const gdouble* al = (const gdouble*)(Q.alpha + (size_t)pb * nm);
+    gdouble* vec = (gdouble*)(Q.vec + (size_t)pb * nm * MCQ_NVEC);
+    gdouble* PX = vec + 0 * nm;   gdouble* PY = vec + 1 * nm;
+    gdouble* CX = vec + 4 * nm;   gdouble* CY = vec + 5 * nm;
+    gdouble* LEN = vec + 6 * nm;  gdouble* CUM = vec + 7 * nm;
+    gint* m_out = (gint*)(Q.m_out + pb);
+    gint* status = (gint*)(Q.status + pb);
+    if (n < 3) {
+        if (tid == 0) { *status = MCQ_BAD_INPUT; *m_out = 0; }
+        return;
+    }
+    double total;
+    const int m = relin_front(ref, nv, al, n, 1.0, Q.stepsize, vec, nm, total);
+    if (m < 2 || m > Q.mmax) {
+        if (tid == 0) { *status = MCQ_BAD_INPUT; *m_out = m > 0 ? m : 0; }
+        return;
+    }
+    gdouble* xy = Q.xy_out ? (gdouble*)(Q.xy_out + (size_t)pb * mm * 2) : nullptr;
+    gdouble* psi = Q.psi_out ? (gdouble*)(Q.psi_out + (size_t)pb * mm) : nullptr;
+    gdouble* kap = (gdouble*)(Q.kappa_out + (size_t)pb * mm);
+    gdouble* el = (gdouble*)(Q.el_out + (size_t)pb * mm);
+    const double step = total / (double)m;                       // numpy.linspace(0, total, m + 1): station j = j * step
+    const double pi = 3.14159265358979323846;
+    for (int j = tid; j < m; j += MCQ_NT) {
+        const double q = (double)j * step;
+        int lo = 0, hi = n;                                      // first index with CUM[idx] > q
+        while (lo < hi) {
+            const int mid = (lo + hi) >> 1;
+            if (CUM[mid] > q) hi = mid; else lo = mid + 1;
+        }
+        const int s = lo < n - 1 ? lo : n - 1;
+        const int sp = s + 1 == n ? 0 : s + 1;
+        const double start = s > 0 ? CUM[s - 1] : 0.0;
+        const double t = (q - start) / LEN[s];
+        const double ax = PX[s], ay = PY[s], cx = CX[s], cy = CY[s];
+        const double bx = (PX[sp] - ax) - (2.0 * cx + CX[sp]) / 3.0, by = (PY[sp] - ay) - (2.0 * cy + CY[sp]) / 3.0;
+        const double dx = (CX[sp] - cx) / 3.0, dy = (CY[sp] - cy) / 3.0;
+        if (xy) {
+            xy[2 * j] = ax + t * (bx + t * (cx + t * dx));
+            xy[2 * j + 1] = ay + t * (by + t * (cy + t * dy));
+        }
+        const double xd = bx + 2.0 * cx * t + 3.0 * dx * t * t, yd = by + 2.0 * cy * t + 3.0 * dy * t * t;
+        const double xdd = 2.0 * cx + 6.0 * dx * t, ydd = 2.0 * cy + 6.0 * dy * t;
+        if (psi) {                                               // heading, 0 = north, wrapped to [-pi, pi) (tph.normalize_psi)
+            double a = atan2(yd, xd) - 0.5 * pi;
+            if (a >= pi) a -= 2.0 * pi;
+            else if (a < -pi) a += 2.0 * pi;
+            psi[j] = a;
+        }
+        const double v2 = xd * xd + yd * yd;
+        kap[j] = (xd * ydd - yd * xdd) / (v2 * sqrt(v2));
+        el[j] = j + 1 < m ? (double)(j + 1) * step - q : total - q;
+    }
+    if (tid == 0) { *status = MCQ_OK; *m_out = m; }
 }
 
 // ---- fp32 boundary (BASELINE config 5): tracks and results stored as float in HBM, every bit of arithmetic still fp64.

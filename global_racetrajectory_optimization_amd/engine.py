@@ -45,7 +45,7 @@ class McqInfo(ctypes.Structure):
 
 EXPORTED_SYMBOLS = ("mcq_create", "mcq_destroy", "mcq_last_error", "mcq_default_opts", "mcq_solve_batch",
                     "mcq_solve_device", "mcq_solve_device_f32", "mcq_solve_device_ragged", "mcq_prep_device", "mcq_relinearise_device",
-                    "mcq_vel_profile_device", "mcq_device_alloc",
+                    "mcq_vel_profile_device", "mcq_vel_profile_device_ragged", "mcq_raceline_device", "mcq_device_alloc",
                     "mcq_device_free", "mcq_copy_to_device", "mcq_copy_to_host", "mcq_sync", "mcq_stream",
                     "mcq_last_timing", "mcq_workspace_bytes")
 
@@ -89,6 +89,12 @@ def load_library(path=None):
     lib.mcq_vel_profile_device.argtypes = [vp, ctypes.c_int, ctypes.c_int, ctypes.c_int, vp, vp, vp, vp, ctypes.c_int, vp,
                                            ctypes.c_int, vp, vp, vp, ctypes.c_double, vp, vp]
     lib.mcq_vel_profile_device.restype = ctypes.c_int
+    lib.mcq_vel_profile_device_ragged.argtypes = [vp, ctypes.c_int, ctypes.c_int, vp, vp, vp, vp, vp, ctypes.c_int, vp,
+                                                  ctypes.c_int, vp, vp, vp, ctypes.c_double, vp, vp]
+    lib.mcq_vel_profile_device_ragged.restype = ctypes.c_int
+    lib.mcq_raceline_device.argtypes = [vp, ctypes.c_int, ctypes.c_int, vp, vp, vp, vp, ctypes.c_double, ctypes.c_int, vp, vp,
+                                        vp, vp, vp, vp]
+    lib.mcq_raceline_device.restype = ctypes.c_int
     lib.mcq_device_alloc.argtypes = [vp, ctypes.c_size_t, ctypes.POINTER(vp)]
     lib.mcq_device_alloc.restype = ctypes.c_int
     lib.mcq_device_free.argtypes = [vp, vp]
@@ -282,11 +288,12 @@ class Engine:
         return [nv[k, :ns[k]].copy() for k in range(bsz)], [sc[k, :ns[k]].copy() for k in range(bsz)]
 
     def vel_profile_batch(self, kappa, el_lengths, ggv, ax_max_machines, drag_coeff, m_veh, v_max, dyn_model_exp=1.0,
-                          track_of=None):
+                          track_of=None, n_of_track=None):
         """ggv velocity profiles and lap times of a batch of variants on the device (mcq_vel_profile_device).
 
         kappa, el_lengths: [tracks, n]; ggv: [batch, g, 3]; ax_max_machines: [batch, m, 2]; drag_coeff, m_veh, v_max: [batch];
-        track_of: [batch] ints (row of kappa / el per variant) or None when tracks == batch.  Returns (vx [batch, n], lap_time
+        track_of: [batch] ints (row of kappa / el per variant) or None when tracks == batch; n_of_track: [tracks] valid entries
+        per row (ragged tracks, mcq_vel_profile_device_ragged) or None (all rows full).  Returns (vx [batch, n], lap_time
         [batch])."""
         kappa = np.ascontiguousarray(kappa, dtype=np.float64)
         el = np.ascontiguousarray(el_lengths, dtype=np.float64)
@@ -295,6 +302,7 @@ class Engine:
         bsz, n = ggv.shape[0], kappa.shape[1]
         scal = [np.ascontiguousarray(np.broadcast_to(np.asarray(a, dtype=np.float64), (bsz,))) for a in (drag_coeff, m_veh, v_max)]
         tr = None if track_of is None else np.ascontiguousarray(track_of, dtype=np.int32)
+        nt = None if n_of_track is None else np.ascontiguousarray(n_of_track, dtype=np.int32)
         ptrs = []
 
         def up(a):
@@ -308,10 +316,61 @@ class Engine:
             d_t = up(tr) if tr is not None else None
             d_vx = self.alloc(bsz * n * 8); ptrs.append(d_vx)
             d_lt = self.alloc(bsz * 8); ptrs.append(d_lt)
-            rc = self.lib.mcq_vel_profile_device(self.h, bsz, n, n, d_t, d_k, d_e, d_g, ggv.shape[1], d_a, axm.shape[1],
-                                                 d_s[0], d_s[1], d_s[2], float(dyn_model_exp), d_vx, d_lt)
+            if nt is not None:
+                rc = self.lib.mcq_vel_profile_device_ragged(self.h, bsz, n, up(nt), d_t, d_k, d_e, d_g, ggv.shape[1], d_a,
+                                                            axm.shape[1], d_s[0], d_s[1], d_s[2], float(dyn_model_exp),
+                                                            d_vx, d_lt)
+            else:
+                rc = self.lib.mcq_vel_profile_device(self.h, bsz, n, n, d_t, d_k, d_e, d_g, ggv.shape[1], d_a, axm.shape[1],
+                                                     d_s[0], d_s[1], d_s[2], float(dyn_model_exp), d_vx, d_lt)
             self._check(rc, "mcq_vel_profile_device")
             return self.download(d_vx, (bsz, n), np.float64), self.download(d_lt, (bsz,), np.float64)
+        finally:
+            for p in ptrs:
+                self.free(p)
+
+    def raceline_batch(self, reftracks, normvecs, alphas, stepsize, mmax=None):
+        """tph.create_raceline + tph.calc_head_curv_an of a list of tracks on the device (mcq_raceline_device)
+        [REF main_globaltraj.py:371-387].  reftracks [n_k, >=2], normvecs [n_k, 2], alphas [n_k].  Returns a dict of padded
+        arrays: xy [B, mmax, 2], psi / kappa / el_lengths [B, mmax], m [B] (valid entries per row), status [B]."""
+        bsz = len(reftracks)
+        ns = np.array([np.asarray(r).shape[0] for r in reftracks], dtype=np.int32)
+        nmax = int(ns.max())
+        ref = np.zeros((bsz, nmax, 4))
+        nv = np.zeros((bsz, nmax, 2))
+        al = np.zeros((bsz, nmax))
+        for k in range(bsz):
+            r = np.asarray(reftracks[k], dtype=np.float64)
+            ref[k, :ns[k], :min(4, r.shape[1])] = r[:, :4]
+            nv[k, :ns[k]] = normvecs[k]
+            al[k, :ns[k]] = alphas[k]
+        if mmax is None:      # polygon length + the widest shift bounds the raceline length from above generously
+            per = [float(np.sum(np.hypot(*np.diff(np.vstack((r[:, :2], r[:1, :2])), axis=0).T)) + 8.0 * np.sum(np.abs(a)))
+                   for r, a in zip(reftracks, alphas)]
+            mmax = int(max(per) / float(stepsize) * 1.25) + 16
+        ptrs = []
+
+        def up(a):
+            p = self.alloc(a.nbytes)
+            ptrs.append(p)
+            self.upload(p, a)
+            return p
+
+        def new(nbytes):
+            p = self.alloc(nbytes)
+            ptrs.append(p)
+            return p
+        try:
+            d_ref, d_nv, d_al, d_n = up(ref), up(nv), up(al), up(ns)
+            d_xy, d_psi, d_k, d_el = new(bsz * mmax * 16), new(bsz * mmax * 8), new(bsz * mmax * 8), new(bsz * mmax * 8)
+            d_m, d_st = new(bsz * 4), new(bsz * 4)
+            rc = self.lib.mcq_raceline_device(self.h, bsz, nmax, d_n, d_ref, d_nv, d_al, float(stepsize), int(mmax), d_xy,
+                                              d_psi, d_k, d_el, d_m, d_st)
+            self._check(rc, "mcq_raceline_device")
+            return dict(xy=self.download(d_xy, (bsz, mmax, 2), np.float64), psi=self.download(d_psi, (bsz, mmax), np.float64),
+                        kappa=self.download(d_k, (bsz, mmax), np.float64),
+                        el_lengths=self.download(d_el, (bsz, mmax), np.float64),
+                        m=self.download(d_m, (bsz,), np.int32), status=self.download(d_st, (bsz,), np.int32))
         finally:
             for p in ptrs:
                 self.free(p)

@@ -168,6 +168,27 @@ int mcq_vel_profile_device(mcq_handle* h, int batch, int n, int nmax, const int*
                            int n_machines, const double* drag_coeff, const double* m_veh, const double* v_max,
                            double dyn_model_exp, double* vx_out, double* lap_time_out);
 
+/* The same over tracks of different lengths: n_of_track [tracks] (device) = valid entries of each kappa / el_lengths row (rows
+ * strided by nmax); a variant whose row has fewer than 2 or more than nmax entries gets lap_time NaN.  This is the shape of
+ * BASELINE config 4's sweep: (reference track x vehicle width) racelines from mcq_raceline_device, each shared by a grid of
+ * ggv / top-speed variants. */
+int mcq_vel_profile_device_ragged(mcq_handle* h, int batch, int nmax, const int* n_of_track, const int* track_of,
+                                  const double* kappa, const double* el_lengths, const double* ggv, int n_ggv,
+                                  const double* ax_max_machines, int n_machines, const double* drag_coeff,
+                                  const double* m_veh, const double* v_max, double dyn_model_exp, double* vx_out,
+                                  double* lap_time_out);
+
+/* What main_globaltraj.py runs between the QP and the velocity profile [REF main_globaltraj.py:371-387], batched on the device:
+ * tph.create_raceline (raceline = refline + alpha * normal, closed cubic spline through it with unit scalings, re-sampled at
+ * ~stepsize = stepsize_interp_after_opt) and tph.calc_head_curv_an (heading and curvature from the spline's derivatives).
+ * Inputs strided by nmax as in mcq_solve_device_ragged (n_in [batch] or NULL: all nmax); outputs strided by mmax:
+ * raceline_out [batch][mmax][2] (or NULL), psi_out [batch][mmax] (heading, 0 = north, [-pi, pi); or NULL), kappa_out and
+ * el_lengths_out [batch][mmax] -- the two inputs of mcq_vel_profile_device(_ragged) --, m_out [batch] points per raceline,
+ * status_out [batch] MCQ_OK or MCQ_BAD_INPUT (n < 3, or more than mmax points needed).  Asynchronous on the handle's stream. */
+int mcq_raceline_device(mcq_handle* h, int batch, int nmax, const int* n_in, const double* reftrack, const double* normvec,
+                        const double* alpha, double stepsize, int mmax, double* raceline_out, double* psi_out,
+                        double* kappa_out, double* el_lengths_out, int* m_out, int* status_out);
+
 /* Device memory plumbing on the handle's device and stream, for callers that keep data resident between calls (the
  * Python IQP driver) without loading a second HIP runtime into the process: allocate (zero-filled) / free / blocking
  * copies.  A reference-side binding would use these exactly where a CUDA/HIP-aware caller uses its own allocator. */
