@@ -348,6 +348,20 @@ extern "C" int mcq_prep_device(mcq_handle* h, int batch, int nmax, const int* n_
     return launch(h, B, o);
 }
 
+extern "C" int mcq_normals_crossing_device(mcq_handle* h, int batch, int nmax, const int* n_list, const double* reftrack,
+                                           const double* normvec, int horizon, int* crossing_out)
+{
+    if (!h || batch <= 0 || nmax <= 0 || !reftrack || !normvec || !crossing_out) {
+        g_err = "mcq_normals_crossing_device: bad argument";
+        return MCQ_E_ARG;
+    }
+    HIP_TRY(hipSetDevice(h->device));
+    hipLaunchKernelGGL(mcq_normals_crossing_kernel, dim3(batch), dim3(256), 0, h->stream, nmax, n_list, reftrack, normvec,
+                       horizon, crossing_out);
+    HIP_TRY(hipGetLastError());
+    return 0;
+}
+
 extern "C" int mcq_relinearise_device(mcq_handle* h, int batch, int nmax, const int* n_in, const double* reftrack_in,
                                       const double* normvec_in, const double* alpha, const int* live, double alpha_scale,
                                       double stepsize, double* reftrack_out, double* normvec_out, int* n_out,

@@ -132,6 +132,11 @@ __global__ void mcq_gram_kernel(McqBatch B);
 __global__ void mcq_gram_tile_kernel(McqBatch B);
 __global__ void mcq_solve_kernel(McqBatch B);
 
+/* tph.check_normals_crossing [REF helper_funcs_glob/src/prep_track.py:57-59], one workgroup per track: crossing_out [batch] =
+ * 1 / 0, or -1 where tph raises (horizon >= n) */
+__global__ void mcq_normals_crossing_kernel(int nmax, const int* n_list, const double* ref_all, const double* nv_all,
+                                            int horizon, int* crossing_out);
+
 /* fp32 boundary (BASELINE config 5): float <-> double streaming conversions around the fp64 engine */
 __global__ void mcq_widen_kernel(const float* src, double* dst, size_t count);
 __global__ void mcq_narrow_kernel(const double* src, float* dst, size_t count);

@@ -3212,6 +3212,41 @@ __global__ void __launch_bounds__(MCQ_NT) mcq_raceline_kernel(McqRace Q)
     if (tid == 0) { *status = MCQ_OK; *m_out = m; }
 }
 
+// ---- tph.check_normals_crossing as prep_track calls it [REF helper_funcs_glob/src/prep_track.py:57-59]: do the normal segments
+//      [p - w_left n, p + w_right n] of two waypoints at most `horizon` apart intersect?  One workgroup per track, thread per
+//      waypoint, 2x2 system per pair in closed form (parallel normals: no crossing). ----
+__global__ void __launch_bounds__(MCQ_NT) mcq_normals_crossing_kernel(int nmax, const int* n_list, const double* ref_all,
+                                                                      const double* nv_all, int horizon, int* crossing_out)
+{
+    __shared__ int s_hit;
+    const int tid = threadIdx.x, pb = blockIdx.x;
+    const int n = n_list ? n_list[pb] : nmax;
+    const gdouble* ref = (const gdouble*)(ref_all + (size_t)pb * nmax * 4);
+    const gdouble* nv = (const gdouble*)(nv_all + (size_t)pb * nmax * 2);
+    if (tid == 0) s_hit = 0;
+    __syncthreads();
+    if (n < 2 || horizon >= n) {                                 // tph raises: "Horizon ... is too large for a track with ..."
+        if (tid == 0) ((gint*)crossing_out)[pb] = -1;
+        return;
+    }
+    int hit = 0;
+    for (int i = tid; i < n; i += MCQ_NT) {
+        const double px = ref[4 * i], py = ref[4 * i + 1], wr = ref[4 * i + 2], wl = ref[4 * i + 3];
+        const double ax = nv[2 * i], ay = nv[2 * i + 1];
+        for (int d = 1; d <= horizon; ++d) {
+            const int j = i + d < n ? i + d : i + d - n;
+            const double bx = nv[2 * j], by = nv[2 * j + 1];
+            const double rx = ref[4 * j] - px, ry = ref[4 * j + 1] - py;
+            const double det = -ax * by + ay * bx;               // p_i + l0 n_i = p_j + l1 n_j
+            const double l0 = (-rx * by + ry * bx) / det, l1 = (ax * ry - ay * rx) / det;
+            if (isfinite(l0) && isfinite(l1) && l0 > -wl && l0 < wr && l1 > -ref[4 * j + 3] && l1 < ref[4 * j + 2]) hit = 1;
+        }
+    }
+    if (hit) s_hit = 1;
+    __syncthreads();
+    if (tid == 0) ((gint*)crossing_out)[pb] = s_hit;
+}
+
 // ---- fp32 boundary (BASELINE config 5): tracks and results stored as float in HBM, every bit of arithmetic still fp64.
 //      cond(H) = 1e9...1e12 rules out fp32 factors; what fp32 buys is half the bytes at the
 //      boundary -- the rows coming in and, above all, the alpha vectors that go through the all-gather.  Plain streaming

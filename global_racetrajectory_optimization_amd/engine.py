@@ -45,7 +45,8 @@ class McqInfo(ctypes.Structure):
 
 EXPORTED_SYMBOLS = ("mcq_create", "mcq_destroy", "mcq_last_error", "mcq_default_opts", "mcq_solve_batch",
                     "mcq_solve_device", "mcq_solve_device_f32", "mcq_solve_device_ragged", "mcq_prep_device", "mcq_relinearise_device",
-                    "mcq_vel_profile_device", "mcq_vel_profile_device_ragged", "mcq_raceline_device", "mcq_device_alloc",
+                    "mcq_vel_profile_device", "mcq_vel_profile_device_ragged", "mcq_raceline_device", "mcq_normals_crossing_device",
+                    "mcq_device_alloc",
                     "mcq_device_free", "mcq_copy_to_device", "mcq_copy_to_host", "mcq_sync", "mcq_stream",
                     "mcq_last_timing", "mcq_workspace_bytes")
 
@@ -95,6 +96,8 @@ def load_library(path=None):
     lib.mcq_raceline_device.argtypes = [vp, ctypes.c_int, ctypes.c_int, vp, vp, vp, vp, ctypes.c_double, ctypes.c_int, vp, vp,
                                         vp, vp, vp, vp]
     lib.mcq_raceline_device.restype = ctypes.c_int
+    lib.mcq_normals_crossing_device.argtypes = [vp, ctypes.c_int, ctypes.c_int, vp, vp, vp, ctypes.c_int, vp]
+    lib.mcq_normals_crossing_device.restype = ctypes.c_int
     lib.mcq_device_alloc.argtypes = [vp, ctypes.c_size_t, ctypes.POINTER(vp)]
     lib.mcq_device_alloc.restype = ctypes.c_int
     lib.mcq_device_free.argtypes = [vp, vp]
@@ -325,6 +328,30 @@ class Engine:
                                                      d_s[0], d_s[1], d_s[2], float(dyn_model_exp), d_vx, d_lt)
             self._check(rc, "mcq_vel_profile_device")
             return self.download(d_vx, (bsz, n), np.float64), self.download(d_lt, (bsz,), np.float64)
+        finally:
+            for p in ptrs:
+                self.free(p)
+
+    def normals_crossing_batch(self, reftracks, normvecs, horizon=10):
+        """tph.check_normals_crossing of a list of tracks on the device [REF helper_funcs_glob/src/prep_track.py:57-59].
+        Returns an int32 array: 1 crossing, 0 none, -1 where tph would raise (horizon >= n)."""
+        bsz = len(reftracks)
+        ns = np.array([np.asarray(r).shape[0] for r in reftracks], dtype=np.int32)
+        nmax = int(ns.max())
+        ref = np.zeros((bsz, nmax, 4))
+        nv = np.zeros((bsz, nmax, 2))
+        for k in range(bsz):
+            ref[k, :ns[k]] = np.asarray(reftracks[k], dtype=np.float64)[:, :4]
+            nv[k, :ns[k]] = normvecs[k]
+        ptrs = []
+        try:
+            for a in (ref, nv, ns):
+                ptrs.append(self.alloc(a.nbytes))
+                self.upload(ptrs[-1], a)
+            ptrs.append(self.alloc(bsz * 4))
+            rc = self.lib.mcq_normals_crossing_device(self.h, bsz, nmax, ptrs[2], ptrs[0], ptrs[1], int(horizon), ptrs[3])
+            self._check(rc, "mcq_normals_crossing_device")
+            return self.download(ptrs[3], (bsz,), np.int32)
         finally:
             for p in ptrs:
                 self.free(p)

@@ -146,6 +146,14 @@ int mcq_solve_device_f32(mcq_handle* h, int batch, int n, const float* reftrack,
 int mcq_prep_device(mcq_handle* h, int batch, int nmax, const int* n_list, const double* reftrack, double* normvec_out,
                     double* scaling_out, int* status_out);
 
+/* The check prep_track runs on the normals [REF helper_funcs_glob/src/prep_track.py:57-59] -- tph.check_normals_crossing(track,
+ * normvec_normalized, horizon = 10): do the normal segments [p - w_left n, p + w_right n] of two waypoints at most `horizon`
+ * apart intersect?  reftrack [batch][nmax][4], normvec [batch][nmax][2], n_list [batch] or NULL (all nmax);
+ * crossing_out [batch] (device) = 1 / 0, or -1 where tph raises RuntimeError (horizon >= n).  Asynchronous on the handle's
+ * stream. */
+int mcq_normals_crossing_device(mcq_handle* h, int batch, int nmax, const int* n_list, const double* reftrack,
+                                const double* normvec, int horizon, int* crossing_out);
+
 /* Device-side glue of tph.iqp_handler between two passes (what upstream does on the host with two dense 4N x 4N spline
  * solves per pass): raceline = refline + alpha_scale * alpha * normal; closed spline through it (unit scalings);
  * arclength re-sampling at ~stepsize (tph.create_raceline); track widths shifted by -/+ alpha and carried over linearly
