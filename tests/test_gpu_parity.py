@@ -385,6 +385,19 @@ def test_raceline_kernel_and_ragged_lap_time_matrix(gpu_engine, golden):
         assert abs(lt_d[k] - float(np.sum(2.0 * el / (vx_cl[:-1] + vx_cl[1:])))) < 1e-8, k
 
 
+def test_normals_crossing_on_device(gpu_engine, golden):
+    """Row f-2's second half: tph.check_normals_crossing [REF helper_funcs_glob/src/prep_track.py:57-59] for a ragged batch."""
+    from global_racetrajectory_optimization_amd.trajectory_planning_helpers import check_normals_crossing as cn
+    from test_emu_kernels import _crossing_cases
+    cases = _crossing_cases(golden) + [(golden[k]["reftrack"], golden[k]["normvec"]) for k in ("berlin_2018", "handling_track")]
+    got = gpu_engine.normals_crossing_batch([c[0] for c in cases], [c[1] for c in cases], horizon=10)
+    for k, (t, nv) in enumerate(cases):
+        if t.shape[0] <= 10:
+            assert got[k] == -1
+        else:
+            assert got[k] == int(cn.check_normals_crossing(t, nv, 10)), k
+
+
 def test_pinned_variables_and_bad_input(gpu_engine, golden):
     """Edge cases of the boundary: waypoints whose box is a single point (w_right + w_left == w_veh: the interior point
     carries them as pinned rows, the masked factorisation path) against the dense oracle, and non-finite input flagged
