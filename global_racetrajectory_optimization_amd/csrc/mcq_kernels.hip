@@ -52,6 +52,8 @@ __shared__ double g_sm[SM_TOTAL];
 
 // ---------------------------------------------------------------------------------------------------------------------
 // small helpers
+#define MCQ_AS_WINDOW 8   /* block pivoting pins the furthest-out row per neighbourhood of this many rows either side */
+
 // ---------------------------------------------------------------------------------------------------------------------
 // i mod n for i in [-n, 2n): two compares instead of an integer division (indices one band width around the ring)
 __device__ __forceinline__ int cyc1(int i, int n)
@@ -2449,8 +2451,10 @@ __device__ __noinline__ int active_set(SolveCtx& c, const McqBatch& B, bool with
     gdouble* T3 = VEC(c.w, nm, V_T3);
     gdouble* Q = VEC(c.w, nm, V_Q);
     gdouble* KF = VEC(c.w, nm, V_SK);      // per-row flag of the curvature working set: 0, +1 (upper), -1 (lower)
+    gdouble* PV = VEC(c.w, nm, V_DXA);     // by how much a free row leaves its box in this round (0 elsewhere)
     gschar* ST = c.w.state;
     const double zscale = sc.zscale, fscale = sc.fscale, kb = sc.kbound;
+    const int win = MCQ_AS_WINDOW < (n - 1) / 2 ? MCQ_AS_WINDOW : (n - 1) / 2;
     iters = 0;
     kkt = 0.0;
     nk_out = 0;
@@ -2586,12 +2590,14 @@ __device__ __noinline__ int active_set(SolveCtx& c, const McqBatch& B, bool with
         for (int i = tid; i < n; i += MCQ_NT) {
             const signed char st = ST[i];
             int v = 0;
+            double pv = 0.0;
             if (st == 0) {
-                if (X[i] < LO[i] - TOLX) v = -1;
-                else if (X[i] > HI[i] + TOLX) v = 1;
+                if (X[i] < LO[i] - TOLX) { v = -1; pv = LO[i] - X[i]; }
+                else if (X[i] > HI[i] + TOLX) { v = 1; pv = X[i] - HI[i]; }
                 kk = fmax(kk, fabs(G[i]));
             } else if (st == -1) { if (G[i] < -toly) v = 2; }
             else if (st == 1) { if (G[i] > toly) v = 2; }
+            PV[i] = pv;
             int vk = 0;
             if (with_kappa) {
                 const double kf = KF[i];
@@ -2637,7 +2643,21 @@ __device__ __noinline__ int active_set(SolveCtx& c, const McqBatch& B, bool with
             int vk = (code + 20) / 8 - 2;
             int v = code - 8 * vk;
             if (v > 2) { v -= 8; vk += 1; }
-            if (v != 0 && (full || i == (int)imax)) ST[i] = v == 2 ? 0 : (signed char)v;
+            if (v != 0 && (full || i == (int)imax)) {
+                // A missing active row lets the minimiser leave the box over a whole stretch of neighbours (the Hessian is a
+                // fourth-difference operator: the raceline bulges through the wall); pinning the stretch pins rows that are
+                // free at the optimum, their multipliers come out with the wrong sign, and on these Hessians the exchange
+                // then wanders for dozens of rounds.  Only the row that leaves the box furthest within MCQ_AS_WINDOW rows
+                // either side is pinned: the wall touches the raceline where it bulges most.  (Wrong-signed multipliers are
+                // all released, and the single-pivot backup rule below still bounds the number of rounds.)
+                bool take = true;
+                if (full && v != 2) {
+                    const double me = PV[i];
+                    for (int o = 1; o <= win && take; ++o)
+                        if (PV[cyc1(i - o, n)] >= me || PV[cyc1(i + o, n)] > me) take = false;
+                }
+                if (take) ST[i] = v == 2 ? 0 : (signed char)v;
+            }
             if (vk != 0 && (full || n + i == (int)imax)) KF[i] = vk == 2 ? 0.0 : (double)vk;
         }
         __syncthreads();

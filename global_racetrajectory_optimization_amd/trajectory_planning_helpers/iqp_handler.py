@@ -95,6 +95,7 @@ def _iqp_batch_device(eng, tracks, kappa_bound, w_veh, stepsize_interp, iters_mi
             curv = eng.download(d_curv, (bsz,), np.float64)
             status = eng.download(d_status, (bsz,), np.int32)
             scale = it * 1.0 / iters_min if it < iters_min else 1.0
+            done = []
             for k in np.nonzero(live)[0]:
                 _omc.raise_for_status(int(status[k]))
                 if print_debug:
@@ -102,11 +103,23 @@ def _iqp_batch_device(eng, tracks, kappa_bound, w_veh, stepsize_interp, iters_mi
                 if it >= iters_min and curv[k] <= curv_error_allowed:
                     if print_debug:
                         print("Finished IQP!")
+                    done.append(int(k))
+            if len(done) > 8:
+                # many tracks finish in the same round (the usual case: identical iters_min): three bulk copies instead of
+                # three small blocking copies per track
+                al_all = eng.download(d_alpha, (bsz, nmax), np.float64)
+                ref_all = eng.download(d_ref[cur], (bsz, nmax, 4), np.float64)
+                nv_all = eng.download(d_nv[cur], (bsz, nmax, 2), np.float64)
+                for k in done:
+                    nk = int(n_host[k])
+                    out[k] = (al_all[k, :nk].copy(), ref_all[k, :nk].copy(), nv_all[k, :nk].copy())
+            else:
+                for k in done:
                     nk = int(n_host[k])
                     out[k] = (eng.download(d_alpha, (nk,), np.float64, k * nmax * f8),
                               eng.download(d_ref[cur], (nk, 4), np.float64, k * nmax * 4 * f8),
                               eng.download(d_nv[cur], (nk, 2), np.float64, k * nmax * 2 * f8))
-                    live[k] = False
+            live[done] = False
             if not live.any():
                 break
             eng.upload(d_live, live.astype(np.int32))

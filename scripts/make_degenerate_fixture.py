@@ -5,7 +5,11 @@ with multipliers down to 1e-7 of the gradient scale.  Solved by the dense Goldfa
 pairs at mu = 1e-10 are 5 mm from the optimum on it and block pivoting from their active-set guess does not settle
  -- this is the regression instance of the two-attempt driver.
 
-  python scripts/make_degenerate_fixture.py        # ~2 minutes on CPU, writes tests/golden/iqp_pass3_oval3.npz
+  python scripts/make_degenerate_fixture.py [TRACK]       # ~2 minutes on CPU, writes tests/golden/iqp_pass3_oval<TRACK>.npz
+
+TRACK = 3 (default) is the regression instance of the two-attempt driver; TRACK = 629 is the instance on which block pivoting
+with whole stretches pinned needed 49 rounds even from the mu = 1e-13 guess (off by ONE row) -- the regression instance of the
+furthest-row-per-neighbourhood rule.
 """
 import os
 import sys
@@ -21,7 +25,8 @@ from oracle import qp_ref, tph_ref                                              
 
 def main():
     qp_ref.build()
-    ref_b, nv_b, sc_b = synthetic.oval_batch(1, n=2000, first=3)
+    track = int(sys.argv[1]) if len(sys.argv) > 1 else 3
+    ref_b, nv_b, sc_b = synthetic.oval_batch(1, n=2000, first=track)
     ref, nv, sc = ref_b[0].copy(), nv_b[0].copy(), sc_b[0]
     for it in (1, 2):
         A = cs.build_les_matrix(ref.shape[0], sc if sc is not None else np.ones(ref.shape[0]))
@@ -30,7 +35,7 @@ def main():
         sc = None
     A = cs.build_les_matrix(ref.shape[0], np.ones(ref.shape[0]))
     alpha, err = tph_ref.opt_min_curv(ref, nv, A, 0.12, 3.4)
-    out = os.path.join(ROOT, "tests", "golden", "iqp_pass3_oval3.npz")
+    out = os.path.join(ROOT, "tests", "golden", "iqp_pass3_oval%d.npz" % track)
     np.savez_compressed(out, reftrack=ref, normvec=nv, alpha=alpha, curv_error_max=err, kappa_bound=0.12, w_veh=3.4)
     print("wrote", out, "N =", ref.shape[0], "active rows:",
           int(np.sum((np.abs(alpha + (ref[:, 3] - 1.7)) < 1e-9) | (np.abs(alpha - (ref[:, 2] - 1.7)) < 1e-9))))

@@ -259,6 +259,28 @@ def test_iqp_device_resident_matches_golden(gpu_engine, golden):
         assert np.max(np.abs(nv_out - g["iqp_normvec"])) < 1e-8
 
 
+def test_iqp_device_resident_driver_bulk_round(gpu_engine):
+    """The device-resident IQP driver (QP pass + glue kernel per round, tracks resident between passes) against the host-glue
+    driver on a batch large enough that the tracks finishing in one round come back with the three bulk copies."""
+    from global_racetrajectory_optimization_amd.trajectory_planning_helpers import iqp_handler as iq
+    from test_emu_kernels import _small_track
+    tracks = []
+    for k in range(12):
+        ref, nv, _, sc = _small_track(18 + k, seed=500 + k)
+        tracks.append(dict(reftrack=ref, normvectors=nv, scaling=sc))
+    step = 2.0 * np.pi * 40.0 / 22.0
+    st_d, st_h = {}, {}
+    out_d = iq.iqp_handler_batch([dict(t, reftrack=t["reftrack"].copy()) for t in tracks], 0.5, 2.0, step, 3, 0.01, engine=gpu_engine,
+                                 stats=st_d, device_resident=True)
+    out_h = iq.iqp_handler_batch([dict(t, reftrack=t["reftrack"].copy()) for t in tracks], 0.5, 2.0, step, 3, 0.01, engine=gpu_engine,
+                                 stats=st_h, device_resident=False)
+    assert st_d["rounds"] == st_h["rounds"] and st_d["qp_solves"] == st_h["qp_solves"]
+    for (a_d, r_d, n_d), (a_h, r_h, n_h) in zip(out_d, out_h):
+        assert a_d.shape == a_h.shape and r_d.shape == r_h.shape
+        assert np.max(np.abs(a_d - a_h)) < 1e-8
+        assert np.max(np.abs(r_d - r_h)) < 1e-8 and np.max(np.abs(n_d - n_h)) < 1e-8
+
+
 def test_degenerate_iqp_pass_two_attempt_driver(gpu_engine):
     """The QP of the third IQP pass on a synthetic N = 2000 oval (tests/golden/iqp_pass3_oval3.npz, made by
     scripts/make_degenerate_fixture.py with the dense oracle): 42 touched bounds with multipliers down to 1e-7 of the
@@ -273,6 +295,22 @@ def test_degenerate_iqp_pass_two_attempt_driver(gpu_engine):
     assert abs(curv[0] - float(g["curv_error_max"])) < CURV_TOL
     assert info[0]["kkt_res"] < 1e-9
     assert info[0]["as_iters"] <= 12
+
+
+def test_block_pivoting_pins_one_row_per_neighbourhood(gpu_engine):
+    """Third IQP pass of synthetic oval 629 (tests/golden/iqp_pass3_oval629.npz): with every row of a stretch that leaves the
+    box pinned at once, block pivoting needed 49 rounds on this instance even from the mu = 1e-13 guess, which is off by ONE
+    row (one slow problem stretches the whole launch: 97 instead of 66 ms for the 1024 third passes).  Pinning only the
+    furthest-out row per neighbourhood settles it -- and the oval-3 instance -- in a handful of rounds."""
+    from conftest import load_golden
+    for name in ("iqp_pass3_oval629", "iqp_pass3_oval3"):
+        g = load_golden(name)
+        al, curv, st, info = gpu_engine.solve_batch([dict(reftrack=g["reftrack"], normvec=g["normvec"], scaling=None,
+                                                          kappa_bound=float(g["kappa_bound"]), w_veh=float(g["w_veh"]))])
+        assert st[0] == 0
+        assert np.max(np.abs(al[0] - g["alpha"])) < ALPHA_TOL
+        assert abs(curv[0] - float(g["curv_error_max"])) < CURV_TOL
+        assert info[0]["as_iters"] <= 8, (name, info[0]["as_iters"])
 
 
 def test_prep_on_device_and_solve_without_normals(gpu_engine, golden):
