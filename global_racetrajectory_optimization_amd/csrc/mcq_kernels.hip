@@ -2732,7 +2732,7 @@ __global__ void __launch_bounds__(MCQ_NT) mcq_solve_kernel(McqBatch B)
         // and the active-set phase starts again with the full budget.
         gdouble* XS = VEC(c.w, nm, V_TL);
         for (int i = tid; i < n; i += MCQ_NT) XS[i] = X[i];
-        const int cap1 = B.max_as_iter < 4 ? B.max_as_iter : 4;
+        const int cap1 = B.max_as_iter < 6 ? B.max_as_iter : 6;
         status = active_set(c, B, false, ipm_iters >= 1 && c.last_step >= 0.9, cap1, sc, as_iters, kkt, nk_dummy);
         if (status == MCQ_ITER_CAP && B.max_as_iter > cap1) {
             c.second_attempt = 1;

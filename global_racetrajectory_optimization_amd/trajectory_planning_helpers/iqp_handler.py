@@ -48,8 +48,7 @@ def _iqp_batch_device(eng, tracks, kappa_bound, w_veh, stepsize_interp, iters_mi
     # 30 % + 16 points of headroom, reported (not truncated) if it ever is not enough
     nmax = 0
     for r in refs:
-        closed = np.vstack((r[:, :2], r[:1, :2]))
-        length = float(np.sum(np.sqrt(np.sum(np.diff(closed, axis=0) ** 2, axis=1))))
+        length = float(np.hypot(np.diff(r[:, 0], append=r[0, 0]), np.diff(r[:, 1], append=r[0, 1])).sum())
         nmax = max(nmax, r.shape[0], int(np.ceil(1.3 * length / stepsize_interp)) + 16)
     ref_h = np.zeros((bsz, nmax, 4))
     nv_h = np.zeros((bsz, nmax, 2))
@@ -110,9 +109,9 @@ def _iqp_batch_device(eng, tracks, kappa_bound, w_veh, stepsize_interp, iters_mi
                 al_all = eng.download(d_alpha, (bsz, nmax), np.float64)
                 ref_all = eng.download(d_ref[cur], (bsz, nmax, 4), np.float64)
                 nv_all = eng.download(d_nv[cur], (bsz, nmax, 2), np.float64)
-                for k in done:
+                for k in done:          # views into the three bulk arrays (no per-track copies)
                     nk = int(n_host[k])
-                    out[k] = (al_all[k, :nk].copy(), ref_all[k, :nk].copy(), nv_all[k, :nk].copy())
+                    out[k] = (al_all[k, :nk], ref_all[k, :nk], nv_all[k, :nk])
             else:
                 for k in done:
                     nk = int(n_host[k])

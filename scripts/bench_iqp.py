@@ -59,14 +59,17 @@ def main():
     tracks = [dict(reftrack=ref[k].copy(), normvectors=nv[k], scaling=sc[k]) for k in range(Bi)]
     res = {}
     for mode in ((True,) if args.no_host else (True, False)):
-        stats = {}
-        t0 = time.perf_counter()
-        out = iqp_handler.iqp_handler_batch([dict(t, reftrack=t["reftrack"].copy()) for t in tracks], 0.12, 3.4, 3.0, 3, 0.01,
-                                            engine=eng, stats=stats, device_resident=mode)
-        dt = time.perf_counter() - t0
-        res["device" if mode else "host"] = dict(seconds=dt, qp_solves=stats["qp_solves"], rounds=stats["rounds"],
-                                                  qp_solves_per_s=stats["qp_solves"] / dt, n_last=int(out[0][0].shape[0]),
-                                                  alpha0=out[0][0])
+        first = None
+        for rep in range(2 if mode else 1):     # device mode: the first run also pays for growing the engine's workspace
+            stats = {}
+            t0 = time.perf_counter()
+            out = iqp_handler.iqp_handler_batch([dict(t, reftrack=t["reftrack"].copy()) for t in tracks], 0.12, 3.4, 3.0, 3, 0.01,
+                                                engine=eng, stats=stats, device_resident=mode)
+            dt = time.perf_counter() - t0
+            first = dt if first is None else first
+        res["device" if mode else "host"] = dict(seconds=dt, seconds_first_run=first, qp_solves=stats["qp_solves"],
+                                                  rounds=stats["rounds"], qp_solves_per_s=stats["qp_solves"] / dt,
+                                                  n_last=int(out[0][0].shape[0]), alpha0=out[0][0])
     diff = None
     if "host" in res and res["device"]["n_last"] == res["host"]["n_last"]:
         diff = float(np.max(np.abs(res["device"]["alpha0"] - res["host"]["alpha0"])))
