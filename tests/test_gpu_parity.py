@@ -161,6 +161,31 @@ def test_fp32_boundary_full_size(gpu_engine):
     assert dev < 5e-2
 
 
+def test_random_rings_against_dense_oracle(gpu_engine):
+    """96 random star-shaped rings (n = 24 ... 160, widths between barely feasible and generous, so anything from a handful to
+    most of the rows ends up on a bound) in one ragged launch, every one against the live dense oracle."""
+    from oracle import tph_ref
+    from test_emu_kernels import _small_track
+    rng = np.random.default_rng(2024)
+    probs, refs = [], []
+    for k in range(96):
+        n = int(rng.integers(24, 161))
+        ref, nv, A, sc = _small_track(n, seed=7000 + k)
+        w_veh = float(rng.choice([1.2, 2.0, 2.6]))
+        ref[:, 2:] = 0.5 * w_veh + rng.uniform(0.05, 2.5) * rng.uniform(0.2, 1.0, size=(n, 2))
+        probs.append(dict(reftrack=ref, normvec=nv, scaling=sc, kappa_bound=1.0, w_veh=w_veh))
+        refs.append(tph_ref.opt_min_curv(ref, nv, A, 1.0, w_veh))
+    al, curv, st, info = gpu_engine.solve_batch(probs)
+    worst = 0.0
+    for k, (a_ref, err_ref) in enumerate(refs):
+        assert st[k] == 0, (k, st[k])
+        worst = max(worst, float(np.max(np.abs(al[k] - a_ref))))
+        assert np.max(np.abs(al[k] - a_ref)) < ALPHA_TOL, (k, info[k])
+        assert abs(curv[k] - err_ref) < CURV_TOL, k
+    print("random rings: max |alpha - oracle| = %.2e m, active rows %d ... %d, pivoting rounds <= %d"
+          % (worst, min(i["n_active_box"] for i in info), max(i["n_active_box"] for i in info), max(i["as_iters"] for i in info)))
+
+
 def test_ragged_batch_and_small_rings(gpu_engine, golden):
     from oracle import tph_ref
     probs, refs = [], []
