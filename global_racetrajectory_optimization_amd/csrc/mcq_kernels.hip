@@ -52,6 +52,12 @@ __shared__ double g_sm[SM_TOTAL];
 
 // ---------------------------------------------------------------------------------------------------------------------
 // small helpers
+#ifndef MCQ_TAPIA_RATIO
+#define MCQ_TAPIA_RATIO 0.7    /* Tapia evidence for an active row: s+/s < RATIO * z+/z and s+/s < SHRINK in the last interior-point step */
+#endif
+#ifndef MCQ_TAPIA_SHRINK
+#define MCQ_TAPIA_SHRINK 0.7
+#endif
 #define MCQ_AS_WINDOW 8   /* block pivoting pins the furthest-out row per neighbourhood of this many rows either side */
 
 // ---------------------------------------------------------------------------------------------------------------------
@@ -2184,7 +2190,7 @@ __device__ __noinline__ int ipm(SolveCtx& c, const McqBatch& B, bool with_kappa,
                 const double sl = X[i] - LO[i], su = HI[i] - X[i];
                 const double rsl = (sl + a * RHS[i]) * ZL[i], rzl = (ZL[i] + a * T1[i]) * sl;
                 const double rsu = (su - a * RHS[i]) * ZU[i], rzu = (ZU[i] + a * T2[i]) * su;
-                const bool al = rsl < 0.3 * rzl && sl + a * RHS[i] < 0.5 * sl, au = rsu < 0.3 * rzu && su - a * RHS[i] < 0.5 * su;
+                const bool al = rsl < MCQ_TAPIA_RATIO * rzl && sl + a * RHS[i] < MCQ_TAPIA_SHRINK * sl, au = rsu < MCQ_TAPIA_RATIO * rzu && su - a * RHS[i] < MCQ_TAPIA_SHRINK * su;
                 VEC(c.w, nm, V_T3)[i] = al ? -1.0 : (au ? 1.0 : 0.0);                     // Tapia indicators, see active_set()
             }
             X[i] += a * RHS[i];
@@ -2397,7 +2403,7 @@ __device__ __noinline__ int ipm_box(SolveCtx& c, const McqBatch& B, const SolveS
                 const double sl = x[u] - lo[u], su = hi[u] - x[u];
                 const double rsl = (sl + a * dx[u]) * zl[u], rzl = (zl[u] + a * dzl[u]) * sl;     // s+/s < z+/z  <=>  s+ z < z+ s
                 const double rsu = (su - a * dx[u]) * zu[u], rzu = (zu[u] + a * dzu[u]) * su;
-                const bool al = rsl < 0.3 * rzl && sl + a * dx[u] < 0.5 * sl, au = rsu < 0.3 * rzu && su - a * dx[u] < 0.5 * su;
+                const bool al = rsl < MCQ_TAPIA_RATIO * rzl && sl + a * dx[u] < MCQ_TAPIA_SHRINK * sl, au = rsu < MCQ_TAPIA_RATIO * rzu && su - a * dx[u] < MCQ_TAPIA_SHRINK * su;
                 IND[i] = al ? -1.0 : (au ? 1.0 : 0.0);
             }
         }
@@ -2468,11 +2474,13 @@ __device__ __noinline__ int active_set(SolveCtx& c, const McqBatch& B, bool with
             signed char st = 0;
             if (sl * zscale < ZL[i] * wdt) st = -1;
             else if (su * zscale < ZU[i] * wdt) st = 1;
-            // ... plus the rows it misses at mu = 1e-10 (multipliers 1e-7 of the gradient scale) when the last interior-point
-            // step gave strong Tapia evidence for them: slack at least halved AND shrinking more than 3x faster than the
-            // multiplier,  s+/s < min(1/2, 0.3 z+/z).  Deliberately one-sided and conservative: a missed active row costs one
-            // more pivoting round, a free row pinned by mistake can send block pivoting on this ill-conditioned H into
-            // dozens of rounds (scripts/proto_ipm.py; 30 synthetic N = 2000 problems: 1.83 -> 1.53 rounds, no false positive).
+            // ... plus the rows it misses at mu = 1e-10 (weakly active: slack and multiplier both ~ sqrt(mu)) when the last
+            // interior-point step gave Tapia evidence for them: slack shrinking faster than the multiplier,
+            // s+/s < MCQ_TAPIA_SHRINK and s+/s < MCQ_TAPIA_RATIO z+/z.  One-sided (it only adds rows).  The thresholds were
+            // 0.5 / 0.3 while a free row pinned by mistake could send block pivoting into dozens of rounds; with the
+            // one-row-per-neighbourhood exchange below a false positive costs one round like a miss does, and 0.7 / 0.7
+            // measured best on the 3 x 1024 problems of the IQP workload (rounds 1.60 -> 1.27 in the first passes;
+            // 1.0 / 1.0: 1.23 but a 6-round straggler).
             if (tapia && st == 0) st = (signed char)VEC(c.w, nm, V_T3)[i];
             ST[i] = st;
         }
