@@ -120,6 +120,24 @@ def test_full_size_oval_properties(gpu_engine):
     assert np.max(np.abs(al3[1] + al[0])) < ALPHA_TOL
 
 
+def test_long_ring_general_path_properties(gpu_engine):
+    """N = 3000 (> 2048 waypoints: the interior point's general vector passes instead of the register-resident ones): KKT
+    certificate, feasibility, start-index rotation."""
+    ref, nv, sc = synthetic.oval_batch(2, n=3000)
+    probs = [dict(reftrack=ref[b], normvec=nv[b], scaling=sc[b], kappa_bound=0.12, w_veh=3.4) for b in range(2)]
+    al, curv, st, info = gpu_engine.solve_batch(probs)
+    assert np.all(st == 0)
+    for b in range(2):
+        lo, hi = -(ref[b, :, 3] - 1.7), ref[b, :, 2] - 1.7
+        assert np.all(al[b] >= lo - 1e-12) and np.all(al[b] <= hi + 1e-12)
+        assert info[b]["kkt_res"] < 1e-9 and 0 < info[b]["n_active_box"] < 3000
+    r = 777
+    pr = dict(reftrack=np.roll(ref[0], r, axis=0), normvec=np.roll(nv[0], r, axis=0), scaling=np.roll(sc[0], r),
+              kappa_bound=0.12, w_veh=3.4)
+    al2, _, st2, _ = gpu_engine.solve_batch([pr])
+    assert st2[0] == 0 and np.max(np.abs(np.roll(al2[0], -r) - al[0])) < ALPHA_TOL
+
+
 def test_oval_n2000_against_dense_gi_oracle(gpu_engine):
     """One full-size problem against the dense Goldfarb-Idnani oracle fed with the dense E (about 10 s of CPU)."""
     from oracle import qp_ref, tph_ref
