@@ -104,6 +104,8 @@ def main():
     ap.add_argument("--io", choices=("f64", "f32"), default="f64")
     ap.add_argument("--perturb-centreline", action="store_true")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--force-collective", action="store_true",
+                    help="initialise RCCL and run the all-gather even with one rank (self-test of the N > 1 path on a 1-GPU box)")
     args = ap.parse_args()
 
     import torch
@@ -117,10 +119,25 @@ def main():
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     dist = None
-    if world > 1:
+    collective = world > 1 or args.force_collective
+    if collective:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group(backend="nccl", rank=rank, world_size=world, device_id=dev)
+        os.environ.setdefault("MASTER_PORT", "29531")
+        # RCCL prints its version banner (NCCL_DEBUG=VERSION is set on the GPU boxes) with printf on the first collective: keep it
+        # off stdout, where exactly ONE JSON line is expected -- file descriptor 1 points at stderr while RCCL comes up
+        import ctypes
+        sys.stdout.flush()
+        saved_fd = os.dup(1)
+        os.dup2(2, 1)
+        try:
+            dist.init_process_group(backend="nccl", rank=rank, world_size=world, device_id=dev)
+            dist.barrier()
+            torch.cuda.synchronize()
+        finally:
+            ctypes.CDLL(None).fflush(None)
+            os.dup2(saved_fd, 1)
+            os.close(saved_fd)
 
     B, n = args.batch, args.n
     ref_h, nv_h, sc_h = synthetic.oval_batch(B, n=n, first=rank * B, perturb_centreline=args.perturb_centreline)
@@ -133,7 +150,7 @@ def main():
     d_curv = torch.zeros((B,), dtype=torch.float64, device=dev)
     d_status = torch.zeros((B,), dtype=torch.int32, device=dev)
     d_info = torch.zeros((B, INFO_DTYPE.itemsize), dtype=torch.uint8, device=dev)
-    d_all = torch.zeros((world * B, n), dtype=io_t, device=dev) if world > 1 else None
+    d_all = torch.zeros((world * B, n), dtype=io_t, device=dev) if collective else None
 
     eng = engine.Engine(local_rank)
     solve_ms = []
@@ -148,13 +165,13 @@ def main():
         eng.sync()
         if record:
             solve_ms.append(eng.last_timing_ms())
-        if world > 1:
+        if collective:
             dist.all_gather_into_tensor(d_all, d_alpha)
 
     def fence():
         eng.sync()
         torch.cuda.synchronize()
-        if world > 1:
+        if collective:
             dist.barrier()
             torch.cuda.synchronize()
 
@@ -166,10 +183,11 @@ def main():
         step(True)
     fence()
     dt = time.perf_counter() - t0
-    if world > 1:
+    if collective:
         t = torch.tensor([dt], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
+        assert torch.equal(d_all[rank * B:(rank + 1) * B], d_alpha), "all-gather: own shard differs"
 
     status = d_status.cpu().numpy()
     info = d_info.cpu().numpy().view(INFO_DTYPE).reshape(B)
@@ -192,7 +210,7 @@ def main():
                                    "curvature-error check) per track per step; kappa_bound=0.12, w_veh=3.4" % (n, B),
                        "batch_per_gpu": B, "n_waypoints": n, "io": args.io + (" rows / alpha in HBM, fp64 arithmetic" if f32 else ""),
                        "centrelines": "perturbed per track" if args.perturb_centreline else "shared",
-                       "collective": "1 all-gather of alpha per step" if world > 1 else "none",
+                       "collective": "1 all-gather of alpha per step" if collective else "none",
                        "failed_problems": n_bad,
                        "mean_ipm_iters": float(info["ipm_iters"].mean()), "mean_as_iters": float(info["as_iters"].mean()),
                        "mean_active_box_rows": float(info["n_active_box"].mean()),
@@ -216,7 +234,7 @@ def main():
                                    "max_abs_alpha_diff_vs_gpu_m": float(np.max(np.abs(a_cpu - alpha0))),
                                    "curv_err_diff": abs(err_cpu - curv0)}
         print(json.dumps(out))
-    if world > 1:
+    if collective:
         dist.destroy_process_group()
     eng.close()
 
