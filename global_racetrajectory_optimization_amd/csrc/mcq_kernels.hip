@@ -52,6 +52,12 @@ __shared__ double g_sm[SM_TOTAL];
 
 // ---------------------------------------------------------------------------------------------------------------------
 // small helpers
+#ifndef MCQ_IPM_GM_MIN
+#define MCQ_IPM_GM_MIN 0.995   /* interior point: fraction of the way to the boundary, max(GM_MIN, 1 - GM_C * mu / mu_0) */
+#endif
+#ifndef MCQ_IPM_GM_C
+#define MCQ_IPM_GM_C 10.0
+#endif
 #ifndef MCQ_TAPIA_RATIO
 #define MCQ_TAPIA_RATIO 0.7    /* Tapia evidence for an active row: s+/s < RATIO * z+/z and s+/s < SHRINK in the last interior-point step */
 #endif
@@ -2364,7 +2370,14 @@ __device__ __noinline__ int ipm_box(SolveCtx& c, const McqBatch& B, const SolveS
             IPB_SETUP
             double dx[IPB_E], x[IPB_E], zl[IPB_E], zu[IPB_E], g[IPB_E], dzl[IPB_E], dzu[IPB_E], hdx[IPB_E];
             bool act[IPB_E];
-            double amax = 1.0 / 0.995;
+            // fraction of the way to the boundary: 0.995 far from the solution, closer to 1 as the complementarity shrinks
+            // (Mehrotra's adaptive rule; saves a third of an iteration on average, scripts/proto_ipm.py "adaptive step")
+#ifdef MCQ_IPM_FIXED_STEP
+            const double gm = 0.995;
+#else
+            const double gm = fmin(fmax(MCQ_IPM_GM_MIN, 1.0 - MCQ_IPM_GM_C * mu / (zscale * sc.wmean)), 1.0 - 1e-9);
+#endif
+            double amax = 1.0 / gm;
             double da[IPB_E], lo[IPB_E], hi[IPB_E], sg[IPB_E];
 #pragma unroll
             for (int u = 0; u < IPB_E; ++u) {
@@ -2389,7 +2402,7 @@ __device__ __noinline__ int ipm_box(SolveCtx& c, const McqBatch& B, const SolveS
                 if (dzu[u] < 0.0) amax = fmin(amax, -zu[u] / dzu[u]);
             }
             amax = block_reduce_(amax, 1, red);
-            const double a = fmin(1.0, 0.995 * amax);
+            const double a = fmin(1.0, gm * amax);
             c.last_step = a;
 #pragma unroll
             for (int u = 0; u < IPB_E; ++u) {
