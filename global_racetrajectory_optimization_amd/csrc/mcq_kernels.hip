@@ -525,8 +525,16 @@ __device__ __forceinline__ double gram_entry(const gdouble* Et, const gdouble* s
     constexpr int GB = 11;
     const int ew = bR + bE + 1;
     double acc = 0.0;
+    // Diagonals oo of the first factor that meet the band of the second one: oo in [-dd, ew - 1 - dd] (no wrapped image can
+    // fall inside the band once the ring is longer than two band widths plus the distance) -- batches outside are skipped
+    int ob0 = 0, ob1 = EW;
+    if (n > 3 * EW) {
+        const int lo = dd < 0 ? -dd : 0, hi = dd > 0 ? ew - 1 - dd : ew - 1;
+        ob0 = (lo / GB) * GB;
+        ob1 = hi + 1;
+    }
 #pragma unroll 1
-    for (int o0 = 0; o0 < EW; o0 += GB) {
+    for (int o0 = ob0; o0 < ob1; o0 += GB) {
         double ea[GB], eb[GB], es[GB];
         bool ok[GB];
 #pragma unroll
