@@ -321,6 +321,41 @@ extern "C" int mcq_solve_device_ragged(mcq_handle* h, int batch, int nmax, const
     return launch(h, B, o);
 }
 
+// The ragged device entry with per-problem vehicle parameters (device arrays): the shape of a vehicle-width sweep whose
+// tracks are already resident (BASELINE config 4).  Either list may be NULL (the scalar applies to every problem).
+extern "C" int mcq_solve_device_ragged_params(mcq_handle* h, int batch, int nmax, const int* n_list, const double* reftrack,
+                                              const double* normvec, const double* scaling, double kappa_bound, double w_veh,
+                                              const double* kappa_bound_list, const double* w_veh_list, const mcq_opts* opts,
+                                              double* alpha_out, double* curv_err_out, int* status_out, mcq_info* info_out)
+{
+    if (!h || batch <= 0 || nmax <= 0 || !n_list || !reftrack || !alpha_out || !curv_err_out || !status_out) {
+        g_err = "mcq_solve_device_ragged_params: bad argument";
+        return MCQ_E_ARG;
+    }
+    HIP_TRY(hipSetDevice(h->device));
+    const mcq_opts o = resolve_opts(opts);
+    int rc = ensure_ws(h, (size_t)batch, (size_t)nmax);
+    if (rc) return rc;
+    McqBatch B;
+    memset(&B, 0, sizeof(B));
+    B.batch = batch;
+    B.n = nmax;
+    B.nmax = nmax;
+    B.n_list = n_list;
+    B.ref = reftrack;
+    B.nv = normvec;
+    B.sc = scaling;
+    B.alpha = alpha_out;
+    B.curv_err = curv_err_out;
+    B.status = status_out;
+    B.info = info_out;
+    B.kappa_bound = kappa_bound;
+    B.w_veh = w_veh;
+    B.kappa_bound_list = kappa_bound_list;
+    B.w_veh_list = w_veh_list;
+    return launch(h, B, o);
+}
+
 extern "C" int mcq_prep_device(mcq_handle* h, int batch, int nmax, const int* n_list, const double* reftrack,
                                double* normvec_out, double* scaling_out, int* status_out)
 {

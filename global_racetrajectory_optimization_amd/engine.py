@@ -44,7 +44,7 @@ class McqInfo(ctypes.Structure):
 
 
 EXPORTED_SYMBOLS = ("mcq_create", "mcq_destroy", "mcq_last_error", "mcq_default_opts", "mcq_solve_batch",
-                    "mcq_solve_device", "mcq_solve_device_f32", "mcq_solve_device_ragged", "mcq_prep_device", "mcq_relinearise_device",
+                    "mcq_solve_device", "mcq_solve_device_f32", "mcq_solve_device_ragged", "mcq_solve_device_ragged_params", "mcq_prep_device", "mcq_relinearise_device",
                     "mcq_vel_profile_device", "mcq_vel_profile_device_ragged", "mcq_raceline_device", "mcq_normals_crossing_device",
                     "mcq_device_alloc",
                     "mcq_device_free", "mcq_copy_to_device", "mcq_copy_to_host", "mcq_sync", "mcq_stream",
@@ -82,6 +82,9 @@ def load_library(path=None):
     lib.mcq_solve_device_ragged.argtypes = [vp, ctypes.c_int, ctypes.c_int, vp, vp, vp, vp, ctypes.c_double,
                                             ctypes.c_double, ctypes.POINTER(McqOpts), vp, vp, vp, vp]
     lib.mcq_solve_device_ragged.restype = ctypes.c_int
+    lib.mcq_solve_device_ragged_params.argtypes = [vp, ctypes.c_int, ctypes.c_int, vp, vp, vp, vp, ctypes.c_double,
+                                                   ctypes.c_double, vp, vp, ctypes.POINTER(McqOpts), vp, vp, vp, vp]
+    lib.mcq_solve_device_ragged_params.restype = ctypes.c_int
     lib.mcq_prep_device.argtypes = [vp, ctypes.c_int, ctypes.c_int, vp, vp, vp, vp, vp]
     lib.mcq_prep_device.restype = ctypes.c_int
     lib.mcq_relinearise_device.argtypes = [vp, ctypes.c_int, ctypes.c_int, vp, vp, vp, vp, vp, ctypes.c_double,
@@ -264,6 +267,16 @@ class Engine:
                                               d_scaling or None, float(kappa_bound), float(w_veh), ctypes.byref(opts),
                                               d_alpha, d_curv, d_status, d_info or None)
         self._check(rc, "mcq_solve_device_ragged")
+
+    def solve_device_ragged_params(self, batch, nmax, d_n, d_reftrack, d_normvec, d_scaling, kappa_bound, w_veh, d_kappa_list,
+                                   d_w_veh_list, d_alpha, d_curv, d_status, d_info=None, **opt_kw):
+        """solve_device_ragged with per-problem kappa_bound / w_veh (device arrays [batch] or None)."""
+        opts = self._opts(**opt_kw)
+        rc = self.lib.mcq_solve_device_ragged_params(self.h, int(batch), int(nmax), d_n, d_reftrack, d_normvec or None,
+                                                     d_scaling or None, float(kappa_bound), float(w_veh), d_kappa_list or None,
+                                                     d_w_veh_list or None, ctypes.byref(opts), d_alpha, d_curv, d_status,
+                                                     d_info or None)
+        self._check(rc, "mcq_solve_device_ragged_params")
 
     def prep_batch(self, reftracks):
         """Unit normals and spline scalings of the closed distance-scaled splines through a list of reference lines

@@ -126,6 +126,14 @@ int mcq_solve_device_ragged(mcq_handle* h, int batch, int nmax, const int* n_lis
                             const mcq_opts* opts, double* alpha_out, double* curv_err_out, int* status_out,
                             mcq_info* info_out);
 
+/* mcq_solve_device_ragged with per-problem vehicle parameters: kappa_bound_list / w_veh_list [batch] (DEVICE arrays; either may
+ * be NULL, then the scalar applies to every problem) -- what mcq_problem.{kappa_bound,w_veh} are to the host-buffer entry.  The
+ * shape of a vehicle-width sweep over resident tracks [REF params/racecar.ini:49,72; BASELINE config 4]. */
+int mcq_solve_device_ragged_params(mcq_handle* h, int batch, int nmax, const int* n_list, const double* reftrack,
+                                   const double* normvec, const double* scaling, double kappa_bound, double w_veh,
+                                   const double* kappa_bound_list, const double* w_veh_list, const mcq_opts* opts,
+                                   double* alpha_out, double* curv_err_out, int* status_out, mcq_info* info_out);
+
 /* fp32 at the boundary (BASELINE config 5: 65536 tracks, alpha collected with one all-gather): as mcq_solve_device, with
  * the tracks stored as float in HBM (reftrack [batch][n][4], normvec [batch][n][2] or NULL, scaling [batch][n] or NULL) and
  * alpha_out [batch][n] written as float.  The arithmetic in between is the fp64 engine, unchanged -- cond(H) = 1e9..1e12

@@ -281,6 +281,48 @@ def test_vehicle_width_sweep_mixed_tracks(gpu_engine, golden):
         assert abs(curv[k] - err_ref) < CURV_TOL, k
 
 
+def test_device_ragged_entry_with_per_problem_vehicle_parameters(gpu_engine, golden):
+    """mcq_solve_device_ragged_params (resident tracks, per-problem w_veh / kappa_bound as device arrays) against the
+    host-buffer entry, which carries the same parameters in mcq_problem: bitwise the same alpha."""
+    names = ("handling_track", "rounded_rectangle", "modena_2019")
+    probs = []
+    for k, name in enumerate(names):
+        for w_veh, kb in ((2.0, 0.12), (3.0, 0.2)):
+            g = golden[name]
+            probs.append(dict(reftrack=g["reftrack"], normvec=g["normvec"], scaling=g["scaling"], kappa_bound=kb, w_veh=w_veh))
+    al_h, curv_h, st_h, _ = gpu_engine.solve_batch(probs)
+    bsz = len(probs)
+    ns = np.array([p["reftrack"].shape[0] for p in probs], dtype=np.int32)
+    nmax = int(ns.max())
+    ref = np.zeros((bsz, nmax, 4)); nv = np.zeros((bsz, nmax, 2)); sc = np.ones((bsz, nmax))
+    for k, p in enumerate(probs):
+        ref[k, :ns[k]] = p["reftrack"]; nv[k, :ns[k]] = p["normvec"]; sc[k, :ns[k]] = p["scaling"]
+    eng = gpu_engine
+    ptrs = []
+
+    def up(a):
+        ptrs.append(eng.alloc(a.nbytes))
+        eng.upload(ptrs[-1], a)
+        return ptrs[-1]
+    try:
+        d_ref, d_nv, d_sc, d_n = up(ref), up(nv), up(sc), up(ns)
+        d_kb = up(np.array([p["kappa_bound"] for p in probs]))
+        d_wv = up(np.array([p["w_veh"] for p in probs]))
+        d_al, d_cu, d_st = up(np.zeros((bsz, nmax))), up(np.zeros(bsz)), up(np.zeros(bsz, dtype=np.int32))
+        eng.solve_device_ragged_params(bsz, nmax, d_n, d_ref, d_nv, d_sc, 0.0, 0.0, d_kb, d_wv, d_al, d_cu, d_st)
+        eng.sync()
+        al_d = eng.download(d_al, (bsz, nmax), np.float64)
+        st_d = eng.download(d_st, (bsz,), np.int32)
+        cu_d = eng.download(d_cu, (bsz,), np.float64)
+    finally:
+        for p in ptrs:
+            eng.free(p)
+    assert np.array_equal(st_d, st_h) and np.all(st_h == 0)
+    for k in range(bsz):
+        assert np.array_equal(al_d[k, :ns[k]], al_h[k]), k
+        assert cu_d[k] == curv_h[k]
+
+
 def test_iqp_device_resident_matches_golden(gpu_engine, golden):
     """Row f-1: a batch of IQP runs with the tracks resident in HBM between the passes (mcq_solve_device_ragged +
     mcq_relinearise_device) against the golden IQP end states of the oracle's host chain; ragged N, tracks finishing in
