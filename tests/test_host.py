@@ -79,3 +79,23 @@ def test_synthetic_oval_generator_is_deterministic():
     assert np.all(ref[:, :, 2:] > 3.4) and np.all(ref[:, :, 2:] < 6.6)
     assert np.max(np.abs(np.sum(nv ** 2, axis=2) - 1.0)) < 1e-12
     assert not np.array_equal(ref[0, :, 2], ref[1, :, 2])
+
+
+def test_header_is_plain_c_and_links_against_the_library(tmp_path):
+    """include/mcq.h is a C ABI: it must compile as C99 with no C++ or torch types in sight, and a C translation unit that
+    references every declared entry point must link against libmcq.so (no compute: nothing is run)."""
+    import shutil
+    import subprocess
+    if shutil.which("gcc") is None:
+        pytest.skip("no gcc")
+    hdr = open(os.path.join(ROOT, "include", "mcq.h")).read()
+    declared = sorted(set(re.findall(r"\b(mcq_[a-z0-9_]+)\s*\(", hdr)) - {"mcq_handle"})
+    src = tmp_path / "abi.c"
+    src.write_text('#include "mcq.h"\n#include <stdio.h>\ntypedef void (*fn_t)(void);\nint main(void) {\n    fn_t p[] = {%s};\n'
+                   '    printf("%%d\\n", (int)(sizeof(p) / sizeof(p[0])));\n    return p[0] == 0;\n}\n'
+                   % ", ".join("(fn_t)%s" % s for s in declared))
+    lib_dir = os.path.dirname(engine.DEFAULT_LIB)
+    exe = tmp_path / "abi"
+    subprocess.run(["gcc", "-std=c99", "-Wall", "-Wextra", "-pedantic", "-Werror", "-I", os.path.join(ROOT, "include"), str(src),
+                    "-o", str(exe), "-L", lib_dir, "-l:libmcq.so", "-Wl,-rpath," + lib_dir, "-Wl,--allow-shlib-undefined"], check=True)
+    assert exe.exists()
