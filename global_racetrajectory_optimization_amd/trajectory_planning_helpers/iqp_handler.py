@@ -6,6 +6,8 @@ followed by the raceline re-sampling glue (create_raceline / interp_track_widths
 from pass to pass, so a batch of IQP runs is driven in lock-step rounds with ragged N (iqp_handler_batch): every
 round is ONE batched engine launch over the tracks that have not terminated yet.
 """
+import time
+
 import numpy as np
 
 from .. import engine as _engine
@@ -40,6 +42,8 @@ def _iqp_batch_device(eng, tracks, kappa_bound, w_veh, stepsize_interp, iters_mi
     mcq_solve_device_ragged, the glue between passes mcq_relinearise_device.  Per round the host
     reads back curv_error / status / N per track and, for the tracks that finish, their final alpha / reftrack /
     normals.  Device memory through the engine's own C ABI (no second HIP runtime in the process)."""
+    t_start = time.perf_counter()
+    t_down = 0.0
     bsz = len(tracks)
     refs = [np.ascontiguousarray(t["reftrack"], dtype=np.float64) for t in tracks]
     nvs = [np.ascontiguousarray(t["normvectors"], dtype=np.float64) for t in tracks]
@@ -82,6 +86,8 @@ def _iqp_batch_device(eng, tracks, kappa_bound, w_veh, stepsize_interp, iters_mi
         live = np.ones(bsz, dtype=bool)
         out = [None] * bsz
         cur, n_solves, it = 0, 0, 0
+        eng.sync()
+        t_up = time.perf_counter() - t_start       # marshalling + upload of the tracks
         while live.any():
             it += 1
             if it > max_rounds:
@@ -94,6 +100,7 @@ def _iqp_batch_device(eng, tracks, kappa_bound, w_veh, stepsize_interp, iters_mi
             curv = eng.download(d_curv, (bsz,), np.float64)
             status = eng.download(d_status, (bsz,), np.int32)
             scale = it * 1.0 / iters_min if it < iters_min else 1.0
+            t_d0 = time.perf_counter()
             done = []
             for k in np.nonzero(live)[0]:
                 _omc.raise_for_status(int(status[k]))
@@ -119,6 +126,7 @@ def _iqp_batch_device(eng, tracks, kappa_bound, w_veh, stepsize_interp, iters_mi
                               eng.download(d_ref[cur], (nk, 4), np.float64, k * nmax * 4 * f8),
                               eng.download(d_nv[cur], (nk, 2), np.float64, k * nmax * 2 * f8))
             live[done] = False
+            t_down += time.perf_counter() - t_d0       # read-back of the tracks that finished in this round
             if not live.any():
                 break
             eng.upload(d_live, live.astype(np.int32))
@@ -136,7 +144,9 @@ def _iqp_batch_device(eng, tracks, kappa_bound, w_veh, stepsize_interp, iters_mi
         for p in bufs:
             eng.free(p)
     if stats is not None:
-        stats.update(rounds=it, qp_solves=n_solves, device_resident=True, nmax=nmax)
+        total = time.perf_counter() - t_start
+        stats.update(rounds=it, qp_solves=n_solves, device_resident=True, nmax=nmax, seconds_upload=t_up,
+                     seconds_download=t_down, seconds_rounds=total - t_up - t_down)
     return out
 
 

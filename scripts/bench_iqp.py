@@ -69,7 +69,8 @@ def main():
             first = dt if first is None else first
         res["device" if mode else "host"] = dict(seconds=dt, seconds_first_run=first, qp_solves=stats["qp_solves"],
                                                   rounds=stats["rounds"], qp_solves_per_s=stats["qp_solves"] / dt,
-                                                  n_last=int(out[0][0].shape[0]), alpha0=out[0][0])
+                                                  n_last=int(out[0][0].shape[0]), alpha0=out[0][0],
+                                                  **{k: stats[k] for k in ("seconds_upload", "seconds_rounds", "seconds_download") if k in stats})
     diff = None
     if "host" in res and res["device"]["n_last"] == res["host"]["n_last"]:
         diff = float(np.max(np.abs(res["device"]["alpha0"] - res["host"]["alpha0"])))
