@@ -38,6 +38,8 @@ struct mcq_handle {
     size_t cap_batch = 0;
     double *Eb = nullptr, *Et = nullptr, *Db = nullptr, *H = nullptr, *L = nullptr, *vec = nullptr, *Z = nullptr;
     signed char* state = nullptr;
+    signed char* state2 = nullptr;     // working sets carried through the IQP glue (warm start of the next pass)
+    bool state2_valid = false;
     // staging for the host-buffer entry point
     double *d_ref = nullptr, *d_nv = nullptr, *d_sc = nullptr, *d_alpha = nullptr, *d_curv = nullptr, *d_kb = nullptr,
            *d_wv = nullptr;
@@ -61,6 +63,7 @@ extern "C" void mcq_default_opts(mcq_opts* o)
     o->refine_steps = 2;
     o->check_kappa = 1;
     o->objective = MCQ_OBJ_MIN_CURV;
+    o->warm_start = 0;
 }
 
 static mcq_opts resolve_opts(const mcq_opts* in)
@@ -74,6 +77,7 @@ static mcq_opts resolve_opts(const mcq_opts* in)
         if (in->refine_steps >= 0) o.refine_steps = in->refine_steps;
         o.check_kappa = in->check_kappa;
         o.objective = in->objective == MCQ_OBJ_SHORTEST_PATH ? MCQ_OBJ_SHORTEST_PATH : MCQ_OBJ_MIN_CURV;
+        o.warm_start = in->warm_start != 0;
     }
     return o;
 }
@@ -97,8 +101,10 @@ extern "C" int mcq_create(int device_id, mcq_handle** out)
 static void free_ws(mcq_handle* h)
 {
     (void)hipFree(h->Eb); (void)hipFree(h->Et); (void)hipFree(h->Db); (void)hipFree(h->H); (void)hipFree(h->L); (void)hipFree(h->vec); (void)hipFree(h->Z); (void)hipFree(h->state);
+    (void)hipFree(h->state2);
     h->Eb = h->Et = h->Db = h->H = h->L = h->vec = h->Z = nullptr;
-    h->state = nullptr;
+    h->state = h->state2 = nullptr;
+    h->state2_valid = false;
     h->cap_elems = h->cap_batch = 0;
 }
 
@@ -139,6 +145,7 @@ static int ensure_ws(mcq_handle* h, size_t batch, size_t nmax)
     HIP_TRY(hipMalloc((void**)&h->vec, elems * MCQ_NVEC * sizeof(double)));
     HIP_TRY(hipMalloc((void**)&h->Z, elems * MCQ_KMAX * sizeof(double)));
     HIP_TRY(hipMalloc((void**)&h->state, elems));
+    HIP_TRY(hipMalloc((void**)&h->state2, elems));
     h->cap_elems = elems;
     h->cap_batch = batch;
     h->ws_bytes = (long long)(elems * ((3 * MCQ_ELD + MCQ_HLD + MCQ_LLD + MCQ_NVEC + MCQ_KMAX) * sizeof(double) + 1));
@@ -175,6 +182,9 @@ static int launch(mcq_handle* h, McqBatch& B, const mcq_opts& o)
     B.refine_steps = o.refine_steps;
     B.check_kappa = o.check_kappa;
     B.objective = o.objective;
+    // warm start: only the working sets mcq_relinearise_device carried over for exactly this batch layout
+    B.warm = (o.warm_start && h->state2_valid && !B.prep_only) ? h->state2 : nullptr;
+    if (!B.prep_only) h->state2_valid = false;
     if (B.objective == MCQ_OBJ_SHORTEST_PATH && !B.prep_only) {
         if (!B.nv) { g_err = "shortest-path objective: normvec is required"; return MCQ_E_ARG; }
         B.check_kappa = 0;
@@ -426,6 +436,9 @@ extern "C" int mcq_relinearise_device(mcq_handle* h, int batch, int nmax, const 
     R.n_out = n_out;
     R.status = status_out;
     R.vec = h->vec;
+    R.state_in = h->state;          // what the last solve on this handle left (the caller solves, then re-linearises, the same batch)
+    R.state_out = h->state2;
+    h->state2_valid = true;
     hipLaunchKernelGGL(mcq_relinearise_kernel, dim3(batch), dim3(256), 0, h->stream, R);
     HIP_TRY(hipGetLastError());
     return 0;

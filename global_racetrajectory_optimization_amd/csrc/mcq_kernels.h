@@ -122,6 +122,7 @@ struct McqBatch {
     const double* kappa_bound_list;  // per-problem overrides (device) or nullptr
     const double* w_veh_list;
     int band_e, max_ipm_iter, max_as_iter, refine_steps, check_kappa;
+    const signed char* warm; // [batch][nmax] working set to start the exchange from (IQP passes 2+), or nullptr (cold: interior point)
     int objective;          // MCQ_OBJ_*: shortest path = H and f written directly by mcq_assemble_sp_kernel (Eb holds the three
                             // diagonals of H, the gradient is H x + f), no curvature rows, no curvature-error post-check
 };
@@ -161,6 +162,8 @@ struct McqRelin {
     int* n_out;             // [batch]
     int* status;            // [batch]: MCQ_OK, or MCQ_BAD_INPUT if the re-sampled ring has < 3 or > nmax points
     double* vec;            // workspace, [batch][MCQ_NVEC][nmax] (the solver's vector slab)
+    const signed char* state_in;   // [batch][nmax] working set the solver left for these tracks (or nullptr)
+    signed char* state_out;        // [batch][nmax] the same carried to the re-sampled rings (warm start of the next pass)
 };
 __global__ void mcq_relinearise_kernel(McqRelin R);
 

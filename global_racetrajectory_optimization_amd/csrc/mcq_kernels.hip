@@ -64,6 +64,11 @@ __shared__ double g_sm[SM_TOTAL];
 #ifndef MCQ_TAPIA_SHRINK
 #define MCQ_TAPIA_SHRINK 0.7
 #endif
+#ifndef MCQ_WARM_ROUNDS
+#define MCQ_WARM_ROUNDS 12
+#endif
+/* ^ rounds a warm-started exchange gets before the cold path (interior point) takes over: 8 / 10 / 12 / 16 measured on the
+ *   3 x 1024 IQP problems -- the launch ends with its slowest problems, and a fallback costs the rounds spent plus the cold path */
 #define MCQ_AS_WINDOW 8   /* block pivoting pins the furthest-out row per neighbourhood of this many rows either side */
 
 // ---------------------------------------------------------------------------------------------------------------------
@@ -2456,7 +2461,7 @@ __device__ __forceinline__ double erow_dot(const SolveCtx& c, int k, const gdoub
 }
 
 __device__ __noinline__ int active_set(SolveCtx& c, const McqBatch& B, bool with_kappa, bool tapia, int cap, const SolveScalars& sc, int& iters,
-                                       double& kkt, int& nk_out)
+                                       double& kkt, int& nk_out, bool identify = true)
 {
     const int tid = threadIdx.x, n = c.d.n, nm = c.nm;
     double* red = g_sm + SM_RED;
@@ -2487,8 +2492,9 @@ __device__ __noinline__ int active_set(SolveCtx& c, const McqBatch& B, bool with
     nk_out = 0;
 
     // ---- identification ---------------------------------------------------------------------------------------------------
+    // (identify == false: the working set is given -- carried over from the previous IQP pass -- and the pairs are not read)
     for (int i = tid; i < n; i += MCQ_NT) {
-        if (ST[i] == 0) {
+        if (identify && ST[i] == 0) {
             // magnitude test on the final pair: active when the scaled multiplier exceeds the scaled slack
             const double wdt = HI[i] - LO[i];
             const double sl = X[i] - LO[i], su = HI[i] - X[i];
@@ -2750,9 +2756,35 @@ __global__ void __launch_bounds__(MCQ_NT) mcq_solve_kernel(McqBatch B)
     int ipm_iters = 0, as_iters = 0, it2 = 0, nact_kappa = 0;
     double kkt = 0.0;
     const bool small = n <= IPB_E * MCQ_NT;
-    int status = small ? ipm_box(c, B, sc, ipm_iters, MCQ_IPM_TOL, false) : ipm(c, B, false, sc, ipm_iters);
     int nk_dummy = 0;
-    if (status == MCQ_OK && small) {
+    // ---- warm start (IQP passes 2+): the working set of the previous pass, carried through the re-sampling by the glue kernel, is
+    //      off by a few dozen rows; the one-row-per-neighbourhood exchange settles from it in a handful of rounds (each one
+    //      factorisation + one solve) -- a third to two thirds of what interior point + exchange cost.  The vertex returned is an
+    //      exact KKT point either way; if the exchange runs out of its rounds the cold path below takes over. ----
+    bool warm_done = false;
+    if (B.warm && small) {
+        const gschar* WS = (const gschar*)(B.warm + (size_t)blockIdx.x * nm);
+        for (int i = tid; i < n; i += MCQ_NT)
+            if (ST[i] == 0) { const signed char s = WS[i]; ST[i] = (s == 1 || s == -1) ? s : (signed char)0; }
+        __syncthreads();
+        const int capw = B.max_as_iter < MCQ_WARM_ROUNDS ? B.max_as_iter : MCQ_WARM_ROUNDS;
+        const int sw = active_set(c, B, false, false, capw, sc, as_iters, kkt, nk_dummy, false);
+        if (sw == MCQ_OK) warm_done = true;
+        else {
+            c.second_attempt = 2;       // reported: warm start abandoned
+            for (int i = tid; i < n; i += MCQ_NT) {
+                ST[i] = !(HI[i] - LO[i] > 1e-12) ? 2 : 0;
+                X[i] = 0.5 * (LO[i] + HI[i]);
+            }
+            __syncthreads();
+            gradient(c, X, nullptr, T0, G);
+        }
+    }
+    const int as_warm = warm_done ? 0 : as_iters;
+    int status = MCQ_OK;
+    if (!warm_done) status = small ? ipm_box(c, B, sc, ipm_iters, MCQ_IPM_TOL, false) : ipm(c, B, false, sc, ipm_iters);
+    if (warm_done) {
+    } else if (status == MCQ_OK && small) {
         // Two attempts.  The pairs at mu = 1e-10 identify the active set of all but the degenerate / extremely
         // ill-conditioned instances (IQP passes on an already optimised raceline: dozens of bounds touched with multipliers
         // down to 1e-7 of the gradient scale, |x_ipm - x*| ~ 5 mm at that mu); there block pivoting from a guess that is off
@@ -2764,7 +2796,7 @@ __global__ void __launch_bounds__(MCQ_NT) mcq_solve_kernel(McqBatch B)
         const int cap1 = B.max_as_iter < 6 ? B.max_as_iter : 6;
         status = active_set(c, B, false, ipm_iters >= 1 && c.last_step >= 0.9, cap1, sc, as_iters, kkt, nk_dummy);
         if (status == MCQ_ITER_CAP && B.max_as_iter > cap1) {
-            c.second_attempt = 1;
+            c.second_attempt |= 1;
             for (int i = tid; i < n; i += MCQ_NT) X[i] = XS[i];
             __syncthreads();
             int it_more = 0, as_more = 0;
@@ -2776,6 +2808,7 @@ __global__ void __launch_bounds__(MCQ_NT) mcq_solve_kernel(McqBatch B)
     } else if (status == MCQ_OK) {
         status = active_set(c, B, false, ipm_iters >= 1 && c.last_step >= 0.9, B.max_as_iter, sc, as_iters, kkt, nk_dummy);
     }
+    as_iters += as_warm;        // rounds of an abandoned warm start are reported too
 
     // kappa(alpha) = k_ref + E alpha
     for (int i = tid; i < n; i += MCQ_NT) X[i] = fmin(fmax(X[i], LO[i]), HI[i]);
@@ -3049,6 +3082,10 @@ __global__ void __launch_bounds__(MCQ_NT) mcq_relinearise_kernel(McqRelin R)
         QY[j] = ay + t * (by + t * (cy + t * dy));
         refo[4 * j + 2] = WR[s] + (WR[sp] - WR[s]) * t;
         refo[4 * j + 3] = WL[s] + (WL[sp] - WL[s]) * t;
+        if (R.state_out) {      // working set of the pass just solved, carried to the new ring: the nearer end of the segment
+            const signed char so = ((const gschar*)(R.state_in + (size_t)pb * nm))[t > 0.5 ? sp : s];
+            ((gschar*)(R.state_out + (size_t)pb * nm))[j] = (so == 1 || so == -1) ? so : (signed char)0;
+        }
     }
     __syncthreads();
     for (int j = tid; j < m; j += MCQ_NT) {

@@ -34,7 +34,8 @@ OBJ_MIN_CURV, OBJ_SHORTEST_PATH = 0, 1      # mcq_opts.objective (include/mcq.h)
 
 class McqOpts(ctypes.Structure):
     _fields_ = [("band_e", ctypes.c_int), ("max_ipm_iter", ctypes.c_int), ("max_as_iter", ctypes.c_int),
-                ("refine_steps", ctypes.c_int), ("check_kappa", ctypes.c_int), ("objective", ctypes.c_int)]
+                ("refine_steps", ctypes.c_int), ("check_kappa", ctypes.c_int), ("objective", ctypes.c_int),
+                ("warm_start", ctypes.c_int)]
 
 
 class McqInfo(ctypes.Structure):
@@ -147,9 +148,10 @@ class Engine:
         except Exception:
             pass
 
-    def _opts(self, band_e=0, max_ipm_iter=0, max_as_iter=0, refine_steps=-1, check_kappa=1, objective=OBJ_MIN_CURV):
+    def _opts(self, band_e=0, max_ipm_iter=0, max_as_iter=0, refine_steps=-1, check_kappa=1, objective=OBJ_MIN_CURV,
+              warm_start=0):
         return McqOpts(int(band_e), int(max_ipm_iter), int(max_as_iter), int(refine_steps), int(check_kappa),
-                       int(objective))
+                       int(objective), int(warm_start))
 
     def _check(self, rc, what):
         if rc != 0:

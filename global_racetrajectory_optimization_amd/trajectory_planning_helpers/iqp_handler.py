@@ -37,7 +37,7 @@ def _relinearise(reftrack_tmp, normvec_tmp, alpha, stepsize_interp):
 
 
 def _iqp_batch_device(eng, tracks, kappa_bound, w_veh, stepsize_interp, iters_min, curv_error_allowed, print_debug,
-                      max_rounds, stats):
+                      max_rounds, stats, warm_start=True):
     """The lock-step IQP rounds with everything but a few scalars per track resident in HBM: the QP pass is
     mcq_solve_device_ragged, the glue between passes mcq_relinearise_device.  Per round the host
     reads back curv_error / status / N per track and, for the tracks that finish, their final alpha / reftrack /
@@ -94,8 +94,9 @@ def _iqp_batch_device(eng, tracks, kappa_bound, w_veh, stepsize_interp, iters_mi
                 raise RuntimeError("iqp_handler: no convergence within %d rounds" % max_rounds)
             # finished tracks keep their buffers but are skipped: n = 0 makes the assembly kernel flag them, the solver returns
             eng.upload(d_nsolve, (n_host * live).astype(np.int32))
+            # passes 2+: the exchange starts from the working set of the previous pass, which the glue kernel carried over
             eng.solve_device_ragged(bsz, nmax, d_nsolve, d_ref[cur], d_nv[cur], d_sc if it == 1 else None, kappa_bound,
-                                    w_veh, d_alpha, d_curv, d_status)
+                                    w_veh, d_alpha, d_curv, d_status, warm_start=1 if (warm_start and it > 1) else 0)
             n_solves += int(live.sum())
             curv = eng.download(d_curv, (bsz,), np.float64)
             status = eng.download(d_status, (bsz,), np.int32)
@@ -152,17 +153,19 @@ def _iqp_batch_device(eng, tracks, kappa_bound, w_veh, stepsize_interp, iters_mi
 
 def iqp_handler_batch(tracks: list, kappa_bound: float, w_veh: float, stepsize_interp: float, iters_min: int = 3,
                       curv_error_allowed: float = 0.01, print_debug: bool = False, engine=None, max_rounds: int = 50,
-                      stats: dict = None, device_resident: bool = False) -> list:
+                      stats: dict = None, device_resident: bool = False, warm_start: bool = True) -> list:
     """tracks: list of dicts {reftrack [N,4], normvectors [N,2], scaling [N] or None}.
 
     Returns a list of (alpha, reftrack, normvectors) like iqp_handler.  `stats` (optional dict) receives
     {'rounds', 'qp_solves'}.  device_resident=True keeps the tracks in HBM between the passes (the glue runs as a HIP
-    kernel, mcq_relinearise_device); the default runs the glue on the host exactly as upstream chains it.
+    kernel, mcq_relinearise_device, and -- warm_start -- passes 2+ start the exchange from the previous pass's working set
+    instead of the interior point: same vertex, a fraction of the factorisations); the default runs the glue on the host
+    exactly as upstream chains it.
     """
     eng = engine or _engine.default_engine()
     if device_resident:
         return _iqp_batch_device(eng, tracks, kappa_bound, w_veh, stepsize_interp, iters_min, curv_error_allowed,
-                                 print_debug, max_rounds, stats)
+                                 print_debug, max_rounds, stats, warm_start)
     state = [dict(ref=np.array(t["reftrack"], dtype=np.float64), nv=np.array(t["normvectors"], dtype=np.float64),
                   sc=None if t.get("scaling") is None else np.array(t["scaling"], dtype=np.float64), done=False,
                   alpha=None) for t in tracks]

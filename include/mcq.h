@@ -78,6 +78,10 @@ typedef struct {
                          * (4 |n_i|^2 on the diagonal, -2 n_i.n_{i+1} beside it), f_i = 2 n_i.(2 p_i - p_{i-1} - p_{i+1}),
                          * deviations clipped at 0.001 m instead of rejected.  normvec is required; scaling, kappa_bound
                          * and the curvature rows are ignored and curv_err_out is 0. */
+    int warm_start;     /* 1: start from the working sets that the preceding mcq_relinearise_device call on this handle carried
+                         * over from the preceding solve of the same batch (IQP passes 2+): the exchange alone, no interior point,
+                         * unless it runs out of 12 rounds (then the cold path; mcq_info.second_attempt & 2).  Ignored when no such
+                         * working sets are at hand.  The result is an exact KKT vertex of the same QP either way.  Default 0. */
 } mcq_opts;
 #define MCQ_OBJ_MIN_CURV 0
 #define MCQ_OBJ_SHORTEST_PATH 1
@@ -96,8 +100,9 @@ typedef struct {
      * a -DMCQ_FINE_TIMERS build reports the inside of the factorisation in [4..6] instead (phase 1, phase 2, tail) */
     long long ticks[8];
     int refine_rounds;  /* fp64 refinement rounds run on the final working set (<= opts.refine_steps) */
-    int second_attempt; /* 1 if the active-set phase ran out of its first budget and the interior point was resumed to
-                           mu = 1e-13 (degenerate / very ill-conditioned instance) */
+    int second_attempt; /* bit 0: the active-set phase ran out of its first budget and the interior point was resumed to
+                           mu = 1e-13 (degenerate / very ill-conditioned instance); bit 1: a warm start (mcq_opts.warm_start)
+                           was abandoned for the cold path */
 } mcq_info;
 
 int mcq_create(int device_id, mcq_handle** out);

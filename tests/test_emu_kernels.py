@@ -333,3 +333,18 @@ def test_normals_crossing_kernel_matches_host_shim(emu, golden):
     with pytest.raises(RuntimeError, match="too large"):
         cn.check_normals_crossing(cases[3][0], cases[3][1], 10)
     assert got[3] == -1
+
+
+def test_iqp_device_resident_with_warm_started_passes(emu, golden):
+    """A whole device-resident IQP run through the unchanged kernels: QP pass, glue kernel (which also carries the working set to
+    the re-sampled ring), passes 2+ warm-started from it (exchange only, no interior point) -- against the golden IQP end
+    state, which the dense oracle + host glue produced."""
+    from global_racetrajectory_optimization_amd.trajectory_planning_helpers import iqp_handler as iq
+    g = golden["rounded_rectangle"]
+    st = {}
+    out = iq.iqp_handler_batch([dict(reftrack=g["reftrack"].copy(), normvectors=g["normvec"], scaling=g["scaling"])], 0.12, 3.4,
+                               3.0, 3, 0.01, engine=emu, stats=st, device_resident=True, warm_start=True)
+    a, r, nv = out[0]
+    assert st["rounds"] == 3 and a.shape == g["iqp_alpha"].shape
+    assert np.max(np.abs(a - g["iqp_alpha"])) < 1e-8
+    assert np.max(np.abs(r - g["iqp_reftrack"])) < 1e-8 and np.max(np.abs(nv - g["iqp_normvec"])) < 1e-8

@@ -366,6 +366,27 @@ def test_iqp_device_resident_driver_bulk_round(gpu_engine):
         assert np.max(np.abs(r_d - r_h)) < 1e-8 and np.max(np.abs(n_d - n_h)) < 1e-8
 
 
+def test_iqp_warm_start_equals_cold_start_full_size(gpu_engine):
+    """32 synthetic N = 2000 ovals through the device-resident IQP driver twice: passes 2+ warm-started from the previous
+    pass's working set (exchange only) and cold (interior point every pass).  Both end at exact KKT vertices of the same QPs:
+    the end states agree to the conditioning of the reduced systems, far inside the 1e-6 m tolerance."""
+    from global_racetrajectory_optimization_amd.trajectory_planning_helpers import iqp_handler as iq
+    ref, nv, sc = synthetic.oval_batch(32, n=2000, first=600)
+    tracks = [dict(reftrack=ref[k], normvectors=nv[k], scaling=sc[k]) for k in range(32)]
+    outs = []
+    for warm in (True, False):
+        st = {}
+        outs.append(iq.iqp_handler_batch([dict(t, reftrack=t["reftrack"].copy()) for t in tracks], 0.12, 3.4, 3.0, 3, 0.01,
+                                         engine=gpu_engine, stats=st, device_resident=True, warm_start=warm))
+        assert st["rounds"] == 3
+    worst = 0.0
+    for (a_w, r_w, n_w), (a_c, r_c, n_c) in zip(*outs):
+        assert a_w.shape == a_c.shape
+        worst = max(worst, float(np.max(np.abs(a_w - a_c))))
+        assert np.max(np.abs(a_w - a_c)) < ALPHA_TOL and np.max(np.abs(r_w - r_c)) < ALPHA_TOL
+    print("IQP warm vs cold start, 32 x N=2000: max |alpha| difference %.2e m" % worst)
+
+
 def test_degenerate_iqp_pass_two_attempt_driver(gpu_engine):
     """The QP of the third IQP pass on a synthetic N = 2000 oval (tests/golden/iqp_pass3_oval3.npz, made by
     scripts/make_degenerate_fixture.py with the dense oracle): 42 touched bounds with multipliers down to 1e-7 of the
