@@ -174,7 +174,8 @@ int mcq_normals_crossing_device(mcq_handle* h, int batch, int nmax, const int* n
  * (tph.calc_splines(use_dist_scaling=False)).  All pointers DEVICE pointers, arrays strided by nmax; `live` [batch] or
  * NULL selects the tracks to process; n_out [batch] receives the new waypoint counts; status_out [batch] MCQ_OK or
  * MCQ_BAD_INPUT (new ring would have < 3 or > nmax points).  Input and output buffers must differ.  Asynchronous on
- * the handle's stream. */
+ * the handle's stream.  Side effect inside the handle: the working sets the preceding solve left for these tracks are carried to
+ * the re-sampled rings (new point -> nearer end of its old segment), for mcq_opts.warm_start of the next pass. */
 int mcq_relinearise_device(mcq_handle* h, int batch, int nmax, const int* n_in, const double* reftrack_in,
                            const double* normvec_in, const double* alpha, const int* live, double alpha_scale,
                            double stepsize, double* reftrack_out, double* normvec_out, int* n_out, int* status_out);
