@@ -3123,19 +3123,31 @@ __device__ __forceinline__ double vp_interp(double x, const gdouble* tab, int cn
     return y0 + (y1 - y0) * (x - x0) / (x1 - x0);
 }
 
-// longitudinal acceleration still available at speed v on radius `rad` (friction ellipse of exponent e, drag)
+// longitudinal acceleration still available at speed v on radius `rad` (tph.calc_vel_profile.calc_ax_poss, mu = 1: tyre
+// potential shared with the lateral acceleration through the friction ellipse of exponent e, machine limit when accelerating,
+// drag -- which helps when the deceleration is integrated backwards)
 __device__ __forceinline__ double vp_ax_possible(double v, double rad, const gdouble* ggv, int ng, const gdouble* axm, int nam,
                                                  bool accel, double e, double drag_over_m)
 {
-    const double ax_t = vp_interp(v, ggv, ng, 3, 1), ay_t = vp_interp(v, ggv, ng, 3, 2);
+    const double ax_t = fabs(vp_interp(v, ggv, ng, 3, 1)), ay_t = vp_interp(v, ggv, ng, 3, 2);
     const double ay_used = v * v / rad;
-    const double radicand = ay_t > 0.0 ? 1.0 - pow(ay_used / ay_t, e) : 0.0;
+    const double radicand = 1.0 - pow(ay_used / ay_t, e);
     const double ax_tires = radicand > 0.0 ? ax_t * pow(radicand, 1.0 / e) : 0.0;
     const double ax_drag = -v * v * drag_over_m;
     if (accel) return fmin(ax_tires, vp_interp(v, axm, nam, 2, 1)) + ax_drag;
-    return ax_tires - ax_drag;                 // braking, integrated backwards
+    return ax_tires - ax_drag;
 }
 
+// One thread per (track, vehicle) variant; the lap-doubled profile lives in a variant-minor scratch (S[j * batch]: coalesced
+// across the threads of a wave).  Follows tph.calc_vel_profile step by step (restated in oracle/vel_ref.py, the checker):
+//   lateral limit: fixed point of v = sqrt(ay_max(v) R) over ALL ggv rows, at most 100 rounds, stopped when the largest relative
+//     change is below 0.5 % (a NaN in that maximum -- kappa == 0 gives inf / inf -- never passes, as numpy.max behaves);
+//   forward sweep over two laps, backward sweep over the doubled SECOND lap of the forward result, second lap of that out;
+//   a sweep is switched on at the first point of every acceleration phase of the profile it starts from (v[i+1] > v[i] and not
+//     v[i] > v[i-1], both on the values before the sweep touched them) and switched off where the attainable speed exceeds v_max;
+//   the backward sweep re-evaluates the deceleration one point ahead at the attainable speed and keeps the smaller speed;
+//   backward, step p -> p-1 uses el[p] (upstream flips its arrays as a whole).
+// A ggv / machine table that ends below v_max (upstream raises RuntimeError) gives lap_time = NaN.
 __global__ void __launch_bounds__(64) mcq_vel_profile_kernel(McqVel V)
 {
     const int v = blockIdx.x * 64 + threadIdx.x;
@@ -3147,73 +3159,88 @@ __global__ void __launch_bounds__(64) mcq_vel_profile_kernel(McqVel V)
     const size_t row = (size_t)trk * V.nmax;
     const gdouble* kap = (const gdouble*)(V.kappa + row);
     const gdouble* el = (const gdouble*)(V.el + row);
-    const gdouble* ggv_all = (const gdouble*)(V.ggv + (size_t)v * V.ng * 3);
+    const gdouble* ggv = (const gdouble*)(V.ggv + (size_t)v * V.ng * 3);
     const gdouble* axm = (const gdouble*)(V.axm + (size_t)v * V.nam * 2);
     gdouble* S = (gdouble*)V.scratch + v;       // S[j * bt]
     const double vmax = V.vmax[v], e = V.dyn_exp, dom = V.drag[v] / V.mass[v];
-    // rows of the ggv diagram up to v_max (tph drops the rest)
-    int ng = V.ng;
-    if (ng > 1) {
-        const double lim = fmax(vmax, ggv_all[0]) + 1e-9;
-        int c = 0;
-        while (c < ng && ggv_all[(size_t)c * 3] <= lim) ++c;
-        ng = c;
-    }
-    const gdouble* ggv = ggv_all;
+    const int ng = V.ng, nam = V.nam;
+    if (ggv[(size_t)(ng - 1) * 3] < vmax || axm[(size_t)(nam - 1) * 2] < vmax) { V.lap_time[v] = NAN; return; }
     double aymin = ggv[2];
     for (int k = 1; k < ng; ++k) aymin = fmin(aymin, ggv[(size_t)k * 3 + 2]);
+#define VP_RAD(i_) ((kap[(i_)] != 0.0) ? fabs(1.0 / kap[(i_)]) : (double)INFINITY)
 
-    // ---- lateral limit  v = sqrt(ay_max(v) R)  by fixed-point iteration -----------------------------------------------------
-    for (int i = 0; i < n; ++i) {
-        const double k = kap[i];
-        const double rad = k != 0.0 ? fabs(1.0 / k) : INFINITY;
-        S[(size_t)i * bt] = sqrt(aymin * rad);
-    }
+    // ---- lateral limit ------------------------------------------------------------------------------------------------------------
+    for (int i = 0; i < n; ++i) S[(size_t)i * bt] = sqrt(aymin * VP_RAD(i));
     for (int it = 0; it < 100; ++it) {
         double worst = 0.0;
+        bool any_nan = false;
         for (int i = 0; i < n; ++i) {
-            const double k = kap[i];
-            const double rad = k != 0.0 ? fabs(1.0 / k) : INFINITY;
             const double vx = S[(size_t)i * bt];
-            const double vn = sqrt(vp_interp(fmin(vx, vmax), ggv, ng, 3, 2) * rad);
-            if (isfinite(vn)) worst = fmax(worst, fabs(vx / (vn > 0.0 ? vn : 1.0) - 1.0));
+            const double vn = sqrt(vp_interp(vx, ggv, ng, 3, 2) * VP_RAD(i));
+            const double ch = fabs(vn / vx - 1.0);
+            if (ch != ch) any_nan = true;
+            worst = fmax(worst, ch);
             S[(size_t)i * bt] = vn;
         }
-        if (worst < 0.005) break;
+        if (!any_nan && worst < 0.005) break;
     }
-    // ---- two laps: acceleration-limited forward sweep, deceleration-limited backward sweep -------------------------------------
+    // ---- lap doubled, cut at the top speed ------------------------------------------------------------------------------------------
     for (int i = 0; i < n; ++i) {
         const double vx = fmin(S[(size_t)i * bt], vmax);
         S[(size_t)i * bt] = vx;
         S[(size_t)(n + i) * bt] = vx;
     }
+    const int m2 = 2 * n;
+    // ---- forward: acceleration-limited --------------------------------------------------------------------------------------------
     {
-        double cur = S[0];
-        for (int j = 0; j < 2 * n - 1; ++j) {
+        bool active = false, prev_rising = false;
+        double cur = S[0];                       // v[j] as the sweep left it
+        double o_cur = cur;                      // v[j] before the sweep
+        for (int j = 0; j < m2 - 1; ++j) {
             const int i = j < n ? j : j - n;
-            const double k = kap[i];
-            const double rad = k != 0.0 ? fabs(1.0 / k) : INFINITY;
-            const double ax = vp_ax_possible(cur, rad, ggv, ng, axm, V.nam, true, e, dom);
-            const double vnext = sqrt(fmax(cur * cur + 2.0 * ax * el[i], 0.0));
-            double nxt = S[(size_t)(j + 1) * bt];
-            if (vnext < nxt) { nxt = vnext; S[(size_t)(j + 1) * bt] = nxt; }
+            double nxt = S[(size_t)(j + 1) * bt];   // untouched so far: the value before the sweep
+            const bool rising = nxt > o_cur;
+            if (rising && !prev_rising) active = true;
+            prev_rising = rising;
+            o_cur = nxt;
+            if (active) {
+                const double ax = vp_ax_possible(cur, VP_RAD(i), ggv, ng, axm, nam, true, e, dom);
+                const double vnext = sqrt(cur * cur + 2.0 * ax * el[i]);
+                if (vnext < nxt) { nxt = vnext; S[(size_t)(j + 1) * bt] = nxt; }
+                if (vnext > vmax) active = false;
+            }
             cur = nxt;
         }
     }
+    // second lap of the forward result, doubled
+    for (int i = 0; i < n; ++i) S[(size_t)i * bt] = S[(size_t)(n + i) * bt];
+    // ---- backward: deceleration-limited, in flipped order  q = m2 - 1 - j ------------------------------------------------------------
     {
-        double cur = S[(size_t)(2 * n - 1) * bt];
-        for (int j = 2 * n - 1; j >= 1; --j) {
-            const int i = j < n ? j : j - n;
-            const int im = (j - 1) < n ? j - 1 : j - 1 - n;
-            const double k = kap[i];
-            const double rad = k != 0.0 ? fabs(1.0 / k) : INFINITY;
-            const double ax = vp_ax_possible(cur, rad, ggv, ng, axm, V.nam, false, e, dom);
-            const double vprev = sqrt(fmax(cur * cur + 2.0 * ax * el[im], 0.0));
+        bool active = false, prev_rising = false;
+        double cur = S[(size_t)(m2 - 1) * bt];
+        double o_cur = cur;
+        for (int j = m2 - 1; j >= 1; --j) {
+            const int i = j < n ? j : j - n;                 // point left
+            const int im = (j - 1) < n ? j - 1 : j - 1 - n;  // point reached
             double prv = S[(size_t)(j - 1) * bt];
-            if (vprev < prv) { prv = vprev; S[(size_t)(j - 1) * bt] = prv; }
+            const bool rising = prv > o_cur;
+            if (rising && !prev_rising) active = true;
+            prev_rising = rising;
+            o_cur = prv;
+            if (active) {
+                const double c2 = cur * cur, l2 = 2.0 * el[i];
+                const double ax = vp_ax_possible(cur, VP_RAD(i), ggv, ng, axm, nam, false, e, dom);
+                double vprev = sqrt(c2 + ax * l2);
+                const double ax2 = vp_ax_possible(vprev, VP_RAD(im), ggv, ng, axm, nam, false, e, dom);
+                const double vtmp = sqrt(c2 + ax2 * l2);
+                if (vtmp < vprev) vprev = vtmp;
+                if (vprev < prv) { prv = vprev; S[(size_t)(j - 1) * bt] = prv; }
+                if (vprev > vmax) active = false;
+            }
             cur = prv;
         }
     }
+#undef VP_RAD
     // ---- second lap out; lap time from the piecewise-constant accelerations (tph.calc_ax_profile / calc_t_profile) -----------
     gdouble* out = (gdouble*)(V.vx_out + (size_t)v * V.nmax);
     double t = 0.0;
@@ -3322,10 +3349,13 @@ __global__ void __launch_bounds__(MCQ_NT) mcq_normals_crossing_kernel(int nmax, 
         for (int d = 1; d <= horizon; ++d) {
             const int j = i + d < n ? i + d : i + d - n;
             const double bx = nv[2 * j], by = nv[2 * j + 1];
+            // upstream skips neighbours whose normal is collinear: numpy.isclose(cross(n_i, n_j), 0.0), i.e. |cross| <= 1e-8
+            if (fabs(ax * by - ay * bx) <= 1e-8) continue;
             const double rx = ref[4 * j] - px, ry = ref[4 * j + 1] - py;
             const double det = -ax * by + ay * bx;               // p_i + l0 n_i = p_j + l1 n_j
             const double l0 = (-rx * by + ry * bx) / det, l1 = (ax * ry - ay * rx) / det;
-            if (isfinite(l0) && isfinite(l1) && l0 > -wl && l0 < wr && l1 > -ref[4 * j + 3] && l1 < ref[4 * j + 2]) hit = 1;
+            // both parameters inside [-w_left, w_right] of their point, bounds included (as upstream)
+            if (l0 >= -wl && l0 <= wr && l1 >= -ref[4 * j + 3] && l1 <= ref[4 * j + 2]) hit = 1;
         }
     }
     if (hit) s_hit = 1;

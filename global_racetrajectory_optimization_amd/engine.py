@@ -319,6 +319,11 @@ class Engine:
         axm = np.ascontiguousarray(ax_max_machines, dtype=np.float64)
         bsz, n = ggv.shape[0], kappa.shape[1]
         scal = [np.ascontiguousarray(np.broadcast_to(np.asarray(a, dtype=np.float64), (bsz,))) for a in (drag_coeff, m_veh, v_max)]
+        # what tph.calc_vel_profile raises on (the kernel itself flags such a variant with lap_time = NaN)
+        if np.any(ggv[:, -1, 0] < scal[2]):
+            raise RuntimeError("ggv has to cover the entire velocity range of the car (i.e. >= v_max)!")
+        if np.any(axm[:, -1, 0] < scal[2]):
+            raise RuntimeError("ax_max_machines has to cover the entire velocity range of the car (i.e. >= v_max)!")
         tr = None if track_of is None else np.ascontiguousarray(track_of, dtype=np.int32)
         nt = None if n_of_track is None else np.ascontiguousarray(n_of_track, dtype=np.int32)
         ptrs = []

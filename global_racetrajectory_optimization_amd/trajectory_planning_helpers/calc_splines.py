@@ -87,13 +87,42 @@ def build_les_matrix(n, scaling):
     return M
 
 
-def scalings_from_les_matrix(A):
-    """Recover s_i from the matrix calc_splines returned: the inverse of build_les_matrix."""
+def scalings_from_les_matrix(A, check=True):
+    """Recover s_i from the matrix calc_splines returned: the inverse of build_les_matrix.
+
+    The engine never sees `A`: everything opt_min_curv needs from it is the N scalings.  That is only valid if `A` IS the
+    matrix of the closed-spline system (what the reference passes on from calc_splines [REF main_globaltraj.py:267,
+    prep_track.py:48-51]); `check` verifies it in O(N) + one counting pass -- the structural entries of every 4-row block, the four entries
+    that must mirror the scalings (-s, -2 s^2), positivity, and the number of non-zeros (12 N: nothing outside the
+    pattern) -- and raises RuntimeError otherwise: a silently wrong alpha is the alternative (there is no dense CPU path in
+    the product to fall back to).
+    """
+    A = np.asarray(A)
     n = A.shape[0] // 4
     i = np.arange(n - 1)
     s = np.empty(n)
     s[:-1] = -A[4 * i + 2, 4 * i + 5]
     s[-1] = A[4 * n - 2, 1]
+    if check:
+        j = 4 * np.arange(n)
+        ji = 4 * i
+        ok = bool(np.all(np.isfinite(s)) and np.all(s > 0.0))
+        ok = ok and bool(np.all(A[j, j] == 1.0) and np.all(A[j + 1, j] == 1.0) and np.all(A[j + 1, j + 1] == 1.0)
+                         and np.all(A[j + 1, j + 2] == 1.0) and np.all(A[j + 1, j + 3] == 1.0))
+        ok = ok and bool(np.all(A[ji + 2, ji + 1] == 1.0) and np.all(A[ji + 2, ji + 2] == 2.0) and np.all(A[ji + 2, ji + 3] == 3.0)
+                         and np.all(A[ji + 3, ji + 2] == 2.0) and np.all(A[ji + 3, ji + 3] == 6.0))
+        ok = ok and bool(np.all(A[-2, -3:] == (-1.0, -2.0, -3.0)) and np.all(A[-1, -2:] == (-2.0, -6.0)))
+        if ok:
+            s2 = 2.0 * s * s
+            ok = bool(np.allclose(-A[ji + 3, ji + 6], s2[:-1], rtol=1e-12, atol=0.0) and np.isclose(A[-1, 2], s2[-1], rtol=1e-12, atol=0.0))
+        if ok:
+            # the 12 N entries checked above are all there is: one pass over A, no temporaries (~60 ms at N = 2000, where
+            # upstream spends 13 s inverting the same matrix)
+            ok = int(np.count_nonzero(A)) == 12 * n
+        if not ok:
+            raise RuntimeError("Spline equation system matrix A does not have the structure of calc_splines' closed-spline "
+                               "system (the MI355X engine derives everything from the N spline scalings it encodes and "
+                               "cannot use an arbitrary matrix)")
     return s
 
 

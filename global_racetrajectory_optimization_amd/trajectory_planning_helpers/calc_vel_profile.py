@@ -1,36 +1,56 @@
 """
 Host-side shim of tph.calc_vel_profile -- boundary [REF main_globaltraj.py:400-410, 469-479].
 
-Forward/backward quasi-steady-state velocity profile over the ggv diagram (a "next" row, host
-side for now, outside the GPU hot path).  Lateral limit v = sqrt(ay_max(v) * R) by fixed-point iteration, then an
-acceleration-limited forward sweep and a deceleration-limited backward sweep; closed tracks are swept over two laps so
-that the result is periodic.
+Forward/backward quasi-steady-state velocity profile over the ggv diagram (the batched device
+form is mcq_vel_profile_device, this is the single-profile host form the untouched script calls).  Same numbers as upstream
+(checked against the restatement in oracle/vel_ref.py by tests/): lateral limit v = sqrt(ay_max(v) R) by fixed-point
+iteration over ALL ggv rows, forward sweep over the lap doubled, backward sweep over the doubled second lap of that, sweeps
+gated on the starts of the acceleration phases and on v_max, one look-ahead round in the backward sweep.
+
+The sweeps are written as ONE pass with an `active` flag -- the form the device kernel uses -- instead of upstream's work
+list of phase starts: a sweep is switched on at every phase start of the profile it was handed (v[i+1] > v[i] and not
+v[i] > v[i-1]) and switched off where the attainable speed exceeds v_max.
 """
+import math
+
 import numpy as np
 
 from . import conv_filt as _cf
 
 
-def _ax_possible(v, radius, ggv, ax_max_machines, mode, dyn_model_exp, drag_coeff, m_veh, mu=1.0):
-    ax_tires = mu * np.interp(v, ggv[:, 0], ggv[:, 1])
+def _ax_possible(v, radius, ggv, ax_max_machines, accel, dyn_model_exp, drag_over_m, mu):
+    ax_tires = abs(mu * np.interp(v, ggv[:, 0], ggv[:, 1]))
     ay_tires = mu * np.interp(v, ggv[:, 0], ggv[:, 2])
-    ay_used = v * v / radius
-    radicand = 1.0 - (ay_used / ay_tires) ** dyn_model_exp if ay_tires > 0.0 else 0.0
-    ax_avail_tires = ax_tires * radicand ** (1.0 / dyn_model_exp) if radicand > 0.0 else 0.0
-    ax_drag = -v * v * drag_coeff / m_veh
-    if mode == "accel":
-        ax_machine = np.interp(v, ax_max_machines[:, 0], ax_max_machines[:, 1])
-        return min(ax_avail_tires, ax_machine) + ax_drag
-    return ax_avail_tires - ax_drag        # braking, integrated backwards
+    radicand = 1.0 - math.pow(v * v / radius / ay_tires, dyn_model_exp)
+    ax_avail = ax_tires * math.pow(radicand, 1.0 / dyn_model_exp) if radicand > 0.0 else 0.0
+    ax_drag = -v * v * drag_over_m
+    if accel:
+        return min(ax_avail, np.interp(v, ax_max_machines[:, 0], ax_max_machines[:, 1])) + ax_drag
+    return ax_avail - ax_drag        # braking, integrated backwards: drag helps
 
 
-def _sweep(vx, radii, el, ggv, ax_max_machines, mode, dyn_model_exp, drag_coeff, m_veh):
-    v = vx.copy()
-    for i in range(v.size - 1):
-        ax = _ax_possible(v[i], radii[i], ggv, ax_max_machines, mode, dyn_model_exp, drag_coeff, m_veh)
-        v_next = np.sqrt(max(v[i] * v[i] + 2.0 * ax * el[i], 0.0))
+def _sweep(v_in, radii, el, mu, ggv, ax_max_machines, v_max, accel, dyn_model_exp, drag_over_m):
+    """One gated pass over v_in (arrays already in sweep order).  Phase starts refer to v_in as handed in."""
+    v = v_in.copy()
+    m = v.size
+    rising = np.diff(v_in) > 0.0
+    active = False
+    for i in range(m - 1):
+        if rising[i] and (i == 0 or not rising[i - 1]):
+            active = True
+        if not active:
+            continue
+        v2 = v[i] * v[i]
+        v_next = math.sqrt(v2 + 2.0 * _ax_possible(v[i], radii[i], ggv, ax_max_machines, accel, dyn_model_exp, drag_over_m,
+                                                   mu[i]) * el[i])
+        if not accel:       # the deceleration available here need not be available one point on: look ahead once
+            v_tmp = math.sqrt(v2 + 2.0 * _ax_possible(v_next, radii[i + 1], ggv, ax_max_machines, accel, dyn_model_exp,
+                                                      drag_over_m, mu[i + 1]) * el[i])
+            v_next = min(v_next, v_tmp)
         if v_next < v[i + 1]:
             v[i + 1] = v_next
+        if v_next > v_max:
+            active = False
     return v
 
 
@@ -38,37 +58,56 @@ def calc_vel_profile(ax_max_machines: np.ndarray, kappa: np.ndarray, el_lengths:
                      drag_coeff: float, m_veh: float, ggv: np.ndarray = None, loc_gg: np.ndarray = None,
                      v_max: float = None, dyn_model_exp: float = 1.0, mu: np.ndarray = None, v_start: float = None,
                      v_end: float = None, filt_window: int = None) -> np.ndarray:
-    if ggv is None or loc_gg is not None or mu is not None:
+    if (ggv is not None or mu is not None) and loc_gg is not None:
+        raise RuntimeError("Either ggv and optionally mu OR loc_gg must be supplied, not both (or all) of them!")
+    if ggv is None and loc_gg is None:
+        raise RuntimeError("Either ggv or loc_gg must be supplied!")
+    if loc_gg is not None:
         raise NotImplementedError("calc_vel_profile shim: only the global-ggv form used by main_globaltraj.py")
     if not closed:
         raise NotImplementedError("calc_vel_profile shim: closed tracks only")
+    if ggv.shape[1] != 3:
+        raise RuntimeError("ggv diagram must consist of the three columns [vx, ax_max, ay_max]!")
+    if mu is not None and kappa.size != mu.size:
+        raise RuntimeError("kappa and mu must have the same length!")
     if kappa.size != el_lengths.size:
         raise RuntimeError("kappa and el_lengths must have the same length if closed!")
     if not 1.0 <= dyn_model_exp <= 2.0:
         print("WARNING: Exponent for the vehicle dynamics model should be in the range [1.0, 2.0]!")
+    if ax_max_machines.shape[1] != 2:
+        raise RuntimeError("ax_max_machines must consist of the two columns [vx, ax_max_machines]!")
     if v_max is None:
-        v_max = float(np.amin(ggv[-1, 0]))
-    ggv = ggv[ggv[:, 0] <= max(v_max, ggv[0, 0]) + 1e-9] if ggv.shape[0] > 1 else ggv
+        v_max = min(ggv[-1, 0], ax_max_machines[-1, 0])
+    else:
+        if ggv[-1, 0] < v_max:
+            raise RuntimeError("ggv has to cover the entire velocity range of the car (i.e. >= v_max)!")
+        if ax_max_machines[-1, 0] < v_max:
+            raise RuntimeError("ax_max_machines has to cover the entire velocity range of the car (i.e. >= v_max)!")
     radii = np.abs(np.divide(1.0, kappa, out=np.full(kappa.size, np.inf), where=kappa != 0.0))
+    mu = np.ones(kappa.size) if mu is None else np.asarray(mu, dtype=np.float64)
 
-    vx = np.sqrt(np.amin(ggv[:, 2]) * radii)
+    vx = np.sqrt(mu * np.amin(ggv[:, 2]) * radii)
+    converged = False
     for _ in range(100):
-        vx_new = np.sqrt(np.interp(np.minimum(vx, v_max), ggv[:, 0], ggv[:, 2]) * radii)
-        done = np.nanmax(np.abs(np.where(np.isfinite(vx_new), vx / np.where(vx_new > 0, vx_new, 1.0) - 1.0, 0.0))) < 0.005
+        vx_new = np.sqrt(mu * np.interp(vx, ggv[:, 0], ggv[:, 2]) * radii)
+        with np.errstate(invalid="ignore", divide="ignore"):
+            worst = np.max(np.abs(vx_new / vx - 1.0))     # NaN (inf / inf where kappa == 0) never passes, as upstream
         vx = vx_new
-        if done:
+        if worst < 0.005:
+            converged = True
             break
+    if not converged:
+        print("The initial vx profile did not converge after 100 iterations, please check radii and ggv!")
     vx = np.minimum(vx, v_max)
 
     n = vx.size
-    vx2 = np.concatenate((vx, vx))
-    rad2 = np.concatenate((radii, radii))
-    el2 = np.concatenate((el_lengths, el_lengths))
-    vx2 = _sweep(vx2, rad2, el2, ggv, ax_max_machines, "accel", dyn_model_exp, drag_coeff, m_veh)
-    back = _sweep(vx2[::-1], rad2[::-1], np.roll(el2, 1)[::-1] if False else np.concatenate((el2[-1:], el2[:-1]))[::-1],
-                  ggv, ax_max_machines, "decel", dyn_model_exp, drag_coeff, m_veh)
-    vx2 = back[::-1]
-    out = vx2[n:]
+    rad2, el2, mu2 = np.concatenate((radii, radii)), np.concatenate((el_lengths, el_lengths)), np.concatenate((mu, mu))
+    dom = drag_coeff / m_veh
+    fwd = _sweep(np.concatenate((vx, vx)), rad2, el2, mu2, ggv, ax_max_machines, v_max, True, dyn_model_exp, dom)
+    lap2 = np.concatenate((fwd[n:], fwd[n:]))
+    # backward: every array flipped as a whole (step i uses the element length stored at the point it leaves, as upstream)
+    bwd = _sweep(lap2[::-1], rad2[::-1], el2[::-1], mu2[::-1], ggv, ax_max_machines, v_max, False, dyn_model_exp, dom)
+    out = bwd[::-1][n:]
     if filt_window is not None:
         out = _cf.conv_filt(signal=out, filt_window=filt_window, closed=True)
     return out

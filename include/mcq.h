@@ -181,7 +181,10 @@ int mcq_relinearise_device(mcq_handle* h, int batch, int nmax, const int* n_in, 
                            double stepsize, double* reftrack_out, double* normvec_out, int* n_out, int* status_out);
 /* ggv velocity profile and lap time of a batch of (track, vehicle) variants -- what the lap-time-matrix sweep of the
  * reference runs per cell [REF main_globaltraj.py:400-422, 460-493]: tph.calc_vel_profile (closed track, global ggv, no
- * filter) followed by calc_ax_profile / calc_t_profile.  One device thread per variant.  All pointers DEVICE pointers:
+ * filter; every step of upstream's solver: fixed-point lateral limit over all ggv rows, sweeps gated on the acceleration-phase
+ * starts and on v_max, one look-ahead round in the backward sweep) followed by calc_ax_profile / calc_t_profile (lap time as
+ * the sum of 2 l / (v_a + v_b)).  One device thread per variant.  A variant whose ggv or machine table ends below its v_max
+ * (tph raises RuntimeError) gets lap_time NaN.  All pointers DEVICE pointers:
  * kappa / el_lengths [tracks][nmax] (n valid entries each), track_of [batch] (row used by a variant) or NULL (row =
  * variant), ggv [batch][n_ggv][3] (v, ax_max, ay_max), ax_max_machines [batch][n_machines][2], drag_coeff / m_veh / v_max
  * [batch]; outputs vx_out [batch][nmax], lap_time_out [batch].  Asynchronous on the handle's stream. */

@@ -5,6 +5,9 @@ QP routes used to pin the oracle against itself:
   solve_qp_gi      dense Goldfarb-Idnani (oracle/gi_dense.c), quadprog calling convention
                    quadprog.solve_qp(H, -f, -G.T, -h, 0)[0]  
   solve_box_bvls   scipy.optimize.lsq_linear(E, -2 k_ref, bounds) -- valid when the kappa rows are inactive
+  solve_box_second_route   the same least-squares form by the trust-region-reflective method (an interior method on the dense
+                   E with exact SVD steps: neither an active-set method nor the normal equations) -- the independent route at
+                   the sizes where BVLS is too slow (N = 663 / 776 / 2000)
   kkt_residuals    certificate: stationarity / primal / dual feasibility / complementarity
 """
 import ctypes
@@ -77,6 +80,16 @@ def solve_box_bvls(E, k_ref, lo, hi, f_scale=2.0):
     """Box-only route: 1/2 a'E'Ea + (f_scale E'k_ref)'a == 1/2 ||E a + f_scale k_ref||^2 + const."""
     from scipy.optimize import lsq_linear
     res = lsq_linear(E, -f_scale * k_ref, bounds=(lo, hi), method="bvls", tol=1e-15, max_iter=50 * E.shape[1])
+    return res.x
+
+
+def solve_box_second_route(E, k_ref, lo, hi, f_scale=2.0):
+    """Second, independent route for the box-only QP at any size: scipy's trust-region-reflective bounded least squares
+    on  1/2 ||E a + f_scale k_ref||^2  (dense E, exact least-squares steps).  Shares nothing with the Goldfarb-Idnani
+    oracle: no Cholesky of H = E'E (cond 1e9..1e12; this route sees cond(E) = its square root), no active-set logic.
+    Valid whenever the curvature rows are inactive at its optimum (true on every fixture; the caller checks)."""
+    from scipy.optimize import lsq_linear
+    res = lsq_linear(E, -f_scale * k_ref, bounds=(lo, hi), method="trf", tol=1e-15, lsq_solver="exact", max_iter=1000)
     return res.x
 
 

@@ -55,6 +55,11 @@ def main():
             a2 = qp_ref.solve_box_bvls(I["E"], I["k_ref"], lo, hi)
             bvls_diff = float(np.max(np.abs(a2 - alpha)))
         rec["bvls_max_diff"] = bvls_diff
+        # second independent route at every size (BVLS needs ~N single-variable exchanges of an O(N^3) least-squares solve each
+        # and is only run for N <= 300): trust-region-reflective bounded least squares on the dense E
+        a3 = qp_ref.solve_box_second_route(I["E"], I["k_ref"], lo, hi)
+        rec["second_route"] = "lsq_linear(trf) on dense E"
+        rec["second_route_max_diff"] = float(np.max(np.abs(a3 - alpha)))
         out = dict(reftrack=reftrack, normvec=normvec, scaling=scaling, alpha=alpha, curv_error_max=curv_err,
                    k_ref=I["k_ref"], f=I["f"], h_diag=np.diag(I["H"]).copy(), e_diag=np.diag(I["E"]).copy(),
                    kappa_bound=KAPPA_BOUND, w_veh=W_VEH)

@@ -138,8 +138,9 @@ def test_long_ring_general_path_properties(gpu_engine):
     assert st2[0] == 0 and np.max(np.abs(np.roll(al2[0], -r) - al[0])) < ALPHA_TOL
 
 
-def test_oval_n2000_against_dense_gi_oracle(gpu_engine):
-    """One full-size problem against the dense Goldfarb-Idnani oracle fed with the dense E (about 10 s of CPU)."""
+def test_oval_n1000_against_dense_gi_oracle(gpu_engine):
+    """One N = 1000 oval against the LIVE dense oracle (dense inverse + dense Goldfarb-Idnani, about 10 s of CPU); the full
+    size, N = 2000, is checked against the committed oracle output in test_oval_n2000_* below."""
     from oracle import qp_ref, tph_ref
     ref, nv, sc = synthetic.oval_batch(1, n=1000)
     path_cl = np.vstack((ref[0, :, :2], ref[0, :1, :2]))
@@ -439,10 +440,13 @@ def test_prep_on_device_and_solve_without_normals(gpu_engine, golden):
 
 def test_velocity_profile_lap_time_sweep(gpu_engine, golden):
     """Row f-3: a (gg-scale x top-speed) grid of vehicle variants over the racelines of two reference tracks in ONE launch
-    (what the reference's lap-time matrix loops over [REF main_globaltraj.py:442-496]) against the host chain
-    calc_vel_profile -> calc_ax_profile -> calc_t_profile, variant by variant."""
-    from global_racetrajectory_optimization_amd.trajectory_planning_helpers import calc_vel_profile as cv, calc_ax_profile as ca, \
-        calc_t_profile as ct, create_raceline as cr, calc_head_curv_an as ch
+    (what the reference's lap-time matrix loops over [REF main_globaltraj.py:442-496]) against the ORACLE's restatement of
+    tph.calc_vel_profile -> calc_ax_profile -> calc_t_profile (oracle/vel_ref.py: acceleration-phase gating, backward
+    look-ahead, all ggv rows), variant by variant; the constant ggv of the reference scaled as the sweep scales it, plus
+    speed-dependent diagrams with top speeds between the grid points."""
+    from oracle import vel_ref
+    from test_emu_kernels import _vehicle_variants_speed_dependent
+    from global_racetrajectory_optimization_amd.trajectory_planning_helpers import create_raceline as cr, calc_head_curv_an as ch
     tracks = []
     for name in ("handling_track", "modena_2019"):
         g = golden[name]
@@ -461,31 +465,34 @@ def test_velocity_profile_lap_time_sweep(gpu_engine, golden):
                 gg[:, 1:] *= scale
                 ggvs.append(gg)
                 vmaxs.append(top)
+        for gg, _, _, _, top in _vehicle_variants_speed_dependent():
+            ggvs.append(gg)
+            vmaxs.append(top)
         bsz = len(ggvs)
-        vx_d, lt_d = gpu_engine.vel_profile_batch(kappa[None, :], el[None, :], np.stack(ggvs), np.stack([axm] * bsz), 0.75, 1200.0,
-                                                  vmaxs, dyn_model_exp=1.0, track_of=np.zeros(bsz, dtype=np.int32))
-        for k in range(bsz):
-            vx_h = cv.calc_vel_profile(ggv=ggvs[k], ax_max_machines=axm, v_max=vmaxs[k], kappa=kappa, el_lengths=el, closed=True,
-                                       filt_window=None, dyn_model_exp=1.0, drag_coeff=0.75, m_veh=1200.0)
-            ax_h = ca.calc_ax_profile(vx_profile=np.append(vx_h, vx_h[0]), el_lengths=el, eq_length_output=False)
-            t_h = ct.calc_t_profile(vx_profile=vx_h, ax_profile=ax_h, el_lengths=el)
-            assert np.max(np.abs(vx_d[k] - vx_h)) < 1e-9, k
-            # lap time: the device sums 2 l / (v_a + v_b) per element -- algebraically calc_t_profile's expression, which
-            # cancels catastrophically on speed-limited stretches (a -> 0); hence exact against the stable form, loose
-            # against the host's
-            vx_cl = np.append(vx_h, vx_h[0])
-            assert abs(lt_d[k] - float(np.sum(2.0 * el / (vx_cl[:-1] + vx_cl[1:])))) < 1e-9, k
-            assert abs(lt_d[k] - t_h[-1]) < 0.5, k
+        for e in (1.0, 1.7):
+            vx_d, lt_d = gpu_engine.vel_profile_batch(kappa[None, :], el[None, :], np.stack(ggvs), np.stack([axm] * bsz), 0.75,
+                                                      1200.0, vmaxs, dyn_model_exp=e, track_of=np.zeros(bsz, dtype=np.int32))
+            for k in range(bsz):
+                vx_o = vel_ref.calc_vel_profile(ax_max_machines=axm, kappa=kappa, el_lengths=el, closed=True, drag_coeff=0.75,
+                                                m_veh=1200.0, ggv=ggvs[k], v_max=vmaxs[k], dyn_model_exp=e)
+                ax_o = vel_ref.calc_ax_profile(np.append(vx_o, vx_o[0]), el)
+                t_o = vel_ref.calc_t_profile(vx_o, el, ax_profile=ax_o)
+                assert np.max(np.abs(vx_d[k] - vx_o)) < 1e-9, (k, e)
+                # lap time: the device sums 2 l / (v_a + v_b) per element -- algebraically calc_t_profile's expression, which
+                # cancels catastrophically on speed-limited stretches (a -> 0); hence exact against the stable form, loose
+                # against upstream's
+                assert abs(lt_d[k] - vel_ref.lap_time_stable(vx_o, el)) < 1e-9, (k, e)
+                assert abs(lt_d[k] - t_o[-1]) < 0.5, (k, e)
     assert nmax > 0
 
 
 def test_raceline_kernel_and_ragged_lap_time_matrix(gpu_engine, golden):
     """The chain after the QP [REF main_globaltraj.py:371-422] on the device over the four reference tracks at once (BASELINE
     config 4's shape): alpha from the engine -> mcq_raceline_device (create_raceline + calc_head_curv_an) -> ragged velocity
-    profiles of a (gg-scale x top-speed) grid per raceline; every raceline against the host shims, every lap time against the
-    host chain."""
-    from global_racetrajectory_optimization_amd.trajectory_planning_helpers import calc_vel_profile as cv, create_raceline as cr, \
-        calc_head_curv_an as ch
+    profiles of a (gg-scale x top-speed) grid per raceline; every raceline against the host shims (themselves checked against
+    oracle/tph_ref.py in tests/test_host.py), every velocity profile / lap time against oracle/vel_ref.py."""
+    from oracle import vel_ref
+    from global_racetrajectory_optimization_amd.trajectory_planning_helpers import create_raceline as cr, calc_head_curv_an as ch
     names = ("berlin_2018", "modena_2019", "handling_track", "rounded_rectangle")
     probs = [_problem(golden[k]) for k in names]
     al, _, st, _ = gpu_engine.solve_batch(probs)
@@ -522,16 +529,16 @@ def test_raceline_kernel_and_ragged_lap_time_matrix(gpu_engine, golden):
                                               n_of_track=out["m"])
     for k in range(bsz):
         kap, el = host[track_of[k]]
-        vx_h = cv.calc_vel_profile(ggv=ggvs[k], ax_max_machines=axm, v_max=tops[k], kappa=kap, el_lengths=el, closed=True,
-                                   filt_window=None, dyn_model_exp=1.0, drag_coeff=0.75, m_veh=1200.0)
-        vx_cl = np.append(vx_h, vx_h[0])
-        assert np.max(np.abs(vx_d[k, :kap.size] - vx_h)) < 1e-8, k
-        assert abs(lt_d[k] - float(np.sum(2.0 * el / (vx_cl[:-1] + vx_cl[1:])))) < 1e-8, k
+        vx_o = vel_ref.calc_vel_profile(ax_max_machines=axm, kappa=kap, el_lengths=el, closed=True, drag_coeff=0.75, m_veh=1200.0,
+                                        ggv=ggvs[k], v_max=tops[k], dyn_model_exp=1.0)
+        assert np.max(np.abs(vx_d[k, :kap.size] - vx_o)) < 1e-8, k
+        assert abs(lt_d[k] - vel_ref.lap_time_stable(vx_o, el)) < 1e-8, k
 
 
 def test_normals_crossing_on_device(gpu_engine, golden):
-    """Row f-2's second half: tph.check_normals_crossing [REF helper_funcs_glob/src/prep_track.py:57-59] for a ragged batch."""
-    from global_racetrajectory_optimization_amd.trajectory_planning_helpers import check_normals_crossing as cn
+    """Row f-2's second half: tph.check_normals_crossing [REF helper_funcs_glob/src/prep_track.py:57-59] for a ragged batch,
+    against the oracle's restatement (oracle/vel_ref.py)."""
+    from oracle import vel_ref as cn
     from test_emu_kernels import _crossing_cases
     cases = _crossing_cases(golden) + [(golden[k]["reftrack"], golden[k]["normvec"]) for k in ("berlin_2018", "handling_track")]
     got = gpu_engine.normals_crossing_batch([c[0] for c in cases], [c[1] for c in cases], horizon=10)
@@ -620,3 +627,88 @@ def test_shortest_path_full_size_properties_and_oracle(gpu_engine):
                                                 w_veh=3.4)], objective=engine.OBJ_SHORTEST_PATH)
     assert st1[0] == 0
     assert np.max(np.abs(a[0] - a_ref)) < ALPHA_TOL
+
+
+def test_mintime_reopt_corridor_config(gpu_engine, golden):
+    """The second consumer of opt_min_curv in the reference: the re-optimisation after the minimum-time run
+    [REF main_globaltraj.py:337-350] with `w_tr_reopt = 2.0` -> widths 1.0 / 1.0 and `w_veh_reopt = 1.6`
+    [REF params/racecar.ini:110-111]: a uniform +-0.2 m corridor around the line.  Same entry point, a very different active
+    fraction (14-28 % of the box rows, and on Berlin two curvature rows at the optimum): every golden track against the live
+    dense oracle (dense inverse + dense Goldfarb-Idnani with all 4N rows)."""
+    from oracle import tph_ref
+    probs, refs = [], []
+    for name, g in golden.items():
+        ref = g["reftrack"].copy()
+        ref[:, 2:] = 0.5 * 2.0
+        A = tph.calc_splines.build_les_matrix(ref.shape[0], g["scaling"])
+        refs.append((name, ref, tph_ref.opt_min_curv(ref, g["normvec"], A, 0.12, 1.6)))
+        probs.append(dict(reftrack=ref, normvec=g["normvec"], scaling=g["scaling"], kappa_bound=0.12, w_veh=1.6))
+    al, curv, st, info = gpu_engine.solve_batch(probs)
+    n_kappa = 0
+    for k, (name, ref, (a_ref, err_ref)) in enumerate(refs):
+        assert st[k] == 0, (name, st[k])
+        assert np.max(np.abs(al[k] - a_ref)) < ALPHA_TOL, (name, float(np.max(np.abs(al[k] - a_ref))))
+        assert abs(curv[k] - err_ref) < CURV_TOL, name
+        assert np.all(np.abs(al[k]) <= 0.2 + 1e-12)
+        assert info[k]["n_active_box"] == int(np.sum(np.abs(np.abs(a_ref) - 0.2) < 1e-9)), name
+        n_kappa += info[k]["n_active_kappa"]
+    assert n_kappa >= 2          # Berlin: the corridor leaves two curvature rows at the bound
+    # and through the drop-in function, as main_globaltraj.py calls it
+    name, ref, (a_ref, _) = refs[-1]
+    g = golden[name]
+    A = tph.calc_splines.build_les_matrix(ref.shape[0], g["scaling"])
+    a = tph.opt_min_curv.opt_min_curv(reftrack=ref, normvectors=g["normvec"], A=A, kappa_bound=0.12, w_veh=1.6,
+                                      print_debug=False, plot_debug=False)[0]
+    assert np.max(np.abs(a - a_ref)) < ALPHA_TOL
+
+
+def _golden_n2000():
+    import os
+    z = np.load(os.path.join(os.path.dirname(__file__), "golden", "oval_n2000.npz"))
+    g = {k: z[k] for k in z.files}
+    # the fixture's inputs ARE the BASELINE config 3 generator's track 0 (what bench.py solves 1024 width variants of)
+    ref, nv, sc = synthetic.oval_batch(1, n=2000)
+    assert np.array_equal(ref[0], g["reftrack"]) and np.array_equal(nv[0], g["normvec"]) and np.array_equal(sc[0], g["scaling"])
+    return g
+
+
+def test_oval_n2000_first_pass_against_golden(gpu_engine):
+    """BASELINE config 3 at full size: alpha and curv_error_max of one opt_min_curv pass at N = 2000 against the committed
+    output of the dense-faithful oracle (8000 x 8000 dense inverse, dense Goldfarb-Idnani with all 8000 rows;
+    scripts/make_golden_n2000.py, pinned there by the trust-region-reflective second route to 3.5e-10 m and by a KKT
+    certificate).  Host-buffer entry, device entry fed rows only (normals derived on the device), and the drop-in function."""
+    g = _golden_n2000()
+    p = dict(reftrack=g["reftrack"], normvec=g["normvec"], scaling=g["scaling"], kappa_bound=0.12, w_veh=3.4)
+    al, curv, st, info = gpu_engine.solve_batch([p, dict(p, normvec=None, scaling=None)])
+    for k in range(2):
+        assert st[k] == 0
+        assert np.max(np.abs(al[k] - g["alpha"])) < ALPHA_TOL, float(np.max(np.abs(al[k] - g["alpha"])))
+        assert abs(curv[k] - float(g["curv_error_max"])) < CURV_TOL
+        assert abs(info[k]["kappa_max"] - float(g["kappa_max"])) < 1e-9
+    A = tph.calc_splines.build_les_matrix(2000, g["scaling"])
+    a, err = tph.opt_min_curv.opt_min_curv(g["reftrack"], g["normvec"], A, 0.12, 3.4)
+    assert np.max(np.abs(a - g["alpha"])) < ALPHA_TOL and abs(err - float(g["curv_error_max"])) < CURV_TOL
+
+
+def test_oval_n2000_iqp_end_state_against_golden(gpu_engine):
+    """BASELINE config 3 IS mincurv_iqp: the END STATE of the whole iqp_handler chain at N = 2000 (three passes, N = 2000 ->
+    2003 -> 2002: re-sampling, width carry-over, re-spline, damping 1/3 and 2/3) against the committed output of the oracle's
+    chain (dense re-linearisation every pass, ~2 min of CPU): through the drop-in function, through the host-glue batch driver,
+    through the device-resident driver cold, and through the device-resident driver with warm-started passes."""
+    from global_racetrajectory_optimization_amd.trajectory_planning_helpers import iqp_handler as iq
+    g = _golden_n2000()
+    A = tph.calc_splines.build_les_matrix(2000, g["scaling"])
+    step = float(g["stepsize_interp"])
+    outs = [tph.iqp_handler.iqp_handler(reftrack=g["reftrack"].copy(), normvectors=g["normvec"], A=A, kappa_bound=0.12, w_veh=3.4,
+                                        print_debug=False, plot_debug=False, stepsize_interp=step, iters_min=3,
+                                        curv_error_allowed=0.01)]
+    trk = [dict(reftrack=g["reftrack"].copy(), normvectors=g["normvec"], scaling=g["scaling"])]
+    for kw in (dict(device_resident=False), dict(device_resident=True, warm_start=False), dict(device_resident=True, warm_start=True)):
+        stt = {}
+        outs.append(iq.iqp_handler_batch(trk, 0.12, 3.4, step, 3, 0.01, engine=gpu_engine, stats=stt, **kw)[0])
+        assert stt["rounds"] == len(g["iqp_n"]) == 3
+    for a, ref_out, nv_out in outs:
+        assert a.shape == g["iqp_alpha"].shape == (int(g["iqp_n"][-1]),)
+        assert np.max(np.abs(a - g["iqp_alpha"])) < ALPHA_TOL, float(np.max(np.abs(a - g["iqp_alpha"])))
+        assert np.max(np.abs(ref_out - g["iqp_reftrack"])) < 1e-6
+        assert np.max(np.abs(nv_out - g["iqp_normvec"])) < 1e-8

@@ -99,3 +99,29 @@ def test_header_is_plain_c_and_links_against_the_library(tmp_path):
     subprocess.run(["gcc", "-std=c99", "-Wall", "-Wextra", "-pedantic", "-Werror", "-I", os.path.join(ROOT, "include"), str(src),
                     "-o", str(exe), "-L", lib_dir, "-l:libmcq.so", "-Wl,-rpath," + lib_dir, "-Wl,--allow-shlib-undefined"], check=True)
     assert exe.exists()
+
+
+def test_les_matrix_structure_guard(golden):
+    """opt_min_curv reads only the N scalings out of the dense matrix A; a matrix that is not calc_splines' closed-spline
+    system must be rejected (RuntimeError), not silently misread."""
+    cs = tph.calc_splines
+    ref = golden["rounded_rectangle"]["reftrack"]
+    path_cl = np.vstack((ref[:, :2], ref[0, :2]))
+    _, _, A, nv = cs.calc_splines(path_cl)
+    n = ref.shape[0]
+    assert np.array_equal(cs.scalings_from_les_matrix(A), cs.spline_scalings(path_cl))
+    assert np.array_equal(cs.scalings_from_les_matrix(tph_ref.calc_splines(path_cl)[2]), cs.spline_scalings(path_cl))
+    for r, c, dv in ((7, 9, 0.5), (4 * n - 1, 0, 1e-3), (2, 2, -2.0), (0, 0, 0.25), (6, 9, 5.0), (40, 200, 1e-9), (7, 10, 1e-6)):
+        B = A.copy()
+        B[r, c] += dv
+        with pytest.raises(RuntimeError, match="structure of calc_splines"):
+            cs.scalings_from_les_matrix(B)
+    with pytest.raises(RuntimeError, match="structure of calc_splines"):
+        cs.scalings_from_les_matrix(np.eye(4 * n))
+    with pytest.raises(RuntimeError, match="structure of calc_splines"):
+        cs.scalings_from_les_matrix(A[::-1].copy())
+    # the drop-in entry points run the guard before anything reaches the engine (no library needed to see it)
+    with pytest.raises(RuntimeError, match="structure of calc_splines"):
+        tph.opt_min_curv.opt_min_curv(ref, nv, np.eye(4 * n), 0.12, 3.4)
+    with pytest.raises(RuntimeError, match="structure of calc_splines"):
+        tph.iqp_handler.iqp_handler(ref, nv, np.eye(4 * n), 0.12, 3.4, False, False, 3.0)
