@@ -8,19 +8,34 @@ batch of 1024 synthetic perturbed-oval reference tracks (BASELINE config 3 gener
 are already resident in HBM; with N > 1 GPUs every rank solves its own 1024 tracks (weak scaling, no data-path
 collective inside the solve) and ONE RCCL all-gather collects the alpha vectors (north_star) inside the timed region.
 
-  python bench.py [--gpus N] [--steps K] [--warmup W] [--batch B] [--n N_WAYPOINTS] [--io f64|f32] [--perturb-centreline]
-                  [--no-cpu-baseline]
+  python bench.py [--gpus N] [--steps K] [--warmup W] [--config 3|4|5] [--batch B] [--n N_WAYPOINTS] [--io f64|f32]
+                  [--perturb-centreline] [--no-cpu-baseline] [--no-extras] [--force-collective]
 
---io f32 (BASELINE config 5's boundary): tracks and alpha live in HBM as float and the all-gather moves float alpha; the
-arithmetic stays fp64 (`dtype` in the JSON line is the arithmetic type).  Config 5 on one node of 8 GPUs is
-`--gpus 8 --batch 8192 --io f32 --perturb-centreline` (65536 synthetic reference tracks, 69 GB of workspace per GPU).
+--gpus N with N > 1 and no launcher environment (WORLD_SIZE unset): bench.py re-launches itself as N ranks, one per GPU,
+under torch.distributed.run on 127.0.0.1 (what the driver does itself when it passes --gpus N under its own launcher).
+
+--config 3 (default)  the headline workload above.
+--config 4            BASELINE config 4: the lap-time matrix of 16384 (track, vehicle width, ggv scale / top speed) variants
+                      over the reference's four tracks, block-partitioned over the ranks (parallel.shard_bounds), one
+                      all-gather of the lap times; metric "lap-time-matrix variants/sec".
+--config 5            BASELINE config 5: 65536 synthetic reference tracks over 8 GPUs = 8192 per GPU, float rows / float alpha
+                      in HBM (fp64 arithmetic), per-track centrelines, one all-gather of float alpha.
+
+Besides the contract's fields the JSON line carries (rank 0, N = 1, unless --no-extras): `host_to_host` -- the wall SURVEY.md
+section 8d defines the metric on (inputs in pinned host memory -> alpha in host memory, mcq_solve_host); `iqp` -- config 3 is
+mincurv_iqp: the whole iqp_handler chain of the 1024 tracks (3 passes each) as one engine call; `cpu_baseline` -- CPU-A (the
+dense-faithful port of the reference's path) and CPU-B (structure-exploiting scalar solver, one problem per host core).
 
 Prints ONE JSON line on rank 0.
 """
 import argparse
+import glob
 import json
 import os
+import socket
+import subprocess
 import sys
+import threading
 import time
 
 import numpy as np
@@ -33,65 +48,194 @@ INFO_DTYPE = np.dtype([("ipm_iters", "<i4"), ("as_iters", "<i4"), ("n_active_box
                        ("kappa_max", "<f8"), ("kkt_res", "<f8"), ("ticks", "<i8", (8,)),
                        ("refine_rounds", "<i4"), ("second_attempt", "<i4")])
 HBM_PEAK_GBS = 8000.0        # MI355X HBM3E spec peak, /opt/skills/guides/MI355X_MICROARCH.md
+FP64_PEAK_TFLOPS = 78.6      # MI355X fp64 vector = matrix peak (public spec; v_mfma_f64_16x16x4 runs at the fp64 VALU rate)
 KAPPA_BOUND, W_VEH = 0.12, 3.4
 
 
-def algorithmic_bytes(n, info, band_e=32):
-    """Algorithmic HBM bytes of mcq_solve_kernel for one launch ('banded-exact' mode).
+# ----------------------------------------------------------------------------------------------------------------------
+# roofline model of mcq_solve_kernel ('banded-exact' mode)
+# ----------------------------------------------------------------------------------------------------------------------
+def work_model(n, info, band_e=32):
+    """Algorithmic HBM bytes and fp64 flops of mcq_solve_kernel for one launch, from the iteration counts the solver reports.
 
-    Row sizes as stored (csrc/mcq_kernels.h): H row 130 doubles (65 band | pad | 64 border), L row 144 doubles
-    (64 band | 16 inverse-diagonal-tile | 64 border W), E / E' bands 65 doubles per row.
-      factorisation : read the H rows + write the L rows               n * (1040 + 1152) B
-      solve         : forward + backward sweep, each reads the L rows  2 * n * 1152 B
-      gradient      : E band + E' band                                 2 * n * 65 * 8 B
+    Rows AS STORED (csrc/mcq_kernels.h): H row 130 doubles (65 band | pad | 64 border), L row 144 doubles (64 band | 16
+    inverse-diagonal-tile | 64 border W), E / E' bands 65 doubles per row.  MINIMAL rows (what the bordered-band algorithm needs
+    whatever the layout): H 129 doubles, L 128 doubles (the inverse diagonal tile is a stored by-product of the factorisation).
+      factorisation : read the H rows + write the L rows;   solve: forward + backward sweep, each reads the L rows
+      gradient      : E band + E' band
     IPM iteration = 1 factorisation + 2 solves (the gradient is carried through the reduced system; one exact gradient
     confirms convergence); active-set iteration = 1 factorisation + 1 solve + 2 gradients; refinement round = 1 solve +
-    1 gradient (the rounds actually run: mcq_info.refine_rounds); + 1 initial gradient + 3 band products in the epilogue.
-    Iteration counts are the ones the solver reports (mcq_info).
+    1 gradient; + 1 initial gradient + 3 band products in the epilogue.
+    Flops (2 per FMA): factorisation 10272 FMAs per column (band 2080 + border 4096 + Schur 4096), sweep
+    144 FMAs per row and direction, band product 65 FMAs per row.
     """
-    fac = n * (130.0 + 144.0) * 8.0
-    sol = 2.0 * n * 144.0 * 8.0
-    grad = 2.0 * n * (2 * band_e + 1) * 8.0
     ipm = info["ipm_iters"].astype(np.float64)
     act = info["as_iters"].astype(np.float64)
     ref = info["refine_rounds"].astype(np.float64)
-    per = ipm * (fac + 2 * sol) + grad + act * (fac + sol + 2 * grad) + ref * (sol + grad) + grad + 1.5 * grad
-    return float(per.sum())
+    n_fac, n_sol = ipm + act, 2 * ipm + act + ref
+    n_grad = 1.0 + 2 * act + ref + 1.0 + 1.5
+
+    def total(h_row, l_row):
+        fac = n * (h_row + l_row) * 8.0
+        sol = 2.0 * n * l_row * 8.0
+        grad = 2.0 * n * (2 * band_e + 1) * 8.0
+        return float((n_fac * fac + n_sol * sol + n_grad * grad).sum())
+
+    flops = float((n_fac * 2.0 * n * 10272.0 + n_sol * 2.0 * 2.0 * n * 144.0 + n_grad * 2.0 * 2.0 * n * (2 * band_e + 1)).sum())
+    return total(130.0, 144.0), total(129.0, 128.0), flops
 
 
 def measured_traffic():
-    """HBM traffic of mcq_solve_kernel per launch from the committed rocprofv3 PMC passes (profiles/latest_pmc.json,
-    written by scripts/pmc_summary.py: separate --pmc FETCH_SIZE / WRITE_SIZE runs of this same command, KiB units,
-    FETCH_SIZE doubled per the gfx950 note of MI355X_MICROARCH.md).  None if no profile is committed."""
+    """HBM traffic of mcq_solve_kernel per launch from the committed rocprofv3 PMC passes (profiles/latest_pmc.json, written by
+    scripts/pmc_summary.py from separate --pmc runs of this same command).  Returns (bytes, source label) or (None, None): the
+    counters cannot be read from inside an unprofiled run, so the line names the file the figure comes from."""
     path = os.path.join(ROOT, "profiles", "latest_pmc.json")
     try:
         with open(path) as fh:
-            k = json.load(fh)["kernels"]["mcq_solve_kernel"]
-        return float(k["traffic_bytes"])
+            doc = json.load(fh)
+        k = doc["kernels"]["mcq_solve_kernel"]
+        return float(k["traffic_bytes"]), "profiles/latest_pmc.json (%s)" % doc.get("source", "rocprofv3 --pmc passes of the default workload")
     except Exception:
+        return None, None
+
+
+# ----------------------------------------------------------------------------------------------------------------------
+# GPU clock / power sampling during the timed region (explains box-to-box spread: DESIGN.md section 10)
+# ----------------------------------------------------------------------------------------------------------------------
+class SmiSampler(threading.Thread):
+    """Polls the amdgpu sysfs nodes of one card (current sclk / mclk level, socket power, junction temperature) while the
+    timed region runs.  Best effort: any node that is absent simply stays out of the record."""
+
+    def __init__(self, index):
+        super().__init__(daemon=True)
+        cards = sorted(glob.glob("/sys/class/drm/card[0-9]*/device/pp_dpm_sclk"))
+        self.dev = os.path.dirname(cards[index]) if index < len(cards) else None
+        self.samples = {"sclk_mhz": [], "mclk_mhz": [], "power_w": [], "temp_c": []}
+        self._halt = threading.Event()
+
+    @staticmethod
+    def _cur_level(path):
+        for line in open(path).read().splitlines():
+            if line.rstrip().endswith("*"):
+                return float(line.split(":")[1].strip().rstrip("*").strip().lower().replace("mhz", ""))
         return None
 
+    def run(self):
+        if not self.dev:
+            return
+        hw = glob.glob(os.path.join(self.dev, "hwmon", "hwmon*"))
+        while not self._halt.is_set():
+            try:
+                v = self._cur_level(os.path.join(self.dev, "pp_dpm_sclk"))
+                if v is not None:
+                    self.samples["sclk_mhz"].append(v)
+                v = self._cur_level(os.path.join(self.dev, "pp_dpm_mclk"))
+                if v is not None:
+                    self.samples["mclk_mhz"].append(v)
+                if hw:
+                    for name, key, div in (("power1_average", "power_w", 1e6), ("power1_input", "power_w", 1e6), ("temp2_input", "temp_c", 1e3),
+                                           ("temp1_input", "temp_c", 1e3)):
+                        f = os.path.join(hw[0], name)
+                        if os.path.exists(f):
+                            self.samples[key].append(float(open(f).read()) / div)
+            except Exception:
+                pass
+            self._halt.wait(0.02)
 
-CPU_SAMPLE = 2       # problems of the workload the CPU baseline is timed on (~10 s each at N = 2000)
+    def stop(self):
+        self._halt.set()
+        self.join(timeout=1.0)
+        out = {}
+        for k, v in self.samples.items():
+            if v:
+                out[k] = {"min": min(v), "mean": float(np.mean(v)), "max": max(v), "samples": len(v)}
+        return out or None
 
 
-def cpu_baseline(ref_b, nv_b, sc_b):
-    """Oracle ('port' of the reference's CPU path: dense-faithful numpy assembly + dense Goldfarb-Idnani in C) timed on
-    the first CPU_SAMPLE problems of the same workload.  Test infrastructure used as the checker/baseline only, never
-    shipped.  Returns (alpha of problem 0, curvature error of problem 0, total seconds, problems timed)."""
+# ----------------------------------------------------------------------------------------------------------------------
+# CPU baselines (test infrastructure used as the checker / baseline only, after the timed region, never shipped)
+# ----------------------------------------------------------------------------------------------------------------------
+def cpu_baseline(ref_b, nv_b, sc_b, alpha_gpu, curv_gpu, a_sample, b_sample):
+    """CPU-A: the port of the reference's CPU path (dense-faithful numpy assembly with BLAS on all cores + dense Goldfarb-Idnani
+    in C, one thread) on the first `a_sample` problems of the workload.  CPU-B: the structure-exploiting scalar solver
+    (oracle/banded_qp.c), one problem per host core, on the first `b_sample` problems.  Both are compared with the GPU's alpha."""
     from global_racetrajectory_optimization_amd.trajectory_planning_helpers import calc_splines as cs
-    from oracle import qp_ref, tph_ref
+    from oracle import banded_ref, qp_ref, tph_ref
     qp_ref.build()
-    k_max = min(CPU_SAMPLE, ref_b.shape[0])
-    out0, dt = None, 0.0
-    for k in range(k_max):
-        A = cs.build_les_matrix(ref_b[k].shape[0], sc_b[k])
+    cores = os.cpu_count()
+    n = ref_b.shape[1]
+    out = {}
+    # CPU-B first (seconds)
+    kb = min(b_sample, ref_b.shape[0])
+    banded_ref.solve_batch(ref_b[:1], nv_b[:1], sc_b[:1], KAPPA_BOUND, W_VEH)            # builds / loads the library
+    t0 = time.perf_counter()
+    a_b, c_b, st_b, it_b, used = banded_ref.solve_batch(ref_b[:kb], nv_b[:kb], sc_b[:kb], KAPPA_BOUND, W_VEH)
+    t_b = time.perf_counter() - t0
+    ok = st_b == 0
+    out["cpu_b"] = {"value": kb / t_b, "unit": "solves/s", "cores": int(used), "kind": "port",
+                    "sample": "%d of the %d N=%d problems, structure-exploiting scalar C (cyclic tridiagonal assembly, banded interior "
+                              "point + active set, oracle/banded_qp.c), one problem per thread, %d threads, %.2f s" % (kb, ref_b.shape[0], n, used, t_b),
+                    "failed": int(np.count_nonzero(~ok)),
+                    "max_abs_alpha_diff_vs_gpu_m": float(np.max(np.abs(a_b[ok] - alpha_gpu[:kb][ok]))) if ok.any() else None,
+                    "max_curv_err_diff_vs_gpu": float(np.max(np.abs(c_b[ok] - curv_gpu[:kb][ok]))) if ok.any() else None,
+                    "mean_ipm_iters": float(it_b[:, 0].mean()), "mean_as_iters": float(it_b[:, 1].mean())}
+    # CPU-A (about 10-30 s per problem at N = 2000)
+    ka = min(a_sample, ref_b.shape[0])
+    dt, worst, worst_c = 0.0, 0.0, 0.0
+    for k in range(ka):
+        A = cs.build_les_matrix(n, sc_b[k])
         t0 = time.perf_counter()
-        res = tph_ref.opt_min_curv(ref_b[k], nv_b[k], A, KAPPA_BOUND, W_VEH)
+        a_ref, err_ref = tph_ref.opt_min_curv(ref_b[k], nv_b[k], A, KAPPA_BOUND, W_VEH)
         dt += time.perf_counter() - t0
-        if k == 0:
-            out0 = res
-    return out0[0], out0[1], dt, k_max
+        worst = max(worst, float(np.max(np.abs(a_ref - alpha_gpu[k]))))
+        worst_c = max(worst_c, abs(err_ref - float(curv_gpu[k])))
+    out["cpu_a"] = {"value": ka / dt, "unit": "solves/s", "cores": cores, "kind": "port",
+                    "sample": "%d of the %d N=%d problems: dense-faithful numpy assembly (dense 4N x 4N inverse, BLAS threads = all %d "
+                              "cores) + dense Goldfarb-Idnani in C (1 thread), %.1f s" % (ka, ref_b.shape[0], n, cores, dt),
+                    "max_abs_alpha_diff_vs_gpu_m": worst, "max_curv_err_diff_vs_gpu": worst_c}
+    return out
+
+
+# ----------------------------------------------------------------------------------------------------------------------
+def self_launch(args):
+    """--gpus N > 1 without a launcher: run N ranks of this script under torch.distributed.run (one process per GPU)."""
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus), "--master-addr", "127.0.0.1",
+           "--master-port", str(port), "--", os.path.abspath(__file__)] + sys.argv[1:]      # "--": the launcher's own parser must not
+    # look at our options (argparse would report --n as an ambiguous prefix of its --nnodes / --nproc-per-node / ...)
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    env.setdefault("OMP_NUM_THREADS", "8")
+    raise SystemExit(subprocess.call(cmd, env=env))
+
+
+def config4_workload(rank, world):
+    """This rank's shard of BASELINE config 4: (track, vehicle width) QPs -- 4 reference tracks x 64 widths, block partition --
+    each carrying its 64 (gg-scale, top-speed) vehicles."""
+    from global_racetrajectory_optimization_amd import parallel
+    tracks = ("berlin_2018", "modena_2019", "handling_track", "rounded_rectangle")
+    gold = [np.load(os.path.join(ROOT, "tests", "golden", t + ".npz")) for t in tracks]
+    w_grid = np.linspace(2.0, 3.4, 64)
+    uniq = [dict(reftrack=g["reftrack"], normvec=g["normvec"], scaling=g["scaling"], kappa_bound=KAPPA_BOUND, w_veh=float(w))
+            for g in gold for w in w_grid]
+    lo, hi = parallel.shard_bounds(len(uniq), world, rank)
+    nveh, side = 64, 8
+    v = np.arange(0.0, 72.1, 4.0)
+    ggv0 = np.column_stack((v, np.full(v.size, 12.0), np.full(v.size, 12.0)))
+    axm0 = np.column_stack((v, np.interp(v, [0.0, 20.0, 72.0], [5.3, 5.3, 1.2])))
+    gg_scale = 0.3 + 0.7 * (np.arange(nveh) % side) / (side - 1)
+    v_top = 100.0 / 3.6 + (150.0 / 3.6) * (np.arange(nveh) // side) / ((nveh - 1) // side)
+    mine = uniq[lo:hi]
+    nvar = len(mine) * nveh
+    track_of = np.repeat(np.arange(len(mine), dtype=np.int32), nveh)
+    veh_of = np.tile(np.arange(nveh), len(mine))
+    ggv = np.repeat(ggv0[None], nvar, axis=0)
+    ggv[:, :, 1:] *= gg_scale[veh_of][:, None, None]
+    return dict(qps=mine, n_total=len(uniq) * nveh, per_rank=-(-len(uniq) // world) * nveh, nvar=nvar, track_of=track_of, ggv=ggv,
+                axm=np.repeat(axm0[None], nvar, axis=0), tops=v_top[veh_of], tracks={t: int(g["reftrack"].shape[0]) for t, g in zip(tracks, gold)})
 
 
 def main():
@@ -99,25 +243,58 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--batch", type=int, default=1024)
+    ap.add_argument("--config", type=int, choices=(3, 4, 5), default=3)
+    ap.add_argument("--batch", type=int, default=None)
     ap.add_argument("--n", type=int, default=2000)
-    ap.add_argument("--io", choices=("f64", "f32"), default="f64")
+    ap.add_argument("--io", choices=("f64", "f32"), default=None)
     ap.add_argument("--perturb-centreline", action="store_true")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-extras", action="store_true", help="skip the host_to_host and iqp records (and the CPU baselines)")
+    ap.add_argument("--cpu-a-sample", type=int, default=3)
+    ap.add_argument("--cpu-b-sample", type=int, default=512)
     ap.add_argument("--force-collective", action="store_true",
                     help="initialise RCCL and run the all-gather even with one rank (self-test of the N > 1 path on a 1-GPU box)")
+    ap.add_argument("--emulate", default=None, metavar="LIBMCQ_EMU_SO",
+                    help="TEST ONLY (tests/test_bench_launch.py): run the launch / sharding / collective logic on CPU tensors with the "
+                         "SIMT-interpreted kernel library and the gloo backend; the line is marked invalid as a measurement")
     args = ap.parse_args()
+    if args.config == 5:
+        args.batch = args.batch or 8192
+        args.io = args.io or "f32"
+        args.perturb_centreline = True
+    args.batch = args.batch or 1024
+    args.io = args.io or "f64"
+    if args.emulate and os.environ.get("MCQ_BENCH_TEST_N"):      # tests/test_bench_launch.py under a launcher whose parser rejects --n
+        args.n = int(os.environ["MCQ_BENCH_TEST_N"])
+
+    world_env = os.environ.get("WORLD_SIZE")
+    if world_env is None and args.gpus > 1:
+        self_launch(args)
+    world = int(world_env or "1")
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != max(args.gpus, 1) and rank == 0:
+        print("bench.py: --gpus %d but the launcher started %d ranks; reporting the ranks that exist" % (args.gpus, world), file=sys.stderr)
 
     import torch
     from global_racetrajectory_optimization_amd import engine, synthetic
 
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if not torch.cuda.is_available():
-        raise SystemExit("bench.py needs a GPU (the engine has no CPU path)")
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
+    emulate = args.emulate is not None
+    if emulate:
+        dev = torch.device("cpu")
+    else:
+        if not torch.cuda.is_available():
+            raise SystemExit("bench.py needs a GPU (the engine has no CPU path)")
+        if local_rank >= torch.cuda.device_count():
+            raise SystemExit("bench.py: rank %d has no GPU (%d visible): --gpus must not exceed the GPUs of the node"
+                             % (local_rank, torch.cuda.device_count()))
+        torch.cuda.set_device(local_rank)
+        dev = torch.device("cuda", local_rank)
+
+    def dev_sync():
+        if not emulate:
+            torch.cuda.synchronize()
+
     dist = None
     collective = world > 1 or args.force_collective
     if collective:
@@ -131,80 +308,133 @@ def main():
         saved_fd = os.dup(1)
         os.dup2(2, 1)
         try:
-            dist.init_process_group(backend="nccl", rank=rank, world_size=world, device_id=dev)
+            if emulate:
+                dist.init_process_group(backend="gloo", rank=rank, world_size=world)
+            else:
+                dist.init_process_group(backend="nccl", rank=rank, world_size=world, device_id=dev)
             dist.barrier()
-            torch.cuda.synchronize()
+            dev_sync()
         finally:
             ctypes.CDLL(None).fflush(None)
             os.dup2(saved_fd, 1)
             os.close(saved_fd)
 
+    eng = engine.Engine(0 if emulate else local_rank, lib_path=args.emulate)
     B, n = args.batch, args.n
-    ref_h, nv_h, sc_h = synthetic.oval_batch(B, n=n, first=rank * B, perturb_centreline=args.perturb_centreline)
     f32 = args.io == "f32"
     io_t = torch.float32 if f32 else torch.float64
-    d_ref = torch.from_numpy(ref_h).to(dev).to(io_t)
-    d_nv = torch.from_numpy(nv_h).to(dev).to(io_t)
-    d_sc = torch.from_numpy(sc_h).to(dev).to(io_t)
-    d_alpha = torch.zeros((B, n), dtype=io_t, device=dev)
-    d_curv = torch.zeros((B,), dtype=torch.float64, device=dev)
-    d_status = torch.zeros((B,), dtype=torch.int32, device=dev)
-    d_info = torch.zeros((B, INFO_DTYPE.itemsize), dtype=torch.uint8, device=dev)
-    d_all = torch.zeros((world * B, n), dtype=io_t, device=dev) if collective else None
-
-    eng = engine.Engine(local_rank)
     solve_ms = []
+    ag_ev = []          # (start, end) CUDA events around every all-gather of the timed region
 
-    def step(record):
-        if f32:     # float normals are unit vectors only to 6e-8: let the engine derive them (and the scalings) in fp64
-            eng.solve_device_f32(B, n, d_ref.data_ptr(), None, None, KAPPA_BOUND, W_VEH,
+    if args.config == 4:
+        wl = config4_workload(rank, world)
+        d_lap = torch.zeros((wl["per_rank"],), dtype=torch.float64, device=dev)
+        d_all = torch.zeros((world * wl["per_rank"],), dtype=torch.float64, device=dev) if collective else None
+        lap_h = [None]
+
+        def step(record):
+            al, _, st, _ = eng.solve_batch(wl["qps"])
+            if np.any(st != 0):
+                raise SystemExit("config 4: QP status %s" % np.unique(st))
+            race = eng.raceline_batch([p["reftrack"] for p in wl["qps"]], [p["normvec"] for p in wl["qps"]], al, 2.0)
+            _, lap = eng.vel_profile_batch(race["kappa"], race["el_lengths"], wl["ggv"], wl["axm"], 0.75, 1200.0, wl["tops"], 1.0,
+                                           track_of=wl["track_of"], n_of_track=race["m"])
+            lap_h[0] = lap
+            d_lap[:lap.size] = torch.from_numpy(lap).to(dev)
+            if collective:
+                dist.all_gather_into_tensor(d_all, d_lap)
+    else:
+        ref_h, nv_h, sc_h = synthetic.oval_batch(B, n=n, first=rank * B, perturb_centreline=args.perturb_centreline)
+        d_ref = torch.from_numpy(ref_h).to(dev).to(io_t)
+        d_nv = torch.from_numpy(nv_h).to(dev).to(io_t)
+        d_sc = torch.from_numpy(sc_h).to(dev).to(io_t)
+        d_alpha = torch.zeros((B, n), dtype=io_t, device=dev)
+        d_curv = torch.zeros((B,), dtype=torch.float64, device=dev)
+        d_status = torch.zeros((B,), dtype=torch.int32, device=dev)
+        d_info = torch.zeros((B, INFO_DTYPE.itemsize), dtype=torch.uint8, device=dev)
+        d_all = torch.zeros((world * B, n), dtype=io_t, device=dev) if collective else None
+
+        def step(record):
+            if f32:     # float normals are unit vectors only to 6e-8: let the engine derive them (and the scalings) in fp64
+                eng.solve_device_f32(B, n, d_ref.data_ptr(), None, None, KAPPA_BOUND, W_VEH,
+                                     d_alpha.data_ptr(), d_curv.data_ptr(), d_status.data_ptr(), d_info.data_ptr())
+            else:
+                eng.solve_device(B, n, d_ref.data_ptr(), d_nv.data_ptr(), d_sc.data_ptr(), KAPPA_BOUND, W_VEH,
                                  d_alpha.data_ptr(), d_curv.data_ptr(), d_status.data_ptr(), d_info.data_ptr())
-        else:
-            eng.solve_device(B, n, d_ref.data_ptr(), d_nv.data_ptr(), d_sc.data_ptr(), KAPPA_BOUND, W_VEH,
-                             d_alpha.data_ptr(), d_curv.data_ptr(), d_status.data_ptr(), d_info.data_ptr())
-        eng.sync()
-        if record:
-            solve_ms.append(eng.last_timing_ms())
-        if collective:
-            dist.all_gather_into_tensor(d_all, d_alpha)
+            eng.sync()
+            if record:
+                solve_ms.append(eng.last_timing_ms())
+            if collective:
+                if record and not emulate:
+                    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                    e0.record()
+                    dist.all_gather_into_tensor(d_all, d_alpha)
+                    e1.record()
+                    ag_ev.append((e0, e1))
+                else:
+                    dist.all_gather_into_tensor(d_all, d_alpha)
 
     def fence():
         eng.sync()
-        torch.cuda.synchronize()
+        dev_sync()
         if collective:
             dist.barrier()
-            torch.cuda.synchronize()
+            dev_sync()
 
     for _ in range(args.warmup):
         step(False)
     fence()
+    sampler = SmiSampler(local_rank) if (rank == 0 and not emulate) else None
+    if sampler:
+        sampler.start()
     t0 = time.perf_counter()
     for _ in range(args.steps):
         step(True)
     fence()
-    dt = time.perf_counter() - t0
+    dt_local = time.perf_counter() - t0
+    clocks = sampler.stop() if sampler else None
+    dt, rank_ms = dt_local, [1e3 * dt_local / args.steps]
     if collective:
-        t = torch.tensor([dt], dtype=torch.float64, device=dev)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dt = float(t.item())
-        assert torch.equal(d_all[rank * B:(rank + 1) * B], d_alpha), "all-gather: own shard differs"
+        t = torch.tensor([dt_local], dtype=torch.float64, device=dev)
+        allt = torch.zeros((world,), dtype=torch.float64, device=dev)
+        dist.all_gather_into_tensor(allt, t)
+        rank_ms = [1e3 * float(v) / args.steps for v in allt.cpu()]
+        dt = float(allt.max().item())
+        if args.config != 4:
+            assert torch.equal(d_all[rank * B:(rank + 1) * B], d_alpha), "all-gather: own shard differs"
+    ranks_seen = dist.get_world_size() if collective else 1
+    ag_ms = float(np.mean([a.elapsed_time(b) for a, b in ag_ev])) if ag_ev else None
 
-    status = d_status.cpu().numpy()
-    info = d_info.cpu().numpy().view(INFO_DTYPE).reshape(B)
-    n_bad = int(np.count_nonzero(status))
-    alpha0 = d_alpha[0].cpu().numpy().astype(np.float64)
-    curv0 = float(d_curv[0].item())
-
-    if rank == 0:
+    out = None
+    if args.config == 4:
+        if rank == 0:
+            lap = lap_h[0]
+            out = {"metric": "lap-time-matrix variants/sec (BASELINE config 4: 16384 variants)", "value": wl["n_total"] * args.steps / dt,
+                   "unit": "variants/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * dt / args.steps,
+                   "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f64", "data": "reference tracks (tests/golden), synthetic vehicles",
+                   "config": {"workload": "BASELINE config 4: lap-time matrix of %d variants = 4 reference tracks x 64 vehicle widths (256 QPs, "
+                                          "solved once each: the vehicle tables do not enter the QP) x 64 (gg-scale, top-speed) vehicles; per step: "
+                                          "QPs + racelines + velocity profiles through the host-buffer entries (packing + PCIe included), block "
+                                          "partition over the ranks, one all-gather of the lap times" % wl["n_total"],
+                              "tracks": wl["tracks"], "variants_this_rank": wl["nvar"], "ranks_seen": ranks_seen,
+                              "rank_ms_per_step": {"min": min(rank_ms), "max": max(rank_ms)},
+                              "lap_time_range_s": [float(lap.min()), float(lap.max())]}}
+    elif rank == 0:
+        status = d_status.cpu().numpy()
+        info = d_info.cpu().numpy().view(INFO_DTYPE).reshape(B)
+        alpha_gpu = d_alpha.cpu().numpy().astype(np.float64)
+        curv_gpu = d_curv.cpu().numpy()
         value = world * B * args.steps / dt
         k_ms = float(np.mean([m["solve"] for m in solve_ms]))
-        alg = algorithmic_bytes(n, info)
+        alg, alg_min, flops = work_model(n, info)
         achieved = alg / (k_ms * 1e-3) / 1e9
+        default_wl = B == 1024 and n == 2000 and not args.perturb_centreline
+        traffic, traffic_src = measured_traffic() if default_wl else (None, None)
         out = {
             "metric": "min-curv QP solves/sec, N=2000 waypoints, batch=1024 per GPU",
             "value": value, "unit": "solves/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": 1e3 * dt / args.steps, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": "f64", "data": "synthetic",
+            "dtype": "f64", "data": "synthetic" if not emulate else "synthetic -- EMULATED ON CPU (test of the launch logic): NOT A MEASUREMENT",
             "config": {"workload": "BASELINE config %s generator: perturbed 2:1 oval, perimeter 6000 m, N=%d, batch=%d "
                                    "%s per GPU, one opt_min_curv pass (assembly + QP + "
                                    "curvature-error check) per track per step; kappa_bound=0.12, w_veh=3.4"
@@ -214,7 +444,9 @@ def main():
                        "batch_per_gpu": B, "n_waypoints": n, "io": args.io + (" rows / alpha in HBM, fp64 arithmetic" if f32 else ""),
                        "centrelines": "perturbed per track" if args.perturb_centreline else "shared",
                        "collective": "1 all-gather of alpha per step" if collective else "none",
-                       "failed_problems": n_bad,
+                       "ranks_seen": ranks_seen, "rank_ms_per_step": {"min": min(rank_ms), "max": max(rank_ms)},
+                       "allgather_ms": ag_ms,
+                       "failed_problems": int(np.count_nonzero(status)),
                        "mean_ipm_iters": float(info["ipm_iters"].mean()), "mean_as_iters": float(info["as_iters"].mean()),
                        "mean_active_box_rows": float(info["n_active_box"].mean()),
                        "mean_refine_rounds": float(info["refine_rounds"].mean()),
@@ -222,23 +454,57 @@ def main():
                        "kernel_ms": {k: float(np.mean([m[k] for m in solve_ms])) for k in ("assemble", "gram", "solve", "total")},
                        "workspace_GB": eng.workspace_bytes() / 1e9,
                        "solver_phase_ms_per_problem": {k: float(info["ticks"][:, j].mean()) / 1e5 for j, k in
-                                                       enumerate(("factor", "solve", "gradient", "kernel", "sweep_fwd", "sweep_bwd"))}},
+                                                       enumerate(("factor", "solve", "gradient", "kernel", "sweep_fwd", "sweep_bwd"))},
+                       "gpu_clocks_during_timed_region": clocks},
             "roofline": {"bound": "hbm", "kernel": "mcq_solve_kernel", "achieved": achieved, "peak": HBM_PEAK_GBS,
                          "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-                         # the committed counter passes are of the default workload only
-                         "traffic": measured_traffic() if (B == 1024 and n == 2000 and not args.perturb_centreline) else None,
-                         "algorithmic_bytes_per_launch": alg, "kernel_ms": k_ms},
+                         "traffic": traffic, "traffic_source": traffic_src,
+                         "algorithmic_bytes_per_launch": alg, "kernel_ms": k_ms,
+                         "frac_minimal_rows": alg_min / (k_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                         "algorithmic_bytes_per_launch_minimal_rows": alg_min,
+                         "fp64_flops_per_launch": flops, "fp64_tflops": flops / (k_ms * 1e-3) / 1e12,
+                         "fp64_frac_of_%.1f_tflops" % FP64_PEAK_TFLOPS: flops / (k_ms * 1e-3) / 1e12 / FP64_PEAK_TFLOPS},
         }
-        if world == 1 and not args.no_cpu_baseline:
-            if f32:     # the baseline solves the rows the engine saw
-                ref_h = ref_h.astype(np.float32).astype(np.float64)
-            a_cpu, err_cpu, t_cpu, k_cpu = cpu_baseline(ref_h, nv_h, sc_h)
-            out["cpu_baseline"] = {"value": k_cpu / t_cpu, "unit": "solves/s", "cores": os.cpu_count(), "kind": "port",
-                                   "sample": "%d of the %d N=%d problems: dense-faithful numpy assembly (BLAS on all "
-                                             "cores) + dense Goldfarb-Idnani in C (1 thread), %.1f s" % (k_cpu, B, n, t_cpu),
-                                   "max_abs_alpha_diff_vs_gpu_m": float(np.max(np.abs(a_cpu - alpha0))),
-                                   "curv_err_diff": abs(err_cpu - curv0)}
+        extras = world == 1 and not args.no_extras and not f32 and not emulate
+        if extras:
+            # ---- the wall SURVEY.md section 8d defines: inputs in pinned host memory -> alpha in host memory ---------------------
+            p_ref, p_nv, p_sc, p_al = eng.host_array((B, n, 4)), eng.host_array((B, n, 2)), eng.host_array((B, n)), eng.host_array((B, n))
+            p_ref[...], p_nv[...], p_sc[...] = ref_h, nv_h, sc_h
+            eng.solve_host(p_ref, p_nv, p_sc, KAPPA_BOUND, W_VEH, alpha_out=p_al)
+            hh = []
+            for _ in range(max(args.steps, 3)):
+                t1 = time.perf_counter()
+                _, _, st_h, _ = eng.solve_host(p_ref, p_nv, p_sc, KAPPA_BOUND, W_VEH, alpha_out=p_al)
+                hh.append(time.perf_counter() - t1)
+            out["host_to_host"] = {"value": B / float(np.mean(hh)), "unit": "solves/s", "ms_per_step": 1e3 * float(np.mean(hh)),
+                                   "what": "mcq_solve_host: rows / normals / scalings in pinned host memory -> H2D -> the same kernels -> alpha, "
+                                           "curv_error, status, info D2H, blocking; %d calls" % len(hh),
+                                   "bytes_h2d": int(p_ref.nbytes + p_nv.nbytes + p_sc.nbytes), "bytes_d2h": int(p_al.nbytes),
+                                   "alpha_equal_to_device_resident_run": bool(np.array_equal(p_al, alpha_gpu)), "failed_problems": int(np.count_nonzero(st_h))}
+            # ---- config 3 is mincurv_iqp: the whole iqp_handler chain of the same tracks as one engine call ------------------------
+            trk = [dict(reftrack=ref_h[k], normvectors=nv_h[k], scaling=sc_h[k]) for k in range(B)]
+            eng.iqp_batch(trk[:8], KAPPA_BOUND, W_VEH, 3.0)
+            t1 = time.perf_counter()
+            iq = eng.iqp_batch(trk, KAPPA_BOUND, W_VEH, 3.0, iters_min=3, curv_error_allowed=0.01, timed=True)
+            t_iqp = time.perf_counter() - t1
+            out["iqp"] = {"value": iq["stats"]["qp_solves"] / t_iqp, "unit": "QP solves/s (end to end: host tracks in, end states out)",
+                          "tracks": B, "seconds": t_iqp, "rounds": iq["stats"]["rounds"], "qp_solves": iq["stats"]["qp_solves"],
+                          "pass_ms": iq["stats"]["solver_ms"], "warm_start_fallbacks_per_pass": iq["stats"]["fallbacks"],
+                          "failed_tracks": int(np.count_nonzero(iq["status"])), "n_final_range": [int(iq["n"].min()), int(iq["n"].max())],
+                          "what": "mcq_iqp_batch: iqp_handler (stepsize_interp 3.0, iters_min 3, curv_error_allowed 0.01) of the %d tracks as one "
+                                  "call -- QP passes, termination test, damping and re-linearisation glue on the device, passes 2+ warm-started; "
+                                  "pass_ms = launch sequence of each round's QP pass (HIP events)" % B}
+            if not args.no_cpu_baseline:
+                cb = cpu_baseline(ref_h, nv_h, sc_h, alpha_gpu, curv_gpu, args.cpu_a_sample, args.cpu_b_sample)
+                out["cpu_baseline"] = dict(cb["cpu_a"], also={"cpu_b": cb["cpu_b"]})
+        elif world == 1 and not args.no_cpu_baseline and not args.no_extras and not emulate:
+            # f32 boundary: the baseline solves the rows the engine saw
+            r32 = ref_h.astype(np.float32).astype(np.float64)
+            cb = cpu_baseline(r32, nv_h, sc_h, alpha_gpu, curv_gpu, args.cpu_a_sample, args.cpu_b_sample)
+            out["cpu_baseline"] = dict(cb["cpu_a"], also={"cpu_b": cb["cpu_b"]})
+    if out is not None:
         print(json.dumps(out))
+        sys.stdout.flush()
     if collective:
         dist.destroy_process_group()
     eng.close()

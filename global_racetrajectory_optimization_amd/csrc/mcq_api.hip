@@ -40,12 +40,20 @@ struct mcq_handle {
     signed char* state = nullptr;
     signed char* state2 = nullptr;     // working sets carried through the IQP glue (warm start of the next pass)
     bool state2_valid = false;
+    int state2_batch = 0, state2_nmax = 0;   // the layout mcq_relinearise_device wrote state2 with: a warm start is honoured only for it
     // staging for the host-buffer entry point
     double *d_ref = nullptr, *d_nv = nullptr, *d_sc = nullptr, *d_alpha = nullptr, *d_curv = nullptr, *d_kb = nullptr,
            *d_wv = nullptr;
     int *d_n = nullptr, *d_status = nullptr;
     mcq_info* d_info = nullptr;
     size_t stage_elems = 0, stage_batch = 0;
+    double *d_ref2 = nullptr, *d_nv2 = nullptr;      // second set of the IQP double buffer (mcq_iqp_batch)
+    size_t stage2_elems = 0;
+    int* d_iqp = nullptr;                             // bookkeeping arrays of mcq_iqp_device, 8 ints per track + 1
+    double* d_iqp_curv = nullptr;
+    size_t iqp_batch = 0;
+    void* pin = nullptr;                              // pinned host staging (packing of the host-buffer entries)
+    size_t pin_bytes = 0;
     long long ws_bytes = 0;
     bool smem_attr_set = false;
     double* vel_scratch = nullptr;      // lap-doubled profiles of mcq_vel_profile_device, [2 nmax][batch]
@@ -75,12 +83,14 @@ static mcq_opts resolve_opts(const mcq_opts* in)
         if (in->max_ipm_iter > 0) o.max_ipm_iter = in->max_ipm_iter;
         if (in->max_as_iter > 0) o.max_as_iter = in->max_as_iter;
         if (in->refine_steps >= 0) o.refine_steps = in->refine_steps;
-        o.check_kappa = in->check_kappa;
+        o.check_kappa = in->check_kappa >= 0 ? 1 : 0;   // 0 (a zero-initialised struct) and 1: carried; < 0: skipped
         o.objective = in->objective == MCQ_OBJ_SHORTEST_PATH ? MCQ_OBJ_SHORTEST_PATH : MCQ_OBJ_MIN_CURV;
-        o.warm_start = in->warm_start != 0;
+        o.warm_start = in->warm_start;
     }
     return o;
 }
+
+extern "C" void mcq_destroy(mcq_handle* h);
 
 extern "C" int mcq_create(int device_id, mcq_handle** out)
 {
@@ -92,8 +102,13 @@ extern "C" int mcq_create(int device_id, mcq_handle** out)
     HIP_TRY(hipSetDevice(device_id));
     mcq_handle* h = new mcq_handle();
     h->device = device_id;
-    HIP_TRY(hipStreamCreate(&h->stream));
-    for (int k = 0; k < 5; ++k) HIP_TRY(hipEventCreate(&h->ev[k]));
+    hipError_t e = hipStreamCreate(&h->stream);
+    for (int k = 0; k < 5 && e == hipSuccess; ++k) e = hipEventCreate(&h->ev[k]);
+    if (e != hipSuccess) {
+        g_err = std::string("mcq_create: ") + hipGetErrorString(e);
+        mcq_destroy(h);         // releases whatever was created
+        return MCQ_E_DEVICE;
+    }
     *out = h;
     return 0;
 }
@@ -116,6 +131,10 @@ static void free_stage(mcq_handle* h)
     h->d_n = h->d_status = nullptr;
     h->d_info = nullptr;
     h->stage_elems = h->stage_batch = 0;
+    (void)hipFree(h->d_ref2); (void)hipFree(h->d_nv2); (void)hipFree(h->d_iqp); (void)hipFree(h->d_iqp_curv);
+    h->d_ref2 = h->d_nv2 = h->d_iqp_curv = nullptr;
+    h->d_iqp = nullptr;
+    h->stage2_elems = h->iqp_batch = 0;
 }
 
 extern "C" void mcq_destroy(mcq_handle* h)
@@ -126,6 +145,7 @@ extern "C" void mcq_destroy(mcq_handle* h)
     free_ws(h);
     free_stage(h);
     (void)hipFree(h->vel_scratch);
+    if (h->pin) (void)hipHostFree(h->pin);
     for (int k = 0; k < 5; ++k) if (h->ev[k]) (void)hipEventDestroy(h->ev[k]);
     if (h->stream) (void)hipStreamDestroy(h->stream);
     delete h;
@@ -146,6 +166,8 @@ static int ensure_ws(mcq_handle* h, size_t batch, size_t nmax)
     HIP_TRY(hipMalloc((void**)&h->Z, elems * MCQ_KMAX * sizeof(double)));
     HIP_TRY(hipMalloc((void**)&h->state, elems));
     HIP_TRY(hipMalloc((void**)&h->state2, elems));
+    HIP_TRY(hipMemsetAsync(h->state, 0, elems, h->stream));
+    HIP_TRY(hipMemsetAsync(h->state2, 0, elems, h->stream));
     h->cap_elems = elems;
     h->cap_batch = batch;
     h->ws_bytes = (long long)(elems * ((3 * MCQ_ELD + MCQ_HLD + MCQ_LLD + MCQ_NVEC + MCQ_KMAX) * sizeof(double) + 1));
@@ -183,7 +205,8 @@ static int launch(mcq_handle* h, McqBatch& B, const mcq_opts& o)
     B.check_kappa = o.check_kappa;
     B.objective = o.objective;
     // warm start: only the working sets mcq_relinearise_device carried over for exactly this batch layout
-    B.warm = (o.warm_start && h->state2_valid && !B.prep_only) ? h->state2 : nullptr;
+    B.warm = (o.warm_start > 0 && h->state2_valid && !B.prep_only && h->state2_batch == B.batch && h->state2_nmax == B.nmax)
+                 ? h->state2 : nullptr;
     if (!B.prep_only) h->state2_valid = false;
     if (B.objective == MCQ_OBJ_SHORTEST_PATH && !B.prep_only) {
         if (!B.nv) { g_err = "shortest-path objective: normvec is required"; return MCQ_E_ARG; }
@@ -439,6 +462,8 @@ extern "C" int mcq_relinearise_device(mcq_handle* h, int batch, int nmax, const 
     R.state_in = h->state;          // what the last solve on this handle left (the caller solves, then re-linearises, the same batch)
     R.state_out = h->state2;
     h->state2_valid = true;
+    h->state2_batch = batch;
+    h->state2_nmax = nmax;
     hipLaunchKernelGGL(mcq_relinearise_kernel, dim3(batch), dim3(256), 0, h->stream, R);
     HIP_TRY(hipGetLastError());
     return 0;
@@ -587,6 +612,284 @@ extern "C" int mcq_last_timing(mcq_handle* h, float ms[5])
 
 extern "C" long long mcq_workspace_bytes(mcq_handle* h) { return h ? h->ws_bytes : 0; }
 
+static int ensure_pin(mcq_handle* h, size_t bytes)
+{
+    if (bytes <= h->pin_bytes) return 0;
+    HIP_TRY(hipStreamSynchronize(h->stream));
+    if (h->pin) (void)hipHostFree(h->pin);
+    h->pin = nullptr;
+    h->pin_bytes = 0;
+    HIP_TRY(hipHostMalloc(&h->pin, bytes, hipHostMallocDefault));
+    h->pin_bytes = bytes;
+    return 0;
+}
+
+// error paths of the host-buffer entries: copies from / to the pinned staging may still be queued
+#define HIP_TRY_SYNC(expr)                                                                                \
+    do {                                                                                                  \
+        hipError_t e_ = (expr);                                                                           \
+        if (e_ != hipSuccess) {                                                                           \
+            char buf_[512];                                                                               \
+            snprintf(buf_, sizeof(buf_), "%s failed: %s (%s:%d)", #expr, hipGetErrorString(e_), __FILE__, \
+                     __LINE__);                                                                           \
+            g_err = buf_;                                                                                 \
+            (void)hipStreamSynchronize(h->stream);                                                        \
+            return MCQ_E_DEVICE;                                                                          \
+        }                                                                                                 \
+    } while (0)
+
+extern "C" int mcq_host_alloc(mcq_handle* h, size_t bytes, void** out)
+{
+    if (!h || !out || bytes == 0) { g_err = "mcq_host_alloc: bad argument"; return MCQ_E_ARG; }
+    HIP_TRY(hipSetDevice(h->device));
+    HIP_TRY(hipHostMalloc(out, bytes, hipHostMallocDefault));
+    return 0;
+}
+
+extern "C" int mcq_host_free(mcq_handle* h, void* ptr)
+{
+    if (!h) { g_err = "mcq_host_free: NULL handle"; return MCQ_E_ARG; }
+    if (!ptr) return 0;
+    HIP_TRY(hipSetDevice(h->device));
+    HIP_TRY(hipStreamSynchronize(h->stream));
+    HIP_TRY(hipHostFree(ptr));
+    return 0;
+}
+
+extern "C" int mcq_solve_host(mcq_handle* h, int batch, int n, const double* reftrack, const double* normvec,
+                              const double* scaling, double kappa_bound, double w_veh, const mcq_opts* opts, double* alpha_out,
+                              double* curv_err_out, int* status_out, mcq_info* info_out)
+{
+    if (!h || batch <= 0 || n <= 0 || !reftrack || !alpha_out || !curv_err_out || !status_out) {
+        g_err = "mcq_solve_host: bad argument";
+        return MCQ_E_ARG;
+    }
+    HIP_TRY(hipSetDevice(h->device));
+    const mcq_opts o = resolve_opts(opts);
+    int rc = ensure_ws(h, (size_t)batch, (size_t)n);
+    if (rc) return rc;
+    rc = ensure_stage(h, (size_t)batch, (size_t)n);
+    if (rc) return rc;
+    const size_t elems = (size_t)batch * n;
+    HIP_TRY_SYNC(hipMemcpyAsync(h->d_ref, reftrack, elems * 4 * sizeof(double), hipMemcpyHostToDevice, h->stream));
+    if (normvec) HIP_TRY_SYNC(hipMemcpyAsync(h->d_nv, normvec, elems * 2 * sizeof(double), hipMemcpyHostToDevice, h->stream));
+    if (scaling) HIP_TRY_SYNC(hipMemcpyAsync(h->d_sc, scaling, elems * sizeof(double), hipMemcpyHostToDevice, h->stream));
+    McqBatch B;
+    memset(&B, 0, sizeof(B));
+    B.batch = batch;
+    B.n = n;
+    B.nmax = n;
+    B.ref = h->d_ref;
+    B.nv = normvec ? h->d_nv : nullptr;
+    B.sc = scaling ? h->d_sc : nullptr;
+    B.alpha = h->d_alpha;
+    B.curv_err = h->d_curv;
+    B.status = h->d_status;
+    B.info = info_out ? h->d_info : nullptr;
+    B.kappa_bound = kappa_bound;
+    B.w_veh = w_veh;
+    rc = launch(h, B, o);
+    if (rc) { (void)hipStreamSynchronize(h->stream); return rc; }
+    HIP_TRY_SYNC(hipMemcpyAsync(alpha_out, h->d_alpha, elems * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+    HIP_TRY_SYNC(hipMemcpyAsync(curv_err_out, h->d_curv, batch * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+    HIP_TRY_SYNC(hipMemcpyAsync(status_out, h->d_status, batch * sizeof(int), hipMemcpyDeviceToHost, h->stream));
+    if (info_out) HIP_TRY_SYNC(hipMemcpyAsync(info_out, h->d_info, batch * sizeof(mcq_info), hipMemcpyDeviceToHost, h->stream));
+    HIP_TRY(hipStreamSynchronize(h->stream));
+    return 0;
+}
+
+// ---- tph.iqp_handler as one call (include/mcq.h) ---------------------------------------------------------------------------------
+static int ensure_iqp(mcq_handle* h, size_t batch)
+{
+    if (batch <= h->iqp_batch) return 0;
+    HIP_TRY(hipStreamSynchronize(h->stream));
+    (void)hipFree(h->d_iqp); (void)hipFree(h->d_iqp_curv);
+    h->d_iqp = nullptr; h->d_iqp_curv = nullptr; h->iqp_batch = 0;
+    HIP_TRY(hipMalloc((void**)&h->d_iqp, (batch * 8 + 16) * sizeof(int)));
+    HIP_TRY(hipMalloc((void**)&h->d_iqp_curv, batch * 2 * sizeof(double)));
+    h->iqp_batch = batch;
+    return 0;
+}
+
+extern "C" int mcq_iqp_device(mcq_handle* h, int batch, int nmax, int* n_io, double* reftrack_a, double* normvec_a,
+                              double* reftrack_b, double* normvec_b, const double* scaling, double kappa_bound, double w_veh,
+                              double stepsize_interp, int iters_min, double curv_error_allowed, int max_rounds,
+                              const mcq_opts* opts, double* alpha_out, int* buf_out, double* curv_err_out, int* status_out,
+                              int* rounds_out, double* curv_trace_out, mcq_iqp_stats* stats)
+{
+    if (!h || batch <= 0 || nmax <= 0 || !n_io || !reftrack_a || !normvec_a || !reftrack_b || !normvec_b || !alpha_out ||
+        !buf_out || !curv_err_out || !status_out || !rounds_out || !(stepsize_interp > 0.0) || iters_min < 1 || max_rounds < 1 ||
+        reftrack_a == reftrack_b || normvec_a == normvec_b) {
+        g_err = "mcq_iqp_device: bad argument";
+        return MCQ_E_ARG;
+    }
+    HIP_TRY(hipSetDevice(h->device));
+    mcq_opts o = resolve_opts(opts);
+    const bool warm = !(opts && opts->warm_start < 0);        // passes 2+ start from the carried working sets unless switched off
+    int rc = ensure_ws(h, (size_t)batch, (size_t)nmax);
+    if (rc) return rc;
+    rc = ensure_iqp(h, (size_t)batch);
+    if (rc) return rc;
+    const bool timed = stats && stats->timed;
+    if (timed) { rc = ensure_stage(h, (size_t)batch, (size_t)nmax); if (rc) return rc; }
+    // bookkeeping arrays: live | n of the other set | glue status | pass status | final_n (= n_io on return) ... live count
+    int* live = h->d_iqp;
+    int* n_b = live + batch;
+    int* rst = n_b + batch;
+    int* pass_status = rst + batch;
+    int* d_final_n = pass_status + batch;
+    int* live_count = d_final_n + batch;
+    double* pass_curv = h->d_iqp_curv;
+    int* n_set[2] = {n_io, n_b};
+    double* ref_set[2] = {reftrack_a, reftrack_b};
+    double* nv_set[2] = {normvec_a, normvec_b};
+    // every track with n >= 1 starts live (a track with n == 0 is skipped altogether: status MCQ_BAD_INPUT, 0 rounds)
+    {
+        std::vector<int> ones((size_t)batch, 1);
+        HIP_TRY(hipMemcpyAsync(live, ones.data(), batch * sizeof(int), hipMemcpyHostToDevice, h->stream));
+        HIP_TRY(hipMemsetAsync(rounds_out, 0, batch * sizeof(int), h->stream));
+        HIP_TRY(hipMemsetAsync(buf_out, 0, batch * sizeof(int), h->stream));
+        HIP_TRY(hipStreamSynchronize(h->stream));      // `ones` goes out of scope
+    }
+    McqIqpStep S;
+    memset(&S, 0, sizeof(S));
+    S.batch = batch;
+    S.iters_min = iters_min;
+    S.curv_allowed = curv_error_allowed;
+    S.curv = pass_curv;
+    S.status = pass_status;
+    S.relin_status = rst;
+    S.live = live;
+    S.final_buf = buf_out;
+    S.final_curv = curv_err_out;
+    S.final_status = status_out;
+    S.final_rounds = rounds_out;
+    S.live_count = live_count;
+    S.curv_trace = curv_trace_out;
+    if (curv_trace_out) HIP_TRY(hipMemsetAsync(curv_trace_out, 0, (size_t)batch * MCQ_IQP_TRACE * sizeof(double), h->stream));
+    const dim3 sgrid((unsigned)((batch + 255) / 256)), sblock(256);
+    int cur = 0, rounds = 0, n_live = batch;
+    long long solves = 0;
+    if (stats) { stats->rounds = 0; stats->qp_solves = 0; for (int k = 0; k < 16; ++k) { stats->solver_ms[k] = 0.f; stats->fallbacks[k] = 0; } }
+    // the final ring sizes are collected in a scratch array and moved to n_io at the end (n_io doubles as set 0's sizes)
+    HIP_TRY(hipMemsetAsync(d_final_n, 0, batch * sizeof(int), h->stream));
+    S.final_n = d_final_n;
+    int err = 0;
+    for (int it = 1; it <= max_rounds && n_live > 0 && !err; ++it) {
+        rounds = it;
+        McqBatch B;
+        memset(&B, 0, sizeof(B));
+        B.batch = batch;
+        B.n = nmax;
+        B.nmax = nmax;
+        B.n_list = n_set[cur];
+        B.ref = ref_set[cur];
+        B.nv = nv_set[cur];
+        B.sc = it == 1 ? scaling : nullptr;                 // the re-spline of passes 2+ uses unit scalings (upstream)
+        B.alpha = alpha_out;
+        B.curv_err = pass_curv;
+        B.status = pass_status;
+        B.info = timed ? h->d_info : nullptr;
+        B.kappa_bound = kappa_bound;
+        B.w_veh = w_veh;
+        o.warm_start = (warm && it > 1) ? 1 : 0;
+        if ((err = launch(h, B, o)) != 0) break;
+        solves += n_live;
+        if (timed && it <= 16) {
+            float ms[5];
+            if (mcq_last_timing(h, ms) == 0) stats->solver_ms[it - 1] = ms[4];
+            std::vector<mcq_info> info((size_t)batch);
+            std::vector<int> lv((size_t)batch);
+            if (hipMemcpyAsync(info.data(), h->d_info, batch * sizeof(mcq_info), hipMemcpyDeviceToHost, h->stream) == hipSuccess &&
+                hipMemcpyAsync(lv.data(), live, batch * sizeof(int), hipMemcpyDeviceToHost, h->stream) == hipSuccess &&
+                hipStreamSynchronize(h->stream) == hipSuccess) {
+                int fb = 0;
+                for (int k = 0; k < batch; ++k) if (lv[k] && (info[k].second_attempt & 2)) ++fb;
+                stats->fallbacks[it - 1] = fb;
+            }
+        }
+        if (hipMemsetAsync(live_count, 0, sizeof(int), h->stream) != hipSuccess) { err = MCQ_E_DEVICE; break; }
+        S.phase = 0;
+        S.round = it;
+        S.cur = cur;
+        S.n_ring = n_set[cur];
+        S.n_next = n_set[1 - cur];
+        hipLaunchKernelGGL(mcq_iqp_step_kernel, sgrid, sblock, 0, h->stream, S);
+        const double scale = it < iters_min ? (double)it / (double)iters_min : 1.0;
+        if ((err = mcq_relinearise_device(h, batch, nmax, n_set[cur], ref_set[cur], nv_set[cur], alpha_out, live, scale,
+                                          stepsize_interp, ref_set[1 - cur], nv_set[1 - cur], n_set[1 - cur], rst)) != 0) break;
+        S.phase = 1;
+        hipLaunchKernelGGL(mcq_iqp_step_kernel, sgrid, sblock, 0, h->stream, S);
+        if (hipGetLastError() != hipSuccess) { err = MCQ_E_DEVICE; break; }
+        cur = 1 - cur;
+        // the first iters_min - 1 rounds cannot end a healthy track: no need to look
+        if (it >= iters_min || it == max_rounds) {
+            if (hipMemcpyAsync(&n_live, live_count, sizeof(int), hipMemcpyDeviceToHost, h->stream) != hipSuccess ||
+                hipStreamSynchronize(h->stream) != hipSuccess) { err = MCQ_E_DEVICE; break; }
+        }
+    }
+    if (!err && hipMemcpyAsync(n_io, d_final_n, batch * sizeof(int), hipMemcpyDeviceToDevice, h->stream) != hipSuccess) err = MCQ_E_DEVICE;
+    if (hipStreamSynchronize(h->stream) != hipSuccess && !err) err = MCQ_E_DEVICE;
+    h->state2_valid = false;        // the working sets belong to this run's last glue call, not to a later solve
+    if (err) { if (err == MCQ_E_DEVICE && g_err.empty()) g_err = "mcq_iqp_device: HIP runtime error"; return err; }
+    if (stats) { stats->rounds = rounds; stats->qp_solves = (int)solves; }
+    if (n_live > 0) {
+        // tracks still iterating at max_rounds: report them (status MCQ_ITER_CAP), keep their last state
+        std::vector<int> lv((size_t)batch), stv((size_t)batch);
+        HIP_TRY(hipMemcpy(lv.data(), live, batch * sizeof(int), hipMemcpyDeviceToHost));
+        HIP_TRY(hipMemcpy(stv.data(), status_out, batch * sizeof(int), hipMemcpyDeviceToHost));
+        for (int k = 0; k < batch; ++k) if (lv[k] && stv[k] == MCQ_OK) stv[k] = MCQ_ITER_CAP;
+        HIP_TRY(hipMemcpy(status_out, stv.data(), batch * sizeof(int), hipMemcpyHostToDevice));
+    }
+    return 0;
+}
+
+// Packs the per-problem host buffers into the handle's pinned staging ([batch][nmax][*], zero padded) and queues the uploads.
+// Layout of the pinned block: ref | nv | sc | kb | wv | n   (then, for the results: alpha | info).
+struct PinLayout {
+    double *ref, *nv, *sc, *kb, *wv, *alpha;
+    int* n;
+    mcq_info* info;
+};
+
+static int pack_and_upload(mcq_handle* h, const mcq_problem* probs, int batch, size_t nmax, bool any_sc, bool with_nv,
+                           size_t extra_bytes, PinLayout& P, const char* who)
+{
+    const size_t elems = (size_t)batch * nmax;
+    const size_t bytes = elems * (4 + 2 + 1 + 1) * sizeof(double) + (size_t)batch * (2 * sizeof(double) + sizeof(int) + sizeof(mcq_info)) + 64 + extra_bytes;
+    int rc = ensure_pin(h, bytes);
+    if (rc) return rc;
+    char* base = (char*)h->pin;
+    P.ref = (double*)base;
+    P.nv = P.ref + elems * 4;
+    P.sc = P.nv + elems * 2;
+    P.alpha = P.sc + elems;
+    P.kb = P.alpha + elems;
+    P.wv = P.kb + batch;
+    P.info = (mcq_info*)(P.wv + batch);
+    P.n = (int*)(P.info + batch);
+    memset(P.ref, 0, elems * 4 * sizeof(double));
+    if (with_nv) memset(P.nv, 0, elems * 2 * sizeof(double));
+    if (any_sc) for (size_t q = 0; q < elems; ++q) P.sc[q] = 1.0;
+    for (int b = 0; b < batch; ++b) {
+        const size_t n = (size_t)probs[b].n;
+        memcpy(P.ref + (size_t)b * nmax * 4, probs[b].reftrack, n * 4 * sizeof(double));
+        if (with_nv) memcpy(P.nv + (size_t)b * nmax * 2, probs[b].normvec, n * 2 * sizeof(double));
+        if (any_sc && probs[b].scaling) memcpy(P.sc + (size_t)b * nmax, probs[b].scaling, n * sizeof(double));
+        P.kb[b] = probs[b].kappa_bound;
+        P.wv[b] = probs[b].w_veh;
+        P.n[b] = probs[b].n;
+    }
+    (void)who;
+    HIP_TRY_SYNC(hipMemcpyAsync(h->d_ref, P.ref, elems * 4 * sizeof(double), hipMemcpyHostToDevice, h->stream));
+    if (with_nv) HIP_TRY_SYNC(hipMemcpyAsync(h->d_nv, P.nv, elems * 2 * sizeof(double), hipMemcpyHostToDevice, h->stream));
+    if (any_sc) HIP_TRY_SYNC(hipMemcpyAsync(h->d_sc, P.sc, elems * sizeof(double), hipMemcpyHostToDevice, h->stream));
+    HIP_TRY_SYNC(hipMemcpyAsync(h->d_kb, P.kb, batch * sizeof(double), hipMemcpyHostToDevice, h->stream));
+    HIP_TRY_SYNC(hipMemcpyAsync(h->d_wv, P.wv, batch * sizeof(double), hipMemcpyHostToDevice, h->stream));
+    HIP_TRY_SYNC(hipMemcpyAsync(h->d_n, P.n, batch * sizeof(int), hipMemcpyHostToDevice, h->stream));
+    return 0;
+}
+
 extern "C" int mcq_solve_batch(mcq_handle* h, const mcq_problem* probs, int batch, const mcq_opts* opts,
                                double* alpha_out, double* curv_err_out, int* status_out, mcq_info* info_out)
 {
@@ -610,28 +913,9 @@ extern "C" int mcq_solve_batch(mcq_handle* h, const mcq_problem* probs, int batc
     if (rc) return rc;
     rc = ensure_stage(h, (size_t)batch, nmax);
     if (rc) return rc;
-
-    // pack [batch][nmax][*]
-    std::vector<double> ref((size_t)batch * nmax * 4, 0.0), nv((size_t)batch * nmax * 2, 0.0), sc;
-    std::vector<double> kb(batch), wv(batch);
-    std::vector<int> nl(batch);
-    if (any_sc) sc.assign((size_t)batch * nmax, 1.0);
-    for (int b = 0; b < batch; ++b) {
-        const size_t n = (size_t)probs[b].n;
-        memcpy(&ref[(size_t)b * nmax * 4], probs[b].reftrack, n * 4 * sizeof(double));
-        if (probs[b].normvec) memcpy(&nv[(size_t)b * nmax * 2], probs[b].normvec, n * 2 * sizeof(double));
-        if (any_sc && probs[b].scaling) memcpy(&sc[(size_t)b * nmax], probs[b].scaling, n * sizeof(double));
-        kb[b] = probs[b].kappa_bound;
-        wv[b] = probs[b].w_veh;
-        nl[b] = probs[b].n;
-    }
-    HIP_TRY(hipMemcpyAsync(h->d_ref, ref.data(), ref.size() * sizeof(double), hipMemcpyHostToDevice, h->stream));
-    HIP_TRY(hipMemcpyAsync(h->d_nv, nv.data(), nv.size() * sizeof(double), hipMemcpyHostToDevice, h->stream));
-    if (any_sc)
-        HIP_TRY(hipMemcpyAsync(h->d_sc, sc.data(), sc.size() * sizeof(double), hipMemcpyHostToDevice, h->stream));
-    HIP_TRY(hipMemcpyAsync(h->d_kb, kb.data(), batch * sizeof(double), hipMemcpyHostToDevice, h->stream));
-    HIP_TRY(hipMemcpyAsync(h->d_wv, wv.data(), batch * sizeof(double), hipMemcpyHostToDevice, h->stream));
-    HIP_TRY(hipMemcpyAsync(h->d_n, nl.data(), batch * sizeof(int), hipMemcpyHostToDevice, h->stream));
+    PinLayout P;
+    rc = pack_and_upload(h, probs, batch, nmax, any_sc, probs[0].normvec != nullptr, 0, P, "mcq_solve_batch");
+    if (rc) return rc;
 
     McqBatch B;
     memset(&B, 0, sizeof(B));
@@ -649,21 +933,110 @@ extern "C" int mcq_solve_batch(mcq_handle* h, const mcq_problem* probs, int batc
     B.kappa_bound_list = h->d_kb;
     B.w_veh_list = h->d_wv;
     rc = launch(h, B, o);
-    if (rc) return rc;
+    if (rc) { (void)hipStreamSynchronize(h->stream); return rc; }
 
-    std::vector<double> alpha((size_t)batch * nmax);
-    std::vector<mcq_info> info(batch);
-    HIP_TRY(hipMemcpyAsync(alpha.data(), h->d_alpha, alpha.size() * sizeof(double), hipMemcpyDeviceToHost, h->stream));
-    HIP_TRY(hipMemcpyAsync(curv_err_out, h->d_curv, batch * sizeof(double), hipMemcpyDeviceToHost, h->stream));
-    HIP_TRY(hipMemcpyAsync(status_out, h->d_status, batch * sizeof(int), hipMemcpyDeviceToHost, h->stream));
-    HIP_TRY(hipMemcpyAsync(info.data(), h->d_info, batch * sizeof(mcq_info), hipMemcpyDeviceToHost, h->stream));
+    HIP_TRY_SYNC(hipMemcpyAsync(P.alpha, h->d_alpha, (size_t)batch * nmax * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+    HIP_TRY_SYNC(hipMemcpyAsync(curv_err_out, h->d_curv, batch * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+    HIP_TRY_SYNC(hipMemcpyAsync(status_out, h->d_status, batch * sizeof(int), hipMemcpyDeviceToHost, h->stream));
+    HIP_TRY_SYNC(hipMemcpyAsync(P.info, h->d_info, batch * sizeof(mcq_info), hipMemcpyDeviceToHost, h->stream));
     HIP_TRY(hipStreamSynchronize(h->stream));
     size_t off = 0;
     for (int b = 0; b < batch; ++b) {
         const size_t n = (size_t)probs[b].n;
-        memcpy(alpha_out + off, &alpha[(size_t)b * nmax], n * sizeof(double));
+        memcpy(alpha_out + off, P.alpha + (size_t)b * nmax, n * sizeof(double));
         off += n;
-        if (info_out) info_out[b] = info[b];
+        if (info_out) info_out[b] = P.info[b];
+    }
+    return 0;
+}
+
+extern "C" int mcq_iqp_batch(mcq_handle* h, const mcq_problem* probs, int batch, double stepsize_interp, int iters_min,
+                             double curv_error_allowed, int max_rounds, const mcq_opts* opts, int nmax_out, double* alpha_out,
+                             double* reftrack_out, double* normvec_out, int* n_out, double* curv_err_out, int* status_out,
+                             int* rounds_out, double* curv_trace_out, mcq_iqp_stats* stats)
+{
+    if (!h || !probs || batch <= 0 || nmax_out < 3 || !alpha_out || !reftrack_out || !normvec_out || !n_out || !curv_err_out ||
+        !status_out || !rounds_out) {
+        g_err = "mcq_iqp_batch: bad argument";
+        return MCQ_E_ARG;
+    }
+    HIP_TRY(hipSetDevice(h->device));
+    const size_t nmax = (size_t)nmax_out;
+    bool any_sc = false;
+    for (int b = 0; b < batch; ++b) {
+        if (!probs[b].reftrack || !probs[b].normvec || probs[b].n < 0) { g_err = "mcq_iqp_batch: reftrack and normvec are required"; return MCQ_E_ARG; }
+        if ((size_t)probs[b].n > nmax) { g_err = "mcq_iqp_batch: a track has more waypoints than nmax_out"; return MCQ_E_TOO_LARGE; }
+        if (probs[b].kappa_bound != probs[0].kappa_bound || probs[b].w_veh != probs[0].w_veh) {
+            g_err = "mcq_iqp_batch: one kappa_bound / w_veh per call";
+            return MCQ_E_ARG;
+        }
+        if (probs[b].scaling) any_sc = true;
+    }
+    int rc = ensure_ws(h, (size_t)batch, nmax);
+    if (rc) return rc;
+    rc = ensure_stage(h, (size_t)batch, nmax);
+    if (rc) return rc;
+    const size_t elems = (size_t)batch * nmax;
+    if (elems > h->stage2_elems) {
+        HIP_TRY(hipStreamSynchronize(h->stream));
+        (void)hipFree(h->d_ref2); (void)hipFree(h->d_nv2);
+        h->d_ref2 = h->d_nv2 = nullptr; h->stage2_elems = 0;
+        HIP_TRY(hipMalloc((void**)&h->d_ref2, elems * 4 * sizeof(double)));
+        HIP_TRY(hipMalloc((void**)&h->d_nv2, elems * 2 * sizeof(double)));
+        h->stage2_elems = elems;
+    }
+    PinLayout P;
+    // results need room for both buffer sets' ref / nv in the worst case: one extra set
+    rc = pack_and_upload(h, probs, batch, nmax, any_sc, true, elems * 6 * sizeof(double) + (size_t)batch * 3 * sizeof(int), P, "mcq_iqp_batch");
+    if (rc) return rc;
+    double* d_trace = nullptr;
+    if (curv_trace_out) HIP_TRY(hipMalloc((void**)&d_trace, (size_t)batch * MCQ_IQP_TRACE * sizeof(double)));
+    // d_kb / d_wv staging doubles as the per-track outputs of the loop: curvature error (double), buffer index / rounds (ints)
+    int* d_buf = (int*)h->d_kb;                 // batch doubles >= 2 * batch ints
+    int* d_rounds = d_buf + batch;
+    rc = mcq_iqp_device(h, batch, (int)nmax, h->d_n, h->d_ref, h->d_nv, h->d_ref2, h->d_nv2, any_sc ? h->d_sc : nullptr,
+                        probs[0].kappa_bound, probs[0].w_veh, stepsize_interp, iters_min, curv_error_allowed, max_rounds, opts,
+                        h->d_alpha, d_buf, h->d_curv, h->d_status, d_rounds, d_trace, stats);
+    if (!rc && d_trace && hipMemcpy(curv_trace_out, d_trace, (size_t)batch * MCQ_IQP_TRACE * sizeof(double), hipMemcpyDeviceToHost) != hipSuccess) {
+        g_err = "mcq_iqp_batch: read-back of the curvature-error trace failed";
+        rc = MCQ_E_DEVICE;
+    }
+    (void)hipFree(d_trace);
+    if (rc) return rc;
+    int* buf_h = P.n;                            // the pinned int block: n | (extra) buf, rounds
+    HIP_TRY_SYNC(hipMemcpyAsync(n_out, h->d_n, batch * sizeof(int), hipMemcpyDeviceToHost, h->stream));
+    HIP_TRY_SYNC(hipMemcpyAsync(buf_h, d_buf, batch * sizeof(int), hipMemcpyDeviceToHost, h->stream));
+    HIP_TRY_SYNC(hipMemcpyAsync(rounds_out, d_rounds, batch * sizeof(int), hipMemcpyDeviceToHost, h->stream));
+    HIP_TRY_SYNC(hipMemcpyAsync(curv_err_out, h->d_curv, batch * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+    HIP_TRY_SYNC(hipMemcpyAsync(status_out, h->d_status, batch * sizeof(int), hipMemcpyDeviceToHost, h->stream));
+    HIP_TRY_SYNC(hipMemcpyAsync(P.alpha, h->d_alpha, elems * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+    HIP_TRY(hipStreamSynchronize(h->stream));
+    bool use[2] = {false, false};
+    for (int b = 0; b < batch; ++b) use[buf_h[b] ? 1 : 0] = true;
+    // final reftrack / normvectors: set 0 lands in the (now free) input staging, set 1 in the extra block behind it
+    double* ref_h[2] = {P.ref, (double*)(P.n + batch + 16)};
+    double* nv_h[2] = {P.nv, ref_h[1] + elems * 4};
+    {
+        // keep the extra block 8-byte aligned
+        size_t addr = (size_t)ref_h[1];
+        addr = (addr + 7) & ~(size_t)7;
+        ref_h[1] = (double*)addr;
+        nv_h[1] = ref_h[1] + elems * 4;
+    }
+    const double* d_ref_set[2] = {h->d_ref, h->d_ref2};
+    const double* d_nv_set[2] = {h->d_nv, h->d_nv2};
+    for (int q = 0; q < 2; ++q) {
+        if (!use[q]) continue;
+        HIP_TRY_SYNC(hipMemcpyAsync(ref_h[q], d_ref_set[q], elems * 4 * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+        HIP_TRY_SYNC(hipMemcpyAsync(nv_h[q], d_nv_set[q], elems * 2 * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+    }
+    HIP_TRY(hipStreamSynchronize(h->stream));
+    for (int b = 0; b < batch; ++b) {
+        const int q = buf_h[b] ? 1 : 0;
+        const size_t n = n_out[b] > 0 ? (size_t)n_out[b] : 0;
+        memcpy(alpha_out + (size_t)b * nmax, P.alpha + (size_t)b * nmax, nmax * sizeof(double));
+        memcpy(reftrack_out + (size_t)b * nmax * 4, ref_h[q] + (size_t)b * nmax * 4, n * 4 * sizeof(double));
+        memcpy(normvec_out + (size_t)b * nmax * 2, nv_h[q] + (size_t)b * nmax * 2, n * 2 * sizeof(double));
     }
     return 0;
 }

@@ -167,6 +167,26 @@ struct McqRelin {
 };
 __global__ void mcq_relinearise_kernel(McqRelin R);
 
+/* ---- the bookkeeping of tph.iqp_handler between the QP pass and the glue, on the device (one thread per track):
+ *      phase 0 (after the QP pass of round `round`): record the state of every live track (it is the final one if the track
+ *              stops here), stop it if its QP failed or if round >= iters_min and curv_error_max <= curv_allowed;
+ *      phase 1 (after the glue): a live track whose re-sampled ring did not fit stops with MCQ_BAD_INPUT; tracks that stopped get
+ *              n_next = 0 (the next QP pass skips them).  live_count [1] = tracks still iterating (zeroed before phase 0). ---- */
+struct McqIqpStep {
+    int batch, phase, round, iters_min, cur;
+    double curv_allowed;
+    const double* curv;         // [batch] curvature error of the pass just solved
+    const int* status;          // [batch] its status
+    const int* relin_status;    // [batch] status of the glue (phase 1)
+    int* live;                  // [batch]
+    const int* n_ring;          // [batch] ring sizes solved in this round
+    int* n_next;                // [batch] ring sizes of the next round (phase 1: zeroed for stopped tracks)
+    int* final_n; int* final_buf; double* final_curv; int* final_status; int* final_rounds;
+    double* curv_trace;         // [batch][MCQ_IQP_TRACE] or nullptr
+    int* live_count;
+};
+__global__ void mcq_iqp_step_kernel(McqIqpStep S);
+
 /* ---- raceline at the output resolution + heading / curvature (what main_globaltraj.py runs between the QP and the velocity
  *      profile [REF main_globaltraj.py:371-387]: tph.create_raceline + tph.calc_head_curv_an).  One workgroup per track. ---- */
 struct McqRace {

@@ -2841,6 +2841,8 @@ __global__ void __launch_bounds__(MCQ_NT) mcq_solve_kernel(McqBatch B)
         for (int i = tid; i < n; i += MCQ_NT) k2 = fmax(k2, fabs(T0[i]));
         km = block_reduce_(k2, 2, red);
         if (status == MCQ_OK && km > kbound * (1.0 + 1e-8)) status = MCQ_KAPPA_ACTIVE;
+    } else if (status == MCQ_OK && !B.check_kappa && !c.direct && km > kbound * (1.0 + 1e-9)) {
+        status = MCQ_KAPPA_ACTIVE;      // curvature rows switched off by the caller: the violated row is reported, not enforced
     }
 
     // ---- outputs: alpha, opt_min_curv's curvature-error post-check ------------------------------------
@@ -3106,6 +3108,34 @@ __global__ void __launch_bounds__(MCQ_NT) mcq_relinearise_kernel(McqRelin R)
         nvo[2 * j + 1] = -bx / nrm;
     }
     if (tid == 0) { *status = MCQ_OK; *n_out = m; }
+}
+
+// ---- iqp_handler's bookkeeping between the passes (see McqIqpStep) -------------------------------------------------------------------
+__global__ void __launch_bounds__(256) mcq_iqp_step_kernel(McqIqpStep S)
+{
+    const int k = blockIdx.x * 256 + threadIdx.x;
+    if (k >= S.batch) return;
+    if (S.phase == 0) {
+        if (S.live[k] == 0) return;
+        const int st = S.status[k];
+        const double ce = S.curv[k];
+        S.final_n[k] = S.n_ring[k];
+        S.final_buf[k] = S.cur;
+        S.final_curv[k] = ce;
+        S.final_status[k] = st;
+        S.final_rounds[k] = S.round;
+        if (S.curv_trace && S.round <= MCQ_IQP_TRACE) S.curv_trace[(size_t)k * MCQ_IQP_TRACE + S.round - 1] = ce;
+        const bool stop = st != MCQ_OK || (S.round >= S.iters_min && ce <= S.curv_allowed);
+        if (stop) S.live[k] = 0;
+        else atomicAdd(S.live_count, 1);
+    } else {
+        if (S.live[k] != 0 && S.relin_status[k] != MCQ_OK) {      // the re-sampled ring does not fit the buffers
+            S.live[k] = 0;
+            S.final_status[k] = MCQ_BAD_INPUT;
+            atomicAdd(S.live_count, -1);
+        }
+        if (S.live[k] == 0) S.n_next[k] = 0;
+    }
 }
 
 // =====================================================================================================================

@@ -44,7 +44,15 @@ class McqInfo(ctypes.Structure):
                 ("ticks", ctypes.c_longlong * 8), ("refine_rounds", ctypes.c_int), ("second_attempt", ctypes.c_int)]
 
 
-EXPORTED_SYMBOLS = ("mcq_create", "mcq_destroy", "mcq_last_error", "mcq_default_opts", "mcq_solve_batch",
+class McqIqpStats(ctypes.Structure):
+    _fields_ = [("rounds", ctypes.c_int), ("qp_solves", ctypes.c_int), ("solver_ms", ctypes.c_float * 16),
+                ("fallbacks", ctypes.c_int * 16), ("timed", ctypes.c_int)]
+
+
+IQP_TRACE = 16      # MCQ_IQP_TRACE
+
+EXPORTED_SYMBOLS = ("mcq_create", "mcq_destroy", "mcq_last_error", "mcq_default_opts", "mcq_solve_batch", "mcq_solve_host",
+                    "mcq_iqp_device", "mcq_iqp_batch", "mcq_host_alloc", "mcq_host_free",
                     "mcq_solve_device", "mcq_solve_device_f32", "mcq_solve_device_ragged", "mcq_solve_device_ragged_params", "mcq_prep_device", "mcq_relinearise_device",
                     "mcq_vel_profile_device", "mcq_vel_profile_device_ragged", "mcq_raceline_device", "mcq_normals_crossing_device",
                     "mcq_device_alloc",
@@ -78,6 +86,20 @@ def load_library(path=None):
     lib.mcq_solve_device.argtypes = [vp, ctypes.c_int, ctypes.c_int, vp, vp, vp, ctypes.c_double, ctypes.c_double,
                                      ctypes.POINTER(McqOpts), vp, vp, vp, vp]
     lib.mcq_solve_device.restype = ctypes.c_int
+    lib.mcq_solve_host.argtypes = lib.mcq_solve_device.argtypes
+    lib.mcq_solve_host.restype = ctypes.c_int
+    lib.mcq_iqp_device.argtypes = [vp, ctypes.c_int, ctypes.c_int, vp, vp, vp, vp, vp, vp, ctypes.c_double, ctypes.c_double,
+                                   ctypes.c_double, ctypes.c_int, ctypes.c_double, ctypes.c_int, ctypes.POINTER(McqOpts), vp, vp, vp,
+                                   vp, vp, vp, ctypes.POINTER(McqIqpStats)]
+    lib.mcq_iqp_device.restype = ctypes.c_int
+    lib.mcq_iqp_batch.argtypes = [vp, ctypes.POINTER(McqProblem), ctypes.c_int, ctypes.c_double, ctypes.c_int, ctypes.c_double,
+                                  ctypes.c_int, ctypes.POINTER(McqOpts), ctypes.c_int, _dp, _dp, _dp, _ip, _dp, _ip, _ip, _dp,
+                                  ctypes.POINTER(McqIqpStats)]
+    lib.mcq_iqp_batch.restype = ctypes.c_int
+    lib.mcq_host_alloc.argtypes = [vp, ctypes.c_size_t, ctypes.POINTER(vp)]
+    lib.mcq_host_alloc.restype = ctypes.c_int
+    lib.mcq_host_free.argtypes = [vp, vp]
+    lib.mcq_host_free.restype = ctypes.c_int
     lib.mcq_solve_device_f32.argtypes = lib.mcq_solve_device.argtypes
     lib.mcq_solve_device_f32.restype = ctypes.c_int
     lib.mcq_solve_device_ragged.argtypes = [vp, ctypes.c_int, ctypes.c_int, vp, vp, vp, vp, ctypes.c_double,
@@ -139,6 +161,9 @@ class Engine:
 
     def close(self):
         if getattr(self, "h", None):
+            for p in getattr(self, "_pinned", []):
+                self.lib.mcq_host_free(self.h, p)
+            self._pinned = []
             self.lib.mcq_destroy(self.h)
             self.h = None
 
@@ -222,6 +247,88 @@ class Engine:
                                            float(kappa_bound), float(w_veh), ctypes.byref(opts), d_alpha, d_curv, d_status,
                                            d_info or None)
         self._check(rc, "mcq_solve_device_f32")
+
+    def solve_host(self, reftrack, normvec, scaling, kappa_bound, w_veh, alpha_out=None, **opt_kw):
+        """Uniform batch from / to host arrays in one call (mcq_solve_host): reftrack [B, n, 4], normvec [B, n, 2] or None,
+        scaling [B, n] or None -- float64, C-contiguous, ideally views of pinned memory (host_array).  Returns (alpha [B, n],
+        curv_err [B], status [B], info as a structured array of McqInfo)."""
+        ref = np.ascontiguousarray(reftrack, dtype=np.float64)
+        bsz, n = ref.shape[0], ref.shape[1]
+        nv = None if normvec is None else np.ascontiguousarray(normvec, dtype=np.float64)
+        sc = None if scaling is None else np.ascontiguousarray(scaling, dtype=np.float64)
+        alpha = np.empty((bsz, n)) if alpha_out is None else alpha_out
+        curv = np.empty(bsz)
+        status = np.empty(bsz, dtype=np.int32)
+        info = (McqInfo * bsz)()
+        opts = self._opts(**opt_kw)
+        rc = self.lib.mcq_solve_host(self.h, bsz, n, ref.ctypes.data, nv.ctypes.data if nv is not None else None,
+                                     sc.ctypes.data if sc is not None else None, float(kappa_bound), float(w_veh),
+                                     ctypes.byref(opts), alpha.ctypes.data, curv.ctypes.data, status.ctypes.data,
+                                     ctypes.addressof(info))
+        self._check(rc, "mcq_solve_host")
+        return alpha, curv, status, info
+
+    def host_array(self, shape, dtype=np.float64):
+        """numpy array backed by pinned host memory of the engine (mcq_host_alloc); freed with the engine (or host_free)."""
+        nbytes = int(np.prod(shape)) * np.dtype(dtype).itemsize
+        p = ctypes.c_void_p()
+        self._check(self.lib.mcq_host_alloc(self.h, max(nbytes, 1), ctypes.byref(p)), "mcq_host_alloc")
+        self._pinned = getattr(self, "_pinned", [])
+        self._pinned.append(p.value)
+        buf = (ctypes.c_char * max(nbytes, 1)).from_address(p.value)
+        return np.frombuffer(buf, dtype=dtype, count=int(np.prod(shape))).reshape(shape)
+
+    def iqp_batch(self, tracks, kappa_bound, w_veh, stepsize_interp, iters_min=3, curv_error_allowed=0.01, max_rounds=50,
+                  nmax=None, timed=False, **opt_kw):
+        """tph.iqp_handler for a batch of tracks as ONE engine call (mcq_iqp_batch): tracks = list of dicts {reftrack [N,4],
+        normvectors [N,2], scaling [N] or None}.  Returns a dict: alpha / reftrack / normvectors (lists of the final arrays),
+        n, curv_err, status, rounds (arrays [B]), curv_trace [B, IQP_TRACE], stats (rounds, qp_solves, and with timed=True
+        solver_ms / fallbacks per round)."""
+        bsz = len(tracks)
+        refs = [np.ascontiguousarray(t["reftrack"], dtype=np.float64) for t in tracks]
+        nvs = [np.ascontiguousarray(t["normvectors"], dtype=np.float64) for t in tracks]
+        scs = [None if t.get("scaling") is None else np.ascontiguousarray(t["scaling"], dtype=np.float64) for t in tracks]
+        if nmax is None:
+            # capacity for the re-sampled rings: the raceline is never much longer than the polygon through the reference
+            # points; 30 % + 16 points of headroom (a ring that outgrows it is reported per track, not truncated)
+            nmax = 0
+            for r in refs:
+                length = float(np.hypot(np.diff(r[:, 0], append=r[0, 0]), np.diff(r[:, 1], append=r[0, 1])).sum())
+                nmax = max(nmax, r.shape[0], int(np.ceil(1.3 * length / stepsize_interp)) + 16)
+        arr = (McqProblem * bsz)()
+        for k in range(bsz):
+            n = refs[k].shape[0]
+            if refs[k].ndim != 2 or refs[k].shape[1] != 4 or nvs[k].shape != (n, 2) or (scs[k] is not None and scs[k].shape != (n,)):
+                raise ValueError("reftrack must be [n,4], normvectors [n,2], scaling [n]")
+            arr[k].n = n
+            arr[k].reftrack = _as_dp(refs[k])
+            arr[k].normvec = _as_dp(nvs[k])
+            arr[k].scaling = _as_dp(scs[k]) if scs[k] is not None else None
+            arr[k].kappa_bound = float(kappa_bound)
+            arr[k].w_veh = float(w_veh)
+        alpha = np.zeros((bsz, nmax))
+        ref_o = np.zeros((bsz, nmax, 4))
+        nv_o = np.zeros((bsz, nmax, 2))
+        n_o = np.zeros(bsz, dtype=np.int32)
+        curv = np.zeros(bsz)
+        status = np.zeros(bsz, dtype=np.int32)
+        rounds = np.zeros(bsz, dtype=np.int32)
+        trace = np.zeros((bsz, IQP_TRACE))
+        st = McqIqpStats()
+        st.timed = 1 if timed else 0
+        opts = self._opts(**opt_kw)
+        rc = self.lib.mcq_iqp_batch(self.h, arr, bsz, float(stepsize_interp), int(iters_min), float(curv_error_allowed),
+                                    int(max_rounds), ctypes.byref(opts), int(nmax), _as_dp(alpha), _as_dp(ref_o), _as_dp(nv_o),
+                                    n_o.ctypes.data_as(_ip), _as_dp(curv), status.ctypes.data_as(_ip),
+                                    rounds.ctypes.data_as(_ip), _as_dp(trace), ctypes.byref(st))
+        self._check(rc, "mcq_iqp_batch")
+        stats = dict(rounds=int(st.rounds), qp_solves=int(st.qp_solves), nmax=int(nmax))
+        if timed:
+            stats["solver_ms"] = [float(st.solver_ms[k]) for k in range(min(st.rounds, 16))]
+            stats["fallbacks"] = [int(st.fallbacks[k]) for k in range(min(st.rounds, 16))]
+        return dict(alpha=[alpha[k, :n_o[k]] for k in range(bsz)], reftrack=[ref_o[k, :n_o[k]] for k in range(bsz)],
+                    normvectors=[nv_o[k, :n_o[k]] for k in range(bsz)], n=n_o, curv_err=curv, status=status, rounds=rounds,
+                    curv_trace=trace, stats=stats)
 
     def solve_uniform_f32(self, reftrack, normvec, scaling, kappa_bound, w_veh, **opt_kw):
         """Host convenience around solve_device_f32 for a uniform-n batch: reftrack [B,n,4] (cast to float32), normvec

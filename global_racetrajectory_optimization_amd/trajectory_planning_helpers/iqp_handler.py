@@ -2,9 +2,10 @@
 Drop-in for tph.iqp_handler.iqp_handler -- boundary [REF main_globaltraj.py:273-284].
 
 Iterated re-linearisation: each pass is one minimum-curvature QP on the MI355X engine,
-followed by the raceline re-sampling glue (create_raceline / interp_track_widths / re-spline) on the host.  N changes
-from pass to pass, so a batch of IQP runs is driven in lock-step rounds with ragged N (iqp_handler_batch): every
-round is ONE batched engine launch over the tracks that have not terminated yet.
+followed by the raceline re-sampling glue (create_raceline / interp_track_widths / re-spline).  N changes from pass to pass,
+so a batch of IQP runs is driven in lock-step rounds with ragged N: every round is ONE batched QP launch over the tracks that
+have not terminated yet.  The default is the engine's own loop (mcq_iqp_batch: glue, termination test and damping on the
+device, the host reads one int per round); the host-glue driver below is the upstream chain written out, kept as its check.
 """
 import time
 
@@ -38,129 +39,41 @@ def _relinearise(reftrack_tmp, normvec_tmp, alpha, stepsize_interp):
 
 def _iqp_batch_device(eng, tracks, kappa_bound, w_veh, stepsize_interp, iters_min, curv_error_allowed, print_debug,
                       max_rounds, stats, warm_start=True):
-    """The lock-step IQP rounds with everything but a few scalars per track resident in HBM: the QP pass is
-    mcq_solve_device_ragged, the glue between passes mcq_relinearise_device.  Per round the host
-    reads back curv_error / status / N per track and, for the tracks that finish, their final alpha / reftrack /
-    normals.  Device memory through the engine's own C ABI (no second HIP runtime in the process)."""
+    """The whole batch of IQP runs as ONE engine call (mcq_iqp_batch): QP passes, termination test, damping and the glue
+    between the passes all run on the device; the host packs the tracks, waits, and unpacks the
+    end states.  The per-round curvature errors come back as a trace, for the print_debug lines upstream prints per round."""
     t_start = time.perf_counter()
-    t_down = 0.0
-    bsz = len(tracks)
-    refs = [np.ascontiguousarray(t["reftrack"], dtype=np.float64) for t in tracks]
-    nvs = [np.ascontiguousarray(t["normvectors"], dtype=np.float64) for t in tracks]
-    n_host = np.array([r.shape[0] for r in refs], dtype=np.int32)
-    # capacity for the re-sampled rings: the raceline is never much longer than the polygon through the reference points;
-    # 30 % + 16 points of headroom, reported (not truncated) if it ever is not enough
-    nmax = 0
-    for r in refs:
-        length = float(np.hypot(np.diff(r[:, 0], append=r[0, 0]), np.diff(r[:, 1], append=r[0, 1])).sum())
-        nmax = max(nmax, r.shape[0], int(np.ceil(1.3 * length / stepsize_interp)) + 16)
-    ref_h = np.zeros((bsz, nmax, 4))
-    nv_h = np.zeros((bsz, nmax, 2))
-    sc_h = np.ones((bsz, nmax))
-    for k in range(bsz):
-        ref_h[k, :n_host[k]] = refs[k]
-        nv_h[k, :n_host[k]] = nvs[k]
-        if tracks[k].get("scaling") is not None:
-            sc_h[k, :n_host[k]] = tracks[k]["scaling"]
-    f8, i4 = 8, 4
-    bufs = []
-
-    def dalloc(nbytes, init=None):
-        p = eng.alloc(nbytes)
-        bufs.append(p)
-        if init is not None:
-            eng.upload(p, init)
-        return p
-
-    try:
-        d_ref = [dalloc(ref_h.nbytes, ref_h), dalloc(ref_h.nbytes)]
-        d_nv = [dalloc(nv_h.nbytes, nv_h), dalloc(nv_h.nbytes)]
-        d_sc = dalloc(sc_h.nbytes, sc_h)
-        d_alpha = dalloc(bsz * nmax * f8)
-        d_curv = dalloc(bsz * f8)
-        d_status = dalloc(bsz * i4)
-        d_n = [dalloc(bsz * i4, n_host), dalloc(bsz * i4)]
-        d_nsolve = dalloc(bsz * i4)
-        d_live = dalloc(bsz * i4)
-        d_rst = dalloc(bsz * i4)
-        live = np.ones(bsz, dtype=bool)
-        out = [None] * bsz
-        cur, n_solves, it = 0, 0, 0
-        eng.sync()
-        t_up = time.perf_counter() - t_start       # marshalling + upload of the tracks
-        while live.any():
-            it += 1
-            if it > max_rounds:
-                raise RuntimeError("iqp_handler: no convergence within %d rounds" % max_rounds)
-            # finished tracks keep their buffers but are skipped: n = 0 makes the assembly kernel flag them, the solver returns
-            eng.upload(d_nsolve, (n_host * live).astype(np.int32))
-            # passes 2+: the exchange starts from the working set of the previous pass, which the glue kernel carried over
-            eng.solve_device_ragged(bsz, nmax, d_nsolve, d_ref[cur], d_nv[cur], d_sc if it == 1 else None, kappa_bound,
-                                    w_veh, d_alpha, d_curv, d_status, warm_start=1 if (warm_start and it > 1) else 0)
-            n_solves += int(live.sum())
-            curv = eng.download(d_curv, (bsz,), np.float64)
-            status = eng.download(d_status, (bsz,), np.int32)
-            scale = it * 1.0 / iters_min if it < iters_min else 1.0
-            t_d0 = time.perf_counter()
-            done = []
-            for k in np.nonzero(live)[0]:
-                _omc.raise_for_status(int(status[k]))
-                if print_debug:
-                    print("Minimum curvature IQP: iteration %i, curv_error_max: %.4frad/m" % (it, curv[k]))
-                if it >= iters_min and curv[k] <= curv_error_allowed:
-                    if print_debug:
-                        print("Finished IQP!")
-                    done.append(int(k))
-            if len(done) > 8:
-                # many tracks finish in the same round (the usual case: identical iters_min): three bulk copies instead of
-                # three small blocking copies per track
-                al_all = eng.download(d_alpha, (bsz, nmax), np.float64)
-                ref_all = eng.download(d_ref[cur], (bsz, nmax, 4), np.float64)
-                nv_all = eng.download(d_nv[cur], (bsz, nmax, 2), np.float64)
-                for k in done:          # views into the three bulk arrays (no per-track copies)
-                    nk = int(n_host[k])
-                    out[k] = (al_all[k, :nk], ref_all[k, :nk], nv_all[k, :nk])
-            else:
-                for k in done:
-                    nk = int(n_host[k])
-                    out[k] = (eng.download(d_alpha, (nk,), np.float64, k * nmax * f8),
-                              eng.download(d_ref[cur], (nk, 4), np.float64, k * nmax * 4 * f8),
-                              eng.download(d_nv[cur], (nk, 2), np.float64, k * nmax * 2 * f8))
-            live[done] = False
-            t_down += time.perf_counter() - t_d0       # read-back of the tracks that finished in this round
-            if not live.any():
-                break
-            eng.upload(d_live, live.astype(np.int32))
-            eng.relinearise_device(bsz, nmax, d_n[cur], d_ref[cur], d_nv[cur], d_alpha, d_live, scale, stepsize_interp,
-                                   d_ref[1 - cur], d_nv[1 - cur], d_n[1 - cur], d_rst)
-            rst = eng.download(d_rst, (bsz,), np.int32)
-            n_new = eng.download(d_n[1 - cur], (bsz,), np.int32)
-            for k in np.nonzero(live)[0]:
-                if rst[k] != 0:
-                    raise RuntimeError("iqp_handler: re-sampled raceline of track %d does not fit the device buffers "
-                                       "(nmax = %d)" % (k, nmax))
-                n_host[k] = n_new[k]
-            cur = 1 - cur
-    finally:
-        for p in bufs:
-            eng.free(p)
+    out = eng.iqp_batch(tracks, kappa_bound, w_veh, stepsize_interp, iters_min, curv_error_allowed, max_rounds,
+                        timed=bool(stats is not None and stats.get("timed")), warm_start=0 if warm_start else -1)
+    for k in range(len(tracks)):
+        if print_debug:
+            for it in range(int(out["rounds"][k])):
+                if it < out["curv_trace"].shape[1]:
+                    print("Minimum curvature IQP: iteration %i, curv_error_max: %.4frad/m" % (it + 1, out["curv_trace"][k, it]))
+        if int(out["status"][k]) == _engine.STATUS_ITER_CAP and int(out["rounds"][k]) >= max_rounds:
+            raise RuntimeError("iqp_handler: no convergence within %d rounds" % max_rounds)
+        if int(out["status"][k]) == _engine.STATUS_BAD_INPUT and int(out["rounds"][k]) >= 1 and out["n"][k] >= 3:
+            raise RuntimeError("iqp_handler: re-sampled raceline of track %d does not fit the device buffers "
+                               "(nmax = %d)" % (k, out["stats"]["nmax"]))
+        _omc.raise_for_status(int(out["status"][k]))
+        if print_debug:
+            print("Finished IQP!")
     if stats is not None:
-        total = time.perf_counter() - t_start
-        stats.update(rounds=it, qp_solves=n_solves, device_resident=True, nmax=nmax, seconds_upload=t_up,
-                     seconds_download=t_down, seconds_rounds=total - t_up - t_down)
-    return out
+        stats.update(out["stats"], device_resident=True, seconds_total=time.perf_counter() - t_start)
+    return [(out["alpha"][k], out["reftrack"][k], out["normvectors"][k]) for k in range(len(tracks))]
 
 
 def iqp_handler_batch(tracks: list, kappa_bound: float, w_veh: float, stepsize_interp: float, iters_min: int = 3,
                       curv_error_allowed: float = 0.01, print_debug: bool = False, engine=None, max_rounds: int = 50,
-                      stats: dict = None, device_resident: bool = False, warm_start: bool = True) -> list:
+                      stats: dict = None, device_resident: bool = True, warm_start: bool = True) -> list:
     """tracks: list of dicts {reftrack [N,4], normvectors [N,2], scaling [N] or None}.
 
     Returns a list of (alpha, reftrack, normvectors) like iqp_handler.  `stats` (optional dict) receives
-    {'rounds', 'qp_solves'}.  device_resident=True keeps the tracks in HBM between the passes (the glue runs as a HIP
-    kernel, mcq_relinearise_device, and -- warm_start -- passes 2+ start the exchange from the previous pass's working set
-    instead of the interior point: same vertex, a fraction of the factorisations); the default runs the glue on the host
-    exactly as upstream chains it.
+    {'rounds', 'qp_solves', ...}.  device_resident=True (the default, and what the drop-in iqp_handler runs) is ONE engine
+    call: the tracks stay in HBM between the passes, the glue runs as a HIP kernel, termination and damping are decided on
+    the device and -- warm_start -- passes 2+ start the exchange from the previous pass's working set instead of the interior
+    point (same vertex, a fraction of the factorisations).  device_resident=False runs the glue on the host exactly as
+    upstream chains it, one engine launch per round (kept as the cross-check of the device chain).
     """
     eng = engine or _engine.default_engine()
     if device_resident:

@@ -46,7 +46,8 @@ enum {
     MCQ_ITER_CAP = 3,        /* iteration cap hit */
     MCQ_BAD_INPUT = 4,       /* n < 3, non-finite input */
     MCQ_KAPPA_INFEASIBLE = 5, /* curvature rows cannot be satisfied -> quadprog raises ValueError("constraints are inconsistent, no solution") */
-    MCQ_KAPPA_ACTIVE = 6      /* box-only optimum violates a curvature row and the curvature-row phase is disabled / failed */
+    MCQ_KAPPA_ACTIVE = 6      /* box-only optimum violates a curvature row and the curvature-row phase is disabled (check_kappa < 0) /
+                               * failed */
 };
 
 /* library-level error codes (negative return values) */
@@ -72,7 +73,9 @@ typedef struct {
     int max_ipm_iter;   /* 0 => default 60 */
     int max_as_iter;    /* 0 => default 60 */
     int refine_steps;   /* fp64 residual-refinement rounds on the final active set; <0 => default 2 */
-    int check_kappa;    /* 0 => skip the curvature rows (box-only QP); default 1 */
+    int check_kappa;    /* curvature rows |k_ref + E a| <= kappa_bound: 0 or 1 => carried (the default: a zero-initialised mcq_opts
+                         * solves the QP the reference solves); < 0 => skipped (box-only QP; a violated row is then reported as
+                         * MCQ_KAPPA_ACTIVE instead of being enforced) */
     int objective;      /* MCQ_OBJ_MIN_CURV (0, default) or MCQ_OBJ_SHORTEST_PATH: the QP of tph.opt_shortest_path
                          * [REF main_globaltraj.py:286-290] on the same box rows -- H = cyclic tridiagonal
                          * (4 |n_i|^2 on the diagonal, -2 n_i.n_{i+1} beside it), f_i = 2 n_i.(2 p_i - p_{i-1} - p_{i+1}),
@@ -213,6 +216,60 @@ int mcq_vel_profile_device_ragged(mcq_handle* h, int batch, int nmax, const int*
 int mcq_raceline_device(mcq_handle* h, int batch, int nmax, const int* n_in, const double* reftrack, const double* normvec,
                         const double* alpha, double stepsize, int mmax, double* raceline_out, double* psi_out,
                         double* kappa_out, double* el_lengths_out, int* m_out, int* status_out);
+
+/* Host-buffer entry for a UNIFORM batch (every track n waypoints): reftrack [batch][n][4], normvec [batch][n][2] or NULL,
+ * scaling [batch][n] or NULL in host memory, results to host memory.  One asynchronous copy per array straight from / to the
+ * caller's buffers -- no packing pass; buffers from mcq_host_alloc (pinned) are copied at PCIe speed, pageable ones go through
+ * the runtime's staging.  This is the wall SURVEY.md section 8d defines the metric on ("inputs resident in host pinned memory
+ * -> alpha resident in host memory"); bench.py reports it next to the device-resident rate.  Blocking. */
+int mcq_solve_host(mcq_handle* h, int batch, int n, const double* reftrack, const double* normvec, const double* scaling,
+                   double kappa_bound, double w_veh, const mcq_opts* opts, double* alpha_out, double* curv_err_out,
+                   int* status_out, mcq_info* info_out);
+
+/* ---- tph.iqp_handler [REF main_globaltraj.py:273-284] as ONE call: the whole iterated re-linearisation of a batch of tracks.
+ *
+ * Every round is one batched QP pass (mcq_solve_device_ragged; passes 2+ warm-started from the working set the glue carried
+ * over) followed, on the device, by the termination test of iqp_handler (round >= iters_min and curv_error_max <=
+ * curv_error_allowed), the damping of the early rounds (alpha * round / iters_min) and the glue of mcq_relinearise_device for
+ * the tracks that go on.  The host enqueues the first iters_min rounds without looking and then reads ONE int per round (how
+ * many tracks are still iterating).  A track whose QP fails keeps that status and stops; the others are not affected.
+ *
+ * mcq_iqp_device: everything resident.  reftrack_a / normvec_a [batch][nmax][*] hold the tracks on entry (n_io [batch] their
+ * waypoint counts), reftrack_b / normvec_b are the second set of the double buffer; scaling [batch][nmax] (first pass) or NULL.
+ * On return: alpha_out [batch][nmax] = alpha of the last pass (damped if the track ended in an early round -- only with
+ * iters_min > the rounds run, as upstream), n_io = waypoint counts of the last re-linearisation, buf_out [batch] = 0 / 1: which
+ * set holds a track's final reftrack / normvectors, curv_err_out / status_out / rounds_out [batch]; curv_trace_out
+ * [batch][MCQ_IQP_TRACE] (optional) = curv_error_max of every round of a track (what iqp_handler prints with print_debug;
+ * rounds beyond MCQ_IQP_TRACE are not recorded).  stats (optional, host): see mcq_iqp_stats.  Blocking (the loop needs the
+ * live count). */
+#define MCQ_IQP_TRACE 16
+typedef struct {
+    int rounds;             /* rounds run (the slowest track) */
+    int qp_solves;          /* QP passes summed over the tracks */
+    float solver_ms[16];    /* per round: the QP pass's launch sequence (HIP events; rounds beyond 16 are not recorded; only
+                             * filled when `timed` is set on entry: costs one event synchronisation per round) */
+    int fallbacks[16];      /* per round: warm starts abandoned for the cold path (needs info read-back: only when `timed`) */
+    int timed;              /* in: 1 => fill solver_ms / fallbacks */
+} mcq_iqp_stats;
+int mcq_iqp_device(mcq_handle* h, int batch, int nmax, int* n_io, double* reftrack_a, double* normvec_a, double* reftrack_b,
+                   double* normvec_b, const double* scaling, double kappa_bound, double w_veh, double stepsize_interp,
+                   int iters_min, double curv_error_allowed, int max_rounds, const mcq_opts* opts, double* alpha_out,
+                   int* buf_out, double* curv_err_out, int* status_out, int* rounds_out, double* curv_trace_out,
+                   mcq_iqp_stats* stats);
+/* The same from / to host buffers -- what iqp_handler binds.  problems [batch] as for mcq_solve_batch (normvec required);
+ * outputs padded to nmax_out waypoints per track (caller's capacity for the re-sampled rings; MCQ_E_TOO_LARGE names nothing
+ * partial: a track whose ring outgrows it gets status MCQ_BAD_INPUT): alpha_out [batch][nmax_out], reftrack_out
+ * [batch][nmax_out][4], normvec_out [batch][nmax_out][2], n_out / status_out / rounds_out [batch], curv_err_out [batch],
+ * curv_trace_out [batch][MCQ_IQP_TRACE] or NULL. */
+int mcq_iqp_batch(mcq_handle* h, const mcq_problem* probs, int batch, double stepsize_interp, int iters_min,
+                  double curv_error_allowed, int max_rounds, const mcq_opts* opts, int nmax_out, double* alpha_out,
+                  double* reftrack_out, double* normvec_out, int* n_out, double* curv_err_out, int* status_out,
+                  int* rounds_out, double* curv_trace_out, mcq_iqp_stats* stats);
+
+/* Pinned (page-locked) host memory for callers that want their buffers copied at PCIe speed (mcq_solve_host, mcq_solve_batch,
+ * mcq_copy_*). */
+int mcq_host_alloc(mcq_handle* h, size_t bytes, void** out);
+int mcq_host_free(mcq_handle* h, void* ptr);
 
 /* Device memory plumbing on the handle's device and stream, for callers that keep data resident between calls (the
  * Python IQP driver) without loading a second HIP runtime into the process: allocate (zero-filled) / free / blocking

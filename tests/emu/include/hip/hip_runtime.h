@@ -249,6 +249,7 @@ inline double __hiloint2double(int hi, int lo)
     double d; memcpy(&d, &b, 8); return d;
 }
 inline int __shfl_xor(int v, int m) { return (int)__shfl_xor((double)v, m); }
+inline int atomicAdd(int* p, int v) { const int o = *p; *p = o + v; return o; }    /* one work-item runs at a time */
 
 // ---- host runtime subset -------------------------------------------------------------------------------------------
 typedef int hipError_t;
@@ -268,6 +269,9 @@ inline hipError_t hipStreamDestroy(hipStream_t) { return hipSuccess; }
 inline hipError_t hipStreamSynchronize(hipStream_t) { return hipSuccess; }
 inline hipError_t hipMalloc(void** p, size_t n) { *p = calloc(n ? n : 1, 1); return *p ? hipSuccess : hipErrorInvalidValue; }
 inline hipError_t hipFree(void* p) { free(p); return hipSuccess; }
+enum { hipHostMallocDefault = 0 };
+inline hipError_t hipHostMalloc(void** p, size_t n, unsigned) { *p = calloc(n ? n : 1, 1); return *p ? hipSuccess : hipErrorInvalidValue; }
+inline hipError_t hipHostFree(void* p) { free(p); return hipSuccess; }
 inline hipError_t hipMemcpyAsync(void* d, const void* s, size_t n, hipMemcpyKind, hipStream_t) { memcpy(d, s, n); return hipSuccess; }
 inline hipError_t hipMemsetAsync(void* d, int v, size_t n, hipStream_t) { memset(d, v, n); return hipSuccess; }
 inline hipError_t hipMemcpy(void* d, const void* s, size_t n, hipMemcpyKind) { memcpy(d, s, n); return hipSuccess; }

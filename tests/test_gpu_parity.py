@@ -679,12 +679,12 @@ def test_oval_n2000_first_pass_against_golden(gpu_engine):
     certificate).  Host-buffer entry, device entry fed rows only (normals derived on the device), and the drop-in function."""
     g = _golden_n2000()
     p = dict(reftrack=g["reftrack"], normvec=g["normvec"], scaling=g["scaling"], kappa_bound=0.12, w_veh=3.4)
-    al, curv, st, info = gpu_engine.solve_batch([p, dict(p, normvec=None, scaling=None)])
-    for k in range(2):
-        assert st[k] == 0
-        assert np.max(np.abs(al[k] - g["alpha"])) < ALPHA_TOL, float(np.max(np.abs(al[k] - g["alpha"])))
-        assert abs(curv[k] - float(g["curv_error_max"])) < CURV_TOL
-        assert abs(info[k]["kappa_max"] - float(g["kappa_max"])) < 1e-9
+    for prob in (p, dict(p, normvec=None, scaling=None)):
+        al, curv, st, info = gpu_engine.solve_batch([prob])
+        assert st[0] == 0
+        assert np.max(np.abs(al[0] - g["alpha"])) < ALPHA_TOL, float(np.max(np.abs(al[0] - g["alpha"])))
+        assert abs(curv[0] - float(g["curv_error_max"])) < CURV_TOL
+        assert abs(info[0]["kappa_max"] - float(g["kappa_max"])) < 1e-9
     A = tph.calc_splines.build_les_matrix(2000, g["scaling"])
     a, err = tph.opt_min_curv.opt_min_curv(g["reftrack"], g["normvec"], A, 0.12, 3.4)
     assert np.max(np.abs(a - g["alpha"])) < ALPHA_TOL and abs(err - float(g["curv_error_max"])) < CURV_TOL

@@ -142,3 +142,34 @@ def test_shortest_path_oracle_encodes_the_polygon_length(golden):
     kkt = qp_ref.kkt_residuals(H, f, G, h, alpha)
     assert kkt["stationarity"] < 1e-12 and kkt["primal"] < 1e-12
     assert tph_ref.path_length_sq(ref, nv, alpha) < c0
+
+
+def test_cpu_b_banded_solver_matches_dense_oracle(golden):
+    """oracle/banded_qp.c ("CPU-B": cyclic-tridiagonal assembly, E band of half width 36, bordered-band interior point + active
+    set + refinement through E, scalar C) against the dense-faithful oracle's committed alpha on the reference's two long
+    tracks and on the N = 2000 oval -- three routes now agree there (dense Goldfarb-Idnani, trust-region-reflective least
+    squares, banded interior point / active set); and its status codes."""
+    import os
+    from oracle import banded_ref
+    cases = [golden["modena_2019"], golden["berlin_2018"]]
+    z = np.load(os.path.join(os.path.dirname(__file__), "golden", "oval_n2000.npz"))
+    cases.append({k: z[k] for k in z.files})
+    for g in cases:
+        a, c, st, it, used = banded_ref.solve_batch(g["reftrack"][None], g["normvec"][None], g["scaling"][None], 0.12, 3.4)
+        assert st[0] == 0 and used == 1
+        assert np.max(np.abs(a[0] - g["alpha"])) < 1e-8
+        assert abs(c[0] - float(g["curv_error_max"])) < 1e-12
+        assert 5 <= it[0, 0] <= 40 and 1 <= it[0, 1] <= 20
+    # a batch over threads returns what the single calls return, bitwise
+    g = cases[0]
+    refs = np.stack([g["reftrack"]] * 3)
+    refs[1, :, 2:] += 0.3
+    refs[2, :, 2:] = 1.0                                   # w_r + w_l < w_veh: infeasible widths
+    a3, c3, st3, _, used = banded_ref.solve_batch(refs, np.stack([g["normvec"]] * 3), np.stack([g["scaling"]] * 3), 0.12, 3.4, nthreads=3)
+    a0, _, _, _, _ = banded_ref.solve_batch(refs[:1], g["normvec"][None], g["scaling"][None], 0.12, 3.4)
+    assert list(st3) == [0, 0, 1] and np.array_equal(a3[0], a0[0]) and not np.array_equal(a3[0], a3[1])
+    # a ring too short for its bordered band is refused, not mis-solved
+    h = golden["handling_track"]
+    assert banded_ref.solve_batch(h["reftrack"][None], h["normvec"][None], h["scaling"][None], 0.12, 3.4)[2][0] == 4
+    # curvature rows are checked: a bound below the curvature at the box optimum is reported (status 6)
+    assert banded_ref.solve_batch(g["reftrack"][None], g["normvec"][None], g["scaling"][None], 0.05, 3.4)[2][0] == 6
