@@ -163,14 +163,15 @@ static int ensure_ws(mcq_handle* h, size_t batch, size_t nmax)
     HIP_TRY(hipMalloc((void**)&h->H, elems * MCQ_HLD * sizeof(double)));
     HIP_TRY(hipMalloc((void**)&h->L, elems * MCQ_LLD * sizeof(double)));
     HIP_TRY(hipMalloc((void**)&h->vec, elems * MCQ_NVEC * sizeof(double)));
-    HIP_TRY(hipMalloc((void**)&h->Z, elems * MCQ_KMAX * sizeof(double)));
+    HIP_TRY(hipMalloc((void**)&h->Z, (elems + batch * (size_t)MCQ_KMAX * MCQ_KMAX) * sizeof(double)));
     HIP_TRY(hipMalloc((void**)&h->state, elems));
     HIP_TRY(hipMalloc((void**)&h->state2, elems));
     HIP_TRY(hipMemsetAsync(h->state, 0, elems, h->stream));
     HIP_TRY(hipMemsetAsync(h->state2, 0, elems, h->stream));
     h->cap_elems = elems;
     h->cap_batch = batch;
-    h->ws_bytes = (long long)(elems * ((3 * MCQ_ELD + MCQ_HLD + MCQ_LLD + MCQ_NVEC + MCQ_KMAX) * sizeof(double) + 1));
+    h->ws_bytes = (long long)(elems * ((3 * MCQ_ELD + MCQ_HLD + MCQ_LLD + MCQ_NVEC + 1) * sizeof(double) + 2) +
+                              batch * (size_t)MCQ_KMAX * MCQ_KMAX * sizeof(double));
     return 0;
 }
 
@@ -868,14 +869,15 @@ static int pack_and_upload(mcq_handle* h, const mcq_problem* probs, int batch, s
     P.wv = P.kb + batch;
     P.info = (mcq_info*)(P.wv + batch);
     P.n = (int*)(P.info + batch);
-    memset(P.ref, 0, elems * 4 * sizeof(double));
-    if (with_nv) memset(P.nv, 0, elems * 2 * sizeof(double));
-    if (any_sc) for (size_t q = 0; q < elems; ++q) P.sc[q] = 1.0;
+    // (the padding behind a track's n waypoints is never read by a kernel: no need to clear it)
     for (int b = 0; b < batch; ++b) {
         const size_t n = (size_t)probs[b].n;
         memcpy(P.ref + (size_t)b * nmax * 4, probs[b].reftrack, n * 4 * sizeof(double));
         if (with_nv) memcpy(P.nv + (size_t)b * nmax * 2, probs[b].normvec, n * 2 * sizeof(double));
-        if (any_sc && probs[b].scaling) memcpy(P.sc + (size_t)b * nmax, probs[b].scaling, n * sizeof(double));
+        if (any_sc) {
+            if (probs[b].scaling) memcpy(P.sc + (size_t)b * nmax, probs[b].scaling, n * sizeof(double));
+            else for (size_t q = 0; q < n; ++q) P.sc[(size_t)b * nmax + q] = 1.0;
+        }
         P.kb[b] = probs[b].kappa_bound;
         P.wv[b] = probs[b].w_veh;
         P.n[b] = probs[b].n;
@@ -1009,24 +1011,32 @@ extern "C" int mcq_iqp_batch(mcq_handle* h, const mcq_problem* probs, int batch,
     HIP_TRY_SYNC(hipMemcpyAsync(rounds_out, d_rounds, batch * sizeof(int), hipMemcpyDeviceToHost, h->stream));
     HIP_TRY_SYNC(hipMemcpyAsync(curv_err_out, h->d_curv, batch * sizeof(double), hipMemcpyDeviceToHost, h->stream));
     HIP_TRY_SYNC(hipMemcpyAsync(status_out, h->d_status, batch * sizeof(int), hipMemcpyDeviceToHost, h->stream));
-    HIP_TRY_SYNC(hipMemcpyAsync(P.alpha, h->d_alpha, elems * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+    // alpha straight into the caller's [batch][nmax_out] array (its padding holds whatever the device buffer held)
+    HIP_TRY_SYNC(hipMemcpyAsync(alpha_out, h->d_alpha, elems * sizeof(double), hipMemcpyDeviceToHost, h->stream));
     HIP_TRY(hipStreamSynchronize(h->stream));
     bool use[2] = {false, false};
     for (int b = 0; b < batch; ++b) use[buf_h[b] ? 1 : 0] = true;
-    // final reftrack / normvectors: set 0 lands in the (now free) input staging, set 1 in the extra block behind it
-    double* ref_h[2] = {P.ref, (double*)(P.n + batch + 16)};
-    double* nv_h[2] = {P.nv, ref_h[1] + elems * 4};
+    const double* d_ref_set[2] = {h->d_ref, h->d_ref2};
+    const double* d_nv_set[2] = {h->d_nv, h->d_nv2};
+    if (use[0] != use[1]) {
+        // the usual case (one iters_min for all: every track ends in the same round): the final set goes out in two copies
+        const int q = use[1] ? 1 : 0;
+        HIP_TRY_SYNC(hipMemcpyAsync(reftrack_out, d_ref_set[q], elems * 4 * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+        HIP_TRY_SYNC(hipMemcpyAsync(normvec_out, d_nv_set[q], elems * 2 * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+        HIP_TRY(hipStreamSynchronize(h->stream));
+        return 0;
+    }
+    // tracks ended in different rounds: both sets through the pinned staging (set 0 into the now free input block, set 1 into
+    // the extra block behind it), then track by track
+    double* ref_h[2] = {P.ref, nullptr};
+    double* nv_h[2] = {P.nv, nullptr};
     {
-        // keep the extra block 8-byte aligned
-        size_t addr = (size_t)ref_h[1];
-        addr = (addr + 7) & ~(size_t)7;
+        size_t addr = (size_t)(P.n + batch + 16);
+        addr = (addr + 7) & ~(size_t)7;                 // keep the extra block 8-byte aligned
         ref_h[1] = (double*)addr;
         nv_h[1] = ref_h[1] + elems * 4;
     }
-    const double* d_ref_set[2] = {h->d_ref, h->d_ref2};
-    const double* d_nv_set[2] = {h->d_nv, h->d_nv2};
     for (int q = 0; q < 2; ++q) {
-        if (!use[q]) continue;
         HIP_TRY_SYNC(hipMemcpyAsync(ref_h[q], d_ref_set[q], elems * 4 * sizeof(double), hipMemcpyDeviceToHost, h->stream));
         HIP_TRY_SYNC(hipMemcpyAsync(nv_h[q], d_nv_set[q], elems * 2 * sizeof(double), hipMemcpyDeviceToHost, h->stream));
     }
@@ -1034,7 +1044,6 @@ extern "C" int mcq_iqp_batch(mcq_handle* h, const mcq_problem* probs, int batch,
     for (int b = 0; b < batch; ++b) {
         const int q = buf_h[b] ? 1 : 0;
         const size_t n = n_out[b] > 0 ? (size_t)n_out[b] : 0;
-        memcpy(alpha_out + (size_t)b * nmax, P.alpha + (size_t)b * nmax, nmax * sizeof(double));
         memcpy(reftrack_out + (size_t)b * nmax * 4, ref_h[q] + (size_t)b * nmax * 4, n * 4 * sizeof(double));
         memcpy(normvec_out + (size_t)b * nmax * 2, nv_h[q] + (size_t)b * nmax * 2, n * 2 * sizeof(double));
     }

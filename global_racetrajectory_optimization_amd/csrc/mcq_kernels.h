@@ -44,7 +44,8 @@
 #define MCQ_LBI 64                 /* offset of the inverse diagonal tile row inside an L row */
 #define MCQ_LBW 80                 /* offset of the border part W inside an L row */
 #define MCQ_NVEC 30
-#define MCQ_KMAX 24                /* active curvature rows the Schur-complement path of the active-set phase holds */
+#define MCQ_KMAX 120               /* active curvature rows the Schur-complement path of the active-set phase holds */
+#define MCQ_ZLD(nmax) ((size_t)(nmax) + (size_t)MCQ_KMAX * MCQ_KMAX)   /* doubles of the curvature-row scratch per problem: one vector + the Schur matrix */
 #define MCQ_PIVOT_WARMUP 64
 
 // bE / bR: half-widths of the cyclic band of E_kappa to the left / right of the diagonal.  bR = bE except for small
@@ -90,7 +91,7 @@ struct McqWork {
     gdouble* L;           // also scratch for the T^-1 rows during assembly
     gdouble* vec;         // MCQ_NVEC vectors of length nmax, see enum below
     gschar* state;        // [n] 0 free, -1 at lower bound, +1 at upper bound, 2 fixed (lo == hi)
-    gdouble* Z;           // [MCQ_KMAX][nmax] M^-1 E_K' columns of the curvature-row Schur complement
+    gdouble* Z;           // curvature-row path: [nmax] scratch vector, then the [MCQ_KMAX][MCQ_KMAX] Schur matrix / its LU factors
     gdouble* alpha;       // [n] output
     gdouble* curv_err;    // [1]
     gint* status;         // [1]

@@ -39,10 +39,12 @@ typedef double v4d __attribute__((vector_size(32)));   /* accumulator fragment o
 #define SM_CHUNK SM_OVL                           /* NBUF x CH x CLD */
 #define SM_RHS (SM_CHUNK + NBUF * CH * CLD)       /* NRB x CH */
 #define SM_VR (SM_RHS + NRB * CH)                 /* VRING */
-#define SM_KS (SM_OVL + OVL_SIZE)                 /* KMAX x KMAX Schur matrix of the active curvature rows */
-#define SM_KV (SM_KS + MCQ_KMAX * MCQ_KMAX)       /* 2 x KMAX: multipliers, right-hand side */
-#define SM_KI (SM_KV + 2 * MCQ_KMAX)              /* ints: nk, row index[KMAX], sign[KMAX] */
-#define SM_TOTAL (SM_KI + MCQ_KMAX + 2)
+#define SM_KV (SM_OVL + OVL_SIZE)                 /* 3 x KMAX: multipliers, right-hand side, elimination multipliers */
+#define SM_KI (SM_KV + 3 * MCQ_KMAX)              /* ints: nk, row index[KMAX], sign[KMAX], pivot row[KMAX] */
+#define SM_TOTAL (SM_KI + (3 * MCQ_KMAX + 2 + 1) / 2 + 1)
+/* the KMAX x KMAX Schur matrix of the active curvature rows lives in HBM (McqWork.Z) and is brought into the overlay region
+   between two triangular solves for its (parallel) elimination */
+static_assert(MCQ_KMAX * MCQ_KMAX <= OVL_SIZE, "the Schur matrix of the curvature rows must fit the LDS overlay");
 
 size_t mcq_solve_lds_bytes() { return sizeof(double) * SM_TOTAL; }
 
@@ -159,7 +161,7 @@ __device__ McqWork mcq_work(const McqBatch& B, int pb, int& n, double& kb, doubl
     w.L = (gdouble*)(B.L + (size_t)pb * nm * MCQ_LLD);
     w.vec = (gdouble*)(B.vec + (size_t)pb * nm * MCQ_NVEC);
     w.state = (gschar*)(B.state + (size_t)pb * nm);
-    w.Z = (gdouble*)(B.Z + (size_t)pb * nm * MCQ_KMAX);
+    w.Z = (gdouble*)(B.Z + (size_t)pb * MCQ_ZLD(nm));
     w.alpha = B.alpha ? (gdouble*)(B.alpha + (size_t)pb * nm) : nullptr;
     w.curv_err = B.curv_err ? (gdouble*)(B.curv_err + pb) : nullptr;
     w.status = (gint*)(B.status + pb);
@@ -2460,12 +2462,108 @@ __device__ __forceinline__ double erow_dot(const SolveCtx& c, int k, const gdoub
     return acc;
 }
 
+// ---- curvature rows of the working set: the Schur complement  S = E_K M^-1 E_K'  (nk x nk, nk <= MCQ_KMAX) ------------------------
+// S lives in HBM (row-major, leading dimension MCQ_KMAX, behind the scratch vector of McqWork.Z); for the elimination it is
+// brought into the LDS overlay (free between two triangular solves), factored there by all 256 threads -- LU with partial
+// pivoting: S is symmetric positive definite when the active rows are independent on the free set, pivoting keeps a nearly
+// dependent working set from blowing up -- and written back, so that later right-hand sides (the refinement) reuse the factors.
+__device__ void kappa_lu_factor(gdouble* SG, int nk)
+{
+    const int tid = threadIdx.x;
+    double* A = g_sm + SM_OVL;                       // nk x nk, leading dimension nk
+    double* mul = g_sm + SM_KV + 2 * MCQ_KMAX;       // multipliers of the current column
+    int* piv = (int*)(g_sm + SM_KI) + 1 + 2 * MCQ_KMAX;
+    __syncthreads();
+    for (int e = tid; e < nk * nk; e += MCQ_NT) A[e] = SG[(size_t)(e / nk) * MCQ_KMAX + (e % nk)];
+    __syncthreads();
+    for (int cidx = 0; cidx < nk; ++cidx) {
+        if (tid == 0) {
+            int pr = cidx;
+            for (int r = cidx + 1; r < nk; ++r)
+                if (fabs(A[r * nk + cidx]) > fabs(A[pr * nk + cidx])) pr = r;
+            piv[cidx] = pr;
+        }
+        __syncthreads();
+        const int pr = piv[cidx];
+        if (pr != cidx)
+            for (int cc = tid; cc < nk; cc += MCQ_NT) {
+                const double t = A[cidx * nk + cc];
+                A[cidx * nk + cc] = A[pr * nk + cc];
+                A[pr * nk + cc] = t;
+            }
+        __syncthreads();
+        const double pv = A[cidx * nk + cidx];
+        for (int r = cidx + 1 + tid; r < nk; r += MCQ_NT) mul[r] = pv != 0.0 ? A[r * nk + cidx] / pv : 0.0;
+        __syncthreads();
+        const int rem = nk - cidx - 1;
+        for (int e = tid; e < rem * rem; e += MCQ_NT) {
+            const int r = cidx + 1 + e / rem, cc = cidx + 1 + e % rem;
+            A[r * nk + cc] -= mul[r] * A[cidx * nk + cc];
+        }
+        __syncthreads();
+        for (int r = cidx + 1 + tid; r < nk; r += MCQ_NT) A[r * nk + cidx] = mul[r];      // L below the diagonal
+        __syncthreads();
+    }
+    for (int e = tid; e < nk * nk; e += MCQ_NT) SG[(size_t)(e / nk) * MCQ_KMAX + (e % nk)] = A[e];
+    __syncthreads();
+}
+
+// KMU <- S^-1 KRH with the factors kappa_lu_factor left in SG (row interchanges applied to the right-hand side first)
+__device__ void kappa_lu_solve(const gdouble* SG, int nk)
+{
+    const int tid = threadIdx.x;
+    double* A = g_sm + SM_OVL;
+    double* KMU = g_sm + SM_KV;
+    const double* KRH = g_sm + SM_KV + MCQ_KMAX;
+    const int* piv = (const int*)(g_sm + SM_KI) + 1 + 2 * MCQ_KMAX;
+    __syncthreads();
+    for (int e = tid; e < nk * nk; e += MCQ_NT) A[e] = SG[(size_t)(e / nk) * MCQ_KMAX + (e % nk)];
+    for (int q = tid; q < nk; q += MCQ_NT) KMU[q] = KRH[q];
+    __syncthreads();
+    if (tid == 0)
+        for (int cidx = 0; cidx < nk; ++cidx) {
+            const int pr = piv[cidx];
+            if (pr != cidx) { const double t = KMU[cidx]; KMU[cidx] = KMU[pr]; KMU[pr] = t; }
+        }
+    __syncthreads();
+    for (int cidx = 0; cidx < nk; ++cidx) {               // L y = P b   (unit lower triangle)
+        const double yc = KMU[cidx];
+        __syncthreads();
+        for (int r = cidx + 1 + tid; r < nk; r += MCQ_NT) KMU[r] -= A[r * nk + cidx] * yc;
+        __syncthreads();
+    }
+    for (int cidx = nk - 1; cidx >= 0; --cidx) {          // U x = y
+        if (tid == 0) { const double pv = A[cidx * nk + cidx]; KMU[cidx] = pv != 0.0 ? KMU[cidx] / pv : 0.0; }
+        __syncthreads();
+        const double xc = KMU[cidx];
+        for (int r = tid; r < cidx; r += MCQ_NT) KMU[r] -= A[r * nk + cidx] * xc;
+        __syncthreads();
+    }
+}
+
+// v <- M^-1 (E_K' KMU restricted to the free set):  the multipliers scattered onto their rows (Q), one band product, one solve
+__device__ void kappa_apply(SolveCtx& c, int nk, gdouble* Q, gdouble* v)
+{
+    const int tid = threadIdx.x, n = c.d.n;
+    const double* KMU = g_sm + SM_KV;
+    const int* KI = (const int*)(g_sm + SM_KI);
+    const gschar* ST = c.w.state;
+    for (int i = tid; i < n; i += MCQ_NT) Q[i] = 0.0;
+    __syncthreads();
+    for (int q = tid; q < nk; q += MCQ_NT) Q[KI[1 + q]] = KMU[q];
+    __syncthreads();
+    band_matvec(c.w.Et, c.d.bR, c.d.bE, n, c.nm, Q, nullptr, 0.0, v);
+    __syncthreads();
+    for (int i = tid; i < n; i += MCQ_NT) if (ST[i] != 0) v[i] = 0.0;
+    __syncthreads();
+    timed_solve(c, v);
+}
+
 __device__ __noinline__ int active_set(SolveCtx& c, const McqBatch& B, bool with_kappa, bool tapia, int cap, const SolveScalars& sc, int& iters,
                                        double& kkt, int& nk_out, bool identify = true)
 {
     const int tid = threadIdx.x, n = c.d.n, nm = c.nm;
     double* red = g_sm + SM_RED;
-    double* KS = g_sm + SM_KS;
     double* KMU = g_sm + SM_KV;
     double* KRH = g_sm + SM_KV + MCQ_KMAX;
     int* KI = (int*)(g_sm + SM_KI);        // KI[0] = nk, KI[1+q] = row, KI[1+KMAX+q] = sign
@@ -2556,63 +2654,32 @@ __device__ __noinline__ int active_set(SolveCtx& c, const McqBatch& B, bool with
         if (fs != 0) return fs;
         timed_solve(c, RHS);                    // x0 (pinned rows carry their bounds)
         if (nk > 0) {
-            // Z_q = M^-1 (E_kq' restricted to the free set)
+            // column q of S = E_K (M^-1 E_kq' restricted to the free set): one banded solve per active row, nothing but one
+            // scratch vector kept (x = x0 - M^-1 E_K' mu costs one more solve afterwards instead of nk stored columns)
+            gdouble* Zs = c.w.Z;
+            gdouble* SG = c.w.Z + nm;
             for (int q = 0; q < nk; ++q) {
-                gdouble* Zq = c.w.Z + (size_t)q * nm;
                 const int k = KI[1 + q];
-                for (int i = tid; i < n; i += MCQ_NT) Zq[i] = 0.0;
+                for (int i = tid; i < n; i += MCQ_NT) Zs[i] = 0.0;
                 __syncthreads();
                 for (int oo = tid; oo < c.d.ew; oo += MCQ_NT) {
                     const int j = cyc(k + oo - c.d.bE, n);
-                    if (ST[j] == 0) Zq[j] = c.w.Eb[(size_t)oo * nm + k];
+                    if (ST[j] == 0) Zs[j] = c.w.Eb[(size_t)oo * nm + k];
                 }
                 __syncthreads();
-                timed_solve(c, Zq);
+                timed_solve(c, Zs);
+                for (int q2 = tid; q2 < nk; q2 += MCQ_NT) SG[(size_t)q2 * MCQ_KMAX + q] = erow_dot(c, KI[1 + q2], Zs);
+                __syncthreads();
             }
-            // S = E_K Z,  rhs = E_K x0 + k_ref - s kb     (thread q handles row q: short band dot products)
-            for (int e = tid; e < nk * (nk + 1); e += MCQ_NT) {
-                const int q = e / (nk + 1), q2 = e - q * (nk + 1);
+            // rhs = E_K x0 + k_ref - s kb
+            for (int q = tid; q < nk; q += MCQ_NT) {
                 const int k = KI[1 + q];
-                if (q2 < nk) KS[q * MCQ_KMAX + q2] = erow_dot(c, k, c.w.Z + (size_t)q2 * nm);
-                else KRH[q] = erow_dot(c, k, RHS) + KR[k] - KI[1 + MCQ_KMAX + q] * kb;
+                KRH[q] = erow_dot(c, k, RHS) + KR[k] - KI[1 + MCQ_KMAX + q] * kb;
             }
-            __syncthreads();
-            if (tid == 0) {   // dense solve S mu = rhs, Gaussian elimination with partial pivoting (|K| <= MCQ_KMAX)
-                for (int cidx = 0; cidx < nk; ++cidx) {
-                    int pr = cidx;
-                    for (int r = cidx + 1; r < nk; ++r)
-                        if (fabs(KS[r * MCQ_KMAX + cidx]) > fabs(KS[pr * MCQ_KMAX + cidx])) pr = r;
-                    if (pr != cidx) {
-                        for (int cc = 0; cc < nk; ++cc) {
-                            const double t = KS[cidx * MCQ_KMAX + cc];
-                            KS[cidx * MCQ_KMAX + cc] = KS[pr * MCQ_KMAX + cc];
-                            KS[pr * MCQ_KMAX + cc] = t;
-                        }
-                        const double t = KRH[cidx]; KRH[cidx] = KRH[pr]; KRH[pr] = t;
-                    }
-                    const double pv = KS[cidx * MCQ_KMAX + cidx];
-                    for (int r = cidx + 1; r < nk; ++r) {
-                        const double m = pv != 0.0 ? KS[r * MCQ_KMAX + cidx] / pv : 0.0;
-                        for (int cc = cidx; cc < nk; ++cc) KS[r * MCQ_KMAX + cc] -= m * KS[cidx * MCQ_KMAX + cc];
-                        KRH[r] -= m * KRH[cidx];
-                    }
-                }
-                for (int r = nk - 1; r >= 0; --r) {
-                    double t = KRH[r];
-                    for (int cc = r + 1; cc < nk; ++cc) t -= KS[r * MCQ_KMAX + cc] * KMU[cc];
-                    const double pv = KS[r * MCQ_KMAX + r];
-                    KMU[r] = pv != 0.0 ? t / pv : 0.0;
-                }
-            }
-            __syncthreads();
-            for (int i = tid; i < n; i += MCQ_NT) {
-                double x = RHS[i];
-                for (int q = 0; q < nk; ++q) x -= KMU[q] * c.w.Z[(size_t)q * nm + i];
-                RHS[i] = x;
-                Q[i] = 0.0;
-            }
-            __syncthreads();
-            for (int q = tid; q < nk; q += MCQ_NT) Q[KI[1 + q]] = KMU[q];     // multipliers scattered onto their rows
+            kappa_lu_factor(SG, nk);
+            kappa_lu_solve(SG, nk);
+            kappa_apply(c, nk, Q, Zs);          // Q = multipliers on their rows, Zs = M^-1 E_K' mu
+            for (int i = tid; i < n; i += MCQ_NT) RHS[i] -= Zs[i];
             __syncthreads();
         }
         for (int i = tid; i < n; i += MCQ_NT) X[i] = ST[i] == 0 ? RHS[i] : T1[i];
@@ -2653,13 +2720,35 @@ __device__ __noinline__ int active_set(SolveCtx& c, const McqBatch& B, bool with
             // fp64 residual refinement through E on the final working set (same factor); box-only working sets
             // A round whose correction is already below 1e-8 m is the last one: the next would move alpha by (cond * eps)
             // times that, i.e. far below the 1e-9 m at which the dense oracle itself is known.
-            for (int r = 0; r < (nk == 0 ? B.refine_steps : 0); ++r) {
+            for (int r = 0; r < B.refine_steps; ++r) {
                 for (int i = tid; i < n; i += MCQ_NT) RHS[i] = ST[i] == 0 ? -G[i] : 0.0;
                 timed_solve(c, RHS);
+                if (nk > 0) {
+                    // curvature rows in the working set: one step on the KKT system [M E_K'; E_K 0] through the factored Schur
+                    // complement -- dx0 = M^-1(-g), S dmu = E_K dx0 + (E_K x + k_ref - s kb), dx = dx0 - M^-1 E_K' dmu
+                    gdouble* Zs = c.w.Z;
+                    const gdouble* SG = c.w.Z + nm;
+                    for (int q = tid; q < nk; q += MCQ_NT) {
+                        const int k = KI[1 + q];
+                        KRH[q] = erow_dot(c, k, RHS) + T2[k] - KI[1 + MCQ_KMAX + q] * kb;
+                    }
+                    kappa_lu_solve(SG, nk);
+                    for (int q = tid; q < nk; q += MCQ_NT) KRH[q] = KMU[q];       // dmu (kappa_apply reads KMU, Q is rebuilt below)
+                    __syncthreads();
+                    kappa_apply(c, nk, T1, Zs);
+                    for (int i = tid; i < n; i += MCQ_NT) RHS[i] -= Zs[i];
+                    __syncthreads();
+                    for (int q = tid; q < nk; q += MCQ_NT) Q[KI[1 + q]] += KRH[q];
+                    __syncthreads();
+                }
                 double dm = 0.0;
                 for (int i = tid; i < n; i += MCQ_NT) if (ST[i] == 0) { X[i] += RHS[i]; dm = fmax(dm, fabs(RHS[i])); }
                 dm = block_reduce_(dm, 2, red);
-                gradient(c, X, nullptr, T0, G);
+                gradient(c, X, nk > 0 ? Q : nullptr, T0, G);
+                if (nk > 0) {
+                    band_matvec(c.w.Eb, c.d.bE, c.d.bR, n, nm, X, KR, 1.0, T2);      // r = E x + k_ref
+                    __syncthreads();
+                }
                 c.refine_rounds = r + 1;
                 if (!(dm > 1e-8)) break;
             }
@@ -2715,6 +2804,7 @@ __global__ void __launch_bounds__(MCQ_NT) mcq_solve_kernel(McqBatch B)
     c.refine_rounds = c.second_attempt = 0;
     c.direct = B.objective == MCQ_OBJ_SHORTEST_PATH;
     const long long t_kernel0 = TICK();
+    const long long c_kernel0 = (long long)clock64();      // shader-clock counter (s_memtime): with ticks[3] the effective clock
     double* red = g_sm + SM_RED;
     const int nm = B.nmax;
 
@@ -2892,6 +2982,7 @@ __global__ void __launch_bounds__(MCQ_NT) mcq_solve_kernel(McqBatch B)
                 o.refine_rounds = c.refine_rounds;
                 o.second_attempt = c.second_attempt;
                 c.tk[3] = TICK() - t_kernel0;
+                if (!MCQ_FINE_TIMERS) c.tk[6] = (long long)clock64() - c_kernel0;
                 for (int q = 0; q < 8; ++q) o.ticks[q] = c.tk[q];
                 *(mcq_info*)c.w.info = o;
             }

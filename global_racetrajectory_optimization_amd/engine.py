@@ -291,10 +291,13 @@ class Engine:
         if nmax is None:
             # capacity for the re-sampled rings: the raceline is never much longer than the polygon through the reference
             # points; 30 % + 16 points of headroom (a ring that outgrows it is reported per track, not truncated)
-            nmax = 0
-            for r in refs:
-                length = float(np.hypot(np.diff(r[:, 0], append=r[0, 0]), np.diff(r[:, 1], append=r[0, 1])).sum())
-                nmax = max(nmax, r.shape[0], int(np.ceil(1.3 * length / stepsize_interp)) + 16)
+            if len({r.shape for r in refs}) == 1:           # uniform batch: one vectorised pass over all tracks
+                xy = np.stack([r[:, :2] for r in refs])
+                seg = xy - np.roll(xy, -1, axis=1)
+                lengths = np.sqrt(np.einsum("bnk,bnk->bn", seg, seg)).sum(axis=1)
+            else:
+                lengths = np.array([np.hypot(np.diff(r[:, 0], append=r[0, 0]), np.diff(r[:, 1], append=r[0, 1])).sum() for r in refs])
+            nmax = max(max(r.shape[0] for r in refs), int(np.ceil(1.3 * float(lengths.max()) / stepsize_interp)) + 16)
         arr = (McqProblem * bsz)()
         for k in range(bsz):
             n = refs[k].shape[0]

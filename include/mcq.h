@@ -100,6 +100,7 @@ typedef struct {
     /* device wall-clock (s_memrealtime, 100 MHz ticks) spent by this problem's workgroup in the phases of the solver
      * kernel: [0] banded factorisations, [1] triangular solves, [2] gradient band products, [3] whole kernel,
      * [4] / [5] forward / backward interior sweeps of the triangular solves as wave 0 sees them (part of [1]);
+     * [6] the same span as [3] in shader-clock cycles (s_memtime): [6] / [3] x 100 MHz = the clock the CU actually ran at;
      * a -DMCQ_FINE_TIMERS build reports the inside of the factorisation in [4..6] instead (phase 1, phase 2, tail) */
     long long ticks[8];
     int refine_rounds;  /* fp64 refinement rounds run on the final working set (<= opts.refine_steps) */

@@ -14,4 +14,5 @@ timeout 300 python bench.py --steps 5 --warmup 1 --force-collective --no-extras 
 echo "fc rc $?"
 timeout 300 python bench.py --config 4 --steps 2 --warmup 1 --force-collective > gpurun_out/${T}_bench_c4.json 2> gpurun_out/${T}_bench_c4.err
 echo "c4 rc $?"; cut -c1-300 gpurun_out/${T}_bench_c4.json
-scripts/profile_round.sh ${T}
+if [ "${2:-prof}" = "prof" ]; then scripts/profile_round.sh ${T}; fi
+python __graft_entry__.py smoke > gpurun_out/${T}_smoke.log 2>&1; tail -2 gpurun_out/${T}_smoke.log

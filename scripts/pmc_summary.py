@@ -113,9 +113,14 @@ def main(base, tag, out_prefix, title):
                 if nm in c:
                     d[nm + "_over_WAVE_CYCLES"] = c[nm] / wc
         gui = c.get("GRBM_GUI_ACTIVE")
+        ms_k = stats.get("mcq_solve_kernel", {}).get("avg_ms")
         if gui and "SQ_VALU_MFMA_BUSY_CYCLES" in c:
-            # MfmaUtil as rocprofv3 derives it: busy cycles / (GUI-active cycles x SIMDs); 256 CUs x 4 SIMDs
-            d["MfmaUtil_pct"] = 100.0 * c["SQ_VALU_MFMA_BUSY_CYCLES"] / (gui * 1024.0)
+            # MfmaUtil as rocprofv3 derives it: busy cycles / (GUI-active cycles x SIMDs), 256 CUs x 4 SIMDs.  The per-dispatch
+            # GRBM_GUI_ACTIVE value in the csv is the SUM over the 8 XCDs (rocprofv3's own formula takes the max over them).
+            d["gui_active_cycles_per_xcd"] = gui / 8.0
+            d["MfmaUtil_pct"] = 100.0 * c["SQ_VALU_MFMA_BUSY_CYCLES"] / (gui / 8.0 * 1024.0)
+            if ms_k:
+                d["effective_clock_ghz"] = gui / 8.0 / (ms_k * 1e-3) / 1e9
         if "SQ_INSTS_VALU_MFMA_MOPS_F64" in c:
             d["mfma_f64_flops_per_launch"] = c["SQ_INSTS_VALU_MFMA_MOPS_F64"] * 512.0
         if "SQ_INSTS_VALU_FMA_F64" in c:

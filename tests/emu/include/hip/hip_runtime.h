@@ -210,6 +210,7 @@ inline hipemu_u2 hipemu_permlane_swap(unsigned d, unsigned s, int width)
 #define __builtin_amdgcn_permlane16_swap(d, s, fi, bc) hipemu_permlane_swap((unsigned)(d), (unsigned)(s), 16)
 
 inline long long wall_clock64() { return (long long)(hipemu_now() * 1e5); }
+inline long long clock64() { return (long long)(hipemu_now() * 1e6); }
 
 // v_mfma_f64_16x16x4_f64: D(16x16) = A(16x4) B(4x16) + C.  Lane l holds A[l&15][l>>4], B[l>>4][l&15]; C/D register r of lane l
 // is element (row (l>>4) + 4r, col l&15)   (/opt/skills/guides/cdna_hip_programming.md, section 3, f64 layout).

@@ -712,3 +712,37 @@ def test_oval_n2000_iqp_end_state_against_golden(gpu_engine):
         assert np.max(np.abs(a - g["iqp_alpha"])) < ALPHA_TOL, float(np.max(np.abs(a - g["iqp_alpha"])))
         assert np.max(np.abs(ref_out - g["iqp_reftrack"])) < 1e-6
         assert np.max(np.abs(nv_out - g["iqp_normvec"])) < 1e-8
+
+
+def test_many_active_curvature_rows_against_dense_gi(gpu_engine, golden):
+    """quadprog carries any number of active curvature rows [REF params/racecar.ini:49 curvlim]; so must the engine.  The handling
+    track with kappa_bound tightened until 40 / 51 curvature rows are active at the optimum (dense Goldfarb-Idnani, all 4N rows),
+    and Berlin at 0.07 (11 rows on a 776-point ring): alpha at the north_star tolerance, the same number of active rows, the
+    bound met to round-off, refinement run on the curvature-row working set; and just beyond feasibility: status 5 ->
+    ValueError("constraints are inconsistent, no solution") like quadprog."""
+    from oracle import qp_ref, tph_ref
+    cases = [("handling_track", 0.0495), ("handling_track", 0.048), ("berlin_2018", 0.07)]
+    probs, want = [], []
+    for name, kb in cases:
+        g = golden[name]
+        n = g["reftrack"].shape[0]
+        A = tph.calc_splines.build_les_matrix(n, g["scaling"])
+        info = {}
+        a_ref, err_ref = tph_ref.opt_min_curv(g["reftrack"], g["normvec"], A, kb, 3.4,
+                                              solver=lambda H, f, G, h: qp_ref.solve_qp_gi(H, f, G, h, info))
+        want.append((a_ref, err_ref, int(np.sum(info["lagr"][2 * n:] > 0))))
+        probs.append(dict(reftrack=g["reftrack"], normvec=g["normvec"], scaling=g["scaling"], kappa_bound=kb, w_veh=3.4))
+    assert want[0][2] >= 40 and want[1][2] >= 50
+    al, curv, st, info = gpu_engine.solve_batch(probs)
+    for k, (a_ref, err_ref, nk) in enumerate(want):
+        assert st[k] == 0, (cases[k], st[k])
+        assert np.max(np.abs(al[k] - a_ref)) < ALPHA_TOL, (cases[k], float(np.max(np.abs(al[k] - a_ref))))
+        assert abs(curv[k] - err_ref) < CURV_TOL
+        assert info[k]["n_active_kappa"] == nk, (cases[k], info[k]["n_active_kappa"], nk)
+        assert abs(info[k]["kappa_max"] - cases[k][1]) < 1e-9 and info[k]["refine_rounds"] >= 1
+    g = golden["handling_track"]
+    A = tph.calc_splines.build_les_matrix(g["reftrack"].shape[0], g["scaling"])
+    with pytest.raises(ValueError, match="inconsistent"):
+        tph_ref.opt_min_curv(g["reftrack"], g["normvec"], A, 0.04, 3.4)
+    with pytest.raises(ValueError, match="constraints are inconsistent, no solution"):
+        tph.opt_min_curv.opt_min_curv(g["reftrack"], g["normvec"], A, 0.04, 3.4)
