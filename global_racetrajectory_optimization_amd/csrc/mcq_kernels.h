@@ -76,6 +76,7 @@ __host__ __device__ inline McqDims mcq_dims(int n, int band_e)
 // compile to global_load / global_store (a generic pointer would become FLAT and serialise against LDS traffic).
 typedef __attribute__((address_space(1))) double gdouble;
 typedef __attribute__((address_space(1))) signed char gschar;
+typedef __attribute__((address_space(1))) char gchar;
 typedef __attribute__((address_space(1))) int gint;
 typedef __attribute__((address_space(1))) mcq_info ginfo;
 

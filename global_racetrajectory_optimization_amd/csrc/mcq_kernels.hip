@@ -6,6 +6,8 @@
 #define MCQ_NT 256
 #define MCQ_NW (MCQ_NT / 64)
 typedef double v4d __attribute__((vector_size(32)));   /* accumulator fragment of v_mfma_f64_16x16x4_f64 */
+typedef double d2 __attribute__((vector_size(16)));
+typedef __attribute__((address_space(1))) d2 gd2;
 #define TB 16                           /* tile edge of the blocked factorisation (v_mfma_f64_16x16x4_f64) */
 #define TLD 17                          /* padded row stride of an LDS tile: conflict-free MFMA operand reads */
 #define TSZ (TB * TLD)
@@ -29,13 +31,13 @@ typedef double v4d __attribute__((vector_size(32)));   /* accumulator fragment o
 #define SM_S (SM_PART + MCQ_NW * 128)             /* L_S^-1, packed rows: entry (r, c <= r) at r (r + 1) / 2 + c */
 #define SM_OVL (SM_S + SPK)                       /* overlay region */
 #define NTRC (NTR + 1)                   /* tile rows of the border window: one more than the band (committed a phase earlier) */
-#define OVL_SIZE_F (NTR * NTR * TSZ + NTRC * NCT * TSZ + 2 * TSZ + 32)
+#define NCT5 (NCT + 1)                   /* tiles of a border-window row slot: the inverse of the step's diagonal tile, then C(., 0..3) */
+#define OVL_SIZE_F (NTR * NTR * TSZ + NTRC * NCT5 * TSZ + 32)
 #define OVL_SIZE_S (NBUF * CH * CLD + NRB * CH + VRING)
 #define OVL_SIZE (OVL_SIZE_F > OVL_SIZE_S ? OVL_SIZE_F : OVL_SIZE_S)
 #define SM_BT SM_OVL                              /* band tiles   (NTR x NTR) */
-#define SM_CT (SM_BT + NTR * NTR * TSZ)           /* border tiles (NTRC x NCT) */
-#define SM_LINV (SM_CT + NTRC * NCT * TSZ)        /* inverses of the current and the previous diagonal tile (by step parity) */
-#define SM_DINV (SM_LINV + 2 * TSZ)                   /* 16 reciprocal pivots of the current diagonal tile + fail flag */
+#define SM_CT (SM_BT + NTR * NTR * TSZ)           /* border window: NTRC row slots of [inverse diagonal tile | C(., 0..3)] */
+#define SM_DINV (SM_CT + NTRC * NCT5 * TSZ)       /* fail flag of the factorisation (slot TB) */
 #define SM_CHUNK SM_OVL                           /* NBUF x CH x CLD */
 #define SM_RHS (SM_CHUNK + NBUF * CH * CLD)       /* NRB x CH */
 #define SM_VR (SM_RHS + NRB * CH)                 /* VRING */
@@ -830,6 +832,22 @@ struct SolveCtx {
 #define MCQ_FINE_TIMERS 0
 #endif
 #define FTICK() (MCQ_FINE_TIMERS ? TICK() : 0LL)
+// -DMCQ_WORKER_TIMERS=w (diagnostic build, scripts/gpu_variants.sh): where the lag-worker wave w = 1..3 spends phase 1 of a factorisation
+// step -- shader-clock cycles (s_memtime) summed over all steps and factorisations of a problem, reported in mcq_info.ticks[0..7]
+// INSTEAD of the usual phase timers: [0] fetch issue, [1] LDS reads of the lag work, [2] border products + write-back, [3] Schur + band products, [4] write-out, [5] commit,
+// [6] wait at the phase-1 barrier, [7] phase 2 + its barrier (w = 4: wave 0 -- [0] its diagonal tile + inverse, [6], [7] as above).
+// Every sample drains the wave's LDS queue: the sum is an upper bound.
+#ifndef MCQ_WORKER_TIMERS
+#define MCQ_WORKER_TIMERS 0
+#endif
+#define WT(k)                                                                                              \
+    do {                                                                                                   \
+        if (MCQ_WORKER_TIMERS) {                                                                           \
+            const long long t_ = (long long)clock64();                                                     \
+            wt[(k)] += t_ - wt_last;                                                                       \
+            wt_last = t_;                                                                                  \
+        }                                                                                                  \
+    } while (0)
 // default build: ticks[4] / ticks[5] = wave 0's forward / backward interior sweeps (part of ticks[1]), two samples per solve
 #define STICK() (MCQ_FINE_TIMERS ? 0LL : TICK())
 
@@ -844,8 +862,13 @@ struct SolveCtx {
 //            stays in flight across the LDS-only barriers.
 // Output: L rows in w.L (row i: [0] = 1/L_ii, [k] = L[i,i-k]; [HBO+jj] = W[i][jj]); L_S (p x p, lower) in LDS SM_S.
 // Returns 0 or MCQ_NOT_PD (uniform across the block).
-#define BTILE(I, K) (bt + ((((I) % NTR) * NTR) + ((K) % NTR)) * TSZ)
-#define CTILE(I, a) (ct + ((((I) % NTRC) * NCT) + (a)) * TSZ)
+// Band tile (I, K), I - 4 <= K <= I, lives in row slot I mod 5 at the RELATIVE column K - I + 4: one runtime modulo per row, and
+// the address of an item of tile row R is a wave-uniform base plus a per-thread constant.  (K - I = 1 wraps to column 0: the
+// slot of the finished tile (I, I - 4) -- the "dead" slot LTILE(1, .) borrows.)
+#define BTILE(I, K) (bt + ((((I) % NTR) * NTR) + (((K) - (I) + 2 * NTR - 1) % NTR)) * TSZ)
+#define CROW(I) (ct + (((I) % NTRC) * NCT5) * TSZ)           /* border row slot of step / tile row I */
+#define INVT(I) CROW(I)                                      /* inverse of the diagonal tile of step I */
+#define CTILE(I, a) (CROW(I) + (1 + (a)) * TSZ)
 // L(P+dI, P), dI = 1..4, once the panel of step P is done: in place, except the first sub-diagonal tile, which every wave
 // still reads as T(P+1, P) while wave 0 produces it -- that one goes to the dead upper-triangle slot (P+1, P+2)
 #define LTILE(dI, P) ((dI) == 1 ? BTILE((P) + 1, (P) + 2) : BTILE((P) + (dI), (P)))
@@ -937,7 +960,7 @@ __device__ __forceinline__ void tile_row_store(double* bt, double* ct, int R, in
 struct PfConst {
     int goff;      // H offset relative to row block R:  + R * TB * MCQ_HLD
     int loff;      // LDS offset inside the tile slot (band) / inside the border tile row (border)
-    int flags;     // bit 0 band item, bit 1 entry exists (inside the band / column < p), bit 2 diagonal entry; bits 8.. 1 + tile column
+    int flags;     // bit 0 band item, bit 1 entry exists (inside the band / column < p), bit 2 diagonal entry
     int m0, m1;    // mask byte indices: relative to R * TB (band: column, row; border: row), absolute (border: ni + column)
 };
 
@@ -950,8 +973,8 @@ __device__ __forceinline__ PfConst pf_const(int q, int ni, int b, int p)
         const int kk = (NTR - 1 - tcol) * TB + rr - cc;
         const bool valid = (kk >= 0) & (kk <= b);
         k.goff = ((tcol - (NTR - 1)) * TB + cc) * MCQ_HLD + (valid ? kk : 0);
-        k.loff = rr * TLD + cc;
-        k.flags = 1 | (valid ? 2 : 0) | (kk == 0 ? 4 : 0) | ((1 + tcol) << 8);
+        k.loff = tcol * TSZ + rr * TLD + cc;          // relative tile column tcol of the row slot
+        k.flags = 1 | (valid ? 2 : 0) | (kk == 0 ? 4 : 0);
         k.m0 = (tcol - (NTR - 1)) * TB + cc;
         k.m1 = rr;
     } else {
@@ -959,7 +982,7 @@ __device__ __forceinline__ PfConst pf_const(int q, int ni, int b, int p)
         const int rr = q2 / MCQ_P_MAX, jj = q2 - rr * MCQ_P_MAX;
         const bool ok = jj < p;
         k.goff = rr * MCQ_HLD + MCQ_HBO + (ok ? jj : 0);
-        k.loff = (jj / TB) * TSZ + rr * TLD + (jj % TB);
+        k.loff = (1 + jj / TB) * TSZ + rr * TLD + (jj % TB);      // behind the inverse-tile slot of the row
         k.flags = ok ? 2 : 0;
         k.m0 = rr;
         k.m1 = ni + (ok ? jj : 0);
@@ -996,13 +1019,10 @@ __device__ __forceinline__ void tile_row_commit_fast(double* bt, double* ct, con
         const bool dg = MAYDIAG && (k.flags & 4);
         if (MK) v = pinned ? (dg ? 1.0 : 0.0) : v;
         if (SIG && MAYDIAG) v += (dg && !pinned) ? e.sg : 0.0;
-        const int r5 = R % NTR;
-        int kc = r5 + (k.flags >> 8);               // (R - (NTR-1) + tcol) mod NTR
-        kc = kc >= NTR ? kc - NTR : kc;
-        bt[(r5 * NTR + kc) * TSZ + k.loff] = v;
+        bt[(R % NTR) * (NTR * TSZ) + k.loff] = v;         // wave-uniform row-slot base + per-thread constant
     } else {
         if (MK) v = pinned ? 0.0 : v;
-        ct[(R % NTRC) * (NCT * TSZ) + k.loff] = v;
+        ct[(R % NTRC) * (NCT5 * TSZ) + k.loff] = v;
     }
 }
 
@@ -1060,7 +1080,6 @@ __device__ __forceinline__ int factor_t(const SolveCtx& c, const gdouble* Hsrc, 
     double* bt = g_sm + SM_BT;
     double* ct = g_sm + SM_CT;
     double* dinv = g_sm + SM_DINV;
-    double* linv = g_sm + SM_LINV;
     const gdouble* H = Hsrc;
     gdouble* L = c.w.L;
     const int lane = tid & 63, w0 = tid >> 6;
@@ -1071,6 +1090,8 @@ __device__ __forceinline__ int factor_t(const SolveCtx& c, const gdouble* Hsrc, 
 #pragma unroll
     for (int m = 0; m < NCT; ++m) sacc[m] = (v4d){0.0, 0.0, 0.0, 0.0};
     RawEntry pf[PF_ITEMS];
+    long long wt[8] = {0, 0, 0, 0, 0, 0, 0, 0}, wt_last = 0;
+    (void)wt; (void)wt_last;
 
     const int lt = tid - 64;         // fetch / commit thread of waves 1..3
     PfConst pc[PF_ITEMS];
@@ -1112,87 +1133,68 @@ __device__ __forceinline__ int factor_t(const SolveCtx& c, const gdouble* Hsrc, 
     // All LDS operand / accumulator reads of a group are issued before its MFMAs, all writes after them.
 #define LAG_WORK(P, WL)                                                                                                    \
     {                                                                                                                  \
-        /* ---- border tiles: C(P+dI, a) -= L(P+dI, P) W_P(a) ---- */                                                  \
+        /* The three groups of the step's lag work (border, band, Schur tiles) used to run read -> MFMA -> write one after \
+           the other; the compiler cannot move a group's LDS reads above the previous group's LDS writes (same address     \
+           space, no alias info), so each group paid its own LDS round trip with the matrix pipe idle.  Now operands       \
+           shared between groups are read once (the W row block of step P: border and Schur; the L tiles: border and       \
+           band), the border products run off one batch of reads, and the band accumulators are read behind the border     \
+           tiles' write-back with the Schur products (registers only) in between to cover that one round trip.  (All      \
+           reads up front costs 16 more live VGPRs than the allocator has: spills, and a crash in hipcc 7.2's                \
+           AGPR-copy rewrite pass.)                                                                                      \
+             border tiles  C(P+dI, a) -= L(P+dI, P) W_P(a)            a = WL for dI = 1..4, plus (WL+1, 3) [and (4, 3) on WL 0]   \
+             band tiles    T(P+dI, P+dK) -= L(P+dI, P) L(P+dK, P)'    2 <= dK <= dI <= 4, tile t % 3 == WL                 \
+             Schur tiles   S(a, bb) -= W_P(a)' W_P(bb)                 lower, (t + 1) % 3 == WL, kept in registers */    \
+        double la_[4][4], wv_[NCT][4];                                                                                 \
+        v4d cacc_[4], c3a_, c3b_, bacc_[2];                                                                            \
+        _Pragma("unroll") for (int a_ = 0; a_ < NCT; ++a_) {                                                           \
+            const double* wa2_ = CTILE((P), a_);                                                                       \
+            _Pragma("unroll") for (int kc = 0; kc < 4; ++kc) wv_[a_][kc] = wa2_[(l4 + 4 * kc) * TLD + l15];            \
+        }                                                                                                              \
+        _Pragma("unroll") for (int dI_ = 1; dI_ < NTR; ++dI_) {                                                        \
+            const double* li_ = LTILE(dI_, (P));                                                                       \
+            const double* ctl_ = CTILE((P) + dI_, (WL));                                                               \
+            _Pragma("unroll") for (int kc = 0; kc < 4; ++kc) la_[dI_ - 1][kc] = -li_[l15 * TLD + l4 + 4 * kc];         \
+            _Pragma("unroll") for (int r = 0; r < 4; ++r) cacc_[dI_ - 1][r] = ctl_[(l4 + 4 * r) * TLD + l15];          \
+        }                                                                                                              \
         {                                                                                                              \
-            double la_[4][4], wa_[4], w3_[4];                                                                          \
-            v4d cacc_[4], c3a_, c3b_;                                                                                  \
-            const double* wt_ = CTILE((P), (WL));                                                                        \
-            const double* w3t_ = CTILE((P), 3);                                                                        \
-            _Pragma("unroll") for (int kc = 0; kc < 4; ++kc) {                                                         \
-                wa_[kc] = wt_[(l4 + 4 * kc) * TLD + l15];                                                              \
-                w3_[kc] = w3t_[(l4 + 4 * kc) * TLD + l15];                                                             \
+            const double* c3p_ = CTILE((P) + (WL) + 1, 3);                                                             \
+            const double* c3q_ = CTILE((P) + 4, 3);                                                                    \
+            _Pragma("unroll") for (int r = 0; r < 4; ++r) {                                                            \
+                c3a_[r] = c3p_[(l4 + 4 * r) * TLD + l15];                                                              \
+                c3b_[r] = c3q_[(l4 + 4 * r) * TLD + l15];                                                              \
             }                                                                                                          \
-            _Pragma("unroll") for (int dI_ = 1; dI_ < NTR; ++dI_) {                                                    \
-                const double* li_ = LTILE(dI_, (P));                                                                       \
-                const double* ctl_ = CTILE((P) + dI_, (WL));                                                             \
-                _Pragma("unroll") for (int kc = 0; kc < 4; ++kc) la_[dI_ - 1][kc] = -li_[l15 * TLD + l4 + 4 * kc];     \
-                _Pragma("unroll") for (int r = 0; r < 4; ++r) cacc_[dI_ - 1][r] = ctl_[(l4 + 4 * r) * TLD + l15];      \
+        }                                                                                                              \
+        WT(1);                                                                                                         \
+        /* ---- products ---- */                                                                                       \
+        _Pragma("unroll") for (int dI_ = 1; dI_ < NTR; ++dI_) cacc_[dI_ - 1] = mfma16(la_[dI_ - 1], wv_[(WL)], cacc_[dI_ - 1]); \
+        c3a_ = mfma16(la_[(WL)], wv_[3], c3a_);                                                                        \
+        if ((WL) == 0) c3b_ = mfma16(la_[3], wv_[3], c3b_);                                                            \
+        /* ---- updated tiles back to the window ---- */                                                               \
+        _Pragma("unroll") for (int dI_ = 1; dI_ < NTR; ++dI_) {                                                        \
+            double* ctl_ = CTILE((P) + dI_, (WL));                                                                     \
+            _Pragma("unroll") for (int r = 0; r < 4; ++r) ctl_[(l4 + 4 * r) * TLD + l15] = cacc_[dI_ - 1][r];          \
+        }                                                                                                              \
+        {                                                                                                              \
+            double* c3p_ = CTILE((P) + (WL) + 1, 3);                                                                   \
+            double* c3q_ = CTILE((P) + 4, 3);                                                                          \
+            _Pragma("unroll") for (int r = 0; r < 4; ++r) {                                                            \
+                c3p_[(l4 + 4 * r) * TLD + l15] = c3a_[r];                                                              \
+                if ((WL) == 0) c3q_[(l4 + 4 * r) * TLD + l15] = c3b_[r];                                               \
             }                                                                                                          \
-            {                                                                                                          \
-                const double* c3p_ = CTILE((P) + (WL) + 1, 3);                                                           \
-                const double* c3q_ = CTILE((P) + 4, 3);                                                                \
-                _Pragma("unroll") for (int r = 0; r < 4; ++r) {                                                        \
-                    c3a_[r] = c3p_[(l4 + 4 * r) * TLD + l15];                                                          \
-                    c3b_[r] = c3q_[(l4 + 4 * r) * TLD + l15];                                                          \
-                }                                                                                                      \
-            }                                                                                                          \
-            _Pragma("unroll") for (int dI_ = 1; dI_ < NTR; ++dI_) cacc_[dI_ - 1] = mfma16(la_[dI_ - 1], wa_, cacc_[dI_ - 1]); \
-            c3a_ = mfma16(la_[(WL)], w3_, c3a_);                                                                         \
-            if ((WL) == 0) c3b_ = mfma16(la_[3], w3_, c3b_);                                                             \
-            _Pragma("unroll") for (int dI_ = 1; dI_ < NTR; ++dI_) {                                                    \
-                double* ctl_ = CTILE((P) + dI_, (WL));                                                                   \
-                _Pragma("unroll") for (int r = 0; r < 4; ++r) ctl_[(l4 + 4 * r) * TLD + l15] = cacc_[dI_ - 1][r];      \
-            }                                                                                                          \
-            {                                                                                                          \
-                double* c3p_ = CTILE((P) + (WL) + 1, 3);                                                                 \
-                double* c3q_ = CTILE((P) + 4, 3);                                                                      \
-                _Pragma("unroll") for (int r = 0; r < 4; ++r) {                                                        \
-                    c3p_[(l4 + 4 * r) * TLD + l15] = c3a_[r];                                                          \
-                    if ((WL) == 0) c3q_[(l4 + 4 * r) * TLD + l15] = c3b_[r];                                             \
-                }                                                                                                      \
-            }                                                                                                          \
-            /* ---- band tiles not in block column P+1:  T(P+dI, P+dK) -= L(P+dI,P) L(P+dK,P)',  2 <= dK <= dI <= 4; the   \
-                    row-form operand of L(P+dI, P) is la_[dI-1] (negated), the column-form operand of L(P+dK, P) is the    \
-                    same register pattern un-negated ---- */                                                              \
-            {                                                                                                          \
-                v4d bacc_[2];                                                                                          \
-                int t_ = 0, s_ = 0;                                                                                    \
-                _Pragma("unroll") for (int dK_ = 2; dK_ < NTR; ++dK_) {                                                \
-                    _Pragma("unroll") for (int dI_ = dK_; dI_ < NTR; ++dI_, ++t_) {                                    \
-                        if (t_ % 3 != (WL)) continue;                                                                    \
-                        const double* tt_ = BTILE((P) + dI_, (P) + dK_);                                               \
-                        _Pragma("unroll") for (int r = 0; r < 4; ++r) bacc_[s_][r] = tt_[(l4 + 4 * r) * TLD + l15];    \
-                        ++s_;                                                                                          \
-                    }                                                                                                  \
-                }                                                                                                      \
-                t_ = 0; s_ = 0;                                                                                        \
-                _Pragma("unroll") for (int dK_ = 2; dK_ < NTR; ++dK_) {                                                \
-                    _Pragma("unroll") for (int dI_ = dK_; dI_ < NTR; ++dI_, ++t_) {                                    \
-                        if (t_ % 3 != (WL)) continue;                                                                    \
-                        double bv_[4];                                                                                 \
-                        _Pragma("unroll") for (int kc = 0; kc < 4; ++kc) bv_[kc] = -la_[dK_ - 1][kc];                  \
-                        bacc_[s_] = mfma16(la_[dI_ - 1], bv_, bacc_[s_]);                                              \
-                        ++s_;                                                                                          \
-                    }                                                                                                  \
-                }                                                                                                      \
-                t_ = 0; s_ = 0;                                                                                        \
-                _Pragma("unroll") for (int dK_ = 2; dK_ < NTR; ++dK_) {                                                \
-                    _Pragma("unroll") for (int dI_ = dK_; dI_ < NTR; ++dI_, ++t_) {                                    \
-                        if (t_ % 3 != (WL)) continue;                                                                    \
-                        double* tt_ = BTILE((P) + dI_, (P) + dK_);                                                     \
-                        _Pragma("unroll") for (int r = 0; r < 4; ++r) tt_[(l4 + 4 * r) * TLD + l15] = bacc_[s_][r];    \
-                        ++s_;                                                                                          \
-                    }                                                                                                  \
+        }                                                                                                              \
+        {                                                                                                              \
+            int t_ = 0, s_ = 0;                                                                                        \
+            _Pragma("unroll") for (int dK_ = 2; dK_ < NTR; ++dK_) {                                                    \
+                _Pragma("unroll") for (int dI_ = dK_; dI_ < NTR; ++dI_, ++t_) {                                        \
+                    if (t_ % 3 != (WL)) continue;                                                                      \
+                    const double* tt_ = BTILE((P) + dI_, (P) + dK_);                                                   \
+                    _Pragma("unroll") for (int r = 0; r < 4; ++r) bacc_[s_][r] = tt_[(l4 + 4 * r) * TLD + l15];        \
+                    ++s_;                                                                                              \
                 }                                                                                                      \
             }                                                                                                          \
         }                                                                                                              \
-        /* ---- Schur tiles (lower)  S(a, bb) -= W_P(a)' W_P(bb),  kept in registers ---- */                           \
+        WT(2);                                                                                                         \
         {                                                                                                              \
-            double wv_[NCT][4];                                                                                        \
-            _Pragma("unroll") for (int a_ = 0; a_ < NCT; ++a_) {                                                       \
-                const double* wa2_ = CTILE((P), a_);                                                                   \
-                _Pragma("unroll") for (int kc = 0; kc < 4; ++kc) wv_[a_][kc] = wa2_[(l4 + 4 * kc) * TLD + l15];        \
-            }                                                                                                          \
             int t_ = 0;                                                                                                \
             _Pragma("unroll") for (int a_ = 0; a_ < NCT; ++a_) {                                                       \
                 _Pragma("unroll") for (int bb_ = 0; bb_ <= a_; ++bb_, ++t_) {                                          \
@@ -1203,6 +1205,30 @@ __device__ __forceinline__ int factor_t(const SolveCtx& c, const gdouble* Hsrc, 
                 }                                                                                                      \
             }                                                                                                          \
         }                                                                                                              \
+        {                                                                                                              \
+            int t_ = 0, s_ = 0;                                                                                        \
+            _Pragma("unroll") for (int dK_ = 2; dK_ < NTR; ++dK_) {                                                    \
+                _Pragma("unroll") for (int dI_ = dK_; dI_ < NTR; ++dI_, ++t_) {                                        \
+                    if (t_ % 3 != (WL)) continue;                                                                      \
+                    double bv_[4];                                                                                     \
+                    _Pragma("unroll") for (int kc = 0; kc < 4; ++kc) bv_[kc] = -la_[dK_ - 1][kc];                      \
+                    bacc_[s_] = mfma16(la_[dI_ - 1], bv_, bacc_[s_]);                                                  \
+                    ++s_;                                                                                              \
+                }                                                                                                      \
+            }                                                                                                          \
+        }                                                                                                              \
+        {                                                                                                              \
+            int t_ = 0, s_ = 0;                                                                                        \
+            _Pragma("unroll") for (int dK_ = 2; dK_ < NTR; ++dK_) {                                                    \
+                _Pragma("unroll") for (int dI_ = dK_; dI_ < NTR; ++dI_, ++t_) {                                        \
+                    if (t_ % 3 != (WL)) continue;                                                                      \
+                    double* tt_ = BTILE((P) + dI_, (P) + dK_);                                                         \
+                    _Pragma("unroll") for (int r = 0; r < 4; ++r) tt_[(l4 + 4 * r) * TLD + l15] = bacc_[s_][r];        \
+                    ++s_;                                                                                              \
+                }                                                                                                      \
+            }                                                                                                          \
+        }                                                                                                              \
+        WT(3);                                                                                                         \
     }
 
 #define LAG_DISPATCH(P)                                                                                                \
@@ -1219,45 +1245,60 @@ __device__ __forceinline__ int factor_t(const SolveCtx& c, const gdouble* Hsrc, 
     }
     // Write-out of block column P of L (tiles below the diagonal one; the sweeps use the inverse tile instead of the
     // entries inside the diagonal tile), of the inverse diagonal tile and of block row P of W.  Shared by the three lag waves
-    // (64 lanes each): wl = 2 writes the four L tiles, wl = 1 / wl = 0 one half each of the [inverse tile | W] rows.  Fixed
-    // trip counts, LDS reads batched before the stores.  The inverse tile of step P is read from its own buffer (linv is
-    // double-buffered by step parity).
-#define WO_T 64
-#define WO_L ((4 * TB * TB) / WO_T)
-#define WO_W ((TB * (TB + MCQ_P_MAX)) / WO_T)
+    // (64 lanes each): wl = 2 writes the four L tiles, wl = 1 / wl = 0 one half each of the [inverse tile | W] rows.
+    // Index arithmetic is kept off the per-item path (it was 40 % of a worker wave's phase 1): every address is a wave-uniform
+    // base plus a per-lane constant plus a literal.
+    //   L tiles : lane (rg = lane >> 4, cc = lane & 15) takes, of tile tI = 1..4, the rows rg + 4 j (j = 0..3) of column cc:
+    //             element (tI, rr, cc) = L[i, i - k], k = 16 tI + rr - cc, goes to L-row i slot k - 1, i.e. to
+    //             P 16 LLD + (16 tI + 4 j)(LLD + 1) + [rg (LLD + 1) - cc - 1]  -- 16 lanes write 128 contiguous bytes;
+    //   W rows  : lane (rr = lane >> 2, part = lane & 3) takes 10 consecutive entries of row rr of [inverse | W] (80 doubles:
+    //             the row slot of the border window holds them as 5 adjacent tiles) = 80 contiguous bytes, five 16-byte stores.
+#define WO_L 16
 #define WRITE_OUT_L(P)                                                                                                 \
     {                                                                                                                  \
+        const int rg_ = lane >> 4, cc_ = lane & 15;                                                                    \
+        const int lo_ = rg_ * TLD + cc_;                                                                               \
+        /* byte offset of (tI = 1, j = 0) relative to the L row block of step P: >= 0, 32 bits */                        \
+        const unsigned go8_ = (unsigned)((rg_ * (MCQ_LLD + 1) - cc_ - 1 + TB * (MCQ_LLD + 1)) * 8);                    \
+        gchar* glb_ = (gchar*)(L + (size_t)(P) * (TB * MCQ_LLD));                                                      \
+        const bool full_ = ((P) + NTR) * TB <= ni;          /* every row of the four tiles is an interior row */        \
         _Pragma("unroll") for (int h_ = 0; h_ < 2; ++h_) {                                                             \
             double ev_[WO_L / 2];                                                                                      \
             _Pragma("unroll") for (int m_ = 0; m_ < WO_L / 2; ++m_) {                                                  \
-                const int q = lane + (m_ + h_ * (WO_L / 2)) * WO_T;                                                    \
-                ev_[m_] = LTILE(1 + (m_ + h_ * (WO_L / 2)) / 4, (P))[((q / TB) % TB) * TLD + (q % TB)];                \
+                const int mm_ = m_ + h_ * (WO_L / 2);                                                                  \
+                ev_[m_] = LTILE(1 + mm_ / 4, (P))[lo_ + (mm_ % 4) * 4 * TLD];                                          \
             }                                                                                                          \
-            _Pragma("unroll") for (int m_ = 0; m_ < WO_L / 2; ++m_) {                                                  \
-                const int q = lane + (m_ + h_ * (WO_L / 2)) * WO_T;                                                    \
-                const int tI = 1 + q / (TB * TB), rr = (q / TB) % TB, cc = q % TB;                                     \
-                const int i = ((P) + tI) * TB + rr, k = tI * TB + rr - cc;                                             \
-                if (i < ni && k <= MCQ_BH_MAX) L[(size_t)i * MCQ_LLD + (k - 1)] = ev_[m_];                             \
+            if (full_) {                                                                                               \
+                _Pragma("unroll") for (int m_ = 0; m_ < WO_L / 2; ++m_) {                                              \
+                    const int mm_ = m_ + h_ * (WO_L / 2);                                                              \
+                    const int tI = 1 + mm_ / 4, rr = rg_ + 4 * (mm_ % 4);                                              \
+                    const unsigned off_ = go8_ + (unsigned)((((tI - 1) * TB + 4 * (mm_ % 4)) * (MCQ_LLD + 1)) * 8);    \
+                    if (tI < NTR - 1 || rr <= cc_) *(gdouble*)(glb_ + off_) = ev_[m_];   /* k <= 64: only the last tile is cut */ \
+                }                                                                                                      \
+            } else {                                                                                                   \
+                _Pragma("unroll") for (int m_ = 0; m_ < WO_L / 2; ++m_) {                                              \
+                    const int mm_ = m_ + h_ * (WO_L / 2);                                                              \
+                    const int tI = 1 + mm_ / 4, rr = rg_ + 4 * (mm_ % 4);                                              \
+                    const unsigned off_ = go8_ + (unsigned)((((tI - 1) * TB + 4 * (mm_ % 4)) * (MCQ_LLD + 1)) * 8);    \
+                    if (((P) + tI) * TB + rr < ni && (tI < NTR - 1 || rr <= cc_)) *(gdouble*)(glb_ + off_) = ev_[m_];  \
+                }                                                                                                      \
             }                                                                                                          \
         }                                                                                                              \
     }
+#define WO_W 10
 #define WRITE_OUT_W(P, HALF)                                                                                           \
     {                                                                                                                  \
-        const double* lv_ = linv + ((P) & 1) * TSZ;                                                                    \
-        double fv_[WO_W / 2];                                                                                          \
-        _Pragma("unroll") for (int m_ = 0; m_ < WO_W / 2; ++m_) {                                                      \
-            const int q = lane + (m_ + (HALF) * (WO_W / 2)) * WO_T;                                                    \
-            const int rr = q / (TB + MCQ_P_MAX), e = q - rr * (TB + MCQ_P_MAX);                                        \
-            const int es = e < TB ? 0 : e - TB;                                                                        \
-            const double a1_ = lv_[rr * TLD + (e < TB ? e : 0)];                                                       \
-            const double a2_ = CTILE((P), es / TB)[rr * TLD + (es % TB)];                                              \
-            fv_[m_] = e < TB ? a1_ : a2_;                                                                              \
+        const int rr_ = lane >> 2, e0_ = 40 * (HALF) + 10 * (lane & 3);                                                \
+        const double* row_ = CROW((P)) + rr_ * TLD;                                                                    \
+        double fv_[WO_W];                                                                                              \
+        _Pragma("unroll") for (int m_ = 0; m_ < WO_W; ++m_) {                                                          \
+            const int e = e0_ + m_;                                                                                    \
+            fv_[m_] = row_[(e >> 4) * TSZ + (e & 15)];                                                                 \
         }                                                                                                              \
-        _Pragma("unroll") for (int m_ = 0; m_ < WO_W / 2; ++m_) {                                                      \
-            const int q = lane + (m_ + (HALF) * (WO_W / 2)) * WO_T;                                                    \
-            const int rr = q / (TB + MCQ_P_MAX), e = q - rr * (TB + MCQ_P_MAX);                                        \
-            const int i = (P) * TB + rr;                                                                               \
-            if (i < ni) L[(size_t)i * MCQ_LLD + MCQ_LBI + e] = fv_[m_];                                                \
+        const int i = (P) * TB + rr_;                                                                                  \
+        if (i < ni) {                                                                                                  \
+            gd2* dst_ = (gd2*)(L + (size_t)i * MCQ_LLD + MCQ_LBI + e0_);                                               \
+            _Pragma("unroll") for (int m_ = 0; m_ < WO_W / 2; ++m_) dst_[m_] = (d2){fv_[2 * m_], fv_[2 * m_ + 1]};     \
         }                                                                                                              \
     }
 
@@ -1265,8 +1306,10 @@ __device__ __forceinline__ int factor_t(const SolveCtx& c, const gdouble* Hsrc, 
         long long tp = FTICK();
         // ---- phase 1 --------------------------------------------------------------------------------------------------------
         if (w0 == 0) {
-            const bool bad = diag_tile_inv(BTILE(J, J), linv + (J & 1) * TSZ, l15);
+            if (MCQ_WORKER_TIMERS) wt_last = (long long)clock64();
+            const bool bad = diag_tile_inv(BTILE(J, J), INVT(J), l15);
             if (bad && lane == 0) dinv[TB] = 1.0;
+            WT(0);
         } else {
             // Tile row J+NTR goes in flight first; the lag work and the write-out of step J-1 follow; only then is tile row
             // J-1+NTR -- fetched at the top of the PREVIOUS step, i.e. one and a half steps ago: the commit never waits on
@@ -1274,6 +1317,7 @@ __device__ __forceinline__ int factor_t(const SolveCtx& c, const gdouble* Hsrc, 
             // -- tile row J-2 of the 6-row border window -- by lag(J-2); lag(J-1) does not touch either, panel(J) needs
             // tile (J+4, J).
             RawEntry pfn[PF_ITEMS];
+            if (MCQ_WORKER_TIMERS) wt_last = (long long)clock64();
             {
                 const int R = J + NTR;
                 if (PF_FAST(R)) {
@@ -1289,7 +1333,9 @@ __device__ __forceinline__ int factor_t(const SolveCtx& c, const gdouble* Hsrc, 
                     for (int u = 0; u < PF_ITEMS; ++u) pfn[u] = tile_row_fetch<MK, SIG>(H, sig, mk, ni, b, p, R, lt + u * PF_THREADS);
                 }
             }
+            WT(0);
             if (J > 0) { LAG_DISPATCH(J - 1) WRITE_OUT_DISPATCH(J - 1) }
+            WT(4);
             if (J > 0) {
                 const int R = J - 1 + NTR;
                 if (PF_FAST(R)) {
@@ -1310,8 +1356,10 @@ __device__ __forceinline__ int factor_t(const SolveCtx& c, const gdouble* Hsrc, 
             }
 #pragma unroll
             for (int u = 0; u < PF_ITEMS; ++u) pf[u] = pfn[u];
+            WT(5);
         }
         lds_barrier();
+        WT(6);
         c.tk[4] += FTICK() - tp; tp = FTICK();
         if (dinv[TB] != 0.0) { fail = 1; break; }
         // ---- phase 2: panel + block column J+1, all on the matrix cores, one tile row per wave ---------------------------------
@@ -1319,7 +1367,7 @@ __device__ __forceinline__ int factor_t(const SolveCtx& c, const gdouble* Hsrc, 
         //   W_w = M C(J, w),   T(J+1+w, J+1) -= Xw X1'.
         // The transposed products leave X in exactly the per-lane layout the update's operands need: no LDS round trip.
         {
-            const double* lv = linv + (J & 1) * TSZ;
+            const double* lv = INVT(J);
             const double* t1 = BTILE(J + 1, J);
             const double* tw = BTILE(J + 1 + w0, J);
             double* cw = CTILE(J, w0);
@@ -1352,7 +1400,12 @@ __device__ __forceinline__ int factor_t(const SolveCtx& c, const gdouble* Hsrc, 
             }
         }
         lds_barrier();
+        WT(7);
         c.tk[5] += FTICK() - tp;
+    }
+    if (MCQ_WORKER_TIMERS && tid == 64 * (MCQ_WORKER_TIMERS & 3)) {     // the value of the switch picks the wave: 1..3 workers, 4: wave 0
+        long long* acc = (long long*)c.w.Z;       // diagnostic build only: the curvature-row scratch doubles as the accumulator
+        for (int q = 0; q < 8; ++q) acc[q] += wt[q];
     }
     if (fail) return MCQ_NOT_PD;
     const long long t_tail = FTICK();
@@ -1525,8 +1578,6 @@ __device__ __noinline__ int factor(const SolveCtx& c, const gdouble* Hsrc, const
 #define LD_THREADS (MCQ_NT - 64)
 #define LD_PAIRS (CH * CLD / 2)                                 /* 16-byte items of a chunk's L rows */
 #define LD_ITEMS ((LD_PAIRS + LD_THREADS - 1) / LD_THREADS)
-typedef double d2 __attribute__((vector_size(16)));
-typedef __attribute__((address_space(1))) d2 gd2;
 
 // Loader item u of thread lt: the 16-byte pair e2 = lt + u * LD_THREADS of the chunk image (row e2 / 40, doubles
 // 2 (e2 % 40) ..+1 of the 80-double LDS row); the chunk image in LDS is the linear array of these pairs.  `goff[u]` (row *
@@ -2805,6 +2856,7 @@ __global__ void __launch_bounds__(MCQ_NT) mcq_solve_kernel(McqBatch B)
     c.direct = B.objective == MCQ_OBJ_SHORTEST_PATH;
     const long long t_kernel0 = TICK();
     const long long c_kernel0 = (long long)clock64();      // shader-clock counter (s_memtime): with ticks[3] the effective clock
+    if (MCQ_WORKER_TIMERS && tid == 64) for (int q = 0; q < 8; ++q) ((long long*)c.w.Z)[q] = 0;
     double* red = g_sm + SM_RED;
     const int nm = B.nmax;
 
@@ -2983,7 +3035,7 @@ __global__ void __launch_bounds__(MCQ_NT) mcq_solve_kernel(McqBatch B)
                 o.second_attempt = c.second_attempt;
                 c.tk[3] = TICK() - t_kernel0;
                 if (!MCQ_FINE_TIMERS) c.tk[6] = (long long)clock64() - c_kernel0;
-                for (int q = 0; q < 8; ++q) o.ticks[q] = c.tk[q];
+                for (int q = 0; q < 8; ++q) o.ticks[q] = MCQ_WORKER_TIMERS ? ((const long long*)c.w.Z)[q] : c.tk[q];
                 *(mcq_info*)c.w.info = o;
             }
         }

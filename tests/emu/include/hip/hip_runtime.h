@@ -186,6 +186,18 @@ inline double __shfl_xor(double v, int m)
     return __shfl(v, (s.cur ^ m) & 63);
 }
 inline int __shfl(int v, int src) { return (int)__shfl((double)v, src); }
+inline unsigned long long __ballot(int pred)
+{
+    hipemu::State& s = hipemu::st();
+    const int t = s.cur, base = t & ~63;
+    s.slot_i[t] = pred ? 1 : 0;
+    hipemu::wave_barrier();
+    unsigned long long m = 0;
+    const int wave_size = (s.nt - base) > 64 ? 64 : (s.nt - base);
+    for (int l = 0; l < wave_size; ++l) if (s.slot_i[base + l]) m |= 1ull << l;
+    hipemu::wave_barrier();
+    return m;
+}
 
 
 // v_permlane32_swap / v_permlane16_swap (gfx950): [0] = new vdst, [1] = new src0.
@@ -240,6 +252,7 @@ inline int hipemu_readlane(int v, int src) { return (int)__shfl((double)v, src);
 #define __builtin_amdgcn_readfirstlane(v) (v)     /* only used on wave-uniform values */
 #define __builtin_amdgcn_sched_barrier(mask) ((void)0)
 #define MCQ_PIN_SVV(sreg, vreg0, vreg1) ((void)0)
+#define MCQ_PIN_SV(sreg, vreg) ((void)0)
 #define __builtin_amdgcn_wave_barrier() hipemu::wave_barrier()
 #define __builtin_amdgcn_fence(...) ((void)0)
 inline int __double2loint(double d) { long long b; memcpy(&b, &d, 8); return (int)(b & 0xffffffffLL); }
