@@ -32,12 +32,14 @@ typedef __attribute__((address_space(1))) d2 gd2;
 #define SM_OVL (SM_S + SPK)                       /* overlay region */
 #define NTRC (NTR + 1)                   /* tile rows of the border window: one more than the band (committed a phase earlier) */
 #define NCT5 (NCT + 1)                   /* tiles of a border-window row slot: the inverse of the step's diagonal tile, then C(., 0..3) */
-#define OVL_SIZE_F (NTR * NTR * TSZ + NTRC * NCT5 * TSZ + 32)
+#define OVL_SIZE_F (NTR * NTR * TSZ + NTRC * NCT5 * TSZ + 32 + 2 * VRING)
 #define OVL_SIZE_S (NBUF * CH * CLD + NRB * CH + VRING)
 #define OVL_SIZE (OVL_SIZE_F > OVL_SIZE_S ? OVL_SIZE_F : OVL_SIZE_S)
 #define SM_BT SM_OVL                              /* band tiles   (NTR x NTR) */
 #define SM_CT (SM_BT + NTR * NTR * TSZ)           /* border window: NTRC row slots of [inverse diagonal tile | C(., 0..3)] */
 #define SM_DINV (SM_CT + NTRC * NCT5 * TSZ)       /* fail flag of the factorisation (slot TB) */
+#define SM_YR (SM_DINV + 32)                      /* forward substitution fused into the factorisation: VRING most recent unknowns ... */
+#define SM_PEND (SM_YR + VRING)                   /* ... and VRING pending sums  - sum_K L(I, K) y_K  of the block rows ahead */
 #define SM_CHUNK SM_OVL                           /* NBUF x CH x CLD */
 #define SM_RHS (SM_CHUNK + NBUF * CH * CLD)       /* NRB x CH */
 #define SM_VR (SM_RHS + NRB * CH)                 /* VRING */
@@ -817,6 +819,9 @@ __global__ void __launch_bounds__(MCQ_NT) mcq_assemble_sp_kernel(McqBatch B)
 #ifndef MCQ_IPM_TOL
 #define MCQ_IPM_TOL 1e-10
 #endif
+#ifndef MCQ_FUSE_FWD
+#define MCQ_FUSE_FWD 1     /* forward substitution of the predictor / active-set solve fused into the factorisation (factor_t) */
+#endif
 struct SolveCtx {
     McqDims d;
     McqWork w;
@@ -1072,8 +1077,13 @@ __device__ __forceinline__ bool diag_tile_inv(const double* d0, double* lv, int 
     return bad;
 }
 
+// `fv` (optional): right-hand side of the solve that follows.  Its interior FORWARD substitution  y_B = L_B^-1 v_B  and the border
+// sums W'y_B are then produced block row by block row during the factorisation itself, by wave 0 in the part of a step where it
+// would otherwise wait for the lag workers (~2200 cycles): everything the tile step of the forward sweep needs -- L(J, J-4 .. J-1),
+// M_J = L_JJ^-1, W_(J-1) -- sits in the LDS window at that moment.  solve(..., fwd_done = true) then starts at the border system:
+// one of the four passes over L per interior-point iteration (and one of two per active-set round) is never streamed from HBM.
 template <bool MK, bool SIG>
-__device__ __forceinline__ int factor_t(const SolveCtx& c, const gdouble* Hsrc, const gdouble* sig, const gschar* mk)
+__device__ __forceinline__ int factor_t(const SolveCtx& c, const gdouble* Hsrc, const gdouble* sig, const gschar* mk, gdouble* fv)
 {
     const int tid = threadIdx.x;
     const int b = c.d.b, p = c.d.p, ni = c.d.ni;
@@ -1090,6 +1100,11 @@ __device__ __forceinline__ int factor_t(const SolveCtx& c, const gdouble* Hsrc, 
 #pragma unroll
     for (int m = 0; m < NCT; ++m) sacc[m] = (v4d){0.0, 0.0, 0.0, 0.0};
     RawEntry pf[PF_ITEMS];
+    double* yring = g_sm + SM_YR;
+    double* pend = g_sm + SM_PEND;
+    double* svx = g_sm + SM_RED;          // 16 doubles: a block row's partial right-hand side on its way to all four lane groups
+    double ff_tacc = 0.0;                 // lane jj of wave 0: (W'y)_jj
+    double ff_rhs = 0.0;                  // lanes 0..15 of wave 0: right-hand side of the block row solved in the NEXT step
     long long wt[8] = {0, 0, 0, 0, 0, 0, 0, 0}, wt_last = 0;
     (void)wt; (void)wt_last;
 
@@ -1114,6 +1129,10 @@ __device__ __forceinline__ int factor_t(const SolveCtx& c, const gdouble* Hsrc, 
         }
     }
     if (tid == 0) dinv[TB] = 0.0;   // fail flag
+    if (fv && w0 == 0) {
+        for (int q = lane; q < VRING; q += 64) { yring[q] = 0.0; pend[q] = 0.0; }
+        ff_rhs = (lane < TB && lane < ni) ? fv[lane] : 0.0;
+    }
     __syncthreads();
 
     // Software-pipelined block loop, two LDS barriers per step.  The critical path of one step is
@@ -1310,6 +1329,60 @@ __device__ __forceinline__ int factor_t(const SolveCtx& c, const gdouble* Hsrc, 
             const bool bad = diag_tile_inv(BTILE(J, J), INVT(J), l15);
             if (bad && lane == 0) dinv[TB] = 1.0;
             WT(0);
+            if (fv) {
+                // ---- forward substitution fused into the factorisation (see the header of factor_t), column-oriented: the tiles
+                //      L(P+1 .. P+4, P) of block column P = J-1 and W_P are all in the window during this phase (they are what the
+                //      lag workers read); a row's own tiles are not (L(J, J-4)'s slot was recycled for L(J, J-1)) ----
+                if (J > 0) {
+                    const int P = J - 1;
+                    double yv[TB];
+                    const double* yp = yring + ((P * TB) & (VRING - 1));
+#pragma unroll
+                    for (int cc = 0; cc < TB; ++cc) yv[cc] = yp[cc];
+                    {   // border sums (W'y)_jj += sum_rr W_P[rr][jj] y_P[rr]: lane = column jj = 16 l4 + l15
+                        const double* wt_ = CTILE(P, l4) + l15;
+                        double a0 = 0.0, a1 = 0.0;
+#pragma unroll
+                        for (int rr = 0; rr < TB; rr += 2) {
+                            a0 += wt_[rr * TLD] * yv[rr];
+                            a1 += wt_[(rr + 1) * TLD] * yv[rr + 1];
+                        }
+                        ff_tacc += a0 + a1;
+                    }
+                    {   // pending sums of the block rows P+1 .. P+4 -= L(P+1+l4, P) y_P: lane (row l15, group l4)
+                        const double* lt_ = (l4 == 0 ? BTILE(P + 1, P + 2) : BTILE(P + 1 + l4, P)) + l15 * TLD;   // LTILE(1 + l4, P)
+                        double a0 = 0.0, a1 = 0.0;
+#pragma unroll
+                        for (int cc = 0; cc < TB; cc += 2) {
+                            a0 += lt_[cc] * yv[cc];
+                            a1 += lt_[cc + 1] * yv[cc + 1];
+                        }
+                        pend[((P + 1 + l4) * TB + l15) & (VRING - 1)] -= a0 + a1;
+                    }
+                }
+                __builtin_amdgcn_wave_barrier();
+                // block row J:  y_J = M_J (v_J + pending), M_J = L_JJ^-1 just written by this wave
+                const int iJ = J * TB + l15;
+                const double sv = ff_rhs + pend[iJ & (VRING - 1)];            // used in lanes 0..15
+                {
+                    const int ip = iJ + TB;
+                    ff_rhs = (lane < TB && ip < ni) ? fv[ip] : 0.0;           // the next step's right-hand side goes in flight now
+                }
+                __builtin_amdgcn_wave_barrier();
+                if (lane < TB) { svx[lane] = sv; pend[iJ & (VRING - 1)] = 0.0; }
+                __builtin_amdgcn_wave_barrier();
+                // over all 64 lanes: group l4 takes columns 4 l4 .. 4 l4 + 3 of row l15 of M_J
+                const double* mrow = INVT(J) + l15 * TLD + 4 * l4;
+                const double y = row4_sum_low16((mrow[0] * svx[4 * l4] + mrow[1] * svx[4 * l4 + 1])
+                                                + (mrow[2] * svx[4 * l4 + 2] + mrow[3] * svx[4 * l4 + 3]));
+                __builtin_amdgcn_wave_barrier();
+                if (lane < TB) {
+                    yring[iJ & (VRING - 1)] = y;
+                    if (iJ < ni) fv[iJ] = y;
+                }
+                __builtin_amdgcn_wave_barrier();
+                WT(1);
+            }
         } else {
             // Tile row J+NTR goes in flight first; the lag work and the write-out of step J-1 follow; only then is tile row
             // J-1+NTR -- fetched at the top of the PREVIOUS step, i.e. one and a half steps ago: the commit never waits on
@@ -1412,6 +1485,20 @@ __device__ __forceinline__ int factor_t(const SolveCtx& c, const gdouble* Hsrc, 
     // drain: what the last step still owes
     if (nblk > 0) {
         if (w0 > 0) { LAG_DISPATCH(nblk - 1) WRITE_OUT_DISPATCH(nblk - 1) }
+        else if (fv) {
+            // border sums of the last block row, then (W'y) to where solve() expects the loader waves' partial sums
+            const int P = nblk - 1;
+            const double* wt_ = CTILE(P, l4) + l15;
+            const double* yp = yring + ((P * TB) & (VRING - 1));
+            double a0 = 0.0;
+#pragma unroll
+            for (int rr = 0; rr < TB; ++rr) a0 += wt_[rr * TLD] * yp[rr];
+            ff_tacc += a0;
+            double* part = g_sm + SM_PART;
+            part[1 * 64 + lane] = ff_tacc;
+            part[2 * 64 + lane] = 0.0;
+            part[3 * 64 + lane] = 0.0;
+        }
     }
 #undef LAG_WORK
 #undef PF_FAST
@@ -1555,12 +1642,12 @@ __device__ __forceinline__ int factor_t(const SolveCtx& c, const gdouble* Hsrc, 
     return 0;
 }
 
-__device__ __noinline__ int factor(const SolveCtx& c, const gdouble* Hsrc, const gdouble* sig, const gschar* mk)
+__device__ __noinline__ int factor(const SolveCtx& c, const gdouble* Hsrc, const gdouble* sig, const gschar* mk, gdouble* fv)
 {
     // the configurations the solver uses: interior point (diagonal added; variables with lo == hi masked -- usually there are
-    // none, then no mask bytes are fetched at all) and active set (mask only)
-    if (sig) return mk ? factor_t<true, true>(c, Hsrc, sig, mk) : factor_t<false, true>(c, Hsrc, sig, mk);
-    return factor_t<true, false>(c, Hsrc, sig, mk);
+    // none, then no mask bytes are fetched at all) and active set (mask only); fv: see factor_t
+    if (sig) return mk ? factor_t<true, true>(c, Hsrc, sig, mk, fv) : factor_t<false, true>(c, Hsrc, sig, mk, fv);
+    return factor_t<true, false>(c, Hsrc, sig, mk, fv);
 }
 
 // ---- solve  M v = rhs  in place (v in global memory) with the factor produced by factor() ---------------------------
@@ -1790,7 +1877,9 @@ __device__ __noinline__ void sweep_bwd_wave0(const SolveCtx& c, gdouble* v)
 #undef BW_STEP
 }
 
-__device__ __noinline__ void solve(const SolveCtx& c, gdouble* v)
+// fwd_done: the interior forward substitution and the border sums W'y were produced by factor(..., fv = v) (v holds y_B, the sums
+// sit where the loader waves leave theirs): start at the border system.
+__device__ __noinline__ void solve(const SolveCtx& c, gdouble* v, bool fwd_done)
 {
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     const int l15 = lane & 15, l4 = lane >> 4;
@@ -1834,6 +1923,7 @@ __device__ __noinline__ void solve(const SolveCtx& c, gdouble* v)
     }
 
     __syncthreads();
+    if (!fwd_done) {
     for (int q = tid; q < VRING; q += MCQ_NT) vring[q] = 0.0;
     // ================= forward substitution, interior rows =================
     // a tile needs only its own rows: chunk cq resident, cq+1 committed one step ahead, cq+2 committed during step cq.
@@ -1872,6 +1962,7 @@ __device__ __noinline__ void solve(const SolveCtx& c, gdouble* v)
             part[wv * 64 + 16 * u + 2 * c8] = tacc[u][0];
             part[wv * 64 + 16 * u + 2 * c8 + 1] = tacc[u][1];
         }
+    }
     }
     __syncthreads();
     // ================= border:  t = v_D - W' y_B,  x_D = L_S^-T (L_S^-1 t)  as two LDS mat-vecs =================
@@ -1987,17 +2078,17 @@ __device__ __noinline__ void gradient(SolveCtx& c, const gdouble* x, const gdoub
     c.tk[2] += TICK() - t0;
 }
 
-__device__ __forceinline__ int timed_factor(SolveCtx& c, const gdouble* src, const gdouble* sig, const gschar* mk)
+__device__ __forceinline__ int timed_factor(SolveCtx& c, const gdouble* src, const gdouble* sig, const gschar* mk, gdouble* fv = nullptr)
 {
     const long long t0 = TICK();
-    const int r = factor(c, src, sig, mk);
+    const int r = factor(c, src, sig, mk, fv);
     c.tk[0] += TICK() - t0;
     return r;
 }
-__device__ __forceinline__ void timed_solve(SolveCtx& c, gdouble* v)
+__device__ __forceinline__ void timed_solve(SolveCtx& c, gdouble* v, bool fwd_done = false)
 {
     const long long t0 = TICK();
-    solve(c, v);
+    solve(c, v, fwd_done);
     c.tk[1] += TICK() - t0;
 }
 
@@ -2381,9 +2472,12 @@ __device__ __noinline__ int ipm_box(SolveCtx& c, const McqBatch& B, const SolveS
         }
 
         // ---- factorisation, predictor solve -----------------------------------------------------------------------------
-        const int fs = timed_factor(c, c.w.H, VEC(c.w, c.nm, V_SIG), any_fixed ? c.w.state : nullptr);
+        // the predictor's right-hand side (written in pass 1) rides through the factorisation: its forward substitution is done
+        // when the factor is (MCQ_FUSE_FWD = 0: the plain sequence)
+        const int fs = timed_factor(c, c.w.H, VEC(c.w, c.nm, V_SIG), any_fixed ? c.w.state : nullptr,
+                                    MCQ_FUSE_FWD ? VEC(c.w, c.nm, V_RHS) : nullptr);
         if (fs != 0) return fs;
-        timed_solve(c, VEC(c.w, c.nm, V_RHS));
+        timed_solve(c, VEC(c.w, c.nm, V_RHS), MCQ_FUSE_FWD != 0);
 
         // ---- pass 2: affine step lengths, centring parameter, corrector right-hand side (one load phase) --------------
         double smu;
@@ -2701,9 +2795,9 @@ __device__ __noinline__ int active_set(SolveCtx& c, const McqBatch& B, bool with
         }
         gradient(c, T1, nullptr, T0, T2);       // T2 = H x_A + f
         for (int i = tid; i < n; i += MCQ_NT) RHS[i] = ST[i] == 0 ? -T2[i] : T1[i];
-        const int fs = timed_factor(c, c.w.H, nullptr, ST);
+        const int fs = timed_factor(c, c.w.H, nullptr, ST, MCQ_FUSE_FWD ? RHS : nullptr);
         if (fs != 0) return fs;
-        timed_solve(c, RHS);                    // x0 (pinned rows carry their bounds)
+        timed_solve(c, RHS, MCQ_FUSE_FWD != 0);   // x0 (pinned rows carry their bounds)
         if (nk > 0) {
             // column q of S = E_K (M^-1 E_kq' restricted to the free set): one banded solve per active row, nothing but one
             // scratch vector kept (x = x0 - M^-1 E_K' mu costs one more solve afterwards instead of nk stored columns)
