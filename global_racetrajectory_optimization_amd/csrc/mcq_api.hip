@@ -7,6 +7,7 @@
 
 #include <stddef.h>
 #include <stdio.h>
+#include <stdlib.h>
 #include <string.h>
 
 #include <string>
@@ -54,6 +55,9 @@ struct mcq_handle {
     size_t iqp_batch = 0;
     void* pin = nullptr;                              // pinned host staging (packing of the host-buffer entries)
     size_t pin_bytes = 0;
+    bool poison = false;    // MCQ_POISON=1 (debugging aid): every workspace / staging allocation is filled with 0xFF bytes (NaN as a
+                            // double), so that a read of memory nothing has written shows up as a wrong result on every box instead of
+                            // on the rare one whose recycled memory happens to hold garbage
     long long ws_bytes = 0;
     bool smem_attr_set = false;
     double* vel_scratch = nullptr;      // lap-doubled profiles of mcq_vel_profile_device, [2 nmax][batch]
@@ -102,6 +106,10 @@ extern "C" int mcq_create(int device_id, mcq_handle** out)
     HIP_TRY(hipSetDevice(device_id));
     mcq_handle* h = new mcq_handle();
     h->device = device_id;
+    {
+        const char* e = getenv("MCQ_POISON");
+        h->poison = e && e[0] == '1';
+    }
     hipError_t e = hipStreamCreate(&h->stream);
     for (int k = 0; k < 5 && e == hipSuccess; ++k) e = hipEventCreate(&h->ev[k]);
     if (e != hipSuccess) {
@@ -168,6 +176,15 @@ static int ensure_ws(mcq_handle* h, size_t batch, size_t nmax)
     HIP_TRY(hipMalloc((void**)&h->state2, elems));
     HIP_TRY(hipMemsetAsync(h->state, 0, elems, h->stream));
     HIP_TRY(hipMemsetAsync(h->state2, 0, elems, h->stream));
+    if (h->poison) {
+        HIP_TRY(hipMemsetAsync(h->Eb, 0xff, elems * MCQ_ELD * sizeof(double), h->stream));
+        HIP_TRY(hipMemsetAsync(h->Et, 0xff, elems * MCQ_ELD * sizeof(double), h->stream));
+        HIP_TRY(hipMemsetAsync(h->Db, 0xff, elems * MCQ_ELD * sizeof(double), h->stream));
+        HIP_TRY(hipMemsetAsync(h->H, 0xff, elems * MCQ_HLD * sizeof(double), h->stream));
+        HIP_TRY(hipMemsetAsync(h->L, 0xff, elems * MCQ_LLD * sizeof(double), h->stream));
+        HIP_TRY(hipMemsetAsync(h->vec, 0xff, elems * MCQ_NVEC * sizeof(double), h->stream));
+        HIP_TRY(hipMemsetAsync(h->Z, 0xff, (elems + batch * (size_t)MCQ_KMAX * MCQ_KMAX) * sizeof(double), h->stream));
+    }
     h->cap_elems = elems;
     h->cap_batch = batch;
     h->ws_bytes = (long long)(elems * ((3 * MCQ_ELD + MCQ_HLD + MCQ_LLD + MCQ_NVEC + 1) * sizeof(double) + 2) +
@@ -191,6 +208,12 @@ static int ensure_stage(mcq_handle* h, size_t batch, size_t nmax)
     HIP_TRY(hipMalloc((void**)&h->d_n, batch * sizeof(int)));
     HIP_TRY(hipMalloc((void**)&h->d_status, batch * sizeof(int)));
     HIP_TRY(hipMalloc((void**)&h->d_info, batch * sizeof(mcq_info)));
+    if (h->poison) {
+        HIP_TRY(hipMemsetAsync(h->d_ref, 0xff, elems * 4 * sizeof(double), h->stream));
+        HIP_TRY(hipMemsetAsync(h->d_nv, 0xff, elems * 2 * sizeof(double), h->stream));
+        HIP_TRY(hipMemsetAsync(h->d_sc, 0xff, elems * sizeof(double), h->stream));
+        HIP_TRY(hipMemsetAsync(h->d_alpha, 0xff, elems * sizeof(double), h->stream));
+    }
     h->stage_elems = elems;
     h->stage_batch = batch;
     return 0;
@@ -205,6 +228,7 @@ static int launch(mcq_handle* h, McqBatch& B, const mcq_opts& o)
     B.refine_steps = o.refine_steps;
     B.check_kappa = o.check_kappa;
     B.objective = o.objective;
+    B.poison_lds = h->poison ? 1 : 0;
     // warm start: only the working sets mcq_relinearise_device carried over for exactly this batch layout
     B.warm = (o.warm_start > 0 && h->state2_valid && !B.prep_only && h->state2_batch == B.batch && h->state2_nmax == B.nmax)
                  ? h->state2 : nullptr;
@@ -621,6 +645,7 @@ static int ensure_pin(mcq_handle* h, size_t bytes)
     h->pin = nullptr;
     h->pin_bytes = 0;
     HIP_TRY(hipHostMalloc(&h->pin, bytes, hipHostMallocDefault));
+    if (h->poison) memset(h->pin, 0xff, bytes);
     h->pin_bytes = bytes;
     return 0;
 }

@@ -125,6 +125,7 @@ struct McqBatch {
     const double* w_veh_list;
     int band_e, max_ipm_iter, max_as_iter, refine_steps, check_kappa;
     const signed char* warm; // [batch][nmax] working set to start the exchange from (IQP passes 2+), or nullptr (cold: interior point)
+    int poison_lds;         // MCQ_POISON=1 (debugging aid): the solver kernel starts from an LDS full of NaNs, like the workspaces
     int objective;          // MCQ_OBJ_*: shortest path = H and f written directly by mcq_assemble_sp_kernel (Eb holds the three
                             // diagonals of H, the gradient is H x + f), no curvature rows, no curvature-error post-check
 };

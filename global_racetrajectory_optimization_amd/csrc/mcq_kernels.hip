@@ -819,6 +819,14 @@ __global__ void __launch_bounds__(MCQ_NT) mcq_assemble_sp_kernel(McqBatch B)
 #ifndef MCQ_IPM_TOL
 #define MCQ_IPM_TOL 1e-10
 #endif
+// -DMCQ_SKEW=k (diagnostic builds, scripts/gpu_variants.sh): one group of waves sleeps ~8000 cycles at one point of every factorisation
+// step (1: wave 0 / 2: the lag workers at the top of phase 1, 3: wave 0 behind the diagonal tile, 4 / 5: top of phase 2) -- an
+// ordering assumption between wave 0 and the lag workers that only holds by timing fails reproducibly under one of them.
+// (Stale-memory bugs are a different tool: MCQ_POISON=1, McqBatch::poison_lds.)
+#ifndef MCQ_SKEW
+#define MCQ_SKEW 0
+#endif
+#define SKEW(k, cond) do { if (MCQ_SKEW == (k) && (cond)) __builtin_amdgcn_s_sleep(127); } while (0)
 #ifndef MCQ_FUSE_FWD
 #define MCQ_FUSE_FWD 1     /* forward substitution of the predictor / active-set solve fused into the factorisation (factor_t) */
 #endif
@@ -1077,6 +1085,63 @@ __device__ __forceinline__ bool diag_tile_inv(const double* d0, double* lv, int 
     return bad;
 }
 
+// One step of the forward substitution fused into the factorisation (wave 0, phase 1 of step J; see the header of factor_t).
+__device__ __forceinline__ void fused_fwd_step(int J, gdouble* fv, int ni, double* bt, double* ct, double* yring, double* pend, double* svx,
+                                               int lane, int l15, int l4, double& ff_tacc, double& ff_rhs)
+{
+    // ---- forward substitution fused into the factorisation (see the header of factor_t), column-oriented: the tiles
+    //      L(P+1 .. P+4, P) of block column P = J-1 and W_P are all in the window during this phase (they are what the
+    //      lag workers read); a row's own tiles are not (L(J, J-4)'s slot was recycled for L(J, J-1)) ----
+    if (J > 0) {
+        const int P = J - 1;
+        double yv[TB];
+        const double* yp = yring + ((P * TB) & (VRING - 1));
+#pragma unroll
+        for (int cc = 0; cc < TB; ++cc) yv[cc] = yp[cc];
+        {   // border sums (W'y)_jj += sum_rr W_P[rr][jj] y_P[rr]: lane = column jj = 16 l4 + l15
+            const double* wt_ = CTILE(P, l4) + l15;
+            double a0 = 0.0, a1 = 0.0;
+#pragma unroll
+            for (int rr = 0; rr < TB; rr += 2) {
+                a0 += wt_[rr * TLD] * yv[rr];
+                a1 += wt_[(rr + 1) * TLD] * yv[rr + 1];
+            }
+            ff_tacc += a0 + a1;
+        }
+        {   // pending sums of the block rows P+1 .. P+4 -= L(P+1+l4, P) y_P: lane (row l15, group l4)
+            const double* lt_ = (l4 == 0 ? BTILE(P + 1, P + 2) : BTILE(P + 1 + l4, P)) + l15 * TLD;   // LTILE(1 + l4, P)
+            double a0 = 0.0, a1 = 0.0;
+#pragma unroll
+            for (int cc = 0; cc < TB; cc += 2) {
+                a0 += lt_[cc] * yv[cc];
+                a1 += lt_[cc + 1] * yv[cc + 1];
+            }
+            pend[((P + 1 + l4) * TB + l15) & (VRING - 1)] -= a0 + a1;
+        }
+    }
+    __builtin_amdgcn_wave_barrier();
+    // block row J:  y_J = M_J (v_J + pending), M_J = L_JJ^-1 just written by this wave
+    const int iJ = J * TB + l15;
+    const double sv = ff_rhs + pend[iJ & (VRING - 1)];            // used in lanes 0..15
+    {
+        const int ip = iJ + TB;
+        ff_rhs = (lane < TB && ip < ni) ? fv[ip] : 0.0;  // the next step's right-hand side goes in flight now
+    }
+    __builtin_amdgcn_wave_barrier();
+    if (lane < TB) { svx[lane] = sv; pend[iJ & (VRING - 1)] = 0.0; }
+    __builtin_amdgcn_wave_barrier();
+    // over all 64 lanes: group l4 takes columns 4 l4 .. 4 l4 + 3 of row l15 of M_J
+    const double* mrow = INVT(J) + l15 * TLD + 4 * l4;
+    const double y = row4_sum_low16((mrow[0] * svx[4 * l4] + mrow[1] * svx[4 * l4 + 1])
+                                    + (mrow[2] * svx[4 * l4 + 2] + mrow[3] * svx[4 * l4 + 3]));
+    __builtin_amdgcn_wave_barrier();
+    if (lane < TB) {
+        yring[iJ & (VRING - 1)] = y;
+        if (iJ < ni) fv[iJ] = y;
+    }
+    __builtin_amdgcn_wave_barrier();
+}
+
 // `fv` (optional): right-hand side of the solve that follows.  Its interior FORWARD substitution  y_B = L_B^-1 v_B  and the border
 // sums W'y_B are then produced block row by block row during the factorisation itself, by wave 0 in the part of a step where it
 // would otherwise wait for the lag workers (~2200 cycles): everything the tile step of the forward sweep needs -- L(J, J-4 .. J-1),
@@ -1324,63 +1389,16 @@ __device__ __forceinline__ int factor_t(const SolveCtx& c, const gdouble* Hsrc, 
     for (int J = 0; J < nblk; ++J) {
         long long tp = FTICK();
         // ---- phase 1 --------------------------------------------------------------------------------------------------------
+        SKEW(1, w0 == 0);
+        SKEW(2, w0 > 0);
         if (w0 == 0) {
             if (MCQ_WORKER_TIMERS) wt_last = (long long)clock64();
             const bool bad = diag_tile_inv(BTILE(J, J), INVT(J), l15);
             if (bad && lane == 0) dinv[TB] = 1.0;
             WT(0);
+            SKEW(3, true);
             if (fv) {
-                // ---- forward substitution fused into the factorisation (see the header of factor_t), column-oriented: the tiles
-                //      L(P+1 .. P+4, P) of block column P = J-1 and W_P are all in the window during this phase (they are what the
-                //      lag workers read); a row's own tiles are not (L(J, J-4)'s slot was recycled for L(J, J-1)) ----
-                if (J > 0) {
-                    const int P = J - 1;
-                    double yv[TB];
-                    const double* yp = yring + ((P * TB) & (VRING - 1));
-#pragma unroll
-                    for (int cc = 0; cc < TB; ++cc) yv[cc] = yp[cc];
-                    {   // border sums (W'y)_jj += sum_rr W_P[rr][jj] y_P[rr]: lane = column jj = 16 l4 + l15
-                        const double* wt_ = CTILE(P, l4) + l15;
-                        double a0 = 0.0, a1 = 0.0;
-#pragma unroll
-                        for (int rr = 0; rr < TB; rr += 2) {
-                            a0 += wt_[rr * TLD] * yv[rr];
-                            a1 += wt_[(rr + 1) * TLD] * yv[rr + 1];
-                        }
-                        ff_tacc += a0 + a1;
-                    }
-                    {   // pending sums of the block rows P+1 .. P+4 -= L(P+1+l4, P) y_P: lane (row l15, group l4)
-                        const double* lt_ = (l4 == 0 ? BTILE(P + 1, P + 2) : BTILE(P + 1 + l4, P)) + l15 * TLD;   // LTILE(1 + l4, P)
-                        double a0 = 0.0, a1 = 0.0;
-#pragma unroll
-                        for (int cc = 0; cc < TB; cc += 2) {
-                            a0 += lt_[cc] * yv[cc];
-                            a1 += lt_[cc + 1] * yv[cc + 1];
-                        }
-                        pend[((P + 1 + l4) * TB + l15) & (VRING - 1)] -= a0 + a1;
-                    }
-                }
-                __builtin_amdgcn_wave_barrier();
-                // block row J:  y_J = M_J (v_J + pending), M_J = L_JJ^-1 just written by this wave
-                const int iJ = J * TB + l15;
-                const double sv = ff_rhs + pend[iJ & (VRING - 1)];            // used in lanes 0..15
-                {
-                    const int ip = iJ + TB;
-                    ff_rhs = (lane < TB && ip < ni) ? fv[ip] : 0.0;           // the next step's right-hand side goes in flight now
-                }
-                __builtin_amdgcn_wave_barrier();
-                if (lane < TB) { svx[lane] = sv; pend[iJ & (VRING - 1)] = 0.0; }
-                __builtin_amdgcn_wave_barrier();
-                // over all 64 lanes: group l4 takes columns 4 l4 .. 4 l4 + 3 of row l15 of M_J
-                const double* mrow = INVT(J) + l15 * TLD + 4 * l4;
-                const double y = row4_sum_low16((mrow[0] * svx[4 * l4] + mrow[1] * svx[4 * l4 + 1])
-                                                + (mrow[2] * svx[4 * l4 + 2] + mrow[3] * svx[4 * l4 + 3]));
-                __builtin_amdgcn_wave_barrier();
-                if (lane < TB) {
-                    yring[iJ & (VRING - 1)] = y;
-                    if (iJ < ni) fv[iJ] = y;
-                }
-                __builtin_amdgcn_wave_barrier();
+                fused_fwd_step(J, fv, ni, bt, ct, yring, pend, svx, lane, l15, l4, ff_tacc, ff_rhs);
                 WT(1);
             }
         } else {
@@ -1435,6 +1453,8 @@ __device__ __forceinline__ int factor_t(const SolveCtx& c, const gdouble* Hsrc, 
         WT(6);
         c.tk[4] += FTICK() - tp; tp = FTICK();
         if (dinv[TB] != 0.0) { fail = 1; break; }
+        SKEW(4, w0 == 0);
+        SKEW(5, w0 > 0);
         // ---- phase 2: panel + block column J+1, all on the matrix cores, one tile row per wave ---------------------------------
         //   X1' = M T(J+1,J)'  (every wave: the column-form operand of the update),   Xw' = M T(J+1+w,J)'  (L(J+1+w, J) = Xw),
         //   W_w = M C(J, w),   T(J+1+w, J+1) -= Xw X1'.
@@ -2020,6 +2040,14 @@ __device__ __noinline__ void solve(const SolveCtx& c, gdouble* v, bool fwd_done)
     if (nch > 0) {
         const int cl = nch - 1;
         if (wv > 0) {
+            // The top tiles of the sweep read the ring slot of chunk cl + 1 (rows beyond the last one: zeros times zeros).  The
+            // forward sweep leaves zeros there; when it ran inside the factorisation the slot still holds the factorisation's tile
+            // window -- including the tiles' padding words, which nothing ever wrote (stale LDS of whatever ran on this CU
+            // before: a NaN bit pattern there turned every unknown into NaN on some boxes) -- so the slot is cleared first.
+            if (fwd_done) {
+                d2* dst = (d2*)(chunk + ((cl + 1) % NBUF) * CH * CLD);
+                for (int e2 = lt; e2 < LD_PAIRS; e2 += LD_THREADS) dst[e2] = (d2){0.0, 0.0};
+            }
             chunk_fetch(L, v, ni, b, cl, cl, lt, goff, regs, rreg);
             chunk_commit(chunk, rring, cl, cl, lt, regs, rreg);
             chunk_fetch(L, v, ni, b, -1, cl - 1, lt, goff, regs, rreg);
@@ -2948,6 +2976,10 @@ __global__ void __launch_bounds__(MCQ_NT) mcq_solve_kernel(McqBatch B)
     c.last_step = 0.0;
     c.refine_rounds = c.second_attempt = 0;
     c.direct = B.objective == MCQ_OBJ_SHORTEST_PATH;
+    if (B.poison_lds) {      // debugging aid: whatever a phase reads from LDS without having written it shows up as NaN on every box
+        for (int q = tid; q < SM_TOTAL; q += MCQ_NT) g_sm[q] = __longlong_as_double(-1LL);
+        __syncthreads();
+    }
     const long long t_kernel0 = TICK();
     const long long c_kernel0 = (long long)clock64();      // shader-clock counter (s_memtime): with ticks[3] the effective clock
     if (MCQ_WORKER_TIMERS && tid == 64) for (int q = 0; q < 8; ++q) ((long long*)c.w.Z)[q] = 0;

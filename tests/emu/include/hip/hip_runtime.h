@@ -137,7 +137,11 @@ inline void run_block(F&& f, unsigned nt, size_t smem)
         const long long sw0 = s.switches;
         const int alive0 = s.alive;
         const unsigned g0 = s.bar_gen;
-        for (unsigned t = 0; t < nt; ++t) {
+        // HIPEMU_REVERSE=1: the work-items of a block take their turns in reverse order (the LAST wave runs a phase first): an
+        // ordering bug between waves that the natural order hides shows up deterministically
+        static const bool reverse = getenv("HIPEMU_REVERSE") && getenv("HIPEMU_REVERSE")[0] == '1';
+        for (unsigned tt = 0; tt < nt; ++tt) {
+            const unsigned t = reverse ? nt - 1 - tt : tt;
             if (s.done[t]) continue;
             s.cur = (int)t;
             tidx().x = t;
@@ -251,12 +255,14 @@ inline int hipemu_readlane(int v, int src) { return (int)__shfl((double)v, src);
 #define __builtin_amdgcn_s_barrier() hipemu::block_barrier()
 #define __builtin_amdgcn_readfirstlane(v) (v)     /* only used on wave-uniform values */
 #define __builtin_amdgcn_sched_barrier(mask) ((void)0)
+#define __builtin_amdgcn_s_sleep(n) ((void)0)
 #define MCQ_PIN_SVV(sreg, vreg0, vreg1) ((void)0)
 #define MCQ_PIN_SV(sreg, vreg) ((void)0)
 #define __builtin_amdgcn_wave_barrier() hipemu::wave_barrier()
 #define __builtin_amdgcn_fence(...) ((void)0)
 inline int __double2loint(double d) { long long b; memcpy(&b, &d, 8); return (int)(b & 0xffffffffLL); }
 inline int __double2hiint(double d) { long long b; memcpy(&b, &d, 8); return (int)((b >> 32) & 0xffffffffLL); }
+inline double __longlong_as_double(long long v) { double d; memcpy(&d, &v, 8); return d; }
 inline double __hiloint2double(int hi, int lo)
 {
     long long b = ((long long)(unsigned)hi << 32) | (unsigned)lo;

@@ -482,3 +482,27 @@ def test_thirteen_active_curvature_rows_with_refinement(emu, golden):
     assert st[0] == 0 and nk == 13 and inf[0]["n_active_kappa"] == nk
     assert np.max(np.abs(al[0] - a_ref)) < 1e-9 and abs(curv[0] - err_ref) < 1e-10
     assert abs(inf[0]["kappa_max"] - 0.06) < 1e-12 and inf[0]["refine_rounds"] >= 1
+
+
+def test_poisoned_workspaces_and_lds(emu, emu_lib, golden, monkeypatch):
+    """MCQ_POISON=1: every workspace / staging allocation and the solver kernel's whole LDS start out as NaN bit patterns, so anything a
+    phase reads without having written it surfaces on every run instead of on the boxes whose stale memory happens to hold a NaN
+    (round 2: the backward sweep behind the fused forward substitution read a chunk-ring slot only the plain forward sweep clears)."""
+    monkeypatch.setenv("MCQ_POISON", "1")
+    eng = engine.Engine(0, lib_path=emu_lib)
+    try:
+        names = ("rounded_rectangle", "handling_track")
+        al, curv, st, info = eng.solve_batch([_problem(golden[k]) for k in names])
+        for k, name in enumerate(names):
+            assert st[k] == 0 and np.max(np.abs(al[k] - golden[name]["alpha"])) < 1e-9
+        # curvature rows active (the exchange + refinement path) and a warm-started IQP under the same poison
+        g = golden["rounded_rectangle"]
+        al2, curv2, st2, _ = eng.solve_batch([dict(_problem(g), kappa_bound=0.10)])
+        al3, curv3, st3, _ = emu.solve_batch([dict(_problem(g), kappa_bound=0.10)])
+        assert st2[0] == st3[0] and np.array_equal(al2[0], al3[0]) and np.array_equal(curv2, curv3)     # bitwise: nothing stale was read
+        from global_racetrajectory_optimization_amd.trajectory_planning_helpers import iqp_handler as iq
+        out = iq.iqp_handler_batch([dict(reftrack=g["reftrack"].copy(), normvectors=g["normvec"], scaling=g["scaling"])], 0.12, 3.4,
+                                   3.0, 3, 0.01, engine=eng, device_resident=True, warm_start=True)
+        assert np.max(np.abs(out[0][0] - g["iqp_alpha"])) < 1e-8
+    finally:
+        eng.close()

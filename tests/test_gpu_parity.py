@@ -746,3 +746,27 @@ def test_many_active_curvature_rows_against_dense_gi(gpu_engine, golden):
         tph_ref.opt_min_curv(g["reftrack"], g["normvec"], A, 0.04, 3.4)
     with pytest.raises(ValueError, match="constraints are inconsistent, no solution"):
         tph.opt_min_curv.opt_min_curv(g["reftrack"], g["normvec"], A, 0.04, 3.4)
+
+
+def test_poisoned_workspaces_and_lds_bitwise(gpu_engine, golden, monkeypatch):
+    """MCQ_POISON=1 (workspaces, staging buffers and the solver kernel's LDS start out as NaN patterns): the golden tracks, a
+    curvature-row case, a 64-problem full-size batch and a warm-started IQP come out BITWISE as on the unpoisoned engine -- nothing
+    the kernels read was left over from whatever ran on the CU before (round 2: the fused forward substitution's backward sweep)."""
+    monkeypatch.setenv("MCQ_POISON", "1")
+    eng = engine.Engine(0)
+    try:
+        probs = [_problem(golden[k]) for k in golden] + [dict(_problem(golden["rounded_rectangle"]), kappa_bound=0.10)]
+        ref, nv, sc = synthetic.oval_batch(64, 2000, first=5)
+        probs += [dict(reftrack=ref[k], normvec=nv[k], scaling=sc[k], kappa_bound=0.12, w_veh=2.0) for k in range(64)]
+        a1, c1, s1, _ = eng.solve_batch(probs)
+        a0, c0, s0, _ = gpu_engine.solve_batch(probs)
+        assert list(s1) == list(s0) and np.array_equal(c1, c0)
+        assert all(np.array_equal(x, y) for x, y in zip(a1, a0))
+        for k, name in enumerate(golden):
+            assert s1[k] == 0 and np.max(np.abs(a1[k] - golden[name]["alpha"])) < ALPHA_TOL
+        tracks = [dict(reftrack=ref[k].copy(), normvectors=nv[k], scaling=sc[k]) for k in range(8)]
+        o1 = tph.iqp_handler.iqp_handler_batch(tracks, 0.12, 2.0, 3.0, 4, 0.01, engine=eng, device_resident=True, warm_start=True)
+        o0 = tph.iqp_handler.iqp_handler_batch(tracks, 0.12, 2.0, 3.0, 4, 0.01, engine=gpu_engine, device_resident=True, warm_start=True)
+        assert all(np.array_equal(x[0], y[0]) and np.array_equal(x[1], y[1]) for x, y in zip(o1, o0))
+    finally:
+        eng.close()
