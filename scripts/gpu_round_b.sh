@@ -8,6 +8,9 @@ cd $R
 timeout 1500 python -m pytest tests -m gpu -q --durations=8 > gpurun_out/${T}_pytest.log 2>&1
 echo "pytest rc $?" >> gpurun_out/${T}_pytest.log
 tail -12 gpurun_out/${T}_pytest.log
+if [ -d scratch_ft/reference ]; then   # BASELINE config 1 on the real library: the untouched main_globaltraj.py, stdout kept
+  timeout 600 python -m pytest tests/test_harness.py -m gpu -s -q > gpurun_out/${T}_harness_berlin.log 2>&1; tail -2 gpurun_out/${T}_harness_berlin.log
+fi
 timeout 900 python bench.py --steps 10 --warmup 2 > gpurun_out/${T}_bench.json 2> gpurun_out/${T}_bench.err
 echo "bench rc $?"; cut -c1-300 gpurun_out/${T}_bench.json
 timeout 300 python bench.py --steps 5 --warmup 1 --force-collective --no-extras > gpurun_out/${T}_bench_fc.json 2> gpurun_out/${T}_bench_fc.err
