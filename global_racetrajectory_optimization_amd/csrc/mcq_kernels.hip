@@ -1051,6 +1051,13 @@ __device__ __forceinline__ v4d mfma16(const double a[4], const double b[4], v4d 
 // (a[k] = L[i][k]); left-looking by columns, the multipliers L[j][k] are v_readlane broadcasts.  The same multipliers give
 // the inverse M = L^-1 by rows for free: lane c holds column c of M,  M[j][c] = rs_j ( [j == c] - sum_{k<j} L[j][k] M[k][c] ).
 // Writes M (row-major, upper part zero) to `lv`; returns true if a pivot is not positive.
+// Broadcast of lane N of every 16-lane row to the whole row: one v_mov_b64_dpp row_newbcast (full-rate VALU, no SGPR round trip).
+template <int N> __device__ __forceinline__ double bcast_row16(double v)
+{
+    return __builtin_amdgcn_update_dpp(0.0, v, 0x150 + N, 0xf, 0xf, true);
+}
+
+#ifdef MCQ_DIAG_READLANE
 __device__ __forceinline__ bool diag_tile_inv(const double* d0, double* lv, int l15)
 {
     double a[TB], m[TB];
@@ -1084,10 +1091,62 @@ __device__ __forceinline__ bool diag_tile_inv(const double* d0, double* lv, int 
     for (int j = 0; j < TB; ++j) lv[j * TLD + l15] = m[j];
     return bad;
 }
+#else
+// Right-looking form on row broadcasts.  All four 16-lane rows of the wave hold the same tile (lane l15 = row l15), so the
+// multiplier L[j][k] = a[k] of lane j reaches every lane as a ROW broadcast -- one DPP move per double instead of two
+// v_readlane_b32 through an SGPR pair (240 of them were the instruction-issue bound of this wave: 5500 cycles per tile).  As soon as
+// column k is final it is applied to the columns behind it, nearest first: the chain a[k] -> a[k+1] -> pivot -> rsqrt is the
+// critical path, the other columns' updates and the M chain (same multipliers) fill its latency; a multiplier lives for two FMAs.
+// columns J0 .. J1-1 (and the rows of M) take the update of finalised column K
+template <int K, int J0, int J1> __device__ __forceinline__ void diag_apply(double (&a)[TB], double (&m)[TB])
+{
+    if constexpr (J0 < J1 && J0 < TB) {
+        const double s = bcast_row16<J0>(a[K]);     // L[J0][K]
+        a[J0] -= a[K] * s;                          // column J0 of the tile (this lane's row)
+        m[J0] -= m[K] * s;                          // row J0 of M (this lane's column)
+        diag_apply<K, J0 + 1, J1>(a, m);
+    }
+}
+// Column K becomes final.  A single wave issues in order, so the latency of the pivot's chain -- broadcast, v_rsq_f64, the
+// refinement r = r0 + r0 e (1/2 + 3/8 e), e = 1 - piv r0^2 (the sequence rsqrt() compiles to, written out so that it can be
+// spread) -- is filled by hand: the updates column K-1 still owes the columns BEHIND K sit between its stages, two per gap.
+template <int K> __device__ __forceinline__ void diag_cols(double (&a)[TB], double (&m)[TB], bool& bad)
+{
+    if constexpr (K < TB) {
+        if constexpr (K > 0) diag_apply<K - 1, K, K + 1>(a, m);          // completes column K
+        const double piv = bcast_row16<K>(a[K]);
+        bad |= !(piv > 0.0);
+        const double r0 = __builtin_amdgcn_rsq(piv);
+        if constexpr (K > 0) diag_apply<K - 1, K + 1, K + 3>(a, m);
+        const double t = -piv * r0;
+        if constexpr (K > 0) diag_apply<K - 1, K + 3, K + 5>(a, m);
+        const double e = fma(t, r0, 1.0);
+        if constexpr (K > 0) diag_apply<K - 1, K + 5, K + 7>(a, m);
+        const double u = r0 * e, w = fma(e, 0.375, 0.5);
+        if constexpr (K > 0) diag_apply<K - 1, K + 7, K + 9>(a, m);
+        const double rs = fma(u, w, r0);
+        if constexpr (K > 0) diag_apply<K - 1, K + 9, TB>(a, m);
+        a[K] *= rs;
+        m[K] *= rs;
+        diag_cols<K + 1>(a, m, bad);
+    }
+}
+__device__ __forceinline__ bool diag_tile_inv(const double* d0, double* lv, int l15)
+{
+    double a[TB], m[TB];
+#pragma unroll
+    for (int cc = 0; cc < TB; ++cc) { a[cc] = d0[l15 * TLD + cc]; m[cc] = (l15 == cc) ? 1.0 : 0.0; }
+    bool bad = false;
+    diag_cols<0>(a, m, bad);
+#pragma unroll
+    for (int j = 0; j < TB; ++j) lv[j * TLD + l15] = m[j];
+    return bad;
+}
+#endif
 
 // One step of the forward substitution fused into the factorisation (wave 0, phase 1 of step J; see the header of factor_t).
 __device__ __forceinline__ void fused_fwd_step(int J, gdouble* fv, int ni, double* bt, double* ct, double* yring, double* pend, double* svx,
-                                               int lane, int l15, int l4, double& ff_tacc, double& ff_rhs)
+                                               int lane, int l15, int l4, double& ff_tacc, double& ff_rhs, double ff_next)
 {
     // ---- forward substitution fused into the factorisation (see the header of factor_t), column-oriented: the tiles
     //      L(P+1 .. P+4, P) of block column P = J-1 and W_P are all in the window during this phase (they are what the
@@ -1123,10 +1182,7 @@ __device__ __forceinline__ void fused_fwd_step(int J, gdouble* fv, int ni, doubl
     // block row J:  y_J = M_J (v_J + pending), M_J = L_JJ^-1 just written by this wave
     const int iJ = J * TB + l15;
     const double sv = ff_rhs + pend[iJ & (VRING - 1)];            // used in lanes 0..15
-    {
-        const int ip = iJ + TB;
-        ff_rhs = (lane < TB && ip < ni) ? fv[ip] : 0.0;  // the next step's right-hand side goes in flight now
-    }
+    ff_rhs = ff_next;             // the next block row's right-hand side: in flight since the top of this phase (behind the diagonal tile)
     __builtin_amdgcn_wave_barrier();
     if (lane < TB) { svx[lane] = sv; pend[iJ & (VRING - 1)] = 0.0; }
     __builtin_amdgcn_wave_barrier();
@@ -1215,7 +1271,7 @@ __device__ __forceinline__ int factor_t(const SolveCtx& c, const gdouble* Hsrc, 
     //   Schur tiles (lower, 10): (t + 1) % 3 == wl, register slot t / 3;    band tiles (6): t % 3 == wl
     // wl is a literal inside LAG_WORK (three-way dispatch) so that every register array is indexed statically.
     // All LDS operand / accumulator reads of a group are issued before its MFMAs, all writes after them.
-#define LAG_WORK(P, WL)                                                                                                    \
+#define LAG_WORK(P, WL, CM)                                                                                                  \
     {                                                                                                                  \
         /* The three groups of the step's lag work (border, band, Schur tiles) used to run read -> MFMA -> write one after \
            the other; the compiler cannot move a group's LDS reads above the previous group's LDS writes (same address     \
@@ -1253,6 +1309,11 @@ __device__ __forceinline__ int factor_t(const SolveCtx& c, const gdouble* Hsrc, 
         _Pragma("unroll") for (int dI_ = 1; dI_ < NTR; ++dI_) cacc_[dI_ - 1] = mfma16(la_[dI_ - 1], wv_[(WL)], cacc_[dI_ - 1]); \
         c3a_ = mfma16(la_[(WL)], wv_[3], c3a_);                                                                        \
         if ((WL) == 0) c3b_ = mfma16(la_[3], wv_[3], c3b_);                                                            \
+        /* ---- in the shadow of those 20 / 24 fp64 MFMAs (64 cycles each, results not needed yet): this wave's share of the     \
+                write-out of step P -- LDS reads of final tiles, global stores; nothing the products touch ---- */            \
+        __builtin_amdgcn_sched_barrier(0);                                                                             \
+        if ((WL) == 0) { WRITE_OUT_W((P), 1) } else if ((WL) == 1) { WRITE_OUT_W((P), 0) } else { WRITE_OUT_L((P)) }   \
+        __builtin_amdgcn_sched_barrier(0);                                                                             \
         /* ---- updated tiles back to the window ---- */                                                               \
         _Pragma("unroll") for (int dI_ = 1; dI_ < NTR; ++dI_) {                                                        \
             double* ctl_ = CTILE((P) + dI_, (WL));                                                                     \
@@ -1301,6 +1362,10 @@ __device__ __forceinline__ int factor_t(const SolveCtx& c, const gdouble* Hsrc, 
                 }                                                                                                      \
             }                                                                                                          \
         }                                                                                                              \
+        /* ---- in the shadow of the Schur / band products: the commit of the tile row fetched a step and a half ago ---- */    \
+        __builtin_amdgcn_sched_barrier(0);                                                                             \
+        if (CM) { COMMIT_ROW((P) + NTR) }                                                                              \
+        __builtin_amdgcn_sched_barrier(0);                                                                             \
         {                                                                                                              \
             int t_ = 0, s_ = 0;                                                                                        \
             _Pragma("unroll") for (int dK_ = 2; dK_ < NTR; ++dK_) {                                                    \
@@ -1315,17 +1380,31 @@ __device__ __forceinline__ int factor_t(const SolveCtx& c, const gdouble* Hsrc, 
         WT(3);                                                                                                         \
     }
 
-#define LAG_DISPATCH(P)                                                                                                \
+#define LAG_DISPATCH(P, CM)                                                                                            \
     {                                                                                                                  \
-        if (wl == 0) { LAG_WORK((P), 0) }                                                                              \
-        else if (wl == 1) { LAG_WORK((P), 1) }                                                                         \
-        else { LAG_WORK((P), 2) }                                                                                      \
+        if (wl == 0) { LAG_WORK((P), 0, CM) }                                                                          \
+        else if (wl == 1) { LAG_WORK((P), 1, CM) }                                                                     \
+        else { LAG_WORK((P), 2, CM) }                                                                                  \
     }
-#define WRITE_OUT_DISPATCH(P)                                                                                          \
+    // Tile row R, fetched at the top of the PREVIOUS step (one and a half steps in flight: the commit never waits on HBM), is
+    // decoded into the window: its band slots -- tile row R - NTR -- were last read by panel(R - NTR), its border slots -- tile
+    // row R - NTRC of the 6-row border window -- by lag(R - NTRC); lag(R - NTR) touches neither, panel(R - NTR + 1) needs tile
+    // (R, R - NTR + 1).
+#define COMMIT_ROW(R)                                                                                                  \
     {                                                                                                                  \
-        if (wl == 0) { WRITE_OUT_W((P), 1) }                                                                           \
-        else if (wl == 1) { WRITE_OUT_W((P), 0) }                                                                      \
-        else { WRITE_OUT_L((P)) }                                                                                      \
+        if (PF_FAST((R))) {                                                                                            \
+            _Pragma("unroll") for (int u = 0; u < PF_ITEMS; ++u) {                                                     \
+                if (u < 6) tile_row_commit_fast<MK, SIG>(bt, ct, pf[u], (R), pc[u], true, u == 5);                      \
+                else if (u > 6) tile_row_commit_fast<MK, SIG>(bt, ct, pf[u], (R), pc[u], false, false);                 \
+                else if (wave3) tile_row_commit_fast<MK, SIG>(bt, ct, pf[u], (R), pc[u], false, false);                 \
+                else tile_row_commit_fast<MK, SIG>(bt, ct, pf[u], (R), pc[u], true, true);                              \
+            }                                                                                                          \
+        } else {                                                                                                       \
+            _Pragma("unroll") for (int u = 0; u < PF_ITEMS; ++u) {                                                     \
+                const int q = lt + u * PF_THREADS;                                                                     \
+                tile_row_store(bt, ct, (R), q, tile_row_decode<MK, SIG>(pf[u], ni, b, p, (R), q));                     \
+            }                                                                                                          \
+        }                                                                                                              \
     }
     // Write-out of block column P of L (tiles below the diagonal one; the sweeps use the inverse tile instead of the
     // entries inside the diagonal tile), of the inverse diagonal tile and of block row P of W.  Shared by the three lag waves
@@ -1393,20 +1472,21 @@ __device__ __forceinline__ int factor_t(const SolveCtx& c, const gdouble* Hsrc, 
         SKEW(2, w0 > 0);
         if (w0 == 0) {
             if (MCQ_WORKER_TIMERS) wt_last = (long long)clock64();
+            // fused forward substitution: the right-hand side of block row J+1 goes in flight before the diagonal tile's chain
+            // (issued inside the fused step it was waited for on the spot: its register is copied to an AGPR there)
+            double ff_next = 0.0;
+            if (fv) { const int ip = (J + 1) * TB + lane; if (lane < TB && ip < ni) ff_next = fv[ip]; }
             const bool bad = diag_tile_inv(BTILE(J, J), INVT(J), l15);
             if (bad && lane == 0) dinv[TB] = 1.0;
             WT(0);
             SKEW(3, true);
             if (fv) {
-                fused_fwd_step(J, fv, ni, bt, ct, yring, pend, svx, lane, l15, l4, ff_tacc, ff_rhs);
+                fused_fwd_step(J, fv, ni, bt, ct, yring, pend, svx, lane, l15, l4, ff_tacc, ff_rhs, ff_next);
                 WT(1);
             }
         } else {
-            // Tile row J+NTR goes in flight first; the lag work and the write-out of step J-1 follow; only then is tile row
-            // J-1+NTR -- fetched at the top of the PREVIOUS step, i.e. one and a half steps ago: the commit never waits on
-            // HBM -- decoded into the window: its band slots -- tile row J-1 -- were last read by panel(J-1), its border slots
-            // -- tile row J-2 of the 6-row border window -- by lag(J-2); lag(J-1) does not touch either, panel(J) needs
-            // tile (J+4, J).
+            // Tile row J+NTR goes in flight first; then the lag work of step J-1, with this wave's share of the write-out of step
+            // J-1 and the commit of tile row J-1+NTR (COMMIT_ROW) issued in the shadow of its matrix-core products.
             RawEntry pfn[PF_ITEMS];
             if (MCQ_WORKER_TIMERS) wt_last = (long long)clock64();
             {
@@ -1425,26 +1505,8 @@ __device__ __forceinline__ int factor_t(const SolveCtx& c, const gdouble* Hsrc, 
                 }
             }
             WT(0);
-            if (J > 0) { LAG_DISPATCH(J - 1) WRITE_OUT_DISPATCH(J - 1) }
+            if (J > 0) { LAG_DISPATCH(J - 1, 1) }
             WT(4);
-            if (J > 0) {
-                const int R = J - 1 + NTR;
-                if (PF_FAST(R)) {
-#pragma unroll
-                    for (int u = 0; u < PF_ITEMS; ++u) {
-                        if (u < 6) tile_row_commit_fast<MK, SIG>(bt, ct, pf[u], R, pc[u], true, u == 5);
-                        else if (u > 6) tile_row_commit_fast<MK, SIG>(bt, ct, pf[u], R, pc[u], false, false);
-                        else if (wave3) tile_row_commit_fast<MK, SIG>(bt, ct, pf[u], R, pc[u], false, false);
-                        else tile_row_commit_fast<MK, SIG>(bt, ct, pf[u], R, pc[u], true, true);
-                    }
-                } else {
-#pragma unroll
-                    for (int u = 0; u < PF_ITEMS; ++u) {
-                        const int q = lt + u * PF_THREADS;
-                        tile_row_store(bt, ct, R, q, tile_row_decode<MK, SIG>(pf[u], ni, b, p, R, q));
-                    }
-                }
-            }
 #pragma unroll
             for (int u = 0; u < PF_ITEMS; ++u) pf[u] = pfn[u];
             WT(5);
@@ -1504,7 +1566,7 @@ __device__ __forceinline__ int factor_t(const SolveCtx& c, const gdouble* Hsrc, 
     const long long t_tail = FTICK();
     // drain: what the last step still owes
     if (nblk > 0) {
-        if (w0 > 0) { LAG_DISPATCH(nblk - 1) WRITE_OUT_DISPATCH(nblk - 1) }
+        if (w0 > 0) { LAG_DISPATCH(nblk - 1, 0) }
         else if (fv) {
             // border sums of the last block row, then (W'y) to where solve() expects the loader waves' partial sums
             const int P = nblk - 1;
@@ -1523,7 +1585,7 @@ __device__ __forceinline__ int factor_t(const SolveCtx& c, const gdouble* Hsrc, 
 #undef LAG_WORK
 #undef PF_FAST
 #undef LAG_DISPATCH
-#undef WRITE_OUT_DISPATCH
+#undef COMMIT_ROW
 #undef WRITE_OUT_L
 #undef WRITE_OUT_W
     lds_barrier();

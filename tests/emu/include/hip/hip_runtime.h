@@ -250,6 +250,15 @@ inline hipemu_v4d hipemu_mfma_f64_16x16x4(double a, double b, hipemu_v4d c)
 #define __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, c, x, y, z) hipemu_mfma_f64_16x16x4((a), (b), (c))
 
 // AMDGCN builtins used by the kernels
+// v_mov_b64_dpp row_newbcast:n (dpp_ctrl 0x150 + n): lane n of every 16-lane row to all lanes of that row -- the only DPP control used
+inline double hipemu_update_dpp(double, double src, int ctrl)
+{
+    const int lane = hipemu::st().cur & 63;
+    if (ctrl < 0x150 || ctrl > 0x15f) { fprintf(stderr, "hipemu: unsupported dpp_ctrl 0x%x\n", ctrl); abort(); }
+    return __shfl(src, (lane & ~15) | (ctrl - 0x150));
+}
+#define __builtin_amdgcn_rsq(x) (1.0 / sqrt((double)(x)))      /* v_rsq_f64: the kernels refine it */
+#define __builtin_amdgcn_update_dpp(old, src, ctrl, rm, bm, bc) hipemu_update_dpp((old), (src), (ctrl))
 inline int hipemu_readlane(int v, int src) { return (int)__shfl((double)v, src); }
 #define __builtin_amdgcn_readlane(v, l) hipemu_readlane((v), (l))
 #define __builtin_amdgcn_s_barrier() hipemu::block_barrier()
