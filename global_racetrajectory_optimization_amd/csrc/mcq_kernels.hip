@@ -827,6 +827,9 @@ __global__ void __launch_bounds__(MCQ_NT) mcq_assemble_sp_kernel(McqBatch B)
 #define MCQ_SKEW 0
 #endif
 #define SKEW(k, cond) do { if (MCQ_SKEW == (k) && (cond)) __builtin_amdgcn_s_sleep(127); } while (0)
+#ifndef MCQ_BAND_WAVE0
+#define MCQ_BAND_WAVE0 3    /* how many of the six band tiles of a step's lag work wave 0 takes (0, 3 or 6: one / two per lag wave) */
+#endif
 #ifndef MCQ_FUSE_FWD
 #define MCQ_FUSE_FWD 1     /* forward substitution of the predictor / active-set solve fused into the factorisation (factor_t) */
 #endif
@@ -1331,7 +1334,7 @@ __device__ __forceinline__ int factor_t(const SolveCtx& c, const gdouble* Hsrc, 
             int t_ = 0, s_ = 0;                                                                                        \
             _Pragma("unroll") for (int dK_ = 2; dK_ < NTR; ++dK_) {                                                    \
                 _Pragma("unroll") for (int dI_ = dK_; dI_ < NTR; ++dI_, ++t_) {                                        \
-                    if (t_ % 3 != (WL)) continue;                                                                      \
+                    if (t_ % 3 != (WL) || t_ < MCQ_BAND_WAVE0) continue;                                              \
                     const double* tt_ = BTILE((P) + dI_, (P) + dK_);                                                   \
                     _Pragma("unroll") for (int r = 0; r < 4; ++r) bacc_[s_][r] = tt_[(l4 + 4 * r) * TLD + l15];        \
                     ++s_;                                                                                              \
@@ -1354,7 +1357,7 @@ __device__ __forceinline__ int factor_t(const SolveCtx& c, const gdouble* Hsrc, 
             int t_ = 0, s_ = 0;                                                                                        \
             _Pragma("unroll") for (int dK_ = 2; dK_ < NTR; ++dK_) {                                                    \
                 _Pragma("unroll") for (int dI_ = dK_; dI_ < NTR; ++dI_, ++t_) {                                        \
-                    if (t_ % 3 != (WL)) continue;                                                                      \
+                    if (t_ % 3 != (WL) || t_ < MCQ_BAND_WAVE0) continue;                                              \
                     double bv_[4];                                                                                     \
                     _Pragma("unroll") for (int kc = 0; kc < 4; ++kc) bv_[kc] = -la_[dK_ - 1][kc];                      \
                     bacc_[s_] = mfma16(la_[dI_ - 1], bv_, bacc_[s_]);                                                  \
@@ -1370,7 +1373,7 @@ __device__ __forceinline__ int factor_t(const SolveCtx& c, const gdouble* Hsrc, 
             int t_ = 0, s_ = 0;                                                                                        \
             _Pragma("unroll") for (int dK_ = 2; dK_ < NTR; ++dK_) {                                                    \
                 _Pragma("unroll") for (int dI_ = dK_; dI_ < NTR; ++dI_, ++t_) {                                        \
-                    if (t_ % 3 != (WL)) continue;                                                                      \
+                    if (t_ % 3 != (WL) || t_ < MCQ_BAND_WAVE0) continue;                                              \
                     double* tt_ = BTILE((P) + dI_, (P) + dK_);                                                         \
                     _Pragma("unroll") for (int r = 0; r < 4; ++r) tt_[(l4 + 4 * r) * TLD + l15] = bacc_[s_][r];        \
                     ++s_;                                                                                              \
@@ -1380,6 +1383,49 @@ __device__ __forceinline__ int factor_t(const SolveCtx& c, const gdouble* Hsrc, 
         WT(3);                                                                                                         \
     }
 
+    // The first MCQ_BAND_WAVE0 of the six band tiles of step P on wave 0: T(P+dI, P+dK) -= L(P+dI, P) L(P+dK, P)', 2 <= dK <= dI <= 4 -- wave 0 is done
+    // with its chain 2300 cycles before the lag waves are with their products, and fp64 MFMA time (64 cycles a piece, at the vector
+    // fp64 rate on this part) is what their phase is made of.
+#define LAG_BAND_WAVE0(P)                                                                                              \
+    {                                                                                                                  \
+        double lb_[4][4];                                                                                              \
+        v4d ba_[6];                                                                                                    \
+        _Pragma("unroll") for (int dI_ = 2; dI_ < NTR; ++dI_) {                                                        \
+            const double* li_ = LTILE(dI_, (P));                                                                       \
+            _Pragma("unroll") for (int kc = 0; kc < 4; ++kc) lb_[dI_ - 1][kc] = li_[l15 * TLD + l4 + 4 * kc];          \
+        }                                                                                                              \
+        {                                                                                                              \
+            int t_ = 0;                                                                                                \
+            _Pragma("unroll") for (int dK_ = 2; dK_ < NTR; ++dK_) {                                                    \
+                _Pragma("unroll") for (int dI_ = dK_; dI_ < NTR; ++dI_, ++t_) {                                        \
+                    if (t_ >= MCQ_BAND_WAVE0) continue;                                                                \
+                    const double* tt_ = BTILE((P) + dI_, (P) + dK_);                                                   \
+                    _Pragma("unroll") for (int r = 0; r < 4; ++r) ba_[t_][r] = tt_[(l4 + 4 * r) * TLD + l15];          \
+                }                                                                                                      \
+            }                                                                                                          \
+        }                                                                                                              \
+        {                                                                                                              \
+            int t_ = 0;                                                                                                \
+            _Pragma("unroll") for (int dK_ = 2; dK_ < NTR; ++dK_) {                                                    \
+                _Pragma("unroll") for (int dI_ = dK_; dI_ < NTR; ++dI_, ++t_) {                                        \
+                    if (t_ >= MCQ_BAND_WAVE0) continue;                                                                \
+                    double av_[4];                                                                                     \
+                    _Pragma("unroll") for (int kc = 0; kc < 4; ++kc) av_[kc] = -lb_[dI_ - 1][kc];                      \
+                    ba_[t_] = mfma16(av_, lb_[dK_ - 1], ba_[t_]);                                                      \
+                }                                                                                                      \
+            }                                                                                                          \
+        }                                                                                                              \
+        {                                                                                                              \
+            int t_ = 0;                                                                                                \
+            _Pragma("unroll") for (int dK_ = 2; dK_ < NTR; ++dK_) {                                                    \
+                _Pragma("unroll") for (int dI_ = dK_; dI_ < NTR; ++dI_, ++t_) {                                        \
+                    if (t_ >= MCQ_BAND_WAVE0) continue;                                                                \
+                    double* tt_ = BTILE((P) + dI_, (P) + dK_);                                                         \
+                    _Pragma("unroll") for (int r = 0; r < 4; ++r) tt_[(l4 + 4 * r) * TLD + l15] = ba_[t_][r];          \
+                }                                                                                                      \
+            }                                                                                                          \
+        }                                                                                                              \
+    }
 #define LAG_DISPATCH(P, CM)                                                                                            \
     {                                                                                                                  \
         if (wl == 0) { LAG_WORK((P), 0, CM) }                                                                          \
@@ -1484,6 +1530,8 @@ __device__ __forceinline__ int factor_t(const SolveCtx& c, const gdouble* Hsrc, 
                 fused_fwd_step(J, fv, ni, bt, ct, yring, pend, svx, lane, l15, l4, ff_tacc, ff_rhs, ff_next);
                 WT(1);
             }
+            if (MCQ_BAND_WAVE0 && J > 0) { LAG_BAND_WAVE0(J - 1) }
+            WT(2);
         } else {
             // Tile row J+NTR goes in flight first; then the lag work of step J-1, with this wave's share of the write-out of step
             // J-1 and the commit of tile row J-1+NTR (COMMIT_ROW) issued in the shadow of its matrix-core products.
@@ -1567,7 +1615,8 @@ __device__ __forceinline__ int factor_t(const SolveCtx& c, const gdouble* Hsrc, 
     // drain: what the last step still owes
     if (nblk > 0) {
         if (w0 > 0) { LAG_DISPATCH(nblk - 1, 0) }
-        else if (fv) {
+        else if (MCQ_BAND_WAVE0) { LAG_BAND_WAVE0(nblk - 1) }
+        if (w0 == 0 && fv) {
             // border sums of the last block row, then (W'y) to where solve() expects the loader waves' partial sums
             const int P = nblk - 1;
             const double* wt_ = CTILE(P, l4) + l15;
@@ -1585,6 +1634,7 @@ __device__ __forceinline__ int factor_t(const SolveCtx& c, const gdouble* Hsrc, 
 #undef LAG_WORK
 #undef PF_FAST
 #undef LAG_DISPATCH
+#undef LAG_BAND_WAVE0
 #undef COMMIT_ROW
 #undef WRITE_OUT_L
 #undef WRITE_OUT_W
