@@ -2097,6 +2097,24 @@ __device__ __noinline__ void solve(const SolveCtx& c, gdouble* v, bool fwd_done)
     }
     }
     __syncthreads();
+    // The loader waves have nothing to do while wave 0 solves the border system: the first two chunks of the BACKWARD sweep (L rows
+    // and the raw y_B of the last rows, W rows of the last chunk) go in flight and into the ring now -- they do not depend on x_D.
+    const int cl = nch - 1;
+    if (wv > 0 && nch > 0) {
+        // The top tiles of the sweep read the ring slot of chunk cl + 1 (rows beyond the last one: zeros times zeros).  The
+        // forward sweep leaves zeros there; when it ran inside the factorisation the slot still holds the factorisation's tile
+        // window -- including the tiles' padding words, which nothing ever wrote (stale LDS of whatever ran on this CU
+        // before: a NaN bit pattern there turned every unknown into NaN on some boxes) -- so the slot is cleared first.
+        if (fwd_done) {
+            d2* dst = (d2*)(chunk + ((cl + 1) % NBUF) * CH * CLD);
+            for (int e2 = lt; e2 < LD_PAIRS; e2 += LD_THREADS) dst[e2] = (d2){0.0, 0.0};
+        }
+        chunk_fetch(L, v, ni, b, cl, cl, lt, goff, regs, rreg);
+        chunk_commit(chunk, rring, cl, cl, lt, regs, rreg);
+        chunk_fetch(L, v, ni, b, -1, cl - 1, lt, goff, regs, rreg);
+        chunk_commit(chunk, rring, -1, cl - 1, lt, regs, rreg);
+        WFETCH(cl)
+    }
     // ================= border:  t = v_D - W' y_B,  x_D = L_S^-T (L_S^-1 t)  as two LDS mat-vecs =================
     if (wv == 0) {
         double t = 0.0;
@@ -2150,22 +2168,6 @@ __device__ __noinline__ void solve(const SolveCtx& c, gdouble* v, bool fwd_done)
 #pragma unroll
     for (int u = 0; u < 4; ++u) xdr[u] = (d2){xd[16 * u + 2 * c8], xd[16 * u + 2 * c8 + 1]};
     if (nch > 0) {
-        const int cl = nch - 1;
-        if (wv > 0) {
-            // The top tiles of the sweep read the ring slot of chunk cl + 1 (rows beyond the last one: zeros times zeros).  The
-            // forward sweep leaves zeros there; when it ran inside the factorisation the slot still holds the factorisation's tile
-            // window -- including the tiles' padding words, which nothing ever wrote (stale LDS of whatever ran on this CU
-            // before: a NaN bit pattern there turned every unknown into NaN on some boxes) -- so the slot is cleared first.
-            if (fwd_done) {
-                d2* dst = (d2*)(chunk + ((cl + 1) % NBUF) * CH * CLD);
-                for (int e2 = lt; e2 < LD_PAIRS; e2 += LD_THREADS) dst[e2] = (d2){0.0, 0.0};
-            }
-            chunk_fetch(L, v, ni, b, cl, cl, lt, goff, regs, rreg);
-            chunk_commit(chunk, rring, cl, cl, lt, regs, rreg);
-            chunk_fetch(L, v, ni, b, -1, cl - 1, lt, goff, regs, rreg);
-            chunk_commit(chunk, rring, -1, cl - 1, lt, regs, rreg);
-            WFETCH(cl)
-        }
         __syncthreads();
         if (wv > 0) {
             RHS_SUB(cl)
