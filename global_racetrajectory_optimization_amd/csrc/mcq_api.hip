@@ -219,6 +219,9 @@ static int ensure_stage(mcq_handle* h, size_t batch, size_t nmax)
     return 0;
 }
 
+#ifndef MCQ_GRAM_Y
+#define MCQ_GRAM_Y 16     /* workgroups per problem of the generic Gram kernel (boundary rows, border part) */
+#endif
 static int launch(mcq_handle* h, McqBatch& B, const mcq_opts& o)
 {
     B.Eb = h->Eb; B.Et = h->Et; B.Db = h->Db; B.H = h->H; B.L = h->L; B.vec = h->vec; B.Z = h->Z; B.state = h->state;
@@ -253,7 +256,7 @@ static int launch(mcq_handle* h, McqBatch& B, const mcq_opts& o)
     HIP_TRY(hipGetLastError());
     if (B.prep_only) return 0;
     HIP_TRY(hipEventRecord(h->ev[1], h->stream));
-    hipLaunchKernelGGL(mcq_gram_kernel, dim3(B.batch, 8), dim3(256), 0, h->stream, B);
+    hipLaunchKernelGGL(mcq_gram_kernel, dim3(B.batch, MCQ_GRAM_Y), dim3(256), 0, h->stream, B);
     HIP_TRY(hipGetLastError());
     hipLaunchKernelGGL(mcq_gram_tile_kernel, dim3(B.batch, (B.nmax + 63) / 64), dim3(256), 0, h->stream, B);
     HIP_TRY(hipGetLastError());

@@ -279,11 +279,15 @@ class Engine:
         return np.frombuffer(buf, dtype=dtype, count=int(np.prod(shape))).reshape(shape)
 
     def iqp_batch(self, tracks, kappa_bound, w_veh, stepsize_interp, iters_min=3, curv_error_allowed=0.01, max_rounds=50,
-                  nmax=None, timed=False, **opt_kw):
+                  nmax=None, timed=False, out=None, **opt_kw):
         """tph.iqp_handler for a batch of tracks as ONE engine call (mcq_iqp_batch): tracks = list of dicts {reftrack [N,4],
         normvectors [N,2], scaling [N] or None}.  Returns a dict: alpha / reftrack / normvectors (lists of the final arrays),
         n, curv_err, status, rounds (arrays [B]), curv_trace [B, IQP_TRACE], stats (rounds, qp_solves, and with timed=True
-        solver_ms / fallbacks per round)."""
+        solver_ms / fallbacks per round).
+        out (optional): dict with preallocated 'alpha' [B, nmax], 'reftrack' [B, nmax, 4], 'normvectors' [B, nmax, 2] float64 arrays
+        (e.g. from host_array: page-locked) that receive the end states -- a caller that runs batch after batch keeps them; the
+        returned per-track arrays are views into them.  Without it fresh arrays are allocated AND touched here: a device-to-host
+        copy into never-touched pageable memory runs at a tenth of the PCIe rate (page faults inside the copy)."""
         bsz = len(tracks)
         refs = [np.ascontiguousarray(t["reftrack"], dtype=np.float64) for t in tracks]
         nvs = [np.ascontiguousarray(t["normvectors"], dtype=np.float64) for t in tracks]
@@ -309,9 +313,18 @@ class Engine:
             arr[k].scaling = _as_dp(scs[k]) if scs[k] is not None else None
             arr[k].kappa_bound = float(kappa_bound)
             arr[k].w_veh = float(w_veh)
-        alpha = np.zeros((bsz, nmax))
-        ref_o = np.zeros((bsz, nmax, 4))
-        nv_o = np.zeros((bsz, nmax, 2))
+        def _out(key, shape):
+            if out is not None and key in out:
+                a = out[key]
+                if a.dtype != np.float64 or not a.flags["C_CONTIGUOUS"] or a.shape != shape:
+                    raise ValueError("out[%r] must be a C-contiguous float64 array of shape %r" % (key, shape))
+                return a
+            a = np.empty(shape)
+            a.fill(0.0)              # touch the pages before the driver copies into them
+            return a
+        alpha = _out("alpha", (bsz, nmax))
+        ref_o = _out("reftrack", (bsz, nmax, 4))
+        nv_o = _out("normvectors", (bsz, nmax, 2))
         n_o = np.zeros(bsz, dtype=np.int32)
         curv = np.zeros(bsz)
         status = np.zeros(bsz, dtype=np.int32)
