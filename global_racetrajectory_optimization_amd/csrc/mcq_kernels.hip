@@ -461,8 +461,10 @@ __global__ void __launch_bounds__(MCQ_NT) mcq_assemble_kernel(McqBatch B)
             const double gu1 = g0 * RU[i], gd1 = g0 * RD[i];
             {
                 const double dv = 6.0 * (gu1 - (1.0 + S[im]) * g0 + S[imm] * gd1);
+                const double ev = dv * (cpx * NY[i] - cpy * NX[i]);
                 w.Db[(size_t)MCQ_BE_MAX * nm + i] = dv;
-                w.Eb[(size_t)MCQ_BE_MAX * nm + i] = dv * (cpx * NY[i] - cpy * NX[i]);
+                w.Eb[(size_t)MCQ_BE_MAX * nm + i] = ev;
+                w.Et[(size_t)MCQ_BE_MAX * nm + i] = ev;      // E'[o'][j] = E[j + o'][j]: entry (i, j = i + o) is diagonal o' = -o of column j
             }
             // upwards: prev = g[o-1], cur = g[o], j = i + o
             {
@@ -472,8 +474,10 @@ __global__ void __launch_bounds__(MCQ_NT) mcq_assemble_kernel(McqBatch B)
                 for (int o = 1; o <= MCQ_BE_MAX; ++o) {
                     const double nxt = cur * RU[j];
                     const double dv = 6.0 * (nxt - (1.0 + S[jm1]) * cur + S[jm2] * prev);
+                    const double ev = dv * (cpx * NY[j] - cpy * NX[j]);
                     w.Db[(size_t)(MCQ_BE_MAX + o) * nm + i] = dv;
-                    w.Eb[(size_t)(MCQ_BE_MAX + o) * nm + i] = dv * (cpx * NY[j] - cpy * NX[j]);
+                    w.Eb[(size_t)(MCQ_BE_MAX + o) * nm + i] = ev;
+                    w.Et[(size_t)(MCQ_BE_MAX - o) * nm + j] = ev;        // consecutive threads: consecutive j (a wrap splits the run once)
                     prev = cur;
                     cur = nxt;
                     jm2 = jm1;
@@ -489,8 +493,10 @@ __global__ void __launch_bounds__(MCQ_NT) mcq_assemble_kernel(McqBatch B)
                 for (int o = -1; o >= -MCQ_BE_MAX; --o) {
                     const double prv = cur * RD[j];            // g[o-1]
                     const double dv = 6.0 * (nxt - (1.0 + S[jm1]) * cur + S[jm2] * prv);
+                    const double ev = dv * (cpx * NY[j] - cpy * NX[j]);
                     w.Db[(size_t)(MCQ_BE_MAX + o) * nm + i] = dv;
-                    w.Eb[(size_t)(MCQ_BE_MAX + o) * nm + i] = dv * (cpx * NY[j] - cpy * NX[j]);
+                    w.Eb[(size_t)(MCQ_BE_MAX + o) * nm + i] = ev;
+                    w.Et[(size_t)(MCQ_BE_MAX - o) * nm + j] = ev;
                     nxt = cur;
                     cur = prv;
                     j = jm1;
@@ -509,6 +515,7 @@ __global__ void __launch_bounds__(MCQ_NT) mcq_assemble_kernel(McqBatch B)
         w.Db[(size_t)oo * nm + i] = dv;
         w.Eb[(size_t)oo * nm + i] = dv * CP[i] * (XP[i] * NY[j] - YP[i] * NX[j]);
     }
+    if (long_ring) return;         // (E' written alongside E above: no second pass over the band)
     __syncthreads();
     // ---- phase 3c: transpose band  Et[(bR+o) * nm + j] = E[(j+o) mod n][j],  -bR <= o <= bE --------------------------
     for (int idx = tid; idx < n * ew; idx += MCQ_NT) {
