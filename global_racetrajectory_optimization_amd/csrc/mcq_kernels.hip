@@ -641,6 +641,15 @@ __device__ __forceinline__ void gram_fast_range(const McqDims& d, int& f0, int& 
     }
 }
 
+// Long rings with the full band: mcq_gram_tile_kernel produces EVERY entry of H (and f) from the cyclic-band form
+//   h(i, k) = H[i, (i+k) mod n] = sum_{o >= k} E'[o][i] E'[o-k][(i+k) mod n],   k = 0 .. 64,
+// and scatters it into the bordered storage (band slot, border slot, border block and its mirror image, wrap-around entries of
+// the first rows); the generic entry-by-entry routine (130 loads per entry) is left for short rings and narrow bands.
+__device__ __forceinline__ bool gram_all_rows(const McqDims& d)
+{
+    return d.bE == MCQ_BE_MAX && d.bR == MCQ_BE_MAX && d.b == MCQ_BH_MAX && d.p == MCQ_P_MAX && d.n >= 4 * GT_ROWS;
+}
+
 // Entries k == G (mod 4) of one row of the band of H for mcq_gram_tile_kernel: k is a literal, so every LDS offset is an
 // immediate and only the 65 - k products that exist are formed.  a[o] = E'[o][row]; sc = tile base + row.
 template <int G>
@@ -669,14 +678,17 @@ __device__ __forceinline__ void gram_tile_class(const double* a, const double* s
 __global__ void __launch_bounds__(MCQ_NT) mcq_gram_tile_kernel(McqBatch B)
 {
     __shared__ double S[(2 * MCQ_BE_MAX + 1) * 2 * GT_ROWS];
+    __shared__ double KS[GT_ROWS + 2 * MCQ_BE_MAX + 32];
     int n;
     double kb, wveh;
     const McqWork w = mcq_work(B, blockIdx.x, n, kb, wveh);
     if (*w.status != MCQ_OK) return;
     const int nm = B.nmax;
     const McqDims d = mcq_dims(n, B.band_e);
+    const bool all = gram_all_rows(d);
     int f0, f1;
     gram_fast_range(d, f0, f1);
+    if (all) { f0 = 0; f1 = n; }
     const int i0 = f0 + blockIdx.y * GT_ROWS;
     if (i0 >= f1) return;
     const int tid = threadIdx.x;
@@ -684,7 +696,9 @@ __global__ void __launch_bounds__(MCQ_NT) mcq_gram_tile_kernel(McqBatch B)
     // 65 x 128 doubles = 32.5 loads per thread: issued in batches of 11 independent loads (one HBM round trip per batch)
     {
         const int cc = tid & (NC - 1), o0 = tid / NC;              // 256 threads = 2 diagonals x 128 columns per pass
-        const gdouble* src = w.Et + (size_t)i0 + cc;                // i0 + cc <= f1 - 1 + 64 + 63 < n
+        int col = i0 + cc;                                         // fast range: i0 + cc < n; all rows: columns around the ring
+        col = col >= n ? col - n : col;
+        const gdouble* src = w.Et + (size_t)col;
 #pragma unroll
         for (int pass = 0; pass < 3; ++pass) {
             double t[11];
@@ -699,6 +713,11 @@ __global__ void __launch_bounds__(MCQ_NT) mcq_gram_tile_kernel(McqBatch B)
                 if (o < NO) S[o * NC + cc] = t[u];
             }
         }
+        if (all && tid < GT_ROWS + 2 * MCQ_BE_MAX) {               // k_ref around the tile: entry c = ring index i0 - bR + c
+            int q = i0 - MCQ_BE_MAX + tid;
+            q = q < 0 ? q + n : (q >= n ? q - n : q);
+            KS[tid] = VEC(w, nm, V_KREF)[q];
+        }
     }
     __syncthreads();
     const int r = tid & (GT_ROWS - 1);
@@ -706,6 +725,13 @@ __global__ void __launch_bounds__(MCQ_NT) mcq_gram_tile_kernel(McqBatch B)
     double a[2 * MCQ_BE_MAX + 1];
 #pragma unroll
     for (int o = 0; o < NO; ++o) a[o] = S[o * NC + r];
+    if (all && g == 3 && i0 + r < n) {       // f = F_SCALE E' k_ref: this thread's column of E is in registers (the class with the fewest entries)
+        double acc0 = 0.0, acc1 = 0.0;
+#pragma unroll
+        for (int o = 0; o + 1 < NO; o += 2) { acc0 += a[o] * KS[r + o]; acc1 += a[o + 1] * KS[r + o + 1]; }
+        acc0 += a[NO - 1] * KS[r + NO - 1];
+        VEC(w, nm, V_F)[i0 + r] = MCQ_F_SCALE * (acc0 + acc1);
+    }
     double res[(MCQ_BH_MAX + 4) / 4];
     if (g == 0) gram_tile_class<0>(a, S + r, res);
     else if (g == 1) gram_tile_class<1>(a, S + r, res);
@@ -720,9 +746,44 @@ __global__ void __launch_bounds__(MCQ_NT) mcq_gram_tile_kernel(McqBatch B)
         if (k <= MCQ_BH_MAX) S[r * OW + k] = res[m];
     }
     __syncthreads();
+    if (!all) {
+        for (int q = tid; q < GT_ROWS * OW; q += MCQ_NT) {
+            const int row = q / OW, k = q - row * OW;
+            w.H[(size_t)(i0 + row) * MCQ_HLD + k] = S[q];
+        }
+        return;
+    }
+    // ---- all rows: every (row, slot) of the bordered storage has exactly one writer ---------------------------------------
+    const int ni = d.ni;
     for (int q = tid; q < GT_ROWS * OW; q += MCQ_NT) {
         const int row = q / OW, k = q - row * OW;
-        w.H[(size_t)(i0 + row) * MCQ_HLD + k] = S[q];
+        const int i = i0 + row;
+        if (i >= n) continue;
+        const double h = S[q];
+        const int j = i + k;
+        if (i < ni) {                               // interior row: i + k < n always
+            if (j < ni) w.H[(size_t)i * MCQ_HLD + k] = h;
+            else {
+                w.H[(size_t)i * MCQ_HLD + k] = 0.0;                        // the band ends at the border
+                w.H[(size_t)i * MCQ_HLD + MCQ_HBO + (j - ni)] = h;
+            }
+        } else {                                    // border row ii = i - ni
+            const int ii = i - ni;
+            if (j < n) {
+                w.H[(size_t)i * MCQ_HLD + MCQ_HBO + (j - ni)] = h;         // border block, upper part ...
+                if (k > 0) w.H[(size_t)j * MCQ_HLD + MCQ_HBO + ii] = h;    // ... and its mirror image
+            } else {
+                w.H[(size_t)(j - n) * MCQ_HLD + MCQ_HBO + ii] = h;         // around the ring: border slot of one of the first rows
+            }
+        }
+    }
+    // border slots of this tile's interior rows that no entry above reaches: zero.  Slot jj of row i is reached from row i itself
+    // when ni + jj - i <= 64, and from border row ni + jj around the ring when i <= jj (never both on rings this long).
+    for (int q = tid; q < GT_ROWS * MCQ_P_MAX; q += MCQ_NT) {
+        const int row = q / MCQ_P_MAX, jj = q - row * MCQ_P_MAX;
+        const int i = i0 + row;
+        if (i >= ni) continue;
+        if (ni + jj - i > MCQ_BH_MAX && i > jj) w.H[(size_t)i * MCQ_HLD + MCQ_HBO + jj] = 0.0;
     }
 }
 
@@ -736,6 +797,7 @@ __global__ void __launch_bounds__(MCQ_NT) mcq_gram_kernel(McqBatch B)
     if (*w.status != MCQ_OK) return;
     const int nm = B.nmax;
     const McqDims d = mcq_dims(n, B.band_e);
+    if (gram_all_rows(d)) return;            // long rings: mcq_gram_tile_kernel writes all of H and f
     const gdouble* KR = VEC(w, nm, V_KREF);
     gdouble* F = VEC(w, nm, V_F);
 
