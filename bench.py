@@ -349,13 +349,22 @@ def main():
         d_ref = torch.from_numpy(ref_h).to(dev).to(io_t)
         d_nv = torch.from_numpy(nv_h).to(dev).to(io_t)
         d_sc = torch.from_numpy(sc_h).to(dev).to(io_t)
-        d_alpha = torch.zeros((B, n), dtype=io_t, device=dev)
+        # two result buffers, used in turn: the all-gather of step k (RCCL, torch's stream) runs while step k+1 solves into the other one
+        d_alpha2 = [torch.zeros((B, n), dtype=io_t, device=dev) for _ in range(2 if collective else 1)]
+        d_alpha = d_alpha2[0]
+        step_no = [0]
+        gather_done = [None, None]
         d_curv = torch.zeros((B,), dtype=torch.float64, device=dev)
         d_status = torch.zeros((B,), dtype=torch.int32, device=dev)
         d_info = torch.zeros((B, INFO_DTYPE.itemsize), dtype=torch.uint8, device=dev)
         d_all = torch.zeros((world * B, n), dtype=io_t, device=dev) if collective else None
 
         def step(record):
+            slot = step_no[0] % len(d_alpha2)
+            d_alpha = d_alpha2[slot]
+            step_no[0] += 1
+            if gather_done[slot] is not None:
+                gather_done[slot].synchronize()      # the all-gather that last read this buffer (two steps ago) has finished
             if f32:     # float normals are unit vectors only to 6e-8: let the engine derive them (and the scalings) in fp64
                 eng.solve_device_f32(B, n, d_ref.data_ptr(), None, None, KAPPA_BOUND, W_VEH,
                                      d_alpha.data_ptr(), d_curv.data_ptr(), d_status.data_ptr(), d_info.data_ptr())
@@ -374,6 +383,10 @@ def main():
                     ag_ev.append((e0, e1))
                 else:
                     dist.all_gather_into_tensor(d_all, d_alpha)
+                if not emulate:
+                    ev = torch.cuda.Event()
+                    ev.record()
+                    gather_done[slot] = ev
 
     def fence():
         eng.sync()
@@ -393,6 +406,8 @@ def main():
         step(True)
     fence()
     dt_local = time.perf_counter() - t0
+    if args.config != 4:
+        d_alpha = d_alpha2[(step_no[0] - 1) % len(d_alpha2)]     # the buffer of the last step
     clocks = sampler.stop() if sampler else None
     dt, rank_ms = dt_local, [1e3 * dt_local / args.steps]
     if collective:
