@@ -945,6 +945,9 @@ struct SolveCtx {
 // INSTEAD of the usual phase timers: [0] fetch issue, [1] LDS reads of the lag work, [2] border products + write-back, [3] Schur + band products, [4] write-out, [5] commit,
 // [6] wait at the phase-1 barrier, [7] phase 2 + its barrier (w = 4: wave 0 -- [0] its diagonal tile + inverse, [6], [7] as above).
 // Every sample drains the wave's LDS queue: the sum is an upper bound.
+#ifndef MCQ_SOLVE_TIMERS
+#define MCQ_SOLVE_TIMERS 0      /* 1: where loader wave 1 spends a step of the backward sweep (shader cycles in ticks[0..5]) */
+#endif
 #ifndef MCQ_WORKER_TIMERS
 #define MCQ_WORKER_TIMERS 0
 #endif
@@ -2271,13 +2274,22 @@ __device__ __noinline__ void solve(const SolveCtx& c, gdouble* v, bool fwd_done)
         else {
             // W rows first: fetched at the top of the previous step, consumed at the top of this one and re-fetched at once, they
             // get a whole step in flight like the L rows (behind the commit they had half of one; forward the same order loses)
+            long long st_[6] = {0, 0, 0, 0, 0, 0}, sl_ = MCQ_SOLVE_TIMERS ? (long long)clock64() : 0;
+#define ST(k) do { if (MCQ_SOLVE_TIMERS) { __builtin_amdgcn_s_waitcnt(0xc07f); const long long t_ = (long long)clock64(); st_[k] += t_ - sl_; sl_ = t_; } } while (0)
             for (int cq = cl; cq >= 0; --cq) {
                 RHS_SUB(cq - 1)
+                ST(0);
                 WFETCH(cq - 2)
+                ST(1);
                 chunk_commit(chunk, rring, cq - 1, cq - 2, lt, regs, rreg);
+                ST(2);
                 chunk_fetch(L, v, ni, b, cq - 2, cq - 3, lt, goff, regs, rreg);
+                ST(3);
                 lds_barrier();
+                ST(4);
             }
+            if (MCQ_SOLVE_TIMERS && tid == 64) { long long* acc = (long long*)c.w.Z; for (int q = 0; q < 5; ++q) acc[q] += st_[q]; acc[5] += cl + 1; }
+#undef ST
         }
     }
     __syncthreads();
@@ -3188,7 +3200,7 @@ __global__ void __launch_bounds__(MCQ_NT) mcq_solve_kernel(McqBatch B)
     }
     const long long t_kernel0 = TICK();
     const long long c_kernel0 = (long long)clock64();      // shader-clock counter (s_memtime): with ticks[3] the effective clock
-    if (MCQ_WORKER_TIMERS && tid == 64) for (int q = 0; q < 8; ++q) ((long long*)c.w.Z)[q] = 0;
+    if ((MCQ_WORKER_TIMERS || MCQ_SOLVE_TIMERS) && tid == 64) for (int q = 0; q < 8; ++q) ((long long*)c.w.Z)[q] = 0;
     double* red = g_sm + SM_RED;
     const int nm = B.nmax;
 
@@ -3367,7 +3379,7 @@ __global__ void __launch_bounds__(MCQ_NT) mcq_solve_kernel(McqBatch B)
                 o.second_attempt = c.second_attempt;
                 c.tk[3] = TICK() - t_kernel0;
                 if (!MCQ_FINE_TIMERS) c.tk[6] = (long long)clock64() - c_kernel0;
-                for (int q = 0; q < 8; ++q) o.ticks[q] = MCQ_WORKER_TIMERS ? ((const long long*)c.w.Z)[q] : c.tk[q];
+                for (int q = 0; q < 8; ++q) o.ticks[q] = (MCQ_WORKER_TIMERS || MCQ_SOLVE_TIMERS) ? ((const long long*)c.w.Z)[q] : c.tk[q];
                 *(mcq_info*)c.w.info = o;
             }
         }
