@@ -265,6 +265,7 @@ inline int hipemu_readlane(int v, int src) { return (int)__shfl((double)v, src);
 #define __builtin_amdgcn_readfirstlane(v) (v)     /* only used on wave-uniform values */
 #define __builtin_amdgcn_sched_barrier(mask) ((void)0)
 #define __builtin_amdgcn_s_sleep(n) ((void)0)
+#define __builtin_amdgcn_s_waitcnt(n) ((void)0)
 #define MCQ_PIN_SVV(sreg, vreg0, vreg1) ((void)0)
 #define MCQ_PIN_SV(sreg, vreg) ((void)0)
 #define __builtin_amdgcn_wave_barrier() hipemu::wave_barrier()
