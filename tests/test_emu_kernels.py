@@ -506,3 +506,20 @@ def test_poisoned_workspaces_and_lds(emu, emu_lib, golden, monkeypatch):
         assert np.max(np.abs(out[0][0] - g["iqp_alpha"])) < 1e-8
     finally:
         eng.close()
+
+
+def test_iqp_batch_into_caller_kept_buffers(emu, golden):
+    """Engine.iqp_batch(out=...): the end states land in arrays the caller keeps across calls (page-locked ones from host_array in
+    production); same results as the call that allocates its own, wrong shapes are refused."""
+    g = golden["rounded_rectangle"]
+    trk = [dict(reftrack=g["reftrack"].copy(), normvectors=g["normvec"], scaling=g["scaling"])] * 2
+    a = emu.iqp_batch(trk, 0.12, 3.4, 3.0, 3, 0.01)
+    nmax = a["stats"]["nmax"]
+    buf = dict(alpha=emu.host_array((2, nmax)), reftrack=emu.host_array((2, nmax, 4)), normvectors=emu.host_array((2, nmax, 2)))
+    b = emu.iqp_batch(trk, 0.12, 3.4, 3.0, 3, 0.01, nmax=nmax, out=buf)
+    for k in range(2):
+        assert np.array_equal(a["alpha"][k], b["alpha"][k]) and np.array_equal(a["reftrack"][k], b["reftrack"][k])
+        assert np.shares_memory(b["alpha"][k], buf["alpha"])
+        assert np.max(np.abs(b["alpha"][k] - g["iqp_alpha"])) < 1e-8
+    with pytest.raises(ValueError):
+        emu.iqp_batch(trk, 0.12, 3.4, 3.0, 3, 0.01, nmax=nmax, out=dict(alpha=np.zeros((2, nmax + 1))))
