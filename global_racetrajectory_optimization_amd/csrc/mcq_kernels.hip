@@ -1634,7 +1634,19 @@ __device__ __forceinline__ int factor_t(const SolveCtx& c, const gdouble* Hsrc, 
             if (MCQ_WORKER_TIMERS) wt_last = (long long)clock64();
             {
                 const int R = J + NTR;
-                if (PF_FAST(R)) {
+                if (PF_FAST(R) && R * TB >= MCQ_BH_MAX && (R + 1) * TB <= ni - MCQ_BH_MAX) {
+                    // Rows further than the band width from both ends of the interior have no border entries at all (the border
+                    // couples to the first and the last 64 rows only): half of every H row is zeros that need not be streamed --
+                    // 1 MB of the 2.1 MB a factorisation of an N = 2000 problem used to read.
+                    const RawEntry zero_entry = {0.0, 0.0, 0, 0};
+#pragma unroll
+                    for (int u = 0; u < PF_ITEMS; ++u) {
+                        if (u < 6) pfn[u] = tile_row_fetch_fast<MK, SIG>(H, sig, mk, R, pc[u], true, u == 5);
+                        else if (u > 6) pfn[u] = zero_entry;
+                        else if (wave3) pfn[u] = zero_entry;
+                        else pfn[u] = tile_row_fetch_fast<MK, SIG>(H, sig, mk, R, pc[u], true, true);
+                    }
+                } else if (PF_FAST(R)) {
 #pragma unroll
                     for (int u = 0; u < PF_ITEMS; ++u) {
                         if (u < 6) pfn[u] = tile_row_fetch_fast<MK, SIG>(H, sig, mk, R, pc[u], true, u == 5);
