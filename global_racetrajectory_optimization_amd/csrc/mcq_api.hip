@@ -62,6 +62,14 @@ struct mcq_handle {
     bool smem_attr_set = false;
     double* vel_scratch = nullptr;      // lap-doubled profiles of mcq_vel_profile_device, [2 nmax][batch]
     size_t vel_scratch_bytes = 0;
+    double* d_org = nullptr;            // per-track origins of the fp32 row entries, [batch][2]
+    double* d_trace = nullptr;          // curvature-error trace of mcq_iqp_batch, [batch][MCQ_IQP_TRACE] (grown with d_iqp)
+    // mcq_solve_host_pipelined: two copy streams, the second set of staging buffers, one event triple per slot
+    hipStream_t cs_in = nullptr, cs_out = nullptr;
+    hipEvent_t ev_up[2] = {nullptr, nullptr}, ev_done[2] = {nullptr, nullptr}, ev_down[2] = {nullptr, nullptr};
+    double *p_ref = nullptr, *p_nv = nullptr, *p_sc = nullptr, *p_alpha = nullptr, *p_curv = nullptr;
+    int* p_status = nullptr;
+    size_t pipe_elems = 0, pipe_batch = 0;
 };
 
 extern "C" const char* mcq_last_error(void) { return g_err.c_str(); }
@@ -143,6 +151,16 @@ static void free_stage(mcq_handle* h)
     h->d_ref2 = h->d_nv2 = h->d_iqp_curv = nullptr;
     h->d_iqp = nullptr;
     h->stage2_elems = h->iqp_batch = 0;
+    (void)hipFree(h->d_org); (void)hipFree(h->d_trace);
+    h->d_org = h->d_trace = nullptr;
+}
+
+static void free_pipe(mcq_handle* h)
+{
+    (void)hipFree(h->p_ref); (void)hipFree(h->p_nv); (void)hipFree(h->p_sc); (void)hipFree(h->p_alpha); (void)hipFree(h->p_curv); (void)hipFree(h->p_status);
+    h->p_ref = h->p_nv = h->p_sc = h->p_alpha = h->p_curv = nullptr;
+    h->p_status = nullptr;
+    h->pipe_elems = h->pipe_batch = 0;
 }
 
 extern "C" void mcq_destroy(mcq_handle* h)
@@ -150,8 +168,18 @@ extern "C" void mcq_destroy(mcq_handle* h)
     if (!h) return;
     (void)hipSetDevice(h->device);
     if (h->stream) (void)hipStreamSynchronize(h->stream);
+    if (h->cs_in) (void)hipStreamSynchronize(h->cs_in);
+    if (h->cs_out) (void)hipStreamSynchronize(h->cs_out);
     free_ws(h);
     free_stage(h);
+    free_pipe(h);
+    for (int k = 0; k < 2; ++k) {
+        if (h->ev_up[k]) (void)hipEventDestroy(h->ev_up[k]);
+        if (h->ev_done[k]) (void)hipEventDestroy(h->ev_done[k]);
+        if (h->ev_down[k]) (void)hipEventDestroy(h->ev_down[k]);
+    }
+    if (h->cs_in) (void)hipStreamDestroy(h->cs_in);
+    if (h->cs_out) (void)hipStreamDestroy(h->cs_out);
     (void)hipFree(h->vel_scratch);
     if (h->pin) (void)hipHostFree(h->pin);
     for (int k = 0; k < 5; ++k) if (h->ev[k]) (void)hipEventDestroy(h->ev[k]);
@@ -208,6 +236,7 @@ static int ensure_stage(mcq_handle* h, size_t batch, size_t nmax)
     HIP_TRY(hipMalloc((void**)&h->d_n, batch * sizeof(int)));
     HIP_TRY(hipMalloc((void**)&h->d_status, batch * sizeof(int)));
     HIP_TRY(hipMalloc((void**)&h->d_info, batch * sizeof(mcq_info)));
+    HIP_TRY(hipMalloc((void**)&h->d_org, batch * 2 * sizeof(double)));
     if (h->poison) {
         HIP_TRY(hipMemsetAsync(h->d_ref, 0xff, elems * 4 * sizeof(double), h->stream));
         HIP_TRY(hipMemsetAsync(h->d_nv, 0xff, elems * 2 * sizeof(double), h->stream));
@@ -349,6 +378,53 @@ extern "C" int mcq_solve_device_f32(mcq_handle* h, int batch, int n, const float
     hipLaunchKernelGGL(mcq_narrow_kernel, dim3(blocks), dim3(256), 0, h->stream, (const double*)h->d_alpha, alpha_out, elems);
     HIP_TRY(hipGetLastError());
     return 0;
+}
+
+// fp32 rows in either layout (include/mcq.h: MCQ_F32_ABSOLUTE / MCQ_F32_INCREMENTS), device-resident: the rows are rebuilt as fp64
+// [x, y, w_r, w_l] in the handle's staging buffer (mcq_widen_rows_kernel: running sums in fp64, closure defect spread over the
+// ring), normals and scalings are derived on the device, alpha is narrowed on the way out.
+static int solve_f32_rows(mcq_handle* h, int batch, int n, int layout, const float* d_rows, const double* d_origin, double kappa_bound,
+                          double w_veh, const mcq_opts& o, float* d_alpha_out, double* curv_err_out, int* status_out, mcq_info* info_out)
+{
+    const size_t elems = (size_t)batch * n;
+    hipLaunchKernelGGL(mcq_widen_rows_kernel, dim3((unsigned)batch), dim3(64), 0, h->stream, d_rows, d_origin, h->d_ref, n, layout);
+    HIP_TRY(hipGetLastError());
+    McqBatch B;
+    memset(&B, 0, sizeof(B));
+    B.batch = batch;
+    B.n = n;
+    B.nmax = n;
+    B.ref = h->d_ref;
+    B.alpha = h->d_alpha;
+    B.curv_err = curv_err_out;
+    B.status = status_out;
+    B.info = info_out;
+    B.kappa_bound = kappa_bound;
+    B.w_veh = w_veh;
+    int rc = launch(h, B, o);
+    if (rc) return rc;
+    const unsigned blocks = (unsigned)((elems / 4 + 255) / 256 < 4096 ? (elems / 4 + 255) / 256 + 1 : 4096);
+    hipLaunchKernelGGL(mcq_narrow_kernel, dim3(blocks), dim3(256), 0, h->stream, (const double*)h->d_alpha, d_alpha_out, elems);
+    HIP_TRY(hipGetLastError());
+    return 0;
+}
+
+extern "C" int mcq_solve_device_f32_rows(mcq_handle* h, int batch, int n, int layout, const float* reftrack, const double* origin,
+                                         double kappa_bound, double w_veh, const mcq_opts* opts, float* alpha_out,
+                                         double* curv_err_out, int* status_out, mcq_info* info_out)
+{
+    if (!h || batch <= 0 || n <= 0 || !reftrack || !alpha_out || !curv_err_out || !status_out ||
+        (layout != MCQ_F32_ABSOLUTE && layout != MCQ_F32_INCREMENTS)) {
+        g_err = "mcq_solve_device_f32_rows: bad argument";
+        return MCQ_E_ARG;
+    }
+    HIP_TRY(hipSetDevice(h->device));
+    const mcq_opts o = resolve_opts(opts);
+    int rc = ensure_ws(h, (size_t)batch, (size_t)n);
+    if (rc) return rc;
+    rc = ensure_stage(h, (size_t)batch, (size_t)n);
+    if (rc) return rc;
+    return solve_f32_rows(h, batch, n, layout, reftrack, origin, kappa_bound, w_veh, o, alpha_out, curv_err_out, status_out, info_out);
 }
 
 extern "C" int mcq_solve_device_ragged(mcq_handle* h, int batch, int nmax, const int* n_list, const double* reftrack,
@@ -727,15 +803,165 @@ extern "C" int mcq_solve_host(mcq_handle* h, int batch, int n, const double* ref
     return 0;
 }
 
+// Host-buffer fp32 entry (mcq_solve_batch_f32): float rows in, float alpha out -- half the PCIe bytes of the
+// fp64 entry.  The float rows land in the staging buffer of the (unused) normals -- batch * n * 2 doubles = batch * n * 4 floats --,
+// the float alpha in the one of the scalings; the fp64 rows are rebuilt next to them (solve_f32_rows).
+extern "C" int mcq_solve_batch_f32(mcq_handle* h, int batch, int n, int layout, const float* reftrack, const double* origin,
+                                   double kappa_bound, double w_veh, const mcq_opts* opts, float* alpha_out, double* curv_err_out,
+                                   int* status_out, mcq_info* info_out)
+{
+    if (!h || batch <= 0 || n <= 0 || !reftrack || !alpha_out || !curv_err_out || !status_out ||
+        (layout != MCQ_F32_ABSOLUTE && layout != MCQ_F32_INCREMENTS)) {
+        g_err = "mcq_solve_batch_f32: bad argument";
+        return MCQ_E_ARG;
+    }
+    HIP_TRY(hipSetDevice(h->device));
+    const mcq_opts o = resolve_opts(opts);
+    int rc = ensure_ws(h, (size_t)batch, (size_t)n);
+    if (rc) return rc;
+    rc = ensure_stage(h, (size_t)batch, (size_t)n);
+    if (rc) return rc;
+    const size_t elems = (size_t)batch * n;
+    float* d_rows = (float*)h->d_nv;
+    float* d_al32 = (float*)h->d_sc;
+    HIP_TRY_SYNC(hipMemcpyAsync(d_rows, reftrack, elems * 4 * sizeof(float), hipMemcpyHostToDevice, h->stream));
+    if (origin) HIP_TRY_SYNC(hipMemcpyAsync(h->d_org, origin, (size_t)batch * 2 * sizeof(double), hipMemcpyHostToDevice, h->stream));
+    rc = solve_f32_rows(h, batch, n, layout, d_rows, origin ? h->d_org : nullptr, kappa_bound, w_veh, o, d_al32, h->d_curv, h->d_status,
+                        info_out ? h->d_info : nullptr);
+    if (rc) { (void)hipStreamSynchronize(h->stream); return rc; }
+    HIP_TRY_SYNC(hipMemcpyAsync(alpha_out, d_al32, elems * sizeof(float), hipMemcpyDeviceToHost, h->stream));
+    HIP_TRY_SYNC(hipMemcpyAsync(curv_err_out, h->d_curv, batch * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+    HIP_TRY_SYNC(hipMemcpyAsync(status_out, h->d_status, batch * sizeof(int), hipMemcpyDeviceToHost, h->stream));
+    if (info_out) HIP_TRY_SYNC(hipMemcpyAsync(info_out, h->d_info, batch * sizeof(mcq_info), hipMemcpyDeviceToHost, h->stream));
+    HIP_TRY(hipStreamSynchronize(h->stream));
+    return 0;
+}
+
+// ---- a stream of uniform host batches with the PCIe behind the kernels (include/mcq.h) ------------------------------------------
+static int ensure_pipe(mcq_handle* h, size_t batch, size_t nmax)
+{
+    if (!h->cs_in) {
+        HIP_TRY(hipStreamCreate(&h->cs_in));
+        HIP_TRY(hipStreamCreate(&h->cs_out));
+        for (int k = 0; k < 2; ++k) {
+            HIP_TRY(hipEventCreate(&h->ev_up[k]));
+            HIP_TRY(hipEventCreate(&h->ev_done[k]));
+            HIP_TRY(hipEventCreate(&h->ev_down[k]));
+        }
+    }
+    const size_t elems = batch * nmax;
+    if (elems <= h->pipe_elems && batch <= h->pipe_batch) return 0;
+    HIP_TRY(hipStreamSynchronize(h->stream));
+    HIP_TRY(hipStreamSynchronize(h->cs_in));
+    HIP_TRY(hipStreamSynchronize(h->cs_out));
+    free_pipe(h);
+    HIP_TRY(hipMalloc((void**)&h->p_ref, elems * 4 * sizeof(double)));
+    HIP_TRY(hipMalloc((void**)&h->p_nv, elems * 2 * sizeof(double)));
+    HIP_TRY(hipMalloc((void**)&h->p_sc, elems * sizeof(double)));
+    HIP_TRY(hipMalloc((void**)&h->p_alpha, elems * sizeof(double)));
+    HIP_TRY(hipMalloc((void**)&h->p_curv, batch * sizeof(double)));
+    HIP_TRY(hipMalloc((void**)&h->p_status, batch * sizeof(int)));
+    h->pipe_elems = elems;
+    h->pipe_batch = batch;
+    return 0;
+}
+
+// every stream of the pipeline is drained before an error is reported: copies from / into the caller's buffers may be queued
+#define HIP_TRY_PIPE(expr)                                                                                \
+    do {                                                                                                  \
+        hipError_t e_ = (expr);                                                                           \
+        if (e_ != hipSuccess) {                                                                           \
+            char buf_[512];                                                                               \
+            snprintf(buf_, sizeof(buf_), "%s failed: %s (%s:%d)", #expr, hipGetErrorString(e_), __FILE__, \
+                     __LINE__);                                                                           \
+            g_err = buf_;                                                                                 \
+            (void)hipStreamSynchronize(h->cs_in);                                                         \
+            (void)hipStreamSynchronize(h->stream);                                                        \
+            (void)hipStreamSynchronize(h->cs_out);                                                        \
+            return MCQ_E_DEVICE;                                                                          \
+        }                                                                                                 \
+    } while (0)
+
+extern "C" int mcq_solve_host_pipelined(mcq_handle* h, int steps, int batch, int n, const double* const* reftrack,
+                                        const double* const* normvec, const double* const* scaling, double kappa_bound, double w_veh,
+                                        const mcq_opts* opts, double* const* alpha_out, double* const* curv_err_out,
+                                        int* const* status_out)
+{
+    if (!h || steps <= 0 || batch <= 0 || n <= 0 || !reftrack || !alpha_out || !curv_err_out || !status_out) {
+        g_err = "mcq_solve_host_pipelined: bad argument";
+        return MCQ_E_ARG;
+    }
+    for (int k = 0; k < steps; ++k) {
+        if (!reftrack[k] || !alpha_out[k] || !curv_err_out[k] || !status_out[k]) { g_err = "mcq_solve_host_pipelined: NULL buffer in step list"; return MCQ_E_ARG; }
+    }
+    HIP_TRY(hipSetDevice(h->device));
+    const mcq_opts o = resolve_opts(opts);
+    int rc = ensure_ws(h, (size_t)batch, (size_t)n);
+    if (rc) return rc;
+    rc = ensure_stage(h, (size_t)batch, (size_t)n);
+    if (rc) return rc;
+    rc = ensure_pipe(h, (size_t)batch, (size_t)n);
+    if (rc) return rc;
+    HIP_TRY(hipStreamSynchronize(h->stream));          // whatever ran before on the handle's stream is done with the staging buffers
+    const size_t elems = (size_t)batch * n;
+    double* s_ref[2] = {h->d_ref, h->p_ref};
+    double* s_nv[2] = {h->d_nv, h->p_nv};
+    double* s_sc[2] = {h->d_sc, h->p_sc};
+    double* s_al[2] = {h->d_alpha, h->p_alpha};
+    double* s_cu[2] = {h->d_curv, h->p_curv};
+    int* s_st[2] = {h->d_status, h->p_status};
+    for (int k = 0; k < steps; ++k) {
+        const int s = k & 1;
+        const double* nv_k = normvec ? normvec[k] : nullptr;
+        const double* sc_k = scaling ? scaling[k] : nullptr;
+        // upload of step k into slot s: the kernels of step k - 2 were the last readers of that slot's rows
+        if (k >= 2) HIP_TRY_PIPE(hipStreamWaitEvent(h->cs_in, h->ev_done[s], 0));
+        HIP_TRY_PIPE(hipMemcpyAsync(s_ref[s], reftrack[k], elems * 4 * sizeof(double), hipMemcpyHostToDevice, h->cs_in));
+        if (nv_k) HIP_TRY_PIPE(hipMemcpyAsync(s_nv[s], nv_k, elems * 2 * sizeof(double), hipMemcpyHostToDevice, h->cs_in));
+        if (sc_k) HIP_TRY_PIPE(hipMemcpyAsync(s_sc[s], sc_k, elems * sizeof(double), hipMemcpyHostToDevice, h->cs_in));
+        HIP_TRY_PIPE(hipEventRecord(h->ev_up[s], h->cs_in));
+        // kernels of step k: after its upload, and after the download of step k - 2 has left the slot's result buffers
+        HIP_TRY_PIPE(hipStreamWaitEvent(h->stream, h->ev_up[s], 0));
+        if (k >= 2) HIP_TRY_PIPE(hipStreamWaitEvent(h->stream, h->ev_down[s], 0));
+        McqBatch B;
+        memset(&B, 0, sizeof(B));
+        B.batch = batch;
+        B.n = n;
+        B.nmax = n;
+        B.ref = s_ref[s];
+        B.nv = nv_k ? s_nv[s] : nullptr;
+        B.sc = sc_k ? s_sc[s] : nullptr;
+        B.alpha = s_al[s];
+        B.curv_err = s_cu[s];
+        B.status = s_st[s];
+        B.kappa_bound = kappa_bound;
+        B.w_veh = w_veh;
+        rc = launch(h, B, o);
+        if (rc) { (void)hipStreamSynchronize(h->cs_in); (void)hipStreamSynchronize(h->stream); (void)hipStreamSynchronize(h->cs_out); return rc; }
+        HIP_TRY_PIPE(hipEventRecord(h->ev_done[s], h->stream));
+        // download of step k
+        HIP_TRY_PIPE(hipStreamWaitEvent(h->cs_out, h->ev_done[s], 0));
+        HIP_TRY_PIPE(hipMemcpyAsync(alpha_out[k], s_al[s], elems * sizeof(double), hipMemcpyDeviceToHost, h->cs_out));
+        HIP_TRY_PIPE(hipMemcpyAsync(curv_err_out[k], s_cu[s], batch * sizeof(double), hipMemcpyDeviceToHost, h->cs_out));
+        HIP_TRY_PIPE(hipMemcpyAsync(status_out[k], s_st[s], batch * sizeof(int), hipMemcpyDeviceToHost, h->cs_out));
+        HIP_TRY_PIPE(hipEventRecord(h->ev_down[s], h->cs_out));
+    }
+    HIP_TRY_PIPE(hipStreamSynchronize(h->cs_in));
+    HIP_TRY_PIPE(hipStreamSynchronize(h->stream));
+    HIP_TRY_PIPE(hipStreamSynchronize(h->cs_out));
+    return 0;
+}
+
 // ---- tph.iqp_handler as one call (include/mcq.h) ---------------------------------------------------------------------------------
 static int ensure_iqp(mcq_handle* h, size_t batch)
 {
     if (batch <= h->iqp_batch) return 0;
     HIP_TRY(hipStreamSynchronize(h->stream));
-    (void)hipFree(h->d_iqp); (void)hipFree(h->d_iqp_curv);
-    h->d_iqp = nullptr; h->d_iqp_curv = nullptr; h->iqp_batch = 0;
+    (void)hipFree(h->d_iqp); (void)hipFree(h->d_iqp_curv); (void)hipFree(h->d_trace);
+    h->d_iqp = nullptr; h->d_iqp_curv = nullptr; h->d_trace = nullptr; h->iqp_batch = 0;
     HIP_TRY(hipMalloc((void**)&h->d_iqp, (batch * 8 + 16) * sizeof(int)));
     HIP_TRY(hipMalloc((void**)&h->d_iqp_curv, batch * 2 * sizeof(double)));
+    HIP_TRY(hipMalloc((void**)&h->d_trace, batch * MCQ_IQP_TRACE * sizeof(double)));     // mcq_iqp_batch's trace staging
     h->iqp_batch = batch;
     return 0;
 }
@@ -823,7 +1049,6 @@ extern "C" int mcq_iqp_device(mcq_handle* h, int batch, int nmax, int* n_io, dou
         B.w_veh = w_veh;
         o.warm_start = (warm && it > 1) ? 1 : 0;
         if ((err = launch(h, B, o)) != 0) break;
-        solves += n_live;
         if (timed && it <= 16) {
             float ms[5];
             if (mcq_last_timing(h, ms) == 0) stats->solver_ms[it - 1] = ms[4];
@@ -861,7 +1086,15 @@ extern "C" int mcq_iqp_device(mcq_handle* h, int batch, int nmax, int* n_io, dou
     if (hipStreamSynchronize(h->stream) != hipSuccess && !err) err = MCQ_E_DEVICE;
     h->state2_valid = false;        // the working sets belong to this run's last glue call, not to a later solve
     if (err) { if (err == MCQ_E_DEVICE && g_err.empty()) g_err = "mcq_iqp_device: HIP runtime error"; return err; }
-    if (stats) { stats->rounds = rounds; stats->qp_solves = (int)solves; }
+    if (stats) {
+        // QP passes summed over the tracks = sum of the rounds every track ran (the live count is only read back from round
+        // iters_min on: counting launches x live tracks over-counted tracks that failed in an early round)
+        std::vector<int> rv((size_t)batch);
+        HIP_TRY(hipMemcpy(rv.data(), rounds_out, batch * sizeof(int), hipMemcpyDeviceToHost));
+        for (int k = 0; k < batch; ++k) solves += rv[k];
+        stats->rounds = rounds;
+        stats->qp_solves = (int)solves;
+    }
     if (n_live > 0) {
         // tracks still iterating at max_rounds: report them (status MCQ_ITER_CAP), keep their last state
         std::vector<int> lv((size_t)batch), stv((size_t)batch);
@@ -1019,8 +1252,9 @@ extern "C" int mcq_iqp_batch(mcq_handle* h, const mcq_problem* probs, int batch,
     // results need room for both buffer sets' ref / nv in the worst case: one extra set
     rc = pack_and_upload(h, probs, batch, nmax, any_sc, true, elems * 6 * sizeof(double) + (size_t)batch * 3 * sizeof(int), P, "mcq_iqp_batch");
     if (rc) return rc;
-    double* d_trace = nullptr;
-    if (curv_trace_out) HIP_TRY(hipMalloc((void**)&d_trace, (size_t)batch * MCQ_IQP_TRACE * sizeof(double)));
+    rc = ensure_iqp(h, (size_t)batch);                 // the trace staging lives in the handle (no allocation / hipFree -- an implicit
+    if (rc) return rc;                                 // device-wide synchronisation -- per call)
+    double* d_trace = curv_trace_out ? h->d_trace : nullptr;
     // d_kb / d_wv staging doubles as the per-track outputs of the loop: curvature error (double), buffer index / rounds (ints)
     int* d_buf = (int*)h->d_kb;                 // batch doubles >= 2 * batch ints
     int* d_rounds = d_buf + batch;
@@ -1031,7 +1265,6 @@ extern "C" int mcq_iqp_batch(mcq_handle* h, const mcq_problem* probs, int batch,
         g_err = "mcq_iqp_batch: read-back of the curvature-error trace failed";
         rc = MCQ_E_DEVICE;
     }
-    (void)hipFree(d_trace);
     if (rc) return rc;
     int* buf_h = P.n;                            // the pinned int block: n | (extra) buf, rounds
     HIP_TRY_SYNC(hipMemcpyAsync(n_out, h->d_n, batch * sizeof(int), hipMemcpyDeviceToHost, h->stream));

@@ -144,6 +144,8 @@ __global__ void mcq_normals_crossing_kernel(int nmax, const int* n_list, const d
 /* fp32 boundary (BASELINE config 5): float <-> double streaming conversions around the fp64 engine */
 __global__ void mcq_widen_kernel(const float* src, double* dst, size_t count);
 __global__ void mcq_narrow_kernel(const double* src, float* dst, size_t count);
+/* float rows -> fp64 rows [x, y, w_r, w_l]: layout 0 absolute coordinates, 1 ring increments (include/mcq.h MCQ_F32_*); one wave per track */
+__global__ void mcq_widen_rows_kernel(const float* rows, const double* origin, double* dst, int n, int layout);
 
 size_t mcq_solve_lds_bytes();   /* static LDS of the solver kernel (reporting only) */
 

@@ -3684,7 +3684,13 @@ __global__ void __launch_bounds__(64) mcq_vel_profile_kernel(McqVel V)
     const int bt = V.batch;
     const int trk = V.track_of ? V.track_of[v] : v;
     const int n = V.n_of_track ? V.n_of_track[trk] : V.n;        // ragged tracks: per-row waypoint counts
-    if (n < 2 || n > V.nmax) { V.lap_time[v] = NAN; return; }
+    // a variant that cannot be computed (bad row length, or -- below -- a ggv / machine table that ends under its v_max, where tph
+    // raises) is flagged by lap_time = NaN AND a vx_out row of NaNs: a C-ABI caller never sees stale buffer contents as a profile
+    if (n < 2 || n > V.nmax) {
+        V.lap_time[v] = NAN;
+        for (int i = 0; i < V.nmax; ++i) V.vx_out[(size_t)v * V.nmax + i] = NAN;
+        return;
+    }
     const size_t row = (size_t)trk * V.nmax;
     const gdouble* kap = (const gdouble*)(V.kappa + row);
     const gdouble* el = (const gdouble*)(V.el + row);
@@ -3693,7 +3699,11 @@ __global__ void __launch_bounds__(64) mcq_vel_profile_kernel(McqVel V)
     gdouble* S = (gdouble*)V.scratch + v;       // S[j * bt]
     const double vmax = V.vmax[v], e = V.dyn_exp, dom = V.drag[v] / V.mass[v];
     const int ng = V.ng, nam = V.nam;
-    if (ggv[(size_t)(ng - 1) * 3] < vmax || axm[(size_t)(nam - 1) * 2] < vmax) { V.lap_time[v] = NAN; return; }
+    if (ggv[(size_t)(ng - 1) * 3] < vmax || axm[(size_t)(nam - 1) * 2] < vmax) {
+        V.lap_time[v] = NAN;
+        for (int i = 0; i < n; ++i) V.vx_out[(size_t)v * V.nmax + i] = NAN;
+        return;
+    }
     double aymin = ggv[2];
     for (int k = 1; k < ng; ++k) aymin = fmin(aymin, ggv[(size_t)k * 3 + 2]);
 #define VP_RAD(i_) ((kap[(i_)] != 0.0) ? fabs(1.0 / kap[(i_)]) : (double)INFINITY)
@@ -3923,3 +3933,48 @@ __global__ void mcq_narrow_kernel(const double* src, float* dst, size_t count)
     }
     for (size_t i = 4 * quads + (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < count; i += stride) dst[i] = (float)src[i];
 }
+
+// ---- fp32 rows, increment layout (include/mcq.h: MCQ_F32_INCREMENTS): the QP sees the reference line only through differences of
+//      neighbouring waypoints, so the float rows carry those -- row i = [x_{i+1} - x_i, y_{i+1} - y_i, w_r, w_l], ring order -- and
+//      x, y are rebuilt here in fp64: running sum from the track's origin, with the closure defect of the float increments (they do
+//      not sum to zero exactly) spread evenly over the ring.  One wave per track: lane l sums its contiguous slice, an exclusive
+//      scan over the 64 slice sums (wave shuffles), then every lane writes its slice.  layout 0 (absolute rows): widened, origin
+//      added.  32 KB per track next to the ~180 MB the solver moves for it: not measurable. ----
+__global__ void __launch_bounds__(64) mcq_widen_rows_kernel(const float* rows, const double* origin, double* dst, int n, int layout)
+{
+    const int pb = blockIdx.x, lane = threadIdx.x & 63;
+    const float* src = rows + (size_t)pb * n * 4;
+    double* out = dst + (size_t)pb * n * 4;
+    const double ox = origin ? origin[2 * pb] : 0.0, oy = origin ? origin[2 * pb + 1] : 0.0;
+    const int per = (n + 63) / 64;
+    const int i0 = lane * per < n ? lane * per : n, i1 = i0 + per < n ? i0 + per : n;
+    if (layout == 0) {
+        for (int i = i0; i < i1; ++i) {
+            out[4 * i] = ox + (double)src[4 * i];
+            out[4 * i + 1] = oy + (double)src[4 * i + 1];
+            out[4 * i + 2] = (double)src[4 * i + 2];
+            out[4 * i + 3] = (double)src[4 * i + 3];
+        }
+        return;
+    }
+    double sx = 0.0, sy = 0.0;
+    for (int i = i0; i < i1; ++i) { sx += (double)src[4 * i]; sy += (double)src[4 * i + 1]; }
+    // inclusive scan of the slice sums over the wave (Hillis-Steele on shuffles), then exclusive = inclusive - own
+    double ix = sx, iy = sy;
+    for (int d = 1; d < 64; d <<= 1) {
+        const double ux = __shfl(ix, lane >= d ? lane - d : lane), uy = __shfl(iy, lane >= d ? lane - d : lane);
+        if (lane >= d) { ix += ux; iy += uy; }
+    }
+    const double tx = __shfl(ix, 63), ty = __shfl(iy, 63);          // closure defect of the ring
+    const double cx = tx / (double)n, cy = ty / (double)n;
+    double x = ox + (ix - sx) - cx * (double)i0, y = oy + (iy - sy) - cy * (double)i0;
+    for (int i = i0; i < i1; ++i) {
+        out[4 * i] = x;
+        out[4 * i + 1] = y;
+        out[4 * i + 2] = (double)src[4 * i + 2];
+        out[4 * i + 3] = (double)src[4 * i + 3];
+        x += (double)src[4 * i] - cx;
+        y += (double)src[4 * i + 1] - cy;
+    }
+}
+

@@ -53,7 +53,8 @@ IQP_TRACE = 16      # MCQ_IQP_TRACE
 
 EXPORTED_SYMBOLS = ("mcq_create", "mcq_destroy", "mcq_last_error", "mcq_default_opts", "mcq_solve_batch", "mcq_solve_host",
                     "mcq_iqp_device", "mcq_iqp_batch", "mcq_host_alloc", "mcq_host_free",
-                    "mcq_solve_device", "mcq_solve_device_f32", "mcq_solve_device_ragged", "mcq_solve_device_ragged_params", "mcq_prep_device", "mcq_relinearise_device",
+                    "mcq_solve_device", "mcq_solve_device_f32", "mcq_solve_device_f32_rows", "mcq_solve_batch_f32",
+                    "mcq_solve_host_pipelined", "mcq_solve_device_ragged", "mcq_solve_device_ragged_params", "mcq_prep_device", "mcq_relinearise_device",
                     "mcq_vel_profile_device", "mcq_vel_profile_device_ragged", "mcq_raceline_device", "mcq_normals_crossing_device",
                     "mcq_device_alloc",
                     "mcq_device_free", "mcq_copy_to_device", "mcq_copy_to_host", "mcq_sync", "mcq_stream",
@@ -102,6 +103,14 @@ def load_library(path=None):
     lib.mcq_host_free.restype = ctypes.c_int
     lib.mcq_solve_device_f32.argtypes = lib.mcq_solve_device.argtypes
     lib.mcq_solve_device_f32.restype = ctypes.c_int
+    lib.mcq_solve_device_f32_rows.argtypes = [vp, ctypes.c_int, ctypes.c_int, ctypes.c_int, vp, vp, ctypes.c_double, ctypes.c_double,
+                                              ctypes.POINTER(McqOpts), vp, vp, vp, vp]
+    lib.mcq_solve_device_f32_rows.restype = ctypes.c_int
+    lib.mcq_solve_batch_f32.argtypes = lib.mcq_solve_device_f32_rows.argtypes
+    lib.mcq_solve_batch_f32.restype = ctypes.c_int
+    lib.mcq_solve_host_pipelined.argtypes = [vp, ctypes.c_int, ctypes.c_int, ctypes.c_int, vp, vp, vp, ctypes.c_double, ctypes.c_double,
+                                             ctypes.POINTER(McqOpts), vp, vp, vp]
+    lib.mcq_solve_host_pipelined.restype = ctypes.c_int
     lib.mcq_solve_device_ragged.argtypes = [vp, ctypes.c_int, ctypes.c_int, vp, vp, vp, vp, ctypes.c_double,
                                             ctypes.c_double, ctypes.POINTER(McqOpts), vp, vp, vp, vp]
     lib.mcq_solve_device_ragged.restype = ctypes.c_int
@@ -145,6 +154,33 @@ def load_library(path=None):
 
 def _as_dp(a):
     return a.ctypes.data_as(_dp)
+
+
+F32_ABSOLUTE, F32_INCREMENTS = 0, 1      # MCQ_F32_* (include/mcq.h): layout of the coordinate columns of float rows
+
+
+def rows_to_increments(reftrack):
+    """fp64 rows [..., n, 4] = [x, y, w_r, w_l] -> (float32 rows [..., n, 4] = [x_{i+1} - x_i, y_{i+1} - y_i, w_r, w_l] around the
+    ring, float64 origin [..., 2] = the first waypoint): the MCQ_F32_INCREMENTS layout of the fp32 entries.  The differences are
+    taken in fp64 and rounded once."""
+    ref = np.asarray(reftrack, dtype=np.float64)
+    out = np.empty(ref.shape, dtype=np.float32)
+    out[..., :2] = np.roll(ref[..., :2], -1, axis=-2) - ref[..., :2]
+    out[..., 2:] = ref[..., 2:]
+    return out, np.ascontiguousarray(ref[..., 0, :2])
+
+
+def increments_to_rows(rows32, origin=None):
+    """What the device rebuilds from MCQ_F32_INCREMENTS rows (mcq_widen_rows_kernel), in numpy: fp64 running sum from the origin with
+    the closure defect of the float increments spread evenly over the ring.  For tests and for callers that want the reference
+    line the engine saw."""
+    r = np.asarray(rows32, dtype=np.float64)
+    n = r.shape[-2]
+    d = r[..., :2] - r[..., :2].mean(axis=-2, keepdims=True)
+    xy = np.concatenate((np.zeros(r.shape[:-2] + (1, 2)), np.cumsum(d, axis=-2)[..., :-1, :]), axis=-2)
+    if origin is not None:
+        xy = xy + np.asarray(origin, dtype=np.float64)[..., None, :]
+    return np.concatenate((xy, r[..., 2:]), axis=-1)
 
 
 class Engine:
@@ -256,7 +292,13 @@ class Engine:
         bsz, n = ref.shape[0], ref.shape[1]
         nv = None if normvec is None else np.ascontiguousarray(normvec, dtype=np.float64)
         sc = None if scaling is None else np.ascontiguousarray(scaling, dtype=np.float64)
-        alpha = np.empty((bsz, n)) if alpha_out is None else alpha_out
+        if alpha_out is None:
+            alpha = np.empty((bsz, n))
+        else:
+            alpha = alpha_out
+            if not isinstance(alpha, np.ndarray) or alpha.dtype != np.float64 or alpha.shape != (bsz, n) or not alpha.flags["C_CONTIGUOUS"] \
+                    or not alpha.flags["WRITEABLE"]:
+                raise ValueError("alpha_out must be a writeable C-contiguous float64 array of shape %r" % ((bsz, n),))
         curv = np.empty(bsz)
         status = np.empty(bsz, dtype=np.int32)
         info = (McqInfo * bsz)()
@@ -269,7 +311,9 @@ class Engine:
         return alpha, curv, status, info
 
     def host_array(self, shape, dtype=np.float64):
-        """numpy array backed by pinned host memory of the engine (mcq_host_alloc); freed with the engine (or host_free)."""
+        """numpy array backed by pinned (page-locked) host memory of the engine (mcq_host_alloc).  LIFETIME: the memory belongs to
+        the engine -- it is released by host_free(array) or by close() / garbage collection of the engine, after which the array
+        (and every view of it) must not be touched.  Keep the engine alive as long as the arrays are in use."""
         nbytes = int(np.prod(shape)) * np.dtype(dtype).itemsize
         p = ctypes.c_void_p()
         self._check(self.lib.mcq_host_alloc(self.h, max(nbytes, 1), ctypes.byref(p)), "mcq_host_alloc")
@@ -277,6 +321,85 @@ class Engine:
         self._pinned.append(p.value)
         buf = (ctypes.c_char * max(nbytes, 1)).from_address(p.value)
         return np.frombuffer(buf, dtype=dtype, count=int(np.prod(shape))).reshape(shape)
+
+    def host_free(self, arr):
+        """Release a host_array before the engine goes away (the array must not be used afterwards)."""
+        addr = int(arr.ctypes.data)
+        pinned = getattr(self, "_pinned", [])
+        if addr not in pinned:
+            raise ValueError("host_free: not the start of an array from host_array of this engine")
+        pinned.remove(addr)
+        self._check(self.lib.mcq_host_free(self.h, addr), "mcq_host_free")
+
+    def solve_host_pipelined(self, reftracks, normvecs, scalings, kappa_bound, w_veh, alpha_outs, **opt_kw):
+        """A stream of uniform host batches with the PCIe hidden behind the kernels (mcq_solve_host_pipelined): reftracks / normvecs /
+        scalings / alpha_outs are lists (one entry per step) of C-contiguous float64 arrays [B, n, 4] / [B, n, 2] or None / [B, n] or
+        None / [B, n] -- ideally host_array (pinned) memory; entries may repeat.  Returns (curv_err [steps, B], status [steps, B])."""
+        steps = len(reftracks)
+        bsz, n = reftracks[0].shape[0], reftracks[0].shape[1]
+
+        keep = []
+
+        def ptrs(seq, shape, allow_none, output=False):
+            arr = (ctypes.c_void_p * steps)()
+            for k, a in enumerate(seq):
+                if a is None:
+                    if not allow_none:
+                        raise ValueError("missing buffer for step %d" % k)
+                    arr[k] = None
+                    continue
+                if output:
+                    if not isinstance(a, np.ndarray) or a.dtype != np.float64 or a.shape != shape or not a.flags["C_CONTIGUOUS"] \
+                            or not a.flags["WRITEABLE"]:
+                        raise ValueError("step %d: expected a writeable C-contiguous float64 array of shape %r" % (k, shape))
+                else:
+                    a = np.ascontiguousarray(a, dtype=np.float64)       # a no-op for the pinned arrays this entry is meant for
+                    if a.shape != shape:
+                        raise ValueError("step %d: expected shape %r" % (k, shape))
+                    keep.append(a)
+                arr[k] = a.ctypes.data
+            return arr
+        p_ref = ptrs(reftracks, (bsz, n, 4), False)
+        p_nv = ptrs(normvecs, (bsz, n, 2), True) if normvecs is not None else None
+        p_sc = ptrs(scalings, (bsz, n), True) if scalings is not None else None
+        p_al = ptrs(alpha_outs, (bsz, n), False, output=True)
+        curv = np.zeros((steps, bsz))
+        status = np.zeros((steps, bsz), dtype=np.int32)
+        p_cu = (ctypes.c_void_p * steps)(*[curv[k].ctypes.data for k in range(steps)])
+        p_st = (ctypes.c_void_p * steps)(*[status[k].ctypes.data for k in range(steps)])
+        opts = self._opts(**opt_kw)
+        rc = self.lib.mcq_solve_host_pipelined(self.h, steps, bsz, n, p_ref, p_nv, p_sc, float(kappa_bound), float(w_veh),
+                                               ctypes.byref(opts), p_al, p_cu, p_st)
+        self._check(rc, "mcq_solve_host_pipelined")
+        return curv, status
+
+    def solve_device_f32_rows(self, batch, n, layout, d_rows, d_origin, kappa_bound, w_veh, d_alpha, d_curv, d_status, d_info=None,
+                              **opt_kw):
+        """Device-resident float rows in either layout (F32_ABSOLUTE / F32_INCREMENTS; mcq_solve_device_f32_rows): d_rows
+        [batch, n, 4] float32, d_origin [batch, 2] float64 or None, d_alpha [batch, n] float32.  Asynchronous."""
+        opts = self._opts(**opt_kw)
+        rc = self.lib.mcq_solve_device_f32_rows(self.h, int(batch), int(n), int(layout), d_rows, d_origin or None, float(kappa_bound),
+                                                float(w_veh), ctypes.byref(opts), d_alpha, d_curv, d_status, d_info or None)
+        self._check(rc, "mcq_solve_device_f32_rows")
+
+    def solve_batch_f32(self, rows32, origin, kappa_bound, w_veh, layout=F32_INCREMENTS, **opt_kw):
+        """Host-buffer fp32 entry (mcq_solve_batch_f32): rows32 [B, n, 4] float32 in `layout`, origin [B, 2] float64 or None.
+        Returns (alpha float32 [B, n], curv_err [B], status [B], info as a ctypes array of McqInfo)."""
+        rows = np.ascontiguousarray(rows32, dtype=np.float32)
+        bsz, n = rows.shape[0], rows.shape[1]
+        org = None if origin is None else np.ascontiguousarray(origin, dtype=np.float64)
+        if rows.ndim != 3 or rows.shape[2] != 4 or (org is not None and org.shape != (bsz, 2)):
+            raise ValueError("rows32 must be [B, n, 4] and origin [B, 2]")
+        alpha = np.zeros((bsz, n), dtype=np.float32)
+        curv = np.zeros(bsz)
+        status = np.zeros(bsz, dtype=np.int32)
+        info = (McqInfo * bsz)()
+        opts = self._opts(**opt_kw)
+        rc = self.lib.mcq_solve_batch_f32(self.h, bsz, n, int(layout), rows.ctypes.data, org.ctypes.data if org is not None else None,
+                                          float(kappa_bound), float(w_veh), ctypes.byref(opts), alpha.ctypes.data, curv.ctypes.data,
+                                          status.ctypes.data, ctypes.addressof(info))
+        self._check(rc, "mcq_solve_batch_f32")
+        return alpha, curv, status, info
 
     def iqp_batch(self, tracks, kappa_bound, w_veh, stepsize_interp, iters_min=3, curv_error_allowed=0.01, max_rounds=50,
                   nmax=None, timed=False, out=None, **opt_kw):

@@ -154,6 +154,27 @@ int mcq_solve_device_f32(mcq_handle* h, int batch, int n, const float* reftrack,
                          const float* scaling, double kappa_bound, double w_veh, const mcq_opts* opts, float* alpha_out,
                          double* curv_err_out, int* status_out, mcq_info* info_out);
 
+/* fp32 rows in the layout that keeps the QP's accuracy (round 3).  The QP depends on the coordinates only through differences
+ * of neighbouring waypoints (x', x'' of the closed spline), so rounding ABSOLUTE coordinates to float (ulp 1.2e-4 m at |x| = 1.9 km)
+ * throws away what the 3 m steps carry: measured 2e-3 m on alpha at N = 2000.  MCQ_F32_INCREMENTS stores the ring as float
+ * increments -- row i = [x_{i+1} - x_i, y_{i+1} - y_i, w_tr_right_i, w_tr_left_i], row n-1 closing the ring -- plus an optional fp64
+ * origin per track (alpha does not depend on it): the device rebuilds x, y by an fp64 running sum whose closure defect (the float
+ * increments do not sum to zero exactly: ~1e-5 m) is spread evenly over the n increments.  Measured: |alpha - alpha(fp64 rows)|
+ * <= 5e-6 m at N = 2000, the same as rounding the two WIDTH columns alone; stated tolerance of BASELINE config 5: 1e-4 m
+ * (tests/test_gpu_parity.py::test_fp32_boundary_full_size).  Normals and scalings are always derived on the device in fp64.
+ * layout = MCQ_F32_ABSOLUTE takes rows [x, y, w_r, w_l] like mcq_solve_device_f32 (origin added if given). */
+#define MCQ_F32_ABSOLUTE 0
+#define MCQ_F32_INCREMENTS 1
+/* device-resident: reftrack [batch][n][4] float, origin [batch][2] double or NULL, alpha_out [batch][n] float (DEVICE pointers) */
+int mcq_solve_device_f32_rows(mcq_handle* h, int batch, int n, int layout, const float* reftrack, const double* origin,
+                              double kappa_bound, double w_veh, const mcq_opts* opts, float* alpha_out, double* curv_err_out,
+                              int* status_out, mcq_info* info_out);
+/* host buffers (SURVEY.md section 8b's `mcq_solve_batch_f32`): the same for a uniform batch in HOST memory -- float rows in, float
+ * alpha out, half the PCIe bytes of mcq_solve_host; curv_err_out / status_out / info_out (may be NULL) in host memory.  Blocking. */
+int mcq_solve_batch_f32(mcq_handle* h, int batch, int n, int layout, const float* reftrack, const double* origin,
+                        double kappa_bound, double w_veh, const mcq_opts* opts, float* alpha_out, double* curv_err_out,
+                        int* status_out, mcq_info* info_out);
+
 /* The front half of prep_track on the device [REF helper_funcs_glob/src/prep_track.py:48-51]: unit normals (pointing
  * right) and spline scalings s_i = l_i / l_{i+1} of the closed distance-scaled cubic spline through the reference line --
  * what tph.calc_splines(path) returns as normvec_normalized and encodes in its matrix.  reftrack [batch][nmax][4],
@@ -188,7 +209,7 @@ int mcq_relinearise_device(mcq_handle* h, int batch, int nmax, const int* n_in, 
  * filter; every step of upstream's solver: fixed-point lateral limit over all ggv rows, sweeps gated on the acceleration-phase
  * starts and on v_max, one look-ahead round in the backward sweep) followed by calc_ax_profile / calc_t_profile (lap time as
  * the sum of 2 l / (v_a + v_b)).  One device thread per variant.  A variant whose ggv or machine table ends below its v_max
- * (tph raises RuntimeError) gets lap_time NaN.  All pointers DEVICE pointers:
+ * (tph raises RuntimeError) gets lap_time NaN and a vx_out row of NaNs (never stale buffer contents).  All pointers DEVICE pointers:
  * kappa / el_lengths [tracks][nmax] (n valid entries each), track_of [batch] (row used by a variant) or NULL (row =
  * variant), ggv [batch][n_ggv][3] (v, ax_max, ay_max), ax_max_machines [batch][n_machines][2], drag_coeff / m_veh / v_max
  * [batch]; outputs vx_out [batch][nmax], lap_time_out [batch].  Asynchronous on the handle's stream. */
@@ -226,6 +247,17 @@ int mcq_raceline_device(mcq_handle* h, int batch, int nmax, const int* n_in, con
 int mcq_solve_host(mcq_handle* h, int batch, int n, const double* reftrack, const double* normvec, const double* scaling,
                    double kappa_bound, double w_veh, const mcq_opts* opts, double* alpha_out, double* curv_err_out,
                    int* status_out, mcq_info* info_out);
+
+/* A STREAM of uniform batches from / to host memory with the PCIe hidden behind the kernels (SURVEY.md section 8d defines the
+ * metric "inputs resident in host pinned memory -> alpha resident in host memory"): step k's kernels run while step k+1's rows are
+ * uploaded and step k-1's results are downloaded, on two copy streams and two sets of device staging buffers.  Arrays of `steps`
+ * host pointers (pinned memory from mcq_host_alloc for full PCIe speed): reftrack[k] [batch][n][4], normvec[k] [batch][n][2] (array or
+ * entries may be NULL: derived on the device), scaling[k] [batch][n] (may be NULL), alpha_out[k] [batch][n], curv_err_out[k] [batch],
+ * status_out[k] [batch].  Results of step k are bitwise those of mcq_solve_host on the same buffers.  Blocking; returns when
+ * every step's results are in host memory. */
+int mcq_solve_host_pipelined(mcq_handle* h, int steps, int batch, int n, const double* const* reftrack, const double* const* normvec,
+                             const double* const* scaling, double kappa_bound, double w_veh, const mcq_opts* opts,
+                             double* const* alpha_out, double* const* curv_err_out, int* const* status_out);
 
 /* ---- tph.iqp_handler [REF main_globaltraj.py:273-284] as ONE call: the whole iterated re-linearisation of a batch of tracks.
  *

@@ -264,6 +264,7 @@ inline int hipemu_readlane(int v, int src) { return (int)__shfl((double)v, src);
 #define __builtin_amdgcn_s_barrier() hipemu::block_barrier()
 #define __builtin_amdgcn_readfirstlane(v) (v)     /* only used on wave-uniform values */
 #define __builtin_amdgcn_sched_barrier(mask) ((void)0)
+#define __builtin_amdgcn_sched_group_barrier(mask, size, id) ((void)0)
 #define __builtin_amdgcn_s_sleep(n) ((void)0)
 #define __builtin_amdgcn_s_waitcnt(n) ((void)0)
 #define MCQ_PIN_SVV(sreg, vreg0, vreg1) ((void)0)
@@ -311,6 +312,7 @@ inline hipError_t hipEventCreate(hipEvent_t* e) { *e = new hipemu_event{0.0}; re
 inline hipError_t hipEventDestroy(hipEvent_t e) { delete e; return hipSuccess; }
 inline hipError_t hipEventRecord(hipEvent_t e, hipStream_t) { e->t = hipemu_now(); return hipSuccess; }
 inline hipError_t hipEventSynchronize(hipEvent_t) { return hipSuccess; }
+inline hipError_t hipStreamWaitEvent(hipStream_t, hipEvent_t, unsigned) { return hipSuccess; }   /* every emulated stream is synchronous */
 inline hipError_t hipEventElapsedTime(float* ms, hipEvent_t a, hipEvent_t b) { *ms = (float)(b->t - a->t); return hipSuccess; }
 
 template <typename K, typename... Args>

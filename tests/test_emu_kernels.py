@@ -523,3 +523,55 @@ def test_iqp_batch_into_caller_kept_buffers(emu, golden):
         assert np.max(np.abs(b["alpha"][k] - g["iqp_alpha"])) < 1e-8
     with pytest.raises(ValueError):
         emu.iqp_batch(trk, 0.12, 3.4, 3.0, 3, 0.01, nmax=nmax, out=dict(alpha=np.zeros((2, nmax + 1))))
+
+
+def test_fp32_increment_rows_keep_the_accuracy(emu, golden):
+    """MCQ_F32_INCREMENTS (round 3): float rows [x_{i+1} - x_i, y_{i+1} - y_i, w_r, w_l] + an fp64 origin per track.  (i) the engine
+    solves EXACTLY the QP of the rows it rebuilds (fp64 running sum, closure defect spread over the ring): against the dense oracle
+    on engine.increments_to_rows(...) to one float rounding of alpha; (ii) that QP is far closer to the fp64-input one than with
+    absolute float coordinates -- the stated reason for the layout; (iii) layout 0 through the same entry equals the old float entry;
+    (iv) the origin does not enter alpha."""
+    g = golden["rounded_rectangle"]
+    ref = g["reftrack"].copy()
+    ref[:, :2] += np.array([1500.0, -900.0])          # a track far from the origin: absolute float coordinates lose 1.2e-4 m
+    rows32, org = engine.rows_to_increments(ref[None])
+    a_inc, curv, st, info = emu.solve_batch_f32(rows32, org, 0.12, 3.4, layout=engine.F32_INCREMENTS)
+    assert a_inc.dtype == np.float32 and st[0] == 0
+    r64 = engine.increments_to_rows(rows32, org)[0]
+    assert np.max(np.abs(r64[:, :2] - ref[:, :2])) < 1e-5
+    _, _, A, nv_d = tph_ref.calc_splines(np.vstack((r64[:, :2], r64[0, :2])))
+    a_ref, err_ref = tph_ref.opt_min_curv(r64, nv_d, A, 0.12, 3.4)
+    assert np.max(np.abs(a_inc[0] - a_ref)) <= np.max(np.abs(a_ref)) * 2.0 ** -24 + 1e-9
+    assert abs(curv[0] - err_ref) < 1e-10
+    d_inc = float(np.max(np.abs(a_inc[0] - g["alpha"])))
+    a_abs, _, st_a, _ = emu.solve_batch_f32(ref[None].astype(np.float32), None, 0.12, 3.4, layout=engine.F32_ABSOLUTE)
+    d_abs = float(np.max(np.abs(a_abs[0] - g["alpha"])))
+    assert st_a[0] == 0 and d_inc < 2e-6 and d_abs > 20 * d_inc, (d_inc, d_abs)
+    a_old, _, st_o, _ = emu.solve_uniform_f32(ref[None].astype(np.float32), None, None, 0.12, 3.4)
+    assert st_o[0] == 0 and np.array_equal(a_old, a_abs)
+    a_no_org, _, _, _ = emu.solve_batch_f32(rows32, None, 0.12, 3.4, layout=engine.F32_INCREMENTS)
+    assert np.max(np.abs(a_no_org[0].astype(np.float64) - a_inc[0])) < 1e-6
+
+
+def test_solve_host_pipelined_equals_solve_host(emu, golden):
+    """mcq_solve_host_pipelined (uploads / kernels / downloads of consecutive batches overlapped on three streams, two staging
+    slots): every step's results are bitwise those of the blocking entry on the same buffers -- five steps, so both slots are
+    reused, with different rows per step and the normals derived on the device in one of them."""
+    g = golden["rounded_rectangle"]
+    n = g["reftrack"].shape[0]
+    refs, nvs, scs, outs = [], [], [], []
+    for k in range(5):
+        r = np.stack((g["reftrack"], g["reftrack"]))
+        r[0, :, 2:] += 0.05 * k
+        r[1, :, 2:] += 0.02 * (k + 1)
+        refs.append(r)
+        nvs.append(None if k == 2 else np.stack((g["normvec"],) * 2))
+        scs.append(None if k == 2 else np.stack((g["scaling"],) * 2))
+        outs.append(np.full((2, n), np.nan))
+    curv, st = emu.solve_host_pipelined(refs, nvs, scs, 0.12, 3.4, outs)
+    assert np.all(st == 0)
+    for k in range(5):
+        al, cu, s1, _ = emu.solve_host(refs[k], nvs[k], scs[k], 0.12, 3.4)
+        assert np.array_equal(al, outs[k]) and np.array_equal(cu, curv[k]) and list(s1) == [0, 0], k
+    with pytest.raises(ValueError):
+        emu.solve_host(refs[0], nvs[0], scs[0], 0.12, 3.4, alpha_out=np.zeros((2, n), dtype=np.float32))

@@ -31,20 +31,58 @@ def test_reference_tracks_match_golden(gpu_engine, golden):
 
 
 def test_berlin_n333(gpu_engine):
-    """BASELINE config 2 at 'N ~ 330' (stepsize_reg = 7 m) against the live dense oracle."""
+    """BASELINE config 2 at its second size, 'N ~ 330': the reference's own preprocessing of inputs/tracks/berlin_2018.csv with
+    stepsize_reg = 7.0 m (tph.spline_approximation, FITPACK) -- NOT a subsampling of the N = 776 ring -- committed with the dense
+    oracle's alpha as tests/golden/berlin_2018_n333.npz (scripts/make_golden_r3.py; second route TRF 1.3e-10 m, KKT 7e-15).
+    Against the fixture, against the live dense oracle on the fixture's rows, and through the drop-in function."""
+    from conftest import load_golden
     from oracle import tph_ref
-    import os
-    g = np.load(os.path.join(os.path.dirname(__file__), "golden", "berlin_2018.npz"))
-    ref776 = g["reftrack"]
-    # re-sample the committed N=776 reftrack to every ~7 m (no access to /root/reference on the GPU box)
-    idx = np.round(np.linspace(0, ref776.shape[0], 333, endpoint=False)).astype(int)
-    ref = ref776[idx]
+    g = load_golden("berlin_2018_n333")
+    ref = g["reftrack"]
+    assert ref.shape == (333, 4)
+    al, curv, st, info = gpu_engine.solve_batch([dict(reftrack=ref, normvec=g["normvec"], scaling=g["scaling"], kappa_bound=0.12, w_veh=3.4)])
+    assert st[0] == 0 and info[0]["kkt_res"] < 1e-9
+    assert np.max(np.abs(al[0] - g["alpha"])) < ALPHA_TOL
+    assert abs(curv[0] - float(g["curv_error_max"])) < CURV_TOL
     path_cl = np.vstack((ref[:, :2], ref[0, :2]))
     _, _, A, nv = tph_ref.calc_splines(path_cl)
+    assert np.max(np.abs(nv - g["normvec"])) < 1e-12
     a_ref, err_ref = tph_ref.opt_min_curv(ref, nv, A, 0.12, 3.4)
     a, err = tph.opt_min_curv.opt_min_curv(ref, nv, A, 0.12, 3.4)
-    assert np.max(np.abs(a - a_ref)) < ALPHA_TOL
+    assert np.max(np.abs(a - a_ref)) < ALPHA_TOL and np.max(np.abs(a_ref - g["alpha"])) < 1e-9
     assert abs(err - err_ref) < CURV_TOL
+
+
+def test_iqp_handler_reference_default_flow_berlin_modena(gpu_engine, golden):
+    """The reference's DEFAULT flow [REF main_globaltraj.py:273-284; params/racecar.ini:72-74: iters_min 3, curv_error_allowed
+    0.01, stepsize_interp = stepsize_reg = 3.0] on its shipped track (Berlin, N = 776) and on Modena (N = 663): the END STATE of
+    the whole iterated re-linearisation against the dense oracle's chain (tests/golden/*_iqp.npz: dense 4N x 4N re-spline and
+    dense Goldfarb-Idnani with all 4N rows every pass, scripts/make_golden_r3.py) -- through the drop-in iqp_handler (one engine
+    call, warm-started passes), the device-resident driver cold, and the host-glue driver; per-pass ring sizes and curvature
+    errors against the oracle's trace."""
+    from conftest import load_golden
+    from global_racetrajectory_optimization_amd.trajectory_planning_helpers import iqp_handler as iq
+    for name in ("berlin_2018", "modena_2019"):
+        g, q = golden[name], load_golden(name + "_iqp")
+        A = tph.calc_splines.build_les_matrix(g["reftrack"].shape[0], g["scaling"])
+        outs = [tph.iqp_handler.iqp_handler(reftrack=g["reftrack"].copy(), normvectors=g["normvec"], A=A, kappa_bound=0.12, w_veh=3.4,
+                                            print_debug=False, plot_debug=False, stepsize_interp=3.0, iters_min=3,
+                                            curv_error_allowed=0.01)]
+        trk = [dict(reftrack=g["reftrack"].copy(), normvectors=g["normvec"], scaling=g["scaling"])]
+        for kw in (dict(device_resident=True, warm_start=False), dict(device_resident=False)):
+            stt = {}
+            outs.append(iq.iqp_handler_batch(trk, 0.12, 3.4, 3.0, 3, 0.01, engine=gpu_engine, stats=stt, **kw)[0])
+            assert stt["rounds"] == len(q["iqp_n"])
+        for a, ref_out, nv_out in outs:
+            assert a.shape == q["iqp_alpha"].shape == (int(q["iqp_n"][-1]),), name
+            assert np.max(np.abs(a - q["iqp_alpha"])) < ALPHA_TOL, (name, float(np.max(np.abs(a - q["iqp_alpha"]))))
+            assert np.max(np.abs(ref_out - q["iqp_reftrack"])) < 1e-6, name
+            assert np.max(np.abs(nv_out - q["iqp_normvec"])) < 1e-8, name
+        # the trace the engine keeps per round (what print_debug prints) against the oracle's
+        res = gpu_engine.iqp_batch(trk, 0.12, 3.4, 3.0, iters_min=3, curv_error_allowed=0.01)
+        k = int(res["rounds"][0])
+        assert k == len(q["iqp_curv_err"])
+        assert np.max(np.abs(res["curv_trace"][0, :k] - q["iqp_curv_err"])) < 1e-8, name
 
 
 def test_drop_in_opt_min_curv_signature(golden):
@@ -688,6 +726,32 @@ def test_oval_n2000_first_pass_against_golden(gpu_engine):
     A = tph.calc_splines.build_les_matrix(2000, g["scaling"])
     a, err = tph.opt_min_curv.opt_min_curv(g["reftrack"], g["normvec"], A, 0.12, 3.4)
     assert np.max(np.abs(a - g["alpha"])) < ALPHA_TOL and abs(err - float(g["curv_error_max"])) < CURV_TOL
+
+
+def test_oval_n2000_more_width_seeds_and_config5_tracks_against_golden(gpu_engine):
+    """Four more full-size problems through the dense oracle (scripts/make_golden_r3.py; each pinned by the TRF second route to
+    < 1e-9 m and a KKT certificate): width seeds 1 and 2 of the bench workload (BASELINE config 3) and generator indices 5 and 9
+    of config 5's generator (perturb_centreline = True: per-track centrelines).  The fixtures' inputs must BE the generator's
+    output; alpha / curv_error_max against the oracle's, from rows + normals + scalings and from rows alone."""
+    from conftest import load_golden
+    probs, want = [], []
+    for name, idx, pert in (("oval_n2000_w1", 1, False), ("oval_n2000_w2", 2, False), ("oval_n2000_c5", 5, True), ("oval_n2000_c9", 9, True)):
+        g = load_golden(name)
+        ref, nv, sc = synthetic.oval_batch(1, n=2000, first=idx, perturb_centreline=pert)
+        assert np.array_equal(ref[0], g["reftrack"]) and np.array_equal(nv[0], g["normvec"]) and np.array_equal(sc[0], g["scaling"]), name
+        probs.append(dict(reftrack=g["reftrack"], normvec=g["normvec"], scaling=g["scaling"], kappa_bound=0.12, w_veh=3.4))
+        probs.append(dict(reftrack=g["reftrack"], normvec=None, scaling=None, kappa_bound=0.12, w_veh=3.4))
+        want += [(name, g), (name, g)]
+    al, curv, st, info = gpu_engine.solve_batch(probs[0::2])
+    al2, curv2, st2, info2 = gpu_engine.solve_batch(probs[1::2])
+    worst = 0.0
+    for k, (name, g) in enumerate(want[0::2]):
+        for a, c, s in ((al[k], curv[k], st[k]), (al2[k], curv2[k], st2[k])):
+            assert s == 0, name
+            worst = max(worst, float(np.max(np.abs(a - g["alpha"]))))
+            assert np.max(np.abs(a - g["alpha"])) < ALPHA_TOL, (name, float(np.max(np.abs(a - g["alpha"]))))
+            assert abs(c - float(g["curv_error_max"])) < CURV_TOL, name
+    print("N=2000 goldens (2 width seeds, 2 config-5 tracks): max |alpha - dense oracle| = %.2e m" % worst)
 
 
 def test_oval_n2000_iqp_end_state_against_golden(gpu_engine):
