@@ -56,51 +56,75 @@ KAPPA_BOUND, W_VEH = 0.12, 3.4
 # roofline model of mcq_solve_kernel ('banded-exact' mode)
 # ----------------------------------------------------------------------------------------------------------------------
 def work_model(n, info, band_e=32):
-    """Algorithmic HBM bytes and fp64 flops of mcq_solve_kernel for one launch, from the iteration counts the solver reports.
+    """HBM bytes and fp64 flops of mcq_solve_kernel for one launch, from the iteration counts the solver reports (mcq_info).
 
-    Rows AS STORED (csrc/mcq_kernels.h): H row 130 doubles (65 band | pad | 64 border), L row 144 doubles (64 band | 16
-    inverse-diagonal-tile | 64 border W), E / E' bands 65 doubles per row.  MINIMAL rows (what the bordered-band algorithm needs
-    whatever the layout): H 129 doubles, L 128 doubles (the inverse diagonal tile is a stored by-product of the factorisation).
-      factorisation : read the H rows + write the L rows;   solve: forward + backward sweep, each reads the L rows
-      gradient      : E band + E' band
-    IPM iteration = 1 factorisation + 2 solves (the gradient is carried through the reduced system; one exact gradient
-    confirms convergence); active-set iteration = 1 factorisation + 1 solve + 2 gradients; refinement round = 1 solve +
-    1 gradient; + 1 initial gradient + 3 band products in the epilogue.
-    Flops (2 per FMA): factorisation 10272 FMAs per column (band 2080 + border 4096 + Schur 4096), sweep
-    144 FMAs per row and direction, band product 65 FMAs per row.
+    Two byte counts:
 
-    Since round 2 the forward sweep of the solve that follows a factorisation (the predictor's, the active-set round's) is fused
-    into the factorisation -- its L rows are used from the LDS window and never streamed.  The DECLARED model (first value:
-    what the algorithm nominally moves, the figure `roofline.achieved` has been computed from since round 1) does not credit
-    that; the third value returned is the same count minus the fused sweeps: what this implementation has to stream.
+    streamed   what THIS implementation has to move through HBM per launch -- the figure `roofline.achieved` / `frac` are computed
+               from since round 3 (the declared model credited bytes the kernel no longer moves).  Rows as stored
+               (csrc/mcq_kernels.h): L row 144 doubles (64 band | 16 inverse-diagonal-tile | 64 border W), E / E' bands 65 doubles
+               per row, H row 65 band doubles + 64 border doubles for the 128 rows within the band width of either end of the
+               interior (elsewhere the border half is zeros and is not read).
+                 factorisation       : read H (n * 65 + 128 * 64 doubles) + write L (n * 144 doubles); the forward substitution of
+                                       the solve that follows rides through it on the LDS window (no bytes)
+                 solve after a factorisation (interior-point predictor, active-set round): backward sweep only, n * 144 doubles
+                 any other solve (corrector, refinement round)                             : both sweeps, 2 n * 144 doubles
+                 gradient            : E band + E' band, 2 n * 65 doubles
+               interior-point iteration = 1 factorisation + predictor solve + corrector solve (one exact gradient per problem
+               confirms convergence); active-set round = 1 factorisation + 1 solve + 2 gradients; refinement round = 1 solve + 1
+               gradient; + 1 initial gradient + 1.5 band products in the epilogue.
+    declared   SURVEY.md section 8(d)'s banded-exact formula as rounds 1-2 declared it: every solve counted with both sweeps, every
+               H row with all 130 doubles.  Kept as the secondary figure (`frac_declared_model`) for continuity.
+
+    Flops (2 per FMA): factorisation 10272 FMAs per column (band 2080 + border 4096 + Schur 4096), sweep 144
+    FMAs per row and direction, band product 65 FMAs per row.
     """
     ipm = info["ipm_iters"].astype(np.float64)
     act = info["as_iters"].astype(np.float64)
     ref = info["refine_rounds"].astype(np.float64)
     n_fac, n_sol = ipm + act, 2 * ipm + act + ref
     n_grad = 1.0 + 2 * act + ref + 1.0 + 1.5
+    ew = 2 * band_e + 1
+    grad = 2.0 * n * ew * 8.0
+    # declared model
+    declared = float((n_fac * n * (130.0 + 144.0) * 8.0 + n_sol * 2.0 * n * 144.0 * 8.0 + n_grad * grad).sum())
+    # streamed model
+    h_read = (n * 65.0 + 128.0 * 64.0) * 8.0
+    l_row = n * 144.0 * 8.0
+    sweeps = 2.0 * n_sol - n_fac                   # one forward sweep per factorisation is fused into it
+    streamed = float((n_fac * (h_read + l_row) + sweeps * l_row + n_grad * grad).sum())
+    flops = float((n_fac * 2.0 * n * 10272.0 + n_sol * 2.0 * 2.0 * n * 144.0 + n_grad * 2.0 * 2.0 * n * ew).sum())
+    return dict(streamed=streamed, declared=declared, flops=flops,
+                per_problem=dict(factorisations=float(n_fac.mean()), solves=float(n_sol.mean()), sweeps_streamed=float(sweeps.mean()),
+                                 gradients=float(n_grad.mean()), bytes_factorisation=h_read + l_row, bytes_sweep=l_row, bytes_gradient=grad))
 
-    def total(h_row, l_row):
-        fac = n * (h_row + l_row) * 8.0
-        sol = 2.0 * n * l_row * 8.0
-        grad = 2.0 * n * (2 * band_e + 1) * 8.0
-        return float((n_fac * fac + n_sol * sol + n_grad * grad).sum())
 
-    flops = float((n_fac * 2.0 * n * 10272.0 + n_sol * 2.0 * 2.0 * n * 144.0 + n_grad * 2.0 * 2.0 * n * (2 * band_e + 1)).sum())
-    fused = float((n_fac * n * 144.0 * 8.0).sum())          # one forward sweep per factorisation rides through it
-    return total(130.0, 144.0), total(129.0, 128.0), flops, total(130.0, 144.0) - fused
+def source_sha():
+    """SHA-256 over the engine's sources (csrc/*.hip, *.h, build.sh): what ties a counter summary under profiles/ to the binary a
+    bench line was measured on (the GPU box has no .git)."""
+    import hashlib
+    h = hashlib.sha256()
+    base = os.path.join(ROOT, "global_racetrajectory_optimization_amd", "csrc")
+    for name in ("build.sh", "mcq_api.hip", "mcq_kernels.h", "mcq_kernels.hip"):
+        with open(os.path.join(base, name), "rb") as fh:
+            h.update(name.encode() + b"\0" + fh.read())
+    return h.hexdigest()
 
 
 def measured_traffic():
     """HBM traffic of mcq_solve_kernel per launch from the committed rocprofv3 PMC passes (profiles/latest_pmc.json, written by
-    scripts/pmc_summary.py from separate --pmc runs of this same command).  Returns (bytes, source label) or (None, None): the
-    counters cannot be read from inside an unprofiled run, so the line names the file the figure comes from."""
+    scripts/pmc_summary.py from separate --pmc runs of this same command; the counters cannot be read from inside an unprofiled
+    run).  The summary carries the SHA-256 of the engine sources it was collected on (scripts/profile_round.sh writes it on the GPU
+    box): a summary of OTHER sources is not quoted -- (None, reason)."""
     path = os.path.join(ROOT, "profiles", "latest_pmc.json")
     try:
         with open(path) as fh:
             doc = json.load(fh)
         k = doc["kernels"]["mcq_solve_kernel"]
-        return float(k["traffic_bytes"]), "profiles/latest_pmc.json (%s)" % doc.get("source", "rocprofv3 --pmc passes of the default workload")
+        sha = doc.get("engine_source_sha256")
+        if sha != source_sha():
+            return None, "profiles/latest_pmc.json is from other engine sources (%s...): not quoted" % (sha[:12] if sha else "unstamped")
+        return float(k["traffic_bytes"]), "profiles/latest_pmc.json (%s; engine sources %s...)" % (doc.get("source", "rocprofv3 --pmc passes"), sha[:12])
     except Exception:
         return None, None
 
@@ -213,29 +237,28 @@ def self_launch(args):
     raise SystemExit(subprocess.call(cmd, env=env))
 
 
-def config4_workload(rank, world):
+def config4_workload(rank, world, tracks=("berlin_2018", "modena_2019", "handling_track", "rounded_rectangle"), n_widths=64, nveh=64):
     """This rank's shard of BASELINE config 4: (track, vehicle width) QPs -- 4 reference tracks x 64 widths, block partition --
-    each carrying its 64 (gg-scale, top-speed) vehicles."""
+    each carrying its 64 (gg-scale, top-speed) vehicles.  (tracks / n_widths / nveh: the defaults ARE config 4; tests shrink them.)"""
     from global_racetrajectory_optimization_amd import parallel
-    tracks = ("berlin_2018", "modena_2019", "handling_track", "rounded_rectangle")
     gold = [np.load(os.path.join(ROOT, "tests", "golden", t + ".npz")) for t in tracks]
-    w_grid = np.linspace(2.0, 3.4, 64)
+    w_grid = np.linspace(2.0, 3.4, n_widths)
     uniq = [dict(reftrack=g["reftrack"], normvec=g["normvec"], scaling=g["scaling"], kappa_bound=KAPPA_BOUND, w_veh=float(w))
             for g in gold for w in w_grid]
     lo, hi = parallel.shard_bounds(len(uniq), world, rank)
-    nveh, side = 64, 8
+    side = max(int(round(np.sqrt(nveh))), 1)
     v = np.arange(0.0, 72.1, 4.0)
     ggv0 = np.column_stack((v, np.full(v.size, 12.0), np.full(v.size, 12.0)))
     axm0 = np.column_stack((v, np.interp(v, [0.0, 20.0, 72.0], [5.3, 5.3, 1.2])))
-    gg_scale = 0.3 + 0.7 * (np.arange(nveh) % side) / (side - 1)
-    v_top = 100.0 / 3.6 + (150.0 / 3.6) * (np.arange(nveh) // side) / ((nveh - 1) // side)
+    gg_scale = 0.3 + 0.7 * (np.arange(nveh) % side) / max(side - 1, 1)
+    v_top = 100.0 / 3.6 + (150.0 / 3.6) * (np.arange(nveh) // side) / max((nveh - 1) // side, 1)
     mine = uniq[lo:hi]
     nvar = len(mine) * nveh
     track_of = np.repeat(np.arange(len(mine), dtype=np.int32), nveh)
     veh_of = np.tile(np.arange(nveh), len(mine))
     ggv = np.repeat(ggv0[None], nvar, axis=0)
     ggv[:, :, 1:] *= gg_scale[veh_of][:, None, None]
-    return dict(qps=mine, n_total=len(uniq) * nveh, per_rank=-(-len(uniq) // world) * nveh, nvar=nvar, track_of=track_of, ggv=ggv,
+    return dict(qps=mine, lo=lo, n_total=len(uniq) * nveh, per_rank=-(-len(uniq) // world) * nveh, nvar=nvar, track_of=track_of, ggv=ggv,
                 axm=np.repeat(axm0[None], nvar, axis=0), tops=v_top[veh_of], tracks={t: int(g["reftrack"].shape[0]) for t, g in zip(tracks, gold)})
 
 
@@ -248,6 +271,13 @@ def main():
     ap.add_argument("--batch", type=int, default=None)
     ap.add_argument("--n", type=int, default=2000)
     ap.add_argument("--io", choices=("f64", "f32"), default=None)
+    ap.add_argument("--f32-layout", choices=("inc", "abs"), default="inc",
+                    help="--io f32: float rows as ring increments + an fp64 origin per track (MCQ_F32_INCREMENTS, the default: "
+                         "|alpha - alpha(fp64 rows)| <= 1e-4 m) or as absolute coordinates (MCQ_F32_ABSOLUTE: 2e-3 m at N = 2000)")
+    ap.add_argument("--host-steps", type=int, default=20, help="steps of the pipelined host_to_host record")
+    ap.add_argument("--c4-tracks", default="berlin_2018,modena_2019,handling_track,rounded_rectangle", help="config 4: tracks of the matrix")
+    ap.add_argument("--c4-widths", type=int, default=64, help="config 4: vehicle widths per track")
+    ap.add_argument("--c4-vehicles", type=int, default=64, help="config 4: (gg-scale, top-speed) vehicles per QP (a square number)")
     ap.add_argument("--perturb-centreline", action="store_true")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extras", action="store_true", help="skip the host_to_host and iqp records (and the CPU baselines)")
@@ -328,7 +358,7 @@ def main():
     ag_ev = []          # (start, end) CUDA events around every all-gather of the timed region
 
     if args.config == 4:
-        wl = config4_workload(rank, world)
+        wl = config4_workload(rank, world, tuple(args.c4_tracks.split(",")), args.c4_widths, args.c4_vehicles)
         d_lap = torch.zeros((wl["per_rank"],), dtype=torch.float64, device=dev)
         d_all = torch.zeros((world * wl["per_rank"],), dtype=torch.float64, device=dev) if collective else None
         lap_h = [None]
@@ -346,7 +376,13 @@ def main():
                 dist.all_gather_into_tensor(d_all, d_lap)
     else:
         ref_h, nv_h, sc_h = synthetic.oval_batch(B, n=n, first=rank * B, perturb_centreline=args.perturb_centreline)
-        d_ref = torch.from_numpy(ref_h).to(dev).to(io_t)
+        d_org = None
+        if f32 and args.f32_layout == "inc":
+            rows32, org = engine.rows_to_increments(ref_h)           # float ring increments + fp64 origin per track
+            d_ref = torch.from_numpy(rows32).to(dev)
+            d_org = torch.from_numpy(org).to(dev)
+        else:
+            d_ref = torch.from_numpy(ref_h).to(dev).to(io_t)
         d_nv = torch.from_numpy(nv_h).to(dev).to(io_t)
         d_sc = torch.from_numpy(sc_h).to(dev).to(io_t)
         # two result buffers, used in turn: the all-gather of step k (RCCL, torch's stream) runs while step k+1 solves into the other one
@@ -365,9 +401,10 @@ def main():
             step_no[0] += 1
             if gather_done[slot] is not None:
                 gather_done[slot].synchronize()      # the all-gather that last read this buffer (two steps ago) has finished
-            if f32:     # float normals are unit vectors only to 6e-8: let the engine derive them (and the scalings) in fp64
-                eng.solve_device_f32(B, n, d_ref.data_ptr(), None, None, KAPPA_BOUND, W_VEH,
-                                     d_alpha.data_ptr(), d_curv.data_ptr(), d_status.data_ptr(), d_info.data_ptr())
+            if f32:     # float normals are unit vectors only to 6e-8: the engine derives them (and the scalings) in fp64
+                eng.solve_device_f32_rows(B, n, engine.F32_INCREMENTS if d_org is not None else engine.F32_ABSOLUTE, d_ref.data_ptr(),
+                                          d_org.data_ptr() if d_org is not None else None, KAPPA_BOUND, W_VEH,
+                                          d_alpha.data_ptr(), d_curv.data_ptr(), d_status.data_ptr(), d_info.data_ptr())
             else:
                 eng.solve_device(B, n, d_ref.data_ptr(), d_nv.data_ptr(), d_sc.data_ptr(), KAPPA_BOUND, W_VEH,
                                  d_alpha.data_ptr(), d_curv.data_ptr(), d_status.data_ptr(), d_info.data_ptr())
@@ -419,20 +456,35 @@ def main():
         if args.config != 4:
             assert torch.equal(d_all[rank * B:(rank + 1) * B], d_alpha), "all-gather: own shard differs"
     ranks_seen = dist.get_world_size() if collective else 1
+    assert ranks_seen == world, "process group has %d ranks, the launcher announced %d" % (ranks_seen, world)
     ag_ms = float(np.mean([a.elapsed_time(b) for a, b in ag_ev])) if ag_ev else None
 
     out = None
     if args.config == 4:
+        # every rank's lap times in partition order (the gathered tensor is padded to the largest shard); listed in the line for
+        # small matrices only (tests)
+        gathered_laps = None
+        if wl["n_total"] <= 256:
+            if collective:
+                allv = d_all.cpu().numpy().reshape(world, wl["per_rank"])
+                from global_racetrajectory_optimization_amd import parallel as _par
+                nq = wl["n_total"] // args.c4_vehicles
+                gathered_laps = [float(v) for r in range(world)
+                                 for v in allv[r, :(_par.shard_bounds(nq, world, r)[1] - _par.shard_bounds(nq, world, r)[0]) * args.c4_vehicles]]
+            else:
+                gathered_laps = [float(v) for v in lap_h[0]]
         if rank == 0:
             lap = lap_h[0]
             out = {"metric": "lap-time-matrix variants/sec (BASELINE config 4: 16384 variants)", "value": wl["n_total"] * args.steps / dt,
                    "unit": "variants/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * dt / args.steps,
-                   "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f64", "data": "reference tracks (tests/golden), synthetic vehicles",
+                   "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f64",
+                   "data": "reference tracks (tests/golden), synthetic vehicles" + (" -- EMULATED ON CPU (test of the launch logic): NOT A MEASUREMENT" if emulate else ""),
                    "config": {"workload": "BASELINE config 4: lap-time matrix of %d variants = 4 reference tracks x 64 vehicle widths (256 QPs, "
                                           "solved once each: the vehicle tables do not enter the QP) x 64 (gg-scale, top-speed) vehicles; per step: "
                                           "QPs + racelines + velocity profiles through the host-buffer entries (packing + PCIe included), block "
                                           "partition over the ranks, one all-gather of the lap times" % wl["n_total"],
-                              "tracks": wl["tracks"], "variants_this_rank": wl["nvar"], "ranks_seen": ranks_seen,
+                              "tracks": wl["tracks"], "variants_total": wl["n_total"], "variants_this_rank": wl["nvar"], "ranks_seen": ranks_seen,
+                              "lap_times_gathered_s": gathered_laps,
                               "rank_ms_per_step": {"min": min(rank_ms), "max": max(rank_ms)},
                               "lap_time_range_s": [float(lap.min()), float(lap.max())]}}
     elif rank == 0:
@@ -442,8 +494,8 @@ def main():
         curv_gpu = d_curv.cpu().numpy()
         value = world * B * args.steps / dt
         k_ms = float(np.mean([m["solve"] for m in solve_ms]))
-        alg, alg_min, flops, alg_streamed = work_model(n, info)
-        achieved = alg / (k_ms * 1e-3) / 1e9
+        wm = work_model(n, info)
+        achieved = wm["streamed"] / (k_ms * 1e-3) / 1e9
         default_wl = B == 1024 and n == 2000 and not args.perturb_centreline
         traffic, traffic_src = measured_traffic() if default_wl else (None, None)
         out = {
@@ -457,11 +509,12 @@ def main():
                                    % ("5" if args.perturb_centreline else "3", n, B,
                                       "reference tracks (centreline and widths perturbed per track)" if args.perturb_centreline
                                       else "track-width perturbations"),
-                       "batch_per_gpu": B, "n_waypoints": n, "io": args.io + (" rows / alpha in HBM, fp64 arithmetic" if f32 else ""),
+                       "batch_per_gpu": B, "n_waypoints": n,
+                       "io": args.io + ((" rows (%s) / float alpha in HBM, fp64 arithmetic" % ("ring increments + fp64 origin" if args.f32_layout == "inc" else "absolute coordinates")) if f32 else ""),
                        "centrelines": "perturbed per track" if args.perturb_centreline else "shared",
                        "collective": "1 all-gather of alpha per step" if collective else "none",
                        "ranks_seen": ranks_seen, "rank_ms_per_step": {"min": min(rank_ms), "max": max(rank_ms)},
-                       "allgather_ms": ag_ms,
+                       "allgather_ms": ag_ms, "allgather_dtype": str(io_t).replace("torch.", ""),
                        "failed_problems": int(np.count_nonzero(status)),
                        "mean_ipm_iters": float(info["ipm_iters"].mean()), "mean_as_iters": float(info["as_iters"].mean()),
                        "mean_active_box_rows": float(info["n_active_box"].mean()),
@@ -475,34 +528,52 @@ def main():
                        # effective shader clock of the solver kernel: s_memtime / s_memrealtime read inside the kernel, per problem
                        "solver_effective_sclk_mhz": {"mean": float(np.mean(100.0 * info["ticks"][:, 6] / np.maximum(info["ticks"][:, 3], 1))),
                                                      "min": float(np.min(100.0 * info["ticks"][:, 6] / np.maximum(info["ticks"][:, 3], 1)))},
+                       "engine_source_sha256": source_sha(),
                        "gpu_power_temp_during_timed_region": clocks},
+            # `achieved` / `frac`: the bytes this implementation has to stream (work_model: fused forward sweeps and the all-zero border
+            # halves of H are NOT counted) over the kernel's average duration (HIP events on the engine's stream, this run).
             "roofline": {"bound": "hbm", "kernel": "mcq_solve_kernel", "achieved": achieved, "peak": HBM_PEAK_GBS,
                          "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                          "traffic": traffic, "traffic_source": traffic_src,
-                         "algorithmic_bytes_per_launch": alg, "kernel_ms": k_ms,
-                         "frac_minimal_rows": alg_min / (k_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
-                         "frac_streamed_model": alg_streamed / (k_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
-                         "streamed_bytes_per_launch": alg_streamed,
-                         "algorithmic_bytes_per_launch_minimal_rows": alg_min,
-                         "fp64_flops_per_launch": flops, "fp64_tflops": flops / (k_ms * 1e-3) / 1e12,
-                         "fp64_frac_of_%.1f_tflops" % FP64_PEAK_TFLOPS: flops / (k_ms * 1e-3) / 1e12 / FP64_PEAK_TFLOPS},
+                         "algorithmic_bytes_per_launch": wm["streamed"], "kernel_ms": k_ms,
+                         "model": "streamed (DESIGN.md section 6); per problem: %s" % json.dumps({k: round(v, 3) for k, v in wm["per_problem"].items()}),
+                         "frac_of_measured_traffic": (traffic / (k_ms * 1e-3) / 1e9 / HBM_PEAK_GBS) if traffic else None,
+                         "declared_bytes_per_launch": wm["declared"],
+                         "frac_declared_model": wm["declared"] / (k_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                         "fp64_flops_per_launch": wm["flops"], "fp64_tflops": wm["flops"] / (k_ms * 1e-3) / 1e12,
+                         "fp64_frac_of_%.1f_tflops" % FP64_PEAK_TFLOPS: wm["flops"] / (k_ms * 1e-3) / 1e12 / FP64_PEAK_TFLOPS},
         }
         extras = world == 1 and not args.no_extras and not f32 and not emulate
         if extras:
             # ---- the wall SURVEY.md section 8d defines: inputs in pinned host memory -> alpha in host memory ---------------------
-            p_ref, p_nv, p_sc, p_al = eng.host_array((B, n, 4)), eng.host_array((B, n, 2)), eng.host_array((B, n)), eng.host_array((B, n))
+            # blocking entry (one batch: H2D -> kernels -> D2H) and the pipelined stream of batches (mcq_solve_host_pipelined: step k's
+            # kernels run while step k+1 uploads and step k-1 downloads)
+            p_ref, p_nv, p_sc = eng.host_array((B, n, 4)), eng.host_array((B, n, 2)), eng.host_array((B, n))
+            p_al = [eng.host_array((B, n)), eng.host_array((B, n))]
             p_ref[...], p_nv[...], p_sc[...] = ref_h, nv_h, sc_h
-            eng.solve_host(p_ref, p_nv, p_sc, KAPPA_BOUND, W_VEH, alpha_out=p_al)
+            eng.solve_host(p_ref, p_nv, p_sc, KAPPA_BOUND, W_VEH, alpha_out=p_al[0])
             hh = []
-            for _ in range(max(args.steps, 3)):
+            for _ in range(3):
                 t1 = time.perf_counter()
-                _, _, st_h, _ = eng.solve_host(p_ref, p_nv, p_sc, KAPPA_BOUND, W_VEH, alpha_out=p_al)
+                _, _, st_h, _ = eng.solve_host(p_ref, p_nv, p_sc, KAPPA_BOUND, W_VEH, alpha_out=p_al[0])
                 hh.append(time.perf_counter() - t1)
-            out["host_to_host"] = {"value": B / float(np.mean(hh)), "unit": "solves/s", "ms_per_step": 1e3 * float(np.mean(hh)),
-                                   "what": "mcq_solve_host: rows / normals / scalings in pinned host memory -> H2D -> the same kernels -> alpha, "
-                                           "curv_error, status, info D2H, blocking; %d calls" % len(hh),
-                                   "bytes_h2d": int(p_ref.nbytes + p_nv.nbytes + p_sc.nbytes), "bytes_d2h": int(p_al.nbytes),
-                                   "alpha_equal_to_device_resident_run": bool(np.array_equal(p_al, alpha_gpu)), "failed_problems": int(np.count_nonzero(st_h))}
+            hs = max(args.host_steps, 2)
+            eng.solve_host_pipelined([p_ref] * 2, [p_nv] * 2, [p_sc] * 2, KAPPA_BOUND, W_VEH, p_al)       # staging slots, streams
+            p_al[0][...] = np.nan
+            p_al[1][...] = np.nan
+            t1 = time.perf_counter()
+            _, st_p = eng.solve_host_pipelined([p_ref] * hs, [p_nv] * hs, [p_sc] * hs, KAPPA_BOUND, W_VEH, [p_al[k & 1] for k in range(hs)])
+            t_pipe = time.perf_counter() - t1
+            out["host_to_host"] = {"value": B * hs / t_pipe, "unit": "solves/s", "ms_per_step": 1e3 * t_pipe / hs, "steps": hs,
+                                   "what": "mcq_solve_host_pipelined: a stream of %d batches, rows / normals / scalings in pinned host memory -> alpha, "
+                                           "curv_error, status in pinned host memory; uploads, kernels and downloads of consecutive batches overlap "
+                                           "(two copy streams, two staging slots)" % hs,
+                                   "ratio_to_device_resident": (B * hs / t_pipe) / value,
+                                   "blocking_single_batch": {"value": B / float(np.mean(hh)), "ms_per_step": 1e3 * float(np.mean(hh)),
+                                                             "what": "mcq_solve_host: H2D -> kernels -> D2H, blocking; %d calls" % len(hh)},
+                                   "bytes_h2d_per_step": int(p_ref.nbytes + p_nv.nbytes + p_sc.nbytes), "bytes_d2h_per_step": int(p_al[0].nbytes),
+                                   "alpha_equal_to_device_resident_run": bool(np.array_equal(p_al[0], alpha_gpu) and np.array_equal(p_al[1], alpha_gpu)),
+                                   "failed_problems": int(np.count_nonzero(st_h) + np.count_nonzero(st_p))}
             # ---- config 3 is mincurv_iqp: the whole iqp_handler chain of the same tracks as one engine call ------------------------
             trk = [dict(reftrack=ref_h[k], normvectors=nv_h[k], scaling=sc_h[k]) for k in range(B)]
             w0 = eng.iqp_batch(trk, KAPPA_BOUND, W_VEH, 3.0)  # first call: workspace + pinned staging of this size are allocated
@@ -531,8 +602,10 @@ def main():
                 out["cpu_baseline"] = dict(cb["cpu_a"], also={"cpu_b": cb["cpu_b"]})
         elif world == 1 and not args.no_cpu_baseline and not args.no_extras and not emulate:
             # f32 boundary: the baseline solves the rows the engine saw
-            r32 = ref_h.astype(np.float32).astype(np.float64)
-            cb = cpu_baseline(r32, nv_h, sc_h, alpha_gpu, curv_gpu, args.cpu_a_sample, args.cpu_b_sample)
+            r32 = engine.increments_to_rows(rows32, org) if d_org is not None else ref_h.astype(np.float32).astype(np.float64)
+            nv32 = np.stack([synthetic.prepared_track(r32[k, :, :2])[0] for k in range(min(B, args.cpu_b_sample))])
+            sc32 = np.stack([synthetic.prepared_track(r32[k, :, :2])[1] for k in range(min(B, args.cpu_b_sample))])
+            cb = cpu_baseline(r32[:nv32.shape[0]], nv32, sc32, alpha_gpu, curv_gpu, args.cpu_a_sample, args.cpu_b_sample)
             out["cpu_baseline"] = dict(cb["cpu_a"], also={"cpu_b": cb["cpu_b"]})
     if out is not None:
         print(json.dumps(out))

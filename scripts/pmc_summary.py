@@ -85,7 +85,12 @@ def main(base, tag, out_prefix, title):
     write_factor = 1.0 / w8 if w8 else 1.0
     calib.update(fetch_factor_used=fetch_factor, write_factor_used=write_factor,
                  fetch_factor_8B_per_lane=(1.0 / f8 if f8 else None), fetch_factor_16B_per_lane=(1.0 / f16 if f16 else None))
-    out = {"title": title, "source": "gpurun_out/%s_* (scripts/profile_round.sh)" % tag, "calibration": calib, "kernels": {}}
+    sha = None
+    sha_file = os.path.join(base, tag + "_source_sha.txt")
+    if os.path.exists(sha_file):
+        sha = open(sha_file).read().strip() or None
+    out = {"title": title, "source": "gpurun_out/%s_* (scripts/profile_round.sh)" % tag, "engine_source_sha256": sha,
+           "calibration": calib, "kernels": {}}
     lines = ["# " + title, "",
              "| kernel | calls | avg ms | % | read GB/launch | how | write GB/launch | traffic GB/launch | L2 hit % |", "|---|---|---|---|---|---|---|---|---|"]
     for k in sorted(stats, key=lambda k: -stats[k]["pct"]):

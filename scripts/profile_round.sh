@@ -15,6 +15,8 @@ mkdir -p $R/gpurun_out
 export TMPDIR=/tmp
 cd /tmp
 BENCH="python $R/bench.py --no-extras $*"
+# what was profiled: SHA-256 of the engine sources on THIS box (bench.py quotes a counter summary only for the sources it runs on)
+(cd $R && python -c "import bench; print(bench.source_sha())") > $R/gpurun_out/${TAG}_source_sha.txt
 timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/${TAG}_stats -- $BENCH --steps 3 --warmup 1 > $R/gpurun_out/${TAG}_stats.log 2>&1
 declare -A SETS
 SETS[wave]="SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_WAIT_INST_LDS SQ_INSTS_LDS"

@@ -8,6 +8,8 @@ import socket
 import subprocess
 import sys
 
+import numpy as np
+
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
@@ -56,3 +58,40 @@ def test_bench_under_the_drivers_launcher(emu_lib):
     res = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600, cwd=ROOT)
     assert res.returncode == 0, res.stderr[-2000:]
     _check_line(res.stdout, 2)
+
+
+def test_bench_config4_four_rank_shard(emu_lib):
+    """BASELINE config 4's 4-GPU shard (never run anywhere): `bench.py --config 4 --gpus 4` as four gloo ranks on the
+    emulated library -- block partition of the (track x vehicle width) QPs, racelines and velocity profiles per rank, ONE all-gather
+    of the lap times.  The matrix is shrunk to 2 tracks x 2 widths x 4 vehicles so that the interpreter finishes: one QP per rank."""
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "4", "--config", "4", "--steps", "1", "--warmup", "0",
+           "--c4-tracks", "rounded_rectangle,handling_track", "--c4-widths", "2", "--c4-vehicles", "4", "--emulate", emu_lib, "--no-extras"]
+    res = subprocess.run(cmd, env=_env(), capture_output=True, text=True, timeout=900, cwd=ROOT)
+    assert res.returncode == 0, res.stderr[-2000:]
+    lines = [l for l in res.stdout.splitlines() if l.strip()]
+    assert len(lines) == 1, res.stdout
+    rec = json.loads(lines[0])
+    assert rec["n_gpus"] == 4 and rec["config"]["ranks_seen"] == 4 and rec["scaling"] == "strong" and rec["unit"] == "variants/s"
+    assert rec["config"]["variants_total"] == 16 and rec["config"]["variants_this_rank"] == 4
+    assert "EMULATED" in rec["data"]
+    # every rank's lap times arrived, in partition order, and are the single-process ones
+    laps = np.array(rec["config"]["lap_times_gathered_s"])
+    assert laps.shape == (16,) and np.all(np.isfinite(laps)) and np.all(laps > 5.0)
+    cmd1 = [c for c in cmd]
+    cmd1[cmd1.index("--gpus") + 1] = "1"
+    res1 = subprocess.run(cmd1, env=_env(), capture_output=True, text=True, timeout=900, cwd=ROOT)
+    assert res1.returncode == 0, res1.stderr[-2000:]
+    rec1 = json.loads([l for l in res1.stdout.splitlines() if l.strip()][0])
+    assert np.array_equal(np.array(rec1["config"]["lap_times_gathered_s"]), laps)
+
+
+def test_bench_config5_f32_two_rank(emu_lib):
+    """BASELINE config 5's path on two gloo ranks: per-track centrelines, float increment rows + fp64 origins in "HBM", float alpha,
+    ONE all-gather of the float alpha (half the bytes of the fp64 collective)."""
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--config", "5", "--steps", "1", "--warmup", "0", "--batch", "1",
+           "--n", "120", "--emulate", emu_lib, "--no-extras"]
+    res = subprocess.run(cmd, env=_env(), capture_output=True, text=True, timeout=900, cwd=ROOT)
+    assert res.returncode == 0, res.stderr[-2000:]
+    rec = _check_line(res.stdout, 2)
+    assert rec["config"]["io"].startswith("f32 rows (ring increments + fp64 origin)")
+    assert rec["config"]["centrelines"] == "perturbed per track" and rec["config"]["allgather_dtype"] == "float32"

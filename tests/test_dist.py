@@ -52,6 +52,10 @@ def test_two_rank_gloo_matches_single_process(emu_lib):
     from global_racetrajectory_optimization_amd import engine
     eng = engine.Engine(0, lib_path=emu_lib)
     a_ref, c_ref, s_ref = parallel.solve_sharded(_problems(), eng)
+    # the device-resident shard path (padded tensors -> mcq_solve_device_ragged_params -> the gathered tensor) returns bitwise what the
+    # host-buffer entry returns
+    a_h, c_h, s_h, _ = eng.solve_batch(_problems())
+    assert list(s_h) == list(s_ref) and np.array_equal(c_h, c_ref) and all(np.array_equal(x, y) for x, y in zip(a_h, a_ref))
     with socket.socket() as sk:
         sk.bind(("127.0.0.1", 0))
         port = sk.getsockname()[1]
