@@ -1064,76 +1064,95 @@ __device__ __forceinline__ void tile_row_store(double* bt, double* ct, int R, in
     }
 }
 
-// Steady-state fetch / commit of a tile row: for tile rows that lie completely inside the interior (R >= NTR-1 and
-// 16 (R+1) <= ni) every index of an item is its per-thread constant plus a multiple of R, so the per-step address
-// arithmetic of the generic functions above (divisions, bounds, band limits: ~40 integer instructions per item, twice per
-// step) shrinks to a handful.  Constants are derived once per factorisation from the same item numbering.
-struct PfConst {
-    int goff;      // H offset relative to row block R:  + R * TB * MCQ_HLD
-    int loff;      // LDS offset inside the tile slot (band) / inside the border tile row (border)
-    int flags;     // bit 0 band item, bit 1 entry exists (inside the band / column < p), bit 2 diagonal entry
-    int m0, m1;    // mask byte indices: relative to R * TB (band: column, row; border: row), absolute (border: ni + column)
+// Steady-state fetch / commit of a tile row (tile rows that lie completely inside the interior, R >= NTR-1 and 16 (R+1) <= ni, of a
+// problem with the full band and border width): round 3 mapping.  The 16 x 144 entries of a tile row are 9 tiles (5 band, 4 border)
+// of 4 blocks of 64 entries each; a fetch wave takes 12 whole blocks, one entry per lane and block, and inside a block the lane ->
+// entry map is the same for every block of its kind:
+//     band   tile tcol (relative column), block k:  row rr = l15, column cc = l4 + 4k   -- 16 lanes read 16 contiguous doubles of an
+//            H row (the tile's column cc is contiguous in H), LDS word  tcol TSZ + l15 TLD + l4 + 4k
+//     border tile a, block k:                       row rr = l4 + 4k, column jj = 16a + l15 -- 16 lanes read 128 contiguous bytes,
+//            LDS word  (1 + a) TSZ + (l4 + 4k) TLD + l15
+// so every address of an item is a wave-uniform base + ONE per-lane constant per kind + a literal.  (Rounds 1-2 numbered the items
+// q = thread + 192 u through the generic index arithmetic: 12 x {global offset, LDS offset, flags} = 36 loop-invariant VGPRs per
+// lane that the allocator parked in AGPRs / scratch and copied back every step -- and whose reloads from scratch wait on vmcnt(0),
+// i.e. on the tile row in flight.)  Blocks are dealt to the three fetch waves by residue: band block 4 tcol + k to wave (4 tcol + k) % 3
+// (7 / 7 / 6), border block 4 a + k to wave (4 a + k + 2) % 3 (5 / 5 / 6): twelve per wave, and in the rows whose border half is all
+// zeros (not fetched) the band blocks alone are still spread 7 / 7 / 6.
+struct PfLane {
+    int gB, gC;     // global offsets relative to H + R * TB * MCQ_HLD: band / border item of this lane (block literal to be added)
+    int lB, lC;     // LDS words relative to the row slot
 };
-
-__device__ __forceinline__ PfConst pf_const(int q, int ni, int b, int p)
+__device__ __forceinline__ PfLane pf_lane(int l15, int l4)
 {
-    PfConst k;
-    if (q < TB * NTR * TB) {
-        const int ee = q / TB, rr = q - ee * TB;
-        const int tcol = ee / TB, cc = ee % TB;
-        const int kk = (NTR - 1 - tcol) * TB + rr - cc;
-        const bool valid = (kk >= 0) & (kk <= b);
-        k.goff = ((tcol - (NTR - 1)) * TB + cc) * MCQ_HLD + (valid ? kk : 0);
-        k.loff = tcol * TSZ + rr * TLD + cc;          // relative tile column tcol of the row slot
-        k.flags = 1 | (valid ? 2 : 0) | (kk == 0 ? 4 : 0);
-        k.m0 = (tcol - (NTR - 1)) * TB + cc;
-        k.m1 = rr;
-    } else {
-        const int q2 = q - TB * NTR * TB;
-        const int rr = q2 / MCQ_P_MAX, jj = q2 - rr * MCQ_P_MAX;
-        const bool ok = jj < p;
-        k.goff = rr * MCQ_HLD + MCQ_HBO + (ok ? jj : 0);
-        k.loff = (1 + jj / TB) * TSZ + rr * TLD + (jj % TB);      // behind the inverse-tile slot of the row
-        k.flags = ok ? 2 : 0;
-        k.m0 = rr;
-        k.m1 = ni + (ok ? jj : 0);
+    PfLane c;
+    c.gB = l4 * MCQ_HLD + l15 - l4;
+    c.gC = l4 * MCQ_HLD + l15;
+    c.lB = l15 * TLD + l4;
+    c.lC = l4 * TLD + l15;
+    return c;
+}
+#define PF_NBAND(WL) ((WL) < 2 ? 7 : 6)                              /* band blocks of fetch wave WL */
+#define PF_BBLK(WL, u) ((WL) + 3 * (u))                               /* u-th band block of wave WL: 4 tcol + k */
+#define PF_CBLK(WL, v) ((((WL) + 1) % 3) + 3 * (v))                   /* v-th border block of wave WL: 4 a + k */
+
+template <int WL, bool MK, bool SIG>
+__device__ __forceinline__ void tile_row_fetch_fast(const gdouble* H, const gdouble* sig, const gschar* mk, int R, int ni, const PfLane& c,
+                                                    int l15, int l4, bool border_zero, RawEntry (&e)[PF_ITEMS])
+{
+    const gdouble* Hr = H + (size_t)R * (TB * MCQ_HLD);
+#pragma unroll
+    for (int u = 0; u < PF_ITEMS; ++u) {
+        e[u].sg = 0.0;
+        e[u].m0 = e[u].m1 = 0;
+        if (u < PF_NBAND(WL)) {
+            const int tcol = PF_BBLK(WL, u) / 4, k = PF_BBLK(WL, u) % 4;
+            // entry (rr = l15, cc = l4 + 4k) of T(R, R - 4 + tcol) = H[c][i - c]; entries outside the band (tcol 4: above the
+            // diagonal, tcol 0: beyond 64) read an in-bounds neighbour and are dropped at the commit
+            e[u].h = Hr[c.gB + ((TB * (tcol - (NTR - 1)) + 4 * k) * MCQ_HLD + TB * (NTR - 1 - tcol) - 4 * k)];
+            if (MK) {
+                e[u].m0 = mk[R * TB + TB * (tcol - (NTR - 1)) + l4 + 4 * k];
+                e[u].m1 = mk[R * TB + l15];
+            }
+            if (SIG && tcol == NTR - 1) e[u].sg = sig[R * TB + l4 + 4 * k];
+        } else {
+            const int a = PF_CBLK(WL, u - PF_NBAND(WL)) / 4, k = PF_CBLK(WL, u - PF_NBAND(WL)) % 4;
+            if (border_zero) {
+                e[u].h = 0.0;
+            } else {
+                e[u].h = Hr[c.gC + (4 * k * MCQ_HLD + MCQ_HBO + TB * a)];
+                if (MK) {
+                    e[u].m0 = mk[R * TB + l4 + 4 * k];
+                    e[u].m1 = mk[ni + TB * a + l15];
+                }
+            }
+        }
     }
-    return k;
 }
 
-// BAND (band / border item) is a compile-time property of an item slot: with 192 fetch threads, slots 0..5 are band items,
-// slots 7..11 border items for every thread, slot 6 is a band item on waves 1 and 2 and a border item on wave 3 (a scalar
-// branch on the wave index).  Diagonal entries (the only ones that take the sig shift) occur in slots 5 and 6 only.
-template <bool MK, bool SIG>
-__device__ __forceinline__ RawEntry tile_row_fetch_fast(const gdouble* H, const gdouble* sig, const gschar* mk, int R, const PfConst& k,
-                                                        const bool BAND, const bool MAYDIAG)
+template <int WL, bool MK, bool SIG>
+__device__ __forceinline__ void tile_row_commit_fast(double* bt, double* ct, const RawEntry (&e)[PF_ITEMS], int R, const PfLane& c,
+                                                     int l15, int l4)
 {
-    RawEntry e;
-    e.sg = 0.0;
-    e.m0 = e.m1 = 0;
-    e.h = H[(size_t)R * (TB * MCQ_HLD) + k.goff];
-    if (MK) {
-        e.m0 = mk[R * TB + k.m0];
-        e.m1 = mk[BAND ? R * TB + k.m1 : k.m1];
-    }
-    if (SIG && BAND && MAYDIAG) e.sg = sig[R * TB + k.m0];      // column index: valid for every band item, used by the diagonal ones
-    return e;
-}
-
-template <bool MK, bool SIG>
-__device__ __forceinline__ void tile_row_commit_fast(double* bt, double* ct, const RawEntry& e, int R, const PfConst& k,
-                                                     const bool BAND, const bool MAYDIAG)
-{
-    const bool pinned = MK && ((e.m0 != 0) | (e.m1 != 0));
-    double v = (k.flags & 2) ? e.h : 0.0;
-    if (BAND) {
-        const bool dg = MAYDIAG && (k.flags & 4);
-        if (MK) v = pinned ? (dg ? 1.0 : 0.0) : v;
-        if (SIG && MAYDIAG) v += (dg && !pinned) ? e.sg : 0.0;
-        bt[(R % NTR) * (NTR * TSZ) + k.loff] = v;         // wave-uniform row-slot base + per-thread constant
-    } else {
-        if (MK) v = pinned ? 0.0 : v;
-        ct[(R % NTRC) * (NCT5 * TSZ) + k.loff] = v;
+    double* brow = bt + (R % NTR) * (NTR * TSZ) + c.lB;       // wave-uniform row slot + per-lane constant; block offsets are literals
+    double* crow = ct + (R % NTRC) * (NCT5 * TSZ) + c.lC;
+#pragma unroll
+    for (int u = 0; u < PF_ITEMS; ++u) {
+        const bool pinned = MK && ((e[u].m0 != 0) | (e[u].m1 != 0));
+        if (u < PF_NBAND(WL)) {
+            const int tcol = PF_BBLK(WL, u) / 4, k = PF_BBLK(WL, u) % 4;
+            const int cc = l4 + 4 * k;
+            const bool valid = tcol == NTR - 1 ? l15 >= cc : (tcol == 0 ? l15 <= cc : true);      // 0 <= 16 (4 - tcol) + rr - cc <= 64
+            const bool dg = tcol == NTR - 1 && l15 == cc;
+            double v = valid ? e[u].h : 0.0;
+            if (MK) v = pinned ? (dg ? 1.0 : 0.0) : v;
+            if (SIG && tcol == NTR - 1) v += (dg && !pinned) ? e[u].sg : 0.0;
+            brow[tcol * TSZ + 4 * k] = v;
+        } else {
+            const int a = PF_CBLK(WL, u - PF_NBAND(WL)) / 4, k = PF_CBLK(WL, u - PF_NBAND(WL)) % 4;
+            double v = e[u].h;
+            if (MK) v = pinned ? 0.0 : v;
+            crow[(1 + a) * TSZ + 4 * k * TLD] = v;
+        }
     }
 }
 
@@ -1328,11 +1347,9 @@ __device__ __forceinline__ int factor_t(const SolveCtx& c, const gdouble* Hsrc, 
     (void)wt; (void)wt_last;
 
     const int lt = tid - 64;         // fetch / commit thread of waves 1..3
-    PfConst pc[PF_ITEMS];
-#pragma unroll
-    for (int u = 0; u < PF_ITEMS; ++u) pc[u] = pf_const((lt >= 0 ? lt : 0) + u * PF_THREADS, ni, b, p);
-#define PF_FAST(R) ((R) >= NTR - 1 && ((R) + 1) * TB <= ni)
-    const bool wave3 = __builtin_amdgcn_readfirstlane(w0) == 3;      // scalar: slot 6 is a border item on wave 3 only
+    const PfLane pc = pf_lane(l15, l4);
+    const bool pf_dims = (b == MCQ_BH_MAX) & (p == MCQ_P_MAX);       // the literal band limits of the fast fetch / commit
+#define PF_FAST(R) (pf_dims && (R) >= NTR - 1 && ((R) + 1) * TB <= ni)
     __syncthreads();
     // prologue: tile rows 0 .. NTR-1
     if (lt >= 0) {
@@ -1369,6 +1386,10 @@ __device__ __forceinline__ int factor_t(const SolveCtx& c, const gdouble* Hsrc, 
     //   Schur tiles (lower, 10): (t + 1) % 3 == wl, register slot t / 3;    band tiles (6): t % 3 == wl
     // wl is a literal inside LAG_WORK (three-way dispatch) so that every register array is indexed statically.
     // All LDS operand / accumulator reads of a group are issued before its MFMAs, all writes after them.
+#ifndef MCQ_LAG_ORDER
+#define MCQ_LAG_ORDER 1     /* 1: round-3 order of a lag wave's step (one read phase, Schur products first); 0: round 2's */
+#endif
+#if MCQ_LAG_ORDER == 0
 #define LAG_WORK(P, WL, CM)                                                                                                  \
     {                                                                                                                  \
         /* The three groups of the step's lag work (border, band, Schur tiles) used to run read -> MFMA -> write one after \
@@ -1477,6 +1498,121 @@ __device__ __forceinline__ int factor_t(const SolveCtx& c, const gdouble* Hsrc, 
         }                                                                                                              \
         WT(3);                                                                                                         \
     }
+#else
+#define LAG_WORK(P, WL, CM)                                                                                                  \
+    {                                                                                                                  \
+        /* Round 3 order: the products that need nothing but the W row block run FIRST (see below).                            \
+             border tiles  C(P+dI, a) -= L(P+dI, P) W_P(a)            a = WL for dI = 1..4, plus (WL+1, 3) [and (4, 3) on WL 0]   \
+             band tiles    T(P+dI, P+dK) -= L(P+dI, P) L(P+dK, P)'    2 <= dK <= dI <= 4, tile t % 3 == WL                 \
+             Schur tiles   S(a, bb) -= W_P(a)' W_P(bb)                 lower, (t + 1) % 3 == WL, kept in registers           \
+           The W operands are read first (LDS returns in order), then every other operand and accumulator of the step; the  \
+           Schur products (13 / 14 fp64 MFMAs = 850 cycles, W operands only, results in registers) run while those reads land --  \
+           until round 2 the wave sat through that round trip (1860 cycles of a 6500-cycle phase with all three lag waves       \
+           reading at once) with the matrix pipe idle.  Border products next, the write-out of step P in their shadow; the     \
+           band accumulators are read behind the border tiles' write-back (up front as well they are 8 live VGPRs too many:      \
+           spills, and hipcc 7.2's AGPR-copy rewrite pass crashes on them), the commit of tile row P+NTR -- decode arithmetic     \
+           and LDS writes, independent of everything here -- covers that round trip. */                                        \
+        double la_[4][4], wv_[NCT][4];                                                                                 \
+        v4d cacc_[4], c3a_, c3b_, bacc_[2];                                                                            \
+        _Pragma("unroll") for (int a_ = 0; a_ < NCT; ++a_) {                                                           \
+            const double* wa2_ = CTILE((P), a_);                                                                       \
+            _Pragma("unroll") for (int kc = 0; kc < 4; ++kc) wv_[a_][kc] = wa2_[(l4 + 4 * kc) * TLD + l15];            \
+        }                                                                                                              \
+        _Pragma("unroll") for (int dI_ = 1; dI_ < NTR; ++dI_) {                                                        \
+            const double* li_ = LTILE(dI_, (P));                                                                       \
+            _Pragma("unroll") for (int kc = 0; kc < 4; ++kc) la_[dI_ - 1][kc] = -li_[l15 * TLD + l4 + 4 * kc];         \
+        }                                                                                                              \
+        _Pragma("unroll") for (int dI_ = 1; dI_ < NTR; ++dI_) {                                                        \
+            const double* ctl_ = CTILE((P) + dI_, (WL));                                                               \
+            _Pragma("unroll") for (int r = 0; r < 4; ++r) cacc_[dI_ - 1][r] = ctl_[(l4 + 4 * r) * TLD + l15];          \
+        }                                                                                                              \
+        {                                                                                                              \
+            const double* c3p_ = CTILE((P) + (WL) + 1, 3);                                                             \
+            const double* c3q_ = CTILE((P) + 4, 3);                                                                    \
+            _Pragma("unroll") for (int r = 0; r < 4; ++r) {                                                            \
+                c3a_[r] = c3p_[(l4 + 4 * r) * TLD + l15];                                                              \
+                c3b_[r] = c3q_[(l4 + 4 * r) * TLD + l15];                                                              \
+            }                                                                                                          \
+        }                                                                                                              \
+        WT(1);                                                                                                         \
+        /* ---- Schur products: W operands only ---- */                                                                 \
+        {                                                                                                              \
+            int t_ = 0;                                                                                                \
+            _Pragma("unroll") for (int a_ = 0; a_ < NCT; ++a_) {                                                       \
+                _Pragma("unroll") for (int bb_ = 0; bb_ <= a_; ++bb_, ++t_) {                                          \
+                    if ((t_ + 1) % 3 != (WL)) continue;                                                                \
+                    double av_[4];                                                                                     \
+                    _Pragma("unroll") for (int kc = 0; kc < 4; ++kc) av_[kc] = -wv_[a_][kc];                           \
+                    sacc[t_ / 3] = mfma16(av_, wv_[bb_], sacc[t_ / 3]);                                                \
+                }                                                                                                      \
+            }                                                                                                          \
+        }                                                                                                              \
+        WT(2);                                                                                                         \
+        /* ---- border products ---- */                                                                                 \
+        _Pragma("unroll") for (int dI_ = 1; dI_ < NTR; ++dI_) cacc_[dI_ - 1] = mfma16(la_[dI_ - 1], wv_[(WL)], cacc_[dI_ - 1]); \
+        c3a_ = mfma16(la_[(WL)], wv_[3], c3a_);                                                                        \
+        if ((WL) == 0) c3b_ = mfma16(la_[3], wv_[3], c3b_);                                                            \
+        /* ---- in the shadow of the band / border products (results not needed yet): this wave's share of the write-out of   \
+                step P -- LDS reads of final tiles, global stores -- and the commit of the tile row fetched a step and a half    \
+                ago; nothing the products touch ---- */                                                                    \
+        __builtin_amdgcn_sched_barrier(0);                                                                             \
+        if ((WL) == 0) { WRITE_OUT_W((P), 1) } else if ((WL) == 1) { WRITE_OUT_W((P), 0) } else { WRITE_OUT_L((P)) }   \
+        __builtin_amdgcn_sched_barrier(0);                                                                             \
+        /* ---- updated tiles back to the window ---- */                                                               \
+        _Pragma("unroll") for (int dI_ = 1; dI_ < NTR; ++dI_) {                                                        \
+            double* ctl_ = CTILE((P) + dI_, (WL));                                                                     \
+            _Pragma("unroll") for (int r = 0; r < 4; ++r) ctl_[(l4 + 4 * r) * TLD + l15] = cacc_[dI_ - 1][r];          \
+        }                                                                                                              \
+        {                                                                                                              \
+            double* c3p_ = CTILE((P) + (WL) + 1, 3);                                                                   \
+            double* c3q_ = CTILE((P) + 4, 3);                                                                          \
+            _Pragma("unroll") for (int r = 0; r < 4; ++r) {                                                            \
+                c3p_[(l4 + 4 * r) * TLD + l15] = c3a_[r];                                                              \
+                if ((WL) == 0) c3q_[(l4 + 4 * r) * TLD + l15] = c3b_[r];                                               \
+            }                                                                                                          \
+        }                                                                                                              \
+        {                                                                                                              \
+            int t_ = 0, s_ = 0;                                                                                        \
+            _Pragma("unroll") for (int dK_ = 2; dK_ < NTR; ++dK_) {                                                    \
+                _Pragma("unroll") for (int dI_ = dK_; dI_ < NTR; ++dI_, ++t_) {                                        \
+                    if (t_ % 3 != (WL) || t_ < MCQ_BAND_WAVE0) continue;                                              \
+                    const double* tt_ = BTILE((P) + dI_, (P) + dK_);                                                   \
+                    _Pragma("unroll") for (int r = 0; r < 4; ++r) bacc_[s_][r] = tt_[(l4 + 4 * r) * TLD + l15];        \
+                    ++s_;                                                                                              \
+                }                                                                                                      \
+            }                                                                                                          \
+        }                                                                                                              \
+        /* ---- the commit of the tile row fetched a step and a half ago, while the band accumulators arrive ---- */          \
+        __builtin_amdgcn_sched_barrier(0);                                                                             \
+        if (CM) { COMMIT_ROW((P) + NTR) }                                                                              \
+        __builtin_amdgcn_sched_barrier(0);                                                                             \
+        /* ---- band products ---- */                                                                                   \
+        {                                                                                                              \
+            int t_ = 0, s_ = 0;                                                                                        \
+            _Pragma("unroll") for (int dK_ = 2; dK_ < NTR; ++dK_) {                                                    \
+                _Pragma("unroll") for (int dI_ = dK_; dI_ < NTR; ++dI_, ++t_) {                                        \
+                    if (t_ % 3 != (WL) || t_ < MCQ_BAND_WAVE0) continue;                                              \
+                    double bv_[4];                                                                                     \
+                    _Pragma("unroll") for (int kc = 0; kc < 4; ++kc) bv_[kc] = -la_[dK_ - 1][kc];                      \
+                    bacc_[s_] = mfma16(la_[dI_ - 1], bv_, bacc_[s_]);                                                  \
+                    ++s_;                                                                                              \
+                }                                                                                                      \
+            }                                                                                                          \
+        }                                                                                                              \
+        {                                                                                                              \
+            int t_ = 0, s_ = 0;                                                                                        \
+            _Pragma("unroll") for (int dK_ = 2; dK_ < NTR; ++dK_) {                                                    \
+                _Pragma("unroll") for (int dI_ = dK_; dI_ < NTR; ++dI_, ++t_) {                                        \
+                    if (t_ % 3 != (WL) || t_ < MCQ_BAND_WAVE0) continue;                                              \
+                    double* tt_ = BTILE((P) + dI_, (P) + dK_);                                                         \
+                    _Pragma("unroll") for (int r = 0; r < 4; ++r) tt_[(l4 + 4 * r) * TLD + l15] = bacc_[s_][r];        \
+                    ++s_;                                                                                              \
+                }                                                                                                      \
+            }                                                                                                          \
+        }                                                                                                              \
+        WT(3);                                                                                                         \
+    }
+#endif
 
     // The first MCQ_BAND_WAVE0 of the six band tiles of step P on wave 0: T(P+dI, P+dK) -= L(P+dI, P) L(P+dK, P)', 2 <= dK <= dI <= 4 -- wave 0 is done
     // with its chain 2300 cycles before the lag waves are with their products, and fp64 MFMA time (64 cycles a piece, at the vector
@@ -1534,12 +1670,9 @@ __device__ __forceinline__ int factor_t(const SolveCtx& c, const gdouble* Hsrc, 
 #define COMMIT_ROW(R)                                                                                                  \
     {                                                                                                                  \
         if (PF_FAST((R))) {                                                                                            \
-            _Pragma("unroll") for (int u = 0; u < PF_ITEMS; ++u) {                                                     \
-                if (u < 6) tile_row_commit_fast<MK, SIG>(bt, ct, pf[u], (R), pc[u], true, u == 5);                      \
-                else if (u > 6) tile_row_commit_fast<MK, SIG>(bt, ct, pf[u], (R), pc[u], false, false);                 \
-                else if (wave3) tile_row_commit_fast<MK, SIG>(bt, ct, pf[u], (R), pc[u], false, false);                 \
-                else tile_row_commit_fast<MK, SIG>(bt, ct, pf[u], (R), pc[u], true, true);                              \
-            }                                                                                                          \
+            if (wl == 0) tile_row_commit_fast<0, MK, SIG>(bt, ct, pf, (R), pc, l15, l4);                               \
+            else if (wl == 1) tile_row_commit_fast<1, MK, SIG>(bt, ct, pf, (R), pc, l15, l4);                          \
+            else tile_row_commit_fast<2, MK, SIG>(bt, ct, pf, (R), pc, l15, l4);                                       \
         } else {                                                                                                       \
             _Pragma("unroll") for (int u = 0; u < PF_ITEMS; ++u) {                                                     \
                 const int q = lt + u * PF_THREADS;                                                                     \
@@ -1555,8 +1688,8 @@ __device__ __forceinline__ int factor_t(const SolveCtx& c, const gdouble* Hsrc, 
     //   L tiles : lane (rg = lane >> 4, cc = lane & 15) takes, of tile tI = 1..4, the rows rg + 4 j (j = 0..3) of column cc:
     //             element (tI, rr, cc) = L[i, i - k], k = 16 tI + rr - cc, goes to L-row i slot k - 1, i.e. to
     //             P 16 LLD + (16 tI + 4 j)(LLD + 1) + [rg (LLD + 1) - cc - 1]  -- 16 lanes write 128 contiguous bytes;
-    //   W rows  : lane (rr = lane >> 2, part = lane & 3) takes 10 consecutive entries of row rr of [inverse | W] (80 doubles:
-    //             the row slot of the border window holds them as 5 adjacent tiles) = 80 contiguous bytes, five 16-byte stores.
+    //   W rows  : lane (rr = lane >> 2, q) takes one 16-byte pair of each of the five tiles of row rr of [inverse | W] (80 doubles: the
+    //             row slot of the border window holds them as 5 adjacent tiles): five 16-byte stores, 128 bytes apart.
 #define WO_L 16
 #define WRITE_OUT_L(P)                                                                                                 \
     {                                                                                                                  \
@@ -1589,20 +1722,22 @@ __device__ __forceinline__ int factor_t(const SolveCtx& c, const gdouble* Hsrc, 
             }                                                                                                          \
         }                                                                                                              \
     }
-#define WO_W 10
 #define WRITE_OUT_W(P, HALF)                                                                                           \
     {                                                                                                                  \
-        const int rr_ = lane >> 2, e0_ = 40 * (HALF) + 10 * (lane & 3);                                                \
-        const double* row_ = CROW((P)) + rr_ * TLD;                                                                    \
-        double fv_[WO_W];                                                                                              \
-        _Pragma("unroll") for (int m_ = 0; m_ < WO_W; ++m_) {                                                          \
-            const int e = e0_ + m_;                                                                                    \
-            fv_[m_] = row_[(e >> 4) * TSZ + (e & 15)];                                                                 \
+        /* lane (rr = lane >> 2, q = 4 HALF + (lane & 3)) takes the entry pair (2q, 2q + 1) of each of the five tiles of row rr of   \
+           [inverse | W]: one per-lane LDS base and one per-lane global base, the tile index is a literal in both (16 entries = 128    \
+           bytes apart in the L row); four lanes write 64 contiguous bytes */                                              \
+        const int rr_ = lane >> 2, q2_ = 2 * (4 * (HALF) + (lane & 3));                                                \
+        const double* row_ = CROW((P)) + rr_ * TLD + q2_;                                                              \
+        double fv_[2 * NCT5];                                                                                          \
+        _Pragma("unroll") for (int t_ = 0; t_ < NCT5; ++t_) {                                                          \
+            fv_[2 * t_] = row_[t_ * TSZ];                                                                              \
+            fv_[2 * t_ + 1] = row_[t_ * TSZ + 1];                                                                      \
         }                                                                                                              \
         const int i = (P) * TB + rr_;                                                                                  \
         if (i < ni) {                                                                                                  \
-            gd2* dst_ = (gd2*)(L + (size_t)i * MCQ_LLD + MCQ_LBI + e0_);                                               \
-            _Pragma("unroll") for (int m_ = 0; m_ < WO_W / 2; ++m_) dst_[m_] = (d2){fv_[2 * m_], fv_[2 * m_ + 1]};     \
+            gd2* dst_ = (gd2*)(L + (size_t)i * MCQ_LLD + MCQ_LBI + q2_);                                               \
+            _Pragma("unroll") for (int t_ = 0; t_ < NCT5; ++t_) dst_[t_ * (TB / 2)] = (d2){fv_[2 * t_], fv_[2 * t_ + 1]}; \
         }                                                                                                              \
     }
 
@@ -1634,26 +1769,14 @@ __device__ __forceinline__ int factor_t(const SolveCtx& c, const gdouble* Hsrc, 
             if (MCQ_WORKER_TIMERS) wt_last = (long long)clock64();
             {
                 const int R = J + NTR;
-                if (PF_FAST(R) && R * TB >= MCQ_BH_MAX && (R + 1) * TB <= ni - MCQ_BH_MAX) {
+                if (PF_FAST(R)) {
                     // Rows further than the band width from both ends of the interior have no border entries at all (the border
                     // couples to the first and the last 64 rows only): half of every H row is zeros that need not be streamed --
                     // 1 MB of the 2.1 MB a factorisation of an N = 2000 problem used to read.
-                    const RawEntry zero_entry = {0.0, 0.0, 0, 0};
-#pragma unroll
-                    for (int u = 0; u < PF_ITEMS; ++u) {
-                        if (u < 6) pfn[u] = tile_row_fetch_fast<MK, SIG>(H, sig, mk, R, pc[u], true, u == 5);
-                        else if (u > 6) pfn[u] = zero_entry;
-                        else if (wave3) pfn[u] = zero_entry;
-                        else pfn[u] = tile_row_fetch_fast<MK, SIG>(H, sig, mk, R, pc[u], true, true);
-                    }
-                } else if (PF_FAST(R)) {
-#pragma unroll
-                    for (int u = 0; u < PF_ITEMS; ++u) {
-                        if (u < 6) pfn[u] = tile_row_fetch_fast<MK, SIG>(H, sig, mk, R, pc[u], true, u == 5);
-                        else if (u > 6) pfn[u] = tile_row_fetch_fast<MK, SIG>(H, sig, mk, R, pc[u], false, false);
-                        else if (wave3) pfn[u] = tile_row_fetch_fast<MK, SIG>(H, sig, mk, R, pc[u], false, false);
-                        else pfn[u] = tile_row_fetch_fast<MK, SIG>(H, sig, mk, R, pc[u], true, true);
-                    }
+                    const bool bz = R * TB >= MCQ_BH_MAX && (R + 1) * TB <= ni - MCQ_BH_MAX;
+                    if (wl == 0) tile_row_fetch_fast<0, MK, SIG>(H, sig, mk, R, ni, pc, l15, l4, bz, pfn);
+                    else if (wl == 1) tile_row_fetch_fast<1, MK, SIG>(H, sig, mk, R, ni, pc, l15, l4, bz, pfn);
+                    else tile_row_fetch_fast<2, MK, SIG>(H, sig, mk, R, ni, pc, l15, l4, bz, pfn);
                 } else {
 #pragma unroll
                     for (int u = 0; u < PF_ITEMS; ++u) pfn[u] = tile_row_fetch<MK, SIG>(H, sig, mk, ni, b, p, R, lt + u * PF_THREADS);

@@ -1,12 +1,12 @@
 #!/bin/bash
-# Runs on the GPU box: every build variant under csrc/variants/*.so (compiled in the build container with different -D switches;
-# git-ignored, they travel with the snapshot) through a parity check and the bench line.   scripts/gpu_variants.sh <tag> [pytest -k expr]
+# Runs on the GPU box: every build variant under build/variants/*.so (compiled in the build container by scripts/build_variants.sh
+# with different -D switches; git-ignored, they travel with the snapshot) through a parity check and the bench line.   scripts/gpu_variants.sh <tag> [pytest -k expr]
 R=${GRAFT_REPO_ROOT:-$(pwd)}
 T=${1:-var}
 K=${2:-"reference_tracks_match_golden or n2000_first_pass or full_size_oval_properties"}
 cd $R
 mkdir -p gpurun_out
-for so in global_racetrajectory_optimization_amd/csrc/variants/*.so; do
+for so in build/variants/*.so; do
   name=$(basename $so .so | sed 's/^libmcq_//')
   export MCQ_LIB=$R/$so
   timeout 300 python -m pytest tests/test_gpu_parity.py -m gpu -q -x -k "$K" > gpurun_out/${T}_${name}_pytest.log 2>&1
