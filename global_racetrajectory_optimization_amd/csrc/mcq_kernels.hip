@@ -922,6 +922,29 @@ __global__ void __launch_bounds__(MCQ_NT) mcq_assemble_sp_kernel(McqBatch B)
 #ifndef MCQ_BAND_WAVE0
 #define MCQ_BAND_WAVE0 3    /* how many of the six band tiles of a step's lag work wave 0 takes (0, 3 or 6: one / two per lag wave) */
 #endif
+// -DMCQ_ABL=mask (scripts/factor_bench.hip ONLY: the results are garbage, the time is what is looked at): parts of a factorisation
+// step removed -- 1 Schur products, 2 border products, 4 write-out, 8 commit, 16 fetch, 32 diagonal tile, 128 wave 0's band tiles,
+// 256 phase 2, 512 the whole lag work, 1024 the not-positive-definite exit, 2048 the band products of the lag waves, 4096 the fetch
+// reads the same two tile rows all the time (cache hits), 8192 the write-out's global stores (its LDS reads stay).
+#ifndef MCQ_ABL
+#define MCQ_ABL 0
+#endif
+#ifndef MCQ_SCALAR_WAVE
+#define MCQ_SCALAR_WAVE 0
+#endif
+#ifndef MCQ_CRING
+#define MCQ_CRING 1         /* 1: the border accumulators of a lag wave's own column stay in registers across the steps (needs MCQ_FETCH_SINGLE) */
+#endif
+#ifndef MCQ_IO_SPLIT
+#define MCQ_IO_SPLIT 0      /* 1: lag waves 1 and 2 fetch / commit (loads only), lag wave 3 writes out (stores only); 0: every lag wave both */
+#endif
+#ifndef MCQ_PD_CHECK_PER_STEP
+#define MCQ_PD_CHECK_PER_STEP 0
+#endif
+#ifndef MCQ_FETCH_SINGLE
+#define MCQ_FETCH_SINGLE 1   /* 1: one tile row in flight per fetch wave, committed at the top of the next step (round 3); 0: round 2's two sets */
+#endif
+#define ABL(bit) ((MCQ_ABL & (bit)) != 0)
 #ifndef MCQ_FUSE_FWD
 #define MCQ_FUSE_FWD 1     /* forward substitution of the predictor / active-set solve fused into the factorisation (factor_t) */
 #endif
@@ -984,8 +1007,18 @@ struct SolveCtx {
 // still reads as T(P+1, P) while wave 0 produces it -- that one goes to the dead upper-triangle slot (P+1, P+2)
 #define LTILE(dI, P) ((dI) == 1 ? BTILE((P) + 1, (P) + 2) : BTILE((P) + (dI), (P)))
 #define ROW_ITEMS (TB * (NTR * TB + MCQ_P_MAX))            /* 16 x 144 doubles per tile row */
-#define PF_THREADS (MCQ_NT - 64)                           /* waves 1..3 fetch and commit; wave 0 only runs the critical path */
-#define PF_ITEMS (ROW_ITEMS / PF_THREADS)                 /* 2304 / 192 = 12 */
+// Who moves what (round 3, MCQ_IO_SPLIT): s_waitcnt vmcnt counts the loads AND the stores of a wave, and the two complete out of order
+// with respect to each other -- a wave that has stores in flight can only wait for "everything" (vmcnt(0)) when it needs a loaded
+// value, i.e. for its stores' round trip to HBM as well.  With the write-out stores on the waves that fetch, that wait cost 2000-3900
+// of a lag wave's ~8000 cycles per step (scripts/factor_bench.hip, -DMCQ_ABL=8 / 8192).  So the roles are split by wave: waves 1 and 2
+// fetch and commit the tile rows (loads only), wave 3 writes L / W out (stores only), wave 0 keeps the critical path.
+#if MCQ_IO_SPLIT
+#define PF_WAVES 2
+#else
+#define PF_WAVES 3
+#endif
+#define PF_THREADS (64 * PF_WAVES)                         /* fetch / commit threads (waves 1 .. PF_WAVES) */
+#define PF_ITEMS (ROW_ITEMS / PF_THREADS)                 /* 2304 / 128 = 18  (2304 / 192 = 12) */
 
 // Raw (un-decoded) loads of one window entry: kept in registers while the loads are in flight, decoded when the entry is
 // committed to LDS -- nothing between fetch and commit depends on the loaded values, so no s_waitcnt is placed early.
@@ -1091,15 +1124,23 @@ __device__ __forceinline__ PfLane pf_lane(int l15, int l4)
     c.lC = l4 * TLD + l15;
     return c;
 }
+#if MCQ_IO_SPLIT
+#define PF_NBAND(WL) 10                                               /* band blocks of fetch wave WL (two fetch waves: even / odd) */
+#define PF_BBLK(WL, u) ((WL) + 2 * (u))                               /* u-th band block of wave WL: 4 tcol + k */
+#define PF_CBLK(WL, v) ((WL) + 2 * (v))                               /* v-th border block of wave WL: 4 a + k */
+#else
 #define PF_NBAND(WL) ((WL) < 2 ? 7 : 6)                              /* band blocks of fetch wave WL */
 #define PF_BBLK(WL, u) ((WL) + 3 * (u))                               /* u-th band block of wave WL: 4 tcol + k */
 #define PF_CBLK(WL, v) ((((WL) + 1) % 3) + 3 * (v))                   /* v-th border block of wave WL: 4 a + k */
+#endif
 
-template <int WL, bool MK, bool SIG>
+// (BZ -- the border half of the row is all zeros and is not fetched -- is a template parameter: a run-time flag merges loaded values
+//  with constants through control flow, and the compiler then waits for the loads at the merge, i.e. right behind their issue)
+template <int WL, bool MK, bool SIG, bool BZ>
 __device__ __forceinline__ void tile_row_fetch_fast(const gdouble* H, const gdouble* sig, const gschar* mk, int R, int ni, const PfLane& c,
-                                                    int l15, int l4, bool border_zero, RawEntry (&e)[PF_ITEMS])
+                                                    int l15, int l4, RawEntry (&e)[PF_ITEMS])
 {
-    const gdouble* Hr = H + (size_t)R * (TB * MCQ_HLD);
+    const gdouble* Hr = H + (size_t)(ABL(4096) ? NTR + (R & 1) : R) * (TB * MCQ_HLD);     // (ablation 4096: the same two tile rows over and over -- cache hits)
 #pragma unroll
     for (int u = 0; u < PF_ITEMS; ++u) {
         e[u].sg = 0.0;
@@ -1116,7 +1157,7 @@ __device__ __forceinline__ void tile_row_fetch_fast(const gdouble* H, const gdou
             if (SIG && tcol == NTR - 1) e[u].sg = sig[R * TB + l4 + 4 * k];
         } else {
             const int a = PF_CBLK(WL, u - PF_NBAND(WL)) / 4, k = PF_CBLK(WL, u - PF_NBAND(WL)) % 4;
-            if (border_zero) {
+            if (BZ) {
                 e[u].h = 0.0;
             } else {
                 e[u].h = Hr[c.gC + (4 * k * MCQ_HLD + MCQ_HBO + TB * a)];
@@ -1330,13 +1371,18 @@ __device__ __forceinline__ int factor_t(const SolveCtx& c, const gdouble* Hsrc, 
     double* dinv = g_sm + SM_DINV;
     const gdouble* H = Hsrc;
     gdouble* L = c.w.L;
-    const int lane = tid & 63, w0 = tid >> 6;
+    // the wave index as a SCALAR: every role dispatch below (wave 0 / lag waves, the three lag waves' literal tile ownership, the fetch
+    // waves' block lists) is then a scalar branch between mutually exclusive paths.  Left as the vector value tid >> 6 the compiler
+    // lays the alternatives out one behind the other under exec masks and must assume that all of them run: registers a load of one
+    // alternative is still filling cannot be written by the next without an s_waitcnt vmcnt(0) in front.
+    const int lane = tid & 63, w0 = MCQ_SCALAR_WAVE ? __builtin_amdgcn_readfirstlane(tid >> 6) : (tid >> 6);
     const int l15 = lane & 15, l4 = lane >> 4;
     const int nblk = (ni + TB - 1) / TB;
 
     v4d sacc[NCT];
+    v4d cring[NTR - 1];     // MCQ_CRING: a lag wave's border column, the four tile rows in flight (see LAG_WORK)
 #pragma unroll
-    for (int m = 0; m < NCT; ++m) sacc[m] = (v4d){0.0, 0.0, 0.0, 0.0};
+    for (int m = 0; m < NCT; ++m) { sacc[m] = (v4d){0.0, 0.0, 0.0, 0.0}; cring[m] = (v4d){0.0, 0.0, 0.0, 0.0}; }
     RawEntry pf[PF_ITEMS];
     double* yring = g_sm + SM_YR;
     double* pend = g_sm + SM_PEND;
@@ -1352,7 +1398,7 @@ __device__ __forceinline__ int factor_t(const SolveCtx& c, const gdouble* Hsrc, 
 #define PF_FAST(R) (pf_dims && (R) >= NTR - 1 && ((R) + 1) * TB <= ni)
     __syncthreads();
     // prologue: tile rows 0 .. NTR-1
-    if (lt >= 0) {
+    if (lt >= 0 && lt < PF_THREADS) {
         for (int R = 0; R < NTR; ++R) {
             // all loads of a tile row are issued before the first decode (one HBM round trip per tile row, not per item)
 #pragma unroll
@@ -1388,6 +1434,9 @@ __device__ __forceinline__ int factor_t(const SolveCtx& c, const gdouble* Hsrc, 
     // All LDS operand / accumulator reads of a group are issued before its MFMAs, all writes after them.
 #ifndef MCQ_LAG_ORDER
 #define MCQ_LAG_ORDER 1     /* 1: round-3 order of a lag wave's step (one read phase, Schur products first); 0: round 2's */
+#endif
+#if MCQ_IO_SPLIT && (!MCQ_FETCH_SINGLE || MCQ_LAG_ORDER != 1)
+#error "MCQ_IO_SPLIT needs MCQ_FETCH_SINGLE = 1 and MCQ_LAG_ORDER = 1"
 #endif
 #if MCQ_LAG_ORDER == 0
 #define LAG_WORK(P, WL, CM)                                                                                                  \
@@ -1522,9 +1571,22 @@ __device__ __forceinline__ int factor_t(const SolveCtx& c, const gdouble* Hsrc, 
             const double* li_ = LTILE(dI_, (P));                                                                       \
             _Pragma("unroll") for (int kc = 0; kc < 4; ++kc) la_[dI_ - 1][kc] = -li_[l15 * TLD + l4 + 4 * kc];         \
         }                                                                                                              \
+        if (MCQ_CRING) {                                                                                               \
+            /* border column WL: the four tile rows in flight live in registers across the steps (cring); only the row that      \
+               enters (P+4, untouched so far) is read, only the row that is finished (P+1) is written */                        \
+            if ((P) == 0) {                                                                                            \
+                _Pragma("unroll") for (int dI_ = 1; dI_ < NTR - 1; ++dI_) {                                            \
+                    const double* ctl_ = CTILE((P) + dI_, (WL));                                                       \
+                    _Pragma("unroll") for (int r = 0; r < 4; ++r) cring[dI_ - 1][r] = ctl_[(l4 + 4 * r) * TLD + l15];  \
+                }                                                                                                      \
+            }                                                                                                          \
+            const double* ctl_ = CTILE((P) + NTR - 1, (WL));                                                           \
+            _Pragma("unroll") for (int r = 0; r < 4; ++r) cring[NTR - 2][r] = ctl_[(l4 + 4 * r) * TLD + l15];          \
+        } else {                                                                                                       \
         _Pragma("unroll") for (int dI_ = 1; dI_ < NTR; ++dI_) {                                                        \
             const double* ctl_ = CTILE((P) + dI_, (WL));                                                               \
             _Pragma("unroll") for (int r = 0; r < 4; ++r) cacc_[dI_ - 1][r] = ctl_[(l4 + 4 * r) * TLD + l15];          \
+        }                                                                                                              \
         }                                                                                                              \
         {                                                                                                              \
             const double* c3p_ = CTILE((P) + (WL) + 1, 3);                                                             \
@@ -1540,7 +1602,7 @@ __device__ __forceinline__ int factor_t(const SolveCtx& c, const gdouble* Hsrc, 
             int t_ = 0;                                                                                                \
             _Pragma("unroll") for (int a_ = 0; a_ < NCT; ++a_) {                                                       \
                 _Pragma("unroll") for (int bb_ = 0; bb_ <= a_; ++bb_, ++t_) {                                          \
-                    if ((t_ + 1) % 3 != (WL)) continue;                                                                \
+                    if ((t_ + 1) % 3 != (WL) || ABL(1)) continue;                                                      \
                     double av_[4];                                                                                     \
                     _Pragma("unroll") for (int kc = 0; kc < 4; ++kc) av_[kc] = -wv_[a_][kc];                           \
                     sacc[t_ / 3] = mfma16(av_, wv_[bb_], sacc[t_ / 3]);                                                \
@@ -1549,19 +1611,32 @@ __device__ __forceinline__ int factor_t(const SolveCtx& c, const gdouble* Hsrc, 
         }                                                                                                              \
         WT(2);                                                                                                         \
         /* ---- border products ---- */                                                                                 \
-        _Pragma("unroll") for (int dI_ = 1; dI_ < NTR; ++dI_) cacc_[dI_ - 1] = mfma16(la_[dI_ - 1], wv_[(WL)], cacc_[dI_ - 1]); \
+        if (!ABL(2)) {                                                                                                 \
+        if (MCQ_CRING) { _Pragma("unroll") for (int dI_ = 1; dI_ < NTR; ++dI_) cring[dI_ - 1] = mfma16(la_[dI_ - 1], wv_[(WL)], cring[dI_ - 1]); } \
+        else { _Pragma("unroll") for (int dI_ = 1; dI_ < NTR; ++dI_) cacc_[dI_ - 1] = mfma16(la_[dI_ - 1], wv_[(WL)], cacc_[dI_ - 1]); } \
         c3a_ = mfma16(la_[(WL)], wv_[3], c3a_);                                                                        \
         if ((WL) == 0) c3b_ = mfma16(la_[3], wv_[3], c3b_);                                                            \
+        }                                                                                                              \
         /* ---- in the shadow of the band / border products (results not needed yet): this wave's share of the write-out of   \
                 step P -- LDS reads of final tiles, global stores -- and the commit of the tile row fetched a step and a half    \
                 ago; nothing the products touch ---- */                                                                    \
         __builtin_amdgcn_sched_barrier(0);                                                                             \
-        if ((WL) == 0) { WRITE_OUT_W((P), 1) } else if ((WL) == 1) { WRITE_OUT_W((P), 0) } else { WRITE_OUT_L((P)) }   \
+        if (!ABL(4)) {                                                                                                 \
+            if (MCQ_IO_SPLIT) { if ((WL) == 2) { WRITE_OUT_W((P), 0) WRITE_OUT_W((P), 1) WRITE_OUT_L((P)) } }          \
+            else if ((WL) == 0) { WRITE_OUT_W((P), 1) } else if ((WL) == 1) { WRITE_OUT_W((P), 0) } else { WRITE_OUT_L((P)) } \
+        }                                                                                                              \
         __builtin_amdgcn_sched_barrier(0);                                                                             \
+        WT(4);                                                                                                         \
         /* ---- updated tiles back to the window ---- */                                                               \
+        if (MCQ_CRING) {                                                                                               \
+            double* ctl_ = CTILE((P) + 1, (WL));                                                                       \
+            _Pragma("unroll") for (int r = 0; r < 4; ++r) ctl_[(l4 + 4 * r) * TLD + l15] = cring[0][r];                \
+            _Pragma("unroll") for (int dI_ = 1; dI_ < NTR - 1; ++dI_) cring[dI_ - 1] = cring[dI_];                     \
+        } else {                                                                                                       \
         _Pragma("unroll") for (int dI_ = 1; dI_ < NTR; ++dI_) {                                                        \
             double* ctl_ = CTILE((P) + dI_, (WL));                                                                     \
             _Pragma("unroll") for (int r = 0; r < 4; ++r) ctl_[(l4 + 4 * r) * TLD + l15] = cacc_[dI_ - 1][r];          \
+        }                                                                                                              \
         }                                                                                                              \
         {                                                                                                              \
             double* c3p_ = CTILE((P) + (WL) + 1, 3);                                                                   \
@@ -1584,7 +1659,7 @@ __device__ __forceinline__ int factor_t(const SolveCtx& c, const gdouble* Hsrc, 
         }                                                                                                              \
         /* ---- the commit of the tile row fetched a step and a half ago, while the band accumulators arrive ---- */          \
         __builtin_amdgcn_sched_barrier(0);                                                                             \
-        if (CM) { COMMIT_ROW((P) + NTR) }                                                                              \
+        if (CM && !ABL(8)) { COMMIT_ROW((P) + NTR) }                                                                   \
         __builtin_amdgcn_sched_barrier(0);                                                                             \
         /* ---- band products ---- */                                                                                   \
         {                                                                                                              \
@@ -1594,7 +1669,7 @@ __device__ __forceinline__ int factor_t(const SolveCtx& c, const gdouble* Hsrc, 
                     if (t_ % 3 != (WL) || t_ < MCQ_BAND_WAVE0) continue;                                              \
                     double bv_[4];                                                                                     \
                     _Pragma("unroll") for (int kc = 0; kc < 4; ++kc) bv_[kc] = -la_[dK_ - 1][kc];                      \
-                    bacc_[s_] = mfma16(la_[dI_ - 1], bv_, bacc_[s_]);                                                  \
+                    if (!ABL(2048)) bacc_[s_] = mfma16(la_[dI_ - 1], bv_, bacc_[s_]);                                  \
                     ++s_;                                                                                              \
                 }                                                                                                      \
             }                                                                                                          \
@@ -1671,8 +1746,8 @@ __device__ __forceinline__ int factor_t(const SolveCtx& c, const gdouble* Hsrc, 
     {                                                                                                                  \
         if (PF_FAST((R))) {                                                                                            \
             if (wl == 0) tile_row_commit_fast<0, MK, SIG>(bt, ct, pf, (R), pc, l15, l4);                               \
-            else if (wl == 1) tile_row_commit_fast<1, MK, SIG>(bt, ct, pf, (R), pc, l15, l4);                          \
-            else tile_row_commit_fast<2, MK, SIG>(bt, ct, pf, (R), pc, l15, l4);                                       \
+            else if (wl == 1 || PF_WAVES == 2) tile_row_commit_fast<1, MK, SIG>(bt, ct, pf, (R), pc, l15, l4);         \
+            else tile_row_commit_fast<PF_WAVES == 2 ? 1 : 2, MK, SIG>(bt, ct, pf, (R), pc, l15, l4);                   \
         } else {                                                                                                       \
             _Pragma("unroll") for (int u = 0; u < PF_ITEMS; ++u) {                                                     \
                 const int q = lt + u * PF_THREADS;                                                                     \
@@ -1705,7 +1780,11 @@ __device__ __forceinline__ int factor_t(const SolveCtx& c, const gdouble* Hsrc, 
                 const int mm_ = m_ + h_ * (WO_L / 2);                                                                  \
                 ev_[m_] = LTILE(1 + mm_ / 4, (P))[lo_ + (mm_ % 4) * 4 * TLD];                                          \
             }                                                                                                          \
-            if (full_) {                                                                                               \
+            if (ABL(8192)) {                                                                                           \
+                double sink_ = 0.0;                                                                                    \
+                _Pragma("unroll") for (int m_ = 0; m_ < WO_L / 2; ++m_) sink_ += ev_[m_];                              \
+                if (sink_ == 1.2345e-300) dinv[TB + 1] = sink_;                                                        \
+            } else if (full_) {                                                                                        \
                 _Pragma("unroll") for (int m_ = 0; m_ < WO_L / 2; ++m_) {                                              \
                     const int mm_ = m_ + h_ * (WO_L / 2);                                                              \
                     const int tI = 1 + mm_ / 4, rr = rg_ + 4 * (mm_ % 4);                                              \
@@ -1735,7 +1814,7 @@ __device__ __forceinline__ int factor_t(const SolveCtx& c, const gdouble* Hsrc, 
             fv_[2 * t_ + 1] = row_[t_ * TSZ + 1];                                                                      \
         }                                                                                                              \
         const int i = (P) * TB + rr_;                                                                                  \
-        if (i < ni) {                                                                                                  \
+        if (i < ni && !ABL(8192)) {                                                                                    \
             gd2* dst_ = (gd2*)(L + (size_t)i * MCQ_LLD + MCQ_LBI + q2_);                                               \
             _Pragma("unroll") for (int t_ = 0; t_ < NCT5; ++t_) dst_[t_ * (TB / 2)] = (d2){fv_[2 * t_], fv_[2 * t_ + 1]}; \
         }                                                                                                              \
@@ -1752,7 +1831,7 @@ __device__ __forceinline__ int factor_t(const SolveCtx& c, const gdouble* Hsrc, 
             // (issued inside the fused step it was waited for on the spot: its register is copied to an AGPR there)
             double ff_next = 0.0;
             if (fv) { const int ip = (J + 1) * TB + lane; if (lane < TB && ip < ni) ff_next = fv[ip]; }
-            const bool bad = diag_tile_inv(BTILE(J, J), INVT(J), l15);
+            const bool bad = ABL(32) ? false : diag_tile_inv(BTILE(J, J), INVT(J), l15);
             if (bad && lane == 0) dinv[TB] = 1.0;
             WT(0);
             SKEW(3, true);
@@ -1760,46 +1839,104 @@ __device__ __forceinline__ int factor_t(const SolveCtx& c, const gdouble* Hsrc, 
                 fused_fwd_step(J, fv, ni, bt, ct, yring, pend, svx, lane, l15, l4, ff_tacc, ff_rhs, ff_next);
                 WT(1);
             }
-            if (MCQ_BAND_WAVE0 && J > 0) { LAG_BAND_WAVE0(J - 1) }
+            if (MCQ_BAND_WAVE0 && J > 0 && !ABL(128)) { LAG_BAND_WAVE0(J - 1) }
             WT(2);
         } else {
+#if MCQ_FETCH_SINGLE
+            // Round 3: ONE tile row in flight per fetch wave.  The row fetched at the top of the previous step (tile row J-1+NTR: a
+            // whole step in flight) is committed first -- its band slots, tile row J-1's, were last read by panel(J-1); its border
+            // slots, tile row J-2's, by lag(J-2), the write-out of step J-2 and the fused forward step J-1: all behind the last
+            // barrier -- then tile row J+NTR goes in flight into the same registers, then the lag work of step J-1.
+            // What this order is about: `s_waitcnt vmcnt` counts loads AND stores of a wave in issue order, and across the loop's
+            // back-edge the compiler can only wait for ALL of them.  With the commit (and the register copy of the rows in flight)
+            // at the END of the phase, behind this step's write-out stores, that wait sat on the stores' round trip to HBM -- 2000 of
+            // a lag wave's ~8000 cycles per step (scripts/factor_bench.hip: -DMCQ_ABL=8 / 4) -- and kept two register sets alive.
+            // Here the youngest stores are a phase and a half old when the wait comes.
+            if (MCQ_WORKER_TIMERS) wt_last = (long long)clock64();
+            if (J > 0 && !ABL(8) && wl < PF_WAVES) { COMMIT_ROW(J - 1 + NTR) }
+            WT(5);
+            if (wl < PF_WAVES) {
+                const int R = J + NTR;
+                if (ABL(16)) {
+                    const RawEntry zero_entry = {0.0, 0.0, 0, 0};
+#pragma unroll
+                    for (int u = 0; u < PF_ITEMS; ++u) pf[u] = zero_entry;
+                } else if (PF_FAST(R)) {
+                    // Rows further than the band width from both ends of the interior have no border entries at all (the border
+                    // couples to the first and the last 64 rows only): half of every H row is zeros that need not be streamed --
+                    // 1 MB of the 2.1 MB a factorisation of an N = 2000 problem used to read.
+                    const bool bz = R * TB >= MCQ_BH_MAX && (R + 1) * TB <= ni - MCQ_BH_MAX;
+                    if (bz) {
+                        if (wl == 0) tile_row_fetch_fast<0, MK, SIG, true>(H, sig, mk, R, ni, pc, l15, l4, pf);
+                        else if (wl == 1 || PF_WAVES == 2) tile_row_fetch_fast<1, MK, SIG, true>(H, sig, mk, R, ni, pc, l15, l4, pf);
+                        else tile_row_fetch_fast<PF_WAVES == 2 ? 1 : 2, MK, SIG, true>(H, sig, mk, R, ni, pc, l15, l4, pf);
+                    } else {
+                        if (wl == 0) tile_row_fetch_fast<0, MK, SIG, false>(H, sig, mk, R, ni, pc, l15, l4, pf);
+                        else if (wl == 1 || PF_WAVES == 2) tile_row_fetch_fast<1, MK, SIG, false>(H, sig, mk, R, ni, pc, l15, l4, pf);
+                        else tile_row_fetch_fast<PF_WAVES == 2 ? 1 : 2, MK, SIG, false>(H, sig, mk, R, ni, pc, l15, l4, pf);
+                    }
+                } else {
+#pragma unroll
+                    for (int u = 0; u < PF_ITEMS; ++u) pf[u] = tile_row_fetch<MK, SIG>(H, sig, mk, ni, b, p, R, lt + u * PF_THREADS);
+                }
+            }
+            WT(0);
+            if (J > 0 && !ABL(512)) { LAG_DISPATCH(J - 1, 0) }
+            WT(4);
+        }
+#else
             // Tile row J+NTR goes in flight first; then the lag work of step J-1, with this wave's share of the write-out of step
             // J-1 and the commit of tile row J-1+NTR (COMMIT_ROW) issued in the shadow of its matrix-core products.
             RawEntry pfn[PF_ITEMS];
             if (MCQ_WORKER_TIMERS) wt_last = (long long)clock64();
             {
                 const int R = J + NTR;
-                if (PF_FAST(R)) {
+                if (ABL(16)) {
+                    const RawEntry zero_entry = {0.0, 0.0, 0, 0};
+#pragma unroll
+                    for (int u = 0; u < PF_ITEMS; ++u) pfn[u] = zero_entry;
+                } else if (PF_FAST(R)) {
                     // Rows further than the band width from both ends of the interior have no border entries at all (the border
                     // couples to the first and the last 64 rows only): half of every H row is zeros that need not be streamed --
                     // 1 MB of the 2.1 MB a factorisation of an N = 2000 problem used to read.
                     const bool bz = R * TB >= MCQ_BH_MAX && (R + 1) * TB <= ni - MCQ_BH_MAX;
-                    if (wl == 0) tile_row_fetch_fast<0, MK, SIG>(H, sig, mk, R, ni, pc, l15, l4, bz, pfn);
-                    else if (wl == 1) tile_row_fetch_fast<1, MK, SIG>(H, sig, mk, R, ni, pc, l15, l4, bz, pfn);
-                    else tile_row_fetch_fast<2, MK, SIG>(H, sig, mk, R, ni, pc, l15, l4, bz, pfn);
+                    if (bz) {
+                        if (wl == 0) tile_row_fetch_fast<0, MK, SIG, true>(H, sig, mk, R, ni, pc, l15, l4, pfn);
+                        else if (wl == 1 || PF_WAVES == 2) tile_row_fetch_fast<1, MK, SIG, true>(H, sig, mk, R, ni, pc, l15, l4, pfn);
+                        else tile_row_fetch_fast<PF_WAVES == 2 ? 1 : 2, MK, SIG, true>(H, sig, mk, R, ni, pc, l15, l4, pfn);
+                    } else {
+                        if (wl == 0) tile_row_fetch_fast<0, MK, SIG, false>(H, sig, mk, R, ni, pc, l15, l4, pfn);
+                        else if (wl == 1 || PF_WAVES == 2) tile_row_fetch_fast<1, MK, SIG, false>(H, sig, mk, R, ni, pc, l15, l4, pfn);
+                        else tile_row_fetch_fast<PF_WAVES == 2 ? 1 : 2, MK, SIG, false>(H, sig, mk, R, ni, pc, l15, l4, pfn);
+                    }
                 } else {
 #pragma unroll
                     for (int u = 0; u < PF_ITEMS; ++u) pfn[u] = tile_row_fetch<MK, SIG>(H, sig, mk, ni, b, p, R, lt + u * PF_THREADS);
                 }
             }
             WT(0);
-            if (J > 0) { LAG_DISPATCH(J - 1, 1) }
+            if (J > 0 && !ABL(512)) { LAG_DISPATCH(J - 1, 1) }
             WT(4);
 #pragma unroll
             for (int u = 0; u < PF_ITEMS; ++u) pf[u] = pfn[u];
             WT(5);
         }
+#endif
         lds_barrier();
         WT(6);
         c.tk[4] += FTICK() - tp; tp = FTICK();
-        if (dinv[TB] != 0.0) { fail = 1; break; }
+        // (a non-positive pivot raises dinv[TB]; it is looked at ONCE, behind the loop: reading the flag here, right behind the barrier
+        //  and in front of every wave's phase 2, cost 270 cycles per step -- the steps after a failed pivot compute NaNs, nothing else)
+#if MCQ_PD_CHECK_PER_STEP
+        if (!ABL(1024) && dinv[TB] != 0.0) { fail = 1; break; }
+#endif
         SKEW(4, w0 == 0);
         SKEW(5, w0 > 0);
         // ---- phase 2: panel + block column J+1, all on the matrix cores, one tile row per wave ---------------------------------
         //   X1' = M T(J+1,J)'  (every wave: the column-form operand of the update),   Xw' = M T(J+1+w,J)'  (L(J+1+w, J) = Xw),
         //   W_w = M C(J, w),   T(J+1+w, J+1) -= Xw X1'.
         // The transposed products leave X in exactly the per-lane layout the update's operands need: no LDS round trip.
-        {
+        if (!ABL(256)) {
             const double* lv = INVT(J);
             const double* t1 = BTILE(J + 1, J);
             const double* tw = BTILE(J + 1 + w0, J);
@@ -1840,6 +1977,7 @@ __device__ __forceinline__ int factor_t(const SolveCtx& c, const gdouble* Hsrc, 
         long long* acc = (long long*)c.w.Z;       // diagnostic build only: the curvature-row scratch doubles as the accumulator
         for (int q = 0; q < 8; ++q) acc[q] += wt[q];
     }
+    if (!MCQ_PD_CHECK_PER_STEP && !ABL(1024) && dinv[TB] != 0.0) fail = 1;     // dinv[TB]: written before the loop's last barrier
     if (fail) return MCQ_NOT_PD;
     const long long t_tail = FTICK();
     // drain: what the last step still owes
@@ -1982,7 +2120,7 @@ __device__ __forceinline__ int factor_t(const SolveCtx& c, const gdouble* Hsrc, 
         if (bad && lane == 0) dinv[TB] = 1.0;
     }
     __syncthreads();
-    if (dinv[TB] != 0.0) return MCQ_NOT_PD;
+    if (!ABL(1024) && dinv[TB] != 0.0) return MCQ_NOT_PD;
     // L_S^-1 packed (lower triangle by rows) into SM_S, outside the overlay, for the triangular solves that follow: the
     // border solves of every sweep are two LDS mat-vecs.
     {

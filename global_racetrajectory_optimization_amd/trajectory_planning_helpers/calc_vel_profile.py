@@ -86,7 +86,9 @@ def calc_vel_profile(ax_max_machines: np.ndarray, kappa: np.ndarray, el_lengths:
     radii = np.abs(np.divide(1.0, kappa, out=np.full(kappa.size, np.inf), where=kappa != 0.0))
     mu = np.ones(kappa.size) if mu is None else np.asarray(mu, dtype=np.float64)
 
-    vx = np.sqrt(mu * np.amin(ggv[:, 2]) * radii)
+    # first estimate of the lateral limit from the MEAN friction coefficient, as upstream (ay_max_global = mu_mean * min(ay_max)); the
+    # fixed point below stops on a 0.5 % relative change, so the start matters at that level when mu is not uniform
+    vx = np.sqrt(float(np.mean(mu)) * np.amin(ggv[:, 2]) * radii)
     converged = False
     for _ in range(100):
         vx_new = np.sqrt(mu * np.interp(vx, ggv[:, 0], ggv[:, 2]) * radii)

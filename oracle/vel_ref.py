@@ -146,7 +146,8 @@ def calc_vel_profile(ax_max_machines, kappa, el_lengths, closed, drag_coeff, m_v
     no_points = radii.size
 
     # lateral limit
-    ay_max_global = mu * np.amin(ggv[:, 2])
+    mu_mean = float(np.mean(mu))                       # upstream: the first estimate uses the mean friction coefficient
+    ay_max_global = mu_mean * np.amin(ggv[:, 2])
     vx_profile = np.sqrt(ay_max_global * radii)
     rounds = 0
     for _ in range(100):
