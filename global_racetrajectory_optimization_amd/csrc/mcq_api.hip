@@ -62,6 +62,8 @@ struct mcq_handle {
     bool smem_attr_set = false;
     double* vel_scratch = nullptr;      // lap-doubled profiles of mcq_vel_profile_device, [2 nmax][batch]
     size_t vel_scratch_bytes = 0;
+    double* kbig = nullptr;             // overflow slots of the curvature-row working set (MCQ_KBIG_SLOTS x MCQ_KBIG_SLOT doubles)
+    int* kbig_count = nullptr;          // slots claimed by the launch in flight
     double* d_org = nullptr;            // per-track origins of the fp32 row entries, [batch][2]
     double* d_trace = nullptr;          // curvature-error trace of mcq_iqp_batch, [batch][MCQ_IQP_TRACE] (grown with d_iqp)
     // mcq_solve_host_pipelined: two copy streams, the second set of staging buffers, one event triple per slot
@@ -133,6 +135,8 @@ static void free_ws(mcq_handle* h)
 {
     (void)hipFree(h->Eb); (void)hipFree(h->Et); (void)hipFree(h->Db); (void)hipFree(h->H); (void)hipFree(h->L); (void)hipFree(h->vec); (void)hipFree(h->Z); (void)hipFree(h->state);
     (void)hipFree(h->state2);
+    (void)hipFree(h->kbig); (void)hipFree(h->kbig_count);
+    h->kbig = nullptr; h->kbig_count = nullptr;
     h->Eb = h->Et = h->Db = h->H = h->L = h->vec = h->Z = nullptr;
     h->state = h->state2 = nullptr;
     h->state2_valid = false;
@@ -202,6 +206,9 @@ static int ensure_ws(mcq_handle* h, size_t batch, size_t nmax)
     HIP_TRY(hipMalloc((void**)&h->Z, (elems + batch * (size_t)MCQ_KMAX * MCQ_KMAX) * sizeof(double)));
     HIP_TRY(hipMalloc((void**)&h->state, elems));
     HIP_TRY(hipMalloc((void**)&h->state2, elems));
+    HIP_TRY(hipMalloc((void**)&h->kbig, (size_t)MCQ_KBIG_SLOTS * MCQ_KBIG_SLOT * sizeof(double)));
+    HIP_TRY(hipMalloc((void**)&h->kbig_count, sizeof(int)));
+    if (h->poison) HIP_TRY(hipMemsetAsync(h->kbig, 0xff, (size_t)MCQ_KBIG_SLOTS * MCQ_KBIG_SLOT * sizeof(double), h->stream));
     HIP_TRY(hipMemsetAsync(h->state, 0, elems, h->stream));
     HIP_TRY(hipMemsetAsync(h->state2, 0, elems, h->stream));
     if (h->poison) {
@@ -216,7 +223,8 @@ static int ensure_ws(mcq_handle* h, size_t batch, size_t nmax)
     h->cap_elems = elems;
     h->cap_batch = batch;
     h->ws_bytes = (long long)(elems * ((3 * MCQ_ELD + MCQ_HLD + MCQ_LLD + MCQ_NVEC + 1) * sizeof(double) + 2) +
-                              batch * (size_t)MCQ_KMAX * MCQ_KMAX * sizeof(double));
+                              batch * (size_t)MCQ_KMAX * MCQ_KMAX * sizeof(double) +
+                              (size_t)MCQ_KBIG_SLOTS * MCQ_KBIG_SLOT * sizeof(double));
     return 0;
 }
 
@@ -261,6 +269,10 @@ static int launch(mcq_handle* h, McqBatch& B, const mcq_opts& o)
     B.check_kappa = o.check_kappa;
     B.objective = o.objective;
     B.poison_lds = h->poison ? 1 : 0;
+    B.kbig = h->kbig;
+    B.kbig_count = h->kbig_count;
+    B.kbig_slots = MCQ_KBIG_SLOTS;
+    if (!B.prep_only) HIP_TRY(hipMemsetAsync(h->kbig_count, 0, sizeof(int), h->stream));
     // warm start: only the working sets mcq_relinearise_device carried over for exactly this batch layout
     B.warm = (o.warm_start > 0 && h->state2_valid && !B.prep_only && h->state2_batch == B.batch && h->state2_nmax == B.nmax)
                  ? h->state2 : nullptr;
@@ -998,7 +1010,7 @@ extern "C" int mcq_iqp_device(mcq_handle* h, int batch, int nmax, int* n_io, dou
     int* n_set[2] = {n_io, n_b};
     double* ref_set[2] = {reftrack_a, reftrack_b};
     double* nv_set[2] = {normvec_a, normvec_b};
-    // every track with n >= 1 starts live (a track with n == 0 is skipped altogether: status MCQ_BAD_INPUT, 0 rounds)
+    // every track starts live (a track with n == 0 ends in its first, empty pass: status MCQ_BAD_INPUT, rounds_out 1)
     {
         std::vector<int> ones((size_t)batch, 1);
         HIP_TRY(hipMemcpyAsync(live, ones.data(), batch * sizeof(int), hipMemcpyHostToDevice, h->stream));

@@ -45,6 +45,9 @@
 #define MCQ_LBW 80                 /* offset of the border part W inside an L row */
 #define MCQ_NVEC 30
 #define MCQ_KMAX 120               /* active curvature rows the Schur-complement path of the active-set phase holds */
+#define MCQ_KBIG 512               /* ... and of the overflow path (round 3): a problem with more of them claims one of the handle's slots, */
+#define MCQ_KBIG_SLOT ((size_t)MCQ_KBIG * MCQ_KBIG + 6 * (size_t)MCQ_KBIG)   /* doubles per slot: Schur matrix, three vectors, the index / sign / pivot lists */
+#define MCQ_KBIG_SLOTS 8           /* slots per handle (17 MB): problems of one launch that can take the overflow path */
 #define MCQ_ZLD(nmax) ((size_t)(nmax) + (size_t)MCQ_KMAX * MCQ_KMAX)   /* doubles of the curvature-row scratch per problem: one vector + the Schur matrix */
 #define MCQ_PIVOT_WARMUP 64
 
@@ -126,6 +129,9 @@ struct McqBatch {
     int band_e, max_ipm_iter, max_as_iter, refine_steps, check_kappa;
     const signed char* warm; // [batch][nmax] working set to start the exchange from (IQP passes 2+), or nullptr (cold: interior point)
     int poison_lds;         // MCQ_POISON=1 (debugging aid): the solver kernel starts from an LDS full of NaNs, like the workspaces
+    double* kbig;           // overflow slots of the curvature-row working set (MCQ_KBIG_SLOT doubles each), kbig_slots of them;
+    int* kbig_count;        // slots claimed in this launch (zeroed by the host before it)
+    int kbig_slots;
     int objective;          // MCQ_OBJ_*: shortest path = H and f written directly by mcq_assemble_sp_kernel (Eb holds the three
                             // diagonals of H, the gradient is H x + f), no curvature rows, no curvature-error post-check
 };

@@ -929,22 +929,10 @@ __global__ void __launch_bounds__(MCQ_NT) mcq_assemble_sp_kernel(McqBatch B)
 #ifndef MCQ_ABL
 #define MCQ_ABL 0
 #endif
-#ifndef MCQ_SCALAR_WAVE
-#define MCQ_SCALAR_WAVE 0
-#endif
-#ifndef MCQ_CRING
-#define MCQ_CRING 1         /* 1: the border accumulators of a lag wave's own column stay in registers across the steps (needs MCQ_FETCH_SINGLE) */
-#endif
-#ifndef MCQ_IO_SPLIT
-#define MCQ_IO_SPLIT 0      /* 1: lag waves 1 and 2 fetch / commit (loads only), lag wave 3 writes out (stores only); 0: every lag wave both */
-#endif
-#ifndef MCQ_PD_CHECK_PER_STEP
-#define MCQ_PD_CHECK_PER_STEP 0
-#endif
-#ifndef MCQ_FETCH_SINGLE
-#define MCQ_FETCH_SINGLE 1   /* 1: one tile row in flight per fetch wave, committed at the top of the next step (round 3); 0: round 2's two sets */
-#endif
 #define ABL(bit) ((MCQ_ABL & (bit)) != 0)
+#ifndef MCQ_PD_CHECK_PER_STEP
+#define MCQ_PD_CHECK_PER_STEP 0     /* 1: the non-positive-pivot flag is read after every step (round 2) instead of once per factorisation */
+#endif
 #ifndef MCQ_FUSE_FWD
 #define MCQ_FUSE_FWD 1     /* forward substitution of the predictor / active-set solve fused into the factorisation (factor_t) */
 #endif
@@ -1007,18 +995,8 @@ struct SolveCtx {
 // still reads as T(P+1, P) while wave 0 produces it -- that one goes to the dead upper-triangle slot (P+1, P+2)
 #define LTILE(dI, P) ((dI) == 1 ? BTILE((P) + 1, (P) + 2) : BTILE((P) + (dI), (P)))
 #define ROW_ITEMS (TB * (NTR * TB + MCQ_P_MAX))            /* 16 x 144 doubles per tile row */
-// Who moves what (round 3, MCQ_IO_SPLIT): s_waitcnt vmcnt counts the loads AND the stores of a wave, and the two complete out of order
-// with respect to each other -- a wave that has stores in flight can only wait for "everything" (vmcnt(0)) when it needs a loaded
-// value, i.e. for its stores' round trip to HBM as well.  With the write-out stores on the waves that fetch, that wait cost 2000-3900
-// of a lag wave's ~8000 cycles per step (scripts/factor_bench.hip, -DMCQ_ABL=8 / 8192).  So the roles are split by wave: waves 1 and 2
-// fetch and commit the tile rows (loads only), wave 3 writes L / W out (stores only), wave 0 keeps the critical path.
-#if MCQ_IO_SPLIT
-#define PF_WAVES 2
-#else
-#define PF_WAVES 3
-#endif
-#define PF_THREADS (64 * PF_WAVES)                         /* fetch / commit threads (waves 1 .. PF_WAVES) */
-#define PF_ITEMS (ROW_ITEMS / PF_THREADS)                 /* 2304 / 128 = 18  (2304 / 192 = 12) */
+#define PF_THREADS (MCQ_NT - 64)                           /* waves 1..3 fetch and commit; wave 0 only runs the critical path */
+#define PF_ITEMS (ROW_ITEMS / PF_THREADS)                 /* 2304 / 192 = 12 */
 
 // Raw (un-decoded) loads of one window entry: kept in registers while the loads are in flight, decoded when the entry is
 // committed to LDS -- nothing between fetch and commit depends on the loaded values, so no s_waitcnt is placed early.
@@ -1124,15 +1102,9 @@ __device__ __forceinline__ PfLane pf_lane(int l15, int l4)
     c.lC = l4 * TLD + l15;
     return c;
 }
-#if MCQ_IO_SPLIT
-#define PF_NBAND(WL) 10                                               /* band blocks of fetch wave WL (two fetch waves: even / odd) */
-#define PF_BBLK(WL, u) ((WL) + 2 * (u))                               /* u-th band block of wave WL: 4 tcol + k */
-#define PF_CBLK(WL, v) ((WL) + 2 * (v))                               /* v-th border block of wave WL: 4 a + k */
-#else
 #define PF_NBAND(WL) ((WL) < 2 ? 7 : 6)                              /* band blocks of fetch wave WL */
 #define PF_BBLK(WL, u) ((WL) + 3 * (u))                               /* u-th band block of wave WL: 4 tcol + k */
 #define PF_CBLK(WL, v) ((((WL) + 1) % 3) + 3 * (v))                   /* v-th border block of wave WL: 4 a + k */
-#endif
 
 // (BZ -- the border half of the row is all zeros and is not fetched -- is a template parameter: a run-time flag merges loaded values
 //  with constants through control flow, and the compiler then waits for the loads at the merge, i.e. right behind their issue)
@@ -1371,18 +1343,13 @@ __device__ __forceinline__ int factor_t(const SolveCtx& c, const gdouble* Hsrc, 
     double* dinv = g_sm + SM_DINV;
     const gdouble* H = Hsrc;
     gdouble* L = c.w.L;
-    // the wave index as a SCALAR: every role dispatch below (wave 0 / lag waves, the three lag waves' literal tile ownership, the fetch
-    // waves' block lists) is then a scalar branch between mutually exclusive paths.  Left as the vector value tid >> 6 the compiler
-    // lays the alternatives out one behind the other under exec masks and must assume that all of them run: registers a load of one
-    // alternative is still filling cannot be written by the next without an s_waitcnt vmcnt(0) in front.
-    const int lane = tid & 63, w0 = MCQ_SCALAR_WAVE ? __builtin_amdgcn_readfirstlane(tid >> 6) : (tid >> 6);
+    const int lane = tid & 63, w0 = tid >> 6;
     const int l15 = lane & 15, l4 = lane >> 4;
     const int nblk = (ni + TB - 1) / TB;
 
     v4d sacc[NCT];
-    v4d cring[NTR - 1];     // MCQ_CRING: a lag wave's border column, the four tile rows in flight (see LAG_WORK)
 #pragma unroll
-    for (int m = 0; m < NCT; ++m) { sacc[m] = (v4d){0.0, 0.0, 0.0, 0.0}; cring[m] = (v4d){0.0, 0.0, 0.0, 0.0}; }
+    for (int m = 0; m < NCT; ++m) sacc[m] = (v4d){0.0, 0.0, 0.0, 0.0};
     RawEntry pf[PF_ITEMS];
     double* yring = g_sm + SM_YR;
     double* pend = g_sm + SM_PEND;
@@ -1398,7 +1365,7 @@ __device__ __forceinline__ int factor_t(const SolveCtx& c, const gdouble* Hsrc, 
 #define PF_FAST(R) (pf_dims && (R) >= NTR - 1 && ((R) + 1) * TB <= ni)
     __syncthreads();
     // prologue: tile rows 0 .. NTR-1
-    if (lt >= 0 && lt < PF_THREADS) {
+    if (lt >= 0) {
         for (int R = 0; R < NTR; ++R) {
             // all loads of a tile row are issued before the first decode (one HBM round trip per tile row, not per item)
 #pragma unroll
@@ -1432,13 +1399,6 @@ __device__ __forceinline__ int factor_t(const SolveCtx& c, const gdouble* Hsrc, 
     //   Schur tiles (lower, 10): (t + 1) % 3 == wl, register slot t / 3;    band tiles (6): t % 3 == wl
     // wl is a literal inside LAG_WORK (three-way dispatch) so that every register array is indexed statically.
     // All LDS operand / accumulator reads of a group are issued before its MFMAs, all writes after them.
-#ifndef MCQ_LAG_ORDER
-#define MCQ_LAG_ORDER 1     /* 1: round-3 order of a lag wave's step (one read phase, Schur products first); 0: round 2's */
-#endif
-#if MCQ_IO_SPLIT && (!MCQ_FETCH_SINGLE || MCQ_LAG_ORDER != 1)
-#error "MCQ_IO_SPLIT needs MCQ_FETCH_SINGLE = 1 and MCQ_LAG_ORDER = 1"
-#endif
-#if MCQ_LAG_ORDER == 0
 #define LAG_WORK(P, WL, CM)                                                                                                  \
     {                                                                                                                  \
         /* The three groups of the step's lag work (border, band, Schur tiles) used to run read -> MFMA -> write one after \
@@ -1474,13 +1434,15 @@ __device__ __forceinline__ int factor_t(const SolveCtx& c, const gdouble* Hsrc, 
         }                                                                                                              \
         WT(1);                                                                                                         \
         /* ---- products ---- */                                                                                       \
+        if (!ABL(2)) {                                                                                                 \
         _Pragma("unroll") for (int dI_ = 1; dI_ < NTR; ++dI_) cacc_[dI_ - 1] = mfma16(la_[dI_ - 1], wv_[(WL)], cacc_[dI_ - 1]); \
         c3a_ = mfma16(la_[(WL)], wv_[3], c3a_);                                                                        \
         if ((WL) == 0) c3b_ = mfma16(la_[3], wv_[3], c3b_);                                                            \
+        }                                                                                                              \
         /* ---- in the shadow of those 20 / 24 fp64 MFMAs (64 cycles each, results not needed yet): this wave's share of the     \
                 write-out of step P -- LDS reads of final tiles, global stores; nothing the products touch ---- */            \
         __builtin_amdgcn_sched_barrier(0);                                                                             \
-        if ((WL) == 0) { WRITE_OUT_W((P), 1) } else if ((WL) == 1) { WRITE_OUT_W((P), 0) } else { WRITE_OUT_L((P)) }   \
+        if (!ABL(4)) { if ((WL) == 0) { WRITE_OUT_W((P), 1) } else if ((WL) == 1) { WRITE_OUT_W((P), 0) } else { WRITE_OUT_L((P)) } } \
         __builtin_amdgcn_sched_barrier(0);                                                                             \
         /* ---- updated tiles back to the window ---- */                                                               \
         _Pragma("unroll") for (int dI_ = 1; dI_ < NTR; ++dI_) {                                                        \
@@ -1507,97 +1469,6 @@ __device__ __forceinline__ int factor_t(const SolveCtx& c, const gdouble* Hsrc, 
             }                                                                                                          \
         }                                                                                                              \
         WT(2);                                                                                                         \
-        {                                                                                                              \
-            int t_ = 0;                                                                                                \
-            _Pragma("unroll") for (int a_ = 0; a_ < NCT; ++a_) {                                                       \
-                _Pragma("unroll") for (int bb_ = 0; bb_ <= a_; ++bb_, ++t_) {                                          \
-                    if ((t_ + 1) % 3 != (WL)) continue;                                                                \
-                    double av_[4];                                                                                     \
-                    _Pragma("unroll") for (int kc = 0; kc < 4; ++kc) av_[kc] = -wv_[a_][kc];                           \
-                    sacc[t_ / 3] = mfma16(av_, wv_[bb_], sacc[t_ / 3]);                                                \
-                }                                                                                                      \
-            }                                                                                                          \
-        }                                                                                                              \
-        {                                                                                                              \
-            int t_ = 0, s_ = 0;                                                                                        \
-            _Pragma("unroll") for (int dK_ = 2; dK_ < NTR; ++dK_) {                                                    \
-                _Pragma("unroll") for (int dI_ = dK_; dI_ < NTR; ++dI_, ++t_) {                                        \
-                    if (t_ % 3 != (WL) || t_ < MCQ_BAND_WAVE0) continue;                                              \
-                    double bv_[4];                                                                                     \
-                    _Pragma("unroll") for (int kc = 0; kc < 4; ++kc) bv_[kc] = -la_[dK_ - 1][kc];                      \
-                    bacc_[s_] = mfma16(la_[dI_ - 1], bv_, bacc_[s_]);                                                  \
-                    ++s_;                                                                                              \
-                }                                                                                                      \
-            }                                                                                                          \
-        }                                                                                                              \
-        /* ---- in the shadow of the Schur / band products: the commit of the tile row fetched a step and a half ago ---- */    \
-        __builtin_amdgcn_sched_barrier(0);                                                                             \
-        if (CM) { COMMIT_ROW((P) + NTR) }                                                                              \
-        __builtin_amdgcn_sched_barrier(0);                                                                             \
-        {                                                                                                              \
-            int t_ = 0, s_ = 0;                                                                                        \
-            _Pragma("unroll") for (int dK_ = 2; dK_ < NTR; ++dK_) {                                                    \
-                _Pragma("unroll") for (int dI_ = dK_; dI_ < NTR; ++dI_, ++t_) {                                        \
-                    if (t_ % 3 != (WL) || t_ < MCQ_BAND_WAVE0) continue;                                              \
-                    double* tt_ = BTILE((P) + dI_, (P) + dK_);                                                         \
-                    _Pragma("unroll") for (int r = 0; r < 4; ++r) tt_[(l4 + 4 * r) * TLD + l15] = bacc_[s_][r];        \
-                    ++s_;                                                                                              \
-                }                                                                                                      \
-            }                                                                                                          \
-        }                                                                                                              \
-        WT(3);                                                                                                         \
-    }
-#else
-#define LAG_WORK(P, WL, CM)                                                                                                  \
-    {                                                                                                                  \
-        /* Round 3 order: the products that need nothing but the W row block run FIRST (see below).                            \
-             border tiles  C(P+dI, a) -= L(P+dI, P) W_P(a)            a = WL for dI = 1..4, plus (WL+1, 3) [and (4, 3) on WL 0]   \
-             band tiles    T(P+dI, P+dK) -= L(P+dI, P) L(P+dK, P)'    2 <= dK <= dI <= 4, tile t % 3 == WL                 \
-             Schur tiles   S(a, bb) -= W_P(a)' W_P(bb)                 lower, (t + 1) % 3 == WL, kept in registers           \
-           The W operands are read first (LDS returns in order), then every other operand and accumulator of the step; the  \
-           Schur products (13 / 14 fp64 MFMAs = 850 cycles, W operands only, results in registers) run while those reads land --  \
-           until round 2 the wave sat through that round trip (1860 cycles of a 6500-cycle phase with all three lag waves       \
-           reading at once) with the matrix pipe idle.  Border products next, the write-out of step P in their shadow; the     \
-           band accumulators are read behind the border tiles' write-back (up front as well they are 8 live VGPRs too many:      \
-           spills, and hipcc 7.2's AGPR-copy rewrite pass crashes on them), the commit of tile row P+NTR -- decode arithmetic     \
-           and LDS writes, independent of everything here -- covers that round trip. */                                        \
-        double la_[4][4], wv_[NCT][4];                                                                                 \
-        v4d cacc_[4], c3a_, c3b_, bacc_[2];                                                                            \
-        _Pragma("unroll") for (int a_ = 0; a_ < NCT; ++a_) {                                                           \
-            const double* wa2_ = CTILE((P), a_);                                                                       \
-            _Pragma("unroll") for (int kc = 0; kc < 4; ++kc) wv_[a_][kc] = wa2_[(l4 + 4 * kc) * TLD + l15];            \
-        }                                                                                                              \
-        _Pragma("unroll") for (int dI_ = 1; dI_ < NTR; ++dI_) {                                                        \
-            const double* li_ = LTILE(dI_, (P));                                                                       \
-            _Pragma("unroll") for (int kc = 0; kc < 4; ++kc) la_[dI_ - 1][kc] = -li_[l15 * TLD + l4 + 4 * kc];         \
-        }                                                                                                              \
-        if (MCQ_CRING) {                                                                                               \
-            /* border column WL: the four tile rows in flight live in registers across the steps (cring); only the row that      \
-               enters (P+4, untouched so far) is read, only the row that is finished (P+1) is written */                        \
-            if ((P) == 0) {                                                                                            \
-                _Pragma("unroll") for (int dI_ = 1; dI_ < NTR - 1; ++dI_) {                                            \
-                    const double* ctl_ = CTILE((P) + dI_, (WL));                                                       \
-                    _Pragma("unroll") for (int r = 0; r < 4; ++r) cring[dI_ - 1][r] = ctl_[(l4 + 4 * r) * TLD + l15];  \
-                }                                                                                                      \
-            }                                                                                                          \
-            const double* ctl_ = CTILE((P) + NTR - 1, (WL));                                                           \
-            _Pragma("unroll") for (int r = 0; r < 4; ++r) cring[NTR - 2][r] = ctl_[(l4 + 4 * r) * TLD + l15];          \
-        } else {                                                                                                       \
-        _Pragma("unroll") for (int dI_ = 1; dI_ < NTR; ++dI_) {                                                        \
-            const double* ctl_ = CTILE((P) + dI_, (WL));                                                               \
-            _Pragma("unroll") for (int r = 0; r < 4; ++r) cacc_[dI_ - 1][r] = ctl_[(l4 + 4 * r) * TLD + l15];          \
-        }                                                                                                              \
-        }                                                                                                              \
-        {                                                                                                              \
-            const double* c3p_ = CTILE((P) + (WL) + 1, 3);                                                             \
-            const double* c3q_ = CTILE((P) + 4, 3);                                                                    \
-            _Pragma("unroll") for (int r = 0; r < 4; ++r) {                                                            \
-                c3a_[r] = c3p_[(l4 + 4 * r) * TLD + l15];                                                              \
-                c3b_[r] = c3q_[(l4 + 4 * r) * TLD + l15];                                                              \
-            }                                                                                                          \
-        }                                                                                                              \
-        WT(1);                                                                                                         \
-        /* ---- Schur products: W operands only ---- */                                                                 \
         {                                                                                                              \
             int t_ = 0;                                                                                                \
             _Pragma("unroll") for (int a_ = 0; a_ < NCT; ++a_) {                                                       \
@@ -1609,59 +1480,6 @@ __device__ __forceinline__ int factor_t(const SolveCtx& c, const gdouble* Hsrc, 
                 }                                                                                                      \
             }                                                                                                          \
         }                                                                                                              \
-        WT(2);                                                                                                         \
-        /* ---- border products ---- */                                                                                 \
-        if (!ABL(2)) {                                                                                                 \
-        if (MCQ_CRING) { _Pragma("unroll") for (int dI_ = 1; dI_ < NTR; ++dI_) cring[dI_ - 1] = mfma16(la_[dI_ - 1], wv_[(WL)], cring[dI_ - 1]); } \
-        else { _Pragma("unroll") for (int dI_ = 1; dI_ < NTR; ++dI_) cacc_[dI_ - 1] = mfma16(la_[dI_ - 1], wv_[(WL)], cacc_[dI_ - 1]); } \
-        c3a_ = mfma16(la_[(WL)], wv_[3], c3a_);                                                                        \
-        if ((WL) == 0) c3b_ = mfma16(la_[3], wv_[3], c3b_);                                                            \
-        }                                                                                                              \
-        /* ---- in the shadow of the band / border products (results not needed yet): this wave's share of the write-out of   \
-                step P -- LDS reads of final tiles, global stores -- and the commit of the tile row fetched a step and a half    \
-                ago; nothing the products touch ---- */                                                                    \
-        __builtin_amdgcn_sched_barrier(0);                                                                             \
-        if (!ABL(4)) {                                                                                                 \
-            if (MCQ_IO_SPLIT) { if ((WL) == 2) { WRITE_OUT_W((P), 0) WRITE_OUT_W((P), 1) WRITE_OUT_L((P)) } }          \
-            else if ((WL) == 0) { WRITE_OUT_W((P), 1) } else if ((WL) == 1) { WRITE_OUT_W((P), 0) } else { WRITE_OUT_L((P)) } \
-        }                                                                                                              \
-        __builtin_amdgcn_sched_barrier(0);                                                                             \
-        WT(4);                                                                                                         \
-        /* ---- updated tiles back to the window ---- */                                                               \
-        if (MCQ_CRING) {                                                                                               \
-            double* ctl_ = CTILE((P) + 1, (WL));                                                                       \
-            _Pragma("unroll") for (int r = 0; r < 4; ++r) ctl_[(l4 + 4 * r) * TLD + l15] = cring[0][r];                \
-            _Pragma("unroll") for (int dI_ = 1; dI_ < NTR - 1; ++dI_) cring[dI_ - 1] = cring[dI_];                     \
-        } else {                                                                                                       \
-        _Pragma("unroll") for (int dI_ = 1; dI_ < NTR; ++dI_) {                                                        \
-            double* ctl_ = CTILE((P) + dI_, (WL));                                                                     \
-            _Pragma("unroll") for (int r = 0; r < 4; ++r) ctl_[(l4 + 4 * r) * TLD + l15] = cacc_[dI_ - 1][r];          \
-        }                                                                                                              \
-        }                                                                                                              \
-        {                                                                                                              \
-            double* c3p_ = CTILE((P) + (WL) + 1, 3);                                                                   \
-            double* c3q_ = CTILE((P) + 4, 3);                                                                          \
-            _Pragma("unroll") for (int r = 0; r < 4; ++r) {                                                            \
-                c3p_[(l4 + 4 * r) * TLD + l15] = c3a_[r];                                                              \
-                if ((WL) == 0) c3q_[(l4 + 4 * r) * TLD + l15] = c3b_[r];                                               \
-            }                                                                                                          \
-        }                                                                                                              \
-        {                                                                                                              \
-            int t_ = 0, s_ = 0;                                                                                        \
-            _Pragma("unroll") for (int dK_ = 2; dK_ < NTR; ++dK_) {                                                    \
-                _Pragma("unroll") for (int dI_ = dK_; dI_ < NTR; ++dI_, ++t_) {                                        \
-                    if (t_ % 3 != (WL) || t_ < MCQ_BAND_WAVE0) continue;                                              \
-                    const double* tt_ = BTILE((P) + dI_, (P) + dK_);                                                   \
-                    _Pragma("unroll") for (int r = 0; r < 4; ++r) bacc_[s_][r] = tt_[(l4 + 4 * r) * TLD + l15];        \
-                    ++s_;                                                                                              \
-                }                                                                                                      \
-            }                                                                                                          \
-        }                                                                                                              \
-        /* ---- the commit of the tile row fetched a step and a half ago, while the band accumulators arrive ---- */          \
-        __builtin_amdgcn_sched_barrier(0);                                                                             \
-        if (CM && !ABL(8)) { COMMIT_ROW((P) + NTR) }                                                                   \
-        __builtin_amdgcn_sched_barrier(0);                                                                             \
-        /* ---- band products ---- */                                                                                   \
         {                                                                                                              \
             int t_ = 0, s_ = 0;                                                                                        \
             _Pragma("unroll") for (int dK_ = 2; dK_ < NTR; ++dK_) {                                                    \
@@ -1674,6 +1492,10 @@ __device__ __forceinline__ int factor_t(const SolveCtx& c, const gdouble* Hsrc, 
                 }                                                                                                      \
             }                                                                                                          \
         }                                                                                                              \
+        /* ---- in the shadow of the Schur / band products: the commit of the tile row fetched a step and a half ago ---- */    \
+        __builtin_amdgcn_sched_barrier(0);                                                                             \
+        if (CM && !ABL(8)) { COMMIT_ROW((P) + NTR) }                                                                   \
+        __builtin_amdgcn_sched_barrier(0);                                                                             \
         {                                                                                                              \
             int t_ = 0, s_ = 0;                                                                                        \
             _Pragma("unroll") for (int dK_ = 2; dK_ < NTR; ++dK_) {                                                    \
@@ -1687,7 +1509,6 @@ __device__ __forceinline__ int factor_t(const SolveCtx& c, const gdouble* Hsrc, 
         }                                                                                                              \
         WT(3);                                                                                                         \
     }
-#endif
 
     // The first MCQ_BAND_WAVE0 of the six band tiles of step P on wave 0: T(P+dI, P+dK) -= L(P+dI, P) L(P+dK, P)', 2 <= dK <= dI <= 4 -- wave 0 is done
     // with its chain 2300 cycles before the lag waves are with their products, and fp64 MFMA time (64 cycles a piece, at the vector
@@ -1746,8 +1567,8 @@ __device__ __forceinline__ int factor_t(const SolveCtx& c, const gdouble* Hsrc, 
     {                                                                                                                  \
         if (PF_FAST((R))) {                                                                                            \
             if (wl == 0) tile_row_commit_fast<0, MK, SIG>(bt, ct, pf, (R), pc, l15, l4);                               \
-            else if (wl == 1 || PF_WAVES == 2) tile_row_commit_fast<1, MK, SIG>(bt, ct, pf, (R), pc, l15, l4);         \
-            else tile_row_commit_fast<PF_WAVES == 2 ? 1 : 2, MK, SIG>(bt, ct, pf, (R), pc, l15, l4);                   \
+            else if (wl == 1) tile_row_commit_fast<1, MK, SIG>(bt, ct, pf, (R), pc, l15, l4);                          \
+            else tile_row_commit_fast<2, MK, SIG>(bt, ct, pf, (R), pc, l15, l4);                                       \
         } else {                                                                                                       \
             _Pragma("unroll") for (int u = 0; u < PF_ITEMS; ++u) {                                                     \
                 const int q = lt + u * PF_THREADS;                                                                     \
@@ -1842,49 +1663,6 @@ __device__ __forceinline__ int factor_t(const SolveCtx& c, const gdouble* Hsrc, 
             if (MCQ_BAND_WAVE0 && J > 0 && !ABL(128)) { LAG_BAND_WAVE0(J - 1) }
             WT(2);
         } else {
-#if MCQ_FETCH_SINGLE
-            // Round 3: ONE tile row in flight per fetch wave.  The row fetched at the top of the previous step (tile row J-1+NTR: a
-            // whole step in flight) is committed first -- its band slots, tile row J-1's, were last read by panel(J-1); its border
-            // slots, tile row J-2's, by lag(J-2), the write-out of step J-2 and the fused forward step J-1: all behind the last
-            // barrier -- then tile row J+NTR goes in flight into the same registers, then the lag work of step J-1.
-            // What this order is about: `s_waitcnt vmcnt` counts loads AND stores of a wave in issue order, and across the loop's
-            // back-edge the compiler can only wait for ALL of them.  With the commit (and the register copy of the rows in flight)
-            // at the END of the phase, behind this step's write-out stores, that wait sat on the stores' round trip to HBM -- 2000 of
-            // a lag wave's ~8000 cycles per step (scripts/factor_bench.hip: -DMCQ_ABL=8 / 4) -- and kept two register sets alive.
-            // Here the youngest stores are a phase and a half old when the wait comes.
-            if (MCQ_WORKER_TIMERS) wt_last = (long long)clock64();
-            if (J > 0 && !ABL(8) && wl < PF_WAVES) { COMMIT_ROW(J - 1 + NTR) }
-            WT(5);
-            if (wl < PF_WAVES) {
-                const int R = J + NTR;
-                if (ABL(16)) {
-                    const RawEntry zero_entry = {0.0, 0.0, 0, 0};
-#pragma unroll
-                    for (int u = 0; u < PF_ITEMS; ++u) pf[u] = zero_entry;
-                } else if (PF_FAST(R)) {
-                    // Rows further than the band width from both ends of the interior have no border entries at all (the border
-                    // couples to the first and the last 64 rows only): half of every H row is zeros that need not be streamed --
-                    // 1 MB of the 2.1 MB a factorisation of an N = 2000 problem used to read.
-                    const bool bz = R * TB >= MCQ_BH_MAX && (R + 1) * TB <= ni - MCQ_BH_MAX;
-                    if (bz) {
-                        if (wl == 0) tile_row_fetch_fast<0, MK, SIG, true>(H, sig, mk, R, ni, pc, l15, l4, pf);
-                        else if (wl == 1 || PF_WAVES == 2) tile_row_fetch_fast<1, MK, SIG, true>(H, sig, mk, R, ni, pc, l15, l4, pf);
-                        else tile_row_fetch_fast<PF_WAVES == 2 ? 1 : 2, MK, SIG, true>(H, sig, mk, R, ni, pc, l15, l4, pf);
-                    } else {
-                        if (wl == 0) tile_row_fetch_fast<0, MK, SIG, false>(H, sig, mk, R, ni, pc, l15, l4, pf);
-                        else if (wl == 1 || PF_WAVES == 2) tile_row_fetch_fast<1, MK, SIG, false>(H, sig, mk, R, ni, pc, l15, l4, pf);
-                        else tile_row_fetch_fast<PF_WAVES == 2 ? 1 : 2, MK, SIG, false>(H, sig, mk, R, ni, pc, l15, l4, pf);
-                    }
-                } else {
-#pragma unroll
-                    for (int u = 0; u < PF_ITEMS; ++u) pf[u] = tile_row_fetch<MK, SIG>(H, sig, mk, ni, b, p, R, lt + u * PF_THREADS);
-                }
-            }
-            WT(0);
-            if (J > 0 && !ABL(512)) { LAG_DISPATCH(J - 1, 0) }
-            WT(4);
-        }
-#else
             // Tile row J+NTR goes in flight first; then the lag work of step J-1, with this wave's share of the write-out of step
             // J-1 and the commit of tile row J-1+NTR (COMMIT_ROW) issued in the shadow of its matrix-core products.
             RawEntry pfn[PF_ITEMS];
@@ -1902,12 +1680,12 @@ __device__ __forceinline__ int factor_t(const SolveCtx& c, const gdouble* Hsrc, 
                     const bool bz = R * TB >= MCQ_BH_MAX && (R + 1) * TB <= ni - MCQ_BH_MAX;
                     if (bz) {
                         if (wl == 0) tile_row_fetch_fast<0, MK, SIG, true>(H, sig, mk, R, ni, pc, l15, l4, pfn);
-                        else if (wl == 1 || PF_WAVES == 2) tile_row_fetch_fast<1, MK, SIG, true>(H, sig, mk, R, ni, pc, l15, l4, pfn);
-                        else tile_row_fetch_fast<PF_WAVES == 2 ? 1 : 2, MK, SIG, true>(H, sig, mk, R, ni, pc, l15, l4, pfn);
+                        else if (wl == 1) tile_row_fetch_fast<1, MK, SIG, true>(H, sig, mk, R, ni, pc, l15, l4, pfn);
+                        else tile_row_fetch_fast<2, MK, SIG, true>(H, sig, mk, R, ni, pc, l15, l4, pfn);
                     } else {
                         if (wl == 0) tile_row_fetch_fast<0, MK, SIG, false>(H, sig, mk, R, ni, pc, l15, l4, pfn);
-                        else if (wl == 1 || PF_WAVES == 2) tile_row_fetch_fast<1, MK, SIG, false>(H, sig, mk, R, ni, pc, l15, l4, pfn);
-                        else tile_row_fetch_fast<PF_WAVES == 2 ? 1 : 2, MK, SIG, false>(H, sig, mk, R, ni, pc, l15, l4, pfn);
+                        else if (wl == 1) tile_row_fetch_fast<1, MK, SIG, false>(H, sig, mk, R, ni, pc, l15, l4, pfn);
+                        else tile_row_fetch_fast<2, MK, SIG, false>(H, sig, mk, R, ni, pc, l15, l4, pfn);
                     }
                 } else {
 #pragma unroll
@@ -1921,7 +1699,6 @@ __device__ __forceinline__ int factor_t(const SolveCtx& c, const gdouble* Hsrc, 
             for (int u = 0; u < PF_ITEMS; ++u) pf[u] = pfn[u];
             WT(5);
         }
-#endif
         lds_barrier();
         WT(6);
         c.tk[4] += FTICK() - tp; tp = FTICK();
@@ -2684,6 +2461,7 @@ __device__ __noinline__ int ipm(SolveCtx& c, const McqBatch& B, bool with_kappa,
     // it carries is the residual of the banded solve.  Convergence is only declared on an exactly recomputed gradient.
     // On entry G holds the exact gradient at the box centre (computed by the caller for the scaling).
     bool g_exact = true;
+    double mu_first = 0.0;
     for (int it = 1; it <= B.max_ipm_iter; ++it) {
         // ---- residuals: g = H x + f;  with kappa also r, rho and the dual residual needs E'(yu - yl) ---------------------
         if (with_kappa) {
@@ -2719,6 +2497,7 @@ __device__ __noinline__ int ipm(SolveCtx& c, const McqBatch& B, bool with_kappa,
             g_exact = true;
         }
         iters = it;
+        if (it == 1) mu_first = mu;
 
         // ---- factorisation of the reduced system ---------------------------------------------------------------------
         int fs;
@@ -2729,6 +2508,13 @@ __device__ __noinline__ int ipm(SolveCtx& c, const McqBatch& B, bool with_kappa,
             gram_bordered(c.w.Et, EDA, c.d, nm, nullptr, c.w.H, tid, MCQ_NT);
             __syncthreads();
             fs = timed_factor(c, c.w.H, SIG, any_fixed ? ST : nullptr);
+            // With many curvature rows close to their bound the weights y / t reach 1e10 and more near the end; the band of
+            // E' diag(1 + SK) E then carries rounding errors of that size against eigenvalues of order one, and the Cholesky can
+            // meet a non-positive pivot although the matrix is positive definite (round 3: a 360-point stadium with 134 active
+            // rows).  Late in the path -- the complementarity is down by 1e-6 from where it started -- that is no reason to give
+            // up: the pairs of the last completed iteration identify the working set, and the exact active-set phase that follows
+            // does not form this matrix.
+            if (fs == MCQ_NOT_PD && mu < 1e-6 * mu_first) return MCQ_OK;
         } else {
             fs = timed_factor(c, c.w.H, SIG, any_fixed ? ST : nullptr);
         }
@@ -3126,64 +2912,115 @@ __device__ __forceinline__ double erow_dot(const SolveCtx& c, int k, const gdoub
     return acc;
 }
 
-// ---- curvature rows of the working set: the Schur complement  S = E_K M^-1 E_K'  (nk x nk, nk <= MCQ_KMAX) ------------------------
-// S lives in HBM (row-major, leading dimension MCQ_KMAX, behind the scratch vector of McqWork.Z); for the elimination it is
-// brought into the LDS overlay (free between two triangular solves), factored there by all 256 threads -- LU with partial
-// pivoting: S is symmetric positive definite when the active rows are independent on the free set, pivoting keeps a nearly
-// dependent working set from blowing up -- and written back, so that later right-hand sides (the refinement) reuse the factors.
-__device__ void kappa_lu_factor(gdouble* SG, int nk)
+// ---- curvature rows of the working set: the Schur complement  S = E_K M^-1 E_K'  (nk x nk) --------------------------------------
+// Where the working set's arrays live (KappaMem).  Up to MCQ_KMAX rows -- every case the reference's tracks produce -- the index /
+// sign / pivot lists and the three nk-vectors sit in LDS, S in HBM behind the scratch vector of McqWork.Z (row-major, leading
+// dimension MCQ_KMAX) and its LU factorisation with partial pivoting runs on a copy in the LDS overlay, all 256 threads on the
+// rank-1 updates (S is SPD for independent rows; pivoting keeps a nearly dependent working set from blowing up).  Beyond that
+// (round 3: quadprog has no such limit) the problem claims one of the handle's overflow slots (McqBatch::kbig, MCQ_KBIG rows): every
+// array in HBM, the elimination in place in HBM -- slow, rare, exact.
+struct KappaMem {
+    double* kmu;     // multipliers / solution of the Schur system
+    double* krh;     // its right-hand side
+    double* mul;     // elimination multipliers of the current column
+    int* ki;         // ki[0] = nk, ki[1 + q] = row, ki[1 + cap + q] = sign
+    int* piv;        // pivot rows
+    gdouble* sg;     // S / its factors, row-major
+    int cap, ld;     // rows the arrays hold, leading dimension of sg
+    bool in_lds;     // S is factored on a copy in the LDS overlay
+};
+__device__ __forceinline__ KappaMem kappa_mem_lds(const SolveCtx& c)
+{
+    KappaMem k;
+    k.kmu = g_sm + SM_KV;
+    k.krh = g_sm + SM_KV + MCQ_KMAX;
+    k.mul = g_sm + SM_KV + 2 * MCQ_KMAX;
+    k.ki = (int*)(g_sm + SM_KI);
+    k.piv = (int*)(g_sm + SM_KI) + 1 + 2 * MCQ_KMAX;
+    k.sg = c.w.Z + c.nm;
+    k.cap = MCQ_KMAX;
+    k.ld = MCQ_KMAX;
+    k.in_lds = true;
+    return k;
+}
+__device__ __forceinline__ KappaMem kappa_mem_slot(double* slot)
+{
+    KappaMem k;
+    k.sg = (gdouble*)slot;
+    double* v = slot + (size_t)MCQ_KBIG * MCQ_KBIG;
+    k.kmu = v;
+    k.krh = v + MCQ_KBIG;
+    k.mul = v + 2 * MCQ_KBIG;
+    k.ki = (int*)(v + 3 * MCQ_KBIG);                 // 1 + 2 KBIG ints
+    k.piv = k.ki + 2 + 2 * MCQ_KBIG;                // KBIG ints
+    k.cap = MCQ_KBIG;
+    k.ld = MCQ_KBIG;
+    k.in_lds = false;
+    return k;
+}
+
+// LU with partial pivoting of S (nk x nk, leading dimension ld) in place; A: where the elimination runs (the LDS copy, leading
+// dimension nk, or S itself)
+template <typename PA>
+__device__ __forceinline__ void kappa_lu_eliminate(PA A, int lda, int nk, double* mul, int* piv)
 {
     const int tid = threadIdx.x;
-    double* A = g_sm + SM_OVL;                       // nk x nk, leading dimension nk
-    double* mul = g_sm + SM_KV + 2 * MCQ_KMAX;       // multipliers of the current column
-    int* piv = (int*)(g_sm + SM_KI) + 1 + 2 * MCQ_KMAX;
-    __syncthreads();
-    for (int e = tid; e < nk * nk; e += MCQ_NT) A[e] = SG[(size_t)(e / nk) * MCQ_KMAX + (e % nk)];
-    __syncthreads();
+    double* red = g_sm + SM_RED;
     for (int cidx = 0; cidx < nk; ++cidx) {
-        if (tid == 0) {
-            int pr = cidx;
-            for (int r = cidx + 1; r < nk; ++r)
-                if (fabs(A[r * nk + cidx]) > fabs(A[pr * nk + cidx])) pr = r;
-            piv[cidx] = pr;
+        // pivot row: largest magnitude of the column below the diagonal (block-wide argmax; ties to the lowest row, as a serial scan)
+        double best = -1.0;
+        int brow = cidx;
+        for (int r = cidx + tid; r < nk; r += MCQ_NT) {
+            const double v = fabs(A[(size_t)r * lda + cidx]);
+            if (v > best) { best = v; brow = r; }
         }
-        __syncthreads();
-        const int pr = piv[cidx];
+        const double bmax = block_reduce_(best, 2, red);
+        double cand = (best == bmax && best >= 0.0) ? (double)brow : 1e300;
+        cand = block_reduce_(cand, 1, red);
+        const int pr = cand < 1e299 ? (int)cand : cidx;
+        if (tid == 0) piv[cidx] = pr;
         if (pr != cidx)
             for (int cc = tid; cc < nk; cc += MCQ_NT) {
-                const double t = A[cidx * nk + cc];
-                A[cidx * nk + cc] = A[pr * nk + cc];
-                A[pr * nk + cc] = t;
+                const double t = A[(size_t)cidx * lda + cc];
+                A[(size_t)cidx * lda + cc] = A[(size_t)pr * lda + cc];
+                A[(size_t)pr * lda + cc] = t;
             }
         __syncthreads();
-        const double pv = A[cidx * nk + cidx];
-        for (int r = cidx + 1 + tid; r < nk; r += MCQ_NT) mul[r] = pv != 0.0 ? A[r * nk + cidx] / pv : 0.0;
+        const double pv = A[(size_t)cidx * lda + cidx];
+        for (int r = cidx + 1 + tid; r < nk; r += MCQ_NT) mul[r] = pv != 0.0 ? A[(size_t)r * lda + cidx] / pv : 0.0;
         __syncthreads();
         const int rem = nk - cidx - 1;
         for (int e = tid; e < rem * rem; e += MCQ_NT) {
             const int r = cidx + 1 + e / rem, cc = cidx + 1 + e % rem;
-            A[r * nk + cc] -= mul[r] * A[cidx * nk + cc];
+            A[(size_t)r * lda + cc] -= mul[r] * A[(size_t)cidx * lda + cc];
         }
         __syncthreads();
-        for (int r = cidx + 1 + tid; r < nk; r += MCQ_NT) A[r * nk + cidx] = mul[r];      // L below the diagonal
+        for (int r = cidx + 1 + tid; r < nk; r += MCQ_NT) A[(size_t)r * lda + cidx] = mul[r];      // L below the diagonal
         __syncthreads();
     }
-    for (int e = tid; e < nk * nk; e += MCQ_NT) SG[(size_t)(e / nk) * MCQ_KMAX + (e % nk)] = A[e];
+}
+
+__device__ void kappa_lu_factor(const KappaMem& K, int nk)
+{
+    const int tid = threadIdx.x;
+    __syncthreads();
+    if (K.in_lds) {
+        double* A = g_sm + SM_OVL;                       // nk x nk, leading dimension nk
+        for (int e = tid; e < nk * nk; e += MCQ_NT) A[e] = K.sg[(size_t)(e / nk) * K.ld + (e % nk)];
+        __syncthreads();
+        kappa_lu_eliminate(A, nk, nk, K.mul, K.piv);
+        for (int e = tid; e < nk * nk; e += MCQ_NT) K.sg[(size_t)(e / nk) * K.ld + (e % nk)] = A[e];
+    } else {
+        kappa_lu_eliminate(K.sg, K.ld, nk, K.mul, K.piv);
+    }
     __syncthreads();
 }
 
-// KMU <- S^-1 KRH with the factors kappa_lu_factor left in SG (row interchanges applied to the right-hand side first)
-__device__ void kappa_lu_solve(const gdouble* SG, int nk)
+// kmu <- S^-1 krh with the factors kappa_lu_factor left in sg (row interchanges applied to the right-hand side first)
+template <typename PA>
+__device__ __forceinline__ void kappa_lu_substitute(PA A, int lda, int nk, double* KMU, const int* piv)
 {
     const int tid = threadIdx.x;
-    double* A = g_sm + SM_OVL;
-    double* KMU = g_sm + SM_KV;
-    const double* KRH = g_sm + SM_KV + MCQ_KMAX;
-    const int* piv = (const int*)(g_sm + SM_KI) + 1 + 2 * MCQ_KMAX;
-    __syncthreads();
-    for (int e = tid; e < nk * nk; e += MCQ_NT) A[e] = SG[(size_t)(e / nk) * MCQ_KMAX + (e % nk)];
-    for (int q = tid; q < nk; q += MCQ_NT) KMU[q] = KRH[q];
-    __syncthreads();
     if (tid == 0)
         for (int cidx = 0; cidx < nk; ++cidx) {
             const int pr = piv[cidx];
@@ -3193,24 +3030,40 @@ __device__ void kappa_lu_solve(const gdouble* SG, int nk)
     for (int cidx = 0; cidx < nk; ++cidx) {               // L y = P b   (unit lower triangle)
         const double yc = KMU[cidx];
         __syncthreads();
-        for (int r = cidx + 1 + tid; r < nk; r += MCQ_NT) KMU[r] -= A[r * nk + cidx] * yc;
+        for (int r = cidx + 1 + tid; r < nk; r += MCQ_NT) KMU[r] -= A[(size_t)r * lda + cidx] * yc;
         __syncthreads();
     }
     for (int cidx = nk - 1; cidx >= 0; --cidx) {          // U x = y
-        if (tid == 0) { const double pv = A[cidx * nk + cidx]; KMU[cidx] = pv != 0.0 ? KMU[cidx] / pv : 0.0; }
+        if (tid == 0) { const double pv = A[(size_t)cidx * lda + cidx]; KMU[cidx] = pv != 0.0 ? KMU[cidx] / pv : 0.0; }
         __syncthreads();
         const double xc = KMU[cidx];
-        for (int r = tid; r < cidx; r += MCQ_NT) KMU[r] -= A[r * nk + cidx] * xc;
+        for (int r = tid; r < cidx; r += MCQ_NT) KMU[r] -= A[(size_t)r * lda + cidx] * xc;
         __syncthreads();
     }
 }
 
+__device__ void kappa_lu_solve(const KappaMem& K, int nk)
+{
+    const int tid = threadIdx.x;
+    __syncthreads();
+    for (int q = tid; q < nk; q += MCQ_NT) K.kmu[q] = K.krh[q];
+    if (K.in_lds) {
+        double* A = g_sm + SM_OVL;
+        for (int e = tid; e < nk * nk; e += MCQ_NT) A[e] = K.sg[(size_t)(e / nk) * K.ld + (e % nk)];
+        __syncthreads();
+        kappa_lu_substitute((const double*)A, nk, nk, K.kmu, K.piv);
+    } else {
+        __syncthreads();
+        kappa_lu_substitute((const gdouble*)K.sg, K.ld, nk, K.kmu, K.piv);
+    }
+}
+
 // v <- M^-1 (E_K' KMU restricted to the free set):  the multipliers scattered onto their rows (Q), one band product, one solve
-__device__ void kappa_apply(SolveCtx& c, int nk, gdouble* Q, gdouble* v)
+__device__ void kappa_apply(SolveCtx& c, const KappaMem& K, int nk, gdouble* Q, gdouble* v)
 {
     const int tid = threadIdx.x, n = c.d.n;
-    const double* KMU = g_sm + SM_KV;
-    const int* KI = (const int*)(g_sm + SM_KI);
+    const double* KMU = K.kmu;
+    const int* KI = K.ki;
     const gschar* ST = c.w.state;
     for (int i = tid; i < n; i += MCQ_NT) Q[i] = 0.0;
     __syncthreads();
@@ -3224,13 +3077,14 @@ __device__ void kappa_apply(SolveCtx& c, int nk, gdouble* Q, gdouble* v)
 }
 
 __device__ __noinline__ int active_set(SolveCtx& c, const McqBatch& B, bool with_kappa, bool tapia, int cap, const SolveScalars& sc, int& iters,
-                                       double& kkt, int& nk_out, bool identify = true)
+                                       double& kkt, int& nk_out, bool identify, const KappaMem& K)
 {
     const int tid = threadIdx.x, n = c.d.n, nm = c.nm;
     double* red = g_sm + SM_RED;
-    double* KMU = g_sm + SM_KV;
-    double* KRH = g_sm + SM_KV + MCQ_KMAX;
-    int* KI = (int*)(g_sm + SM_KI);        // KI[0] = nk, KI[1+q] = row, KI[1+KMAX+q] = sign
+    double* KMU = K.kmu;
+    double* KRH = K.krh;
+    int* KI = K.ki;                        // KI[0] = nk, KI[1+q] = row, KI[1+cap+q] = sign
+    const int kcap = K.cap;
     const gdouble* LO = VEC(c.w, nm, V_LO);
     const gdouble* HI = VEC(c.w, nm, V_HI);
     const gdouble* KR = VEC(c.w, nm, V_KREF);
@@ -3297,15 +3151,16 @@ __device__ __noinline__ int active_set(SolveCtx& c, const McqBatch& B, bool with
             int nk = 0;
             if (with_kappa)
                 for (int i = 0; i < n; ++i)
-                    if (KF[i] != 0.0 && nk < MCQ_KMAX + 1) {
-                        if (nk < MCQ_KMAX) { KI[1 + nk] = i; KI[1 + MCQ_KMAX + nk] = KF[i] > 0.0 ? 1 : -1; }
+                    if (KF[i] != 0.0 && nk < kcap + 1) {
+                        if (nk < kcap) { KI[1 + nk] = i; KI[1 + kcap + nk] = KF[i] > 0.0 ? 1 : -1; }
                         ++nk;
                     }
             KI[0] = nk;
         }
         __syncthreads();
         const int nk = KI[0];
-        if (nk > MCQ_KMAX) return MCQ_KAPPA_ACTIVE;      // more active curvature rows than the Schur path holds
+        if (nk > kcap) return MCQ_KAPPA_ACTIVE;          // more active curvature rows than these arrays hold (the caller may retry
+                                                         // with an overflow slot)
         nk_out = nk;
 
         for (int i = tid; i < n; i += MCQ_NT) {
@@ -3321,7 +3176,7 @@ __device__ __noinline__ int active_set(SolveCtx& c, const McqBatch& B, bool with
             // column q of S = E_K (M^-1 E_kq' restricted to the free set): one banded solve per active row, nothing but one
             // scratch vector kept (x = x0 - M^-1 E_K' mu costs one more solve afterwards instead of nk stored columns)
             gdouble* Zs = c.w.Z;
-            gdouble* SG = c.w.Z + nm;
+            gdouble* SG = K.sg;
             for (int q = 0; q < nk; ++q) {
                 const int k = KI[1 + q];
                 for (int i = tid; i < n; i += MCQ_NT) Zs[i] = 0.0;
@@ -3332,17 +3187,17 @@ __device__ __noinline__ int active_set(SolveCtx& c, const McqBatch& B, bool with
                 }
                 __syncthreads();
                 timed_solve(c, Zs);
-                for (int q2 = tid; q2 < nk; q2 += MCQ_NT) SG[(size_t)q2 * MCQ_KMAX + q] = erow_dot(c, KI[1 + q2], Zs);
+                for (int q2 = tid; q2 < nk; q2 += MCQ_NT) SG[(size_t)q2 * K.ld + q] = erow_dot(c, KI[1 + q2], Zs);
                 __syncthreads();
             }
             // rhs = E_K x0 + k_ref - s kb
             for (int q = tid; q < nk; q += MCQ_NT) {
                 const int k = KI[1 + q];
-                KRH[q] = erow_dot(c, k, RHS) + KR[k] - KI[1 + MCQ_KMAX + q] * kb;
+                KRH[q] = erow_dot(c, k, RHS) + KR[k] - KI[1 + kcap + q] * kb;
             }
-            kappa_lu_factor(SG, nk);
-            kappa_lu_solve(SG, nk);
-            kappa_apply(c, nk, Q, Zs);          // Q = multipliers on their rows, Zs = M^-1 E_K' mu
+            kappa_lu_factor(K, nk);
+            kappa_lu_solve(K, nk);
+            kappa_apply(c, K, nk, Q, Zs);       // Q = multipliers on their rows, Zs = M^-1 E_K' mu
             for (int i = tid; i < n; i += MCQ_NT) RHS[i] -= Zs[i];
             __syncthreads();
         }
@@ -3391,15 +3246,14 @@ __device__ __noinline__ int active_set(SolveCtx& c, const McqBatch& B, bool with
                     // curvature rows in the working set: one step on the KKT system [M E_K'; E_K 0] through the factored Schur
                     // complement -- dx0 = M^-1(-g), S dmu = E_K dx0 + (E_K x + k_ref - s kb), dx = dx0 - M^-1 E_K' dmu
                     gdouble* Zs = c.w.Z;
-                    const gdouble* SG = c.w.Z + nm;
                     for (int q = tid; q < nk; q += MCQ_NT) {
                         const int k = KI[1 + q];
-                        KRH[q] = erow_dot(c, k, RHS) + T2[k] - KI[1 + MCQ_KMAX + q] * kb;
+                        KRH[q] = erow_dot(c, k, RHS) + T2[k] - KI[1 + kcap + q] * kb;
                     }
-                    kappa_lu_solve(SG, nk);
+                    kappa_lu_solve(K, nk);
                     for (int q = tid; q < nk; q += MCQ_NT) KRH[q] = KMU[q];       // dmu (kappa_apply reads KMU, Q is rebuilt below)
                     __syncthreads();
-                    kappa_apply(c, nk, T1, Zs);
+                    kappa_apply(c, K, nk, T1, Zs);
                     for (int i = tid; i < n; i += MCQ_NT) RHS[i] -= Zs[i];
                     __syncthreads();
                     for (int q = tid; q < nk; q += MCQ_NT) Q[KI[1 + q]] += KRH[q];
@@ -3527,7 +3381,7 @@ __global__ void __launch_bounds__(MCQ_NT) mcq_solve_kernel(McqBatch B)
             if (ST[i] == 0) { const signed char s = WS[i]; ST[i] = (s == 1 || s == -1) ? s : (signed char)0; }
         __syncthreads();
         const int capw = B.max_as_iter < MCQ_WARM_ROUNDS ? B.max_as_iter : MCQ_WARM_ROUNDS;
-        const int sw = active_set(c, B, false, false, capw, sc, as_iters, kkt, nk_dummy, false);
+        const int sw = active_set(c, B, false, false, capw, sc, as_iters, kkt, nk_dummy, false, kappa_mem_lds(c));
         if (sw == MCQ_OK) warm_done = true;
         else {
             c.second_attempt = 2;       // reported: warm start abandoned
@@ -3553,7 +3407,7 @@ __global__ void __launch_bounds__(MCQ_NT) mcq_solve_kernel(McqBatch B)
         gdouble* XS = VEC(c.w, nm, V_TL);
         for (int i = tid; i < n; i += MCQ_NT) XS[i] = X[i];
         const int cap1 = B.max_as_iter < 6 ? B.max_as_iter : 6;
-        status = active_set(c, B, false, ipm_iters >= 1 && c.last_step >= 0.9, cap1, sc, as_iters, kkt, nk_dummy);
+        status = active_set(c, B, false, ipm_iters >= 1 && c.last_step >= 0.9, cap1, sc, as_iters, kkt, nk_dummy, true, kappa_mem_lds(c));
         if (status == MCQ_ITER_CAP && B.max_as_iter > cap1) {
             c.second_attempt |= 1;
             for (int i = tid; i < n; i += MCQ_NT) X[i] = XS[i];
@@ -3561,11 +3415,11 @@ __global__ void __launch_bounds__(MCQ_NT) mcq_solve_kernel(McqBatch B)
             int it_more = 0, as_more = 0;
             status = ipm_box(c, B, sc, it_more, 1e-13, true);
             ipm_iters += it_more;
-            if (status == MCQ_OK) status = active_set(c, B, false, false, B.max_as_iter, sc, as_more, kkt, nk_dummy);
+            if (status == MCQ_OK) status = active_set(c, B, false, false, B.max_as_iter, sc, as_more, kkt, nk_dummy, true, kappa_mem_lds(c));
             as_iters += as_more;
         }
     } else if (status == MCQ_OK) {
-        status = active_set(c, B, false, ipm_iters >= 1 && c.last_step >= 0.9, B.max_as_iter, sc, as_iters, kkt, nk_dummy);
+        status = active_set(c, B, false, ipm_iters >= 1 && c.last_step >= 0.9, B.max_as_iter, sc, as_iters, kkt, nk_dummy, true, kappa_mem_lds(c));
     }
     as_iters += as_warm;        // rounds of an abandoned warm start are reported too
 
@@ -3589,8 +3443,25 @@ __global__ void __launch_bounds__(MCQ_NT) mcq_solve_kernel(McqBatch B)
         gram_bordered(c.w.Et, nullptr, c.d, nm, nullptr, c.w.H, tid, MCQ_NT);     // restore H = E'E
         __syncthreads();
         if (status == MCQ_OK) {
-            status = active_set(c, B, true, false, B.max_as_iter, sc, it2, kkt, nact_kappa);
+            status = active_set(c, B, true, false, B.max_as_iter, sc, it2, kkt, nact_kappa, true, kappa_mem_lds(c));
             as_iters += it2;
+            if (status == MCQ_KAPPA_ACTIVE && B.kbig && B.kbig_slots > 0) {
+                // More curvature rows in the working set than the LDS-resident arrays hold (MCQ_KMAX): quadprog has no such limit
+                // [REF params/racecar.ini:49 curvlim].  The problem claims one of the handle's overflow slots -- MCQ_KBIG rows, the
+                // Schur matrix and its elimination in HBM -- and the exchange goes on from the box working set the first
+                // attempt left (its curvature flags are rebuilt from the interior point's pairs).  No
+                // slot free (more than kbig_slots such problems in one launch): the status stays MCQ_KAPPA_ACTIVE.
+                int* sslot = (int*)(g_sm + SM_RED);
+                if (tid == 0) sslot[0] = atomicAdd(B.kbig_count, 1);
+                __syncthreads();
+                const int slot = sslot[0];
+                __syncthreads();
+                if (slot < B.kbig_slots) {
+                    status = active_set(c, B, true, false, B.max_as_iter, sc, it2, kkt, nact_kappa, false,
+                                        kappa_mem_slot(B.kbig + (size_t)slot * MCQ_KBIG_SLOT));
+                    as_iters += it2;
+                }
+            }
         }
         for (int i = tid; i < n; i += MCQ_NT) X[i] = fmin(fmax(X[i], LO[i]), HI[i]);
         __syncthreads();
@@ -3891,7 +3762,7 @@ __global__ void __launch_bounds__(256) mcq_iqp_step_kernel(McqIqpStep S)
     } else {
         if (S.live[k] != 0 && S.relin_status[k] != MCQ_OK) {      // the re-sampled ring does not fit the buffers
             S.live[k] = 0;
-            S.final_status[k] = MCQ_BAD_INPUT;
+            S.final_status[k] = MCQ_RING_OVERFLOW;
             atomicAdd(S.live_count, -1);
         }
         if (S.live[k] == 0) S.n_next[k] = 0;

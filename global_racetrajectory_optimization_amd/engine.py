@@ -18,7 +18,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 DEFAULT_LIB = os.path.join(_HERE, "csrc", "libmcq.so")
 
 STATUS_OK, STATUS_INFEASIBLE, STATUS_NOT_PD, STATUS_ITER_CAP, STATUS_BAD_INPUT, STATUS_KAPPA_INFEASIBLE, \
-    STATUS_KAPPA_ACTIVE = range(7)
+    STATUS_KAPPA_ACTIVE, STATUS_RING_OVERFLOW = range(8)
 
 _dp = ctypes.POINTER(ctypes.c_double)
 _ip = ctypes.POINTER(ctypes.c_int)
@@ -424,7 +424,9 @@ class Engine:
                 lengths = np.sqrt(np.einsum("bnk,bnk->bn", seg, seg)).sum(axis=1)
             else:
                 lengths = np.array([np.hypot(np.diff(r[:, 0], append=r[0, 0]), np.diff(r[:, 1], append=r[0, 1])).sum() for r in refs])
-            nmax = max(max(r.shape[0] for r in refs), int(np.ceil(1.3 * float(lengths.max()) / stepsize_interp)) + 16)
+            finite = lengths[np.isfinite(lengths)]          # (a track with non-finite rows is reported by the engine: status 4)
+            longest = float(finite.max()) if finite.size else 0.0
+            nmax = max(max(r.shape[0] for r in refs), int(np.ceil(1.3 * longest / stepsize_interp)) + 16)
         arr = (McqProblem * bsz)()
         for k in range(bsz):
             n = refs[k].shape[0]

@@ -47,12 +47,16 @@ def _iqp_batch_device(eng, tracks, kappa_bound, w_veh, stepsize_interp, iters_mi
                         timed=bool(stats is not None and stats.get("timed")), warm_start=0 if warm_start else -1)
     for k in range(len(tracks)):
         if print_debug:
+            # (the engine runs the whole loop as one call: the per-round lines upstream prints as it goes come out together here)
             for it in range(int(out["rounds"][k])):
                 if it < out["curv_trace"].shape[1]:
                     print("Minimum curvature IQP: iteration %i, curv_error_max: %.4frad/m" % (it + 1, out["curv_trace"][k, it]))
+            if int(out["rounds"][k]) > out["curv_trace"].shape[1]:
+                print("Minimum curvature IQP: ... %d more iterations (the engine records the first %d)"
+                      % (int(out["rounds"][k]) - out["curv_trace"].shape[1], out["curv_trace"].shape[1]))
         if int(out["status"][k]) == _engine.STATUS_ITER_CAP and int(out["rounds"][k]) >= max_rounds:
             raise RuntimeError("iqp_handler: no convergence within %d rounds" % max_rounds)
-        if int(out["status"][k]) == _engine.STATUS_BAD_INPUT and int(out["rounds"][k]) >= 1 and out["n"][k] >= 3:
+        if int(out["status"][k]) == _engine.STATUS_RING_OVERFLOW:
             raise RuntimeError("iqp_handler: re-sampled raceline of track %d does not fit the device buffers "
                                "(nmax = %d)" % (k, out["stats"]["nmax"]))
         _omc.raise_for_status(int(out["status"][k]))

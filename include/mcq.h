@@ -46,8 +46,11 @@ enum {
     MCQ_ITER_CAP = 3,        /* iteration cap hit */
     MCQ_BAD_INPUT = 4,       /* n < 3, non-finite input */
     MCQ_KAPPA_INFEASIBLE = 5, /* curvature rows cannot be satisfied -> quadprog raises ValueError("constraints are inconsistent, no solution") */
-    MCQ_KAPPA_ACTIVE = 6      /* box-only optimum violates a curvature row and the curvature-row phase is disabled (check_kappa < 0) /
-                               * failed */
+    MCQ_KAPPA_ACTIVE = 6,     /* box-only optimum violates a curvature row and the curvature-row phase is disabled (check_kappa < 0); or
+                               * more curvature rows are active than the engine carries: up to 120 in LDS, up to 512 through one of
+                               * the handle's 8 overflow slots per launch (round 3) -- beyond either, this status */
+    MCQ_RING_OVERFLOW = 7     /* mcq_iqp_device / mcq_iqp_batch only: the re-sampled raceline of an IQP round needs more waypoints than
+                               * the buffers hold (nmax / nmax_out) -- not an input error of the QP (that stays MCQ_BAD_INPUT) */
 };
 
 /* library-level error codes (negative return values) */
@@ -198,7 +201,7 @@ int mcq_normals_crossing_device(mcq_handle* h, int batch, int nmax, const int* n
  * (tph.interp_track_widths); unit normals of the closed spline through the re-sampled ring
  * (tph.calc_splines(use_dist_scaling=False)).  All pointers DEVICE pointers, arrays strided by nmax; `live` [batch] or
  * NULL selects the tracks to process; n_out [batch] receives the new waypoint counts; status_out [batch] MCQ_OK or
- * MCQ_BAD_INPUT (new ring would have < 3 or > nmax points).  Input and output buffers must differ.  Asynchronous on
+ * MCQ_BAD_INPUT (new ring would have < 3 or > nmax points; the IQP loop reports that as MCQ_RING_OVERFLOW).  Input and output buffers must differ.  Asynchronous on
  * the handle's stream.  Side effect inside the handle: the working sets the preceding solve left for these tracks are carried to
  * the re-sampled rings (new point -> nearer end of its old segment), for mcq_opts.warm_start of the next pass. */
 int mcq_relinearise_device(mcq_handle* h, int batch, int nmax, const int* n_in, const double* reftrack_in,
@@ -273,7 +276,8 @@ int mcq_solve_host_pipelined(mcq_handle* h, int steps, int batch, int n, const d
  * iters_min > the rounds run, as upstream), n_io = waypoint counts of the last re-linearisation, buf_out [batch] = 0 / 1: which
  * set holds a track's final reftrack / normvectors, curv_err_out / status_out / rounds_out [batch]; curv_trace_out
  * [batch][MCQ_IQP_TRACE] (optional) = curv_error_max of every round of a track (what iqp_handler prints with print_debug;
- * rounds beyond MCQ_IQP_TRACE are not recorded).  stats (optional, host): see mcq_iqp_stats.  Blocking (the loop needs the
+ * rounds beyond MCQ_IQP_TRACE are not recorded: rounds_out tells when the trace is truncated).  A track with n_io == 0 on entry is
+ * not a track: it never runs (status MCQ_BAD_INPUT from its first, empty pass, rounds_out 1).  stats (optional, host): see mcq_iqp_stats.  Blocking (the loop needs the
  * live count). */
 #define MCQ_IQP_TRACE 16
 typedef struct {

@@ -575,3 +575,71 @@ def test_solve_host_pipelined_equals_solve_host(emu, golden):
         assert np.array_equal(al, outs[k]) and np.array_equal(cu, curv[k]) and list(s1) == [0, 0], k
     with pytest.raises(ValueError):
         emu.solve_host(refs[0], nvs[0], scs[0], 0.12, 3.4, alpha_out=np.zeros((2, n), dtype=np.float32))
+
+
+def _stadium(n, ls=120.0, r=40.0):
+    """Two straights and two semicircles, n points equidistant in arclength (counter-clockwise)."""
+    per = 2 * ls + 2 * np.pi * r
+    xy = np.zeros((n, 2))
+    for k, sk in enumerate(np.linspace(0.0, per, n, endpoint=False)):
+        if sk < ls:
+            xy[k] = (sk - ls / 2, -r)
+        elif sk < ls + np.pi * r:
+            th = (sk - ls) / r - np.pi / 2
+            xy[k] = (ls / 2 + r * np.cos(th), r * np.sin(th))
+        elif sk < 2 * ls + np.pi * r:
+            xy[k] = (ls / 2 - (sk - ls - np.pi * r), r)
+        else:
+            th = (sk - 2 * ls - np.pi * r) / r + np.pi / 2
+            xy[k] = (-ls / 2 + r * np.cos(th), r * np.sin(th))
+    return xy
+
+
+def stadium_problem(n=360, kappa_bound=0.0223):
+    """A case quadprog solves and rounds 1-2 of the engine did not: on the two long arcs of a stadium the
+    curvature of the optimal line sits on a plateau, and a bound just below it puts MORE curvature rows into the working set than
+    the LDS-resident Schur path holds (MCQ_KMAX = 120): 134 at n = 360."""
+    xy = _stadium(n)
+    _, _, A, nv = tph_ref.calc_splines(np.vstack((xy, xy[0])))
+    ref = np.column_stack((xy, np.full((n, 2), 4.0)))
+    idx = np.arange(n - 1)
+    sc = np.empty(n)
+    sc[:-1] = -A[4 * idx + 2, 4 * idx + 5]
+    sc[-1] = A[4 * n - 2, 1]
+    return ref, nv, A, sc, kappa_bound
+
+
+def test_more_curvature_rows_than_the_lds_path_holds(emu):
+    """134 active curvature rows (> MCQ_KMAX): the problem claims an overflow slot of the handle -- Schur matrix and its pivoted LU in
+    HBM -- and returns the dense Goldfarb-Idnani vertex with status 0 (it was MCQ_KAPPA_ACTIVE until round 3; before that the
+    curvature-row interior point gave up with a rounding-induced non-positive pivot near the end of its path)."""
+    from oracle import qp_ref
+    ref, nv, A, sc, kb = stadium_problem()
+    n = ref.shape[0]
+    info = {}
+    a_ref, err_ref = tph_ref.opt_min_curv(ref, nv, A, kb, 2.0, solver=lambda H, f, G, h: qp_ref.solve_qp_gi(H, f, G, h, info))
+    nk = int(np.sum(info["lagr"][2 * n:] > 0))
+    assert nk > 120
+    al, curv, st, inf = emu.solve_batch([dict(reftrack=ref, normvec=nv, scaling=sc, kappa_bound=kb, w_veh=2.0)])
+    assert st[0] == 0
+    assert inf[0]["n_active_kappa"] == nk
+    assert np.max(np.abs(al[0] - a_ref)) < 1e-7
+    assert abs(curv[0] - err_ref) < 1e-9
+    assert abs(inf[0]["kappa_max"] - kb) < 1e-9
+
+
+def test_iqp_ring_overflow_has_its_own_status(emu, golden):
+    """a re-sampled raceline that outgrows the caller's buffers is MCQ_RING_OVERFLOW (7), not the MCQ_BAD_INPUT a
+    non-finite input row gets -- and the drop-in raises the message that names the buffers only for the former."""
+    from global_racetrajectory_optimization_amd import trajectory_planning_helpers as tph
+    g = golden["rounded_rectangle"]
+    n = g["reftrack"].shape[0]
+    trk = dict(reftrack=g["reftrack"].copy(), normvectors=g["normvec"], scaling=g["scaling"])
+    out = emu.iqp_batch([trk], 0.12, 3.4, 1.5, iters_min=3, curv_error_allowed=0.01, nmax=n + 8)       # step 1.5 m: ~2 n points
+    assert out["status"][0] == engine.STATUS_RING_OVERFLOW and out["rounds"][0] == 1
+    bad = dict(trk, reftrack=g["reftrack"].copy())
+    bad["reftrack"][3, 0] = np.nan
+    out2 = emu.iqp_batch([bad], 0.12, 3.4, 3.0, iters_min=3, curv_error_allowed=0.01)
+    assert out2["status"][0] == engine.STATUS_BAD_INPUT
+    with pytest.raises(RuntimeError, match="non-finite input"):
+        tph.iqp_handler.iqp_handler_batch([bad], 0.12, 3.4, 3.0, 3, 0.01, engine=emu)

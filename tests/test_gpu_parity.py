@@ -921,3 +921,31 @@ def test_bench_force_collective_initialises_rccl():
     assert c["collective"] == "1 all-gather of alpha per step" and c["ranks_seen"] == 1 and rec["n_gpus"] == 1
     assert c["allgather_ms"] is not None and np.isfinite(c["allgather_ms"]) and 0.0 < c["allgather_ms"] < 50.0
     assert c["failed_problems"] == 0 and rec["value"] > 0
+
+
+def test_curvature_row_overflow_slots_against_dense_gi(gpu_engine):
+    """quadprog carries any number of active curvature rows [REF params/racecar.ini:49 curvlim]; the engine's
+    LDS-resident Schur path holds MCQ_KMAX = 120.  Stadium tracks whose optimal line has its curvature on a plateau, bound just
+    below it: 134 rows at n = 360 and about twice that at n = 720, plus three copies in one launch (each claims its own overflow
+    slot) next to an ordinary problem -- all against the dense Goldfarb-Idnani oracle with all 4N rows."""
+    from oracle import qp_ref, tph_ref
+    from test_emu_kernels import stadium_problem
+    probs, want = [], []
+    for n, kb in ((360, 0.0223), (720, 0.0223)):
+        ref, nv, A, sc, kb = stadium_problem(n, kb)
+        info = {}
+        a_ref, err_ref = tph_ref.opt_min_curv(ref, nv, A, kb, 2.0, solver=lambda H, f, G, h: qp_ref.solve_qp_gi(H, f, G, h, info))
+        nk = int(np.sum(info["lagr"][2 * n:] > 0))
+        for _ in range(3 if n == 360 else 1):
+            probs.append(dict(reftrack=ref, normvec=nv, scaling=sc, kappa_bound=kb, w_veh=2.0))
+            want.append((a_ref, err_ref, nk))
+    assert want[0][2] > 120 and want[-1][2] > 200
+    al, curv, st, info = gpu_engine.solve_batch(probs)
+    for k, (a_ref, err_ref, nk) in enumerate(want):
+        assert st[k] == 0, (k, st[k])
+        assert info[k]["n_active_kappa"] == nk, (k, info[k]["n_active_kappa"], nk)
+        assert np.max(np.abs(al[k] - a_ref)) < ALPHA_TOL, (k, float(np.max(np.abs(al[k] - a_ref))))
+        assert abs(curv[k] - err_ref) < CURV_TOL
+    print("curvature-row overflow: %s active rows, max |alpha - dense GI| = %.2e m"
+          % ([w[2] for w in want], max(float(np.max(np.abs(al[k] - w[0]))) for k, w in enumerate(want))))
+
