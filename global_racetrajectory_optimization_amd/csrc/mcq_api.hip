@@ -922,16 +922,28 @@ extern "C" int mcq_solve_host_pipelined(mcq_handle* h, int steps, int batch, int
     double* s_al[2] = {h->d_alpha, h->p_alpha};
     double* s_cu[2] = {h->d_curv, h->p_curv};
     int* s_st[2] = {h->d_status, h->p_status};
-    for (int k = 0; k < steps; ++k) {
+    // Order of the host's enqueues: upload(0); then per step  kernels(k), upload(k + 1), download(k).  The copies of both directions
+    // drain through one in-order copy queue of the runtime (rocprofv3 --memory-copy-trace, round 3: with download(k) enqueued ahead
+    // of upload(k + 1) the upload sat behind it, i.e. behind the kernels of step k, and nothing overlapped): the upload of the NEXT
+    // step therefore goes in first -- it only depends on kernels two steps back -- and runs while step k computes.
+    auto upload = [&](int k) -> int {
         const int s = k & 1;
         const double* nv_k = normvec ? normvec[k] : nullptr;
         const double* sc_k = scaling ? scaling[k] : nullptr;
-        // upload of step k into slot s: the kernels of step k - 2 were the last readers of that slot's rows
+        // the kernels of step k - 2 were the last readers of this slot's rows
         if (k >= 2) HIP_TRY_PIPE(hipStreamWaitEvent(h->cs_in, h->ev_done[s], 0));
         HIP_TRY_PIPE(hipMemcpyAsync(s_ref[s], reftrack[k], elems * 4 * sizeof(double), hipMemcpyHostToDevice, h->cs_in));
         if (nv_k) HIP_TRY_PIPE(hipMemcpyAsync(s_nv[s], nv_k, elems * 2 * sizeof(double), hipMemcpyHostToDevice, h->cs_in));
         if (sc_k) HIP_TRY_PIPE(hipMemcpyAsync(s_sc[s], sc_k, elems * sizeof(double), hipMemcpyHostToDevice, h->cs_in));
         HIP_TRY_PIPE(hipEventRecord(h->ev_up[s], h->cs_in));
+        return 0;
+    };
+    rc = upload(0);
+    if (rc) return rc;
+    for (int k = 0; k < steps; ++k) {
+        const int s = k & 1;
+        const double* nv_k = normvec ? normvec[k] : nullptr;
+        const double* sc_k = scaling ? scaling[k] : nullptr;
         // kernels of step k: after its upload, and after the download of step k - 2 has left the slot's result buffers
         HIP_TRY_PIPE(hipStreamWaitEvent(h->stream, h->ev_up[s], 0));
         if (k >= 2) HIP_TRY_PIPE(hipStreamWaitEvent(h->stream, h->ev_down[s], 0));
@@ -951,6 +963,7 @@ extern "C" int mcq_solve_host_pipelined(mcq_handle* h, int steps, int batch, int
         rc = launch(h, B, o);
         if (rc) { (void)hipStreamSynchronize(h->cs_in); (void)hipStreamSynchronize(h->stream); (void)hipStreamSynchronize(h->cs_out); return rc; }
         HIP_TRY_PIPE(hipEventRecord(h->ev_done[s], h->stream));
+        if (k + 1 < steps) { rc = upload(k + 1); if (rc) return rc; }
         // download of step k
         HIP_TRY_PIPE(hipStreamWaitEvent(h->cs_out, h->ev_done[s], 0));
         HIP_TRY_PIPE(hipMemcpyAsync(alpha_out[k], s_al[s], elems * sizeof(double), hipMemcpyDeviceToHost, h->cs_out));

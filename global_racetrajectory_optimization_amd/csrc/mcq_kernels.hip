@@ -210,6 +210,14 @@ __device__ __forceinline__ double row4_sum_low16(double x)
     return y + __hiloint2double((int)b1[1], (int)b0[1]);                      // lanes 0..15: + lane 16 above
 }
 
+// D(16x16) += A(16x16) B(16x16) as four K=4 matrix-core steps; a[kc], b[kc] are the per-lane operand values
+__device__ __forceinline__ v4d mfma16(const double a[4], const double b[4], v4d acc)
+{
+#pragma unroll
+    for (int kc = 0; kc < 4; ++kc) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a[kc], b[kc], acc, 0, 0, 0);
+    return acc;
+}
+
 // dst_i = sum_{o=-bl..br} Mb[(bl+o) * nm + i] * src[(i+o) mod n] + addc * add_i
 // Diagonal-major (DIA) band: thread per row, every load of a wave is one contiguous 512-byte segment, no reductions.
 // Loads are issued in batches of MV_RU diagonals (three batches cover the 65/66-wide bands): with one wave per SIMD the
@@ -652,6 +660,9 @@ __device__ __forceinline__ bool gram_all_rows(const McqDims& d)
 
 // Entries k == G (mod 4) of one row of the band of H for mcq_gram_tile_kernel: k is a literal, so every LDS offset is an
 // immediate and only the 65 - k products that exist are formed.  a[o] = E'[o][row]; sc = tile base + row.
+#ifndef MCQ_GRAM_MFMA
+#define MCQ_GRAM_MFMA 1     /* 1: the tile kernel forms H = E'E on the fp64 matrix cores; 0: rounds 1-2's register-column / LDS form */
+#endif
 template <int G>
 __device__ __forceinline__ void gram_tile_class(const double* a, const double* sc, double* res)
 {
@@ -720,6 +731,68 @@ __global__ void __launch_bounds__(MCQ_NT) mcq_gram_tile_kernel(McqBatch B)
         }
     }
     __syncthreads();
+#if MCQ_GRAM_MFMA
+    // ---- H = E'E on the fp64 matrix cores (round 3; what BASELINE's north_star asks the matrix cores for) ---------------------------
+    // The 64 rows of the tile are four 16-column blocks of E, one per wave (a); with E(Q, blk) the 16 x 16 block of E in row block Q
+    // and column block blk,  H(a, a+d) = sum_Q E(Q, a)' E(Q, a+d),  d = 0..4, over the row blocks that meet both bands (5 - d of
+    // them).  The operands come straight from the diagonal-major staging: lane (l15, l4) of P(blk, t) holds
+    //     E[16 blk - 32 + 16 t + l4 + 4 kc,  16 blk + l15]  =  S[o][16 blk + l15],   o = 16 t + l4 + 4 kc - l15   (0 outside 0..64)
+    // -- the same lane layout serves as the A operand (i = l15, k = l4 + 4 kc) of block a and as the B operand (k, n = l15) of block
+    // a+d; consecutive lanes read consecutive banks (stride 127 doubles).  15 tile products = 60 v_mfma_f64_16x16x4_f64 per wave
+    // where 560 FMAs + 560 LDS reads per THREAD were.
+    const int lane = tid & 63, l15 = lane & 15, l4 = lane >> 4;
+    const int a = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int r = tid & (GT_ROWS - 1);
+    if (all && tid < GT_ROWS && i0 + tid < n) {      // f = F_SCALE E' k_ref from the staged columns (wave 0, 65 terms per row)
+        double acc0 = 0.0, acc1 = 0.0;
+#pragma unroll 5
+        for (int o = 0; o + 1 < NO; o += 2) { acc0 += S[o * NC + tid] * KS[tid + o]; acc1 += S[(o + 1) * NC + tid] * KS[tid + o + 1]; }
+        acc0 += S[(NO - 1) * NC + tid] * KS[tid + NO - 1];
+        VEC(w, nm, V_F)[i0 + tid] = MCQ_F_SCALE * (acc0 + acc1);
+    }
+    v4d hacc[5];
+    {
+        double pa[5][4];
+#pragma unroll
+        for (int t = 0; t < 5; ++t) {
+#pragma unroll
+            for (int kc = 0; kc < 4; ++kc) {
+                const int o = 16 * t + l4 + 4 * kc - l15;
+                const double v = S[(o >= 0 && o < NO ? o : 0) * NC + 16 * a + l15];
+                pa[t][kc] = (o >= 0 && o < NO) ? v : 0.0;
+            }
+        }
+#pragma unroll
+        for (int dd = 0; dd < 5; ++dd) {
+            v4d acc = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+            for (int t = dd; t < 5; ++t) {
+                double pb[4];
+#pragma unroll
+                for (int kc = 0; kc < 4; ++kc) {
+                    const int o = 16 * (t - dd) + l4 + 4 * kc - l15;
+                    const double v = S[(o >= 0 && o < NO ? o : 0) * NC + 16 * (a + dd) + l15];
+                    pb[kc] = (o >= 0 && o < NO) ? v : 0.0;
+                }
+                acc = mfma16(pa[t], pb, acc);
+            }
+            hacc[dd] = acc;
+        }
+    }
+    // results through LDS (the E' block is dead): rows leave as contiguous 520-byte runs instead of 8-byte pieces
+    __syncthreads();
+    const int OW = MCQ_BH_MAX + 1;
+#pragma unroll
+    for (int dd = 0; dd < 5; ++dd) {
+#pragma unroll
+        for (int rr = 0; rr < 4; ++rr) {
+            const int ii = l4 + 4 * rr, k = 16 * dd + l15 - ii;       // H[i0 + 16 a + ii, . + k]
+            if (k >= 0 && k <= MCQ_BH_MAX) S[(16 * a + ii) * OW + k] = hacc[dd][rr];
+        }
+    }
+    (void)r;
+    __syncthreads();
+#else
     const int r = tid & (GT_ROWS - 1);
     const int g = __builtin_amdgcn_readfirstlane(tid / GT_ROWS);       // wave-uniform: a scalar branch picks the k class
     double a[2 * MCQ_BE_MAX + 1];
@@ -746,6 +819,7 @@ __global__ void __launch_bounds__(MCQ_NT) mcq_gram_tile_kernel(McqBatch B)
         if (k <= MCQ_BH_MAX) S[r * OW + k] = res[m];
     }
     __syncthreads();
+#endif
     if (!all) {
         for (int q = tid; q < GT_ROWS * OW; q += MCQ_NT) {
             const int row = q / OW, k = q - row * OW;
@@ -1167,14 +1241,6 @@ __device__ __forceinline__ void tile_row_commit_fast(double* bt, double* ct, con
             crow[(1 + a) * TSZ + 4 * k * TLD] = v;
         }
     }
-}
-
-// D(16x16) += A(16x16) B(16x16) as four K=4 matrix-core steps; a[kc], b[kc] are the per-lane operand values
-__device__ __forceinline__ v4d mfma16(const double a[4], const double b[4], v4d acc)
-{
-#pragma unroll
-    for (int kc = 0; kc < 4; ++kc) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a[kc], b[kc], acc, 0, 0, 0);
-    return acc;
 }
 
 // Cholesky factor AND its inverse of one 16x16 LDS tile on ONE wave, in registers.  Lane i (mod 16) holds row i of L
