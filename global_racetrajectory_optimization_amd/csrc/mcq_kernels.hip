@@ -853,10 +853,14 @@ __global__ void __launch_bounds__(MCQ_NT) mcq_gram_tile_kernel(McqBatch B)
     }
     // border slots of this tile's interior rows that no entry above reaches: zero.  Slot jj of row i is reached from row i itself
     // when ni + jj - i <= 64, and from border row ni + jj around the ring when i <= jj (never both on rings this long).
+    // (Only where the factorisation reads them: rows further than the band width from both ends of the interior have no border
+    //  entries at all and factor_t does not fetch that half of their H rows -- 1 MB of zeros per N = 2000 problem that nothing
+    //  needs to write either.  The margins cover the 16-row tile granularity of the fetch.)
     for (int q = tid; q < GT_ROWS * MCQ_P_MAX; q += MCQ_NT) {
         const int row = q / MCQ_P_MAX, jj = q - row * MCQ_P_MAX;
         const int i = i0 + row;
         if (i >= ni) continue;
+        if (i >= MCQ_BH_MAX + TB && i < ni - MCQ_BH_MAX - 2 * TB) continue;
         if (ni + jj - i > MCQ_BH_MAX && i > jj) w.H[(size_t)i * MCQ_HLD + MCQ_HBO + jj] = 0.0;
     }
 }

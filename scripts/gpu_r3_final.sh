@@ -1,0 +1,23 @@
+#!/bin/bash
+# Final GPU call of round 3: the whole -m gpu suite (plain and with poisoned workspaces / LDS), the full bench line, the counter
+# passes (scripts/profile_round.sh), BASELINE config 4 and one rank's shard of config 5 on one GPU, the RCCL self-test line.
+R=${GRAFT_REPO_ROOT:-$(pwd)}
+T=${1:-r03}
+mkdir -p $R/gpurun_out
+cd $R
+timeout 1500 python -m pytest tests -m gpu -q --durations=8 > gpurun_out/${T}_pytest_gpu.log 2>&1
+echo "pytest rc $?" >> gpurun_out/${T}_pytest_gpu.log
+tail -14 gpurun_out/${T}_pytest_gpu.log
+MCQ_POISON=1 timeout 1500 python -m pytest tests/test_gpu_parity.py tests/test_gpu_fuzz.py -m gpu -q > gpurun_out/${T}_pytest_gpu_poison.log 2>&1
+echo "poison pytest rc $?" >> gpurun_out/${T}_pytest_gpu_poison.log
+tail -3 gpurun_out/${T}_pytest_gpu_poison.log
+timeout 900 python bench.py --steps 10 --warmup 2 > gpurun_out/${T}_bench.json 2> gpurun_out/${T}_bench.err
+echo "bench rc $?"; cut -c1-300 gpurun_out/${T}_bench.json
+timeout 600 python bench.py --config 4 --steps 3 --warmup 1 > gpurun_out/${T}_bench_config4_1gpu.json 2> gpurun_out/${T}_bench_config4.err
+echo "config4 rc $?"; cut -c1-300 gpurun_out/${T}_bench_config4_1gpu.json
+timeout 600 python bench.py --force-collective --steps 5 --warmup 2 --no-extras > gpurun_out/${T}_bench_force_collective_1gpu.json 2> gpurun_out/${T}_bench_fc.err
+echo "force-collective rc $?"
+timeout 900 python bench.py --config 5 --steps 2 --warmup 1 --no-extras > gpurun_out/${T}_config5_shard_1gpu.json 2> gpurun_out/${T}_config5.err
+echo "config5 rc $?"; cut -c1-300 gpurun_out/${T}_config5_shard_1gpu.json
+scripts/profile_round.sh $T 2>&1 | grep "pmc\|calib" | tr '\n' ' '
+scripts/gpu_fb.sh ${T}_final > /dev/null 2>&1
