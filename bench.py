@@ -63,9 +63,10 @@ def work_model(n, info, band_e=32):
     streamed   what THIS implementation has to move through HBM per launch -- the figure `roofline.achieved` / `frac` are computed
                from since round 3 (the declared model credited bytes the kernel no longer moves).  Rows as stored
                (csrc/mcq_kernels.h): L row 144 doubles (64 band | 16 inverse-diagonal-tile | 64 border W), E / E' bands 65 doubles
-               per row, H row 65 band doubles + 64 border doubles for the 128 rows within the band width of either end of the
-               interior (elsewhere the border half is zeros and is not read).
-                 factorisation       : read H (n * 65 + 128 * 64 doubles) + write L (n * 144 doubles); the forward substitution of
+               per row, H row 80 band slots (65 used: the band of row i starts i mod 16 slots in, so that a tile's 16 entries of a
+               column are one aligned line; all five lines of the band part are read) + 64 border doubles for the 128 rows within the
+               band width of either end of the interior (elsewhere the border half is zeros and is not read).
+                 factorisation       : read H (n * 80 + 128 * 64 doubles) + write L (n * 144 doubles); the forward substitution of
                                        the solve that follows rides through it on the LDS window (no bytes)
                  solve after a factorisation (interior-point predictor, active-set round): backward sweep only, n * 144 doubles
                  any other solve (corrector, refinement round)                             : both sweeps, 2 n * 144 doubles
@@ -87,9 +88,10 @@ def work_model(n, info, band_e=32):
     ew = 2 * band_e + 1
     grad = 2.0 * n * ew * 8.0
     # declared model
-    declared = float((n_fac * n * (130.0 + 144.0) * 8.0 + n_sol * 2.0 * n * 144.0 * 8.0 + n_grad * grad).sum())
+    declared = float((n_fac * n * (130.0 + 144.0) * 8.0 +   # (rounds 1-2's row sizes, kept as declared then)
+                      n_sol * 2.0 * n * 144.0 * 8.0 + n_grad * grad).sum())
     # streamed model
-    h_read = (n * 65.0 + 128.0 * 64.0) * 8.0
+    h_read = (n * 80.0 + 128.0 * 64.0) * 8.0
     l_row = n * 144.0 * 8.0
     sweeps = 2.0 * n_sol - n_fac                   # one forward sweep per factorisation is fused into it
     streamed = float((n_fac * (h_read + l_row) + sweeps * l_row + n_grad * grad).sum())

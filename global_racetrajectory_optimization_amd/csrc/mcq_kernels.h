@@ -21,8 +21,11 @@
 //   Et       [MCQ_ELD][nmax]  transpose band: entry [(bR+o)*nmax + j] = E[(j+o) mod n, j],  -bR <= o <= bE
 //                             (diagonal-major => a wave reading one diagonal for 64 consecutive rows reads 512 contiguous
 //                              bytes; band products need no cross-lane reduction)
-//   H        [n][MCQ_HLD]  interior rows i < ni: [0..b] upper band H[i,i+k], [MCQ_HBO + jj] border coupling H[i, ni+jj];
-//                          border rows i = ni+j: [MCQ_HBO + jj] = D[j][jj]
+//   H        [n][MCQ_HLD]  interior rows i < ni: [(i mod 16) + k] upper band H[i,i+k], k = 0..b  (MCQ_HBAND: the band of row i starts
+//                          i mod 16 slots into the row, so that the 16 entries H[c, 16 R .. 16 R + 15] of a column c that one tile
+//                          of the factorisation's window takes are ONE aligned 128-byte line -- indexed by k alone they started
+//                          at arbitrary offsets and every fetch touched two lines, round 3);  [MCQ_HBO + jj] border coupling
+//                          H[i, ni+jj];  border rows i = ni+j: [MCQ_HBO + jj] = D[j][jj].  Rows are 9 lines of 128 bytes.
 //   L        [n][MCQ_LLD]  interior rows i < ni: [m] = L[i, i-1-m] (m < 64), [MCQ_LBI + c] = row (i mod 16) of the inverse
 //                          of the 16x16 diagonal tile i/16, [MCQ_LBW + jj] = W[i][jj];  every piece 16-byte aligned.
 //                          (the inverse of the border factor L_S stays in LDS, packed lower-triangular)
@@ -38,8 +41,9 @@
 #define MCQ_ELD 66                 /* 2*BE_MAX+1 = 65, padded */
 #define MCQ_GW (MCQ_BE_MAX + 2)    /* half-width of the T^-1 rows kept */
 #define MCQ_GLD 72                 /* 2*GW+1 = 69, padded */
-#define MCQ_HBO 66                 /* offset of the border part inside an H/L row */
-#define MCQ_HLD 130                /* H rows: BH_MAX+1 band | pad | P_MAX border */
+#define MCQ_HBO 80                 /* offset of the border part inside an H row */
+#define MCQ_HLD 144                /* H rows: 80 band slots (65 used, shifted by i mod 16) | P_MAX border */
+#define MCQ_HBAND(i, k) ((size_t)(i) * MCQ_HLD + (size_t)(((i) & 15) + (k)))      /* slot of H[i, i+k] */
 #define MCQ_LLD 144                /* L rows: 64 band entries | 16 inverse-diagonal-tile entries | 64 border entries */
 #define MCQ_LBI 64                 /* offset of the inverse diagonal tile row inside an L row */
 #define MCQ_LBW 80                 /* offset of the border part W inside an L row */

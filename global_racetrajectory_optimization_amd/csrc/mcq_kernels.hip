@@ -623,7 +623,7 @@ __device__ void gram_bordered(const gdouble* Et, const gdouble* sg, const McqDim
         const int i = rix < skip0 ? rix : rix + nskip;
         double v = 0.0;
         if (k <= d.b && i + k < ni) v = gram_entry(Et, sg, d, nm, i, i + k);
-        out[(size_t)i * MCQ_HLD + k] = v + (base ? base[(size_t)i * MCQ_HLD + k] : 0.0);
+        out[MCQ_HBAND(i, k)] = v + (base ? base[MCQ_HBAND(i, k)] : 0.0);
     }
     for (int idx = t0; idx < MCQ_P_MAX * n; idx += nthreads) {
         const int i = idx / MCQ_P_MAX, jj = idx - i * MCQ_P_MAX;
@@ -823,7 +823,7 @@ __global__ void __launch_bounds__(MCQ_NT) mcq_gram_tile_kernel(McqBatch B)
     if (!all) {
         for (int q = tid; q < GT_ROWS * OW; q += MCQ_NT) {
             const int row = q / OW, k = q - row * OW;
-            w.H[(size_t)(i0 + row) * MCQ_HLD + k] = S[q];
+            w.H[MCQ_HBAND(i0 + row, k)] = S[q];
         }
         return;
     }
@@ -836,9 +836,9 @@ __global__ void __launch_bounds__(MCQ_NT) mcq_gram_tile_kernel(McqBatch B)
         const double h = S[q];
         const int j = i + k;
         if (i < ni) {                               // interior row: i + k < n always
-            if (j < ni) w.H[(size_t)i * MCQ_HLD + k] = h;
+            if (j < ni) w.H[MCQ_HBAND(i, k)] = h;
             else {
-                w.H[(size_t)i * MCQ_HLD + k] = 0.0;                        // the band ends at the border
+                w.H[MCQ_HBAND(i, k)] = 0.0;                                // the band ends at the border
                 w.H[(size_t)i * MCQ_HLD + MCQ_HBO + (j - ni)] = h;
             }
         } else {                                    // border row ii = i - ni
@@ -967,20 +967,21 @@ __global__ void __launch_bounds__(MCQ_NT) mcq_assemble_sp_kernel(McqBatch B)
     }
     // rows of the bordered band: consecutive threads write consecutive entries of one row
     for (int idx = tid; idx < MCQ_HLD * n; idx += MCQ_NT) {
-        const int i = idx / MCQ_HLD, k = idx - i * MCQ_HLD;
+        const int i = idx / MCQ_HLD, slot = idx - i * MCQ_HLD;
         double v = 0.0;
-        if (k < MCQ_HBO) {
+        if (slot < MCQ_HBO) {
+            const int k = slot - (i & 15);         // band slot of H[i, i + k] (MCQ_HBAND)
             if (i < ni) {
                 if (k == 0) v = SP_DIAG(i);
                 else if (k == 1 && d.b >= 1 && i + 1 < ni) v = SP_OFF(i, i + 1);
             }
-        } else if (k - MCQ_HBO < d.p) {
-            const int j = ni + (k - MCQ_HBO);
+        } else if (slot - MCQ_HBO < d.p) {
+            const int j = ni + (slot - MCQ_HBO);
             const int df = sdiff(i, j, n);
             if (df == 0) v = SP_DIAG(i);
             else if (df == 1 || df == -1) v = SP_OFF(i, j);
         }
-        w.H[(size_t)i * MCQ_HLD + k] = v;
+        w.H[(size_t)i * MCQ_HLD + slot] = v;
     }
 #undef SP_DIAG
 #undef SP_OFF
@@ -1003,7 +1004,8 @@ __global__ void __launch_bounds__(MCQ_NT) mcq_assemble_sp_kernel(McqBatch B)
 // -DMCQ_ABL=mask (scripts/factor_bench.hip ONLY: the results are garbage, the time is what is looked at): parts of a factorisation
 // step removed -- 1 Schur products, 2 border products, 4 write-out, 8 commit, 16 fetch, 32 diagonal tile, 128 wave 0's band tiles,
 // 256 phase 2, 512 the whole lag work, 1024 the not-positive-definite exit, 2048 the band products of the lag waves, 4096 the fetch
-// reads the same two tile rows all the time (cache hits), 8192 the write-out's global stores (its LDS reads stay).
+// reads the same two tile rows all the time (cache hits), 8192 the write-out's global stores (its LDS reads stay), 16384 the lag
+// waves' operand / accumulator reads from the LDS window (constants instead), 32768 their write-back.
 #ifndef MCQ_ABL
 #define MCQ_ABL 0
 #endif
@@ -1099,7 +1101,7 @@ __device__ __forceinline__ RawEntry tile_row_fetch(const gdouble* H, const gdoub
         const int k = i - c;
         const bool valid = in & (k >= 0) & (k <= b);
         const int cs = in ? c : 0, is = in ? i : 0;
-        e.h = H[(size_t)cs * MCQ_HLD + (valid ? k : 0)];
+        e.h = H[MCQ_HBAND(cs, valid ? k : 0)];
         if (MK) { e.m0 = mk[cs]; e.m1 = mk[is]; }
         if (SIG && k == 0) e.sg = sig[cs];      // the diagonal shift only touches the 16 diagonal entries of a tile row
     } else {
@@ -1174,7 +1176,7 @@ struct PfLane {
 __device__ __forceinline__ PfLane pf_lane(int l15, int l4)
 {
     PfLane c;
-    c.gB = l4 * MCQ_HLD + l15 - l4;
+    c.gB = l4 * MCQ_HLD + l15;
     c.gC = l4 * MCQ_HLD + l15;
     c.lB = l15 * TLD + l4;
     c.lC = l4 * TLD + l15;
@@ -1197,9 +1199,10 @@ __device__ __forceinline__ void tile_row_fetch_fast(const gdouble* H, const gdou
         e[u].m0 = e[u].m1 = 0;
         if (u < PF_NBAND(WL)) {
             const int tcol = PF_BBLK(WL, u) / 4, k = PF_BBLK(WL, u) % 4;
-            // entry (rr = l15, cc = l4 + 4k) of T(R, R - 4 + tcol) = H[c][i - c]; entries outside the band (tcol 4: above the
-            // diagonal, tcol 0: beyond 64) read an in-bounds neighbour and are dropped at the commit
-            e[u].h = Hr[c.gB + ((TB * (tcol - (NTR - 1)) + 4 * k) * MCQ_HLD + TB * (NTR - 1 - tcol) - 4 * k)];
+            // entry (rr = l15, cc = l4 + 4k) of T(R, R - 4 + tcol) = H[c, i], band slot (c mod 16) + i - c = 16 (4 - tcol) + rr of row c
+            // (MCQ_HBAND): the 16 rows of a column are one aligned 128-byte line.  Entries outside the band (tcol 4: above the
+            // diagonal, tcol 0: beyond 64) read unused slots of the row and are dropped at the commit
+            e[u].h = Hr[c.gB + ((TB * (tcol - (NTR - 1)) + 4 * k) * MCQ_HLD + TB * (NTR - 1 - tcol))];
             if (MK) {
                 e[u].m0 = mk[R * TB + TB * (tcol - (NTR - 1)) + l4 + 4 * k];
                 e[u].m1 = mk[R * TB + l15];
@@ -1486,20 +1489,20 @@ __device__ __forceinline__ int factor_t(const SolveCtx& c, const gdouble* Hsrc, 
         v4d cacc_[4], c3a_, c3b_, bacc_[2];                                                                            \
         _Pragma("unroll") for (int a_ = 0; a_ < NCT; ++a_) {                                                           \
             const double* wa2_ = CTILE((P), a_);                                                                       \
-            _Pragma("unroll") for (int kc = 0; kc < 4; ++kc) wv_[a_][kc] = wa2_[(l4 + 4 * kc) * TLD + l15];            \
+            _Pragma("unroll") for (int kc = 0; kc < 4; ++kc) wv_[a_][kc] = ABL(16384) ? 1.0 + a_ : wa2_[(l4 + 4 * kc) * TLD + l15];            \
         }                                                                                                              \
         _Pragma("unroll") for (int dI_ = 1; dI_ < NTR; ++dI_) {                                                        \
             const double* li_ = LTILE(dI_, (P));                                                                       \
             const double* ctl_ = CTILE((P) + dI_, (WL));                                                               \
-            _Pragma("unroll") for (int kc = 0; kc < 4; ++kc) la_[dI_ - 1][kc] = -li_[l15 * TLD + l4 + 4 * kc];         \
-            _Pragma("unroll") for (int r = 0; r < 4; ++r) cacc_[dI_ - 1][r] = ctl_[(l4 + 4 * r) * TLD + l15];          \
+            _Pragma("unroll") for (int kc = 0; kc < 4; ++kc) la_[dI_ - 1][kc] = ABL(16384) ? 0.5 + dI_ : -li_[l15 * TLD + l4 + 4 * kc];         \
+            _Pragma("unroll") for (int r = 0; r < 4; ++r) cacc_[dI_ - 1][r] = ABL(16384) ? 0.25 : ctl_[(l4 + 4 * r) * TLD + l15];          \
         }                                                                                                              \
         {                                                                                                              \
             const double* c3p_ = CTILE((P) + (WL) + 1, 3);                                                             \
             const double* c3q_ = CTILE((P) + 4, 3);                                                                    \
             _Pragma("unroll") for (int r = 0; r < 4; ++r) {                                                            \
-                c3a_[r] = c3p_[(l4 + 4 * r) * TLD + l15];                                                              \
-                c3b_[r] = c3q_[(l4 + 4 * r) * TLD + l15];                                                              \
+                c3a_[r] = ABL(16384) ? 0.1 : c3p_[(l4 + 4 * r) * TLD + l15];                                           \
+                c3b_[r] = ABL(16384) ? 0.2 : c3q_[(l4 + 4 * r) * TLD + l15];                                                              \
             }                                                                                                          \
         }                                                                                                              \
         WT(1);                                                                                                         \
@@ -1517,13 +1520,13 @@ __device__ __forceinline__ int factor_t(const SolveCtx& c, const gdouble* Hsrc, 
         /* ---- updated tiles back to the window ---- */                                                               \
         _Pragma("unroll") for (int dI_ = 1; dI_ < NTR; ++dI_) {                                                        \
             double* ctl_ = CTILE((P) + dI_, (WL));                                                                     \
-            _Pragma("unroll") for (int r = 0; r < 4; ++r) ctl_[(l4 + 4 * r) * TLD + l15] = cacc_[dI_ - 1][r];          \
+            _Pragma("unroll") for (int r = 0; r < 4; ++r) if (!ABL(32768)) ctl_[(l4 + 4 * r) * TLD + l15] = cacc_[dI_ - 1][r];          \
         }                                                                                                              \
         {                                                                                                              \
             double* c3p_ = CTILE((P) + (WL) + 1, 3);                                                                   \
             double* c3q_ = CTILE((P) + 4, 3);                                                                          \
             _Pragma("unroll") for (int r = 0; r < 4; ++r) {                                                            \
-                c3p_[(l4 + 4 * r) * TLD + l15] = c3a_[r];                                                              \
+                if (!ABL(32768)) c3p_[(l4 + 4 * r) * TLD + l15] = c3a_[r];                                                              \
                 if ((WL) == 0) c3q_[(l4 + 4 * r) * TLD + l15] = c3b_[r];                                               \
             }                                                                                                          \
         }                                                                                                              \
@@ -1533,7 +1536,7 @@ __device__ __forceinline__ int factor_t(const SolveCtx& c, const gdouble* Hsrc, 
                 _Pragma("unroll") for (int dI_ = dK_; dI_ < NTR; ++dI_, ++t_) {                                        \
                     if (t_ % 3 != (WL) || t_ < MCQ_BAND_WAVE0) continue;                                              \
                     const double* tt_ = BTILE((P) + dI_, (P) + dK_);                                                   \
-                    _Pragma("unroll") for (int r = 0; r < 4; ++r) bacc_[s_][r] = tt_[(l4 + 4 * r) * TLD + l15];        \
+                    _Pragma("unroll") for (int r = 0; r < 4; ++r) bacc_[s_][r] = ABL(16384) ? 0.3 : tt_[(l4 + 4 * r) * TLD + l15];        \
                     ++s_;                                                                                              \
                 }                                                                                                      \
             }                                                                                                          \
@@ -1572,7 +1575,7 @@ __device__ __forceinline__ int factor_t(const SolveCtx& c, const gdouble* Hsrc, 
                 _Pragma("unroll") for (int dI_ = dK_; dI_ < NTR; ++dI_, ++t_) {                                        \
                     if (t_ % 3 != (WL) || t_ < MCQ_BAND_WAVE0) continue;                                              \
                     double* tt_ = BTILE((P) + dI_, (P) + dK_);                                                         \
-                    _Pragma("unroll") for (int r = 0; r < 4; ++r) tt_[(l4 + 4 * r) * TLD + l15] = bacc_[s_][r];        \
+                    _Pragma("unroll") for (int r = 0; r < 4; ++r) if (!ABL(32768)) tt_[(l4 + 4 * r) * TLD + l15] = bacc_[s_][r];        \
                     ++s_;                                                                                              \
                 }                                                                                                      \
             }                                                                                                          \

@@ -49,8 +49,8 @@ int main(int argc, char** argv)
     const size_t elems = (size_t)batch * n;
     std::vector<double> Hh((size_t)n * MCQ_HLD, 0.0);
     for (int i = 0; i < d.ni; ++i) {
-        Hh[(size_t)i * MCQ_HLD] = 4.0;
-        for (int k = 1; k <= d.b && i + k < d.ni; ++k) Hh[(size_t)i * MCQ_HLD + k] = 0.5 / ((1.0 + k) * (1.0 + k));
+        Hh[MCQ_HBAND(i, 0)] = 4.0;
+        for (int k = 1; k <= d.b && i + k < d.ni; ++k) Hh[MCQ_HBAND(i, k)] = 0.5 / ((1.0 + k) * (1.0 + k));
         if (i < d.p || i >= d.ni - d.p)
             for (int jj = 0; jj < d.p; ++jj) Hh[(size_t)i * MCQ_HLD + MCQ_HBO + jj] = 0.002 / (1.0 + ((i + jj) % 7));
     }
