@@ -1024,6 +1024,7 @@ struct SolveCtx {
     mutable int refine_rounds, second_attempt;   // diagnostics for mcq_info
     mutable double last_step;  // length of the last interior-point step (the Tapia indicators are only trusted after a near-full one)
     int direct;                // 1: Eb holds the three diagonals of H itself and V_F holds f (shortest-path objective)
+    mutable const gdouble* kkt_w;   // saddle-point elimination: weights of the curvature rows (1 + y/t of the interior point) or nullptr
 };
 #define TICK() ((long long)wall_clock64())
 // fine-grained timers inside the factorisation (ticks[4..7]) cost an s_waitcnt per sample in the hot loop: off by default
@@ -1406,8 +1407,11 @@ __device__ __forceinline__ void fused_fwd_step(int J, gdouble* fv, int ni, doubl
 // would otherwise wait for the lag workers (~2200 cycles): everything the tile step of the forward sweep needs -- L(J, J-4 .. J-1),
 // M_J = L_JJ^-1, W_(J-1) -- sits in the LDS window at that moment.  solve(..., fwd_done = true) then starts at the border system:
 // one of the four passes over L per interior-point iteration (and one of two per active-set round) is never streamed from HBM.
+// (One function per configuration, NOT inlined into factor(): with the three bodies in one function hipcc 7.2 needs long branches
+// (s_getpc / s_setpc through a scavenged SGPR pair) and takes callee-saved s[98:99] for them without saving it -- the caller's loop
+// strides went with it.  scripts/check_csr.py scans the ISA of every device function for exactly this.)
 template <bool MK, bool SIG>
-__device__ __forceinline__ int factor_t(const SolveCtx& c, const gdouble* Hsrc, const gdouble* sig, const gschar* mk, gdouble* fv)
+__device__ __noinline__ int factor_t(const SolveCtx& c, const gdouble* Hsrc, const gdouble* sig, const gschar* mk, gdouble* fv)
 {
     const int tid = threadIdx.x;
     const int b = c.d.b, p = c.d.p, ni = c.d.ni;
@@ -1992,8 +1996,11 @@ __device__ __forceinline__ int factor_t(const SolveCtx& c, const gdouble* Hsrc, 
     return 0;
 }
 
+#include "mcq_kkt.inc"
+
 __device__ __noinline__ int factor(const SolveCtx& c, const gdouble* Hsrc, const gdouble* sig, const gschar* mk, gdouble* fv)
 {
+    if (MCQ_KKT && !__builtin_amdgcn_readfirstlane(c.direct)) return factor_kkt(c, sig, mk, c.kkt_w);     // fv untouched: solve() then runs its own forward chain
     // the configurations the solver uses: interior point (diagonal added; variables with lo == hi masked -- usually there are
     // none, then no mask bytes are fetched at all) and active set (mask only); fv: see factor_t
     if (sig) return mk ? factor_t<true, true>(c, Hsrc, sig, mk, fv) : factor_t<false, true>(c, Hsrc, sig, mk, fv);
@@ -2231,6 +2238,7 @@ __device__ __noinline__ void sweep_bwd_wave0(const SolveCtx& c, gdouble* v)
 // sit where the loader waves leave theirs): start at the border system.
 __device__ __noinline__ void solve(const SolveCtx& c, gdouble* v, bool fwd_done)
 {
+    if (MCQ_KKT && !__builtin_amdgcn_readfirstlane(c.direct)) { solve_kkt(c, v); return; }
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     const int l15 = lane & 15, l4 = lane >> 4;
     const int b = c.d.b, p = c.d.p, ni = c.d.ni;
@@ -2578,9 +2586,14 @@ __device__ __noinline__ int ipm(SolveCtx& c, const McqBatch& B, bool with_kappa,
             // H slab <- E' (I + diag(SK)) E = H + E' diag(SK) E   (H = E'E is rebuilt by the caller after this phase)
             for (int i = tid; i < n; i += MCQ_NT) EDA[i] = 1.0 + SK[i];
             __syncthreads();
-            gram_bordered(c.w.Et, EDA, c.d, nm, nullptr, c.w.H, tid, MCQ_NT);
-            __syncthreads();
+            if (MCQ_KKT && !c.direct) {
+                c.kkt_w = EDA;                       // the weights enter the (cx, cy) block of every waypoint: no band to rebuild
+            } else {
+                gram_bordered(c.w.Et, EDA, c.d, nm, nullptr, c.w.H, tid, MCQ_NT);
+                __syncthreads();
+            }
             fs = timed_factor(c, c.w.H, SIG, any_fixed ? ST : nullptr);
+            c.kkt_w = nullptr;
             // With many curvature rows close to their bound the weights y / t reach 1e10 and more near the end; the band of
             // E' diag(1 + SK) E then carries rounding errors of that size against eigenvalues of order one, and the Cholesky can
             // meet a non-positive pivot although the matrix is positive definite (round 3: a 360-point stadium with 134 active
@@ -3394,6 +3407,7 @@ __global__ void __launch_bounds__(MCQ_NT) mcq_solve_kernel(McqBatch B)
     c.last_step = 0.0;
     c.refine_rounds = c.second_attempt = 0;
     c.direct = B.objective == MCQ_OBJ_SHORTEST_PATH;
+    c.kkt_w = nullptr;
     if (B.poison_lds) {      // debugging aid: whatever a phase reads from LDS without having written it shows up as NaN on every box
         for (int q = tid; q < SM_TOTAL; q += MCQ_NT) g_sm[q] = __longlong_as_double(-1LL);
         __syncthreads();

@@ -250,13 +250,20 @@ inline hipemu_v4d hipemu_mfma_f64_16x16x4(double a, double b, hipemu_v4d c)
 #define __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, c, x, y, z) hipemu_mfma_f64_16x16x4((a), (b), (c))
 
 // AMDGCN builtins used by the kernels
-// v_mov_b64_dpp row_newbcast:n (dpp_ctrl 0x150 + n): lane n of every 16-lane row to all lanes of that row -- the only DPP control used
+// v_mov_b64_dpp row_newbcast:n (dpp_ctrl 0x150 + n): lane n of every 16-lane row to all lanes of that row; row_shl:n (0x100 + n): lane i
+// of a row takes lane i + n of the same row (bound_ctrl: zero beyond the row) -- the DPP controls the kernels use
 inline double hipemu_update_dpp(double, double src, int ctrl)
 {
     const int lane = hipemu::st().cur & 63;
+    if (ctrl >= 0x101 && ctrl <= 0x10f) {
+        const int from = (lane & 15) + (ctrl - 0x100);
+        const double got = __shfl(src, (lane & ~15) | (from & 15));
+        return from < 16 ? got : 0.0;
+    }
     if (ctrl < 0x150 || ctrl > 0x15f) { fprintf(stderr, "hipemu: unsupported dpp_ctrl 0x%x\n", ctrl); abort(); }
     return __shfl(src, (lane & ~15) | (ctrl - 0x150));
 }
+#define __builtin_amdgcn_rcp(x) (1.0 / (double)(x))              /* v_rcp_f64: the kernels refine it */
 #define __builtin_amdgcn_rsq(x) (1.0 / sqrt((double)(x)))      /* v_rsq_f64: the kernels refine it */
 #define __builtin_amdgcn_update_dpp(old, src, ctrl, rm, bm, bc) hipemu_update_dpp((old), (src), (ctrl))
 inline int hipemu_readlane(int v, int src) { return (int)__shfl((double)v, src); }
@@ -298,6 +305,8 @@ inline hipError_t hipSetDevice(int) { return hipSuccess; }
 inline hipError_t hipStreamCreate(hipStream_t* s) { *s = (void*)1; return hipSuccess; }
 inline hipError_t hipStreamDestroy(hipStream_t) { return hipSuccess; }
 inline hipError_t hipStreamSynchronize(hipStream_t) { return hipSuccess; }
+inline hipError_t hipDeviceSynchronize() { return hipSuccess; }
+inline hipError_t hipMemset(void* p, int v, size_t n) { memset(p, v, n); return hipSuccess; }
 inline hipError_t hipMalloc(void** p, size_t n) { *p = calloc(n ? n : 1, 1); return *p ? hipSuccess : hipErrorInvalidValue; }
 inline hipError_t hipFree(void* p) { free(p); return hipSuccess; }
 enum { hipHostMallocDefault = 0 };
