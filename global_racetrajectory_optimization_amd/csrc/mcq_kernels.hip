@@ -2000,7 +2000,7 @@ __device__ __noinline__ int factor_t(const SolveCtx& c, const gdouble* Hsrc, con
 
 __device__ __noinline__ int factor(const SolveCtx& c, const gdouble* Hsrc, const gdouble* sig, const gschar* mk, gdouble* fv)
 {
-    if (MCQ_KKT && !__builtin_amdgcn_readfirstlane(c.direct)) return factor_kkt(c, sig, mk, c.kkt_w);     // fv untouched: solve() then runs its own forward chain
+    if (MCQ_KKT && !__builtin_amdgcn_readfirstlane(c.direct)) return factor_kkt(c, sig, mk, c.kkt_w, MCQ_FUSE_FWD ? fv : nullptr);
     // the configurations the solver uses: interior point (diagonal added; variables with lo == hi masked -- usually there are
     // none, then no mask bytes are fetched at all) and active set (mask only); fv: see factor_t
     if (sig) return mk ? factor_t<true, true>(c, Hsrc, sig, mk, fv) : factor_t<false, true>(c, Hsrc, sig, mk, fv);
@@ -2238,7 +2238,7 @@ __device__ __noinline__ void sweep_bwd_wave0(const SolveCtx& c, gdouble* v)
 // sit where the loader waves leave theirs): start at the border system.
 __device__ __noinline__ void solve(const SolveCtx& c, gdouble* v, bool fwd_done)
 {
-    if (MCQ_KKT && !__builtin_amdgcn_readfirstlane(c.direct)) { solve_kkt(c, v); return; }
+    if (MCQ_KKT && !__builtin_amdgcn_readfirstlane(c.direct)) { solve_kkt(c, v, fwd_done); return; }
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     const int l15 = lane & 15, l4 = lane >> 4;
     const int b = c.d.b, p = c.d.p, ni = c.d.ni;
@@ -2542,7 +2542,7 @@ __device__ __noinline__ int ipm(SolveCtx& c, const McqBatch& B, bool with_kappa,
     // it carries is the residual of the banded solve.  Convergence is only declared on an exactly recomputed gradient.
     // On entry G holds the exact gradient at the box centre (computed by the caller for the scaling).
     bool g_exact = true;
-    double mu_first = 0.0;
+    double mu_first = 0.0, rdm_best = 1e300;
     for (int it = 1; it <= B.max_ipm_iter; ++it) {
         // ---- residuals: g = H x + f;  with kappa also r, rho and the dual residual needs E'(yu - yl) ---------------------
         if (with_kappa) {
@@ -2572,6 +2572,16 @@ __device__ __noinline__ int ipm(SolveCtx& c, const McqBatch& B, bool with_kappa,
             rdm = block_reduce_(rdm, 2, red);
             rhom = block_reduce_(rhom, 2, red);
             const bool conv = mu < IPM_TOL * zscale * sc.wmean && rdm < IPM_TOL * zscale && rhom <= 1e-9 * kb;
+            // Curvature rows, late in the path: the weights 1 + y / t of rows close to their bound reach 1e10 and more, and the dual residual
+            // stops following the complementarity down -- rounding in the weighted system, whichever way it is solved (the band of
+            // E' diag(1 + y/t) E met a non-positive pivot at this point; the saddle-point form carries the weights in its (cx, cy) blocks and
+            // loses the digits there).  Once the complementarity is down by 1e-6 and the dual residual has turned around, the pairs identify
+            // the working set as well as they ever will: the exact active-set phase that follows does not use weights.
+            if (with_kappa && it > 1 && mu < 1e-6 * mu_first && rdm > 10.0 * rdm_best) return MCQ_OK;
+            rdm_best = fmin(rdm_best, rdm);
+#ifdef IPM_TRACE
+            if (tid == 0) printf("ipm%d it %d mu %.3e rdm %.3e rhom %.3e step %.3e\n", (int)with_kappa, it, mu / (zscale * sc.wmean), rdm / zscale, rhom / kb, c.last_step);
+#endif
             if (conv && (with_kappa || g_exact)) return MCQ_OK;
             if (!conv) break;
             gradient(c, X, nullptr, T0, G);          // looks converged on the carried gradient: confirm on the exact one
@@ -2848,6 +2858,9 @@ __device__ __noinline__ int ipm_box(SolveCtx& c, const McqBatch& B, const SolveS
             block_reduce2_(mu, 0, rdm, 2, red);
             mu /= npairs;
             const bool conv = mu < IPM_TOL * zscale * sc.wmean && rdm < IPM_TOL * zscale;
+#ifdef IPM_TRACE
+            if (threadIdx.x == 0) printf("ipmb it %d mu %.3e rdm %.3e exact %d resume %d\n", it, mu / (zscale * sc.wmean), rdm / zscale, (int)g_exact, (int)resume);
+#endif
             if (conv && g_exact) return MCQ_OK;
             if (!conv) break;
             gradient(c, X, nullptr, VEC(c.w, nm, V_T0), G);     // looks converged on the carried gradient: confirm on the exact one
@@ -2867,7 +2880,9 @@ __device__ __noinline__ int ipm_box(SolveCtx& c, const McqBatch& B, const SolveS
         // when the factor is (MCQ_FUSE_FWD = 0: the plain sequence)
         const int fs = timed_factor(c, c.w.H, VEC(c.w, c.nm, V_SIG), any_fixed ? c.w.state : nullptr,
                                     MCQ_FUSE_FWD ? VEC(c.w, c.nm, V_RHS) : nullptr);
-        if (fs != 0) return fs;
+        // resumed attempt (complementarity already below 1e-10): an iterate that sits ON a bound in floating point (slack 0, sig = inf) ends
+        // the attempt like a stalled complementarity does -- the pairs of the last completed iteration go to the active-set phase
+        if (fs != 0) return (resume && fs == MCQ_NOT_PD) ? MCQ_OK : fs;
         timed_solve(c, VEC(c.w, c.nm, V_RHS), MCQ_FUSE_FWD != 0);
 
         // ---- pass 2: affine step lengths, centring parameter, corrector right-hand side (one load phase) --------------

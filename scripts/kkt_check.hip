@@ -11,7 +11,7 @@
 #include <vector>
 #include <cmath>
 
-__global__ void __launch_bounds__(MCQ_NT) kc_kernel(McqBatch B, int reps, const double* rhs0, double* out, int* fsout)
+__global__ void __launch_bounds__(MCQ_NT) kc_kernel(McqBatch B, int reps, const double* rhs0, double* out, int* fsout, int fused)
 {
     int n;
     double kb, wv;
@@ -27,15 +27,21 @@ __global__ void __launch_bounds__(MCQ_NT) kc_kernel(McqBatch B, int reps, const 
     gdouble* SIG = VEC(c.w, c.nm, V_SIG);
     gdouble* RHS = VEC(c.w, c.nm, V_RHS);
     int fs = 0;
+    long long tf = 0, ts = 0;
     for (int r = 0; r < reps; ++r) {
         for (int i = threadIdx.x; i < n; i += MCQ_NT) RHS[i] = rhs0[i];
         __syncthreads();
-        fs |= factor_kkt(c, SIG, nullptr, nullptr);
-        solve_kkt(c, RHS);
+        const long long t0 = (long long)wall_clock64();
+        fs |= factor_kkt(c, SIG, nullptr, nullptr, fused ? RHS : nullptr);
+        const long long t1 = (long long)wall_clock64();
+        solve_kkt(c, RHS, fused != 0);
+        const long long t2 = (long long)wall_clock64();
+        tf += t1 - t0; ts += t2 - t1;
         for (int i = threadIdx.x; i < n; i += MCQ_NT) out[((size_t)blockIdx.x * reps + r) * n + i] = RHS[i];
         __syncthreads();
     }
-    if (threadIdx.x == 0) fsout[blockIdx.x] = fs;
+    if (threadIdx.x == 0 && blockIdx.x == 0 && KKT_TIMERS) printf("   phases (us per call): factor fwd %.1f spikes %.1f separators %.1f | solve fwd %.1f bwd %.1f separators %.1f correction %.1f\n", c.tk[0] / 100.0 / reps, c.tk[1] / 100.0 / reps, c.tk[2] / 100.0 / reps, c.tk[3] / 100.0 / reps, c.tk[4] / 100.0 / reps, c.tk[5] / 100.0 / reps, c.tk[6] / 100.0 / reps);
+    if (threadIdx.x == 0) { fsout[3 * blockIdx.x] = fs; fsout[3 * blockIdx.x + 1] = (int)(tf / reps); fsout[3 * blockIdx.x + 2] = (int)(ts / reps); }
 }
 
 #define CK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { fprintf(stderr, "%s: %s\n", #x, hipGetErrorString(e_)); return 1; } } while (0)
@@ -50,6 +56,8 @@ int main(int argc, char** argv)
 {
     const int n = argc > 1 ? atoi(argv[1]) : 333, reps = argc > 2 ? atoi(argv[2]) : 50, batch = argc > 3 ? atoi(argv[3]) : 4;
     const double srange = argc > 4 ? atof(argv[4]) : 12.0;
+    const int with_ref = argc > 5 ? atoi(argv[5]) : 1;
+    const int fused = argc > 6 ? atoi(argv[6]) : 0;
     const size_t elems = (size_t)batch * n;
     unsigned long long seed = 12345;
     // geometry of an oval: reference derivatives and unit normals; spline scalings near one
@@ -76,7 +84,7 @@ int main(int argc, char** argv)
     CK(hipMalloc((void**)&outd, elems * reps * sizeof(double)));
     CK(hipMalloc((void**)&state, elems));
     CK(hipMalloc((void**)&status, batch * sizeof(int)));
-    CK(hipMalloc((void**)&fsd, batch * sizeof(int)));
+    CK(hipMalloc((void**)&fsd, 3 * batch * sizeof(int)));
     CK(hipMemset(state, 0, elems));
     CK(hipMemset(status, 0, batch * sizeof(int)));
     CK(hipMemset(L, 0xff, elems * MCQ_LLD * sizeof(double)));
@@ -89,13 +97,13 @@ int main(int argc, char** argv)
     B.band_e = 32;
     B.Eb = B.Et = B.Db = B.H = L; B.Z = L;      // unused by the saddle-point path
     B.ref = L; B.kappa_bound = 1.0; B.w_veh = 0.0;
-    hipLaunchKernelGGL(kc_kernel, dim3(batch), dim3(MCQ_NT), 0, 0, B, reps, rhsd, outd, fsd);
+    hipLaunchKernelGGL(kc_kernel, dim3(batch), dim3(MCQ_NT), 0, 0, B, reps, rhsd, outd, fsd, fused);
     CK(hipGetLastError());
     CK(hipDeviceSynchronize());
     std::vector<double> out(elems * reps);
-    std::vector<int> fs(batch);
+    std::vector<int> fs(3 * batch);
     CK(hipMemcpy(out.data(), outd, out.size() * sizeof(double), hipMemcpyDeviceToHost));
-    CK(hipMemcpy(fs.data(), fsd, batch * sizeof(int), hipMemcpyDeviceToHost));
+    CK(hipMemcpy(fs.data(), fsd, 3 * batch * sizeof(int), hipMemcpyDeviceToHost));
     // determinism
     int ndiff = 0, nnan = 0;
     double dmax = 0.0;
@@ -105,9 +113,11 @@ int main(int argc, char** argv)
             if (!(a == a)) { ++nnan; continue; }
             if (a != b0) { ++ndiff; dmax = fmax(dmax, fabs(a - b0)); }
         }
+    { double af = 0, as_ = 0; for (int b = 0; b < batch; ++b) { af += fs[3 * b + 1]; as_ += fs[3 * b + 2]; }
+      printf("   per workgroup: factorisation %.1f us, solve %.1f us (100 MHz wall clock, mean over %d workgroups)\n", af / batch / 100.0, as_ / batch / 100.0, batch); }
     printf("n %d reps %d batch %d: factor status %d, entries differing from the first solution %d (max %.3e), NaNs %d\n", n, reps, batch, fs[0], ndiff, dmax, nnan);
     // host reference: the reduced system (sig + E'E) x = r through T^-1 R (dense, n x n)
-    {
+    if (with_ref) {
         std::vector<double> T((size_t)n * n, 0.0), R((size_t)n * n, 0.0);
         const double* SC = &vec[(size_t)V_SC * n];
         for (int m = 0; m < n; ++m) {

@@ -250,22 +250,26 @@ inline hipemu_v4d hipemu_mfma_f64_16x16x4(double a, double b, hipemu_v4d c)
 #define __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, c, x, y, z) hipemu_mfma_f64_16x16x4((a), (b), (c))
 
 // AMDGCN builtins used by the kernels
-// v_mov_b64_dpp row_newbcast:n (dpp_ctrl 0x150 + n): lane n of every 16-lane row to all lanes of that row; row_shl:n (0x100 + n): lane i
-// of a row takes lane i + n of the same row (bound_ctrl: zero beyond the row) -- the DPP controls the kernels use
-inline double hipemu_update_dpp(double, double src, int ctrl)
+// DPP moves as the kernels use them: row_newbcast:n (dpp_ctrl 0x150 + n): lane n of every 16-lane row to all lanes of that row;
+// row_shl:n (0x100 + n): lane i of a row takes lane i + n of the same row.  Lanes whose row / bank (4 lanes) is not enabled by row_mask /
+// bank_mask keep `old`; a source beyond the row gives 0 with bound_ctrl, `old` without.
+inline double hipemu_update_dpp(double old, double src, int ctrl, int rm, int bm, bool bc)
 {
     const int lane = hipemu::st().cur & 63;
+    const bool enabled = ((rm >> (lane >> 4)) & 1) && ((bm >> ((lane & 15) >> 2)) & 1);
     if (ctrl >= 0x101 && ctrl <= 0x10f) {
         const int from = (lane & 15) + (ctrl - 0x100);
         const double got = __shfl(src, (lane & ~15) | (from & 15));
-        return from < 16 ? got : 0.0;
+        if (!enabled) return old;
+        return from < 16 ? got : (bc ? 0.0 : old);
     }
     if (ctrl < 0x150 || ctrl > 0x15f) { fprintf(stderr, "hipemu: unsupported dpp_ctrl 0x%x\n", ctrl); abort(); }
-    return __shfl(src, (lane & ~15) | (ctrl - 0x150));
+    const double got = __shfl(src, (lane & ~15) | (ctrl - 0x150));
+    return enabled ? got : old;
 }
 #define __builtin_amdgcn_rcp(x) (1.0 / (double)(x))              /* v_rcp_f64: the kernels refine it */
 #define __builtin_amdgcn_rsq(x) (1.0 / sqrt((double)(x)))      /* v_rsq_f64: the kernels refine it */
-#define __builtin_amdgcn_update_dpp(old, src, ctrl, rm, bm, bc) hipemu_update_dpp((old), (src), (ctrl))
+#define __builtin_amdgcn_update_dpp(old, src, ctrl, rm, bm, bc) hipemu_update_dpp((old), (src), (ctrl), (rm), (bm), (bc))
 inline int hipemu_readlane(int v, int src) { return (int)__shfl((double)v, src); }
 #define __builtin_amdgcn_readlane(v, l) hipemu_readlane((v), (l))
 #define __builtin_amdgcn_s_barrier() hipemu::block_barrier()
