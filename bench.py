@@ -58,47 +58,43 @@ KAPPA_BOUND, W_VEH = 0.12, 3.4
 def work_model(n, info, band_e=32):
     """HBM bytes and fp64 flops of mcq_solve_kernel for one launch, from the iteration counts the solver reports (mcq_info).
 
-    Two byte counts:
+    streamed   what THIS implementation has to move through HBM per launch -- the figure `roofline.achieved` /
+               `frac` are computed from.  Since the saddle-point core (round 3, csrc/mcq_kkt.inc) the per-waypoint records are
+                 factorisation : elimination writes D~^-1 | Lo (32 doubles), G (32), the forward-eliminated left spike | y (32); the
+                                 spike pass reads the last two back and writes the alpha rows of the spikes (16); inputs: 8 per-waypoint
+                                 vectors + the mask byte; the right-hand side of the solve that follows rides through both passes
+                                 (read + written once)                                            -> 1489 bytes per waypoint
+                 solve after a factorisation (interior-point predictor, active-set round): the separators' system (LDS) and the spike
+                                 correction: spikes (16 doubles) + the vector (read + written)   -> 144 bytes per waypoint
+                 any other solve (corrector, refinement round): forward chain (D~^-1 | Lo, r, y out), backward chain (G, y, x out),
+                                 correction                                                      -> 800 bytes per waypoint
+                 gradient      : E band + E' band, 2 n * 65 doubles;  f = 2 E'k_ref at the top of the kernel: one band
+               interior-point iteration = 1 factorisation + predictor solve + corrector solve (one exact gradient per problem confirms
+               convergence); active-set round = 1 factorisation + 1 solve + 2 gradients; refinement round = 1 solve + 1 gradient;
+               + 1 initial gradient + 1.5 band products in the epilogue + 0.5 for f.
+    declared   SURVEY.md section 8(d)'s figure was written for the banded-exact algorithm of rounds 1-3 (every factorisation streams the
+               band of H and of L: 274 doubles per row, every sweep 144).  The saddle-point core does not move those bytes; the old figure
+               is reported as `banded_model_bytes` for reference only -- no fraction is quoted on it.
 
-    streamed   what THIS implementation has to move through HBM per launch -- the figure `roofline.achieved` / `frac` are computed
-               from since round 3 (the declared model credited bytes the kernel no longer moves).  Rows as stored
-               (csrc/mcq_kernels.h): L row 144 doubles (64 band | 16 inverse-diagonal-tile | 64 border W), E / E' bands 65 doubles
-               per row, H row 80 band slots (65 used: the band of row i starts i mod 16 slots in, so that a tile's 16 entries of a
-               column are one aligned line; all five lines of the band part are read) + 64 border doubles for the 128 rows within the
-               band width of either end of the interior (elsewhere the border half is zeros and is not read).
-                 factorisation       : read H (n * 80 + 128 * 64 doubles) + write L (n * 144 doubles); the forward substitution of
-                                       the solve that follows rides through it on the LDS window (no bytes)
-                 solve after a factorisation (interior-point predictor, active-set round): backward sweep only, n * 144 doubles
-                 any other solve (corrector, refinement round)                             : both sweeps, 2 n * 144 doubles
-                 gradient            : E band + E' band, 2 n * 65 doubles
-               interior-point iteration = 1 factorisation + predictor solve + corrector solve (one exact gradient per problem
-               confirms convergence); active-set round = 1 factorisation + 1 solve + 2 gradients; refinement round = 1 solve + 1
-               gradient; + 1 initial gradient + 1.5 band products in the epilogue.
-    declared   SURVEY.md section 8(d)'s banded-exact formula as rounds 1-2 declared it: every solve counted with both sweeps, every
-               H row with all 130 doubles.  Kept as the secondary figure (`frac_declared_model`) for continuity.
-
-    Flops (2 per FMA): factorisation 10272 FMAs per column (band 2080 + border 4096 + Schur 4096), sweep 144
-    FMAs per row and direction, band product 65 FMAs per row.
+    Flops (2 per FMA), rough: elimination step ~640 FMAs per waypoint (5 x 16 working matrix, five Gauss-Jordan stages), spike pass 275,
+    a chain of a solve 40 per direction, band product 65 per row.
     """
     ipm = info["ipm_iters"].astype(np.float64)
     act = info["as_iters"].astype(np.float64)
     ref = info["refine_rounds"].astype(np.float64)
     n_fac, n_sol = ipm + act, 2 * ipm + act + ref
-    n_grad = 1.0 + 2 * act + ref + 1.0 + 1.5
+    n_grad = 1.0 + 2 * act + ref + 1.0 + 1.5 + 0.5
     ew = 2 * band_e + 1
     grad = 2.0 * n * ew * 8.0
-    # declared model
-    declared = float((n_fac * n * (130.0 + 144.0) * 8.0 +   # (rounds 1-2's row sizes, kept as declared then)
-                      n_sol * 2.0 * n * 144.0 * 8.0 + n_grad * grad).sum())
-    # streamed model
-    h_read = (n * 80.0 + 128.0 * 64.0) * 8.0
-    l_row = n * 144.0 * 8.0
-    sweeps = 2.0 * n_sol - n_fac                   # one forward sweep per factorisation is fused into it
-    streamed = float((n_fac * (h_read + l_row) + sweeps * l_row + n_grad * grad).sum())
-    flops = float((n_fac * 2.0 * n * 10272.0 + n_sol * 2.0 * 2.0 * n * 144.0 + n_grad * 2.0 * 2.0 * n * ew).sum())
-    return dict(streamed=streamed, declared=declared, flops=flops,
-                per_problem=dict(factorisations=float(n_fac.mean()), solves=float(n_sol.mean()), sweeps_streamed=float(sweeps.mean()),
-                                 gradients=float(n_grad.mean()), bytes_factorisation=h_read + l_row, bytes_sweep=l_row, bytes_gradient=grad))
+    b_fac, b_fused, b_solve = n * 1489.0, n * 144.0, n * 800.0
+    plain = n_sol - n_fac                          # solves that run their own chains
+    streamed = float((n_fac * (b_fac + b_fused) + plain * b_solve + n_grad * grad).sum())
+    banded = float((n_fac * n * (130.0 + 144.0) * 8.0 + n_sol * 2.0 * n * 144.0 * 8.0 + n_grad * grad).sum())
+    flops = float((n_fac * 2.0 * n * (640.0 + 275.0) + plain * 2.0 * 2.0 * n * 40.0 + n_grad * 2.0 * 2.0 * n * ew).sum())
+    return dict(streamed=streamed, declared=banded, flops=flops,
+                per_problem=dict(factorisations=float(n_fac.mean()), solves=float(n_sol.mean()), solves_with_own_chains=float(plain.mean()),
+                                 gradients=float(n_grad.mean()), bytes_factorisation=b_fac, bytes_fused_solve=b_fused, bytes_solve=b_solve,
+                                 bytes_gradient=grad))
 
 
 def source_sha():
@@ -107,7 +103,7 @@ def source_sha():
     import hashlib
     h = hashlib.sha256()
     base = os.path.join(ROOT, "global_racetrajectory_optimization_amd", "csrc")
-    for name in ("build.sh", "mcq_api.hip", "mcq_kernels.h", "mcq_kernels.hip"):
+    for name in ("build.sh", "mcq_api.hip", "mcq_kernels.h", "mcq_kernels.hip", "mcq_kkt.inc"):
         with open(os.path.join(base, name), "rb") as fh:
             h.update(name.encode() + b"\0" + fh.read())
     return h.hexdigest()
@@ -532,16 +528,17 @@ def main():
                                                      "min": float(np.min(100.0 * info["ticks"][:, 6] / np.maximum(info["ticks"][:, 3], 1)))},
                        "engine_source_sha256": source_sha(),
                        "gpu_power_temp_during_timed_region": clocks},
-            # `achieved` / `frac`: the bytes this implementation has to stream (work_model: fused forward sweeps and the all-zero border
-            # halves of H are NOT counted) over the kernel's average duration (HIP events on the engine's stream, this run).
+            # `achieved` / `frac`: the bytes this implementation has to stream (work_model: the records of the saddle-point elimination as
+            # laid out in HBM) over the kernel's average duration (HIP events on the engine's stream, this run).
             "roofline": {"bound": "hbm", "kernel": "mcq_solve_kernel", "achieved": achieved, "peak": HBM_PEAK_GBS,
                          "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                          "traffic": traffic, "traffic_source": traffic_src,
                          "algorithmic_bytes_per_launch": wm["streamed"], "kernel_ms": k_ms,
                          "model": "streamed (DESIGN.md section 6); per problem: %s" % json.dumps({k: round(v, 3) for k, v in wm["per_problem"].items()}),
                          "frac_of_measured_traffic": (traffic / (k_ms * 1e-3) / 1e9 / HBM_PEAK_GBS) if traffic else None,
-                         "declared_bytes_per_launch": wm["declared"],
-                         "frac_declared_model": wm["declared"] / (k_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                         # the bytes the banded-exact algorithm of rounds 1-3 would have moved for the same iteration
+                         # counts: for reference, no fraction quoted -- the saddle-point core does not move them
+                         "banded_model_bytes_per_launch": wm["declared"],
                          "fp64_flops_per_launch": wm["flops"], "fp64_tflops": wm["flops"] / (k_ms * 1e-3) / 1e12,
                          "fp64_frac_of_%.1f_tflops" % FP64_PEAK_TFLOPS: wm["flops"] / (k_ms * 1e-3) / 1e12 / FP64_PEAK_TFLOPS},
         }

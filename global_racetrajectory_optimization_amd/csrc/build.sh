@@ -8,4 +8,15 @@ HIPCC=${HIPCC:-/opt/rocm/bin/hipcc}
 #   non-inlined device function once that function grew past the caller-saved VGPRs (band_matvec with 16-byte loads: the curvature-row
 #   path then read a null pointer on the GPU -- found by the -m gpu suite, not by the SIMT emulator, which never sees the allocator).
 #   Plain calling-convention clobbers are also 1 % faster on the solver kernel.
-$HIPCC --offload-arch=gfx950 -O3 -std=c++17 -fPIC -shared -mllvm -amdgpu-mfma-vgpr-form -mllvm -enable-ipra=0 -o libmcq.so mcq_kernels.hip mcq_api.hip "$@"
+# mcq_kernels.hip is compiled TWICE (see its header): the library's kernels with the saddle-point core for two workgroups per CU
+# (--gpu-max-threads-per-block=512: every device function stays within 256 VGPRs), and -DMCQ_CORE_BAND: namespace mcq_band, the solver
+# kernel on the bordered-band core (shortest-path objective).
+FLAGS="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -mllvm -amdgpu-mfma-vgpr-form -mllvm -enable-ipra=0"
+OUT=${OUT:-libmcq.so}
+TMP=$(mktemp -d)
+$HIPCC $FLAGS --gpu-max-threads-per-block=512 "$@" -c -o $TMP/kkt.o mcq_kernels.hip &
+$HIPCC $FLAGS -DMCQ_CORE_BAND "$@" -c -o $TMP/band.o mcq_kernels.hip &
+$HIPCC $FLAGS "$@" -c -o $TMP/api.o mcq_api.hip &
+wait
+$HIPCC --offload-arch=gfx950 -shared -fPIC -o $OUT $TMP/kkt.o $TMP/band.o $TMP/api.o
+rm -rf $TMP

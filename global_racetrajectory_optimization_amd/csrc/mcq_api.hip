@@ -285,7 +285,7 @@ static int launch(mcq_handle* h, McqBatch& B, const mcq_opts& o)
         HIP_TRY(hipGetLastError());
         HIP_TRY(hipEventRecord(h->ev[1], h->stream));
         HIP_TRY(hipEventRecord(h->ev[2], h->stream));
-        hipLaunchKernelGGL(mcq_solve_kernel, dim3(B.batch), dim3(256), 0, h->stream, B);
+        hipLaunchKernelGGL(mcq_band::mcq_solve_kernel, dim3(B.batch), dim3(256), 0, h->stream, B);
         HIP_TRY(hipGetLastError());
         HIP_TRY(hipEventRecord(h->ev[3], h->stream));
         HIP_TRY(hipEventRecord(h->ev[4], h->stream));
@@ -297,10 +297,8 @@ static int launch(mcq_handle* h, McqBatch& B, const mcq_opts& o)
     HIP_TRY(hipGetLastError());
     if (B.prep_only) return 0;
     HIP_TRY(hipEventRecord(h->ev[1], h->stream));
-    hipLaunchKernelGGL(mcq_gram_kernel, dim3(B.batch, MCQ_GRAM_Y), dim3(256), 0, h->stream, B);
-    HIP_TRY(hipGetLastError());
-    hipLaunchKernelGGL(mcq_gram_tile_kernel, dim3(B.batch, (B.nmax + 63) / 64), dim3(256), 0, h->stream, B);
-    HIP_TRY(hipGetLastError());
+    // (K2, the band of H = E'E: mcq_gram_kernel / mcq_gram_tile_kernel are not launched any more -- the saddle-point core of the solver kernel
+    //  works on the spline system itself, and f = 2 E'k_ref is one band product at the top of the solver kernel)
     HIP_TRY(hipEventRecord(h->ev[2], h->stream));
     hipLaunchKernelGGL(mcq_solve_kernel, dim3(B.batch), dim3(256), 0, h->stream, B);
     HIP_TRY(hipGetLastError());

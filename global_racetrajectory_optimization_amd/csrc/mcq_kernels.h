@@ -144,7 +144,11 @@ __global__ void mcq_assemble_kernel(McqBatch B);
 __global__ void mcq_assemble_sp_kernel(McqBatch B);
 __global__ void mcq_gram_kernel(McqBatch B);
 __global__ void mcq_gram_tile_kernel(McqBatch B);
-__global__ void mcq_solve_kernel(McqBatch B);
+__global__ void mcq_solve_kernel(McqBatch B);      // saddle-point core (mcq_kkt.inc), two workgroups per CU
+namespace mcq_band {
+__global__ void mcq_solve_kernel(McqBatch B);      // bordered-band core (second translation unit of mcq_kernels.hip, -DMCQ_CORE_BAND): H given entry by entry
+size_t mcq_solve_lds_bytes();
+}
 
 /* tph.check_normals_crossing [REF helper_funcs_glob/src/prep_track.py:57-59], one workgroup per track: crossing_out [batch] =
  * 1 / 0, or -1 where tph raises (horizon >= n) */

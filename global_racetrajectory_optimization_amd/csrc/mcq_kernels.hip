@@ -3,6 +3,20 @@
 
 #include <math.h>
 
+// Two translation units are built from this file (build.sh):
+//   default          the library's kernels; the solver's linear algebra is the saddle-point elimination of mcq_kkt.inc.  Compiled for
+//                    TWO workgroups per CU: <= 256 VGPRs (hipcc --gpu-max-threads-per-block=512 + __launch_bounds__(256, 2)), 78 KB of LDS.
+//   -DMCQ_CORE_BAND  namespace mcq_band: ONLY the solver kernel, on the bordered-band Cholesky of rounds 1-3 (H given entry by entry:
+//                    the shortest-path objective, whose H is a cyclic tridiagonal the saddle-point form has no use for); 152 KB of LDS,
+//                    one workgroup per CU.
+#if defined(MCQ_CORE_BAND)
+#define MCQ_KKT 0
+namespace mcq_band {
+#else
+#define MCQ_KKT 1
+#endif
+
+
 #define MCQ_NT 256
 #define MCQ_NW (MCQ_NT / 64)
 typedef double v4d __attribute__((vector_size(32)));   /* accumulator fragment of v_mfma_f64_16x16x4_f64 */
@@ -20,8 +34,11 @@ typedef __attribute__((address_space(1))) d2 gd2;
 #define NBUF 3                          /* chunk ring: current, previous (backward sweep) / next, one being filled */
 #define NRB 4                           /* right-hand-side ring (chunks) */
 #define VRING 128                       /* ring of the most recent unknowns (the band reaches 64 back, tiles are 16 wide) */
+#if defined(MCQ_CORE_BAND)
 #define SPK (MCQ_P_MAX * (MCQ_P_MAX + 1) / 2)   /* packed lower triangle of the inverse border factor */
+#endif
 
+#if defined(MCQ_CORE_BAND)
 // ---------------------------------------------------------------------------------------------------------------------
 // shared-memory carve-up of the solver kernel (doubles).  The triangular sweeps overlay the factorisation window.
 // ---------------------------------------------------------------------------------------------------------------------
@@ -49,6 +66,23 @@ typedef __attribute__((address_space(1))) d2 gd2;
 /* the KMAX x KMAX Schur matrix of the active curvature rows lives in HBM (McqWork.Z) and is brought into the overlay region
    between two triangular solves for its (parallel) elimination */
 static_assert(MCQ_KMAX * MCQ_KMAX <= OVL_SIZE, "the Schur matrix of the curvature rows must fit the LDS overlay");
+
+#else
+// ---------------------------------------------------------------------------------------------------------------------
+// shared-memory carve-up of the solver kernel (doubles), saddle-point core: reduction scratch, the separators' system (persistent between
+// a factorisation and its solves), the overlay (chunk buffers of the chains / scratch of the factorisation / the LDS copy of the
+// curvature rows' Schur matrix), the curvature rows' lists.  78 KB: two workgroups per CU.
+// ---------------------------------------------------------------------------------------------------------------------
+#define SM_RED 0
+#define SM_S (SM_RED + 64)
+#define SPK 1920                                  /* mcq_kkt.inc: KP_* */
+#define SM_OVL (SM_S + SPK)
+#define OVL_SIZE 7464                             /* mcq_kkt.inc: KO_* (static_assert there) */
+#define SM_KV (SM_OVL + OVL_SIZE)
+#define SM_KI (SM_KV + 3 * MCQ_KMAX)
+#define SM_TOTAL (SM_KI + (3 * MCQ_KMAX + 2 + 1) / 2 + 1)
+static_assert(sizeof(double) * SM_TOTAL <= 80 * 1024, "two workgroups of the solver kernel per CU");
+#endif
 
 size_t mcq_solve_lds_bytes() { return sizeof(double) * SM_TOTAL; }
 
@@ -200,6 +234,12 @@ __device__ __forceinline__ double bcast_lane(double v, int src_lane)
 
 // Lanes 0..15: sum of x over the four 16-lane rows (lane, lane+16, lane+32, lane+48); other lanes: unspecified.
 // v_permlane32_swap / v_permlane16_swap (gfx950) are VALU lane exchanges: no LDS-crossbar round trip like ds_bpermute.
+// Broadcast of lane N of every 16-lane row to the whole row: one v_mov_b64_dpp row_newbcast (full-rate VALU, no SGPR round trip).
+template <int N> __device__ __forceinline__ double bcast_row16(double v)
+{
+    return __builtin_amdgcn_update_dpp(0.0, v, 0x150 + N, 0xf, 0xf, true);
+}
+
 __device__ __forceinline__ double row4_sum_low16(double x)
 {
     const auto a0 = __builtin_amdgcn_permlane32_swap(__double2loint(x), __double2loint(x), false, false);
@@ -271,6 +311,7 @@ __device__ __noinline__ void band_matvec(const gdouble* Mb, int bl, int br, int 
     }
 }
 
+#if !defined(MCQ_CORE_BAND)
 // =====================================================================================================================
 // K1: assembly
 // =====================================================================================================================
@@ -557,6 +598,7 @@ __global__ void __launch_bounds__(MCQ_NT) mcq_assemble_kernel(McqBatch B)
 #undef TSUP
 }
 
+#endif   // !defined(MCQ_CORE_BAND)
 // =====================================================================================================================
 // K2: H = E'E (bordered band) and f
 // =====================================================================================================================
@@ -681,6 +723,7 @@ __device__ __forceinline__ void gram_tile_class(const double* a, const double* s
         res[m] = acc0 + acc1;
     }
 }
+#if !defined(MCQ_CORE_BAND)
 
 // H[i, i+k] = sum_{o >= k} E'[o][i] E'[o-k][i+k]  (o, o-k = 0-based diagonal indices of the 65-wide E' band).
 // One workgroup per tile of 64 rows: the 65 x 128 block of E' it touches (columns i0 .. i0+127) is staged once in LDS
@@ -893,9 +936,11 @@ __global__ void __launch_bounds__(MCQ_NT) mcq_gram_kernel(McqBatch B)
     gram_bordered(w.Et, nullptr, d, nm, nullptr, w.H, tid, nthreads, f0, f1);
 }
 
+#endif   // !defined(MCQ_CORE_BAND)
 // =====================================================================================================================
 // K3: solver
 // =====================================================================================================================
+#if !defined(MCQ_CORE_BAND)
 // =====================================================================================================================
 // K1': assembly of the shortest-path QP (tph.opt_shortest_path, call site
 //      [REF main_globaltraj.py:286-290]):   minimise  sum_i |p_{i+1} + a_{i+1} n_{i+1} - p_i - a_i n_i|^2   over the ring,
@@ -987,6 +1032,7 @@ __global__ void __launch_bounds__(MCQ_NT) mcq_assemble_sp_kernel(McqBatch B)
 #undef SP_OFF
 }
 
+#endif   // !defined(MCQ_CORE_BAND)
 #ifndef MCQ_IPM_TOL
 #define MCQ_IPM_TOL 1e-10
 #endif
@@ -1054,6 +1100,7 @@ struct SolveCtx {
 // default build: ticks[4] / ticks[5] = wave 0's forward / backward interior sweeps (part of ticks[1]), two samples per solve
 #define STICK() (MCQ_FINE_TIMERS ? 0LL : TICK())
 
+#if defined(MCQ_CORE_BAND)
 // ---- bordered-band Cholesky of  M = H + diag(sig)  with rows/cols of pinned variables replaced by identity ----------
 // Blocked right-looking factorisation, 16 columns per step, on an LDS window of 5 x 5 band tiles + 6 x 4 border tiles:
 //   phase 1  wave 0 factors the 16x16 diagonal tile in registers (left-looking, v_readlane broadcasts, no LDS trips);
@@ -1255,11 +1302,6 @@ __device__ __forceinline__ void tile_row_commit_fast(double* bt, double* ct, con
 // (a[k] = L[i][k]); left-looking by columns, the multipliers L[j][k] are v_readlane broadcasts.  The same multipliers give
 // the inverse M = L^-1 by rows for free: lane c holds column c of M,  M[j][c] = rs_j ( [j == c] - sum_{k<j} L[j][k] M[k][c] ).
 // Writes M (row-major, upper part zero) to `lv`; returns true if a pivot is not positive.
-// Broadcast of lane N of every 16-lane row to the whole row: one v_mov_b64_dpp row_newbcast (full-rate VALU, no SGPR round trip).
-template <int N> __device__ __forceinline__ double bcast_row16(double v)
-{
-    return __builtin_amdgcn_update_dpp(0.0, v, 0x150 + N, 0xf, 0xf, true);
-}
 
 #ifdef MCQ_DIAG_READLANE
 __device__ __forceinline__ bool diag_tile_inv(const double* d0, double* lv, int l15)
@@ -1996,17 +2038,24 @@ __device__ __noinline__ int factor_t(const SolveCtx& c, const gdouble* Hsrc, con
     return 0;
 }
 
+#else
 #include "mcq_kkt.inc"
+#endif
 
 __device__ __noinline__ int factor(const SolveCtx& c, const gdouble* Hsrc, const gdouble* sig, const gschar* mk, gdouble* fv)
 {
-    if (MCQ_KKT && !__builtin_amdgcn_readfirstlane(c.direct)) return factor_kkt(c, sig, mk, c.kkt_w, MCQ_FUSE_FWD ? fv : nullptr);
+#if defined(MCQ_CORE_BAND)
     // the configurations the solver uses: interior point (diagonal added; variables with lo == hi masked -- usually there are
     // none, then no mask bytes are fetched at all) and active set (mask only); fv: see factor_t
     if (sig) return mk ? factor_t<true, true>(c, Hsrc, sig, mk, fv) : factor_t<false, true>(c, Hsrc, sig, mk, fv);
     return factor_t<true, false>(c, Hsrc, sig, mk, fv);
+#else
+    (void)Hsrc;
+    return factor_kkt(c, sig, mk, c.kkt_w, MCQ_FUSE_FWD ? fv : nullptr);
+#endif
 }
 
+#if defined(MCQ_CORE_BAND)
 // ---- solve  M v = rhs  in place (v in global memory) with the factor produced by factor() ---------------------------
 // Interior triangular sweeps, one 16-row tile per step on wave 0, no serial per-row chain:
 //   s    = rhs_tile - sum over the 4 previous (next) tiles of L-tile x unknowns      64 lanes = 16 rows x 4 tiles, 16 FMAs
@@ -2236,9 +2285,12 @@ __device__ __noinline__ void sweep_bwd_wave0(const SolveCtx& c, gdouble* v)
 
 // fwd_done: the interior forward substitution and the border sums W'y were produced by factor(..., fv = v) (v holds y_B, the sums
 // sit where the loader waves leave theirs): start at the border system.
+#endif   // MCQ_CORE_BAND
 __device__ __noinline__ void solve(const SolveCtx& c, gdouble* v, bool fwd_done)
 {
-    if (MCQ_KKT && !__builtin_amdgcn_readfirstlane(c.direct)) { solve_kkt(c, v, fwd_done); return; }
+#if !defined(MCQ_CORE_BAND)
+    solve_kkt(c, v, fwd_done);
+#else
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     const int l15 = lane & 15, l4 = lane >> 4;
     const int b = c.d.b, p = c.d.p, ni = c.d.ni;
@@ -2430,6 +2482,7 @@ __device__ __noinline__ void solve(const SolveCtx& c, gdouble* v, bool fwd_done)
 #undef WOK
 #undef WROW
 #undef RHS_SUB
+#endif   // MCQ_CORE_BAND
 }
 
 // g = E'(E x + F_SCALE k_ref + extra)      (tmp: scratch vector; extra may be nullptr)
@@ -3105,7 +3158,7 @@ __device__ void kappa_lu_factor(const KappaMem& K, int nk)
 {
     const int tid = threadIdx.x;
     __syncthreads();
-    if (K.in_lds) {
+    if (K.in_lds && nk * nk <= OVL_SIZE) {          // (the saddle-point core's overlay holds 86 x 86: beyond that the elimination runs in HBM)
         double* A = g_sm + SM_OVL;                       // nk x nk, leading dimension nk
         for (int e = tid; e < nk * nk; e += MCQ_NT) A[e] = K.sg[(size_t)(e / nk) * K.ld + (e % nk)];
         __syncthreads();
@@ -3148,7 +3201,7 @@ __device__ void kappa_lu_solve(const KappaMem& K, int nk)
     const int tid = threadIdx.x;
     __syncthreads();
     for (int q = tid; q < nk; q += MCQ_NT) K.kmu[q] = K.krh[q];
-    if (K.in_lds) {
+    if (K.in_lds && nk * nk <= OVL_SIZE) {
         double* A = g_sm + SM_OVL;
         for (int e = tid; e < nk * nk; e += MCQ_NT) A[e] = K.sg[(size_t)(e / nk) * K.ld + (e % nk)];
         __syncthreads();
@@ -3408,7 +3461,11 @@ __device__ __noinline__ int active_set(SolveCtx& c, const McqBatch& B, bool with
     return MCQ_ITER_CAP;
 }
 
+#if defined(MCQ_CORE_BAND)
 __global__ void __launch_bounds__(MCQ_NT) mcq_solve_kernel(McqBatch B)
+#else
+__global__ void __launch_bounds__(MCQ_NT, 2) mcq_solve_kernel(McqBatch B)
+#endif
 {
     const int tid = threadIdx.x;
     int n;
@@ -3445,6 +3502,16 @@ __global__ void __launch_bounds__(MCQ_NT) mcq_solve_kernel(McqBatch B)
     gdouble* Q = VEC(c.w, nm, V_Q);
     gschar* ST = c.w.state;
 
+#if !defined(MCQ_CORE_BAND)
+    {   // f = F_SCALE E' k_ref: the Gram kernels that used to produce it together with the band of H are not launched for this core
+        gdouble* Fw = VEC(c.w, nm, V_F);
+        __syncthreads();
+        band_matvec(c.w.Et, c.d.bR, c.d.bE, n, nm, VEC(c.w, nm, V_KREF), nullptr, 0.0, Fw);
+        __syncthreads();
+        for (int i = tid; i < n; i += MCQ_NT) Fw[i] *= MCQ_F_SCALE;
+        __syncthreads();
+    }
+#endif
     // ---- scalars: scales for the tolerances, initial gradient at the box centre -----------------------------------------
     SolveScalars sc;
     sc.kbound = kbound;
@@ -3542,8 +3609,10 @@ __global__ void __launch_bounds__(MCQ_NT) mcq_solve_kernel(McqBatch B)
         status = ipm(c, B, true, sc, it2);
         ipm_iters += it2;
         __syncthreads();
+#if defined(MCQ_CORE_BAND)
         gram_bordered(c.w.Et, nullptr, c.d, nm, nullptr, c.w.H, tid, MCQ_NT);     // restore H = E'E
         __syncthreads();
+#endif
         if (status == MCQ_OK) {
             status = active_set(c, B, true, false, B.max_as_iter, sc, it2, kkt, nact_kappa, true, kappa_mem_lds(c));
             as_iters += it2;
@@ -3632,6 +3701,7 @@ __global__ void __launch_bounds__(MCQ_NT) mcq_solve_kernel(McqBatch B)
     }
 }
 
+#if !defined(MCQ_CORE_BAND)
 // =====================================================================================================================
 // K4: IQP glue -- re-linearisation on the device
 // =====================================================================================================================
@@ -4211,4 +4281,8 @@ __global__ void __launch_bounds__(64) mcq_widen_rows_kernel(const float* rows, c
         y += (double)src[4 * i + 1] - cy;
     }
 }
+#endif   // !defined(MCQ_CORE_BAND)
 
+#if defined(MCQ_CORE_BAND)
+}   // namespace mcq_band
+#endif

@@ -13,23 +13,17 @@ mkdir -p $OUT /tmp/mcq_base/csrc /tmp/mcq_base/include_dir
 rm -f $OUT/*.so
 BASE_REV=${BASE_REV:-436904a}
 if [ "$BASE_REV" != "none" ]; then
-  git -C $R show $BASE_REV:global_racetrajectory_optimization_amd/csrc/mcq_kernels.hip > /tmp/mcq_base/csrc/mcq_kernels.hip
-  # kernels added to the C ABI since BASE_REV (not on the measured path)
-  python3 - <<PY
-import re
-new = open("$SRC/mcq_kernels.hip").read()
-k = new[new.index("// ---- fp32 rows, increment layout"):]
-open("/tmp/mcq_base/csrc/mcq_kernels.hip", "a").write("\n" + k)
-PY
-  cp $SRC/mcq_kernels.h $SRC/mcq_api.hip /tmp/mcq_base/csrc/
-  mkdir -p /tmp/mcq_base/include && cp $R/include/mcq.h /tmp/mcq_base/include/
+  # the whole csrc of BASE_REV (its own C ABI: entries added since are missing -- variants scripts only call what round 2 had)
+  rm -rf /tmp/mcq_base && mkdir -p /tmp/mcq_base/csrc /tmp/mcq_base/include
+  for f in mcq_kernels.hip mcq_kernels.h mcq_api.hip; do git -C $R show $BASE_REV:global_racetrajectory_optimization_amd/csrc/$f > /tmp/mcq_base/csrc/$f; done
+  git -C $R show $BASE_REV:include/mcq.h > /tmp/mcq_base/include/mcq.h
   sed -i 's#"../../include/mcq.h"#"../include/mcq.h"#' /tmp/mcq_base/csrc/mcq_kernels.h
-  (cd /tmp/mcq_base/csrc && $HIPCC $FLAGS -o $OUT/libmcq_00base.so mcq_kernels.hip mcq_api.hip)
-  echo "built 00base ($BASE_REV kernels)"
+  (cd /tmp/mcq_base/csrc && $HIPCC $FLAGS -o $OUT/libmcq_00base.so mcq_kernels.hip mcq_api.hip) || echo "base build failed"
+  echo "built 00base ($BASE_REV)"
 fi
 while [ $# -ge 2 ]; do
   name=$1; defs=$2; shift 2
-  (cd $SRC && $HIPCC $FLAGS $defs -o $OUT/libmcq_$name.so mcq_kernels.hip mcq_api.hip)
+  OUT=$OUT/libmcq_$name.so $SRC/build.sh $defs
   echo "built $name ($defs)"
 done
 ls -la $OUT

@@ -9,19 +9,20 @@ s[98:99]; found with rocgdb).  Exit code 1 if anything is found.     scripts/che
 import re, subprocess, sys, os, tempfile
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 src = os.path.join(ROOT, "global_racetrajectory_optimization_amd", "csrc", "mcq_kernels.hip")
-out = os.path.join(tempfile.gettempdir(), "mcq_check_csr.s")
-cmd = ["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-mllvm", "-amdgpu-mfma-vgpr-form", "-mllvm", "-enable-ipra=0",
-       "-S", "--cuda-device-only", "-o", out, src] + sys.argv[1:]
-subprocess.run(cmd, check=True, stderr=subprocess.DEVNULL)
+base = ["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-mllvm", "-amdgpu-mfma-vgpr-form", "-mllvm", "-enable-ipra=0",
+        "-S", "--cuda-device-only"]
 funcs, cur = {}, None
-for ln in open(out):
-    m = re.match(r"^(_Z\w+):", ln)
-    if m:
-        cur = m.group(1); funcs[cur] = []; continue
-    if ln.startswith(".Lfunc_end"):
-        cur = None; continue
-    if cur:
-        funcs[cur].append(ln)
+for tag, extra in (("kkt", ["--gpu-max-threads-per-block=512"]), ("band", ["-DMCQ_CORE_BAND"])):      # the two translation units of csrc/build.sh
+    out = os.path.join(tempfile.gettempdir(), "mcq_check_csr_%s.s" % tag)
+    subprocess.run(base + extra + ["-o", out, src] + sys.argv[1:], check=True, stderr=subprocess.DEVNULL)
+    for ln in open(out):
+        m = re.match(r"^(_Z\w+):", ln)
+        if m:
+            cur = tag + ":" + m.group(1); funcs[cur] = []; continue
+        if ln.startswith(".Lfunc_end"):
+            cur = None; continue
+        if cur:
+            funcs[cur].append(ln)
 csr = set(range(34, 40)) | set(range(48, 56)) | set(range(64, 72)) | set(range(80, 88)) | set(range(96, 104))
 SKIP = ("s_cbranch", "s_branch", "s_waitcnt", "s_nop", "s_barrier", "s_setpc", "s_endpgm", "s_sleep", "s_cmp", "s_bitcmp")
 SECOND = ("v_div_scale", "v_add_co", "v_sub_co", "v_addc_co", "v_subb_co", "v_mad_u64", "v_mad_i64")

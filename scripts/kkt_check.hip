@@ -11,7 +11,7 @@
 #include <vector>
 #include <cmath>
 
-__global__ void __launch_bounds__(MCQ_NT) kc_kernel(McqBatch B, int reps, const double* rhs0, double* out, int* fsout, int fused)
+__global__ void __launch_bounds__(MCQ_NT, 2) kc_kernel(McqBatch B, int reps, const double* rhs0, double* out, int* fsout, int fused)
 {
     int n;
     double kb, wv;

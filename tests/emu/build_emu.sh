@@ -4,4 +4,10 @@
 set -e
 cd "$(dirname "$0")"
 SRC=../../global_racetrajectory_optimization_amd/csrc
-g++ -O2 -std=c++17 -fPIC -shared -x c++ -I include -o libmcq_emu.so $SRC/mcq_kernels.hip $SRC/mcq_api.hip -Wno-unused-result -Wno-attributes
+# mcq_kernels.hip twice, like csrc/build.sh: the library's kernels (saddle-point core) and namespace mcq_band (bordered-band core)
+F="-O2 -std=c++17 -fPIC -x c++ -I include -Wno-unused-result -Wno-attributes"
+g++ $F -c -o /tmp/mcq_emu_kkt.o $SRC/mcq_kernels.hip &
+g++ $F -DMCQ_CORE_BAND -c -o /tmp/mcq_emu_band.o $SRC/mcq_kernels.hip &
+g++ $F -c -o /tmp/mcq_emu_api.o $SRC/mcq_api.hip &
+wait
+g++ -shared -fPIC -o libmcq_emu.so /tmp/mcq_emu_kkt.o /tmp/mcq_emu_band.o /tmp/mcq_emu_api.o
