@@ -20,4 +20,4 @@ echo "force-collective rc $?"
 timeout 900 python bench.py --config 5 --steps 2 --warmup 1 --no-extras > gpurun_out/${T}_config5_shard_1gpu.json 2> gpurun_out/${T}_config5.err
 echo "config5 rc $?"; cut -c1-300 gpurun_out/${T}_config5_shard_1gpu.json
 scripts/profile_round.sh $T 2>&1 | grep "pmc\|calib" | tr '\n' ' '
-scripts/gpu_fb.sh ${T}_final > /dev/null 2>&1
+timeout 120 ./build/kc/kc 2000 6 2048 12 0 1 > gpurun_out/${T}_kkt_check_fused.txt 2>&1; timeout 120 ./build/kc/kc 2000 6 2048 12 0 0 > gpurun_out/${T}_kkt_check_plain.txt 2>&1; timeout 300 ./build/kc/kc 333 20 8 14 1 0 > gpurun_out/${T}_kkt_check_n333_reference.txt 2>&1
