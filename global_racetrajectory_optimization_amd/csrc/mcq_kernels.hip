@@ -3564,7 +3564,12 @@ __global__ void __launch_bounds__(MCQ_NT, 2) mcq_solve_kernel(McqBatch B)
     }
     const int as_warm = warm_done ? 0 : as_iters;
     int status = MCQ_OK;
+    const long long t_ipm0 = TICK();
     if (!warm_done) status = small ? ipm_box(c, B, sc, ipm_iters, MCQ_IPM_TOL, false) : ipm(c, B, false, sc, ipm_iters);
+#if !defined(MCQ_CORE_BAND)
+    c.tk[4] = TICK() - t_ipm0;          // wall time of the interior-point phase (ticks[4]; the band core reports its forward sweeps there)
+    const long long t_as0 = TICK();
+#endif
     if (warm_done) {
     } else if (status == MCQ_OK && small) {
         // Two attempts.  The pairs at mu = 1e-10 identify the active set of all but the degenerate / extremely
@@ -3591,6 +3596,10 @@ __global__ void __launch_bounds__(MCQ_NT, 2) mcq_solve_kernel(McqBatch B)
         status = active_set(c, B, false, ipm_iters >= 1 && c.last_step >= 0.9, B.max_as_iter, sc, as_iters, kkt, nk_dummy, true, kappa_mem_lds(c));
     }
     as_iters += as_warm;        // rounds of an abandoned warm start are reported too
+#if !defined(MCQ_CORE_BAND)
+    c.tk[5] = TICK() - t_as0;           // wall time of the active-set phase (ticks[5])
+    const long long t_epi0 = TICK();
+#endif
 
     // kappa(alpha) = k_ref + E alpha
     for (int i = tid; i < n; i += MCQ_NT) X[i] = fmin(fmax(X[i], LO[i]), HI[i]);
@@ -3693,6 +3702,9 @@ __global__ void __launch_bounds__(MCQ_NT, 2) mcq_solve_kernel(McqBatch B)
                 o.refine_rounds = c.refine_rounds;
                 o.second_attempt = c.second_attempt;
                 c.tk[3] = TICK() - t_kernel0;
+#if !defined(MCQ_CORE_BAND)
+                c.tk[7] = TICK() - t_epi0;          // curvature check, (rare) curvature-row phase, outputs (ticks[7])
+#endif
                 if (!MCQ_FINE_TIMERS) c.tk[6] = (long long)clock64() - c_kernel0;
                 for (int q = 0; q < 8; ++q) o.ticks[q] = (MCQ_WORKER_TIMERS || MCQ_SOLVE_TIMERS) ? ((const long long*)c.w.Z)[q] : c.tk[q];
                 *(mcq_info*)c.w.info = o;
