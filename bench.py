@@ -103,7 +103,7 @@ def source_sha():
     import hashlib
     h = hashlib.sha256()
     base = os.path.join(ROOT, "global_racetrajectory_optimization_amd", "csrc")
-    for name in ("build.sh", "mcq_api.hip", "mcq_kernels.h", "mcq_kernels.hip", "mcq_kkt.inc"):
+    for name in ("build.sh", "mcq_api.hip", "mcq_kernels.h", "mcq_kernels.hip", "mcq_kkt.inc", "mcq_tri.inc"):
         with open(os.path.join(base, name), "rb") as fh:
             h.update(name.encode() + b"\0" + fh.read())
     return h.hexdigest()

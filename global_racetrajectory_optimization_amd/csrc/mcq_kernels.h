@@ -47,7 +47,7 @@
 #define MCQ_LLD 144                /* L rows: 64 band entries | 16 inverse-diagonal-tile entries | 64 border entries */
 #define MCQ_LBI 64                 /* offset of the inverse diagonal tile row inside an L row */
 #define MCQ_LBW 80                 /* offset of the border part W inside an L row */
-#define MCQ_NVEC 30
+#define MCQ_NVEC 32
 #define MCQ_KMAX 120               /* active curvature rows the Schur-complement path of the active-set phase holds */
 #define MCQ_KBIG 512               /* ... and of the overflow path (round 3): a problem with more of them claims one of the handle's slots, */
 #define MCQ_KBIG_SLOT ((size_t)MCQ_KBIG * MCQ_KBIG + 6 * (size_t)MCQ_KBIG)   /* doubles per slot: Schur matrix, three vectors, the index / sign / pivot lists */
@@ -108,7 +108,8 @@ struct McqWork {
 
 enum {
     V_XP = 0, V_YP, V_CP, V_KREF, V_XPP, V_YPP, V_F, V_LO, V_HI, V_X, V_G, V_ZL, V_ZU, V_SIG, V_RHS, V_DXA, V_T0, V_T1,
-    V_T2, V_T3, V_TL, V_TU, V_YL, V_YU, V_SK, V_EDA, V_Q, V_NX, V_NY, V_SC    /* unit normals and spline scalings as used (given or derived) */
+    V_T2, V_T3, V_TL, V_TU, V_YL, V_YU, V_SK, V_EDA, V_Q, V_NX, V_NY, V_SC,   /* unit normals and spline scalings as used (given or derived) */
+    V_IDL, V_TUC        /* saddle-point core: 1 / pivot and super-diagonal of the spline matrix T (mcq_tri.inc) */
 };
 
 struct McqBatch {

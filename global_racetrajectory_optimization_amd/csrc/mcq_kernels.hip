@@ -2040,6 +2040,7 @@ __device__ __noinline__ int factor_t(const SolveCtx& c, const gdouble* Hsrc, con
 
 #else
 #include "mcq_kkt.inc"
+#include "mcq_tri.inc"
 #endif
 
 __device__ __noinline__ int factor(const SolveCtx& c, const gdouble* Hsrc, const gdouble* sig, const gschar* mk, gdouble* fv)
@@ -2497,6 +2498,18 @@ __device__ __noinline__ void gradient(SolveCtx& c, const gdouble* x, const gdoub
         c.tk[2] += TICK() - t0;
         return;
     }
+#if !defined(MCQ_CORE_BAND)
+    if (tri_usable(c)) {        // E and E' through the spline system itself (mcq_tri.inc): no band is read
+        tri_apply_E(c, x, VEC(c.w, c.nm, V_KREF), MCQ_F_SCALE, tmp);
+        if (extra) {
+            for (int i = threadIdx.x; i < n; i += MCQ_NT) tmp[i] += extra[i];
+            __syncthreads();
+        }
+        tri_apply_Et(c, tmp, g);
+        c.tk[2] += TICK() - t0;
+        return;
+    }
+#endif
     band_matvec(c.w.Eb, c.d.bE, c.d.bR, n, c.nm, x, VEC(c.w, c.nm, V_KREF), MCQ_F_SCALE, tmp);
     __syncthreads();
     if (extra) {
@@ -2828,6 +2841,7 @@ __device__ __noinline__ int ipm(SolveCtx& c, const McqBatch& B, bool with_kappa,
 // generic routine above does seven dependent passes.  Arithmetic and summation order are those of ipm().
 // ---------------------------------------------------------------------------------------------------------------------
 #define IPB_E 8
+#define IPB_H 4     /* entries a pass keeps in registers at a time: two halves per pass (round 3: at 256 VGPRs -- two workgroups per CU -- eight entries of a pass's arrays spilled) */
 // `resume`: continue from the pairs (X, ZL, ZU) already in memory to the tighter tolerance `tol` -- the second attempt on
 // degenerate / very ill-conditioned instances (see the driver in mcq_solve_kernel).
 __device__ __noinline__ int ipm_box(SolveCtx& c, const McqBatch& B, const SolveScalars& sc, int& iters, double tol, bool resume)
@@ -2855,6 +2869,29 @@ __device__ __noinline__ int ipm_box(SolveCtx& c, const McqBatch& B, const SolveS
         ok[u] = tid + u * MCQ_NT < n;                                                                                  \
         idx[u] = ok[u] ? tid + u * MCQ_NT : 0;          /* entry 0 stands in for the absent ones (loaded, never stored) */ \
     }
+    // the same for one half (entries h * IPB_H .. + IPB_H) of a pass: idx / ok of IPB_H entries
+#define IPB_HALF(h)                                                                                                    \
+    int idx[IPB_H];                                                                                                    \
+    bool ok[IPB_H];                                                                                                    \
+    _Pragma("unroll") for (int u = 0; u < IPB_H; ++u) {                                                                \
+        ok[u] = tid + ((h) * IPB_H + u) * MCQ_NT < n;                                                                  \
+        idx[u] = ok[u] ? tid + ((h) * IPB_H + u) * MCQ_NT : 0;                                                         \
+    }
+#define IPB_PTRS                                                                                                       \
+    const int tid = threadIdx.x, n = c.d.n, nm = c.nm;                                                                 \
+    double* red = g_sm + SM_RED;                                                                                       \
+    const gdouble* LO = VEC(c.w, nm, V_LO);                                                                            \
+    const gdouble* HI = VEC(c.w, nm, V_HI);                                                                            \
+    gdouble* X = VEC(c.w, nm, V_X);                                                                                    \
+    gdouble* G = VEC(c.w, nm, V_G);                                                                                    \
+    gdouble* ZL = VEC(c.w, nm, V_ZL);                                                                                  \
+    gdouble* ZU = VEC(c.w, nm, V_ZU);                                                                                  \
+    gdouble* SIG = VEC(c.w, nm, V_SIG);                                                                                \
+    gdouble* RHS = VEC(c.w, nm, V_RHS);                                                                                \
+    gdouble* DXA = VEC(c.w, nm, V_DXA);                                                                                \
+    gschar* ST = c.w.state;                                                                                            \
+    gdouble* IND = VEC(c.w, nm, V_T3);                                                                                 \
+    (void)IND; (void)red; (void)LO; (void)HI; (void)X; (void)G; (void)ZL; (void)ZU; (void)SIG; (void)RHS; (void)DXA; (void)ST;
     const double zscale = sc.zscale;
     const double IPM_TOL = tol;
     iters = 0;
@@ -2887,26 +2924,30 @@ __device__ __noinline__ int ipm_box(SolveCtx& c, const McqBatch& B, const SolveS
         // ---- pass 1: complementarity, dual residual, sig, predictor right-hand side ----------------------------------------
         double mu;
         for (;;) {
-            IPB_SETUP
-            double x[IPB_E], lo[IPB_E], hi[IPB_E], zl[IPB_E], zu[IPB_E], g[IPB_E];
-            int st[IPB_E];
-#pragma unroll
-            for (int u = 0; u < IPB_E; ++u) {
-                const int i = idx[u];
-                st[u] = ST[i]; x[u] = X[i]; lo[u] = LO[i]; hi[u] = HI[i]; zl[u] = ZL[i]; zu[u] = ZU[i]; g[u] = G[i];
-            }
+            IPB_PTRS
             double rdm = 0.0;
             mu = 0.0;
 #pragma unroll
-            for (int u = 0; u < IPB_E; ++u) {
-                if (!ok[u]) continue;
-                const int i = idx[u];
-                if (st[u] != 0) { RHS[i] = 0.0; continue; }
-                const double sl = x[u] - lo[u], su = hi[u] - x[u];
-                mu += sl * zl[u] + su * zu[u];
-                rdm = fmax(rdm, fabs(g[u] - zl[u] + zu[u]));
-                SIG[i] = zl[u] / sl + zu[u] / su;
-                RHS[i] = -g[u];
+            for (int h = 0; h < IPB_E / IPB_H; ++h) {
+                IPB_HALF(h)
+                double x[IPB_H], lo[IPB_H], hi[IPB_H], zl[IPB_H], zu[IPB_H], g[IPB_H];
+                int st[IPB_H];
+#pragma unroll
+                for (int u = 0; u < IPB_H; ++u) {
+                    const int i = idx[u];
+                    st[u] = ST[i]; x[u] = X[i]; lo[u] = LO[i]; hi[u] = HI[i]; zl[u] = ZL[i]; zu[u] = ZU[i]; g[u] = G[i];
+                }
+#pragma unroll
+                for (int u = 0; u < IPB_H; ++u) {
+                    if (!ok[u]) continue;
+                    const int i = idx[u];
+                    if (st[u] != 0) { RHS[i] = 0.0; continue; }
+                    const double sl = x[u] - lo[u], su = hi[u] - x[u];
+                    mu += sl * zl[u] + su * zu[u];
+                    rdm = fmax(rdm, fabs(g[u] - zl[u] + zu[u]));
+                    SIG[i] = zl[u] / sl + zu[u] / su;
+                    RHS[i] = -g[u];
+                }
             }
             block_reduce2_(mu, 0, rdm, 2, red);
             mu /= npairs;
@@ -2938,57 +2979,93 @@ __device__ __noinline__ int ipm_box(SolveCtx& c, const McqBatch& B, const SolveS
         if (fs != 0) return (resume && fs == MCQ_NOT_PD) ? MCQ_OK : fs;
         timed_solve(c, VEC(c.w, c.nm, V_RHS), MCQ_FUSE_FWD != 0);
 
-        // ---- pass 2: affine step lengths, centring parameter, corrector right-hand side (one load phase) --------------
+        // ---- pass 2: affine step lengths, centring parameter, corrector right-hand side (three load phases of half the entries each:
+        //      what a phase needs again after a block reduction is reloaded -- L2 hits -- instead of living in registers across it) ----
         double smu;
         {
-            IPB_SETUP
-            double dxa[IPB_E], sl[IPB_E], su[IPB_E], zl[IPB_E], zu[IPB_E], g[IPB_E];
-            bool act[IPB_E];
-#pragma unroll
-            for (int u = 0; u < IPB_E; ++u) {
-                const int i = idx[u];
-                const double x = X[i];
-                act[u] = ok[u] && ST[i] == 0;
-                dxa[u] = RHS[i]; sl[u] = x - LO[i]; su[u] = HI[i] - x; zl[u] = ZL[i]; zu[u] = ZU[i]; g[u] = G[i];
-            }
+            IPB_PTRS
             double ap = 1.0, ad = 1.0;
-            double dzla[IPB_E], dzua[IPB_E];
 #pragma unroll
-            for (int u = 0; u < IPB_E; ++u) {
-                if (!ok[u]) continue;
-                if (!act[u]) { DXA[idx[u]] = 0.0; continue; }
-                const double dx = dxa[u];
-                DXA[idx[u]] = dx;
-                dzla[u] = -zl[u] - zl[u] * dx / sl[u];
-                dzua[u] = -zu[u] + zu[u] * dx / su[u];
-                if (dx < 0.0) ap = fmin(ap, -sl[u] / dx);
-                if (dx > 0.0) ap = fmin(ap, su[u] / dx);
-                if (dzla[u] < 0.0) ad = fmin(ad, -zl[u] / dzla[u]);
-                if (dzua[u] < 0.0) ad = fmin(ad, -zu[u] / dzua[u]);
+            for (int h = 0; h < IPB_E / IPB_H; ++h) {
+                IPB_HALF(h)
+                double dxa[IPB_H], sl[IPB_H], su[IPB_H], zl[IPB_H], zu[IPB_H];
+                bool act[IPB_H];
+#pragma unroll
+                for (int u = 0; u < IPB_H; ++u) {
+                    const int i = idx[u];
+                    const double x = X[i];
+                    act[u] = ok[u] && ST[i] == 0;
+                    dxa[u] = RHS[i]; sl[u] = x - LO[i]; su[u] = HI[i] - x; zl[u] = ZL[i]; zu[u] = ZU[i];
+                }
+#pragma unroll
+                for (int u = 0; u < IPB_H; ++u) {
+                    if (!ok[u]) continue;
+                    if (!act[u]) { DXA[idx[u]] = 0.0; continue; }
+                    const double dx = dxa[u];
+                    DXA[idx[u]] = dx;
+                    const double dzla = -zl[u] - zl[u] * dx / sl[u];
+                    const double dzua = -zu[u] + zu[u] * dx / su[u];
+                    if (dx < 0.0) ap = fmin(ap, -sl[u] / dx);
+                    if (dx > 0.0) ap = fmin(ap, su[u] / dx);
+                    if (dzla < 0.0) ad = fmin(ad, -zl[u] / dzla);
+                    if (dzua < 0.0) ad = fmin(ad, -zu[u] / dzua);
+                }
             }
             block_reduce2_(ap, 1, ad, 1, red);
             double mua = 0.0;
 #pragma unroll
-            for (int u = 0; u < IPB_E; ++u) {
-                if (!act[u]) continue;
-                mua += (sl[u] + ap * dxa[u]) * (zl[u] + ad * dzla[u]) + (su[u] - ap * dxa[u]) * (zu[u] + ad * dzua[u]);
+            for (int h = 0; h < IPB_E / IPB_H; ++h) {
+                IPB_HALF(h)
+                double dxa[IPB_H], sl[IPB_H], su[IPB_H], zl[IPB_H], zu[IPB_H];
+                bool act[IPB_H];
+#pragma unroll
+                for (int u = 0; u < IPB_H; ++u) {
+                    const int i = idx[u];
+                    const double x = X[i];
+                    act[u] = ok[u] && ST[i] == 0;
+                    dxa[u] = RHS[i]; sl[u] = x - LO[i]; su[u] = HI[i] - x; zl[u] = ZL[i]; zu[u] = ZU[i];
+                }
+#pragma unroll
+                for (int u = 0; u < IPB_H; ++u) {
+                    if (!act[u]) continue;
+                    const double dzla = -zl[u] - zl[u] * dxa[u] / sl[u];
+                    const double dzua = -zu[u] + zu[u] * dxa[u] / su[u];
+                    mua += (sl[u] + ap * dxa[u]) * (zl[u] + ad * dzla) + (su[u] - ap * dxa[u]) * (zu[u] + ad * dzua);
+                }
             }
             mua = block_reduce_(mua, 0, red) / npairs;
             const double ratio = mua / mu;
             smu = ratio * ratio * ratio * mu;
 #pragma unroll
-            for (int u = 0; u < IPB_E; ++u) {
-                if (!ok[u]) continue;
-                RHS[idx[u]] = act[u] ? -g[u] + (smu - dxa[u] * dzla[u]) / sl[u] - (smu + dxa[u] * dzua[u]) / su[u] : 0.0;
+            for (int h = 0; h < IPB_E / IPB_H; ++h) {
+                IPB_HALF(h)
+                double dxa[IPB_H], sl[IPB_H], su[IPB_H], zl[IPB_H], zu[IPB_H], g[IPB_H];
+                bool act[IPB_H];
+#pragma unroll
+                for (int u = 0; u < IPB_H; ++u) {
+                    const int i = idx[u];
+                    const double x = X[i];
+                    act[u] = ok[u] && ST[i] == 0;
+                    dxa[u] = DXA[i]; sl[u] = x - LO[i]; su[u] = HI[i] - x; zl[u] = ZL[i]; zu[u] = ZU[i]; g[u] = G[i];
+                }
+#pragma unroll
+                for (int u = 0; u < IPB_H; ++u) {
+                    if (!ok[u]) continue;
+                    const double dzla = -zl[u] - zl[u] * dxa[u] / sl[u];
+                    const double dzua = -zu[u] + zu[u] * dxa[u] / su[u];
+                    RHS[idx[u]] = act[u] ? -g[u] + (smu - dxa[u] * dzla) / sl[u] - (smu + dxa[u] * dzua) / su[u] : 0.0;
+                }
             }
         }
         timed_solve(c, VEC(c.w, c.nm, V_RHS));
 
-        // ---- pass 3: step length of the combined direction, update (one load phase) -------------------------------------
+        // ---- pass 3: step length of the combined direction, update (two load phases of half the entries each; the multiplier steps
+        //      and H dx go through the scratch vectors T1, T2, T0 across the block reduction) ---------------------------------------
         {
-            IPB_SETUP
-            double dx[IPB_E], x[IPB_E], zl[IPB_E], zu[IPB_E], g[IPB_E], dzl[IPB_E], dzu[IPB_E], hdx[IPB_E];
-            bool act[IPB_E];
+            IPB_PTRS
+            gdouble* DZL = VEC(c.w, nm, V_T1);
+            gdouble* DZU = VEC(c.w, nm, V_T2);
+            gdouble* HDX = VEC(c.w, nm, V_T0);
             // fraction of the way to the boundary: 0.995 far from the solution, closer to 1 as the complementarity shrinks
             // (Mehrotra's adaptive rule; saves a third of an iteration on average, scripts/proto_ipm.py "adaptive step")
 #ifdef MCQ_IPM_FIXED_STEP
@@ -2997,46 +3074,66 @@ __device__ __noinline__ int ipm_box(SolveCtx& c, const McqBatch& B, const SolveS
             const double gm = fmin(fmax(MCQ_IPM_GM_MIN, 1.0 - MCQ_IPM_GM_C * mu / (zscale * sc.wmean)), 1.0 - 1e-9);
 #endif
             double amax = 1.0 / gm;
-            double da[IPB_E], lo[IPB_E], hi[IPB_E], sg[IPB_E];
 #pragma unroll
-            for (int u = 0; u < IPB_E; ++u) {
-                const int i = idx[u];
-                act[u] = ok[u] && ST[i] == 0;
-                dx[u] = RHS[i]; da[u] = DXA[i]; x[u] = X[i]; lo[u] = LO[i]; hi[u] = HI[i]; zl[u] = ZL[i]; zu[u] = ZU[i];
-                g[u] = G[i]; sg[u] = SIG[i];
-            }
+            for (int h = 0; h < IPB_E / IPB_H; ++h) {
+                IPB_HALF(h)
+                double dx[IPB_H], da[IPB_H], x[IPB_H], lo[IPB_H], hi[IPB_H], zl[IPB_H], zu[IPB_H], g[IPB_H], sg[IPB_H];
+                bool act[IPB_H];
 #pragma unroll
-            for (int u = 0; u < IPB_E; ++u) {
-                if (!act[u]) continue;
-                const double sl = x[u] - lo[u], su = hi[u] - x[u];
-                const double dzla = -zl[u] - zl[u] * da[u] / sl, dzua = -zu[u] + zu[u] * da[u] / su;
-                dzl[u] = (-sl * zl[u] + smu - da[u] * dzla - zl[u] * dx[u]) / sl;
-                dzu[u] = (-su * zu[u] + smu + da[u] * dzua + zu[u] * dx[u]) / su;
-                // H dx = (corrector right-hand side) - sig dx
-                const double rc = -g[u] + (smu - da[u] * dzla) / sl - (smu + da[u] * dzua) / su;
-                hdx[u] = rc - sg[u] * dx[u];
-                if (dx[u] < 0.0) amax = fmin(amax, -sl / dx[u]);
-                if (dx[u] > 0.0) amax = fmin(amax, su / dx[u]);
-                if (dzl[u] < 0.0) amax = fmin(amax, -zl[u] / dzl[u]);
-                if (dzu[u] < 0.0) amax = fmin(amax, -zu[u] / dzu[u]);
+                for (int u = 0; u < IPB_H; ++u) {
+                    const int i = idx[u];
+                    act[u] = ok[u] && ST[i] == 0;
+                    dx[u] = RHS[i]; da[u] = DXA[i]; x[u] = X[i]; lo[u] = LO[i]; hi[u] = HI[i]; zl[u] = ZL[i]; zu[u] = ZU[i];
+                    g[u] = G[i]; sg[u] = SIG[i];
+                }
+#pragma unroll
+                for (int u = 0; u < IPB_H; ++u) {
+                    if (!act[u]) continue;
+                    const double sl = x[u] - lo[u], su = hi[u] - x[u];
+                    const double dzla = -zl[u] - zl[u] * da[u] / sl, dzua = -zu[u] + zu[u] * da[u] / su;
+                    const double dzl = (-sl * zl[u] + smu - da[u] * dzla - zl[u] * dx[u]) / sl;
+                    const double dzu = (-su * zu[u] + smu + da[u] * dzua + zu[u] * dx[u]) / su;
+                    // H dx = (corrector right-hand side) - sig dx
+                    const double rc = -g[u] + (smu - da[u] * dzla) / sl - (smu + da[u] * dzua) / su;
+                    DZL[idx[u]] = dzl;
+                    DZU[idx[u]] = dzu;
+                    HDX[idx[u]] = rc - sg[u] * dx[u];
+                    if (dx[u] < 0.0) amax = fmin(amax, -sl / dx[u]);
+                    if (dx[u] > 0.0) amax = fmin(amax, su / dx[u]);
+                    if (dzl < 0.0) amax = fmin(amax, -zl[u] / dzl);
+                    if (dzu < 0.0) amax = fmin(amax, -zu[u] / dzu);
+                }
             }
             amax = block_reduce_(amax, 1, red);
             const double a = fmin(1.0, gm * amax);
             c.last_step = a;
 #pragma unroll
-            for (int u = 0; u < IPB_E; ++u) {
-                if (!act[u]) continue;
-                const int i = idx[u];
-                G[i] = g[u] + a * hdx[u];
-                X[i] = x[u] + a * dx[u];
-                ZL[i] = zl[u] + a * dzl[u];
-                ZU[i] = zu[u] + a * dzu[u];
-                // Tapia indicators of this step for the active-set identification (the last step's survive)
-                const double sl = x[u] - lo[u], su = hi[u] - x[u];
-                const double rsl = (sl + a * dx[u]) * zl[u], rzl = (zl[u] + a * dzl[u]) * sl;     // s+/s < z+/z  <=>  s+ z < z+ s
-                const double rsu = (su - a * dx[u]) * zu[u], rzu = (zu[u] + a * dzu[u]) * su;
-                const bool al = rsl < MCQ_TAPIA_RATIO * rzl && sl + a * dx[u] < MCQ_TAPIA_SHRINK * sl, au = rsu < MCQ_TAPIA_RATIO * rzu && su - a * dx[u] < MCQ_TAPIA_SHRINK * su;
-                IND[i] = al ? -1.0 : (au ? 1.0 : 0.0);
+            for (int h = 0; h < IPB_E / IPB_H; ++h) {
+                IPB_HALF(h)
+                double dx[IPB_H], x[IPB_H], lo[IPB_H], hi[IPB_H], zl[IPB_H], zu[IPB_H], g[IPB_H], dzl[IPB_H], dzu[IPB_H], hdx[IPB_H];
+                bool act[IPB_H];
+#pragma unroll
+                for (int u = 0; u < IPB_H; ++u) {
+                    const int i = idx[u];
+                    act[u] = ok[u] && ST[i] == 0;
+                    dx[u] = RHS[i]; x[u] = X[i]; lo[u] = LO[i]; hi[u] = HI[i]; zl[u] = ZL[i]; zu[u] = ZU[i]; g[u] = G[i];
+                    dzl[u] = DZL[i]; dzu[u] = DZU[i]; hdx[u] = HDX[i];
+                }
+#pragma unroll
+                for (int u = 0; u < IPB_H; ++u) {
+                    if (!act[u]) continue;
+                    const int i = idx[u];
+                    G[i] = g[u] + a * hdx[u];
+                    X[i] = x[u] + a * dx[u];
+                    ZL[i] = zl[u] + a * dzl[u];
+                    ZU[i] = zu[u] + a * dzu[u];
+                    // Tapia indicators of this step for the active-set identification (the last step's survive)
+                    const double sl = x[u] - lo[u], su = hi[u] - x[u];
+                    const double rsl = (sl + a * dx[u]) * zl[u], rzl = (zl[u] + a * dzl[u]) * sl;     // s+/s < z+/z  <=>  s+ z < z+ s
+                    const double rsu = (su - a * dx[u]) * zu[u], rzu = (zu[u] + a * dzu[u]) * su;
+                    const bool al = rsl < MCQ_TAPIA_RATIO * rzl && sl + a * dx[u] < MCQ_TAPIA_SHRINK * sl, au = rsu < MCQ_TAPIA_RATIO * rzu && su - a * dx[u] < MCQ_TAPIA_SHRINK * su;
+                    IND[i] = al ? -1.0 : (au ? 1.0 : 0.0);
+                }
             }
         }
         g_exact = false;
@@ -3506,7 +3603,12 @@ __global__ void __launch_bounds__(MCQ_NT, 2) mcq_solve_kernel(McqBatch B)
     {   // f = F_SCALE E' k_ref: the Gram kernels that used to produce it together with the band of H are not launched for this core
         gdouble* Fw = VEC(c.w, nm, V_F);
         __syncthreads();
-        band_matvec(c.w.Et, c.d.bR, c.d.bE, n, nm, VEC(c.w, nm, V_KREF), nullptr, 0.0, Fw);
+        if (tri_usable(c)) {
+            tri_prepare(c);
+            tri_apply_Et(c, VEC(c.w, nm, V_KREF), Fw);
+        } else {
+            band_matvec(c.w.Et, c.d.bR, c.d.bE, n, nm, VEC(c.w, nm, V_KREF), nullptr, 0.0, Fw);
+        }
         __syncthreads();
         for (int i = tid; i < n; i += MCQ_NT) Fw[i] *= MCQ_F_SCALE;
         __syncthreads();
@@ -3606,6 +3708,10 @@ __global__ void __launch_bounds__(MCQ_NT, 2) mcq_solve_kernel(McqBatch B)
     __syncthreads();
     double km = 0.0;
     if (!c.direct) {
+#if !defined(MCQ_CORE_BAND)
+        if (tri_usable(c)) tri_apply_E(c, X, VEC(c.w, nm, V_KREF), 1.0, T0);
+        else
+#endif
         band_matvec(c.w.Eb, c.d.bE, c.d.bR, n, nm, X, VEC(c.w, nm, V_KREF), 1.0, T0);
         __syncthreads();
         for (int i = tid; i < n; i += MCQ_NT) km = fmax(km, fabs(T0[i]));
@@ -3670,8 +3776,14 @@ __global__ void __launch_bounds__(MCQ_NT, 2) mcq_solve_kernel(McqBatch B)
         if (!c.direct) {
             for (int i = tid; i < n; i += MCQ_NT) { T1[i] = VEC(c.w, nm, V_NX)[i] * X[i]; T2[i] = VEC(c.w, nm, V_NY)[i] * X[i]; }
             __syncthreads();
+#if !defined(MCQ_CORE_BAND)
+            if (tri_usable(c)) tri_apply_E(c, X, nullptr, 0.0, Q, T0, T3);      // D (n_x alpha), D (n_y alpha) are by-products of E alpha
+            else
+#endif
+            {
             band_matvec(c.w.Db, c.d.bE, c.d.bR, n, nm, T1, nullptr, 0.0, T0);   // D (n_x alpha)
             band_matvec(c.w.Db, c.d.bE, c.d.bR, n, nm, T2, nullptr, 0.0, T3);   // D (n_y alpha)
+            }
             __syncthreads();
         }
         double em = 0.0;

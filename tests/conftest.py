@@ -32,7 +32,7 @@ def emu_lib():
     import subprocess
     path = os.path.join(ROOT, "tests", "emu", "libmcq_emu.so")
     src = [os.path.join(ROOT, "global_racetrajectory_optimization_amd", "csrc", f)
-           for f in ("mcq_kernels.hip", "mcq_kernels.h", "mcq_api.hip", "mcq_kkt.inc")]
+           for f in ("mcq_kernels.hip", "mcq_kernels.h", "mcq_api.hip", "mcq_kkt.inc", "mcq_tri.inc")]
     src.append(os.path.join(ROOT, "tests", "emu", "include", "hip", "hip_runtime.h"))
     if not os.path.exists(path) or any(os.path.getmtime(s) > os.path.getmtime(path) for s in src):
         subprocess.run([os.path.join(ROOT, "tests", "emu", "build_emu.sh")], check=True)
