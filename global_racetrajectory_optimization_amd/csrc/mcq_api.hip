@@ -292,6 +292,7 @@ static int launch(mcq_handle* h, McqBatch& B, const mcq_opts& o)
         h->timing_valid = true;
         return 0;
     }
+    B.skip_db = (!B.prep_only && B.nmax <= MCQ_TRI_MAXN) ? 1 : 0;      // (prep_only stops before the bands anyway)
     HIP_TRY(hipEventRecord(h->ev[0], h->stream));
     hipLaunchKernelGGL(mcq_assemble_kernel, dim3(B.batch), dim3(256), 0, h->stream, B);
     HIP_TRY(hipGetLastError());

@@ -48,6 +48,7 @@
 #define MCQ_LBI 64                 /* offset of the inverse diagonal tile row inside an L row */
 #define MCQ_LBW 80                 /* offset of the border part W inside an L row */
 #define MCQ_NVEC 32
+#define MCQ_TRI_MAXN 2208         /* rings up to this length apply E, E', D through the spline system (mcq_tri.inc: three vectors in the LDS overlay) */
 #define MCQ_KMAX 120               /* active curvature rows the Schur-complement path of the active-set phase holds */
 #define MCQ_KBIG 512               /* ... and of the overflow path (round 3): a problem with more of them claims one of the handle's slots, */
 #define MCQ_KBIG_SLOT ((size_t)MCQ_KBIG * MCQ_KBIG + 6 * (size_t)MCQ_KBIG)   /* doubles per slot: Schur matrix, three vectors, the index / sign / pivot lists */
@@ -124,6 +125,7 @@ struct McqBatch {
     double* nv_out;         // optional outputs of the assembly: normals [batch][nmax][2], scalings [batch][nmax]
     double* sc_out;
     int prep_only;          // assembly kernel stops after the spline quantities (mcq_prep_device)
+    int skip_db;            // assembly kernel does not write the D band: with the saddle-point core and n <= MCQ_TRI_MAXN nobody reads it
     double* Eb; double* Et; double* Db; double* H; double* L; double* vec; double* Z;
     signed char* state;
     double* alpha;          // [batch][nmax]

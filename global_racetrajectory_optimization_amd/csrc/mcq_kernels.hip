@@ -534,7 +534,7 @@ __global__ void __launch_bounds__(MCQ_NT) mcq_assemble_kernel(McqBatch B)
             {
                 const double dv = 6.0 * (gu1 - (1.0 + S[im]) * g0 + S[imm] * gd1);
                 const double ev = dv * (cpx * NY[i] - cpy * NX[i]);
-                w.Db[(size_t)MCQ_BE_MAX * nm + i] = dv;
+                if (!B.skip_db) w.Db[(size_t)MCQ_BE_MAX * nm + i] = dv;
                 w.Eb[(size_t)MCQ_BE_MAX * nm + i] = ev;
                 w.Et[(size_t)MCQ_BE_MAX * nm + i] = ev;      // E'[o'][j] = E[j + o'][j]: entry (i, j = i + o) is diagonal o' = -o of column j
             }
@@ -547,7 +547,7 @@ __global__ void __launch_bounds__(MCQ_NT) mcq_assemble_kernel(McqBatch B)
                     const double nxt = cur * RU[j];
                     const double dv = 6.0 * (nxt - (1.0 + S[jm1]) * cur + S[jm2] * prev);
                     const double ev = dv * (cpx * NY[j] - cpy * NX[j]);
-                    w.Db[(size_t)(MCQ_BE_MAX + o) * nm + i] = dv;
+                    if (!B.skip_db) w.Db[(size_t)(MCQ_BE_MAX + o) * nm + i] = dv;
                     w.Eb[(size_t)(MCQ_BE_MAX + o) * nm + i] = ev;
                     w.Et[(size_t)(MCQ_BE_MAX - o) * nm + j] = ev;        // consecutive threads: consecutive j (a wrap splits the run once)
                     prev = cur;
@@ -566,7 +566,7 @@ __global__ void __launch_bounds__(MCQ_NT) mcq_assemble_kernel(McqBatch B)
                     const double prv = cur * RD[j];            // g[o-1]
                     const double dv = 6.0 * (nxt - (1.0 + S[jm1]) * cur + S[jm2] * prv);
                     const double ev = dv * (cpx * NY[j] - cpy * NX[j]);
-                    w.Db[(size_t)(MCQ_BE_MAX + o) * nm + i] = dv;
+                    if (!B.skip_db) w.Db[(size_t)(MCQ_BE_MAX + o) * nm + i] = dv;
                     w.Eb[(size_t)(MCQ_BE_MAX + o) * nm + i] = ev;
                     w.Et[(size_t)(MCQ_BE_MAX - o) * nm + j] = ev;
                     nxt = cur;
