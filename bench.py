@@ -59,42 +59,47 @@ def work_model(n, info, band_e=32):
     """HBM bytes and fp64 flops of mcq_solve_kernel for one launch, from the iteration counts the solver reports (mcq_info).
 
     streamed   what THIS implementation has to move through HBM per launch -- the figure `roofline.achieved` /
-               `frac` are computed from.  Since the saddle-point core (round 3, csrc/mcq_kkt.inc) the per-waypoint records are
-                 factorisation : elimination writes D~^-1 | Lo (32 doubles), G (32), the forward-eliminated left spike | y (32); the
-                                 spike pass reads the last two back and writes the alpha rows of the spikes (16); inputs: 8 per-waypoint
-                                 vectors + the mask byte; the right-hand side of the solve that follows rides through both passes
-                                 (read + written once)                                            -> 1489 bytes per waypoint
-                 solve after a factorisation (interior-point predictor, active-set round): the separators' system (LDS) and the spike
-                                 correction: spikes (16 doubles) + the vector (read + written)   -> 144 bytes per waypoint
-                 any other solve (corrector, refinement round): forward chain (D~^-1 | Lo, r, y out), backward chain (G, y, x out),
-                                 correction                                                      -> 800 bytes per waypoint
-                 gradient      : E band + E' band, 2 n * 65 doubles;  f = 2 E'k_ref at the top of the kernel: one band
-               interior-point iteration = 1 factorisation + predictor solve + corrector solve (one exact gradient per problem confirms
-               convergence); active-set round = 1 factorisation + 1 solve + 2 gradients; refinement round = 1 solve + 1 gradient;
-               + 1 initial gradient + 1.5 band products in the epilogue + 0.5 for f.
-    declared   SURVEY.md section 8(d)'s figure was written for the banded-exact algorithm of rounds 1-3 (every factorisation streams the
-               band of H and of L: 274 doubles per row, every sweep 144).  The saddle-point core does not move those bytes; the old figure
-               is reported as `banded_model_bytes` for reference only -- no fraction is quoted on it.
+               `frac` are computed from.  Since the saddle-point core (round 3, csrc/mcq_kkt.inc, mcq_tri.inc), per waypoint:
+                 factorisation : elimination writes D~^-1 | Lo (256 B) and the forward-eliminated left spike | y (256) -- G = D~^-1 Up is
+                                 not stored: Up_k is Lo_(k+1)', the consumers rebuild G x from the two records -- ; the spike pass reads
+                                 both back and writes the alpha rows of the spikes (80); inputs: 8 per-waypoint vectors + the mask
+                                 byte (65); the right-hand side of the solve that follows rides through both passes (16)
+                                                                                                              -> 1185 bytes
+                 solve after a factorisation (interior-point predictor, active-set round): the separators' system (LDS) and the
+                                 spike correction: spikes (80) + the vector read and written (16)              -> 96 bytes
+                 any other solve (corrector, refinement round): forward chain (256 + 8 + 40), backward chain (256 + 40 + 8),
+                                 correction (80 + 16)                                                          -> 704 bytes
+                 gradient      : E and E' through four solves with the tridiagonal spline matrix: 27 vector accesses -> 216 bytes
+                                 (the 65-wide bands of E and E' -- 1040 bytes -- are no longer read)
+                 vector passes : one interior-point iteration reads / writes 60 vector entries (three passes, six load phases of
+                                 half a thread's entries), an active-set round ~30                              -> 480 / 240 bytes
+               interior-point iteration = 1 factorisation + predictor solve + corrector solve + passes (one exact gradient per problem
+               confirms convergence); active-set round = 1 factorisation + 1 solve + 2 gradients + passes; refinement round = 1 solve
+               + 1 gradient; + 1 initial gradient + 1 for f and the curvature check + 1 for the post-check.
+    banded     SURVEY.md section 8(d)'s figure was written for the banded-exact algorithm of rounds 1-3 (every factorisation streams the
+               band of H and of L: 274 doubles per row, every sweep 144, every gradient two 65-wide bands).  The saddle-point core does
+               not move those bytes; reported as `banded_model_bytes_per_launch` for reference only -- no fraction is quoted on it.
 
     Flops (2 per FMA), rough: elimination step ~640 FMAs per waypoint (5 x 16 working matrix, five Gauss-Jordan stages), spike pass 275,
-    a chain of a solve 40 per direction, band product 65 per row.
+    a chain of a solve 40 per direction, a tridiagonal solve 4.
     """
     ipm = info["ipm_iters"].astype(np.float64)
     act = info["as_iters"].astype(np.float64)
     ref = info["refine_rounds"].astype(np.float64)
     n_fac, n_sol = ipm + act, 2 * ipm + act + ref
-    n_grad = 1.0 + 2 * act + ref + 1.0 + 1.5 + 0.5
+    n_grad = 1.0 + 2 * act + ref + 1.0 + 1.0 + 1.0
     ew = 2 * band_e + 1
-    grad = 2.0 * n * ew * 8.0
-    b_fac, b_fused, b_solve = n * 1489.0, n * 144.0, n * 800.0
+    grad = n * 216.0
+    b_fac, b_fused, b_solve = n * 1185.0, n * 96.0, n * 704.0
+    passes = ipm * n * 480.0 + act * n * 240.0
     plain = n_sol - n_fac                          # solves that run their own chains
-    streamed = float((n_fac * (b_fac + b_fused) + plain * b_solve + n_grad * grad).sum())
-    banded = float((n_fac * n * (130.0 + 144.0) * 8.0 + n_sol * 2.0 * n * 144.0 * 8.0 + n_grad * grad).sum())
-    flops = float((n_fac * 2.0 * n * (640.0 + 275.0) + plain * 2.0 * 2.0 * n * 40.0 + n_grad * 2.0 * 2.0 * n * ew).sum())
+    streamed = float((n_fac * (b_fac + b_fused) + plain * b_solve + n_grad * grad + passes).sum())
+    banded = float((n_fac * n * (130.0 + 144.0) * 8.0 + n_sol * 2.0 * n * 144.0 * 8.0 + n_grad * 2.0 * n * ew * 8.0).sum())
+    flops = float((n_fac * 2.0 * n * (640.0 + 275.0) + plain * 2.0 * 2.0 * n * 40.0 + n_grad * 2.0 * 16.0 * n).sum())
     return dict(streamed=streamed, declared=banded, flops=flops,
                 per_problem=dict(factorisations=float(n_fac.mean()), solves=float(n_sol.mean()), solves_with_own_chains=float(plain.mean()),
                                  gradients=float(n_grad.mean()), bytes_factorisation=b_fac, bytes_fused_solve=b_fused, bytes_solve=b_solve,
-                                 bytes_gradient=grad))
+                                 bytes_gradient=grad, bytes_vector_passes=float(passes.mean())))
 
 
 def source_sha():
