@@ -71,8 +71,8 @@ def work_model(n, info, band_e=32):
                                  correction (80 + 16)                                                          -> 512 bytes
                  gradient      : E and E' through four solves with the tridiagonal spline matrix: 27 vector accesses -> 216 bytes
                                  (the 65-wide bands of E and E' -- 1040 bytes -- are no longer read)
-                 vector passes : one interior-point iteration reads / writes 60 vector entries (three passes, six load phases of
-                                 half a thread's entries), an active-set round ~30                              -> 480 / 240 bytes
+                 vector passes : one interior-point iteration reads / writes 33 vector entries (three passes of one load phase each;
+                                 pass 1 in two halves), an active-set round ~30                                 -> 264 / 240 bytes
                interior-point iteration = 1 factorisation + predictor solve + corrector solve + passes (one exact gradient per problem
                confirms convergence); active-set round = 1 factorisation + 1 solve + 2 gradients + passes; refinement round = 1 solve
                + 1 gradient; + 1 initial gradient + 1 for f and the curvature check + 1 for the post-check.
@@ -91,7 +91,7 @@ def work_model(n, info, band_e=32):
     ew = 2 * band_e + 1
     grad = n * 216.0
     b_fac, b_fused, b_solve = n * 993.0, n * 96.0, n * 512.0
-    passes = ipm * n * 480.0 + act * n * 240.0
+    passes = ipm * n * 264.0 + act * n * 240.0
     plain = n_sol - n_fac                          # solves that run their own chains
     streamed = float((n_fac * (b_fac + b_fused) + plain * b_solve + n_grad * grad + passes).sum())
     banded = float((n_fac * n * (130.0 + 144.0) * 8.0 + n_sol * 2.0 * n * 144.0 * 8.0 + n_grad * 2.0 * n * ew * 8.0).sum())

@@ -2927,6 +2927,7 @@ __device__ __noinline__ int ipm_box(SolveCtx& c, const McqBatch& B, const SolveS
             IPB_PTRS
             double rdm = 0.0;
             mu = 0.0;
+            {
 #pragma unroll
             for (int h = 0; h < IPB_E / IPB_H; ++h) {
                 IPB_HALF(h)
@@ -2951,6 +2952,7 @@ __device__ __noinline__ int ipm_box(SolveCtx& c, const McqBatch& B, const SolveS
             }
             block_reduce2_(mu, 0, rdm, 2, red);
             mu /= npairs;
+            }
             const bool conv = mu < IPM_TOL * zscale * sc.wmean && rdm < IPM_TOL * zscale;
 #ifdef IPM_TRACE
             if (threadIdx.x == 0) printf("ipmb it %d mu %.3e rdm %.3e exact %d resume %d\n", it, mu / (zscale * sc.wmean), rdm / zscale, (int)g_exact, (int)resume);
@@ -2979,93 +2981,62 @@ __device__ __noinline__ int ipm_box(SolveCtx& c, const McqBatch& B, const SolveS
         if (fs != 0) return (resume && fs == MCQ_NOT_PD) ? MCQ_OK : fs;
         timed_solve(c, VEC(c.w, c.nm, V_RHS), MCQ_FUSE_FWD != 0);
 
-        // ---- pass 2: affine step lengths, centring parameter, corrector right-hand side (three load phases of half the entries each:
-        //      what a phase needs again after a block reduction is reloaded -- L2 hits -- instead of living in registers across it) ----
+        // ---- pass 2: affine step lengths, centring parameter, corrector right-hand side: ONE load phase (six arrays of eight entries stay in
+        //      registers across the two block reductions; the affine multiplier steps are recomputed where they are needed) ----------
         double smu;
         {
-            IPB_PTRS
+            IPB_SETUP
+            double dxa[IPB_E], sl[IPB_E], su[IPB_E], zl[IPB_E], zu[IPB_E], g[IPB_E];
+            bool act[IPB_E];
+#pragma unroll
+            for (int u = 0; u < IPB_E; ++u) {
+                const int i = idx[u];
+                const double x = X[i];
+                act[u] = ok[u] && ST[i] == 0;
+                dxa[u] = RHS[i]; sl[u] = x - LO[i]; su[u] = HI[i] - x; zl[u] = ZL[i]; zu[u] = ZU[i]; g[u] = G[i];
+            }
             double ap = 1.0, ad = 1.0;
 #pragma unroll
-            for (int h = 0; h < IPB_E / IPB_H; ++h) {
-                IPB_HALF(h)
-                double dxa[IPB_H], sl[IPB_H], su[IPB_H], zl[IPB_H], zu[IPB_H];
-                bool act[IPB_H];
-#pragma unroll
-                for (int u = 0; u < IPB_H; ++u) {
-                    const int i = idx[u];
-                    const double x = X[i];
-                    act[u] = ok[u] && ST[i] == 0;
-                    dxa[u] = RHS[i]; sl[u] = x - LO[i]; su[u] = HI[i] - x; zl[u] = ZL[i]; zu[u] = ZU[i];
-                }
-#pragma unroll
-                for (int u = 0; u < IPB_H; ++u) {
-                    if (!ok[u]) continue;
-                    if (!act[u]) { DXA[idx[u]] = 0.0; continue; }
-                    const double dx = dxa[u];
-                    DXA[idx[u]] = dx;
-                    const double dzla = -zl[u] - zl[u] * dx / sl[u];
-                    const double dzua = -zu[u] + zu[u] * dx / su[u];
-                    if (dx < 0.0) ap = fmin(ap, -sl[u] / dx);
-                    if (dx > 0.0) ap = fmin(ap, su[u] / dx);
-                    if (dzla < 0.0) ad = fmin(ad, -zl[u] / dzla);
-                    if (dzua < 0.0) ad = fmin(ad, -zu[u] / dzua);
-                }
+            for (int u = 0; u < IPB_E; ++u) {
+                if (!ok[u]) continue;
+                if (!act[u]) { DXA[idx[u]] = 0.0; continue; }
+                const double dx = dxa[u];
+                DXA[idx[u]] = dx;
+                const double dzla = -zl[u] - zl[u] * dx / sl[u];
+                const double dzua = -zu[u] + zu[u] * dx / su[u];
+                if (dx < 0.0) ap = fmin(ap, -sl[u] / dx);
+                if (dx > 0.0) ap = fmin(ap, su[u] / dx);
+                if (dzla < 0.0) ad = fmin(ad, -zl[u] / dzla);
+                if (dzua < 0.0) ad = fmin(ad, -zu[u] / dzua);
             }
             block_reduce2_(ap, 1, ad, 1, red);
             double mua = 0.0;
 #pragma unroll
-            for (int h = 0; h < IPB_E / IPB_H; ++h) {
-                IPB_HALF(h)
-                double dxa[IPB_H], sl[IPB_H], su[IPB_H], zl[IPB_H], zu[IPB_H];
-                bool act[IPB_H];
-#pragma unroll
-                for (int u = 0; u < IPB_H; ++u) {
-                    const int i = idx[u];
-                    const double x = X[i];
-                    act[u] = ok[u] && ST[i] == 0;
-                    dxa[u] = RHS[i]; sl[u] = x - LO[i]; su[u] = HI[i] - x; zl[u] = ZL[i]; zu[u] = ZU[i];
-                }
-#pragma unroll
-                for (int u = 0; u < IPB_H; ++u) {
-                    if (!act[u]) continue;
-                    const double dzla = -zl[u] - zl[u] * dxa[u] / sl[u];
-                    const double dzua = -zu[u] + zu[u] * dxa[u] / su[u];
-                    mua += (sl[u] + ap * dxa[u]) * (zl[u] + ad * dzla) + (su[u] - ap * dxa[u]) * (zu[u] + ad * dzua);
-                }
+            for (int u = 0; u < IPB_E; ++u) {
+                if (!act[u]) continue;
+                const double dzla = -zl[u] - zl[u] * dxa[u] / sl[u];
+                const double dzua = -zu[u] + zu[u] * dxa[u] / su[u];
+                mua += (sl[u] + ap * dxa[u]) * (zl[u] + ad * dzla) + (su[u] - ap * dxa[u]) * (zu[u] + ad * dzua);
             }
             mua = block_reduce_(mua, 0, red) / npairs;
             const double ratio = mua / mu;
             smu = ratio * ratio * ratio * mu;
 #pragma unroll
-            for (int h = 0; h < IPB_E / IPB_H; ++h) {
-                IPB_HALF(h)
-                double dxa[IPB_H], sl[IPB_H], su[IPB_H], zl[IPB_H], zu[IPB_H], g[IPB_H];
-                bool act[IPB_H];
-#pragma unroll
-                for (int u = 0; u < IPB_H; ++u) {
-                    const int i = idx[u];
-                    const double x = X[i];
-                    act[u] = ok[u] && ST[i] == 0;
-                    dxa[u] = DXA[i]; sl[u] = x - LO[i]; su[u] = HI[i] - x; zl[u] = ZL[i]; zu[u] = ZU[i]; g[u] = G[i];
-                }
-#pragma unroll
-                for (int u = 0; u < IPB_H; ++u) {
-                    if (!ok[u]) continue;
-                    const double dzla = -zl[u] - zl[u] * dxa[u] / sl[u];
-                    const double dzua = -zu[u] + zu[u] * dxa[u] / su[u];
-                    RHS[idx[u]] = act[u] ? -g[u] + (smu - dxa[u] * dzla) / sl[u] - (smu + dxa[u] * dzua) / su[u] : 0.0;
-                }
+            for (int u = 0; u < IPB_E; ++u) {
+                if (!ok[u]) continue;
+                const double dzla = -zl[u] - zl[u] * dxa[u] / sl[u];
+                const double dzua = -zu[u] + zu[u] * dxa[u] / su[u];
+                RHS[idx[u]] = act[u] ? -g[u] + (smu - dxa[u] * dzla) / sl[u] - (smu + dxa[u] * dzua) / su[u] : 0.0;
             }
         }
         timed_solve(c, VEC(c.w, c.nm, V_RHS));
 
-        // ---- pass 3: step length of the combined direction, update (two load phases of half the entries each; the multiplier steps
-        //      and H dx go through the scratch vectors T1, T2, T0 across the block reduction) ---------------------------------------
+        // ---- pass 3: step length of the combined direction, update: ONE load phase -- nine arrays of eight entries stay in registers
+        //      across the block reduction; the multiplier steps and H dx are recomputed after it instead of being kept (at 256 VGPRs --
+        //      two workgroups per CU -- twelve arrays spilled).  (Folding the next iteration's residual pass into this one was tried: the
+        //      extra live values cost more than the seven vector reads it saves.) --------------------------------------------------
         {
-            IPB_PTRS
-            gdouble* DZL = VEC(c.w, nm, V_T1);
-            gdouble* DZU = VEC(c.w, nm, V_T2);
-            gdouble* HDX = VEC(c.w, nm, V_T0);
+            IPB_SETUP
             // fraction of the way to the boundary: 0.995 far from the solution, closer to 1 as the complementarity shrinks
             // (Mehrotra's adaptive rule; saves a third of an iteration on average, scripts/proto_ipm.py "adaptive step")
 #ifdef MCQ_IPM_FIXED_STEP
@@ -3074,67 +3045,52 @@ __device__ __noinline__ int ipm_box(SolveCtx& c, const McqBatch& B, const SolveS
             const double gm = fmin(fmax(MCQ_IPM_GM_MIN, 1.0 - MCQ_IPM_GM_C * mu / (zscale * sc.wmean)), 1.0 - 1e-9);
 #endif
             double amax = 1.0 / gm;
+            double dx[IPB_E], da[IPB_E], x[IPB_E], lo[IPB_E], hi[IPB_E], zl[IPB_E], zu[IPB_E], g[IPB_E], sg[IPB_E];
+            bool act[IPB_E];
 #pragma unroll
-            for (int h = 0; h < IPB_E / IPB_H; ++h) {
-                IPB_HALF(h)
-                double dx[IPB_H], da[IPB_H], x[IPB_H], lo[IPB_H], hi[IPB_H], zl[IPB_H], zu[IPB_H], g[IPB_H], sg[IPB_H];
-                bool act[IPB_H];
+            for (int u = 0; u < IPB_E; ++u) {
+                const int i = idx[u];
+                act[u] = ok[u] && ST[i] == 0;
+                dx[u] = RHS[i]; da[u] = DXA[i]; x[u] = X[i]; lo[u] = LO[i]; hi[u] = HI[i]; zl[u] = ZL[i]; zu[u] = ZU[i];
+                g[u] = G[i]; sg[u] = SIG[i];
+            }
+#define IPB_STEP3(u)                                                                                                          \
+                const double sl = x[u] - lo[u], su = hi[u] - x[u];                                                              \
+                const double dzla = -zl[u] - zl[u] * da[u] / sl, dzua = -zu[u] + zu[u] * da[u] / su;                             \
+                const double dzl = (-sl * zl[u] + smu - da[u] * dzla - zl[u] * dx[u]) / sl;                                     \
+                const double dzu = (-su * zu[u] + smu + da[u] * dzua + zu[u] * dx[u]) / su;
 #pragma unroll
-                for (int u = 0; u < IPB_H; ++u) {
-                    const int i = idx[u];
-                    act[u] = ok[u] && ST[i] == 0;
-                    dx[u] = RHS[i]; da[u] = DXA[i]; x[u] = X[i]; lo[u] = LO[i]; hi[u] = HI[i]; zl[u] = ZL[i]; zu[u] = ZU[i];
-                    g[u] = G[i]; sg[u] = SIG[i];
-                }
-#pragma unroll
-                for (int u = 0; u < IPB_H; ++u) {
-                    if (!act[u]) continue;
-                    const double sl = x[u] - lo[u], su = hi[u] - x[u];
-                    const double dzla = -zl[u] - zl[u] * da[u] / sl, dzua = -zu[u] + zu[u] * da[u] / su;
-                    const double dzl = (-sl * zl[u] + smu - da[u] * dzla - zl[u] * dx[u]) / sl;
-                    const double dzu = (-su * zu[u] + smu + da[u] * dzua + zu[u] * dx[u]) / su;
-                    // H dx = (corrector right-hand side) - sig dx
-                    const double rc = -g[u] + (smu - da[u] * dzla) / sl - (smu + da[u] * dzua) / su;
-                    DZL[idx[u]] = dzl;
-                    DZU[idx[u]] = dzu;
-                    HDX[idx[u]] = rc - sg[u] * dx[u];
-                    if (dx[u] < 0.0) amax = fmin(amax, -sl / dx[u]);
-                    if (dx[u] > 0.0) amax = fmin(amax, su / dx[u]);
-                    if (dzl < 0.0) amax = fmin(amax, -zl[u] / dzl);
-                    if (dzu < 0.0) amax = fmin(amax, -zu[u] / dzu);
-                }
+            for (int u = 0; u < IPB_E; ++u) {
+                if (!act[u]) continue;
+                IPB_STEP3(u)
+                if (dx[u] < 0.0) amax = fmin(amax, -sl / dx[u]);
+                if (dx[u] > 0.0) amax = fmin(amax, su / dx[u]);
+                if (dzl < 0.0) amax = fmin(amax, -zl[u] / dzl);
+                if (dzu < 0.0) amax = fmin(amax, -zu[u] / dzu);
             }
             amax = block_reduce_(amax, 1, red);
             const double a = fmin(1.0, gm * amax);
             c.last_step = a;
 #pragma unroll
-            for (int h = 0; h < IPB_E / IPB_H; ++h) {
-                IPB_HALF(h)
-                double dx[IPB_H], x[IPB_H], lo[IPB_H], hi[IPB_H], zl[IPB_H], zu[IPB_H], g[IPB_H], dzl[IPB_H], dzu[IPB_H], hdx[IPB_H];
-                bool act[IPB_H];
-#pragma unroll
-                for (int u = 0; u < IPB_H; ++u) {
-                    const int i = idx[u];
-                    act[u] = ok[u] && ST[i] == 0;
-                    dx[u] = RHS[i]; x[u] = X[i]; lo[u] = LO[i]; hi[u] = HI[i]; zl[u] = ZL[i]; zu[u] = ZU[i]; g[u] = G[i];
-                    dzl[u] = DZL[i]; dzu[u] = DZU[i]; hdx[u] = HDX[i];
-                }
-#pragma unroll
-                for (int u = 0; u < IPB_H; ++u) {
-                    if (!act[u]) continue;
-                    const int i = idx[u];
-                    G[i] = g[u] + a * hdx[u];
-                    X[i] = x[u] + a * dx[u];
-                    ZL[i] = zl[u] + a * dzl[u];
-                    ZU[i] = zu[u] + a * dzu[u];
-                    // Tapia indicators of this step for the active-set identification (the last step's survive)
-                    const double sl = x[u] - lo[u], su = hi[u] - x[u];
-                    const double rsl = (sl + a * dx[u]) * zl[u], rzl = (zl[u] + a * dzl[u]) * sl;     // s+/s < z+/z  <=>  s+ z < z+ s
-                    const double rsu = (su - a * dx[u]) * zu[u], rzu = (zu[u] + a * dzu[u]) * su;
-                    const bool al = rsl < MCQ_TAPIA_RATIO * rzl && sl + a * dx[u] < MCQ_TAPIA_SHRINK * sl, au = rsu < MCQ_TAPIA_RATIO * rzu && su - a * dx[u] < MCQ_TAPIA_SHRINK * su;
-                    IND[i] = al ? -1.0 : (au ? 1.0 : 0.0);
-                }
+            for (int u = 0; u < IPB_E; ++u) {
+                if (!act[u]) continue;
+                const int i = idx[u];
+                IPB_STEP3(u)
+                // H dx = (corrector right-hand side) - sig dx
+                const double rc = -g[u] + (smu - da[u] * dzla) / sl - (smu + da[u] * dzua) / su;
+                const double hdx = rc - sg[u] * dx[u];
+                const double gn = g[u] + a * hdx, xn = x[u] + a * dx[u], zln = zl[u] + a * dzl, zun = zu[u] + a * dzu;
+                G[i] = gn;
+                X[i] = xn;
+                ZL[i] = zln;
+                ZU[i] = zun;
+                // Tapia indicators of this step for the active-set identification (the last step's survive)
+                const double rsl = (sl + a * dx[u]) * zl[u], rzl = (zl[u] + a * dzl) * sl;     // s+/s < z+/z  <=>  s+ z < z+ s
+                const double rsu = (su - a * dx[u]) * zu[u], rzu = (zu[u] + a * dzu) * su;
+                const bool al = rsl < MCQ_TAPIA_RATIO * rzl && sl + a * dx[u] < MCQ_TAPIA_SHRINK * sl, au = rsu < MCQ_TAPIA_RATIO * rzu && su - a * dx[u] < MCQ_TAPIA_SHRINK * su;
+                IND[i] = al ? -1.0 : (au ? 1.0 : 0.0);
             }
+#undef IPB_STEP3
         }
         g_exact = false;
         __syncthreads();
