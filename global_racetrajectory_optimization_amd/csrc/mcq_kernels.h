@@ -125,7 +125,8 @@ struct McqBatch {
     double* nv_out;         // optional outputs of the assembly: normals [batch][nmax][2], scalings [batch][nmax]
     double* sc_out;
     int prep_only;          // assembly kernel stops after the spline quantities (mcq_prep_device)
-    int skip_db;            // assembly kernel does not write the D band: with the saddle-point core and n <= MCQ_TRI_MAXN nobody reads it
+    int skip_db;            // assembly kernel writes neither the D band nor the E' band: with the saddle-point core and n <= MCQ_TRI_MAXN nobody
+                            // reads them (E' y and D x go through the spline system, mcq_tri.inc); the E band stays (curvature rows)
     double* Eb; double* Et; double* Db; double* H; double* L; double* vec; double* Z;
     signed char* state;
     double* alpha;          // [batch][nmax]

@@ -536,7 +536,7 @@ __global__ void __launch_bounds__(MCQ_NT) mcq_assemble_kernel(McqBatch B)
                 const double ev = dv * (cpx * NY[i] - cpy * NX[i]);
                 if (!B.skip_db) w.Db[(size_t)MCQ_BE_MAX * nm + i] = dv;
                 w.Eb[(size_t)MCQ_BE_MAX * nm + i] = ev;
-                w.Et[(size_t)MCQ_BE_MAX * nm + i] = ev;      // E'[o'][j] = E[j + o'][j]: entry (i, j = i + o) is diagonal o' = -o of column j
+                if (!B.skip_db) w.Et[(size_t)MCQ_BE_MAX * nm + i] = ev;      // E'[o'][j] = E[j + o'][j]: entry (i, j = i + o) is diagonal o' = -o of column j
             }
             // upwards: prev = g[o-1], cur = g[o], j = i + o
             {
@@ -549,7 +549,7 @@ __global__ void __launch_bounds__(MCQ_NT) mcq_assemble_kernel(McqBatch B)
                     const double ev = dv * (cpx * NY[j] - cpy * NX[j]);
                     if (!B.skip_db) w.Db[(size_t)(MCQ_BE_MAX + o) * nm + i] = dv;
                     w.Eb[(size_t)(MCQ_BE_MAX + o) * nm + i] = ev;
-                    w.Et[(size_t)(MCQ_BE_MAX - o) * nm + j] = ev;        // consecutive threads: consecutive j (a wrap splits the run once)
+                    if (!B.skip_db) w.Et[(size_t)(MCQ_BE_MAX - o) * nm + j] = ev;        // consecutive threads: consecutive j (a wrap splits the run once)
                     prev = cur;
                     cur = nxt;
                     jm2 = jm1;
@@ -568,7 +568,7 @@ __global__ void __launch_bounds__(MCQ_NT) mcq_assemble_kernel(McqBatch B)
                     const double ev = dv * (cpx * NY[j] - cpy * NX[j]);
                     if (!B.skip_db) w.Db[(size_t)(MCQ_BE_MAX + o) * nm + i] = dv;
                     w.Eb[(size_t)(MCQ_BE_MAX + o) * nm + i] = ev;
-                    w.Et[(size_t)(MCQ_BE_MAX - o) * nm + j] = ev;
+                    if (!B.skip_db) w.Et[(size_t)(MCQ_BE_MAX - o) * nm + j] = ev;
                     nxt = cur;
                     cur = prv;
                     j = jm1;
@@ -587,7 +587,7 @@ __global__ void __launch_bounds__(MCQ_NT) mcq_assemble_kernel(McqBatch B)
         w.Db[(size_t)oo * nm + i] = dv;
         w.Eb[(size_t)oo * nm + i] = dv * CP[i] * (XP[i] * NY[j] - YP[i] * NX[j]);
     }
-    if (long_ring) return;         // (E' written alongside E above: no second pass over the band)
+    if (long_ring || B.skip_db) return;         // (E' written alongside E above: no second pass over the band; skip_db: nobody reads E')
     __syncthreads();
     // ---- phase 3c: transpose band  Et[(bR+o) * nm + j] = E[(j+o) mod n][j],  -bR <= o <= bE --------------------------
     for (int idx = tid; idx < n * ew; idx += MCQ_NT) {
@@ -2486,6 +2486,15 @@ __device__ __noinline__ void solve(const SolveCtx& c, gdouble* v, bool fwd_done)
 #endif   // MCQ_CORE_BAND
 }
 
+// dst = E' src: through the spline system where the ring allows it (saddle-point core), else from the band of E'
+__device__ void apply_Et(SolveCtx& c, const gdouble* src, gdouble* dst)
+{
+#if !defined(MCQ_CORE_BAND)
+    if (tri_usable(c)) { tri_apply_Et(c, src, dst); return; }
+#endif
+    band_matvec(c.w.Et, c.d.bR, c.d.bE, c.d.n, c.nm, src, nullptr, 0.0, dst);
+}
+
 // g = E'(E x + F_SCALE k_ref + extra)      (tmp: scratch vector; extra may be nullptr)
 __device__ __noinline__ void gradient(SolveCtx& c, const gdouble* x, const gdouble* extra, gdouble* tmp, gdouble* g)
 {
@@ -2690,7 +2699,7 @@ __device__ __noinline__ int ipm(SolveCtx& c, const McqBatch& B, bool with_kappa,
                 Q[i] = YL[i] * rl / TL[i] - YU[i] * ru / TU[i];
             }
             __syncthreads();
-            band_matvec(c.w.Et, c.d.bR, c.d.bE, n, nm, Q, nullptr, 0.0, T2);
+            apply_Et(c, Q, T2);
             __syncthreads();
             for (int i = tid; i < n; i += MCQ_NT) RHS[i] = ST[i] == 0 ? -G[i] + T2[i] : 0.0;
         } else {
@@ -2751,7 +2760,7 @@ __device__ __noinline__ int ipm(SolveCtx& c, const McqBatch& B, bool with_kappa,
                 Q[i] = (smu - dtl * dyl + YL[i] * rl) / TL[i] - (smu - dtu * dyu + YU[i] * ru) / TU[i];
             }
             __syncthreads();
-            band_matvec(c.w.Et, c.d.bR, c.d.bE, n, nm, Q, nullptr, 0.0, T2);
+            apply_Et(c, Q, T2);
             __syncthreads();
         }
         for (int i = tid; i < n; i += MCQ_NT) {
@@ -3276,7 +3285,7 @@ __device__ void kappa_apply(SolveCtx& c, const KappaMem& K, int nk, gdouble* Q, 
     __syncthreads();
     for (int q = tid; q < nk; q += MCQ_NT) Q[KI[1 + q]] = KMU[q];
     __syncthreads();
-    band_matvec(c.w.Et, c.d.bR, c.d.bE, n, c.nm, Q, nullptr, 0.0, v);
+    apply_Et(c, Q, v);
     __syncthreads();
     for (int i = tid; i < n; i += MCQ_NT) if (ST[i] != 0) v[i] = 0.0;
     __syncthreads();
