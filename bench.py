@@ -526,7 +526,7 @@ def main():
                        "kernel_ms": {k: float(np.mean([m[k] for m in solve_ms])) for k in ("assemble", "gram", "solve", "total")},
                        "workspace_GB": eng.workspace_bytes() / 1e9,
                        "solver_phase_ms_per_problem": {k: float(info["ticks"][:, j].mean()) / 1e5 for j, k in
-                                                       enumerate(("factor", "solve", "gradient", "kernel", "sweep_fwd", "sweep_bwd"))},
+                                                       enumerate(("factor", "solve", "gradient", "kernel", "interior_point_phase", "active_set_phase"))},
                        "ticks_mean": [float(v) for v in info["ticks"].mean(axis=0)],
                        # effective shader clock of the solver kernel: s_memtime / s_memrealtime read inside the kernel, per problem
                        "solver_effective_sclk_mhz": {"mean": float(np.mean(100.0 * info["ticks"][:, 6] / np.maximum(info["ticks"][:, 3], 1))),
