@@ -7,7 +7,7 @@ rm -f $R/build/fb/fb_*
 for spec in "$@"; do
   set -- $spec
   name=$1; shift
-  /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -mllvm -amdgpu-mfma-vgpr-form -mllvm -enable-ipra=0 "$@" -o $R/build/fb/fb_$name $R/scripts/factor_bench.hip 2>&1 | grep -i "error" &
+  /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -mllvm -amdgpu-mfma-vgpr-form -mllvm -enable-ipra=0 -DMCQ_CORE_BAND "$@" -o $R/build/fb/fb_$name $R/scripts/factor_bench.hip 2>&1 | grep -i "error" &
 done
 wait
 ls $R/build/fb

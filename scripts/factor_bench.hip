@@ -3,9 +3,12 @@
 // (-DMCQ_ABL=mask, see factor_t) that REMOVE parts of a step -- the results are then garbage, only the time is looked at: what a
 // part costs ON THE CRITICAL PATH of a step is the time that disappears with it.  Same grid shape as the solver (1024 workgroups on
 // 256 CUs), so the memory system sees the factorisation's own traffic.
-//   hipcc --offload-arch=gfx950 -O3 -std=c++17 -mllvm -amdgpu-mfma-vgpr-form -mllvm -enable-ipra=0 [-DMCQ_ABL=..] -o fb scripts/factor_bench.hip
+//   hipcc --offload-arch=gfx950 -O3 -std=c++17 -mllvm -amdgpu-mfma-vgpr-form -mllvm -enable-ipra=0 -DMCQ_CORE_BAND [-DMCQ_ABL=..] -o fb scripts/factor_bench.hip
+// (the bordered-band core of rounds 1-3: since the saddle-point core it only serves the shortest-path objective; scripts/kkt_check.hip is
+//  the diagnostic of the core the headline path runs on)
 //   ./fb [batch 1024] [n 2000] [reps 12] [with_fwd 1]
-#include "../global_racetrajectory_optimization_amd/csrc/mcq_kernels.hip"
+#include "../global_racetrajectory_optimization_amd/csrc/mcq_kernels.hip"      // compiled with -DMCQ_CORE_BAND: the bordered-band core lives in namespace mcq_band
+using namespace mcq_band;
 
 #include <stdio.h>
 #include <string.h>
