@@ -3672,9 +3672,12 @@ __global__ void __launch_bounds__(MCQ_NT, 2) mcq_solve_kernel(McqBatch B)
     for (int i = tid; i < n; i += MCQ_NT) X[i] = fmin(fmax(X[i], LO[i]), HI[i]);
     __syncthreads();
     double km = 0.0;
+    bool dd_valid = false;
     if (!c.direct) {
 #if !defined(MCQ_CORE_BAND)
-        if (tri_usable(c)) tri_apply_E(c, X, VEC(c.w, nm, V_KREF), 1.0, T0);
+        // (the second derivatives the post-check needs, D (n_x alpha) and D (n_y alpha), are by-products of this product: kept in two
+        //  vectors only the curvature-row phase uses, so the post-check repeats the product only if that phase ran)
+        if (tri_usable(c)) { tri_apply_E(c, X, VEC(c.w, nm, V_KREF), 1.0, T0, VEC(c.w, nm, V_TL), VEC(c.w, nm, V_TU)); dd_valid = true; }
         else
 #endif
         band_matvec(c.w.Eb, c.d.bE, c.d.bR, n, nm, X, VEC(c.w, nm, V_KREF), 1.0, T0);
@@ -3686,6 +3689,7 @@ __global__ void __launch_bounds__(MCQ_NT, 2) mcq_solve_kernel(McqBatch B)
     // ---- phase 2 (rare): a curvature-bound row is violated at the box optimum -> interior point with the curvature rows,
     //      then the box active-set polish with the curvature multipliers frozen ---------------------------------------------
     if (status == MCQ_OK && B.check_kappa && !c.direct && km > kbound * (1.0 + 1e-9)) {
+        dd_valid = false;
         status = ipm(c, B, true, sc, it2);
         ipm_iters += it2;
         __syncthreads();
@@ -3742,8 +3746,15 @@ __global__ void __launch_bounds__(MCQ_NT, 2) mcq_solve_kernel(McqBatch B)
             for (int i = tid; i < n; i += MCQ_NT) { T1[i] = VEC(c.w, nm, V_NX)[i] * X[i]; T2[i] = VEC(c.w, nm, V_NY)[i] * X[i]; }
             __syncthreads();
 #if !defined(MCQ_CORE_BAND)
-            if (tri_usable(c)) tri_apply_E(c, X, nullptr, 0.0, Q, T0, T3);      // D (n_x alpha), D (n_y alpha) are by-products of E alpha
-            else
+            if (tri_usable(c)) {
+                if (dd_valid) {
+                    const gdouble* D1 = VEC(c.w, nm, V_TL);
+                    const gdouble* D2 = VEC(c.w, nm, V_TU);
+                    for (int i = tid; i < n; i += MCQ_NT) { T0[i] = D1[i]; T3[i] = D2[i]; }
+                } else {
+                    tri_apply_E(c, X, nullptr, 0.0, Q, T0, T3);      // D (n_x alpha), D (n_y alpha) are by-products of E alpha
+                }
+            } else
 #endif
             {
             band_matvec(c.w.Db, c.d.bE, c.d.bR, n, nm, T1, nullptr, 0.0, T0);   // D (n_x alpha)
