@@ -1,7 +1,7 @@
 // kkt_check.hip -- DIAGNOSTIC (not part of the library): the saddle-point elimination of mcq_kkt.inc in isolation.  One workgroup per problem
 // copy, `reps` factorisations + solves of the same system; every solution is compared with the first one (determinism: races show up as
 // differences between repetitions) and with a dense LU of the same saddle-point system on the host (correctness).
-//   hipcc --offload-arch=gfx950 -O3 -std=c++17 -mllvm -amdgpu-mfma-vgpr-form -mllvm -enable-ipra=0 -o kc scripts/kkt_check.hip ;  ./kc [n 333] [reps 50] [batch 4] [sigma exponent range 12]
+//   hipcc --offload-arch=gfx950 -O3 -std=c++17 -mllvm -amdgpu-mfma-vgpr-form -mllvm -enable-ipra=0 -o kc scripts/kkt_check.hip ;  ./kc [n 333] [reps 50] [batch 4] [sigma exponent range 12] [host reference 1] [fused 0] [pinned fraction 0]
 // (also builds against tests/emu: g++ -O2 -std=c++17 -x c++ -I tests/emu/include scripts/kkt_check.hip)
 #include "../global_racetrajectory_optimization_amd/csrc/mcq_kernels.hip"
 
@@ -11,7 +11,7 @@
 #include <vector>
 #include <cmath>
 
-__global__ void __launch_bounds__(MCQ_NT, 2) kc_kernel(McqBatch B, int reps, const double* rhs0, double* out, int* fsout, int fused)
+__global__ void __launch_bounds__(MCQ_NT, 2) kc_kernel(McqBatch B, int reps, const double* rhs0, double* out, int* fsout, int fused, int masked, int nosig)
 {
     int n;
     double kb, wv;
@@ -32,7 +32,7 @@ __global__ void __launch_bounds__(MCQ_NT, 2) kc_kernel(McqBatch B, int reps, con
         for (int i = threadIdx.x; i < n; i += MCQ_NT) RHS[i] = rhs0[i];
         __syncthreads();
         const long long t0 = (long long)wall_clock64();
-        fs |= factor_kkt(c, SIG, nullptr, nullptr, fused ? RHS : nullptr);
+        fs |= factor_kkt(c, nosig ? nullptr : SIG, masked ? c.w.state : nullptr, nullptr, fused ? RHS : nullptr);
         const long long t1 = (long long)wall_clock64();
         solve_kkt(c, RHS, fused != 0);
         const long long t2 = (long long)wall_clock64();
@@ -58,6 +58,7 @@ int main(int argc, char** argv)
     const double srange = argc > 4 ? atof(argv[4]) : 12.0;
     const int with_ref = argc > 5 ? atoi(argv[5]) : 1;
     const int fused = argc > 6 ? atoi(argv[6]) : 0;
+    const double pin_frac = argc > 7 ? atof(argv[7]) : 0.0;        // fraction of pinned waypoints (rows / columns of the reduced system replaced by identity)
     const size_t elems = (size_t)batch * n;
     unsigned long long seed = 12345;
     // geometry of an oval: reference derivatives and unit normals; spline scalings near one
@@ -72,7 +73,7 @@ int main(int argc, char** argv)
         vec[(size_t)V_NX * n + i] = yp / nrm;
         vec[(size_t)V_NY * n + i] = -xp / nrm;
         vec[(size_t)V_SC * n + i] = 1.0 + 0.05 * sin(3.0 * th);
-        vec[(size_t)V_SIG * n + i] = pow(10.0, -6.0 + (srange + 6.0) * urand(seed));
+        vec[(size_t)V_SIG * n + i] = srange < -90.0 ? 0.0 : pow(10.0, -6.0 + (srange + 6.0) * urand(seed));      // sigma range < -90: no diagonal at all (the active-set phase's systems)
         rhs[i] = 2.0 * urand(seed) - 1.0;
     }
     double *L, *vecd, *rhsd, *outd;
@@ -86,6 +87,11 @@ int main(int argc, char** argv)
     CK(hipMalloc((void**)&status, batch * sizeof(int)));
     CK(hipMalloc((void**)&fsd, 3 * batch * sizeof(int)));
     CK(hipMemset(state, 0, elems));
+    std::vector<signed char> pin(n, 0);
+    if (pin_frac > 0.0) {
+        for (int i = 0; i < n; ++i) pin[i] = urand(seed) < pin_frac ? 1 : 0;
+        for (int b = 0; b < batch; ++b) CK(hipMemcpy(state + (size_t)b * n, pin.data(), n, hipMemcpyHostToDevice));
+    }
     CK(hipMemset(status, 0, batch * sizeof(int)));
     CK(hipMemset(L, 0xff, elems * MCQ_LLD * sizeof(double)));
     for (int b = 0; b < batch; ++b) CK(hipMemcpy(vecd + (size_t)b * n * MCQ_NVEC, vec.data(), vec.size() * sizeof(double), hipMemcpyHostToDevice));
@@ -97,7 +103,7 @@ int main(int argc, char** argv)
     B.band_e = 32;
     B.Eb = B.Et = B.Db = B.H = L; B.Z = L;      // unused by the saddle-point path
     B.ref = L; B.kappa_bound = 1.0; B.w_veh = 0.0;
-    hipLaunchKernelGGL(kc_kernel, dim3(batch), dim3(MCQ_NT), 0, 0, B, reps, rhsd, outd, fsd, fused);
+    hipLaunchKernelGGL(kc_kernel, dim3(batch), dim3(MCQ_NT), 0, 0, B, reps, rhsd, outd, fsd, fused, pin_frac > 0.0 ? 1 : 0, srange < -90.0 ? 1 : 0);
     CK(hipGetLastError());
     CK(hipDeviceSynchronize());
     std::vector<double> out(elems * reps);
@@ -146,7 +152,7 @@ int main(int argc, char** argv)
         std::vector<double> E((size_t)n * n);
         for (int i = 0; i < n; ++i) {
             const double cp = vec[(size_t)V_CP * n + i], a = -2.0 * cp * vec[(size_t)V_YP * n + i], b = 2.0 * cp * vec[(size_t)V_XP * n + i];
-            for (int j = 0; j < n; ++j) E[(size_t)i * n + j] = Bm[(size_t)i * n + j] * (a * vec[(size_t)V_NX * n + j] + b * vec[(size_t)V_NY * n + j]);
+            for (int j = 0; j < n; ++j) E[(size_t)i * n + j] = pin[j] ? 0.0 : Bm[(size_t)i * n + j] * (a * vec[(size_t)V_NX * n + j] + b * vec[(size_t)V_NY * n + j]);
         }
         // residual of the GPU solution:  r - (sig x + E'(E x)),  relative to |sig x| + |E'||E x| + |r|
         std::vector<double> Ex(n, 0.0), res(n), scl(n);
@@ -156,7 +162,7 @@ int main(int argc, char** argv)
         for (int j = 0; j < n; ++j) {
             double s = 0.0, sa = 0.0;
             for (int i = 0; i < n; ++i) { s += E[(size_t)i * n + j] * Ex[i]; sa += fabs(E[(size_t)i * n + j] * Ex[i]); }
-            const double sg = vec[(size_t)V_SIG * n + j];
+            const double sg = pin[j] ? 1.0 : vec[(size_t)V_SIG * n + j];
             rmax = fmax(rmax, fabs(rhs[j] - sg * x[j] - s));
             smax = fmax(smax, fabs(sg * x[j]) + sa + fabs(rhs[j]));
         }

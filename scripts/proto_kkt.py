@@ -410,3 +410,107 @@ if __name__ == "__main__" and len(sys.argv) > 1 and sys.argv[1] == "kernel":
         run2(nm, 4, pin_frac=0.9)
     for nm in ("oval_n2000", "oval_n2000_c5"):
         run2(nm, 0); run2(nm, 2, kappa_w=True); run2(nm, 3, sig_lo=-12, sig_hi=-6, pin_frac=0.0); run2(nm, 5, sig_lo=-3, sig_hi=3, pin_frac=0.3)
+
+
+# ----------------------------------------------------------------------------------------------------------------------
+# Round 3, late: the separators' block-cyclic system by PARALLEL CYCLIC REDUCTION (nseg a power of two) instead of one chain of nseg - 1
+# steps -- log2(nseg) levels, every separator eliminated against both neighbours at once:
+#     L_j x_(j-s) + D_j x_j + U_j x_(j+s) = b_j,      a_j = L_j D_(j-s)^-1,  c_j = U_j D_(j+s)^-1
+#     D_j <- D_j - a_j U_(j-s) - c_j L_(j+s),   L_j <- -a_j L_(j-s),   U_j <- -c_j U_(j+s),   b_j <- b_j - a_j b_(j-s) - c_j b_(j+s)
+# and after the last level x_j = (D_j + L_j + U_j)^-1 b_j.  The 5 x 5 inverses use the kernel's STATIC pivot order.
+#   python scripts/proto_kkt.py pcr
+# ----------------------------------------------------------------------------------------------------------------------
+PIV_ROWS, PIV_COLS = (3, 4, 1, 2, 0), (1, 2, 3, 4, 0)
+
+
+def inv5_static(A):
+    """Gauss-Jordan inverse with the pivot positions the kernel uses (no search)."""
+    W = np.hstack([A.astype(float).copy(), np.eye(5)])
+    for r, c in zip(PIV_ROWS, PIV_COLS):
+        W[r] = W[r] / W[r, c]
+        for i in range(5):
+            if i != r:
+                W[i] = W[i] - W[i, c] * W[r]
+    # row r now holds the unit vector e_c: x_c = (row r of the right half)
+    out = np.zeros((5, 5))
+    for r, c in zip(PIV_ROWS, PIV_COLS):
+        out[c] = W[r, 5:]
+    return out
+
+
+class PcrSeparators:
+    def __init__(self, RD, RL, RU):
+        N = RD.shape[0]
+        assert N & (N - 1) == 0
+        D, L, U = RD.copy(), RL.copy(), RU.copy()
+        self.N = N
+        self.lev = []
+        s = 1
+        while s < N:
+            Di = np.array([inv5_static(D[j]) for j in range(N)])
+            a = np.array([L[j] @ Di[(j - s) % N] for j in range(N)])
+            c = np.array([U[j] @ Di[(j + s) % N] for j in range(N)])
+            Dn = np.array([D[j] - a[j] @ U[(j - s) % N] - c[j] @ L[(j + s) % N] for j in range(N)])
+            Ln = np.array([-a[j] @ L[(j - s) % N] for j in range(N)])
+            Un = np.array([-c[j] @ U[(j + s) % N] for j in range(N)])
+            self.lev.append((s, a, c))
+            D, L, U = Dn, Ln, Un
+            s *= 2
+        self.F = np.array([inv5_static(D[j] + L[j] + U[j]) for j in range(N)])
+
+    def solve(self, b):
+        N = self.N
+        b = b.copy()
+        for s, a, c in self.lev:
+            b = np.array([b[j] - a[j] @ b[(j - s) % N] - c[j] @ b[(j + s) % N] for j in range(N)])
+        return np.einsum("jik,jk->ji", self.F, b)
+
+
+def run_pcr(name, seed=0, nseg=16, sig_lo=-8, sig_hi=12, pin_frac=0.15, kappa_w=False):
+    z = np.load(f"/root/repo/tests/golden/{name}.npz")
+    ref, nv, s = z["reftrack"], z["normvec"], z["scaling"]
+    n = ref.shape[0]
+    rng = np.random.default_rng(seed)
+    T, R, a, b, Eb, k_ref = kkt_coeffs(ref[:, :2], nv, s)
+    Td, Rd = tri_dense(T, n), tri_dense(R, n)
+    Es = np.diag(a) @ np.linalg.solve(Td, Rd @ np.diag(nv[:, 0])) + np.diag(b) @ np.linalg.solve(Td, Rd @ np.diag(nv[:, 1]))
+    sig = 10.0 ** rng.uniform(sig_lo, sig_hi, n)
+    pinned = rng.uniform(size=n) < pin_frac
+    w = 1.0 + (10.0 ** rng.uniform(-3, 10, n) if kappa_w else 0.0) * np.ones(n)
+    r = rng.standard_normal(n)
+    M = Es.T @ (w[:, None] * Es) + np.diag(sig)
+    M[pinned, :] = 0.0; M[:, pinned] = 0.0; M[pinned, pinned] = 1.0
+    Lo, Dg, Up = kkt_blocks(T, R, a, b, nv, sig, w, pinned)
+    F = KktFactor(Lo, Dg, Up, nseg)
+    x_chain = F.solve(r)
+    # the same segments, the separators by PCR
+    P = PcrSeparators(F.RD, F.RL, F.RU)
+    X0s = []
+    rr = np.zeros((nseg, 5))
+    for j in range(nseg):
+        idx, ch = F.seg[j]
+        rhs = np.zeros((len(idx), 5)); rhs[:, 0] = r[idx]
+        X0s.append(ch.solve0(rhs))
+    for j in range(nseg):
+        s0 = F.sep[j]
+        rr[j, 0] = r[s0]
+        rr[j] -= Up[s0] @ X0s[j][0] + Lo[s0] @ X0s[(j - 1) % nseg][-1]
+    xs = P.solve(rr)
+    x = np.zeros(n)
+    for j in range(nseg):
+        idx, ch = F.seg[j]
+        x[F.sep[j]] = xs[j, 0]
+        x[idx] = X0s[j][:, 0] - ch.XL[:, 0, :] @ xs[j] - ch.XR[:, 0, :] @ xs[(j + 1) % nseg]
+    res = lambda x: np.abs(M @ x - r).max() / (np.abs(M) @ np.abs(x) + np.abs(r)).max()
+    print(f"{name} n {n} nseg {nseg} seed {seed}: cond(M) {np.linalg.cond(M):.1e}  backward error chain {res(x_chain):.2e}  pcr {res(x):.2e}   pcr vs chain {np.abs(x - x_chain).max() / np.abs(x_chain).max():.2e}")
+
+
+if __name__ == "__main__" and len(sys.argv) > 1 and sys.argv[1] == "pcr":
+    for nm in ("rounded_rectangle", "handling_track", "berlin_2018_n333"):
+        for nseg in (2, 4, 8, 16):
+            run_pcr(nm, nseg, nseg=nseg)
+        run_pcr(nm, 2, kappa_w=True)
+        run_pcr(nm, 3, sig_lo=-12, sig_hi=-6, pin_frac=0.0)
+        run_pcr(nm, 4, pin_frac=0.9)
+    for nm in ("oval_n2000", "oval_n2000_c5"):
+        run_pcr(nm, 0); run_pcr(nm, 2, kappa_w=True); run_pcr(nm, 3, sig_lo=-12, sig_hi=-6, pin_frac=0.0); run_pcr(nm, 5, sig_lo=-3, sig_hi=3, pin_frac=0.3)

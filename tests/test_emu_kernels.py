@@ -645,20 +645,21 @@ def test_iqp_ring_overflow_has_its_own_status(emu, golden):
         tph.iqp_handler.iqp_handler_batch([bad], 0.12, 3.4, 3.0, 3, 0.01, engine=emu)
 
 
-@pytest.mark.parametrize("n,fused", [(7, 0), (40, 1), (105, 1), (333, 0), (333, 1), (501, 1)])
-def test_saddle_point_elimination_in_isolation(n, fused, tmp_path):
+@pytest.mark.parametrize("n,fused,pinned", [(7, 0, 0.0), (40, 1, 0.0), (105, 1, 0.0), (333, 0, 0.0), (333, 1, 0.0), (501, 1, 0.0), (333, 0, 0.3), (333, 1, 0.9)])
+def test_saddle_point_elimination_in_isolation(n, fused, pinned, tmp_path):
     """The solver's linear algebra (csrc/mcq_kkt.inc) on its own: scripts/kkt_check.hip -- the same diagnostic that runs on the GPU box --
     compiled against the SIMT interpreter.  One synthetic ring, sigma over 18 decades: every repetition must reproduce the first
     solution bit for bit, and the solution must satisfy the DENSE reduced system (sig + E'E) x = r, E built from the dense inverse of the
     spline system, to a backward error of 1e-13 (measured: 3e-16 ... 2e-15) -- with the right-hand side riding through the factorisation
-    (fused) and with the solve's own forward / backward chains; one segment (n < 48), a few, and all sixteen."""
+    (fused) and with the solve's own forward / backward chains; one segment (n < 48), a few, and all sixteen; with 30 % / 90 % of the
+    waypoints pinned (rows and columns of the reduced system replaced by identity: the active-set phase's systems)."""
     import re
     import subprocess
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     exe = str(tmp_path / "kc_emu")
     subprocess.run(["g++", "-O2", "-std=c++17", "-x", "c++", "-I", os.path.join(root, "tests", "emu", "include"), "-o", exe,
                     os.path.join(root, "scripts", "kkt_check.hip"), "-Wno-unused-result", "-Wno-attributes"], check=True)
-    out = subprocess.run([exe, str(n), "2", "2", "12", "1", str(fused)], check=True, capture_output=True, text=True).stdout
+    out = subprocess.run([exe, str(n), "2", "2", "12", "1", str(fused), str(pinned)], check=True, capture_output=True, text=True).stdout
     m = re.search(r"factor status (\d+), entries differing from the first solution (\d+) .* NaNs (\d+)", out)
     assert m and m.group(1) == "0" and m.group(2) == "0" and m.group(3) == "0", out
     berr = float(re.search(r"backward error .*: ([0-9.e+-]+)", out).group(1))
