@@ -293,6 +293,7 @@ static int launch(mcq_handle* h, McqBatch& B, const mcq_opts& o)
         return 0;
     }
     B.skip_db = (!B.prep_only && B.nmax <= MCQ_TRI_MAXN) ? 1 : 0;      // (prep_only stops before the bands anyway)
+    B.skip_eb = B.skip_db;
     HIP_TRY(hipEventRecord(h->ev[0], h->stream));
     hipLaunchKernelGGL(mcq_assemble_kernel, dim3(B.batch), dim3(256), 0, h->stream, B);
     HIP_TRY(hipGetLastError());

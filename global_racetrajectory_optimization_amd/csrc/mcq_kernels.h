@@ -127,6 +127,8 @@ struct McqBatch {
     int prep_only;          // assembly kernel stops after the spline quantities (mcq_prep_device)
     int skip_db;            // assembly kernel writes neither the D band nor the E' band: with the saddle-point core and n <= MCQ_TRI_MAXN nobody
                             // reads them (E' y and D x go through the spline system, mcq_tri.inc); the E band stays (curvature rows)
+    int skip_eb;            // ... nor the E band of the long rings: the solver kernel produces it itself for a problem whose curvature-row phase
+                            // starts (asm_e_band_lazy); short rings (image folding) always get theirs from the assembly kernel
     double* Eb; double* Et; double* Db; double* H; double* L; double* vec; double* Z;
     signed char* state;
     double* alpha;          // [batch][nmax]

@@ -312,6 +312,129 @@ __device__ __noinline__ void band_matvec(const gdouble* Mb, int bl, int br, int 
 }
 
 #if !defined(MCQ_CORE_BAND)
+// ---- pieces of the assembly that the solver kernel repeats when it has to produce the E band itself (McqBatch.skip_eb) ------------------
+#define TDIAG(m) (2.0 * S[cyc1((m) - 1, n)] * S[cyc1((m) - 1, n)] + 2.0 * S[cyc1((m) - 1, n)])
+#define TSUP(m) (S[cyc1((m) - 1, n)] * S[(m)] * S[(m)])
+// periodic pivots of the cyclic tridiagonal system in the c-coefficients: DE top-down, EP bottom-up (every thread a run of rows, started
+// MCQ_PIVOT_WARMUP rows away)
+__device__ void asm_periodic_pivots(const gdouble* S, gdouble* DE, gdouble* EP, int n)
+{
+    const int tid = threadIdx.x;
+    {
+        const int chunk = (n + MCQ_NT - 1) / MCQ_NT;
+        const int m0 = tid * chunk;
+        const int m1 = m0 + chunk < n ? m0 + chunk : n;
+        if (m0 < n) {
+            double dd = TDIAG(cyc(m0 - MCQ_PIVOT_WARMUP, n));
+            for (int k = m0 - MCQ_PIVOT_WARMUP + 1; k < m1; ++k) {
+                const int m = cyc(k, n);
+                dd = TDIAG(m) - TSUP(cyc(m - 1, n)) / dd;
+                if (k >= m0) DE[m] = dd;
+            }
+            double ee = TDIAG(cyc(m1 - 1 + MCQ_PIVOT_WARMUP, n));
+            for (int k = m1 - 2 + MCQ_PIVOT_WARMUP; k >= m0; --k) {
+                const int m = cyc(k, n);
+                ee = TDIAG(m) - TSUP(m) / ee;
+                if (k < m1) EP[m] = ee;
+            }
+        }
+    }
+}
+// the E band (and, write_db, the D band and E') of a long ring from the per-index ratios RU, RD of the rows of T^-1
+__device__ void asm_e_band_long(const McqWork& w, int nm, int n, const gdouble* S, const gdouble* DE, const gdouble* EP, const gdouble* RU,
+                                const gdouble* RD, bool write_db)
+{
+    const int tid = threadIdx.x;
+    const gdouble* XP = VEC(w, nm, V_XP);
+    const gdouble* YP = VEC(w, nm, V_YP);
+    const gdouble* CP = VEC(w, nm, V_CP);
+    const gdouble* NX = VEC(w, nm, V_NX);
+    const gdouble* NY = VEC(w, nm, V_NY);
+        // D[i, i+o] = 6 (g[o+1] - (1 + s_{j-1}) g[o] + s_{j-2} g[o-1]),  j = i + o:  a three-entry window walks up from the
+        // diagonal and down from it; stores are diagonal-major (consecutive threads = consecutive rows)
+        for (int i = tid; i < n; i += MCQ_NT) {
+            const double g0 = 1.0 / (DE[i] + EP[i] - TDIAG(i));
+            const double cpx = CP[i] * XP[i], cpy = CP[i] * YP[i];
+            const int im = i == 0 ? n - 1 : i - 1, imm = im == 0 ? n - 1 : im - 1;
+            const double gu1 = g0 * RU[i], gd1 = g0 * RD[i];
+            {
+                const double dv = 6.0 * (gu1 - (1.0 + S[im]) * g0 + S[imm] * gd1);
+                const double ev = dv * (cpx * NY[i] - cpy * NX[i]);
+                if (write_db) w.Db[(size_t)MCQ_BE_MAX * nm + i] = dv;
+                w.Eb[(size_t)MCQ_BE_MAX * nm + i] = ev;
+                if (write_db) w.Et[(size_t)MCQ_BE_MAX * nm + i] = ev;      // E'[o'][j] = E[j + o'][j]: entry (i, j = i + o) is diagonal o' = -o of column j
+            }
+            // upwards: prev = g[o-1], cur = g[o], j = i + o
+            {
+                double prev = g0, cur = gu1;
+                int j = i + 1 == n ? 0 : i + 1, jm1 = i, jm2 = im;
+#pragma unroll 2
+                for (int o = 1; o <= MCQ_BE_MAX; ++o) {
+                    const double nxt = cur * RU[j];
+                    const double dv = 6.0 * (nxt - (1.0 + S[jm1]) * cur + S[jm2] * prev);
+                    const double ev = dv * (cpx * NY[j] - cpy * NX[j]);
+                    if (write_db) w.Db[(size_t)(MCQ_BE_MAX + o) * nm + i] = dv;
+                    w.Eb[(size_t)(MCQ_BE_MAX + o) * nm + i] = ev;
+                    if (write_db) w.Et[(size_t)(MCQ_BE_MAX - o) * nm + j] = ev;        // consecutive threads: consecutive j (a wrap splits the run once)
+                    prev = cur;
+                    cur = nxt;
+                    jm2 = jm1;
+                    jm1 = j;
+                    j = j + 1 == n ? 0 : j + 1;
+                }
+            }
+            // downwards: nxt = g[o+1], cur = g[o], j = i + o  (o < 0)
+            {
+                double nxt = g0, cur = gd1;
+                int j = im, jm1 = imm, jm2 = imm == 0 ? n - 1 : imm - 1;
+#pragma unroll 2
+                for (int o = -1; o >= -MCQ_BE_MAX; --o) {
+                    const double prv = cur * RD[j];            // g[o-1]
+                    const double dv = 6.0 * (nxt - (1.0 + S[jm1]) * cur + S[jm2] * prv);
+                    const double ev = dv * (cpx * NY[j] - cpy * NX[j]);
+                    if (write_db) w.Db[(size_t)(MCQ_BE_MAX + o) * nm + i] = dv;
+                    w.Eb[(size_t)(MCQ_BE_MAX + o) * nm + i] = ev;
+                    if (write_db) w.Et[(size_t)(MCQ_BE_MAX - o) * nm + j] = ev;
+                    nxt = cur;
+                    cur = prv;
+                    j = jm1;
+                    jm1 = jm2;
+                    jm2 = jm2 == 0 ? n - 1 : jm2 - 1;
+                }
+            }
+        }
+}
+// McqBatch.skip_eb: the assembly kernel left the E band of the long rings unwritten (the saddle-point core reads it only in the rare
+// curvature-row phase); a problem that enters that phase produces its own band first -- pivots, ratios and the band loop again, the four
+// scratch vectors in the unused tail of the L slab (rows 80 .. 83 of MCQ_LLD = 144).  Uniform over the workgroup.
+__device__ __noinline__ void asm_e_band_lazy(const McqWork& w, int nm, int n, int bE)
+{
+    const int W = bE + 2;
+    const bool long_ring = (bE == MCQ_BE_MAX) && (n - W > 96) && (W < (n - 1) / 2);
+    if (!long_ring) return;                       // short rings: written by the assembly kernel whatever the flag says
+    const gdouble* S = VEC(w, nm, V_SC);
+    gdouble* DE = w.L + (size_t)80 * nm;
+    gdouble* EP = w.L + (size_t)81 * nm;
+    gdouble* RU = w.L + (size_t)82 * nm;
+    gdouble* RD = w.L + (size_t)83 * nm;
+    __syncthreads();
+    asm_periodic_pivots(S, DE, EP, n);
+    __syncthreads();
+    for (int m = threadIdx.x; m < n; m += MCQ_NT) {
+        const int mp = cyc1(m + 1, n), mm = cyc1(m - 1, n);
+        RU[m] = -(TSUP(m) / EP[mp]);
+        RD[m] = -1.0 / DE[mm];
+    }
+    __syncthreads();
+    asm_e_band_long(w, nm, n, S, DE, EP, RU, RD, false);
+    __syncthreads();
+}
+static_assert(MCQ_LLD >= 84, "asm_e_band_lazy's scratch rows");
+#undef TDIAG
+#undef TSUP
+#endif
+
+#if !defined(MCQ_CORE_BAND)
 // =====================================================================================================================
 // K1: assembly
 // =====================================================================================================================
@@ -393,25 +516,7 @@ __global__ void __launch_bounds__(MCQ_NT) mcq_assemble_kernel(McqBatch B)
     // centre m:  1*c_{m-1} + (2 s_{m-1}^2 + 2 s_{m-1}) c_m + (s_{m-1} s_m^2) c_{m+1} = 3 (s_{m-1} D_m - D_{m-1})
 #define TDIAG(m) (2.0 * S[cyc1((m) - 1, n)] * S[cyc1((m) - 1, n)] + 2.0 * S[cyc1((m) - 1, n)])
 #define TSUP(m) (S[cyc1((m) - 1, n)] * S[(m)] * S[(m)])
-    {
-        const int chunk = (n + MCQ_NT - 1) / MCQ_NT;
-        const int m0 = tid * chunk;
-        const int m1 = m0 + chunk < n ? m0 + chunk : n;
-        if (m0 < n) {
-            double dd = TDIAG(cyc(m0 - MCQ_PIVOT_WARMUP, n));
-            for (int k = m0 - MCQ_PIVOT_WARMUP + 1; k < m1; ++k) {
-                const int m = cyc(k, n);
-                dd = TDIAG(m) - TSUP(cyc(m - 1, n)) / dd;
-                if (k >= m0) DE[m] = dd;
-            }
-            double ee = TDIAG(cyc(m1 - 1 + MCQ_PIVOT_WARMUP, n));
-            for (int k = m1 - 2 + MCQ_PIVOT_WARMUP; k >= m0; --k) {
-                const int m = cyc(k, n);
-                ee = TDIAG(m) - TSUP(m) / ee;
-                if (k < m1) EP[m] = ee;
-            }
-        }
-    }
+    asm_periodic_pivots(S, DE, EP, n);
     __syncthreads();
 
     // ---- phase 2: rows of T^-1 (periodic Green's function, images folded onto the ring) and the c-coefficients -------
@@ -524,59 +629,8 @@ __global__ void __launch_bounds__(MCQ_NT) mcq_assemble_kernel(McqBatch B)
     // ---- phase 3b: D band (x'' = D x) and E_kappa band, diagonal-major -------------------------------------------------
     const int ew = d.ew;
     if (long_ring) {
-        // D[i, i+o] = 6 (g[o+1] - (1 + s_{j-1}) g[o] + s_{j-2} g[o-1]),  j = i + o:  a three-entry window walks up from the
-        // diagonal and down from it; stores are diagonal-major (consecutive threads = consecutive rows)
-        for (int i = tid; i < n; i += MCQ_NT) {
-            const double g0 = 1.0 / (DE[i] + EP[i] - TDIAG(i));
-            const double cpx = CP[i] * XP[i], cpy = CP[i] * YP[i];
-            const int im = i == 0 ? n - 1 : i - 1, imm = im == 0 ? n - 1 : im - 1;
-            const double gu1 = g0 * RU[i], gd1 = g0 * RD[i];
-            {
-                const double dv = 6.0 * (gu1 - (1.0 + S[im]) * g0 + S[imm] * gd1);
-                const double ev = dv * (cpx * NY[i] - cpy * NX[i]);
-                if (!B.skip_db) w.Db[(size_t)MCQ_BE_MAX * nm + i] = dv;
-                w.Eb[(size_t)MCQ_BE_MAX * nm + i] = ev;
-                if (!B.skip_db) w.Et[(size_t)MCQ_BE_MAX * nm + i] = ev;      // E'[o'][j] = E[j + o'][j]: entry (i, j = i + o) is diagonal o' = -o of column j
-            }
-            // upwards: prev = g[o-1], cur = g[o], j = i + o
-            {
-                double prev = g0, cur = gu1;
-                int j = i + 1 == n ? 0 : i + 1, jm1 = i, jm2 = im;
-#pragma unroll 2
-                for (int o = 1; o <= MCQ_BE_MAX; ++o) {
-                    const double nxt = cur * RU[j];
-                    const double dv = 6.0 * (nxt - (1.0 + S[jm1]) * cur + S[jm2] * prev);
-                    const double ev = dv * (cpx * NY[j] - cpy * NX[j]);
-                    if (!B.skip_db) w.Db[(size_t)(MCQ_BE_MAX + o) * nm + i] = dv;
-                    w.Eb[(size_t)(MCQ_BE_MAX + o) * nm + i] = ev;
-                    if (!B.skip_db) w.Et[(size_t)(MCQ_BE_MAX - o) * nm + j] = ev;        // consecutive threads: consecutive j (a wrap splits the run once)
-                    prev = cur;
-                    cur = nxt;
-                    jm2 = jm1;
-                    jm1 = j;
-                    j = j + 1 == n ? 0 : j + 1;
-                }
-            }
-            // downwards: nxt = g[o+1], cur = g[o], j = i + o  (o < 0)
-            {
-                double nxt = g0, cur = gd1;
-                int j = im, jm1 = imm, jm2 = imm == 0 ? n - 1 : imm - 1;
-#pragma unroll 2
-                for (int o = -1; o >= -MCQ_BE_MAX; --o) {
-                    const double prv = cur * RD[j];            // g[o-1]
-                    const double dv = 6.0 * (nxt - (1.0 + S[jm1]) * cur + S[jm2] * prv);
-                    const double ev = dv * (cpx * NY[j] - cpy * NX[j]);
-                    if (!B.skip_db) w.Db[(size_t)(MCQ_BE_MAX + o) * nm + i] = dv;
-                    w.Eb[(size_t)(MCQ_BE_MAX + o) * nm + i] = ev;
-                    if (!B.skip_db) w.Et[(size_t)(MCQ_BE_MAX - o) * nm + j] = ev;
-                    nxt = cur;
-                    cur = prv;
-                    j = jm1;
-                    jm1 = jm2;
-                    jm2 = jm2 == 0 ? n - 1 : jm2 - 1;
-                }
-            }
-        }
+        // (skip_eb: not even E -- the solver kernel produces the band itself if a problem's curvature-row phase starts: asm_e_band_lazy)
+        if (!B.skip_eb) asm_e_band_long(w, nm, n, S, DE, EP, RU, RD, !B.skip_db);
     } else
     for (int idx = tid; idx < n * ew; idx += MCQ_NT) {
         const int oo = idx / n, i = idx - oo * n, o = oo - d.bE;
@@ -3690,6 +3744,9 @@ __global__ void __launch_bounds__(MCQ_NT, 2) mcq_solve_kernel(McqBatch B)
     //      then the box active-set polish with the curvature multipliers frozen ---------------------------------------------
     if (status == MCQ_OK && B.check_kappa && !c.direct && km > kbound * (1.0 + 1e-9)) {
         dd_valid = false;
+#if !defined(MCQ_CORE_BAND)
+        if (B.skip_eb) asm_e_band_lazy(c.w, nm, n, c.d.bE);      // the E band, first needed here
+#endif
         status = ipm(c, B, true, sc, it2);
         ipm_iters += it2;
         __syncthreads();
