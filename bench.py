@@ -61,10 +61,11 @@ def work_model(n, info, band_e=32):
     streamed   what THIS implementation has to move through HBM per launch -- the figure `roofline.achieved` /
                `frac` are computed from.  Since the saddle-point core (round 3, csrc/mcq_kkt.inc, mcq_tri.inc), per waypoint:
                  factorisation : elimination writes D~^-1 | Lo (160 B: D~^-1 is symmetric, 15 packed entries + Lo's five) and the
-                                 forward-eliminated left spike | y (240) -- G = D~^-1 Up is not stored: Up_k is Lo_(k+1)', the consumers
+                                 forward-eliminated left spike | y (208: four of the spike's five columns, the fifth is a combination of
+                                 two of them) -- G = D~^-1 Up is not stored: Up_k is Lo_(k+1)', the consumers
                                  rebuild G x from the two records -- ; the spike pass reads both back and writes the alpha rows of
                                  the spikes (80); inputs: 8 per-waypoint vectors + the mask byte (65); the right-hand side of the
-                                 solve that follows rides through both passes (16)                             -> 961 bytes
+                                 solve that follows rides through both passes (16)                             -> 897 bytes
                  solve after a factorisation (interior-point predictor, active-set round): the separators' system (LDS) and the
                                  spike correction: spikes (80) + the vector read and written (16)              -> 96 bytes
                  any other solve (corrector, refinement round): forward chain (160 + 8 + 40), backward chain (160 + 40 + 8),
@@ -90,7 +91,7 @@ def work_model(n, info, band_e=32):
     n_grad = 1.0 + 2 * act + ref + 1.0 + 1.0 + 1.0
     ew = 2 * band_e + 1
     grad = n * 216.0
-    b_fac, b_fused, b_solve = n * 961.0, n * 96.0, n * 512.0
+    b_fac, b_fused, b_solve = n * 897.0, n * 96.0, n * 512.0
     passes = ipm * n * 264.0 + act * n * 240.0
     plain = n_sol - n_fac                          # solves that run their own chains
     streamed = float((n_fac * (b_fac + b_fused) + plain * b_solve + n_grad * grad + passes).sum())
