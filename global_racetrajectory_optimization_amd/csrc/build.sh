@@ -3,20 +3,27 @@
 set -e
 cd "$(dirname "$0")"
 HIPCC=${HIPCC:-/opt/rocm/bin/hipcc}
-# -amdgpu-mfma-vgpr-form: MFMA results land in VGPRs (no v_accvgpr_read before every LDS store of an updated tile)
 # -enable-ipra=0: the AMDGPU backend's interprocedural register allocation is OFF.  With it, hipcc 7.2 miscompiled the callers of a
-#   non-inlined device function once that function grew past the caller-saved VGPRs (band_matvec with 16-byte loads: the curvature-row
-#   path then read a null pointer on the GPU -- found by the -m gpu suite, not by the SIMT emulator, which never sees the allocator).
-#   Plain calling-convention clobbers are also 1 % faster on the solver kernel.
-# mcq_kernels.hip is compiled TWICE (see its header): the library's kernels with the saddle-point core for two workgroups per CU
-# (--gpu-max-threads-per-block=512: every device function stays within 256 VGPRs), and -DMCQ_CORE_BAND: namespace mcq_band, the solver
-# kernel on the bordered-band core (shortest-path objective).
-FLAGS="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -mllvm -amdgpu-mfma-vgpr-form -mllvm -enable-ipra=0"
+#   non-inlined device function once that function grew past the caller-saved VGPRs (the curvature-row path then read a null pointer on
+#   the GPU -- found by the -m gpu suite, not by the SIMT emulator, which never sees the allocator).  Plain calling-convention clobbers
+#   are also 1 % faster on the solver kernel.
+# --gpu-max-threads-per-block=512: every device function of mcq_kernels.hip stays within 256 VGPRs (two workgroups of the solver kernel
+#   per CU).
+# ASM_OUT=<file>: also keep the device ISA of mcq_kernels.hip there (scripts/check_csr.py reads it instead of compiling a second time).
+FLAGS="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -mllvm -enable-ipra=0"
 OUT=${OUT:-libmcq.so}
 TMP=$(mktemp -d)
-$HIPCC $FLAGS --gpu-max-threads-per-block=512 "$@" -c -o $TMP/kkt.o mcq_kernels.hip &
-$HIPCC $FLAGS -DMCQ_CORE_BAND "$@" -c -o $TMP/band.o mcq_kernels.hip &
+trap 'rm -rf "$TMP"' EXIT
+$HIPCC $FLAGS --gpu-max-threads-per-block=512 "$@" -c -o $TMP/kernels.o mcq_kernels.hip &
+P1=$!
 $HIPCC $FLAGS "$@" -c -o $TMP/api.o mcq_api.hip &
-wait
-$HIPCC --offload-arch=gfx950 -shared -fPIC -o $OUT $TMP/kkt.o $TMP/band.o $TMP/api.o
-rm -rf $TMP
+P2=$!
+P3=
+if [ -n "$ASM_OUT" ]; then
+  $HIPCC $FLAGS --gpu-max-threads-per-block=512 "$@" -S --cuda-device-only -o "$ASM_OUT" mcq_kernels.hip &
+  P3=$!
+fi
+wait $P1 || { echo "build.sh: mcq_kernels.hip failed to compile" >&2; exit 1; }
+wait $P2 || { echo "build.sh: mcq_api.hip failed to compile" >&2; exit 1; }
+if [ -n "$P3" ]; then wait $P3 || { echo "build.sh: ISA dump failed" >&2; exit 1; }; fi
+$HIPCC --offload-arch=gfx950 -shared -fPIC -o $OUT $TMP/kernels.o $TMP/api.o

@@ -37,7 +37,7 @@ struct mcq_handle {
     // workspace slabs
     size_t cap_elems = 0;   // batch * nmax the slabs are sized for
     size_t cap_batch = 0;
-    double *Eb = nullptr, *Et = nullptr, *Db = nullptr, *H = nullptr, *L = nullptr, *vec = nullptr, *Z = nullptr;
+    double *L = nullptr, *vec = nullptr, *Z = nullptr;
     signed char* state = nullptr;
     signed char* state2 = nullptr;     // working sets carried through the IQP glue (warm start of the next pass)
     bool state2_valid = false;
@@ -93,7 +93,7 @@ static mcq_opts resolve_opts(const mcq_opts* in)
     mcq_opts o;
     mcq_default_opts(&o);
     if (in) {
-        if (in->band_e > 0) o.band_e = in->band_e < MCQ_BE_MAX ? in->band_e : MCQ_BE_MAX;
+        o.band_e = 32;      // (ignored since round 4: E is applied through the spline system, untruncated; the field stays for ABI compatibility)
         if (in->max_ipm_iter > 0) o.max_ipm_iter = in->max_ipm_iter;
         if (in->max_as_iter > 0) o.max_as_iter = in->max_as_iter;
         if (in->refine_steps >= 0) o.refine_steps = in->refine_steps;
@@ -133,11 +133,11 @@ extern "C" int mcq_create(int device_id, mcq_handle** out)
 
 static void free_ws(mcq_handle* h)
 {
-    (void)hipFree(h->Eb); (void)hipFree(h->Et); (void)hipFree(h->Db); (void)hipFree(h->H); (void)hipFree(h->L); (void)hipFree(h->vec); (void)hipFree(h->Z); (void)hipFree(h->state);
+    (void)hipFree(h->L); (void)hipFree(h->vec); (void)hipFree(h->Z); (void)hipFree(h->state);
     (void)hipFree(h->state2);
     (void)hipFree(h->kbig); (void)hipFree(h->kbig_count);
     h->kbig = nullptr; h->kbig_count = nullptr;
-    h->Eb = h->Et = h->Db = h->H = h->L = h->vec = h->Z = nullptr;
+    h->L = h->vec = h->Z = nullptr;
     h->state = h->state2 = nullptr;
     h->state2_valid = false;
     h->cap_elems = h->cap_batch = 0;
@@ -197,10 +197,6 @@ static int ensure_ws(mcq_handle* h, size_t batch, size_t nmax)
     if (elems <= h->cap_elems && batch <= h->cap_batch) return 0;
     HIP_TRY(hipStreamSynchronize(h->stream));
     free_ws(h);
-    HIP_TRY(hipMalloc((void**)&h->Eb, elems * MCQ_ELD * sizeof(double)));
-    HIP_TRY(hipMalloc((void**)&h->Et, elems * MCQ_ELD * sizeof(double)));
-    HIP_TRY(hipMalloc((void**)&h->Db, elems * MCQ_ELD * sizeof(double)));
-    HIP_TRY(hipMalloc((void**)&h->H, elems * MCQ_HLD * sizeof(double)));
     HIP_TRY(hipMalloc((void**)&h->L, elems * MCQ_LLD * sizeof(double)));
     HIP_TRY(hipMalloc((void**)&h->vec, elems * MCQ_NVEC * sizeof(double)));
     HIP_TRY(hipMalloc((void**)&h->Z, (elems + batch * (size_t)MCQ_KMAX * MCQ_KMAX) * sizeof(double)));
@@ -212,17 +208,13 @@ static int ensure_ws(mcq_handle* h, size_t batch, size_t nmax)
     HIP_TRY(hipMemsetAsync(h->state, 0, elems, h->stream));
     HIP_TRY(hipMemsetAsync(h->state2, 0, elems, h->stream));
     if (h->poison) {
-        HIP_TRY(hipMemsetAsync(h->Eb, 0xff, elems * MCQ_ELD * sizeof(double), h->stream));
-        HIP_TRY(hipMemsetAsync(h->Et, 0xff, elems * MCQ_ELD * sizeof(double), h->stream));
-        HIP_TRY(hipMemsetAsync(h->Db, 0xff, elems * MCQ_ELD * sizeof(double), h->stream));
-        HIP_TRY(hipMemsetAsync(h->H, 0xff, elems * MCQ_HLD * sizeof(double), h->stream));
         HIP_TRY(hipMemsetAsync(h->L, 0xff, elems * MCQ_LLD * sizeof(double), h->stream));
         HIP_TRY(hipMemsetAsync(h->vec, 0xff, elems * MCQ_NVEC * sizeof(double), h->stream));
         HIP_TRY(hipMemsetAsync(h->Z, 0xff, (elems + batch * (size_t)MCQ_KMAX * MCQ_KMAX) * sizeof(double), h->stream));
     }
     h->cap_elems = elems;
     h->cap_batch = batch;
-    h->ws_bytes = (long long)(elems * ((3 * MCQ_ELD + MCQ_HLD + MCQ_LLD + MCQ_NVEC + 1) * sizeof(double) + 2) +
+    h->ws_bytes = (long long)(elems * ((MCQ_LLD + MCQ_NVEC + 1) * sizeof(double) + 2) +
                               batch * (size_t)MCQ_KMAX * MCQ_KMAX * sizeof(double) +
                               (size_t)MCQ_KBIG_SLOTS * MCQ_KBIG_SLOT * sizeof(double));
     return 0;
@@ -256,13 +248,9 @@ static int ensure_stage(mcq_handle* h, size_t batch, size_t nmax)
     return 0;
 }
 
-#ifndef MCQ_GRAM_Y
-#define MCQ_GRAM_Y 16     /* workgroups per problem of the generic Gram kernel (boundary rows, border part) */
-#endif
 static int launch(mcq_handle* h, McqBatch& B, const mcq_opts& o)
 {
-    B.Eb = h->Eb; B.Et = h->Et; B.Db = h->Db; B.H = h->H; B.L = h->L; B.vec = h->vec; B.Z = h->Z; B.state = h->state;
-    B.band_e = o.band_e;
+    B.L = h->L; B.vec = h->vec; B.Z = h->Z; B.state = h->state;
     B.max_ipm_iter = o.max_ipm_iter;
     B.max_as_iter = o.max_as_iter;
     B.refine_steps = o.refine_steps;
@@ -285,22 +273,18 @@ static int launch(mcq_handle* h, McqBatch& B, const mcq_opts& o)
         HIP_TRY(hipGetLastError());
         HIP_TRY(hipEventRecord(h->ev[1], h->stream));
         HIP_TRY(hipEventRecord(h->ev[2], h->stream));
-        hipLaunchKernelGGL(mcq_band::mcq_solve_kernel, dim3(B.batch), dim3(256), 0, h->stream, B);
+        hipLaunchKernelGGL(mcq_solve_kernel, dim3(B.batch), dim3(256), 0, h->stream, B);
         HIP_TRY(hipGetLastError());
         HIP_TRY(hipEventRecord(h->ev[3], h->stream));
         HIP_TRY(hipEventRecord(h->ev[4], h->stream));
         h->timing_valid = true;
         return 0;
     }
-    B.skip_db = (!B.prep_only && B.nmax <= MCQ_TRI_MAXN) ? 1 : 0;      // (prep_only stops before the bands anyway)
-    B.skip_eb = B.skip_db;
     HIP_TRY(hipEventRecord(h->ev[0], h->stream));
     hipLaunchKernelGGL(mcq_assemble_kernel, dim3(B.batch), dim3(256), 0, h->stream, B);
     HIP_TRY(hipGetLastError());
     if (B.prep_only) return 0;
     HIP_TRY(hipEventRecord(h->ev[1], h->stream));
-    // (K2, the band of H = E'E: mcq_gram_kernel / mcq_gram_tile_kernel are not launched any more -- the saddle-point core of the solver kernel
-    //  works on the spline system itself, and f = 2 E'k_ref is one band product at the top of the solver kernel)
     HIP_TRY(hipEventRecord(h->ev[2], h->stream));
     hipLaunchKernelGGL(mcq_solve_kernel, dim3(B.batch), dim3(256), 0, h->stream, B);
     HIP_TRY(hipGetLastError());

@@ -4,79 +4,43 @@
 // The maths follows SURVEY.md App. A (restating tph.opt_min_curv, call sites [REF main_globaltraj.py:264-271,
 // 344-350]); DESIGN.md sections 3-5 derive the structure-exploiting form used here:
 //
-//   K1 mcq_assemble_kernel : [x,y,w_r,w_l] rows, normals, spline scalings  ->  cyclic-banded E_kappa (and its
-//                            transpose band), D band, k_ref, x', y', box bounds.  The closed cubic-spline system
-//                            is a cyclic tridiagonal solve; rows of its inverse come from the periodic pivot
-//                            recurrences (exact to fp64 round-off: entries decay like 0.268^k).
-//   K2 mcq_gram_kernel     : H = E'E in "bordered band" storage (interior band + dense border that carries the
-//                            cyclic wrap-around), f = MCQ_F_SCALE * E' k_ref.
-//   K3 mcq_solve_kernel    : Mehrotra predictor-corrector interior point on the box QP (one bordered-band Cholesky
-//                            per iteration, LDS sliding window) -> active-set identification -> block-pivoting
-//                            active-set iterations on the identified vertex (exact KKT point, like the
+//   K1 mcq_assemble_kernel : [x,y,w_r,w_l] rows, normals, spline scalings  ->  box bounds, the pivots of the closed cubic-spline
+//                            system (a cyclic tridiagonal matrix T: periodic pivot recurrences, mcq_tri.inc), x'', y'' (two solves
+//                            with T), x', y', the curvature pre-factor, k_ref.  No matrix is formed: E = a T^-1 R Nx + b T^-1 R Ny.
+//   K3 mcq_solve_kernel    : Mehrotra predictor-corrector interior point on the box QP -> active-set identification ->
+//                            block-pivoting active-set iterations on the identified vertex (exact KKT point, like the
 //                            Goldfarb-Idnani solver the reference uses returns) -> fp64 residual refinement through
-//                            E -> curvature-row check -> opt_min_curv's curvature-error post-check.
+//                            E -> curvature-row check -> opt_min_curv's curvature-error post-check.  Linear algebra: the
+//                            saddle-point elimination of mcq_kkt.inc (5 x 5 blocks per waypoint; H = E'E is never formed),
+//                            E and E' applied through T (mcq_tri.inc); shortest path: scalar cyclic tridiagonal (mcq_tri.inc).
 //
-// Global-memory layout per problem (doubles, leading dimension in brackets):
-//   Eb/Db    [MCQ_ELD][nmax]  cyclic bands, DIAGONAL-MAJOR: entry [(bE+o)*nmax + i] = M[i, (i+o) mod n], -bE <= o <= bR
-//   Et       [MCQ_ELD][nmax]  transpose band: entry [(bR+o)*nmax + j] = E[(j+o) mod n, j],  -bR <= o <= bE
-//                             (diagonal-major => a wave reading one diagonal for 64 consecutive rows reads 512 contiguous
-//                              bytes; band products need no cross-lane reduction)
-//   H        [n][MCQ_HLD]  interior rows i < ni: [(i mod 16) + k] upper band H[i,i+k], k = 0..b  (MCQ_HBAND: the band of row i starts
-//                          i mod 16 slots into the row, so that the 16 entries H[c, 16 R .. 16 R + 15] of a column c that one tile
-//                          of the factorisation's window takes are ONE aligned 128-byte line -- indexed by k alone they started
-//                          at arbitrary offsets and every fetch touched two lines, round 3);  [MCQ_HBO + jj] border coupling
-//                          H[i, ni+jj];  border rows i = ni+j: [MCQ_HBO + jj] = D[j][jj].  Rows are 9 lines of 128 bytes.
-//   L        [n][MCQ_LLD]  interior rows i < ni: [m] = L[i, i-1-m] (m < 64), [MCQ_LBI + c] = row (i mod 16) of the inverse
-//                          of the 16x16 diagonal tile i/16, [MCQ_LBW + jj] = W[i][jj];  every piece 16-byte aligned.
-//                          (the inverse of the border factor L_S stays in LDS, packed lower-triangular)
-//   vectors  [n]           see Work struct
+// Global-memory workspace per problem (doubles):
+//   L        [nmax][MCQ_LLD]  records of the saddle-point elimination (mcq_kkt.inc: K_AD, K_AY, K_AS, K_YV -- 65 doubles per waypoint)
+//                             and three scratch vectors of the long-ring tridiagonal route (K_TS)
+//   vectors  [MCQ_NVEC][nmax] see the enum below
+//   Z        [nmax] + [MCQ_KMAX][MCQ_KMAX]   curvature-row path: one scratch vector, the Schur complement of the active rows
+//   state    [nmax] bytes     working set
 #pragma once
 #include <hip/hip_runtime.h>
 
 #include "../../include/mcq.h"
 
-#define MCQ_BE_MAX 32
-#define MCQ_BH_MAX 64
-#define MCQ_P_MAX 64
-#define MCQ_ELD 66                 /* 2*BE_MAX+1 = 65, padded */
-#define MCQ_GW (MCQ_BE_MAX + 2)    /* half-width of the T^-1 rows kept */
-#define MCQ_GLD 72                 /* 2*GW+1 = 69, padded */
-#define MCQ_HBO 80                 /* offset of the border part inside an H row */
-#define MCQ_HLD 144                /* H rows: 80 band slots (65 used, shifted by i mod 16) | P_MAX border */
-#define MCQ_HBAND(i, k) ((size_t)(i) * MCQ_HLD + (size_t)(((i) & 15) + (k)))      /* slot of H[i, i+k] */
-#define MCQ_LLD 144                /* L rows: 64 band entries | 16 inverse-diagonal-tile entries | 64 border entries */
-#define MCQ_LBI 64                 /* offset of the inverse diagonal tile row inside an L row */
-#define MCQ_LBW 80                 /* offset of the border part W inside an L row */
+#define MCQ_LLD 72                 /* doubles per waypoint of the L slab */
 #define MCQ_NVEC 32
-#define MCQ_TRI_MAXN 2208         /* rings up to this length apply E, E', D through the spline system (mcq_tri.inc: three vectors in the LDS overlay) */
+#define MCQ_TRI_MAXN 2048         /* rings up to this length run the tridiagonal sweeps of mcq_tri.inc in LDS (eight waypoints per thread); longer ones on workspace vectors */
 #define MCQ_KMAX 120               /* active curvature rows the Schur-complement path of the active-set phase holds */
 #define MCQ_KBIG 512               /* ... and of the overflow path (round 3): a problem with more of them claims one of the handle's slots, */
 #define MCQ_KBIG_SLOT ((size_t)MCQ_KBIG * MCQ_KBIG + 6 * (size_t)MCQ_KBIG)   /* doubles per slot: Schur matrix, three vectors, the index / sign / pivot lists */
 #define MCQ_KBIG_SLOTS 8           /* slots per handle (17 MB): problems of one launch that can take the overflow path */
 #define MCQ_ZLD(nmax) ((size_t)(nmax) + (size_t)MCQ_KMAX * MCQ_KMAX)   /* doubles of the curvature-row scratch per problem: one vector + the Schur matrix */
-#define MCQ_PIVOT_WARMUP 64
 
-// bE / bR: half-widths of the cyclic band of E_kappa to the left / right of the diagonal.  bR = bE except for small
-// even n, where the ring is fully covered by offsets [-bE, bE+1] (every column exactly once, E is then dense-exact).
 struct McqDims {
-    int n, bE, bR, ew, bH, p, ni, b;
+    int n;
 };
-
-__host__ __device__ inline McqDims mcq_dims(int n, int band_e)
+__host__ __device__ inline McqDims mcq_dims(int n)
 {
     McqDims d;
     d.n = n;
-    int bE = band_e < (n - 1) / 2 ? band_e : (n - 1) / 2;
-    if (bE < 1) bE = 1;
-    d.bE = bE;
-    d.bR = (n % 2 == 0 && band_e >= n / 2) ? bE + 1 : bE;
-    d.ew = d.bE + d.bR + 1;
-    d.bH = d.bE + d.bR < n / 2 ? d.bE + d.bR : n / 2;
-    if (d.bH < 1) d.bH = 1;
-    d.p = d.bH;
-    d.ni = n - d.p;
-    d.b = d.bH < d.ni - 1 ? d.bH : d.ni - 1;
-    if (d.b < 0) d.b = 0;
     return d;
 }
 
@@ -93,10 +57,6 @@ struct McqWork {
     const gdouble* ref;   // [n][4]
     const gdouble* nv;    // [n][2]
     const gdouble* sc;    // [n] or nullptr
-    gdouble* Eb;
-    gdouble* Et;
-    gdouble* Db;
-    gdouble* H;
     gdouble* L;           // also scratch for the T^-1 rows during assembly
     gdouble* vec;         // MCQ_NVEC vectors of length nmax, see enum below
     gschar* state;        // [n] 0 free, -1 at lower bound, +1 at upper bound, 2 fixed (lo == hi)
@@ -125,36 +85,26 @@ struct McqBatch {
     double* nv_out;         // optional outputs of the assembly: normals [batch][nmax][2], scalings [batch][nmax]
     double* sc_out;
     int prep_only;          // assembly kernel stops after the spline quantities (mcq_prep_device)
-    int skip_db;            // assembly kernel writes neither the D band nor the E' band: with the saddle-point core and n <= MCQ_TRI_MAXN nobody
-                            // reads them (E' y and D x go through the spline system, mcq_tri.inc); the E band stays (curvature rows)
-    int skip_eb;            // ... nor the E band of the long rings: the solver kernel produces it itself for a problem whose curvature-row phase
-                            // starts (asm_e_band_lazy); short rings (image folding) always get theirs from the assembly kernel
-    double* Eb; double* Et; double* Db; double* H; double* L; double* vec; double* Z;
+    double* L; double* vec; double* Z;
     signed char* state;
     double* alpha;          // [batch][nmax]
     double* curv_err; int* status; mcq_info* info;
     double kappa_bound, w_veh;
     const double* kappa_bound_list;  // per-problem overrides (device) or nullptr
     const double* w_veh_list;
-    int band_e, max_ipm_iter, max_as_iter, refine_steps, check_kappa;
+    int max_ipm_iter, max_as_iter, refine_steps, check_kappa;
     const signed char* warm; // [batch][nmax] working set to start the exchange from (IQP passes 2+), or nullptr (cold: interior point)
     int poison_lds;         // MCQ_POISON=1 (debugging aid): the solver kernel starts from an LDS full of NaNs, like the workspaces
     double* kbig;           // overflow slots of the curvature-row working set (MCQ_KBIG_SLOT doubles each), kbig_slots of them;
     int* kbig_count;        // slots claimed in this launch (zeroed by the host before it)
     int kbig_slots;
-    int objective;          // MCQ_OBJ_*: shortest path = H and f written directly by mcq_assemble_sp_kernel (Eb holds the three
-                            // diagonals of H, the gradient is H x + f), no curvature rows, no curvature-error post-check
+    int objective;          // MCQ_OBJ_*: shortest path = H (a cyclic tridiagonal: two vectors) and f written directly by
+                            // mcq_assemble_sp_kernel, the gradient is H x + f; no curvature rows, no curvature-error post-check
 };
 
 __global__ void mcq_assemble_kernel(McqBatch B);
 __global__ void mcq_assemble_sp_kernel(McqBatch B);
-__global__ void mcq_gram_kernel(McqBatch B);
-__global__ void mcq_gram_tile_kernel(McqBatch B);
-__global__ void mcq_solve_kernel(McqBatch B);      // saddle-point core (mcq_kkt.inc), two workgroups per CU
-namespace mcq_band {
-__global__ void mcq_solve_kernel(McqBatch B);      // bordered-band core (second translation unit of mcq_kernels.hip, -DMCQ_CORE_BAND): H given entry by entry
-size_t mcq_solve_lds_bytes();
-}
+__global__ void mcq_solve_kernel(McqBatch B);      // saddle-point elimination (mcq_kkt.inc) / scalar cyclic tridiagonal (shortest path, mcq_tri.inc); two workgroups per CU
 
 /* tph.check_normals_crossing [REF helper_funcs_glob/src/prep_track.py:57-59], one workgroup per track: crossing_out [batch] =
  * 1 / 0, or -1 where tph raises (horizon >= n) */

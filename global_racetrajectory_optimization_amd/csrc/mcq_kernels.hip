@@ -3,71 +3,16 @@
 
 #include <math.h>
 
-// Two translation units are built from this file (build.sh):
-//   default          the library's kernels; the solver's linear algebra is the saddle-point elimination of mcq_kkt.inc.  Compiled for
-//                    TWO workgroups per CU: <= 256 VGPRs (hipcc --gpu-max-threads-per-block=512 + __launch_bounds__(256, 2)), 78 KB of LDS.
-//   -DMCQ_CORE_BAND  namespace mcq_band: ONLY the solver kernel, on the bordered-band Cholesky of rounds 1-3 (H given entry by entry:
-//                    the shortest-path objective, whose H is a cyclic tridiagonal the saddle-point form has no use for); 152 KB of LDS,
-//                    one workgroup per CU.
-#if defined(MCQ_CORE_BAND)
-#define MCQ_KKT 0
-namespace mcq_band {
-#else
-#define MCQ_KKT 1
-#endif
+// ONE translation unit (round 4): the solver's linear algebra is the saddle-point elimination of mcq_kkt.inc (minimum curvature) and the
+// scalar cyclic-tridiagonal elimination of mcq_tri.inc (shortest path).  Compiled for TWO workgroups per CU: <= 256 VGPRs
+// (hipcc --gpu-max-threads-per-block=512 + __launch_bounds__(256, 2)), 78 KB of LDS.
 
 
 #define MCQ_NT 256
 #define MCQ_NW (MCQ_NT / 64)
-typedef double v4d __attribute__((vector_size(32)));   /* accumulator fragment of v_mfma_f64_16x16x4_f64 */
 typedef double d2 __attribute__((vector_size(16)));
 typedef __attribute__((address_space(1))) d2 gd2;
-#define TB 16                           /* tile edge of the blocked factorisation (v_mfma_f64_16x16x4_f64) */
-#define TLD 17                          /* padded row stride of an LDS tile: conflict-free MFMA operand reads */
-#define TSZ (TB * TLD)
-#define NTR (MCQ_BH_MAX / TB + 1)       /* tile rows / cols of the sliding band window (5) */
-#define NCT (MCQ_P_MAX / TB)            /* tile columns of the border block (4) */
-#define SLD (MCQ_P_MAX + 1)
-#define WLD (MCQ_BH_MAX + 1)
-#define CH 64                           /* rows per chunk of the triangular sweeps (4 tiles) */
-#define CLD 80                          /* LDS row of a chunk: 64 band entries + 16 inverse-diagonal-tile entries */
-#define NBUF 3                          /* chunk ring: current, previous (backward sweep) / next, one being filled */
-#define NRB 4                           /* right-hand-side ring (chunks) */
-#define VRING 128                       /* ring of the most recent unknowns (the band reaches 64 back, tiles are 16 wide) */
-#if defined(MCQ_CORE_BAND)
-#define SPK (MCQ_P_MAX * (MCQ_P_MAX + 1) / 2)   /* packed lower triangle of the inverse border factor */
-#endif
 
-#if defined(MCQ_CORE_BAND)
-// ---------------------------------------------------------------------------------------------------------------------
-// shared-memory carve-up of the solver kernel (doubles).  The triangular sweeps overlay the factorisation window.
-// ---------------------------------------------------------------------------------------------------------------------
-#define SM_RED 0
-#define SM_XD (SM_RED + 64)
-#define SM_PART (SM_XD + 64)
-#define SM_S (SM_PART + MCQ_NW * 128)             /* L_S^-1, packed rows: entry (r, c <= r) at r (r + 1) / 2 + c */
-#define SM_OVL (SM_S + SPK)                       /* overlay region */
-#define NTRC (NTR + 1)                   /* tile rows of the border window: one more than the band (committed a phase earlier) */
-#define NCT5 (NCT + 1)                   /* tiles of a border-window row slot: the inverse of the step's diagonal tile, then C(., 0..3) */
-#define OVL_SIZE_F (NTR * NTR * TSZ + NTRC * NCT5 * TSZ + 32 + 2 * VRING)
-#define OVL_SIZE_S (NBUF * CH * CLD + NRB * CH + VRING)
-#define OVL_SIZE (OVL_SIZE_F > OVL_SIZE_S ? OVL_SIZE_F : OVL_SIZE_S)
-#define SM_BT SM_OVL                              /* band tiles   (NTR x NTR) */
-#define SM_CT (SM_BT + NTR * NTR * TSZ)           /* border window: NTRC row slots of [inverse diagonal tile | C(., 0..3)] */
-#define SM_DINV (SM_CT + NTRC * NCT5 * TSZ)       /* fail flag of the factorisation (slot TB) */
-#define SM_YR (SM_DINV + 32)                      /* forward substitution fused into the factorisation: VRING most recent unknowns ... */
-#define SM_PEND (SM_YR + VRING)                   /* ... and VRING pending sums  - sum_K L(I, K) y_K  of the block rows ahead */
-#define SM_CHUNK SM_OVL                           /* NBUF x CH x CLD */
-#define SM_RHS (SM_CHUNK + NBUF * CH * CLD)       /* NRB x CH */
-#define SM_VR (SM_RHS + NRB * CH)                 /* VRING */
-#define SM_KV (SM_OVL + OVL_SIZE)                 /* 3 x KMAX: multipliers, right-hand side, elimination multipliers */
-#define SM_KI (SM_KV + 3 * MCQ_KMAX)              /* ints: nk, row index[KMAX], sign[KMAX], pivot row[KMAX] */
-#define SM_TOTAL (SM_KI + (3 * MCQ_KMAX + 2 + 1) / 2 + 1)
-/* the KMAX x KMAX Schur matrix of the active curvature rows lives in HBM (McqWork.Z) and is brought into the overlay region
-   between two triangular solves for its (parallel) elimination */
-static_assert(MCQ_KMAX * MCQ_KMAX <= OVL_SIZE, "the Schur matrix of the curvature rows must fit the LDS overlay");
-
-#else
 // ---------------------------------------------------------------------------------------------------------------------
 // shared-memory carve-up of the solver kernel (doubles), saddle-point core: reduction scratch, the separators' system (persistent between
 // a factorisation and its solves), the overlay (chunk buffers of the chains / scratch of the factorisation / the LDS copy of the
@@ -82,7 +27,6 @@ static_assert(MCQ_KMAX * MCQ_KMAX <= OVL_SIZE, "the Schur matrix of the curvatur
 #define SM_KI (SM_KV + 3 * MCQ_KMAX)
 #define SM_TOTAL (SM_KI + (3 * MCQ_KMAX + 2 + 1) / 2 + 1)
 static_assert(sizeof(double) * SM_TOTAL <= 80 * 1024, "two workgroups of the solver kernel per CU");
-#endif
 
 size_t mcq_solve_lds_bytes() { return sizeof(double) * SM_TOTAL; }
 
@@ -192,10 +136,6 @@ __device__ McqWork mcq_work(const McqBatch& B, int pb, int& n, double& kb, doubl
     w.ref = (const gdouble*)(B.ref + (size_t)pb * nm * 4);
     w.nv = B.nv ? (const gdouble*)(B.nv + (size_t)pb * nm * 2) : nullptr;
     w.sc = B.sc ? (const gdouble*)(B.sc + (size_t)pb * nm) : nullptr;
-    w.Eb = (gdouble*)(B.Eb + (size_t)pb * nm * MCQ_ELD);
-    w.Et = (gdouble*)(B.Et + (size_t)pb * nm * MCQ_ELD);
-    w.Db = (gdouble*)(B.Db + (size_t)pb * nm * MCQ_ELD);
-    w.H = (gdouble*)(B.H + (size_t)pb * nm * MCQ_HLD);
     w.L = (gdouble*)(B.L + (size_t)pb * nm * MCQ_LLD);
     w.vec = (gdouble*)(B.vec + (size_t)pb * nm * MCQ_NVEC);
     w.state = (gschar*)(B.state + (size_t)pb * nm);
@@ -209,232 +149,31 @@ __device__ McqWork mcq_work(const McqBatch& B, int pb, int& n, double& kb, doubl
 
 #define VEC(w, nmax, id) ((w).vec + (size_t)(id) * (size_t)(nmax))
 
-// Workgroup barrier that orders LDS traffic only: global loads / stores issued before it stay in flight across it
-// (the "local" address-space fence lowers to s_waitcnt lgkmcnt(0); __syncthreads() would also drain vmcnt).
-__device__ __forceinline__ void lds_barrier()
-{
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local");
-    __builtin_amdgcn_s_barrier();
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup", "local");
-}
-
-// Scheduling pin: an empty asm that "rewrites" a scalar and two vector registers, i.e. ties the uses of the scalar that
-// follow to the point where the vector values are final (the SIMT emulator of tests/emu predefines it as a no-op).
-#ifndef MCQ_PIN_SVV
-#define MCQ_PIN_SVV(sreg, vreg0, vreg1) asm volatile("" : "+s"(sreg), "+v"(vreg0), "+v"(vreg1))
-#endif
-
-// broadcast of a double from a wave-uniform lane (two v_readlane_b32 instead of an LDS-crossbar shuffle)
-__device__ __forceinline__ double bcast_lane(double v, int src_lane)
-{
-    const int lo = __builtin_amdgcn_readlane(__double2loint(v), src_lane);
-    const int hi = __builtin_amdgcn_readlane(__double2hiint(v), src_lane);
-    return __hiloint2double(hi, lo);
-}
-
-// Lanes 0..15: sum of x over the four 16-lane rows (lane, lane+16, lane+32, lane+48); other lanes: unspecified.
-// v_permlane32_swap / v_permlane16_swap (gfx950) are VALU lane exchanges: no LDS-crossbar round trip like ds_bpermute.
 // Broadcast of lane N of every 16-lane row to the whole row: one v_mov_b64_dpp row_newbcast (full-rate VALU, no SGPR round trip).
 template <int N> __device__ __forceinline__ double bcast_row16(double v)
 {
     return __builtin_amdgcn_update_dpp(0.0, v, 0x150 + N, 0xf, 0xf, true);
 }
 
-__device__ __forceinline__ double row4_sum_low16(double x)
-{
-    const auto a0 = __builtin_amdgcn_permlane32_swap(__double2loint(x), __double2loint(x), false, false);
-    const auto a1 = __builtin_amdgcn_permlane32_swap(__double2hiint(x), __double2hiint(x), false, false);
-    const double y = x + __hiloint2double((int)a1[1], (int)a0[1]);            // lanes 0..31: + lane 32 above
-    const auto b0 = __builtin_amdgcn_permlane16_swap(__double2loint(y), __double2loint(y), false, false);
-    const auto b1 = __builtin_amdgcn_permlane16_swap(__double2hiint(y), __double2hiint(y), false, false);
-    return y + __hiloint2double((int)b1[1], (int)b0[1]);                      // lanes 0..15: + lane 16 above
-}
-
-// D(16x16) += A(16x16) B(16x16) as four K=4 matrix-core steps; a[kc], b[kc] are the per-lane operand values
-__device__ __forceinline__ v4d mfma16(const double a[4], const double b[4], v4d acc)
-{
-#pragma unroll
-    for (int kc = 0; kc < 4; ++kc) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a[kc], b[kc], acc, 0, 0, 0);
-    return acc;
-}
-
-// dst_i = sum_{o=-bl..br} Mb[(bl+o) * nm + i] * src[(i+o) mod n] + addc * add_i
-// Diagonal-major (DIA) band: thread per row, every load of a wave is one contiguous 512-byte segment, no reductions.
-// Loads are issued in batches of MV_RU diagonals (three batches cover the 65/66-wide bands): with one wave per SIMD the
-// only way to keep enough bytes in flight is per-thread batching (22 x 8 B x 256 threads = 45 KB per round trip).
-#define MV_RU 22
-typedef double d2v __attribute__((vector_size(16)));
-typedef double d2v_u __attribute__((vector_size(16), aligned(8)));       /* 16-byte loads at 8-byte alignment (row pairs of a band) */
-typedef __attribute__((address_space(1))) d2v_u gd2v_u;
-__device__ __noinline__ void band_matvec(const gdouble* Mb, int bl, int br, int n, int nm, const gdouble* src,
-                                         const gdouble* add, double addc, gdouble* dst)
-{
-    const int ew = bl + br + 1;
-    // Two consecutive rows per thread: their matrix entries are adjacent in the diagonal-major band (one 16-byte load), so a batch
-    // of MV_RU diagonals keeps twice the bytes in flight per HBM round trip -- the product is latency-bound with one wave per
-    // SIMD (12 round trips per 512 rows instead of 24).  The two source entries are loaded separately (the ring may wrap between
-    // them: no branch inside the batch).
-    const int npair = n >> 1;
-    for (int ip = threadIdx.x; ip < npair; ip += MCQ_NT) {
-        const int i = 2 * ip;
-        double acc0 = add ? addc * add[i] : 0.0, acc1 = add ? addc * add[i + 1] : 0.0;
-        int j = i - bl;
-        if (j < 0) j += n;
-        if (j < 0) j = cyc(j, n);
-        for (int oo = 0; oo < ew; oo += MV_RU) {
-            d2v m[MV_RU];
-            double x0[MV_RU], x1[MV_RU];
-#pragma unroll
-            for (int u = 0; u < MV_RU; ++u) {
-                const bool ok = oo + u < ew;
-                m[u] = *(const gd2v_u*)(Mb + (size_t)(ok ? oo + u : 0) * nm + i);
-                const int j1 = (j + 1 == n) ? 0 : j + 1;
-                x0[u] = ok ? src[j] : 0.0;
-                x1[u] = ok ? src[j1] : 0.0;
-                j = j1;
-            }
-#pragma unroll
-            for (int u = 0; u < MV_RU; ++u) { acc0 += m[u][0] * x0[u]; acc1 += m[u][1] * x1[u]; }
-        }
-        dst[i] = acc0;
-        dst[i + 1] = acc1;
-    }
-    if ((n & 1) && threadIdx.x == 0) {       // odd ring: the last row on its own
-        const int i = n - 1;
-        double acc = add ? addc * add[i] : 0.0;
-        int j = cyc(i - bl, n);
-        for (int oo = 0; oo < ew; ++oo) {
-            acc += Mb[(size_t)oo * nm + i] * src[j];
-            j = (j + 1 == n) ? 0 : j + 1;
-        }
-        dst[i] = acc;
-    }
-}
-
-#if !defined(MCQ_CORE_BAND)
-// ---- pieces of the assembly that the solver kernel repeats when it has to produce the E band itself (McqBatch.skip_eb) ------------------
-#define TDIAG(m) (2.0 * S[cyc1((m) - 1, n)] * S[cyc1((m) - 1, n)] + 2.0 * S[cyc1((m) - 1, n)])
-#define TSUP(m) (S[cyc1((m) - 1, n)] * S[(m)] * S[(m)])
-// periodic pivots of the cyclic tridiagonal system in the c-coefficients: DE top-down, EP bottom-up (every thread a run of rows, started
-// MCQ_PIVOT_WARMUP rows away)
-__device__ void asm_periodic_pivots(const gdouble* S, gdouble* DE, gdouble* EP, int n)
-{
-    const int tid = threadIdx.x;
-    {
-        const int chunk = (n + MCQ_NT - 1) / MCQ_NT;
-        const int m0 = tid * chunk;
-        const int m1 = m0 + chunk < n ? m0 + chunk : n;
-        if (m0 < n) {
-            double dd = TDIAG(cyc(m0 - MCQ_PIVOT_WARMUP, n));
-            for (int k = m0 - MCQ_PIVOT_WARMUP + 1; k < m1; ++k) {
-                const int m = cyc(k, n);
-                dd = TDIAG(m) - TSUP(cyc(m - 1, n)) / dd;
-                if (k >= m0) DE[m] = dd;
-            }
-            double ee = TDIAG(cyc(m1 - 1 + MCQ_PIVOT_WARMUP, n));
-            for (int k = m1 - 2 + MCQ_PIVOT_WARMUP; k >= m0; --k) {
-                const int m = cyc(k, n);
-                ee = TDIAG(m) - TSUP(m) / ee;
-                if (k < m1) EP[m] = ee;
-            }
-        }
-    }
-}
-// the E band (and, write_db, the D band and E') of a long ring from the per-index ratios RU, RD of the rows of T^-1
-__device__ void asm_e_band_long(const McqWork& w, int nm, int n, const gdouble* S, const gdouble* DE, const gdouble* EP, const gdouble* RU,
-                                const gdouble* RD, bool write_db)
-{
-    const int tid = threadIdx.x;
-    const gdouble* XP = VEC(w, nm, V_XP);
-    const gdouble* YP = VEC(w, nm, V_YP);
-    const gdouble* CP = VEC(w, nm, V_CP);
-    const gdouble* NX = VEC(w, nm, V_NX);
-    const gdouble* NY = VEC(w, nm, V_NY);
-        // D[i, i+o] = 6 (g[o+1] - (1 + s_{j-1}) g[o] + s_{j-2} g[o-1]),  j = i + o:  a three-entry window walks up from the
-        // diagonal and down from it; stores are diagonal-major (consecutive threads = consecutive rows)
-        for (int i = tid; i < n; i += MCQ_NT) {
-            const double g0 = 1.0 / (DE[i] + EP[i] - TDIAG(i));
-            const double cpx = CP[i] * XP[i], cpy = CP[i] * YP[i];
-            const int im = i == 0 ? n - 1 : i - 1, imm = im == 0 ? n - 1 : im - 1;
-            const double gu1 = g0 * RU[i], gd1 = g0 * RD[i];
-            {
-                const double dv = 6.0 * (gu1 - (1.0 + S[im]) * g0 + S[imm] * gd1);
-                const double ev = dv * (cpx * NY[i] - cpy * NX[i]);
-                if (write_db) w.Db[(size_t)MCQ_BE_MAX * nm + i] = dv;
-                w.Eb[(size_t)MCQ_BE_MAX * nm + i] = ev;
-                if (write_db) w.Et[(size_t)MCQ_BE_MAX * nm + i] = ev;      // E'[o'][j] = E[j + o'][j]: entry (i, j = i + o) is diagonal o' = -o of column j
-            }
-            // upwards: prev = g[o-1], cur = g[o], j = i + o
-            {
-                double prev = g0, cur = gu1;
-                int j = i + 1 == n ? 0 : i + 1, jm1 = i, jm2 = im;
-#pragma unroll 2
-                for (int o = 1; o <= MCQ_BE_MAX; ++o) {
-                    const double nxt = cur * RU[j];
-                    const double dv = 6.0 * (nxt - (1.0 + S[jm1]) * cur + S[jm2] * prev);
-                    const double ev = dv * (cpx * NY[j] - cpy * NX[j]);
-                    if (write_db) w.Db[(size_t)(MCQ_BE_MAX + o) * nm + i] = dv;
-                    w.Eb[(size_t)(MCQ_BE_MAX + o) * nm + i] = ev;
-                    if (write_db) w.Et[(size_t)(MCQ_BE_MAX - o) * nm + j] = ev;        // consecutive threads: consecutive j (a wrap splits the run once)
-                    prev = cur;
-                    cur = nxt;
-                    jm2 = jm1;
-                    jm1 = j;
-                    j = j + 1 == n ? 0 : j + 1;
-                }
-            }
-            // downwards: nxt = g[o+1], cur = g[o], j = i + o  (o < 0)
-            {
-                double nxt = g0, cur = gd1;
-                int j = im, jm1 = imm, jm2 = imm == 0 ? n - 1 : imm - 1;
-#pragma unroll 2
-                for (int o = -1; o >= -MCQ_BE_MAX; --o) {
-                    const double prv = cur * RD[j];            // g[o-1]
-                    const double dv = 6.0 * (nxt - (1.0 + S[jm1]) * cur + S[jm2] * prv);
-                    const double ev = dv * (cpx * NY[j] - cpy * NX[j]);
-                    if (write_db) w.Db[(size_t)(MCQ_BE_MAX + o) * nm + i] = dv;
-                    w.Eb[(size_t)(MCQ_BE_MAX + o) * nm + i] = ev;
-                    if (write_db) w.Et[(size_t)(MCQ_BE_MAX - o) * nm + j] = ev;
-                    nxt = cur;
-                    cur = prv;
-                    j = jm1;
-                    jm1 = jm2;
-                    jm2 = jm2 == 0 ? n - 1 : jm2 - 1;
-                }
-            }
-        }
-}
-// McqBatch.skip_eb: the assembly kernel left the E band of the long rings unwritten (the saddle-point core reads it only in the rare
-// curvature-row phase); a problem that enters that phase produces its own band first -- pivots, ratios and the band loop again, the four
-// scratch vectors in the unused tail of the L slab (rows 80 .. 83 of MCQ_LLD = 144).  Uniform over the workgroup.
-__device__ __noinline__ void asm_e_band_lazy(const McqWork& w, int nm, int n, int bE)
-{
-    const int W = bE + 2;
-    const bool long_ring = (bE == MCQ_BE_MAX) && (n - W > 96) && (W < (n - 1) / 2);
-    if (!long_ring) return;                       // short rings: written by the assembly kernel whatever the flag says
-    const gdouble* S = VEC(w, nm, V_SC);
-    gdouble* DE = w.L + (size_t)80 * nm;
-    gdouble* EP = w.L + (size_t)81 * nm;
-    gdouble* RU = w.L + (size_t)82 * nm;
-    gdouble* RD = w.L + (size_t)83 * nm;
-    __syncthreads();
-    asm_periodic_pivots(S, DE, EP, n);
-    __syncthreads();
-    for (int m = threadIdx.x; m < n; m += MCQ_NT) {
-        const int mp = cyc1(m + 1, n), mm = cyc1(m - 1, n);
-        RU[m] = -(TSUP(m) / EP[mp]);
-        RD[m] = -1.0 / DE[mm];
-    }
-    __syncthreads();
-    asm_e_band_long(w, nm, n, S, DE, EP, RU, RD, false);
-    __syncthreads();
-}
-static_assert(MCQ_LLD >= 84, "asm_e_band_lazy's scratch rows");
-#undef TDIAG
-#undef TSUP
+#ifndef MCQ_IPM_TOL
+#define MCQ_IPM_TOL 1e-10
 #endif
+struct SolveCtx {
+    McqDims d;
+    McqWork w;
+    int nm;
+    mutable long long tk[8];   // phase timers (wall_clock64 ticks), meaningful on thread 0
+    mutable int refine_rounds, second_attempt;   // diagnostics for mcq_info
+    mutable double last_step;  // length of the last interior-point step (the Tapia indicators are only trusted after a near-full one)
+    int direct;                // 1: shortest-path objective -- H is a cyclic tridiagonal given entry by entry (V_SPD, V_SPU), V_F holds f
+    mutable const gdouble* sp_sig;  // ... its current "factorisation": the diagonal shift and the working set (mcq_tri.inc, factor_sp)
+    mutable const gschar* sp_mk;
+    mutable const gdouble* kkt_w;   // saddle-point elimination: weights of the curvature rows (1 + y/t of the interior point) or nullptr
+};
+#define TICK() ((long long)wall_clock64())
+#include "mcq_kkt.inc"
+#include "mcq_tri.inc"
 
-#if !defined(MCQ_CORE_BAND)
 // =====================================================================================================================
 // K1: assembly
 // =====================================================================================================================
@@ -446,19 +185,15 @@ __global__ void __launch_bounds__(MCQ_NT) mcq_assemble_kernel(McqBatch B)
     double kb, wveh;
     const McqWork w = mcq_work(B, blockIdx.x, n, kb, wveh);
     const int nm = B.nmax;
-    const McqDims d = mcq_dims(n < 3 ? 3 : n, B.band_e);
     gdouble* LO = VEC(w, nm, V_LO);
     gdouble* HI = VEC(w, nm, V_HI);
-    gdouble* S = VEC(w, nm, V_T0);    // spline scalings
-    gdouble* DE = VEC(w, nm, V_T1);   // periodic pivots, top-down
-    gdouble* EP = VEC(w, nm, V_T2);   // periodic pivots, bottom-up
+    gdouble* S = VEC(w, nm, V_SC);    // spline scalings
     gdouble* XP = VEC(w, nm, V_XP);
     gdouble* YP = VEC(w, nm, V_YP);
     gdouble* CP = VEC(w, nm, V_CP);
     gdouble* KRF = VEC(w, nm, V_KREF);
     gdouble* XPP = VEC(w, nm, V_XPP);
     gdouble* YPP = VEC(w, nm, V_YPP);
-    gdouble* G = w.L;                 // T^-1 rows, diagonal-major [MCQ_GLD][nm] (scratch inside the L slab)
 
     // ---- phase 0: validate, box bounds  [-(w_l - w_veh/2), w_r - w_veh/2]   -----------------
     double flag_bad = 0.0, flag_inf = 0.0;
@@ -488,7 +223,6 @@ __global__ void __launch_bounds__(MCQ_NT) mcq_assemble_kernel(McqBatch B)
         LO[i] = lo;
         HI[i] = hi;
         S[i] = s;
-        VEC(w, nm, V_SC)[i] = s;          // S is a scratch slot; the solver's curvature-error post-check needs s again
     }
     flag_bad = block_reduce_(flag_bad, 2, red);
     flag_inf = block_reduce_(flag_inf, 2, red);
@@ -512,90 +246,27 @@ __global__ void __launch_bounds__(MCQ_NT) mcq_assemble_kernel(McqBatch B)
     }
     __syncthreads();
 
-    // ---- phase 1: periodic pivots of the cyclic tridiagonal system in the c-coefficients -----------------------------
-    // centre m:  1*c_{m-1} + (2 s_{m-1}^2 + 2 s_{m-1}) c_m + (s_{m-1} s_m^2) c_{m+1} = 3 (s_{m-1} D_m - D_{m-1})
-#define TDIAG(m) (2.0 * S[cyc1((m) - 1, n)] * S[cyc1((m) - 1, n)] + 2.0 * S[cyc1((m) - 1, n)])
-#define TSUP(m) (S[cyc1((m) - 1, n)] * S[(m)] * S[(m)])
-    asm_periodic_pivots(S, DE, EP, n);
-    __syncthreads();
-
-    // ---- phase 2: rows of T^-1 (periodic Green's function, images folded onto the ring) and the c-coefficients -------
-    const int W = d.bE + 2;
-    // images of offset k land inside [-W, W] only if k >= n - W: run the recurrences further for short rings
-    const int KR = (n - W > 96) ? W : 96;
-    // Long rings (no image folding, full band): nothing of T^-1 goes through memory.  A row of T^-1 is two geometric-like
-    // recurrences away from its diagonal entry,  g[k+1] = RU[i+k] g[k]  (upwards),  g[-k-1] = RD[i-k] g[-k]  (downwards), with
-    // per-index ratios computed once; phase 2 consumes the entries as they are produced (c-coefficients = T^-1 rhs), phase 3b
-    // produces them again with a three-entry window.  A handful of registers per row: several workgroups per CU hide the
-    // L2 latency of the ratio / right-hand-side loads.
-    const bool long_ring = (d.bE == MCQ_BE_MAX) && (n - W > 96) && (W < (n - 1) / 2);
-    gdouble* RU = VEC(w, nm, V_RHS);
-    gdouble* RD = VEC(w, nm, V_DXA);
+    // ---- phases 1-2: second derivatives of the closed spline through the reference line.  The c-coefficients solve the cyclic tridiagonal
+    //      system   1 c_(m-1) + (2 s_(m-1)^2 + 2 s_(m-1)) c_m + (s_(m-1) s_m^2) c_(m+1) = 3 (s_(m-1) D_m - D_(m-1)),   D_m = p_(m+1) - p_m
+    //      (SURVEY.md App. A.1); x'' = 2 c.  Solved by the periodic-pivot sweeps of mcq_tri.inc, whose factors (V_IDL, V_TUC) the solver
+    //      kernel goes on using.  (Rounds 1-3 built rows of T^-1 here -- with image folding for short rings -- and, from them, the bands
+    //      of E, E' and D; nothing reads a band any more.)
+    SolveCtx c;
+    c.w = w;
+    c.nm = nm;
+    c.d = mcq_dims(n);
+    tri_prepare(c);
     gdouble* RX = VEC(w, nm, V_SK);
     gdouble* RY = VEC(w, nm, V_EDA);
-    if (long_ring) {
-        for (int m = tid; m < n; m += MCQ_NT) {
-            const int mp = cyc1(m + 1, n), mm = cyc1(m - 1, n);
-            const double sm1 = S[mm];
-            RX[m] = 3.0 * (sm1 * (w.ref[4 * mp] - w.ref[4 * m]) - (w.ref[4 * m] - w.ref[4 * mm]));
-            RY[m] = 3.0 * (sm1 * (w.ref[4 * mp + 1] - w.ref[4 * m + 1]) - (w.ref[4 * m + 1] - w.ref[4 * mm + 1]));
-            RU[m] = -(TSUP(m) / EP[mp]);          // g[k+1] = RU[j] g[k],  j = i + k
-            RD[m] = -1.0 / DE[mm];                // g[-k-1] = RD[j] g[-k],  j = i - k
-        }
-        __syncthreads();
-        for (int i = tid; i < n; i += MCQ_NT) {
-            const double g0 = 1.0 / (DE[i] + EP[i] - TDIAG(i));
-            double cx = g0 * RX[i], cy = g0 * RY[i];
-            double cu = g0, cd = g0;
-            int ju = i, jd = i;                    // index of the entry last produced on either side
-#pragma unroll 2
-            for (int k = 1; k <= MCQ_GW; ++k) {
-                cu *= RU[ju];
-                cd *= RD[jd];
-                ju = ju + 1 == n ? 0 : ju + 1;
-                jd = jd == 0 ? n - 1 : jd - 1;
-                cx += cu * RX[ju] + cd * RX[jd];
-                cy += cu * RY[ju] + cd * RY[jd];
-            }
-            XPP[i] = 2.0 * cx;   // x''(0) of spline i
-            YPP[i] = 2.0 * cy;
-        }
-    } else
-    for (int i = tid; i < n; i += MCQ_NT) {
-#define GG(k) G[(size_t)(MCQ_GW + (k)) * nm + i]
-        for (int k = -MCQ_GW; k <= MCQ_GW; ++k) GG(k) = 0.0;
-        const double g0 = 1.0 / (DE[i] + EP[i] - TDIAG(i));
-        for (int o = -W; o <= W; ++o) if (cyc(o, n) == 0) GG(o) += g0;
-        double cur = g0;
-        for (int k = 1; k <= KR; ++k) {
-            const int j = cyc(i + k - 1, n);
-            cur = -(TSUP(j) / EP[cyc(j + 1, n)]) * cur;
-            if (k <= W) GG(k) += cur;
-            if (k >= n - W)   // fold images: every offset o in [-W, W] with o == k (mod n), o != k
-                for (int o = k - n; o >= -W; o -= n) if (o <= W) GG(o) += cur;
-        }
-        cur = g0;
-        for (int k = 1; k <= KR; ++k) {
-            const int j = cyc(i - k + 1, n);
-            cur = -cur / DE[cyc(j - 1, n)];
-            if (k <= W) GG(-k) += cur;
-            if (k >= n - W)
-                for (int o = -k + n; o <= W; o += n) if (o >= -W) GG(o) += cur;
-        }
-        double cx = 0.0, cy = 0.0;
-        const int klo = -((W < (n - 1) / 2) ? W : (n - 1) / 2), khi = (W < n / 2) ? W : n / 2;   // each column once
-        for (int k = klo; k <= khi; ++k) {
-            const int m = cyc(i + k, n), mp = cyc(m + 1, n), mm = cyc(m - 1, n);
-            const double sm1 = S[mm];
-            const double rx = 3.0 * (sm1 * (w.ref[4 * mp] - w.ref[4 * m]) - (w.ref[4 * m] - w.ref[4 * mm]));
-            const double ry = 3.0 * (sm1 * (w.ref[4 * mp + 1] - w.ref[4 * m + 1]) - (w.ref[4 * m + 1] - w.ref[4 * mm + 1]));
-            cx += GG(k) * rx;
-            cy += GG(k) * ry;
-        }
-        XPP[i] = 2.0 * cx;   // x''(0) of spline i
-        YPP[i] = 2.0 * cy;
-#undef GG
+    for (int m = tid; m < n; m += MCQ_NT) {
+        const int mp = cyc1(m + 1, n), mm = cyc1(m - 1, n);
+        const double sm1 = S[mm];
+        RX[m] = 3.0 * (sm1 * (w.ref[4 * mp] - w.ref[4 * m]) - (w.ref[4 * m] - w.ref[4 * mm]));
+        RY[m] = 3.0 * (sm1 * (w.ref[4 * mp + 1] - w.ref[4 * m + 1]) - (w.ref[4 * m + 1] - w.ref[4 * mm + 1]));
     }
+    tri_solve_T(c, RX, XPP);
+    tri_solve_T(c, RY, YPP);
+    for (int i = tid; i < n; i += MCQ_NT) { XPP[i] *= 2.0; YPP[i] *= 2.0; }     // x''(0), y''(0) of spline i
     __syncthreads();
 
     // ---- phase 3a: x', y', curvature pre-factor, reference curvature ------------------------------------------------
@@ -624,384 +295,17 @@ __global__ void __launch_bounds__(MCQ_NT) mcq_assemble_kernel(McqBatch B)
         if (B.sc_out) ((gdouble*)(B.sc_out + (size_t)blockIdx.x * nm))[i] = S[i];
     }
     __syncthreads();
-    if (B.prep_only) return;
-
-    // ---- phase 3b: D band (x'' = D x) and E_kappa band, diagonal-major -------------------------------------------------
-    const int ew = d.ew;
-    if (long_ring) {
-        // (skip_eb: not even E -- the solver kernel produces the band itself if a problem's curvature-row phase starts: asm_e_band_lazy)
-        if (!B.skip_eb) asm_e_band_long(w, nm, n, S, DE, EP, RU, RD, !B.skip_db);
-    } else
-    for (int idx = tid; idx < n * ew; idx += MCQ_NT) {
-        const int oo = idx / n, i = idx - oo * n, o = oo - d.bE;
-        const int j = cyc(i + o, n);
-        const double g1 = G[(size_t)(MCQ_GW + o + 1) * nm + i], g0 = G[(size_t)(MCQ_GW + o) * nm + i],
-                     gm = G[(size_t)(MCQ_GW + o - 1) * nm + i];
-        const double dv = 6.0 * (g1 - (1.0 + S[cyc(j - 1, n)]) * g0 + S[cyc(j - 2, n)] * gm);
-        w.Db[(size_t)oo * nm + i] = dv;
-        w.Eb[(size_t)oo * nm + i] = dv * CP[i] * (XP[i] * NY[j] - YP[i] * NX[j]);
-    }
-    if (long_ring || B.skip_db) return;         // (E' written alongside E above: no second pass over the band; skip_db: nobody reads E')
-    __syncthreads();
-    // ---- phase 3c: transpose band  Et[(bR+o) * nm + j] = E[(j+o) mod n][j],  -bR <= o <= bE --------------------------
-    for (int idx = tid; idx < n * ew; idx += MCQ_NT) {
-        const int oo = idx / n, j = idx - oo * n, o = oo - d.bR;
-        w.Et[(size_t)oo * nm + j] = w.Eb[(size_t)(d.bE - o) * nm + cyc(j + o, n)];
-    }
-#undef TDIAG
-#undef TSUP
 }
 
-#endif   // !defined(MCQ_CORE_BAND)
-// =====================================================================================================================
-// K2: H = E'E (bordered band) and f
-// =====================================================================================================================
-// (E' diag(sg) E)[i,j] = sum_o Et[o][i] * sg[i+o] * Et[t][j],  r = i+o,  t = r - j (mod n) inside [-bR, bE];  sg == nullptr -> 1
-__device__ __forceinline__ double gram_entry(const gdouble* Et, const gdouble* sg, const McqDims& d, int nm, int i, int j)
-{
-    const int n = d.n, bE = d.bE, bR = d.bR;
-    const int dd = sdiff(i, j, n);
-    int r0 = i - bR;
-    if (r0 < 0) r0 += n;
-    if (r0 < 0) r0 = cyc(r0, n);
-    // fixed trip count, branch-free body, loads of a batch issued together: the chain of 2 x 65 dependent L2 round trips
-    // of a data-dependent loop is what this routine costs otherwise
-    constexpr int EW = MCQ_BE_MAX + (MCQ_BE_MAX + 1) + 1;       // bE + bR + 1 <= 66
-    constexpr int GB = 11;
-    const int ew = bR + bE + 1;
-    double acc = 0.0;
-    // Diagonals oo of the first factor that meet the band of the second one: oo in [-dd, ew - 1 - dd] (no wrapped image can
-    // fall inside the band once the ring is longer than two band widths plus the distance) -- batches outside are skipped
-    int ob0 = 0, ob1 = EW;
-    if (n > 3 * EW) {
-        const int lo = dd < 0 ? -dd : 0, hi = dd > 0 ? ew - 1 - dd : ew - 1;
-        ob0 = (lo / GB) * GB;
-        ob1 = hi + 1;
-    }
-#pragma unroll 1
-    for (int o0 = ob0; o0 < ob1; o0 += GB) {
-        double ea[GB], eb[GB], es[GB];
-        bool ok[GB];
-#pragma unroll
-        for (int u = 0; u < GB; ++u) {
-            const int oo = o0 + u;                 // 0-based diagonal of the first factor: o = oo - bR
-            int t = oo - bR + dd;                  // the band holds every column at most once: at most one of t, t -+ n is inside it
-            if (t > bE) t -= n;
-            else if (t < -bR) t += n;
-            ok[u] = (oo < ew) & (t >= -bR) & (t <= bE);
-            const int oa = ok[u] ? oo : 0, ob = ok[u] ? bR + t : 0;
-            int r = r0 + oo;
-            r = r >= n ? r - n : r;
-            r = r >= n ? r - n : r;
-            ea[u] = Et[(size_t)oa * nm + i];
-            eb[u] = Et[(size_t)ob * nm + j];
-            es[u] = sg ? sg[ok[u] ? r : 0] : 1.0;
-        }
-#pragma unroll
-        for (int u = 0; u < GB; ++u) acc += ok[u] ? ea[u] * eb[u] * es[u] : 0.0;
-    }
-    return acc;
-}
-
-// Writes  E' diag(sg) E  in bordered-band storage (row-major rows of MCQ_HLD doubles, see mcq_kernels.h) into `out`.
-// Work items are ordered so that consecutive threads take consecutive entries of ONE row of `out`: the stores (most of
-// them zeros of the border part) are contiguous segments instead of 8-byte pieces 1040 bytes apart, and the second
-// factor's loads of the few entries that need arithmetic are contiguous too.  Rows [skip0, skip1) of the band part are
-// left to mcq_gram_tile_kernel.
-__device__ void gram_bordered(const gdouble* Et, const gdouble* sg, const McqDims& d, int nm, const gdouble* base, gdouble* out,
-                              int t0, int nthreads, int skip0 = 0, int skip1 = 0)
-{
-    const int ni = d.ni, n = d.n;
-    const int bw = MCQ_BH_MAX + 1;
-    const int nskip = skip1 - skip0;
-    for (int idx = t0; idx < bw * (ni - nskip); idx += nthreads) {
-        const int rix = idx / bw, k = idx - rix * bw;
-        const int i = rix < skip0 ? rix : rix + nskip;
-        double v = 0.0;
-        if (k <= d.b && i + k < ni) v = gram_entry(Et, sg, d, nm, i, i + k);
-        out[MCQ_HBAND(i, k)] = v + (base ? base[MCQ_HBAND(i, k)] : 0.0);
-    }
-    for (int idx = t0; idx < MCQ_P_MAX * n; idx += nthreads) {
-        const int i = idx / MCQ_P_MAX, jj = idx - i * MCQ_P_MAX;
-        double v = 0.0;
-        if (jj < d.p) {
-            const int j = ni + jj;
-            if (abs(sdiff(i, j, n)) <= d.bH) v = gram_entry(Et, sg, d, nm, i, j);
-        }
-        out[(size_t)i * MCQ_HLD + MCQ_HBO + jj] = v + (base ? base[(size_t)i * MCQ_HLD + MCQ_HBO + jj] : 0.0);
-    }
-}
-
-// Rows [f0, f1) of the band part of H whose 65 entries involve no wrap-around and no truncation: the LDS-tiled fast path.
-#define GT_ROWS 64
-__device__ __forceinline__ void gram_fast_range(const McqDims& d, int& f0, int& f1)
-{
-    f0 = f1 = 0;
-    if (d.bE == MCQ_BE_MAX && d.bR == MCQ_BE_MAX && d.b == MCQ_BH_MAX) {
-        f0 = MCQ_BE_MAX;
-        const int last = d.ni - MCQ_BH_MAX;                 // exclusive: rows i with i + 64 < ni
-        if (last > f0) f1 = f0 + ((last - f0) / GT_ROWS) * GT_ROWS;
-        if (f1 < f0) f1 = f0;
-    }
-}
-
-// Long rings with the full band: mcq_gram_tile_kernel produces EVERY entry of H (and f) from the cyclic-band form
-//   h(i, k) = H[i, (i+k) mod n] = sum_{o >= k} E'[o][i] E'[o-k][(i+k) mod n],   k = 0 .. 64,
-// and scatters it into the bordered storage (band slot, border slot, border block and its mirror image, wrap-around entries of
-// the first rows); the generic entry-by-entry routine (130 loads per entry) is left for short rings and narrow bands.
-__device__ __forceinline__ bool gram_all_rows(const McqDims& d)
-{
-    return d.bE == MCQ_BE_MAX && d.bR == MCQ_BE_MAX && d.b == MCQ_BH_MAX && d.p == MCQ_P_MAX && d.n >= 4 * GT_ROWS;
-}
-
-// Entries k == G (mod 4) of one row of the band of H for mcq_gram_tile_kernel: k is a literal, so every LDS offset is an
-// immediate and only the 65 - k products that exist are formed.  a[o] = E'[o][row]; sc = tile base + row.
-#ifndef MCQ_GRAM_MFMA
-#define MCQ_GRAM_MFMA 1     /* 1: the tile kernel forms H = E'E on the fp64 matrix cores; 0: rounds 1-2's register-column / LDS form */
-#endif
-template <int G>
-__device__ __forceinline__ void gram_tile_class(const double* a, const double* sc, double* res)
-{
-    constexpr int NO = 2 * MCQ_BE_MAX + 1, NC = 2 * GT_ROWS;
-#pragma unroll
-    for (int m = 0; m < (MCQ_BH_MAX + 4) / 4; ++m) {
-        const int k = G + 4 * m;
-        double acc0 = 0.0, acc1 = 0.0;
-        if (k <= MCQ_BH_MAX) {
-#pragma unroll
-            for (int o = k; o < NO; o += 2) {
-                acc0 += a[o] * sc[(o - k) * NC + k];
-                if (o + 1 < NO) acc1 += a[o + 1] * sc[(o + 1 - k) * NC + k];
-            }
-        }
-        res[m] = acc0 + acc1;
-    }
-}
-#if !defined(MCQ_CORE_BAND)
-
-// H[i, i+k] = sum_{o >= k} E'[o][i] E'[o-k][i+k]  (o, o-k = 0-based diagonal indices of the 65-wide E' band).
-// One workgroup per tile of 64 rows: the 65 x 128 block of E' it touches (columns i0 .. i0+127) is staged once in LDS
-// (66.5 KB, two workgroups per CU); thread (row r, wave g) keeps its column of E in 65 registers and produces the entries
-// k == g (mod 4): one LDS read per FMA, conflict-free (consecutive lanes = consecutive columns), immediate offsets.
-__global__ void __launch_bounds__(MCQ_NT) mcq_gram_tile_kernel(McqBatch B)
-{
-    __shared__ double S[(2 * MCQ_BE_MAX + 1) * 2 * GT_ROWS];
-    __shared__ double KS[GT_ROWS + 2 * MCQ_BE_MAX + 32];
-    int n;
-    double kb, wveh;
-    const McqWork w = mcq_work(B, blockIdx.x, n, kb, wveh);
-    if (*w.status != MCQ_OK) return;
-    const int nm = B.nmax;
-    const McqDims d = mcq_dims(n, B.band_e);
-    const bool all = gram_all_rows(d);
-    int f0, f1;
-    gram_fast_range(d, f0, f1);
-    if (all) { f0 = 0; f1 = n; }
-    const int i0 = f0 + blockIdx.y * GT_ROWS;
-    if (i0 >= f1) return;
-    const int tid = threadIdx.x;
-    const int NO = 2 * MCQ_BE_MAX + 1, NC = 2 * GT_ROWS;
-    // 65 x 128 doubles = 32.5 loads per thread: issued in batches of 11 independent loads (one HBM round trip per batch)
-    {
-        const int cc = tid & (NC - 1), o0 = tid / NC;              // 256 threads = 2 diagonals x 128 columns per pass
-        int col = i0 + cc;                                         // fast range: i0 + cc < n; all rows: columns around the ring
-        col = col >= n ? col - n : col;
-        const gdouble* src = w.Et + (size_t)col;
-#pragma unroll
-        for (int pass = 0; pass < 3; ++pass) {
-            double t[11];
-#pragma unroll
-            for (int u = 0; u < 11; ++u) {
-                const int o = o0 + 2 * (pass * 11 + u);
-                t[u] = src[(size_t)(o < NO ? o : 0) * nm];
-            }
-#pragma unroll
-            for (int u = 0; u < 11; ++u) {
-                const int o = o0 + 2 * (pass * 11 + u);
-                if (o < NO) S[o * NC + cc] = t[u];
-            }
-        }
-        if (all && tid < GT_ROWS + 2 * MCQ_BE_MAX) {               // k_ref around the tile: entry c = ring index i0 - bR + c
-            int q = i0 - MCQ_BE_MAX + tid;
-            q = q < 0 ? q + n : (q >= n ? q - n : q);
-            KS[tid] = VEC(w, nm, V_KREF)[q];
-        }
-    }
-    __syncthreads();
-#if MCQ_GRAM_MFMA
-    // ---- H = E'E on the fp64 matrix cores (round 3; what BASELINE's north_star asks the matrix cores for) ---------------------------
-    // The 64 rows of the tile are four 16-column blocks of E, one per wave (a); with E(Q, blk) the 16 x 16 block of E in row block Q
-    // and column block blk,  H(a, a+d) = sum_Q E(Q, a)' E(Q, a+d),  d = 0..4, over the row blocks that meet both bands (5 - d of
-    // them).  The operands come straight from the diagonal-major staging: lane (l15, l4) of P(blk, t) holds
-    //     E[16 blk - 32 + 16 t + l4 + 4 kc,  16 blk + l15]  =  S[o][16 blk + l15],   o = 16 t + l4 + 4 kc - l15   (0 outside 0..64)
-    // -- the same lane layout serves as the A operand (i = l15, k = l4 + 4 kc) of block a and as the B operand (k, n = l15) of block
-    // a+d; consecutive lanes read consecutive banks (stride 127 doubles).  15 tile products = 60 v_mfma_f64_16x16x4_f64 per wave
-    // where 560 FMAs + 560 LDS reads per THREAD were.
-    const int lane = tid & 63, l15 = lane & 15, l4 = lane >> 4;
-    const int a = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int r = tid & (GT_ROWS - 1);
-    if (all && tid < GT_ROWS && i0 + tid < n) {      // f = F_SCALE E' k_ref from the staged columns (wave 0, 65 terms per row)
-        double acc0 = 0.0, acc1 = 0.0;
-#pragma unroll 5
-        for (int o = 0; o + 1 < NO; o += 2) { acc0 += S[o * NC + tid] * KS[tid + o]; acc1 += S[(o + 1) * NC + tid] * KS[tid + o + 1]; }
-        acc0 += S[(NO - 1) * NC + tid] * KS[tid + NO - 1];
-        VEC(w, nm, V_F)[i0 + tid] = MCQ_F_SCALE * (acc0 + acc1);
-    }
-    v4d hacc[5];
-    {
-        double pa[5][4];
-#pragma unroll
-        for (int t = 0; t < 5; ++t) {
-#pragma unroll
-            for (int kc = 0; kc < 4; ++kc) {
-                const int o = 16 * t + l4 + 4 * kc - l15;
-                const double v = S[(o >= 0 && o < NO ? o : 0) * NC + 16 * a + l15];
-                pa[t][kc] = (o >= 0 && o < NO) ? v : 0.0;
-            }
-        }
-#pragma unroll
-        for (int dd = 0; dd < 5; ++dd) {
-            v4d acc = {0.0, 0.0, 0.0, 0.0};
-#pragma unroll
-            for (int t = dd; t < 5; ++t) {
-                double pb[4];
-#pragma unroll
-                for (int kc = 0; kc < 4; ++kc) {
-                    const int o = 16 * (t - dd) + l4 + 4 * kc - l15;
-                    const double v = S[(o >= 0 && o < NO ? o : 0) * NC + 16 * (a + dd) + l15];
-                    pb[kc] = (o >= 0 && o < NO) ? v : 0.0;
-                }
-                acc = mfma16(pa[t], pb, acc);
-            }
-            hacc[dd] = acc;
-        }
-    }
-    // results through LDS (the E' block is dead): rows leave as contiguous 520-byte runs instead of 8-byte pieces
-    __syncthreads();
-    const int OW = MCQ_BH_MAX + 1;
-#pragma unroll
-    for (int dd = 0; dd < 5; ++dd) {
-#pragma unroll
-        for (int rr = 0; rr < 4; ++rr) {
-            const int ii = l4 + 4 * rr, k = 16 * dd + l15 - ii;       // H[i0 + 16 a + ii, . + k]
-            if (k >= 0 && k <= MCQ_BH_MAX) S[(16 * a + ii) * OW + k] = hacc[dd][rr];
-        }
-    }
-    (void)r;
-    __syncthreads();
-#else
-    const int r = tid & (GT_ROWS - 1);
-    const int g = __builtin_amdgcn_readfirstlane(tid / GT_ROWS);       // wave-uniform: a scalar branch picks the k class
-    double a[2 * MCQ_BE_MAX + 1];
-#pragma unroll
-    for (int o = 0; o < NO; ++o) a[o] = S[o * NC + r];
-    if (all && g == 3 && i0 + r < n) {       // f = F_SCALE E' k_ref: this thread's column of E is in registers (the class with the fewest entries)
-        double acc0 = 0.0, acc1 = 0.0;
-#pragma unroll
-        for (int o = 0; o + 1 < NO; o += 2) { acc0 += a[o] * KS[r + o]; acc1 += a[o + 1] * KS[r + o + 1]; }
-        acc0 += a[NO - 1] * KS[r + NO - 1];
-        VEC(w, nm, V_F)[i0 + r] = MCQ_F_SCALE * (acc0 + acc1);
-    }
-    double res[(MCQ_BH_MAX + 4) / 4];
-    if (g == 0) gram_tile_class<0>(a, S + r, res);
-    else if (g == 1) gram_tile_class<1>(a, S + r, res);
-    else if (g == 2) gram_tile_class<2>(a, S + r, res);
-    else gram_tile_class<3>(a, S + r, res);
-    // results through LDS (the E' block is dead): rows leave as contiguous 520-byte runs instead of 8-byte pieces
-    __syncthreads();
-    const int OW = MCQ_BH_MAX + 1;
-#pragma unroll
-    for (int m = 0; m < (MCQ_BH_MAX + 4) / 4; ++m) {
-        const int k = g + 4 * m;
-        if (k <= MCQ_BH_MAX) S[r * OW + k] = res[m];
-    }
-    __syncthreads();
-#endif
-    if (!all) {
-        for (int q = tid; q < GT_ROWS * OW; q += MCQ_NT) {
-            const int row = q / OW, k = q - row * OW;
-            w.H[MCQ_HBAND(i0 + row, k)] = S[q];
-        }
-        return;
-    }
-    // ---- all rows: every (row, slot) of the bordered storage has exactly one writer ---------------------------------------
-    const int ni = d.ni;
-    for (int q = tid; q < GT_ROWS * OW; q += MCQ_NT) {
-        const int row = q / OW, k = q - row * OW;
-        const int i = i0 + row;
-        if (i >= n) continue;
-        const double h = S[q];
-        const int j = i + k;
-        if (i < ni) {                               // interior row: i + k < n always
-            if (j < ni) w.H[MCQ_HBAND(i, k)] = h;
-            else {
-                w.H[MCQ_HBAND(i, k)] = 0.0;                                // the band ends at the border
-                w.H[(size_t)i * MCQ_HLD + MCQ_HBO + (j - ni)] = h;
-            }
-        } else {                                    // border row ii = i - ni
-            const int ii = i - ni;
-            if (j < n) {
-                w.H[(size_t)i * MCQ_HLD + MCQ_HBO + (j - ni)] = h;         // border block, upper part ...
-                if (k > 0) w.H[(size_t)j * MCQ_HLD + MCQ_HBO + ii] = h;    // ... and its mirror image
-            } else {
-                w.H[(size_t)(j - n) * MCQ_HLD + MCQ_HBO + ii] = h;         // around the ring: border slot of one of the first rows
-            }
-        }
-    }
-    // border slots of this tile's interior rows that no entry above reaches: zero.  Slot jj of row i is reached from row i itself
-    // when ni + jj - i <= 64, and from border row ni + jj around the ring when i <= jj (never both on rings this long).
-    // (Only where the factorisation reads them: rows further than the band width from both ends of the interior have no border
-    //  entries at all and factor_t does not fetch that half of their H rows -- 1 MB of zeros per N = 2000 problem that nothing
-    //  needs to write either.  The margins cover the 16-row tile granularity of the fetch.)
-    for (int q = tid; q < GT_ROWS * MCQ_P_MAX; q += MCQ_NT) {
-        const int row = q / MCQ_P_MAX, jj = q - row * MCQ_P_MAX;
-        const int i = i0 + row;
-        if (i >= ni) continue;
-        if (i >= MCQ_BH_MAX + TB && i < ni - MCQ_BH_MAX - 2 * TB) continue;
-        if (ni + jj - i > MCQ_BH_MAX && i > jj) w.H[(size_t)i * MCQ_HLD + MCQ_HBO + jj] = 0.0;
-    }
-}
-
-__global__ void __launch_bounds__(MCQ_NT) mcq_gram_kernel(McqBatch B)
-{
-    const int tid = threadIdx.x + blockIdx.y * MCQ_NT;
-    const int nthreads = MCQ_NT * gridDim.y;
-    int n;
-    double kb, wveh;
-    const McqWork w = mcq_work(B, blockIdx.x, n, kb, wveh);
-    if (*w.status != MCQ_OK) return;
-    const int nm = B.nmax;
-    const McqDims d = mcq_dims(n, B.band_e);
-    if (gram_all_rows(d)) return;            // long rings: mcq_gram_tile_kernel writes all of H and f
-    const gdouble* KR = VEC(w, nm, V_KREF);
-    gdouble* F = VEC(w, nm, V_F);
-
-    for (int j = tid; j < n; j += nthreads) {   // f = F_SCALE * E' k_ref
-        double acc = 0.0;
-        int r = cyc(j - d.bR, n);
-        for (int oo = 0; oo < d.ew; ++oo) {
-            acc += w.Et[(size_t)oo * nm + j] * KR[r];
-            r = (r + 1 == n) ? 0 : r + 1;
-        }
-        F[j] = MCQ_F_SCALE * acc;
-    }
-    int f0, f1;
-    gram_fast_range(d, f0, f1);
-    gram_bordered(w.Et, nullptr, d, nm, nullptr, w.H, tid, nthreads, f0, f1);
-}
-
-#endif   // !defined(MCQ_CORE_BAND)
 // =====================================================================================================================
 // K3: solver
 // =====================================================================================================================
-#if !defined(MCQ_CORE_BAND)
 // =====================================================================================================================
 // K1': assembly of the shortest-path QP (tph.opt_shortest_path, call site
 //      [REF main_globaltraj.py:286-290]):   minimise  sum_i |p_{i+1} + a_{i+1} n_{i+1} - p_i - a_i n_i|^2   over the ring,
 //      i.e.  1/2 a'Ha + f'a  with  H_ii = 4 |n_i|^2,  H_{i,i+1} = -2 n_i . n_{i+1},  f_i = 2 n_i . (2 p_i - p_{i-1} - p_{i+1}),
 //      on the box  -max(w_l - w_veh/2, 0.001) <= a_i <= max(w_r - w_veh/2, 0.001).
-//      H goes straight into the bordered-band storage the factorisation reads (a cyclic tridiagonal: diagonal, one
-//      off-diagonal, two wrap-around entries in the border); Eb holds its three diagonals for the gradient H x + f.
+//      H is kept as two vectors (diagonal, H[i, i + 1 mod n]): the solver kernel's scalar cyclic-tridiagonal route (mcq_tri.inc).
 // =====================================================================================================================
 __global__ void __launch_bounds__(MCQ_NT) mcq_assemble_sp_kernel(McqBatch B)
 {
@@ -1011,7 +315,6 @@ __global__ void __launch_bounds__(MCQ_NT) mcq_assemble_sp_kernel(McqBatch B)
     double kb, wveh;
     const McqWork w = mcq_work(B, blockIdx.x, n, kb, wveh);
     const int nm = B.nmax;
-    const McqDims d = mcq_dims(n < 3 ? 3 : n, B.band_e);
     gdouble* LO = VEC(w, nm, V_LO);
     gdouble* HI = VEC(w, nm, V_HI);
     gdouble* NX = VEC(w, nm, V_NX);
@@ -1051,1503 +354,34 @@ __global__ void __launch_bounds__(MCQ_NT) mcq_assemble_sp_kernel(McqBatch B)
     }
 
     // entries of the cyclic tridiagonal (n >= 3: the two neighbours of a point are distinct)
-#define SP_DIAG(i) (4.0 * (w.nv[2 * (i)] * w.nv[2 * (i)] + w.nv[2 * (i) + 1] * w.nv[2 * (i) + 1]))
-#define SP_OFF(i, j) (-2.0 * (w.nv[2 * (i)] * w.nv[2 * (j)] + w.nv[2 * (i) + 1] * w.nv[2 * (j) + 1]))
-    const int ni = d.ni;
+    gdouble* HD = VEC(w, nm, V_XP);       // V_SPD / V_SPU of mcq_tri.inc
+    gdouble* HU = VEC(w, nm, V_YP);
     for (int i = tid; i < n; i += MCQ_NT) {
         const int ip = i + 1 == n ? 0 : i + 1, im = i == 0 ? n - 1 : i - 1;
-        const double hd = SP_DIAG(i), hu = SP_OFF(i, ip), hl = SP_OFF(i, im);
-        w.Eb[(size_t)0 * nm + i] = hl;
-        w.Eb[(size_t)1 * nm + i] = hd;
-        w.Eb[(size_t)2 * nm + i] = hu;
+        HD[i] = 4.0 * (w.nv[2 * i] * w.nv[2 * i] + w.nv[2 * i + 1] * w.nv[2 * i + 1]);
+        HU[i] = -2.0 * (w.nv[2 * i] * w.nv[2 * ip] + w.nv[2 * i + 1] * w.nv[2 * ip + 1]);
         const double px = w.ref[4 * i], py = w.ref[4 * i + 1];
         F[i] = 2.0 * (w.nv[2 * i] * ((px - w.ref[4 * im]) - (w.ref[4 * ip] - px))
                       + w.nv[2 * i + 1] * ((py - w.ref[4 * im + 1]) - (w.ref[4 * ip + 1] - py)));
     }
-    // rows of the bordered band: consecutive threads write consecutive entries of one row
-    for (int idx = tid; idx < MCQ_HLD * n; idx += MCQ_NT) {
-        const int i = idx / MCQ_HLD, slot = idx - i * MCQ_HLD;
-        double v = 0.0;
-        if (slot < MCQ_HBO) {
-            const int k = slot - (i & 15);         // band slot of H[i, i + k] (MCQ_HBAND)
-            if (i < ni) {
-                if (k == 0) v = SP_DIAG(i);
-                else if (k == 1 && d.b >= 1 && i + 1 < ni) v = SP_OFF(i, i + 1);
-            }
-        } else if (slot - MCQ_HBO < d.p) {
-            const int j = ni + (slot - MCQ_HBO);
-            const int df = sdiff(i, j, n);
-            if (df == 0) v = SP_DIAG(i);
-            else if (df == 1 || df == -1) v = SP_OFF(i, j);
-        }
-        w.H[(size_t)i * MCQ_HLD + slot] = v;
-    }
-#undef SP_DIAG
-#undef SP_OFF
 }
 
-#endif   // !defined(MCQ_CORE_BAND)
-#ifndef MCQ_IPM_TOL
-#define MCQ_IPM_TOL 1e-10
-#endif
-// -DMCQ_SKEW=k (diagnostic builds, scripts/gpu_variants.sh): one group of waves sleeps ~8000 cycles at one point of every factorisation
-// step (1: wave 0 / 2: the lag workers at the top of phase 1, 3: wave 0 behind the diagonal tile, 4 / 5: top of phase 2) -- an
-// ordering assumption between wave 0 and the lag workers that only holds by timing fails reproducibly under one of them.
-// (Stale-memory bugs are a different tool: MCQ_POISON=1, McqBatch::poison_lds.)
-#ifndef MCQ_SKEW
-#define MCQ_SKEW 0
-#endif
-#define SKEW(k, cond) do { if (MCQ_SKEW == (k) && (cond)) __builtin_amdgcn_s_sleep(127); } while (0)
-#ifndef MCQ_BAND_WAVE0
-#define MCQ_BAND_WAVE0 3    /* how many of the six band tiles of a step's lag work wave 0 takes (0, 3 or 6: one / two per lag wave) */
-#endif
-// -DMCQ_ABL=mask (scripts/factor_bench.hip ONLY: the results are garbage, the time is what is looked at): parts of a factorisation
-// step removed -- 1 Schur products, 2 border products, 4 write-out, 8 commit, 16 fetch, 32 diagonal tile, 128 wave 0's band tiles,
-// 256 phase 2, 512 the whole lag work, 1024 the not-positive-definite exit, 2048 the band products of the lag waves, 4096 the fetch
-// reads the same two tile rows all the time (cache hits), 8192 the write-out's global stores (its LDS reads stay), 16384 the lag
-// waves' operand / accumulator reads from the LDS window (constants instead), 32768 their write-back.
-#ifndef MCQ_ABL
-#define MCQ_ABL 0
-#endif
-#define ABL(bit) ((MCQ_ABL & (bit)) != 0)
-#ifndef MCQ_PD_CHECK_PER_STEP
-#define MCQ_PD_CHECK_PER_STEP 0     /* 1: the non-positive-pivot flag is read after every step (round 2) instead of once per factorisation */
-#endif
-#ifndef MCQ_FUSE_FWD
-#define MCQ_FUSE_FWD 1     /* forward substitution of the predictor / active-set solve fused into the factorisation (factor_t) */
-#endif
-struct SolveCtx {
-    McqDims d;
-    McqWork w;
-    int nm;
-    mutable long long tk[8];   // phase timers (wall_clock64 ticks), meaningful on thread 0
-    mutable int refine_rounds, second_attempt;   // diagnostics for mcq_info
-    mutable double last_step;  // length of the last interior-point step (the Tapia indicators are only trusted after a near-full one)
-    int direct;                // 1: Eb holds the three diagonals of H itself and V_F holds f (shortest-path objective)
-    mutable const gdouble* kkt_w;   // saddle-point elimination: weights of the curvature rows (1 + y/t of the interior point) or nullptr
-};
-#define TICK() ((long long)wall_clock64())
-// fine-grained timers inside the factorisation (ticks[4..7]) cost an s_waitcnt per sample in the hot loop: off by default
-#ifndef MCQ_FINE_TIMERS
-#define MCQ_FINE_TIMERS 0
-#endif
-#define FTICK() (MCQ_FINE_TIMERS ? TICK() : 0LL)
-// -DMCQ_WORKER_TIMERS=w (diagnostic build, scripts/gpu_variants.sh): where the lag-worker wave w = 1..3 spends phase 1 of a factorisation
-// step -- shader-clock cycles (s_memtime) summed over all steps and factorisations of a problem, reported in mcq_info.ticks[0..7]
-// INSTEAD of the usual phase timers: [0] fetch issue, [1] LDS reads of the lag work, [2] border products + write-back, [3] Schur + band products, [4] write-out, [5] commit,
-// [6] wait at the phase-1 barrier, [7] phase 2 + its barrier (w = 4: wave 0 -- [0] its diagonal tile + inverse, [6], [7] as above).
-// Every sample drains the wave's LDS queue: the sum is an upper bound.
-#ifndef MCQ_SOLVE_TIMERS
-#define MCQ_SOLVE_TIMERS 0      /* 1: where loader wave 1 spends a step of the backward sweep (shader cycles in ticks[0..5]) */
-#endif
-#ifndef MCQ_WORKER_TIMERS
-#define MCQ_WORKER_TIMERS 0
-#endif
-#define WT(k)                                                                                              \
-    do {                                                                                                   \
-        if (MCQ_WORKER_TIMERS) {                                                                           \
-            const long long t_ = (long long)clock64();                                                     \
-            wt[(k)] += t_ - wt_last;                                                                       \
-            wt_last = t_;                                                                                  \
-        }                                                                                                  \
-    } while (0)
-// default build: ticks[4] / ticks[5] = wave 0's forward / backward interior sweeps (part of ticks[1]), two samples per solve
-#define STICK() (MCQ_FINE_TIMERS ? 0LL : TICK())
 
-#if defined(MCQ_CORE_BAND)
-// ---- bordered-band Cholesky of  M = H + diag(sig)  with rows/cols of pinned variables replaced by identity ----------
-// Blocked right-looking factorisation, 16 columns per step, on an LDS window of 5 x 5 band tiles + 6 x 4 border tiles:
-//   phase 1  wave 0 factors the 16x16 diagonal tile in registers (left-looking, v_readlane broadcasts, no LDS trips);
-//   phase 2  128 lanes do the 16-step triangular solves of the panel: 64 rows of L below the diagonal tile and the 64
-//            columns of the border block row  W = L00^-1 C;
-//   phase 3  rank-16 trailing update on the fp64 matrix cores (v_mfma_f64_16x16x4_f64): 10 band tiles and 16 border
-//            tiles in LDS, the 16 tiles of the Schur complement S -= W'W in registers;  L / W rows go to HBM as
-//            128-byte segments, the next tile row (16 x 144 doubles) is fetched one step ahead through registers and
-//            stays in flight across the LDS-only barriers.
-// Output: L rows in w.L (row i: [0] = 1/L_ii, [k] = L[i,i-k]; [HBO+jj] = W[i][jj]); L_S (p x p, lower) in LDS SM_S.
-// Returns 0 or MCQ_NOT_PD (uniform across the block).
-// Band tile (I, K), I - 4 <= K <= I, lives in row slot I mod 5 at the RELATIVE column K - I + 4: one runtime modulo per row, and
-// the address of an item of tile row R is a wave-uniform base plus a per-thread constant.  (K - I = 1 wraps to column 0: the
-// slot of the finished tile (I, I - 4) -- the "dead" slot LTILE(1, .) borrows.)
-#define BTILE(I, K) (bt + ((((I) % NTR) * NTR) + (((K) - (I) + 2 * NTR - 1) % NTR)) * TSZ)
-#define CROW(I) (ct + (((I) % NTRC) * NCT5) * TSZ)           /* border row slot of step / tile row I */
-#define INVT(I) CROW(I)                                      /* inverse of the diagonal tile of step I */
-#define CTILE(I, a) (CROW(I) + (1 + (a)) * TSZ)
-// L(P+dI, P), dI = 1..4, once the panel of step P is done: in place, except the first sub-diagonal tile, which every wave
-// still reads as T(P+1, P) while wave 0 produces it -- that one goes to the dead upper-triangle slot (P+1, P+2)
-#define LTILE(dI, P) ((dI) == 1 ? BTILE((P) + 1, (P) + 2) : BTILE((P) + (dI), (P)))
-#define ROW_ITEMS (TB * (NTR * TB + MCQ_P_MAX))            /* 16 x 144 doubles per tile row */
-#define PF_THREADS (MCQ_NT - 64)                           /* waves 1..3 fetch and commit; wave 0 only runs the critical path */
-#define PF_ITEMS (ROW_ITEMS / PF_THREADS)                 /* 2304 / 192 = 12 */
-
-// Raw (un-decoded) loads of one window entry: kept in registers while the loads are in flight, decoded when the entry is
-// committed to LDS -- nothing between fetch and commit depends on the loaded values, so no s_waitcnt is placed early.
-struct RawEntry {
-    double h, sg;
-    int m0, m1;
-};
-
-// item q of tile row R: q < 16*80 -> band part, column-major inside the tile row (16 consecutive rows of one column
-// are 16 contiguous doubles of H); else border part, row-major (64 contiguous doubles of one H row)
-template <bool MK, bool SIG>
-__device__ __forceinline__ RawEntry tile_row_fetch(const gdouble* H, const gdouble* sig, const gschar* mk, int ni, int b, int p,
-                                                   int R, int q)
+// fv: the right-hand side of the solve that follows rides through the elimination (solve(c, fv, true) then finishes it)
+__device__ __noinline__ int factor(const SolveCtx& c, const gdouble* sig, const gschar* mk, gdouble* fv)
 {
-    RawEntry e;
-    e.sg = 0.0;
-    e.m0 = e.m1 = 0;
-    if (q < TB * NTR * TB) {
-        const int ee = q / TB, rr = q - ee * TB;
-        const int i = R * TB + rr, c = (R - (NTR - 1) + ee / TB) * TB + (ee % TB);
-        const bool in = (i < ni) & (c < ni) & (c >= 0);
-        const int k = i - c;
-        const bool valid = in & (k >= 0) & (k <= b);
-        const int cs = in ? c : 0, is = in ? i : 0;
-        e.h = H[MCQ_HBAND(cs, valid ? k : 0)];
-        if (MK) { e.m0 = mk[cs]; e.m1 = mk[is]; }
-        if (SIG && k == 0) e.sg = sig[cs];      // the diagonal shift only touches the 16 diagonal entries of a tile row
-    } else {
-        const int q2 = q - TB * NTR * TB;
-        const int rr = q2 / MCQ_P_MAX, jj = q2 - rr * MCQ_P_MAX;
-        const int i = R * TB + rr;
-        const bool in = (i < ni) & (jj < p);
-        const int is = in ? i : 0, js = in ? jj : 0;
-        e.h = H[(size_t)is * MCQ_HLD + MCQ_HBO + js];
-        if (MK) { e.m0 = mk[is]; e.m1 = mk[ni + js]; }
-    }
-    return e;
+    if (c.direct) return factor_sp(c, sig, mk);
+    return factor_kkt(c, sig, mk, c.kkt_w, fv);
 }
 
-template <bool MK, bool SIG>
-__device__ __forceinline__ double tile_row_decode(const RawEntry& e, int ni, int b, int p, int R, int q)
-{
-    if (q < TB * NTR * TB) {
-        const int ee = q / TB, rr = q - ee * TB;
-        const int i = R * TB + rr, c = (R - (NTR - 1) + ee / TB) * TB + (ee % TB);
-        const bool in = (i < ni) & (c < ni) & (c >= 0);
-        const int k = i - c;
-        const bool valid = in & (k >= 0) & (k <= b);
-        double v = valid ? e.h : 0.0;
-        bool pinned = false;
-        if (MK) {
-            pinned = (e.m0 != 0) | (e.m1 != 0);
-            v = pinned ? (k == 0 ? 1.0 : 0.0) : v;
-        }
-        if (SIG) v += (k == 0 && !pinned) ? e.sg : 0.0;
-        return in ? v : ((k == 0) ? 1.0 : 0.0);     // identity padding beyond the interior
-    }
-    const int q2 = q - TB * NTR * TB;
-    const int rr = q2 / MCQ_P_MAX, jj = q2 - rr * MCQ_P_MAX;
-    const bool in = (R * TB + rr < ni) & (jj < p);
-    double v = e.h;
-    if (MK) v = ((e.m0 != 0) | (e.m1 != 0)) ? 0.0 : v;
-    return in ? v : 0.0;
-}
-
-__device__ __forceinline__ void tile_row_store(double* bt, double* ct, int R, int q, double v)
-{
-    if (q < TB * NTR * TB) {
-        const int e = q / TB, rr = q - e * TB;
-        const int K = R - (NTR - 1) + e / TB, cc = e % TB;
-        if (K >= 0) BTILE(R, K)[rr * TLD + cc] = v;
-    } else if (q < ROW_ITEMS) {
-        const int q2 = q - TB * NTR * TB;
-        const int rr = q2 / MCQ_P_MAX, jj = q2 - rr * MCQ_P_MAX;
-        CTILE(R, jj / TB)[rr * TLD + (jj % TB)] = v;
-    }
-}
-
-// Steady-state fetch / commit of a tile row (tile rows that lie completely inside the interior, R >= NTR-1 and 16 (R+1) <= ni, of a
-// problem with the full band and border width): round 3 mapping.  The 16 x 144 entries of a tile row are 9 tiles (5 band, 4 border)
-// of 4 blocks of 64 entries each; a fetch wave takes 12 whole blocks, one entry per lane and block, and inside a block the lane ->
-// entry map is the same for every block of its kind:
-//     band   tile tcol (relative column), block k:  row rr = l15, column cc = l4 + 4k   -- 16 lanes read 16 contiguous doubles of an
-//            H row (the tile's column cc is contiguous in H), LDS word  tcol TSZ + l15 TLD + l4 + 4k
-//     border tile a, block k:                       row rr = l4 + 4k, column jj = 16a + l15 -- 16 lanes read 128 contiguous bytes,
-//            LDS word  (1 + a) TSZ + (l4 + 4k) TLD + l15
-// so every address of an item is a wave-uniform base + ONE per-lane constant per kind + a literal.  (Rounds 1-2 numbered the items
-// q = thread + 192 u through the generic index arithmetic: 12 x {global offset, LDS offset, flags} = 36 loop-invariant VGPRs per
-// lane that the allocator parked in AGPRs / scratch and copied back every step -- and whose reloads from scratch wait on vmcnt(0),
-// i.e. on the tile row in flight.)  Blocks are dealt to the three fetch waves by residue: band block 4 tcol + k to wave (4 tcol + k) % 3
-// (7 / 7 / 6), border block 4 a + k to wave (4 a + k + 2) % 3 (5 / 5 / 6): twelve per wave, and in the rows whose border half is all
-// zeros (not fetched) the band blocks alone are still spread 7 / 7 / 6.
-struct PfLane {
-    int gB, gC;     // global offsets relative to H + R * TB * MCQ_HLD: band / border item of this lane (block literal to be added)
-    int lB, lC;     // LDS words relative to the row slot
-};
-__device__ __forceinline__ PfLane pf_lane(int l15, int l4)
-{
-    PfLane c;
-    c.gB = l4 * MCQ_HLD + l15;
-    c.gC = l4 * MCQ_HLD + l15;
-    c.lB = l15 * TLD + l4;
-    c.lC = l4 * TLD + l15;
-    return c;
-}
-#define PF_NBAND(WL) ((WL) < 2 ? 7 : 6)                              /* band blocks of fetch wave WL */
-#define PF_BBLK(WL, u) ((WL) + 3 * (u))                               /* u-th band block of wave WL: 4 tcol + k */
-#define PF_CBLK(WL, v) ((((WL) + 1) % 3) + 3 * (v))                   /* v-th border block of wave WL: 4 a + k */
-
-// (BZ -- the border half of the row is all zeros and is not fetched -- is a template parameter: a run-time flag merges loaded values
-//  with constants through control flow, and the compiler then waits for the loads at the merge, i.e. right behind their issue)
-template <int WL, bool MK, bool SIG, bool BZ>
-__device__ __forceinline__ void tile_row_fetch_fast(const gdouble* H, const gdouble* sig, const gschar* mk, int R, int ni, const PfLane& c,
-                                                    int l15, int l4, RawEntry (&e)[PF_ITEMS])
-{
-    const gdouble* Hr = H + (size_t)(ABL(4096) ? NTR + (R & 1) : R) * (TB * MCQ_HLD);     // (ablation 4096: the same two tile rows over and over -- cache hits)
-#pragma unroll
-    for (int u = 0; u < PF_ITEMS; ++u) {
-        e[u].sg = 0.0;
-        e[u].m0 = e[u].m1 = 0;
-        if (u < PF_NBAND(WL)) {
-            const int tcol = PF_BBLK(WL, u) / 4, k = PF_BBLK(WL, u) % 4;
-            // entry (rr = l15, cc = l4 + 4k) of T(R, R - 4 + tcol) = H[c, i], band slot (c mod 16) + i - c = 16 (4 - tcol) + rr of row c
-            // (MCQ_HBAND): the 16 rows of a column are one aligned 128-byte line.  Entries outside the band (tcol 4: above the
-            // diagonal, tcol 0: beyond 64) read unused slots of the row and are dropped at the commit
-            e[u].h = Hr[c.gB + ((TB * (tcol - (NTR - 1)) + 4 * k) * MCQ_HLD + TB * (NTR - 1 - tcol))];
-            if (MK) {
-                e[u].m0 = mk[R * TB + TB * (tcol - (NTR - 1)) + l4 + 4 * k];
-                e[u].m1 = mk[R * TB + l15];
-            }
-            if (SIG && tcol == NTR - 1) e[u].sg = sig[R * TB + l4 + 4 * k];
-        } else {
-            const int a = PF_CBLK(WL, u - PF_NBAND(WL)) / 4, k = PF_CBLK(WL, u - PF_NBAND(WL)) % 4;
-            if (BZ) {
-                e[u].h = 0.0;
-            } else {
-                e[u].h = Hr[c.gC + (4 * k * MCQ_HLD + MCQ_HBO + TB * a)];
-                if (MK) {
-                    e[u].m0 = mk[R * TB + l4 + 4 * k];
-                    e[u].m1 = mk[ni + TB * a + l15];
-                }
-            }
-        }
-    }
-}
-
-template <int WL, bool MK, bool SIG>
-__device__ __forceinline__ void tile_row_commit_fast(double* bt, double* ct, const RawEntry (&e)[PF_ITEMS], int R, const PfLane& c,
-                                                     int l15, int l4)
-{
-    double* brow = bt + (R % NTR) * (NTR * TSZ) + c.lB;       // wave-uniform row slot + per-lane constant; block offsets are literals
-    double* crow = ct + (R % NTRC) * (NCT5 * TSZ) + c.lC;
-#pragma unroll
-    for (int u = 0; u < PF_ITEMS; ++u) {
-        const bool pinned = MK && ((e[u].m0 != 0) | (e[u].m1 != 0));
-        if (u < PF_NBAND(WL)) {
-            const int tcol = PF_BBLK(WL, u) / 4, k = PF_BBLK(WL, u) % 4;
-            const int cc = l4 + 4 * k;
-            const bool valid = tcol == NTR - 1 ? l15 >= cc : (tcol == 0 ? l15 <= cc : true);      // 0 <= 16 (4 - tcol) + rr - cc <= 64
-            const bool dg = tcol == NTR - 1 && l15 == cc;
-            double v = valid ? e[u].h : 0.0;
-            if (MK) v = pinned ? (dg ? 1.0 : 0.0) : v;
-            if (SIG && tcol == NTR - 1) v += (dg && !pinned) ? e[u].sg : 0.0;
-            brow[tcol * TSZ + 4 * k] = v;
-        } else {
-            const int a = PF_CBLK(WL, u - PF_NBAND(WL)) / 4, k = PF_CBLK(WL, u - PF_NBAND(WL)) % 4;
-            double v = e[u].h;
-            if (MK) v = pinned ? 0.0 : v;
-            crow[(1 + a) * TSZ + 4 * k * TLD] = v;
-        }
-    }
-}
-
-// Cholesky factor AND its inverse of one 16x16 LDS tile on ONE wave, in registers.  Lane i (mod 16) holds row i of L
-// (a[k] = L[i][k]); left-looking by columns, the multipliers L[j][k] are v_readlane broadcasts.  The same multipliers give
-// the inverse M = L^-1 by rows for free: lane c holds column c of M,  M[j][c] = rs_j ( [j == c] - sum_{k<j} L[j][k] M[k][c] ).
-// Writes M (row-major, upper part zero) to `lv`; returns true if a pivot is not positive.
-
-#ifdef MCQ_DIAG_READLANE
-__device__ __forceinline__ bool diag_tile_inv(const double* d0, double* lv, int l15)
-{
-    double a[TB], m[TB];
-#pragma unroll
-    for (int cc = 0; cc < TB; ++cc) a[cc] = d0[l15 * TLD + cc];
-    bool bad = false;
-#pragma unroll
-    for (int j = 0; j < TB; ++j) {
-        // The broadcast lane is passed through an opaque register tied to the column of L and the row of M finished last:
-        // without it the compiler hoists all 120 multiplier broadcasts to where their source column becomes final, runs
-        // the M chain after the L chain and parks the multipliers in SGPRs (spilled to VGPR lanes and reloaded) -- with it
-        // at most one column's multipliers are live.
-        int jv = j;
-        if (j > 0) MCQ_PIN_SVV(jv, a[j - 1], m[j - 1]);
-        double mm = (l15 == j) ? 1.0 : 0.0;
-#pragma unroll
-        for (int k = 0; k < j; ++k) {
-            const double s = bcast_lane(a[k], jv);
-            a[j] -= a[k] * s;
-            mm -= m[k] * s;
-        }
-        const double piv = bcast_lane(a[j], jv);
-        bad |= !(piv > 0.0);
-        const double rs = rsqrt(piv);
-        a[j] *= rs;
-        m[j] = mm * rs;
-    }
-    // all four 16-lane groups hold the same columns and store them (same values, same addresses): a store under
-    // "lane < 16" lets the compiler sink the whole M chain behind the L chain and spill its 120 multipliers
-#pragma unroll
-    for (int j = 0; j < TB; ++j) lv[j * TLD + l15] = m[j];
-    return bad;
-}
-#else
-// Right-looking form on row broadcasts.  All four 16-lane rows of the wave hold the same tile (lane l15 = row l15), so the
-// multiplier L[j][k] = a[k] of lane j reaches every lane as a ROW broadcast -- one DPP move per double instead of two
-// v_readlane_b32 through an SGPR pair (240 of them were the instruction-issue bound of this wave: 5500 cycles per tile).  As soon as
-// column k is final it is applied to the columns behind it, nearest first: the chain a[k] -> a[k+1] -> pivot -> rsqrt is the
-// critical path, the other columns' updates and the M chain (same multipliers) fill its latency; a multiplier lives for two FMAs.
-// columns J0 .. J1-1 (and the rows of M) take the update of finalised column K
-template <int K, int J0, int J1> __device__ __forceinline__ void diag_apply(double (&a)[TB], double (&m)[TB])
-{
-    if constexpr (J0 < J1 && J0 < TB) {
-        const double s = bcast_row16<J0>(a[K]);     // L[J0][K]
-        a[J0] -= a[K] * s;                          // column J0 of the tile (this lane's row)
-        m[J0] -= m[K] * s;                          // row J0 of M (this lane's column)
-        diag_apply<K, J0 + 1, J1>(a, m);
-    }
-}
-// Column K becomes final.  A single wave issues in order, so the latency of the pivot's chain -- broadcast, v_rsq_f64, the
-// refinement r = r0 + r0 e (1/2 + 3/8 e), e = 1 - piv r0^2 (the sequence rsqrt() compiles to, written out so that it can be
-// spread) -- is filled by hand: the updates column K-1 still owes the columns BEHIND K sit between its stages, two per gap.
-template <int K> __device__ __forceinline__ void diag_cols(double (&a)[TB], double (&m)[TB], bool& bad)
-{
-    if constexpr (K < TB) {
-        if constexpr (K > 0) diag_apply<K - 1, K, K + 1>(a, m);          // completes column K
-        const double piv = bcast_row16<K>(a[K]);
-        bad |= !(piv > 0.0);
-        const double r0 = __builtin_amdgcn_rsq(piv);
-        if constexpr (K > 0) diag_apply<K - 1, K + 1, K + 3>(a, m);
-        const double t = -piv * r0;
-        if constexpr (K > 0) diag_apply<K - 1, K + 3, K + 5>(a, m);
-        const double e = fma(t, r0, 1.0);
-        if constexpr (K > 0) diag_apply<K - 1, K + 5, K + 7>(a, m);
-        const double u = r0 * e, w = fma(e, 0.375, 0.5);
-        if constexpr (K > 0) diag_apply<K - 1, K + 7, K + 9>(a, m);
-        const double rs = fma(u, w, r0);
-        if constexpr (K > 0) diag_apply<K - 1, K + 9, TB>(a, m);
-        a[K] *= rs;
-        m[K] *= rs;
-        diag_cols<K + 1>(a, m, bad);
-    }
-}
-__device__ __forceinline__ bool diag_tile_inv(const double* d0, double* lv, int l15)
-{
-    double a[TB], m[TB];
-#pragma unroll
-    for (int cc = 0; cc < TB; ++cc) { a[cc] = d0[l15 * TLD + cc]; m[cc] = (l15 == cc) ? 1.0 : 0.0; }
-    bool bad = false;
-    diag_cols<0>(a, m, bad);
-#pragma unroll
-    for (int j = 0; j < TB; ++j) lv[j * TLD + l15] = m[j];
-    return bad;
-}
-#endif
-
-// One step of the forward substitution fused into the factorisation (wave 0, phase 1 of step J; see the header of factor_t).
-__device__ __forceinline__ void fused_fwd_step(int J, gdouble* fv, int ni, double* bt, double* ct, double* yring, double* pend, double* svx,
-                                               int lane, int l15, int l4, double& ff_tacc, double& ff_rhs, double ff_next)
-{
-    // ---- forward substitution fused into the factorisation (see the header of factor_t), column-oriented: the tiles
-    //      L(P+1 .. P+4, P) of block column P = J-1 and W_P are all in the window during this phase (they are what the
-    //      lag workers read); a row's own tiles are not (L(J, J-4)'s slot was recycled for L(J, J-1)) ----
-    if (J > 0) {
-        const int P = J - 1;
-        double yv[TB];
-        const double* yp = yring + ((P * TB) & (VRING - 1));
-#pragma unroll
-        for (int cc = 0; cc < TB; ++cc) yv[cc] = yp[cc];
-        {   // border sums (W'y)_jj += sum_rr W_P[rr][jj] y_P[rr]: lane = column jj = 16 l4 + l15
-            const double* wt_ = CTILE(P, l4) + l15;
-            double a0 = 0.0, a1 = 0.0;
-#pragma unroll
-            for (int rr = 0; rr < TB; rr += 2) {
-                a0 += wt_[rr * TLD] * yv[rr];
-                a1 += wt_[(rr + 1) * TLD] * yv[rr + 1];
-            }
-            ff_tacc += a0 + a1;
-        }
-        {   // pending sums of the block rows P+1 .. P+4 -= L(P+1+l4, P) y_P: lane (row l15, group l4)
-            const double* lt_ = (l4 == 0 ? BTILE(P + 1, P + 2) : BTILE(P + 1 + l4, P)) + l15 * TLD;   // LTILE(1 + l4, P)
-            double a0 = 0.0, a1 = 0.0;
-#pragma unroll
-            for (int cc = 0; cc < TB; cc += 2) {
-                a0 += lt_[cc] * yv[cc];
-                a1 += lt_[cc + 1] * yv[cc + 1];
-            }
-            pend[((P + 1 + l4) * TB + l15) & (VRING - 1)] -= a0 + a1;
-        }
-    }
-    __builtin_amdgcn_wave_barrier();
-    // block row J:  y_J = M_J (v_J + pending), M_J = L_JJ^-1 just written by this wave
-    const int iJ = J * TB + l15;
-    const double sv = ff_rhs + pend[iJ & (VRING - 1)];            // used in lanes 0..15
-    ff_rhs = ff_next;             // the next block row's right-hand side: in flight since the top of this phase (behind the diagonal tile)
-    __builtin_amdgcn_wave_barrier();
-    if (lane < TB) { svx[lane] = sv; pend[iJ & (VRING - 1)] = 0.0; }
-    __builtin_amdgcn_wave_barrier();
-    // over all 64 lanes: group l4 takes columns 4 l4 .. 4 l4 + 3 of row l15 of M_J
-    const double* mrow = INVT(J) + l15 * TLD + 4 * l4;
-    const double y = row4_sum_low16((mrow[0] * svx[4 * l4] + mrow[1] * svx[4 * l4 + 1])
-                                    + (mrow[2] * svx[4 * l4 + 2] + mrow[3] * svx[4 * l4 + 3]));
-    __builtin_amdgcn_wave_barrier();
-    if (lane < TB) {
-        yring[iJ & (VRING - 1)] = y;
-        if (iJ < ni) fv[iJ] = y;
-    }
-    __builtin_amdgcn_wave_barrier();
-}
-
-// `fv` (optional): right-hand side of the solve that follows.  Its interior FORWARD substitution  y_B = L_B^-1 v_B  and the border
-// sums W'y_B are then produced block row by block row during the factorisation itself, by wave 0 in the part of a step where it
-// would otherwise wait for the lag workers (~2200 cycles): everything the tile step of the forward sweep needs -- L(J, J-4 .. J-1),
-// M_J = L_JJ^-1, W_(J-1) -- sits in the LDS window at that moment.  solve(..., fwd_done = true) then starts at the border system:
-// one of the four passes over L per interior-point iteration (and one of two per active-set round) is never streamed from HBM.
-// (One function per configuration, NOT inlined into factor(): with the three bodies in one function hipcc 7.2 needs long branches
-// (s_getpc / s_setpc through a scavenged SGPR pair) and takes callee-saved s[98:99] for them without saving it -- the caller's loop
-// strides went with it.  scripts/check_csr.py scans the ISA of every device function for exactly this.)
-template <bool MK, bool SIG>
-__device__ __noinline__ int factor_t(const SolveCtx& c, const gdouble* Hsrc, const gdouble* sig, const gschar* mk, gdouble* fv)
-{
-    const int tid = threadIdx.x;
-    const int b = c.d.b, p = c.d.p, ni = c.d.ni;
-    double* bt = g_sm + SM_BT;
-    double* ct = g_sm + SM_CT;
-    double* dinv = g_sm + SM_DINV;
-    const gdouble* H = Hsrc;
-    gdouble* L = c.w.L;
-    const int lane = tid & 63, w0 = tid >> 6;
-    const int l15 = lane & 15, l4 = lane >> 4;
-    const int nblk = (ni + TB - 1) / TB;
-
-    v4d sacc[NCT];
-#pragma unroll
-    for (int m = 0; m < NCT; ++m) sacc[m] = (v4d){0.0, 0.0, 0.0, 0.0};
-    RawEntry pf[PF_ITEMS];
-    double* yring = g_sm + SM_YR;
-    double* pend = g_sm + SM_PEND;
-    double* svx = g_sm + SM_RED;          // 16 doubles: a block row's partial right-hand side on its way to all four lane groups
-    double ff_tacc = 0.0;                 // lane jj of wave 0: (W'y)_jj
-    double ff_rhs = 0.0;                  // lanes 0..15 of wave 0: right-hand side of the block row solved in the NEXT step
-    long long wt[8] = {0, 0, 0, 0, 0, 0, 0, 0}, wt_last = 0;
-    (void)wt; (void)wt_last;
-
-    const int lt = tid - 64;         // fetch / commit thread of waves 1..3
-    const PfLane pc = pf_lane(l15, l4);
-    const bool pf_dims = (b == MCQ_BH_MAX) & (p == MCQ_P_MAX);       // the literal band limits of the fast fetch / commit
-#define PF_FAST(R) (pf_dims && (R) >= NTR - 1 && ((R) + 1) * TB <= ni)
-    __syncthreads();
-    // prologue: tile rows 0 .. NTR-1
-    if (lt >= 0) {
-        for (int R = 0; R < NTR; ++R) {
-            // all loads of a tile row are issued before the first decode (one HBM round trip per tile row, not per item)
-#pragma unroll
-            for (int u = 0; u < PF_ITEMS; ++u) pf[u] = tile_row_fetch<MK, SIG>(H, sig, mk, ni, b, p, R, lt + u * PF_THREADS);
-#pragma unroll
-            for (int u = 0; u < PF_ITEMS; ++u) {
-                const int q = lt + u * PF_THREADS;
-                tile_row_store(bt, ct, R, q, tile_row_decode<MK, SIG>(pf[u], ni, b, p, R, q));
-            }
-        }
-    }
-    if (tid == 0) dinv[TB] = 0.0;   // fail flag
-    if (fv && w0 == 0) {
-        for (int q = lane; q < VRING; q += 64) { yring[q] = 0.0; pend[q] = 0.0; }
-        ff_rhs = (lane < TB && lane < ni) ? fv[lane] : 0.0;
-    }
-    __syncthreads();
-
-    // Software-pipelined block loop, two LDS barriers per step.  The critical path of one step is
-    //   diag(J) [+ its inverse M_J]  ->  panel(J) = products with M_J  ->  update of block column J+1;
-    // everything else that step J-1 owes (16 border tiles, 10 Schur tiles, 6 band tiles, the write-out of L / W / the
-    // inverse tile) runs on waves 1..3 WHILE wave 0 factors the next diagonal tile:
-    //   phase 1   wave 0: diag(J) and M_J = L_JJ^-1 (registers, v_readlane), nothing else
-    //             waves 1..3: commit the tile row fetched during the previous step, put the next one in flight,
-    //                         lag(J-1) + write-out(J-1)
-    //   phase 2   wave w: L(J+1+w, J) = T M_J',  W_J(w) = M_J C(J, w),  T(J+1+w, J+1) -= L(J+1+w, J) L(J+1, J)'   (MFMA)
-    int fail = 0;
-    const int wl = w0 - 1;           // lag-worker index of waves 1..3
-    // Tile ownership of the three lag waves (wl = 0..2):
-    //   border tiles C(P+dI, a): column a = wl for dI = 1..4, plus one tile of column 3 (dI = wl + 1); wl = 0 also (4, 3)
-    //   Schur tiles (lower, 10): (t + 1) % 3 == wl, register slot t / 3;    band tiles (6): t % 3 == wl
-    // wl is a literal inside LAG_WORK (three-way dispatch) so that every register array is indexed statically.
-    // All LDS operand / accumulator reads of a group are issued before its MFMAs, all writes after them.
-#define LAG_WORK(P, WL, CM)                                                                                                  \
-    {                                                                                                                  \
-        /* The three groups of the step's lag work (border, band, Schur tiles) used to run read -> MFMA -> write one after \
-           the other; the compiler cannot move a group's LDS reads above the previous group's LDS writes (same address     \
-           space, no alias info), so each group paid its own LDS round trip with the matrix pipe idle.  Now operands       \
-           shared between groups are read once (the W row block of step P: border and Schur; the L tiles: border and       \
-           band), the border products run off one batch of reads, and the band accumulators are read behind the border     \
-           tiles' write-back with the Schur products (registers only) in between to cover that one round trip.  (All      \
-           reads up front costs 16 more live VGPRs than the allocator has: spills, and a crash in hipcc 7.2's                \
-           AGPR-copy rewrite pass.)                                                                                      \
-             border tiles  C(P+dI, a) -= L(P+dI, P) W_P(a)            a = WL for dI = 1..4, plus (WL+1, 3) [and (4, 3) on WL 0]   \
-             band tiles    T(P+dI, P+dK) -= L(P+dI, P) L(P+dK, P)'    2 <= dK <= dI <= 4, tile t % 3 == WL                 \
-             Schur tiles   S(a, bb) -= W_P(a)' W_P(bb)                 lower, (t + 1) % 3 == WL, kept in registers */    \
-        double la_[4][4], wv_[NCT][4];                                                                                 \
-        v4d cacc_[4], c3a_, c3b_, bacc_[2];                                                                            \
-        _Pragma("unroll") for (int a_ = 0; a_ < NCT; ++a_) {                                                           \
-            const double* wa2_ = CTILE((P), a_);                                                                       \
-            _Pragma("unroll") for (int kc = 0; kc < 4; ++kc) wv_[a_][kc] = ABL(16384) ? 1.0 + a_ : wa2_[(l4 + 4 * kc) * TLD + l15];            \
-        }                                                                                                              \
-        _Pragma("unroll") for (int dI_ = 1; dI_ < NTR; ++dI_) {                                                        \
-            const double* li_ = LTILE(dI_, (P));                                                                       \
-            const double* ctl_ = CTILE((P) + dI_, (WL));                                                               \
-            _Pragma("unroll") for (int kc = 0; kc < 4; ++kc) la_[dI_ - 1][kc] = ABL(16384) ? 0.5 + dI_ : -li_[l15 * TLD + l4 + 4 * kc];         \
-            _Pragma("unroll") for (int r = 0; r < 4; ++r) cacc_[dI_ - 1][r] = ABL(16384) ? 0.25 : ctl_[(l4 + 4 * r) * TLD + l15];          \
-        }                                                                                                              \
-        {                                                                                                              \
-            const double* c3p_ = CTILE((P) + (WL) + 1, 3);                                                             \
-            const double* c3q_ = CTILE((P) + 4, 3);                                                                    \
-            _Pragma("unroll") for (int r = 0; r < 4; ++r) {                                                            \
-                c3a_[r] = ABL(16384) ? 0.1 : c3p_[(l4 + 4 * r) * TLD + l15];                                           \
-                c3b_[r] = ABL(16384) ? 0.2 : c3q_[(l4 + 4 * r) * TLD + l15];                                                              \
-            }                                                                                                          \
-        }                                                                                                              \
-        WT(1);                                                                                                         \
-        /* ---- products ---- */                                                                                       \
-        if (!ABL(2)) {                                                                                                 \
-        _Pragma("unroll") for (int dI_ = 1; dI_ < NTR; ++dI_) cacc_[dI_ - 1] = mfma16(la_[dI_ - 1], wv_[(WL)], cacc_[dI_ - 1]); \
-        c3a_ = mfma16(la_[(WL)], wv_[3], c3a_);                                                                        \
-        if ((WL) == 0) c3b_ = mfma16(la_[3], wv_[3], c3b_);                                                            \
-        }                                                                                                              \
-        /* ---- in the shadow of those 20 / 24 fp64 MFMAs (64 cycles each, results not needed yet): this wave's share of the     \
-                write-out of step P -- LDS reads of final tiles, global stores; nothing the products touch ---- */            \
-        __builtin_amdgcn_sched_barrier(0);                                                                             \
-        if (!ABL(4)) { if ((WL) == 0) { WRITE_OUT_W((P), 1) } else if ((WL) == 1) { WRITE_OUT_W((P), 0) } else { WRITE_OUT_L((P)) } } \
-        __builtin_amdgcn_sched_barrier(0);                                                                             \
-        /* ---- updated tiles back to the window ---- */                                                               \
-        _Pragma("unroll") for (int dI_ = 1; dI_ < NTR; ++dI_) {                                                        \
-            double* ctl_ = CTILE((P) + dI_, (WL));                                                                     \
-            _Pragma("unroll") for (int r = 0; r < 4; ++r) if (!ABL(32768)) ctl_[(l4 + 4 * r) * TLD + l15] = cacc_[dI_ - 1][r];          \
-        }                                                                                                              \
-        {                                                                                                              \
-            double* c3p_ = CTILE((P) + (WL) + 1, 3);                                                                   \
-            double* c3q_ = CTILE((P) + 4, 3);                                                                          \
-            _Pragma("unroll") for (int r = 0; r < 4; ++r) {                                                            \
-                if (!ABL(32768)) c3p_[(l4 + 4 * r) * TLD + l15] = c3a_[r];                                                              \
-                if ((WL) == 0) c3q_[(l4 + 4 * r) * TLD + l15] = c3b_[r];                                               \
-            }                                                                                                          \
-        }                                                                                                              \
-        {                                                                                                              \
-            int t_ = 0, s_ = 0;                                                                                        \
-            _Pragma("unroll") for (int dK_ = 2; dK_ < NTR; ++dK_) {                                                    \
-                _Pragma("unroll") for (int dI_ = dK_; dI_ < NTR; ++dI_, ++t_) {                                        \
-                    if (t_ % 3 != (WL) || t_ < MCQ_BAND_WAVE0) continue;                                              \
-                    const double* tt_ = BTILE((P) + dI_, (P) + dK_);                                                   \
-                    _Pragma("unroll") for (int r = 0; r < 4; ++r) bacc_[s_][r] = ABL(16384) ? 0.3 : tt_[(l4 + 4 * r) * TLD + l15];        \
-                    ++s_;                                                                                              \
-                }                                                                                                      \
-            }                                                                                                          \
-        }                                                                                                              \
-        WT(2);                                                                                                         \
-        {                                                                                                              \
-            int t_ = 0;                                                                                                \
-            _Pragma("unroll") for (int a_ = 0; a_ < NCT; ++a_) {                                                       \
-                _Pragma("unroll") for (int bb_ = 0; bb_ <= a_; ++bb_, ++t_) {                                          \
-                    if ((t_ + 1) % 3 != (WL) || ABL(1)) continue;                                                      \
-                    double av_[4];                                                                                     \
-                    _Pragma("unroll") for (int kc = 0; kc < 4; ++kc) av_[kc] = -wv_[a_][kc];                           \
-                    sacc[t_ / 3] = mfma16(av_, wv_[bb_], sacc[t_ / 3]);                                                \
-                }                                                                                                      \
-            }                                                                                                          \
-        }                                                                                                              \
-        {                                                                                                              \
-            int t_ = 0, s_ = 0;                                                                                        \
-            _Pragma("unroll") for (int dK_ = 2; dK_ < NTR; ++dK_) {                                                    \
-                _Pragma("unroll") for (int dI_ = dK_; dI_ < NTR; ++dI_, ++t_) {                                        \
-                    if (t_ % 3 != (WL) || t_ < MCQ_BAND_WAVE0) continue;                                              \
-                    double bv_[4];                                                                                     \
-                    _Pragma("unroll") for (int kc = 0; kc < 4; ++kc) bv_[kc] = -la_[dK_ - 1][kc];                      \
-                    if (!ABL(2048)) bacc_[s_] = mfma16(la_[dI_ - 1], bv_, bacc_[s_]);                                  \
-                    ++s_;                                                                                              \
-                }                                                                                                      \
-            }                                                                                                          \
-        }                                                                                                              \
-        /* ---- in the shadow of the Schur / band products: the commit of the tile row fetched a step and a half ago ---- */    \
-        __builtin_amdgcn_sched_barrier(0);                                                                             \
-        if (CM && !ABL(8)) { COMMIT_ROW((P) + NTR) }                                                                   \
-        __builtin_amdgcn_sched_barrier(0);                                                                             \
-        {                                                                                                              \
-            int t_ = 0, s_ = 0;                                                                                        \
-            _Pragma("unroll") for (int dK_ = 2; dK_ < NTR; ++dK_) {                                                    \
-                _Pragma("unroll") for (int dI_ = dK_; dI_ < NTR; ++dI_, ++t_) {                                        \
-                    if (t_ % 3 != (WL) || t_ < MCQ_BAND_WAVE0) continue;                                              \
-                    double* tt_ = BTILE((P) + dI_, (P) + dK_);                                                         \
-                    _Pragma("unroll") for (int r = 0; r < 4; ++r) if (!ABL(32768)) tt_[(l4 + 4 * r) * TLD + l15] = bacc_[s_][r];        \
-                    ++s_;                                                                                              \
-                }                                                                                                      \
-            }                                                                                                          \
-        }                                                                                                              \
-        WT(3);                                                                                                         \
-    }
-
-    // The first MCQ_BAND_WAVE0 of the six band tiles of step P on wave 0: T(P+dI, P+dK) -= L(P+dI, P) L(P+dK, P)', 2 <= dK <= dI <= 4 -- wave 0 is done
-    // with its chain 2300 cycles before the lag waves are with their products, and fp64 MFMA time (64 cycles a piece, at the vector
-    // fp64 rate on this part) is what their phase is made of.
-#define LAG_BAND_WAVE0(P)                                                                                              \
-    {                                                                                                                  \
-        double lb_[4][4];                                                                                              \
-        v4d ba_[6];                                                                                                    \
-        _Pragma("unroll") for (int dI_ = 2; dI_ < NTR; ++dI_) {                                                        \
-            const double* li_ = LTILE(dI_, (P));                                                                       \
-            _Pragma("unroll") for (int kc = 0; kc < 4; ++kc) lb_[dI_ - 1][kc] = li_[l15 * TLD + l4 + 4 * kc];          \
-        }                                                                                                              \
-        {                                                                                                              \
-            int t_ = 0;                                                                                                \
-            _Pragma("unroll") for (int dK_ = 2; dK_ < NTR; ++dK_) {                                                    \
-                _Pragma("unroll") for (int dI_ = dK_; dI_ < NTR; ++dI_, ++t_) {                                        \
-                    if (t_ >= MCQ_BAND_WAVE0) continue;                                                                \
-                    const double* tt_ = BTILE((P) + dI_, (P) + dK_);                                                   \
-                    _Pragma("unroll") for (int r = 0; r < 4; ++r) ba_[t_][r] = tt_[(l4 + 4 * r) * TLD + l15];          \
-                }                                                                                                      \
-            }                                                                                                          \
-        }                                                                                                              \
-        {                                                                                                              \
-            int t_ = 0;                                                                                                \
-            _Pragma("unroll") for (int dK_ = 2; dK_ < NTR; ++dK_) {                                                    \
-                _Pragma("unroll") for (int dI_ = dK_; dI_ < NTR; ++dI_, ++t_) {                                        \
-                    if (t_ >= MCQ_BAND_WAVE0) continue;                                                                \
-                    double av_[4];                                                                                     \
-                    _Pragma("unroll") for (int kc = 0; kc < 4; ++kc) av_[kc] = -lb_[dI_ - 1][kc];                      \
-                    ba_[t_] = mfma16(av_, lb_[dK_ - 1], ba_[t_]);                                                      \
-                }                                                                                                      \
-            }                                                                                                          \
-        }                                                                                                              \
-        {                                                                                                              \
-            int t_ = 0;                                                                                                \
-            _Pragma("unroll") for (int dK_ = 2; dK_ < NTR; ++dK_) {                                                    \
-                _Pragma("unroll") for (int dI_ = dK_; dI_ < NTR; ++dI_, ++t_) {                                        \
-                    if (t_ >= MCQ_BAND_WAVE0) continue;                                                                \
-                    double* tt_ = BTILE((P) + dI_, (P) + dK_);                                                         \
-                    _Pragma("unroll") for (int r = 0; r < 4; ++r) tt_[(l4 + 4 * r) * TLD + l15] = ba_[t_][r];          \
-                }                                                                                                      \
-            }                                                                                                          \
-        }                                                                                                              \
-    }
-#define LAG_DISPATCH(P, CM)                                                                                            \
-    {                                                                                                                  \
-        if (wl == 0) { LAG_WORK((P), 0, CM) }                                                                          \
-        else if (wl == 1) { LAG_WORK((P), 1, CM) }                                                                     \
-        else { LAG_WORK((P), 2, CM) }                                                                                  \
-    }
-    // Tile row R, fetched at the top of the PREVIOUS step (one and a half steps in flight: the commit never waits on HBM), is
-    // decoded into the window: its band slots -- tile row R - NTR -- were last read by panel(R - NTR), its border slots -- tile
-    // row R - NTRC of the 6-row border window -- by lag(R - NTRC); lag(R - NTR) touches neither, panel(R - NTR + 1) needs tile
-    // (R, R - NTR + 1).
-#define COMMIT_ROW(R)                                                                                                  \
-    {                                                                                                                  \
-        if (PF_FAST((R))) {                                                                                            \
-            if (wl == 0) tile_row_commit_fast<0, MK, SIG>(bt, ct, pf, (R), pc, l15, l4);                               \
-            else if (wl == 1) tile_row_commit_fast<1, MK, SIG>(bt, ct, pf, (R), pc, l15, l4);                          \
-            else tile_row_commit_fast<2, MK, SIG>(bt, ct, pf, (R), pc, l15, l4);                                       \
-        } else {                                                                                                       \
-            _Pragma("unroll") for (int u = 0; u < PF_ITEMS; ++u) {                                                     \
-                const int q = lt + u * PF_THREADS;                                                                     \
-                tile_row_store(bt, ct, (R), q, tile_row_decode<MK, SIG>(pf[u], ni, b, p, (R), q));                     \
-            }                                                                                                          \
-        }                                                                                                              \
-    }
-    // Write-out of block column P of L (tiles below the diagonal one; the sweeps use the inverse tile instead of the
-    // entries inside the diagonal tile), of the inverse diagonal tile and of block row P of W.  Shared by the three lag waves
-    // (64 lanes each): wl = 2 writes the four L tiles, wl = 1 / wl = 0 one half each of the [inverse tile | W] rows.
-    // Index arithmetic is kept off the per-item path (it was 40 % of a worker wave's phase 1): every address is a wave-uniform
-    // base plus a per-lane constant plus a literal.
-    //   L tiles : lane (rg = lane >> 4, cc = lane & 15) takes, of tile tI = 1..4, the rows rg + 4 j (j = 0..3) of column cc:
-    //             element (tI, rr, cc) = L[i, i - k], k = 16 tI + rr - cc, goes to L-row i slot k - 1, i.e. to
-    //             P 16 LLD + (16 tI + 4 j)(LLD + 1) + [rg (LLD + 1) - cc - 1]  -- 16 lanes write 128 contiguous bytes;
-    //   W rows  : lane (rr = lane >> 2, q) takes one 16-byte pair of each of the five tiles of row rr of [inverse | W] (80 doubles: the
-    //             row slot of the border window holds them as 5 adjacent tiles): five 16-byte stores, 128 bytes apart.
-#define WO_L 16
-#define WRITE_OUT_L(P)                                                                                                 \
-    {                                                                                                                  \
-        const int rg_ = lane >> 4, cc_ = lane & 15;                                                                    \
-        const int lo_ = rg_ * TLD + cc_;                                                                               \
-        /* byte offset of (tI = 1, j = 0) relative to the L row block of step P: >= 0, 32 bits */                        \
-        const unsigned go8_ = (unsigned)((rg_ * (MCQ_LLD + 1) - cc_ - 1 + TB * (MCQ_LLD + 1)) * 8);                    \
-        gchar* glb_ = (gchar*)(L + (size_t)(P) * (TB * MCQ_LLD));                                                      \
-        const bool full_ = ((P) + NTR) * TB <= ni;          /* every row of the four tiles is an interior row */        \
-        _Pragma("unroll") for (int h_ = 0; h_ < 2; ++h_) {                                                             \
-            double ev_[WO_L / 2];                                                                                      \
-            _Pragma("unroll") for (int m_ = 0; m_ < WO_L / 2; ++m_) {                                                  \
-                const int mm_ = m_ + h_ * (WO_L / 2);                                                                  \
-                ev_[m_] = LTILE(1 + mm_ / 4, (P))[lo_ + (mm_ % 4) * 4 * TLD];                                          \
-            }                                                                                                          \
-            if (ABL(8192)) {                                                                                           \
-                double sink_ = 0.0;                                                                                    \
-                _Pragma("unroll") for (int m_ = 0; m_ < WO_L / 2; ++m_) sink_ += ev_[m_];                              \
-                if (sink_ == 1.2345e-300) dinv[TB + 1] = sink_;                                                        \
-            } else if (full_) {                                                                                        \
-                _Pragma("unroll") for (int m_ = 0; m_ < WO_L / 2; ++m_) {                                              \
-                    const int mm_ = m_ + h_ * (WO_L / 2);                                                              \
-                    const int tI = 1 + mm_ / 4, rr = rg_ + 4 * (mm_ % 4);                                              \
-                    const unsigned off_ = go8_ + (unsigned)((((tI - 1) * TB + 4 * (mm_ % 4)) * (MCQ_LLD + 1)) * 8);    \
-                    if (tI < NTR - 1 || rr <= cc_) *(gdouble*)(glb_ + off_) = ev_[m_];   /* k <= 64: only the last tile is cut */ \
-                }                                                                                                      \
-            } else {                                                                                                   \
-                _Pragma("unroll") for (int m_ = 0; m_ < WO_L / 2; ++m_) {                                              \
-                    const int mm_ = m_ + h_ * (WO_L / 2);                                                              \
-                    const int tI = 1 + mm_ / 4, rr = rg_ + 4 * (mm_ % 4);                                              \
-                    const unsigned off_ = go8_ + (unsigned)((((tI - 1) * TB + 4 * (mm_ % 4)) * (MCQ_LLD + 1)) * 8);    \
-                    if (((P) + tI) * TB + rr < ni && (tI < NTR - 1 || rr <= cc_)) *(gdouble*)(glb_ + off_) = ev_[m_];  \
-                }                                                                                                      \
-            }                                                                                                          \
-        }                                                                                                              \
-    }
-#define WRITE_OUT_W(P, HALF)                                                                                           \
-    {                                                                                                                  \
-        /* lane (rr = lane >> 2, q = 4 HALF + (lane & 3)) takes the entry pair (2q, 2q + 1) of each of the five tiles of row rr of   \
-           [inverse | W]: one per-lane LDS base and one per-lane global base, the tile index is a literal in both (16 entries = 128    \
-           bytes apart in the L row); four lanes write 64 contiguous bytes */                                              \
-        const int rr_ = lane >> 2, q2_ = 2 * (4 * (HALF) + (lane & 3));                                                \
-        const double* row_ = CROW((P)) + rr_ * TLD + q2_;                                                              \
-        double fv_[2 * NCT5];                                                                                          \
-        _Pragma("unroll") for (int t_ = 0; t_ < NCT5; ++t_) {                                                          \
-            fv_[2 * t_] = row_[t_ * TSZ];                                                                              \
-            fv_[2 * t_ + 1] = row_[t_ * TSZ + 1];                                                                      \
-        }                                                                                                              \
-        const int i = (P) * TB + rr_;                                                                                  \
-        if (i < ni && !ABL(8192)) {                                                                                    \
-            gd2* dst_ = (gd2*)(L + (size_t)i * MCQ_LLD + MCQ_LBI + q2_);                                               \
-            _Pragma("unroll") for (int t_ = 0; t_ < NCT5; ++t_) dst_[t_ * (TB / 2)] = (d2){fv_[2 * t_], fv_[2 * t_ + 1]}; \
-        }                                                                                                              \
-    }
-
-    for (int J = 0; J < nblk; ++J) {
-        long long tp = FTICK();
-        // ---- phase 1 --------------------------------------------------------------------------------------------------------
-        SKEW(1, w0 == 0);
-        SKEW(2, w0 > 0);
-        if (w0 == 0) {
-            if (MCQ_WORKER_TIMERS) wt_last = (long long)clock64();
-            // fused forward substitution: the right-hand side of block row J+1 goes in flight before the diagonal tile's chain
-            // (issued inside the fused step it was waited for on the spot: its register is copied to an AGPR there)
-            double ff_next = 0.0;
-            if (fv) { const int ip = (J + 1) * TB + lane; if (lane < TB && ip < ni) ff_next = fv[ip]; }
-            const bool bad = ABL(32) ? false : diag_tile_inv(BTILE(J, J), INVT(J), l15);
-            if (bad && lane == 0) dinv[TB] = 1.0;
-            WT(0);
-            SKEW(3, true);
-            if (fv) {
-                fused_fwd_step(J, fv, ni, bt, ct, yring, pend, svx, lane, l15, l4, ff_tacc, ff_rhs, ff_next);
-                WT(1);
-            }
-            if (MCQ_BAND_WAVE0 && J > 0 && !ABL(128)) { LAG_BAND_WAVE0(J - 1) }
-            WT(2);
-        } else {
-            // Tile row J+NTR goes in flight first; then the lag work of step J-1, with this wave's share of the write-out of step
-            // J-1 and the commit of tile row J-1+NTR (COMMIT_ROW) issued in the shadow of its matrix-core products.
-            RawEntry pfn[PF_ITEMS];
-            if (MCQ_WORKER_TIMERS) wt_last = (long long)clock64();
-            {
-                const int R = J + NTR;
-                if (ABL(16)) {
-                    const RawEntry zero_entry = {0.0, 0.0, 0, 0};
-#pragma unroll
-                    for (int u = 0; u < PF_ITEMS; ++u) pfn[u] = zero_entry;
-                } else if (PF_FAST(R)) {
-                    // Rows further than the band width from both ends of the interior have no border entries at all (the border
-                    // couples to the first and the last 64 rows only): half of every H row is zeros that need not be streamed --
-                    // 1 MB of the 2.1 MB a factorisation of an N = 2000 problem used to read.
-                    const bool bz = R * TB >= MCQ_BH_MAX && (R + 1) * TB <= ni - MCQ_BH_MAX;
-                    if (bz) {
-                        if (wl == 0) tile_row_fetch_fast<0, MK, SIG, true>(H, sig, mk, R, ni, pc, l15, l4, pfn);
-                        else if (wl == 1) tile_row_fetch_fast<1, MK, SIG, true>(H, sig, mk, R, ni, pc, l15, l4, pfn);
-                        else tile_row_fetch_fast<2, MK, SIG, true>(H, sig, mk, R, ni, pc, l15, l4, pfn);
-                    } else {
-                        if (wl == 0) tile_row_fetch_fast<0, MK, SIG, false>(H, sig, mk, R, ni, pc, l15, l4, pfn);
-                        else if (wl == 1) tile_row_fetch_fast<1, MK, SIG, false>(H, sig, mk, R, ni, pc, l15, l4, pfn);
-                        else tile_row_fetch_fast<2, MK, SIG, false>(H, sig, mk, R, ni, pc, l15, l4, pfn);
-                    }
-                } else {
-#pragma unroll
-                    for (int u = 0; u < PF_ITEMS; ++u) pfn[u] = tile_row_fetch<MK, SIG>(H, sig, mk, ni, b, p, R, lt + u * PF_THREADS);
-                }
-            }
-            WT(0);
-            if (J > 0 && !ABL(512)) { LAG_DISPATCH(J - 1, 1) }
-            WT(4);
-#pragma unroll
-            for (int u = 0; u < PF_ITEMS; ++u) pf[u] = pfn[u];
-            WT(5);
-        }
-        lds_barrier();
-        WT(6);
-        c.tk[4] += FTICK() - tp; tp = FTICK();
-        // (a non-positive pivot raises dinv[TB]; it is looked at ONCE, behind the loop: reading the flag here, right behind the barrier
-        //  and in front of every wave's phase 2, cost 270 cycles per step -- the steps after a failed pivot compute NaNs, nothing else)
-#if MCQ_PD_CHECK_PER_STEP
-        if (!ABL(1024) && dinv[TB] != 0.0) { fail = 1; break; }
-#endif
-        SKEW(4, w0 == 0);
-        SKEW(5, w0 > 0);
-        // ---- phase 2: panel + block column J+1, all on the matrix cores, one tile row per wave ---------------------------------
-        //   X1' = M T(J+1,J)'  (every wave: the column-form operand of the update),   Xw' = M T(J+1+w,J)'  (L(J+1+w, J) = Xw),
-        //   W_w = M C(J, w),   T(J+1+w, J+1) -= Xw X1'.
-        // The transposed products leave X in exactly the per-lane layout the update's operands need: no LDS round trip.
-        if (!ABL(256)) {
-            const double* lv = INVT(J);
-            const double* t1 = BTILE(J + 1, J);
-            const double* tw = BTILE(J + 1 + w0, J);
-            double* cw = CTILE(J, w0);
-            double* tu = BTILE(J + 1 + w0, J + 1);
-            double mv[4], b1[4], bw[4], bc[4];
-            v4d accu;
-#pragma unroll
-            for (int kc = 0; kc < 4; ++kc) {
-                mv[kc] = lv[l15 * TLD + l4 + 4 * kc];
-                b1[kc] = t1[l15 * TLD + l4 + 4 * kc];
-                bw[kc] = tw[l15 * TLD + l4 + 4 * kc];
-                bc[kc] = cw[(l4 + 4 * kc) * TLD + l15];
-            }
-#pragma unroll
-            for (int r = 0; r < 4; ++r) accu[r] = tu[(l4 + 4 * r) * TLD + l15];
-            const v4d z4 = {0.0, 0.0, 0.0, 0.0};
-            const v4d x1 = mfma16(mv, b1, z4);
-            const v4d xw = mfma16(mv, bw, z4);
-            const v4d ww = mfma16(mv, bc, z4);
-            double av[4], bv[4];
-#pragma unroll
-            for (int kc = 0; kc < 4; ++kc) { av[kc] = -xw[kc]; bv[kc] = x1[kc]; }
-            accu = mfma16(av, bv, accu);
-            double* lo = (w0 == 0) ? BTILE(J + 1, J + 2) : BTILE(J + 1 + w0, J);      // LTILE(1 + w0, J)
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                lo[l15 * TLD + l4 + 4 * r] = xw[r];
-                cw[(l4 + 4 * r) * TLD + l15] = ww[r];
-                tu[(l4 + 4 * r) * TLD + l15] = accu[r];
-            }
-        }
-        lds_barrier();
-        WT(7);
-        c.tk[5] += FTICK() - tp;
-    }
-    if (MCQ_WORKER_TIMERS && tid == 64 * (MCQ_WORKER_TIMERS & 3)) {     // the value of the switch picks the wave: 1..3 workers, 4: wave 0
-        long long* acc = (long long*)c.w.Z;       // diagnostic build only: the curvature-row scratch doubles as the accumulator
-        for (int q = 0; q < 8; ++q) acc[q] += wt[q];
-    }
-    if (!MCQ_PD_CHECK_PER_STEP && !ABL(1024) && dinv[TB] != 0.0) fail = 1;     // dinv[TB]: written before the loop's last barrier
-    if (fail) return MCQ_NOT_PD;
-    const long long t_tail = FTICK();
-    // drain: what the last step still owes
-    if (nblk > 0) {
-        if (w0 > 0) { LAG_DISPATCH(nblk - 1, 0) }
-        else if (MCQ_BAND_WAVE0) { LAG_BAND_WAVE0(nblk - 1) }
-        if (w0 == 0 && fv) {
-            // border sums of the last block row, then (W'y) to where solve() expects the loader waves' partial sums
-            const int P = nblk - 1;
-            const double* wt_ = CTILE(P, l4) + l15;
-            const double* yp = yring + ((P * TB) & (VRING - 1));
-            double a0 = 0.0;
-#pragma unroll
-            for (int rr = 0; rr < TB; ++rr) a0 += wt_[rr * TLD] * yp[rr];
-            ff_tacc += a0;
-            double* part = g_sm + SM_PART;
-            part[1 * 64 + lane] = ff_tacc;
-            part[2 * 64 + lane] = 0.0;
-            part[3 * 64 + lane] = 0.0;
-        }
-    }
-#undef LAG_WORK
-#undef PF_FAST
-#undef LAG_DISPATCH
-#undef LAG_BAND_WAVE0
-#undef COMMIT_ROW
-#undef WRITE_OUT_L
-#undef WRITE_OUT_W
-    lds_barrier();
-
-    // ---- Schur complement of the border: S = D - W'W (accumulated above) as 4 x 4 LDS tiles; wave 0 factors it with the same
-    //      tile kernels as the band (diagonal tile + inverse in registers, panel / trailing update / block inverse as MFMA
-    //      products) -- no block barriers, ~15 us instead of 64 barrier-separated column steps + a serial substitution ------
-#define STILE(I, K) (bt + ((I) * NCT + (K)) * TSZ)              /* S, then L_S (lower tiles, row-major) */
-#define MTILE(I) (bt + (NCT * NCT + (I)) * TSZ)                 /* inverses of the diagonal tiles of L_S */
-#define ITILE(I, K) (ct + ((I) * NCT + (K)) * TSZ)              /* off-diagonal tiles of L_S^-1 */
-    __syncthreads();
-    {
-        int t = 0;
-#pragma unroll
-        for (int a = 0; a < NCT; ++a) {
-#pragma unroll
-            for (int bb = 0; bb <= a; ++bb, ++t) {
-                // tile t lives in lag wave (t + 1) % 3, register slot t / 3
-                if (w0 == 0 || (t + 1) % 3 != wl) continue;
-                const int slot = t / 3;
-#pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    const int j1 = TB * a + l4 + 4 * r, j2 = TB * bb + l15;
-                    double v = (j1 == j2) ? 1.0 : 0.0;          // identity padding beyond p, identity rows of pinned variables
-                    if (j1 < p && j2 < p) {
-                        const bool pj = MK && (mk[ni + j1] != 0 || mk[ni + j2] != 0);
-                        if (!pj) {
-                            v = H[(size_t)(ni + j1) * MCQ_HLD + MCQ_HBO + j2] + sacc[slot][r];
-                            if (SIG && j1 == j2) v += sig[ni + j1];
-                        }
-                    }
-                    STILE(a, bb)[(l4 + 4 * r) * TLD + l15] = v;
-                }
-            }
-        }
-    }
-    __syncthreads();
-    if (w0 == 0) {
-        bool bad = false;
-        const v4d z4 = {0.0, 0.0, 0.0, 0.0};
-#pragma unroll 1
-        for (int a = 0; a < NCT; ++a) {
-            bad |= diag_tile_inv(STILE(a, a), MTILE(a), l15);
-            __builtin_amdgcn_wave_barrier();
-            double mv[4];
-#pragma unroll
-            for (int kc = 0; kc < 4; ++kc) mv[kc] = MTILE(a)[l15 * TLD + l4 + 4 * kc];
-            // panel: L_S(i, a) = S(i, a) M_a'  (computed transposed: the result lands in row-major operand layout)
-#pragma unroll 1
-            for (int i = a + 1; i < NCT; ++i) {
-                double* ti = STILE(i, a);
-                double bi[4];
-#pragma unroll
-                for (int kc = 0; kc < 4; ++kc) bi[kc] = ti[l15 * TLD + l4 + 4 * kc];
-                const v4d x = mfma16(mv, bi, z4);
-                __builtin_amdgcn_wave_barrier();
-#pragma unroll
-                for (int r = 0; r < 4; ++r) ti[l15 * TLD + l4 + 4 * r] = x[r];
-            }
-            __builtin_amdgcn_wave_barrier();
-            // trailing update: S(i, k) -= L_S(i, a) L_S(k, a)',  a < k <= i
-#pragma unroll 1
-            for (int i = a + 1; i < NCT; ++i) {
-                double av[4];
-#pragma unroll
-                for (int kc = 0; kc < 4; ++kc) av[kc] = -STILE(i, a)[l15 * TLD + l4 + 4 * kc];
-#pragma unroll 1
-                for (int k = a + 1; k <= i; ++k) {
-                    double bv[4];
-                    v4d acc;
-                    double* tk = STILE(i, k);
-#pragma unroll
-                    for (int kc = 0; kc < 4; ++kc) bv[kc] = STILE(k, a)[l15 * TLD + l4 + 4 * kc];
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) acc[r] = tk[(l4 + 4 * r) * TLD + l15];
-                    acc = mfma16(av, bv, acc);
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) tk[(l4 + 4 * r) * TLD + l15] = acc[r];
-                }
-            }
-            __builtin_amdgcn_wave_barrier();
-        }
-        // block inverse of L_S:  Inv(j, j) = M_j,   Inv(i, j) = -M_i sum_{k=j}^{i-1} L_S(i, k) Inv(k, j)   (i > j)
-#pragma unroll 1
-        for (int j = 0; j < NCT - 1; ++j) {
-#pragma unroll 1
-            for (int i = j + 1; i < NCT; ++i) {
-                v4d acc = z4;
-#pragma unroll 1
-                for (int k = j; k < i; ++k) {
-                    const double* lik = STILE(i, k);
-                    const double* ikj = (k == j) ? MTILE(j) : ITILE(k, j);
-                    double av[4], bv[4];
-#pragma unroll
-                    for (int kc = 0; kc < 4; ++kc) {
-                        av[kc] = lik[l15 * TLD + l4 + 4 * kc];
-                        bv[kc] = ikj[(l4 + 4 * kc) * TLD + l15];
-                    }
-                    acc = mfma16(av, bv, acc);
-                }
-                double mi[4], sb[4];
-#pragma unroll
-                for (int kc = 0; kc < 4; ++kc) {
-                    mi[kc] = -MTILE(i)[l15 * TLD + l4 + 4 * kc];
-                    sb[kc] = acc[kc];                         // accumulator layout == column-operand layout
-                }
-                const v4d res = mfma16(mi, sb, z4);
-                double* o = ITILE(i, j);
-#pragma unroll
-                for (int r = 0; r < 4; ++r) o[(l4 + 4 * r) * TLD + l15] = res[r];
-                __builtin_amdgcn_wave_barrier();
-            }
-        }
-        if (bad && lane == 0) dinv[TB] = 1.0;
-    }
-    __syncthreads();
-    if (!ABL(1024) && dinv[TB] != 0.0) return MCQ_NOT_PD;
-    // L_S^-1 packed (lower triangle by rows) into SM_S, outside the overlay, for the triangular solves that follow: the
-    // border solves of every sweep are two LDS mat-vecs.
-    {
-        double* spk = g_sm + SM_S;
-        for (int q = tid; q < MCQ_P_MAX * MCQ_P_MAX; q += MCQ_NT) {
-            const int r = q / MCQ_P_MAX, cc = q - r * MCQ_P_MAX;
-            if (cc <= r) {
-                const int tr = r / TB, tc = cc / TB;
-                const double* src = (tr == tc) ? MTILE(tr) : ITILE(tr, tc);
-                spk[r * (r + 1) / 2 + cc] = src[(r % TB) * TLD + (cc % TB)];
-            }
-        }
-        __syncthreads();
-    }
-#undef STILE
-#undef MTILE
-#undef ITILE
-    c.tk[6] += FTICK() - t_tail;    // drain + border factor + its inverse
-    return 0;
-}
-
-#else
-#include "mcq_kkt.inc"
-#include "mcq_tri.inc"
-#endif
-
-__device__ __noinline__ int factor(const SolveCtx& c, const gdouble* Hsrc, const gdouble* sig, const gschar* mk, gdouble* fv)
-{
-#if defined(MCQ_CORE_BAND)
-    // the configurations the solver uses: interior point (diagonal added; variables with lo == hi masked -- usually there are
-    // none, then no mask bytes are fetched at all) and active set (mask only); fv: see factor_t
-    if (sig) return mk ? factor_t<true, true>(c, Hsrc, sig, mk, fv) : factor_t<false, true>(c, Hsrc, sig, mk, fv);
-    return factor_t<true, false>(c, Hsrc, sig, mk, fv);
-#else
-    (void)Hsrc;
-    return factor_kkt(c, sig, mk, c.kkt_w, MCQ_FUSE_FWD ? fv : nullptr);
-#endif
-}
-
-#if defined(MCQ_CORE_BAND)
-// ---- solve  M v = rhs  in place (v in global memory) with the factor produced by factor() ---------------------------
-// Interior triangular sweeps, one 16-row tile per step on wave 0, no serial per-row chain:
-//   s    = rhs_tile - sum over the 4 previous (next) tiles of L-tile x unknowns      64 lanes = 16 rows x 4 tiles, 16 FMAs
-//          each, two cross-lane adds;
-//   tile = Linv_tile s   (Linv_tile' s backward)                                       16 independent FMAs per lane, operands
-//          broadcast with v_readlane.
-// L rows (64 band entries + the 16 entries of the inverse diagonal tile) and right-hand sides come from an LDS chunk ring
-// (64 rows per chunk) that waves 1..3 keep filled ahead through registers; the same waves fold the border block in:
-// forward they accumulate W'y for t = v_D - W'y, backward they produce the right-hand side y_B - W x_D.
-// Band mask of the sweeps: an entry beyond the band keeps its low dword and loses its high one -- a denormal (< 2.3e-308)
-// stands in for the zero, one v_cndmask_b32 per entry instead of two on wave 0's serial chain.
-#define BAND_MASK(cond, val) __hiloint2double((cond) ? __double2hiint(val) : 0, __double2loint(val))
-#define LD_THREADS (MCQ_NT - 64)
-#define LD_PAIRS (CH * CLD / 2)                                 /* 16-byte items of a chunk's L rows */
-#define LD_ITEMS ((LD_PAIRS + LD_THREADS - 1) / LD_THREADS)
-
-// Loader item u of thread lt: the 16-byte pair e2 = lt + u * LD_THREADS of the chunk image (row e2 / 40, doubles
-// 2 (e2 % 40) ..+1 of the 80-double LDS row); the chunk image in LDS is the linear array of these pairs.  `goff[u]` (row *
-// MCQ_LLD + column, precomputed once per solve) makes the steady-state fetch one add + one global_load_dwordx4 per item.
-// Generic path (first chunk, last chunk, narrow bands): band entries that do not exist (column < 0, beyond the band,
-// rows >= ni) are zeroed.
-__device__ __forceinline__ void chunk_fetch(const gdouble* L, const gdouble* v, int ni, int b, int qL, int qR, int lt,
-                                            const int* goff, d2* regs, double& rreg)
-{
-    const bool fast = (qL >= 1) & ((qL + 1) * CH <= ni) & (b == MCQ_BH_MAX);
-    if (fast) {
-        const gdouble* base = L + (size_t)qL * CH * MCQ_LLD;
-#pragma unroll
-        for (int u = 0; u < LD_ITEMS; ++u) {
-            const int e2 = lt + u * LD_THREADS;
-            regs[u] = (e2 < LD_PAIRS) ? *(const gd2*)(base + goff[u]) : (d2){0.0, 0.0};
-        }
-    } else {
-#pragma unroll
-        for (int u = 0; u < LD_ITEMS; ++u) {
-            const int e2 = lt + u * LD_THREADS;
-            d2 x = {0.0, 0.0};
-            if (e2 < LD_PAIRS && qL >= 0) {
-                const int r = qL * CH + e2 / (CLD / 2), m = 2 * (e2 % (CLD / 2));
-                if (r < ni) {
-                    x = *(const gd2*)(L + (size_t)r * MCQ_LLD + m);
-                    if (m < MCQ_BH_MAX) {
-                        if (!((m < b) & (m < r))) x[0] = 0.0;
-                        if (!((m + 1 < b) & (m + 1 < r))) x[1] = 0.0;
-                    }
-                }
-            }
-            regs[u] = x;
-        }
-    }
-    rreg = 0.0;
-    if (lt < CH && qR >= 0) {
-        const int r = qR * CH + lt;
-        if (r < ni) rreg = v[r];
-    }
-}
-
-__device__ __forceinline__ void chunk_commit(double* chunk, double* rring, int qL, int qR, int lt, const d2* regs, double rreg)
-{
-    if (qL >= 0) {
-        d2* dst = (d2*)(chunk + (qL % NBUF) * CH * CLD);
-#pragma unroll
-        for (int u = 0; u < LD_ITEMS; ++u) {
-            const int e2 = lt + u * LD_THREADS;
-            if (e2 < LD_PAIRS) dst[e2] = regs[u];
-        }
-    }
-    if (lt < CH && qR >= 0) rring[(qR % NRB) * CH + lt] = rreg;
-}
-
-#define LROW(r) (chunk + (((r) / CH) % NBUF) * CH * CLD + ((r) % CH) * CLD)
-#define RHSV(r) (rring[(((r) / CH) % NRB) * CH + ((r) % CH)])
-#define NLW (MCQ_NW - 1)                        /* loader waves */
-#define WGRP ((CH / 8 + NLW - 1) / NLW)         /* 8-row groups of a chunk handled by one loader wave */
-
-// The interior sweeps of solve() as seen by wave 0, each in a function of its own: compiled separately from the loader
-// waves' code they are free of its register state (16-byte staging registers of a whole chunk, W rows, accumulators -- 150
-// VGPRs that otherwise sit live across the tile chain and make the allocator serialise the LDS reads of a tile through two
-// address / data registers).  One LDS barrier per chunk, matched by the loaders' loop in solve().
-__device__ __noinline__ void sweep_fwd_wave0(const SolveCtx& c, gdouble* v)
-{
-    const int lane = threadIdx.x & 63;
-    const int l15 = lane & 15, l4 = lane >> 4;
-    const int ni = c.d.ni;
-    double* chunk = g_sm + SM_CHUNK;
-    double* rring = g_sm + SM_RHS;
-    double* vring = g_sm + SM_VR;
-    const int nch = (ni + CH - 1) / CH;
-    // lane (row l15, group l4) of tile J covers source tile K = J - 4 + l4: columns 16K + cc, band offset k = i - column.
-    // Entries beyond the band (k > 64, group 0 only) are read from the row's inverse-tile slots and masked; first-chunk
-    // columns < 0 hit masked zeros.  All LDS offsets are compile-time constants off two bases.
-    const int kb = TB * (4 - l4) + l15;          // k for cc = 0
-    // The 32 LDS reads of a tile that do not depend on the tile before it -- its band entries and its row of the inverse
-    // tile -- are issued one tile ahead into a second register set (FW_LOAD of tile J + 1 before the chain of tile J: the
-    // next chunk is resident one step ahead), so that a step's chain starts at the reads of the unknowns just produced.
-    // base at the LOWEST address of the 16 entries: ds_read offsets are unsigned immediates, so only then do all 16 reads
-    // hang off one address register and issue back to back:  lk[TB - 1 - cc] = L[i, i - (kb - cc)]
-#define FW_LOAD(J_, LB_, MB_)                                                                                  \
-    {                                                                                                          \
-        const double* lr_ = LROW((J_) * TB + l15);                                                             \
-        const double* lk_ = lr_ + kb - TB;                                                                     \
-        _Pragma("unroll") for (int cc = 0; cc < TB; ++cc) LB_[cc] = lk_[TB - 1 - cc];                          \
-        _Pragma("unroll") for (int k = 0; k < 4; ++k) MB_[k] = lr_[MCQ_BH_MAX + 4 * l4 + k];                   \
-    }
-#define FW_STEP(J_, LB_, MB_)                                                                                  \
-    {                                                                                                          \
-        const int i = (J_) * TB + l15;                                                                         \
-        const double* vs = vring + ((((J_) - 4 + l4) * TB) & (VRING - 1));   /* 16 consecutive ring slots */    \
-        double a0 = 0.0, a1 = 0.0;                                                                             \
-        _Pragma("unroll") for (int cc = 0; cc < TB; cc += 2) {                                                 \
-            a0 += BAND_MASK(kb - cc <= MCQ_BH_MAX, LB_[cc]) * vs[cc];                                       \
-            a1 += BAND_MASK(kb - cc - 1 <= MCQ_BH_MAX, LB_[cc + 1]) * vs[cc + 1];                           \
-        }                                                                                                      \
-        const double sv = RHSV(i) - row4_sum_low16(a0 + a1);   /* valid in lanes 0..15 */                       \
-        /* y = M_J sv, all 64 lanes: group l4 takes columns 4 l4 .. 4 l4 + 3 of row l15 (sv through a 16-double LDS slot,   \
-           read back as one group-uniform 32-byte piece), a second four-way sum -- 21 instructions where 32 v_readlane     \
-           broadcasts and 16 FMAs on a quarter of the lanes were: the sweeps are bound by wave 0's instruction issue */     \
-        __builtin_amdgcn_wave_barrier();                                                                       \
-        if (lane < TB) svx[lane] = sv;                                                                         \
-        __builtin_amdgcn_wave_barrier();                                                                       \
-        const double y = row4_sum_low16((MB_[0] * svx[4 * l4] + MB_[1] * svx[4 * l4 + 1])                      \
-                                        + (MB_[2] * svx[4 * l4 + 2] + MB_[3] * svx[4 * l4 + 3]));              \
-        __builtin_amdgcn_wave_barrier();                                                                       \
-        if (l4 == 0) {                                                                                         \
-            vring[i & (VRING - 1)] = y;                                                                        \
-            RHSV(i) = y;                                                                                       \
-            if (i < ni) v[i] = y;                                                                              \
-        }                                                                                                      \
-        __builtin_amdgcn_wave_barrier();                                                                       \
-    }
-    double la[TB], ma[4], lb[TB], mb[4];
-    double* svx = g_sm + SM_RED;                 // 16 doubles: the tile's right-hand side on its way to all four lane groups
-    static_assert(CH / TB == 4, "the sweeps are unrolled over the four tiles of a chunk");
-    FW_LOAD(0, la, ma)
-    for (int cq = 0; cq < nch; ++cq) {
-        const int J0 = cq * (CH / TB);
-        FW_LOAD(J0 + 1, lb, mb)
-        FW_STEP(J0, la, ma)
-        FW_LOAD(J0 + 2, la, ma)
-        FW_STEP(J0 + 1, lb, mb)
-        FW_LOAD(J0 + 3, lb, mb)
-        FW_STEP(J0 + 2, la, ma)
-        FW_LOAD(J0 + 4, la, ma)          // first tile of the next chunk (resident; past the end: unused ring contents)
-        FW_STEP(J0 + 3, lb, mb)
-        lds_barrier();
-    }
-#undef FW_LOAD
-#undef FW_STEP
-}
-
-__device__ __noinline__ void sweep_bwd_wave0(const SolveCtx& c, gdouble* v)
-{
-    const int lane = threadIdx.x & 63;
-    const int l15 = lane & 15, l4 = lane >> 4;
-    const int ni = c.d.ni;
-    double* chunk = g_sm + SM_CHUNK;
-    double* rring = g_sm + SM_RHS;
-    double* vring = g_sm + SM_VR;
-    const int nch = (ni + CH - 1) / CH;
-    // lane (column l15, group l4) of tile J covers the rows of tile K = J + 1 + l4: i = 16K + rr, offset k = i - j.
-    // A tile never straddles a chunk: its 16 rows are 16 consecutive LDS rows, so every offset below is a compile-time
-    // constant off one base (entries with k > 64 land in inverse-tile slots and are masked).
-    const int kb = TB * (l4 + 1) - l15;       // k for rr = 0
-    // As forward, the reads that do not depend on the tile solved just before are issued one tile ahead: the band entries
-    // (rows of tiles already solved: resident) always, the tile's own inverse only inside a chunk -- the chunk below is still
-    // being committed by the loader waves until the barrier.
-#define BW_LOADL(J_, LB_)                                                                                      \
-    {                                                                                                          \
-        const double* lk_ = LROW(((J_) + 1 + l4) * TB) + kb - 1;     /* lk[rr (CLD + 1)] = L[i0 + rr, j] */      \
-        _Pragma("unroll") for (int rr = 0; rr < TB; ++rr) LB_[rr] = lk_[rr * (CLD + 1)];                       \
-    }
-#define BW_LOADM(J_, MB_)                                                                                      \
-    {                                                                                                          \
-        const double* mi_ = LROW((J_) * TB) + MCQ_BH_MAX + l15;      /* column l15 of the inverse tile */        \
-        _Pragma("unroll") for (int k = 0; k < 4; ++k) MB_[k] = mi_[(4 * l4 + k) * CLD];                        \
-    }
-#define BW_STEP(J_, LB_, MB_)                                                                                  \
-    {                                                                                                          \
-        const int j = (J_) * TB + l15;               /* unknown handled by this lane's row group */             \
-        const double* vs = vring + ((((J_) + 1 + l4) * TB) & (VRING - 1));                                     \
-        double a0 = 0.0, a1 = 0.0;                                                                             \
-        _Pragma("unroll") for (int rr = 0; rr < TB; rr += 2) {                                                 \
-            a0 += BAND_MASK(kb + rr <= MCQ_BH_MAX, LB_[rr]) * vs[rr];                                       \
-            a1 += BAND_MASK(kb + rr + 1 <= MCQ_BH_MAX, LB_[rr + 1]) * vs[rr + 1];                           \
-        }                                                                                                      \
-        const double sv = RHSV(j) - row4_sum_low16(a0 + a1);   /* valid in lanes 0..15 */                       \
-        /* x = M_J' sv over all 64 lanes: group l4 takes rows 4 l4 .. 4 l4 + 3 of column l15 (see the forward sweep) */    \
-        __builtin_amdgcn_wave_barrier();                                                                       \
-        if (lane < TB) svx[lane] = sv;                                                                         \
-        __builtin_amdgcn_wave_barrier();                                                                       \
-        const double x = row4_sum_low16((MB_[0] * svx[4 * l4] + MB_[1] * svx[4 * l4 + 1])                      \
-                                        + (MB_[2] * svx[4 * l4 + 2] + MB_[3] * svx[4 * l4 + 3]));              \
-        __builtin_amdgcn_wave_barrier();                                                                       \
-        if (l4 == 0) {                                                                                         \
-            vring[j & (VRING - 1)] = x;                                                                        \
-            if (j < ni) v[j] = x;                                                                              \
-        }                                                                                                      \
-        __builtin_amdgcn_wave_barrier();                                                                       \
-    }
-    double la[TB], ma[4], lb[TB], mb[4];
-    double* svx = g_sm + SM_RED;
-    if (nch > 0) {
-        const int Jt = nch * (CH / TB) - 1;
-        BW_LOADL(Jt, la)
-        BW_LOADM(Jt, ma)
-    }
-    for (int cq = nch - 1; cq >= 0; --cq) {
-        const int J3 = cq * (CH / TB) + 3;
-        BW_LOADL(J3 - 1, lb)
-        BW_LOADM(J3 - 1, mb)
-        BW_STEP(J3, la, ma)
-        BW_LOADL(J3 - 2, la)
-        BW_LOADM(J3 - 2, ma)
-        BW_STEP(J3 - 1, lb, mb)
-        BW_LOADL(J3 - 3, lb)
-        BW_LOADM(J3 - 3, mb)
-        BW_STEP(J3 - 2, la, ma)
-        if (cq > 0) BW_LOADL(J3 - 4, la)
-        BW_STEP(J3 - 3, lb, mb)
-        lds_barrier();
-        if (cq > 0) BW_LOADM(J3 - 4, ma)
-    }
-#undef BW_LOADL
-#undef BW_LOADM
-#undef BW_STEP
-}
-
-// fwd_done: the interior forward substitution and the border sums W'y were produced by factor(..., fv = v) (v holds y_B, the sums
-// sit where the loader waves leave theirs): start at the border system.
-#endif   // MCQ_CORE_BAND
 __device__ __noinline__ void solve(const SolveCtx& c, gdouble* v, bool fwd_done)
 {
-#if !defined(MCQ_CORE_BAND)
+    if (c.direct) { (void)sp_solve(c, v, v); return; }
     solve_kkt(c, v, fwd_done);
-#else
-    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
-    const int l15 = lane & 15, l4 = lane >> 4;
-    const int b = c.d.b, p = c.d.p, ni = c.d.ni;
-    const gdouble* L = c.w.L;
-    const double* spk = g_sm + SM_S;      // L_S^-1 packed lower triangle
-    double* xd = g_sm + SM_XD;
-    double* part = g_sm + SM_PART;
-    double* chunk = g_sm + SM_CHUNK;
-    double* rring = g_sm + SM_RHS;
-    double* vring = g_sm + SM_VR;
-    const int nch = (ni + CH - 1) / CH;
-    const int lt = tid - 64;      // loader thread id (waves 1..3)
-    d2 regs[LD_ITEMS];
-    double rreg = 0.0;
-    int goff[LD_ITEMS];
-#pragma unroll
-    for (int u = 0; u < LD_ITEMS; ++u) {
-        const int e2 = (lt >= 0 ? lt : 0) + u * LD_THREADS;
-        goff[u] = (e2 / (CLD / 2)) * MCQ_LLD + 2 * (e2 % (CLD / 2));
-    }
-    // Border block W (64 doubles per row): a loader wave reads EIGHT rows per 16-byte load instruction -- lane (g8, c8) =
-    // (lane >> 3, lane & 7) takes the pair (16 u + 2 c8, +1) of row 8 grp + g8 in load u = 0..3 (128 contiguous bytes per row
-    // and instruction), row groups grp = (wv - 1) + NLW m.  A row's dot product with x_D then reduces over 8 lanes only.
-    const int g8 = lane >> 3, c8 = lane & 7;
-    d2 wreg[WGRP][4];
-#define WGOK(m) ((wv - 1) + NLW * (m) < CH / 8)
-#define WROW(q, m) ((q) * CH + 8 * ((wv - 1) + NLW * (m)) + g8)
-#define WOK(q, m) (WGOK(m) && (q) >= 0 && WROW(q, m) < ni)
-#define WFETCH(q)                                                                                              \
-    _Pragma("unroll") for (int m = 0; m < WGRP; ++m) {                                                         \
-        const int rs_ = WOK(q, m) ? WROW(q, m) : 0;                                                            \
-        const gdouble* wr_ = L + (size_t)rs_ * MCQ_LLD + MCQ_LBW + 2 * c8;                                     \
-        _Pragma("unroll") for (int u = 0; u < 4; ++u) wreg[m][u] = *(const gd2*)(wr_ + 16 * u);                \
-    }
-#define TACC_ADD(q)                                                                                            \
-    _Pragma("unroll") for (int m = 0; m < WGRP; ++m) {                                                         \
-        const bool ok_ = WOK(q, m);                                                                            \
-        const double yr_ = ok_ ? RHSV(ok_ ? WROW(q, m) : 0) : 0.0;                                             \
-        _Pragma("unroll") for (int u = 0; u < 4; ++u) tacc[u] += wreg[m][u] * yr_;                             \
-    }
-
-    __syncthreads();
-    if (!fwd_done) {
-    for (int q = tid; q < VRING; q += MCQ_NT) vring[q] = 0.0;
-    // ================= forward substitution, interior rows =================
-    // a tile needs only its own rows: chunk cq resident, cq+1 committed one step ahead, cq+2 committed during step cq.
-    d2 tacc[4];
-#pragma unroll
-    for (int u = 0; u < 4; ++u) tacc[u] = (d2){0.0, 0.0};
-    if (wv > 0) {
-        for (int q = 0; q <= 1; ++q) {
-            chunk_fetch(L, v, ni, b, q, q, lt, goff, regs, rreg);
-            chunk_commit(chunk, rring, q, q, lt, regs, rreg);
-        }
-        chunk_fetch(L, v, ni, b, 2, 2, lt, goff, regs, rreg);
-    }
-    __syncthreads();
-    if (wv == 0) { const long long ts_ = STICK(); sweep_fwd_wave0(c, v); c.tk[4] += STICK() - ts_; }
-    else {
-        // border right-hand side, fused: t -= W' y for the rows solved in the previous step (W rows in registers)
-        for (int cq = 0; cq < nch; ++cq) {
-            chunk_commit(chunk, rring, cq + 2, cq + 2, lt, regs, rreg);
-            chunk_fetch(L, v, ni, b, cq + 3, cq + 3, lt, goff, regs, rreg);
-            if (cq >= 1) { TACC_ADD(cq - 1) }
-            WFETCH(cq)
-            lds_barrier();
-        }
-    }
-    if (wv > 0 && nch >= 1) { TACC_ADD(nch - 1) }
-    // part[wave][jj]: partial sums of W'y (summed over the wave's rows: the 8 row lanes of every column pair, then LDS)
-#pragma unroll
-    for (int u = 0; u < 4; ++u) {
-#pragma unroll
-        for (int sh = 8; sh <= 32; sh <<= 1) {
-            tacc[u][0] += __shfl_xor(tacc[u][0], sh);
-            tacc[u][1] += __shfl_xor(tacc[u][1], sh);
-        }
-        if (g8 == 0) {
-            part[wv * 64 + 16 * u + 2 * c8] = tacc[u][0];
-            part[wv * 64 + 16 * u + 2 * c8 + 1] = tacc[u][1];
-        }
-    }
-    }
-    __syncthreads();
-    // The loader waves have nothing to do while wave 0 solves the border system: the first two chunks of the BACKWARD sweep (L rows
-    // and the raw y_B of the last rows, W rows of the last chunk) go in flight and into the ring now -- they do not depend on x_D.
-    const int cl = nch - 1;
-    if (wv > 0 && nch > 0) {
-        // The top tiles of the sweep read the ring slot of chunk cl + 1 (rows beyond the last one: zeros times zeros).  The
-        // forward sweep leaves zeros there; when it ran inside the factorisation the slot still holds the factorisation's tile
-        // window -- including the tiles' padding words, which nothing ever wrote (stale LDS of whatever ran on this CU
-        // before: a NaN bit pattern there turned every unknown into NaN on some boxes) -- so the slot is cleared first.
-        if (fwd_done) {
-            d2* dst = (d2*)(chunk + ((cl + 1) % NBUF) * CH * CLD);
-            for (int e2 = lt; e2 < LD_PAIRS; e2 += LD_THREADS) dst[e2] = (d2){0.0, 0.0};
-        }
-        chunk_fetch(L, v, ni, b, cl, cl, lt, goff, regs, rreg);
-        chunk_commit(chunk, rring, cl, cl, lt, regs, rreg);
-        chunk_fetch(L, v, ni, b, -1, cl - 1, lt, goff, regs, rreg);
-        chunk_commit(chunk, rring, -1, cl - 1, lt, regs, rreg);
-        WFETCH(cl)
-    }
-    // ================= border:  t = v_D - W' y_B,  x_D = L_S^-T (L_S^-1 t)  as two LDS mat-vecs =================
-    if (wv == 0) {
-        double t = 0.0;
-        if (lane < p) {
-            t = v[ni + lane];
-            for (int q = 1; q < MCQ_NW; ++q) t -= part[q * 64 + lane];
-        }
-        __builtin_amdgcn_wave_barrier();
-        xd[lane] = t;
-        __builtin_amdgcn_wave_barrier();   // same-wave LDS write -> read (in-order on hardware; ordering point for the compiler)
-        double y = 0.0;
-        for (int cc = 0; cc < MCQ_P_MAX; ++cc) {
-            const double a = spk[lane * (lane + 1) / 2 + (cc <= lane ? cc : 0)];
-            y += (cc <= lane ? a : 0.0) * xd[cc];
-        }
-        __builtin_amdgcn_wave_barrier();
-        part[lane] = lane < p ? y : 0.0;
-        __builtin_amdgcn_wave_barrier();
-        double x = 0.0;
-        for (int r = 0; r < MCQ_P_MAX; ++r) {
-            const double a = spk[r * (r + 1) / 2 + (lane <= r ? lane : 0)];
-            x += (lane <= r ? a : 0.0) * part[r];
-        }
-        if (lane < p) v[ni + lane] = x;
-        xd[lane] = lane < p ? x : 0.0;
-    }
-    __syncthreads();
-    for (int q = tid; q < VRING; q += MCQ_NT) vring[q] = 0.0;
-    // ================= backward substitution, interior rows (descending) =================
-    // tile J needs the band entries of the rows of tiles J+1..J+4 (the chunk processed before) and its own inverse tile.
-    // Right-hand side of a chunk = y_B - W x_D: the raw y_B values are committed to the rhs ring two steps ahead, the
-    // loader waves subtract the 64-wide dot products W[r] . x_D (W rows fetched one step ahead, reduced inside each
-    // 8-lane row group) one step ahead.
-#define RHS_SUB(q)                                                                                             \
-    {                                                                                                          \
-        double a_[WGRP];                                                                                       \
-        _Pragma("unroll") for (int m = 0; m < WGRP; ++m) {                                                     \
-            d2 s_ = wreg[m][0] * xdr[0];                                                                       \
-            _Pragma("unroll") for (int u = 1; u < 4; ++u) s_ += wreg[m][u] * xdr[u];                           \
-            a_[m] = s_[0] + s_[1];                                                                             \
-        }                                                                                                      \
-        _Pragma("unroll") for (int sh = 4; sh >= 1; sh >>= 1) {                                                \
-            _Pragma("unroll") for (int m = 0; m < WGRP; ++m) a_[m] += __shfl_xor(a_[m], sh);                   \
-        }                                                                                                      \
-        _Pragma("unroll") for (int m = 0; m < WGRP; ++m) {                                                     \
-            const bool ok_ = WOK(q, m);                                                                        \
-            if (c8 == 0 && ok_) RHSV(WROW(q, m)) -= a_[m];                                                     \
-        }                                                                                                      \
-    }
-    d2 xdr[4];      // this lane's slice of x_D (constant over the sweep)
-#pragma unroll
-    for (int u = 0; u < 4; ++u) xdr[u] = (d2){xd[16 * u + 2 * c8], xd[16 * u + 2 * c8 + 1]};
-    if (nch > 0) {
-        __syncthreads();
-        if (wv > 0) {
-            RHS_SUB(cl)
-            chunk_fetch(L, v, ni, b, cl - 1, cl - 2, lt, goff, regs, rreg);
-            WFETCH(cl - 1)
-        }
-        __syncthreads();
-        if (wv == 0) { const long long ts_ = STICK(); sweep_bwd_wave0(c, v); c.tk[5] += STICK() - ts_; }
-        else {
-            // W rows first: fetched at the top of the previous step, consumed at the top of this one and re-fetched at once, they
-            // get a whole step in flight like the L rows (behind the commit they had half of one; forward the same order loses)
-            long long st_[6] = {0, 0, 0, 0, 0, 0}, sl_ = MCQ_SOLVE_TIMERS ? (long long)clock64() : 0;
-#define ST(k) do { if (MCQ_SOLVE_TIMERS) { __builtin_amdgcn_s_waitcnt(0xc07f); const long long t_ = (long long)clock64(); st_[k] += t_ - sl_; sl_ = t_; } } while (0)
-            for (int cq = cl; cq >= 0; --cq) {
-                RHS_SUB(cq - 1)
-                ST(0);
-                WFETCH(cq - 2)
-                ST(1);
-                chunk_commit(chunk, rring, cq - 1, cq - 2, lt, regs, rreg);
-                ST(2);
-                chunk_fetch(L, v, ni, b, cq - 2, cq - 3, lt, goff, regs, rreg);
-                ST(3);
-                lds_barrier();
-                ST(4);
-            }
-            if (MCQ_SOLVE_TIMERS && tid == 64) { long long* acc = (long long*)c.w.Z; for (int q = 0; q < 5; ++q) acc[q] += st_[q]; acc[5] += cl + 1; }
-#undef ST
-        }
-    }
-    __syncthreads();
-#undef WFETCH
-#undef TACC_ADD
-#undef WGOK
-#undef WOK
-#undef WROW
-#undef RHS_SUB
-#endif   // MCQ_CORE_BAND
 }
 
-// dst = E' src: through the spline system where the ring allows it (saddle-point core), else from the band of E'
-__device__ void apply_Et(SolveCtx& c, const gdouble* src, gdouble* dst)
-{
-#if !defined(MCQ_CORE_BAND)
-    if (tri_usable(c)) { tri_apply_Et(c, src, dst); return; }
-#endif
-    band_matvec(c.w.Et, c.d.bR, c.d.bE, c.d.n, c.nm, src, nullptr, 0.0, dst);
-}
+// dst = E' src, through the spline system (mcq_tri.inc)
+__device__ __forceinline__ void apply_Et(SolveCtx& c, const gdouble* src, gdouble* dst) { tri_apply_Et(c, src, dst); }
 
 // g = E'(E x + F_SCALE k_ref + extra)      (tmp: scratch vector; extra may be nullptr)
 __device__ __noinline__ void gradient(SolveCtx& c, const gdouble* x, const gdouble* extra, gdouble* tmp, gdouble* g)
@@ -2555,39 +389,32 @@ __device__ __noinline__ void gradient(SolveCtx& c, const gdouble* x, const gdoub
     const int n = c.d.n;
     const long long t0 = TICK();
     __syncthreads();
-    if (c.direct) {          // g = H x + f, H a cyclic tridiagonal given entry by entry: nothing to gain from a factored form
-        band_matvec(c.w.Eb, 1, 1, n, c.nm, x, VEC(c.w, c.nm, V_F), 1.0, g);
+    if (c.direct) {          // g = H x + f, H a cyclic tridiagonal given entry by entry
+        const gdouble* HD = VEC(c.w, c.nm, V_SPD);
+        const gdouble* HU = VEC(c.w, c.nm, V_SPU);
+        const gdouble* F = VEC(c.w, c.nm, V_F);
+        for (int i = threadIdx.x; i < n; i += MCQ_NT) {
+            const int im = i > 0 ? i - 1 : n - 1, ip = i + 1 < n ? i + 1 : 0;
+            g[i] = F[i] + HU[im] * x[im] + HD[i] * x[i] + HU[i] * x[ip];
+        }
         __syncthreads();
         c.tk[2] += TICK() - t0;
         return;
     }
-#if !defined(MCQ_CORE_BAND)
-    if (tri_usable(c)) {        // E and E' through the spline system itself (mcq_tri.inc): no band is read
-        tri_apply_E(c, x, VEC(c.w, c.nm, V_KREF), MCQ_F_SCALE, tmp);
-        if (extra) {
-            for (int i = threadIdx.x; i < n; i += MCQ_NT) tmp[i] += extra[i];
-            __syncthreads();
-        }
-        tri_apply_Et(c, tmp, g);
-        c.tk[2] += TICK() - t0;
-        return;
-    }
-#endif
-    band_matvec(c.w.Eb, c.d.bE, c.d.bR, n, c.nm, x, VEC(c.w, c.nm, V_KREF), MCQ_F_SCALE, tmp);
-    __syncthreads();
+    // E and E' through the spline system itself (mcq_tri.inc): no band is read
+    tri_apply_E(c, x, VEC(c.w, c.nm, V_KREF), MCQ_F_SCALE, tmp);
     if (extra) {
         for (int i = threadIdx.x; i < n; i += MCQ_NT) tmp[i] += extra[i];
         __syncthreads();
     }
-    band_matvec(c.w.Et, c.d.bR, c.d.bE, n, c.nm, tmp, nullptr, 0.0, g);
-    __syncthreads();
+    tri_apply_Et(c, tmp, g);
     c.tk[2] += TICK() - t0;
 }
 
-__device__ __forceinline__ int timed_factor(SolveCtx& c, const gdouble* src, const gdouble* sig, const gschar* mk, gdouble* fv = nullptr)
+__device__ __forceinline__ int timed_factor(SolveCtx& c, const gdouble* sig, const gschar* mk, gdouble* fv = nullptr)
 {
     const long long t0 = TICK();
-    const int r = factor(c, src, sig, mk, fv);
+    const int r = factor(c, sig, mk, fv);
     c.tk[0] += TICK() - t0;
     return r;
 }
@@ -2648,8 +475,7 @@ __device__ __noinline__ int ipm(SolveCtx& c, const McqBatch& B, bool with_kappa,
     }
     __syncthreads();
     if (with_kappa) {
-        band_matvec(c.w.Eb, c.d.bE, c.d.bR, n, nm, X, KR, 1.0, T0);     // r = E x + k_ref
-        __syncthreads();
+        tri_apply_E(c, X, KR, 1.0, T0);     // r = E x + k_ref
         const double mu0 = 0.5 * zscale * sc.wmean;
         for (int i = tid; i < n; i += MCQ_NT) {
             const double r = T0[i];
@@ -2678,8 +504,7 @@ __device__ __noinline__ int ipm(SolveCtx& c, const McqBatch& B, bool with_kappa,
             for (int i = tid; i < n; i += MCQ_NT) Q[i] = YU[i] - YL[i];
             gradient(c, X, Q, T0, T1);                                   // T1 = g + E'(yu - yl)   (dual residual part)
             gradient(c, X, nullptr, T0, G);                              // G  = g
-            band_matvec(c.w.Eb, c.d.bE, c.d.bR, n, nm, X, KR, 1.0, T0);  // T0 = r
-            __syncthreads();
+            tri_apply_E(c, X, KR, 1.0, T0);  // T0 = r
         }
         double mu, rdm, rhom;
         for (;;) {
@@ -2725,13 +550,8 @@ __device__ __noinline__ int ipm(SolveCtx& c, const McqBatch& B, bool with_kappa,
             // H slab <- E' (I + diag(SK)) E = H + E' diag(SK) E   (H = E'E is rebuilt by the caller after this phase)
             for (int i = tid; i < n; i += MCQ_NT) EDA[i] = 1.0 + SK[i];
             __syncthreads();
-            if (MCQ_KKT && !c.direct) {
-                c.kkt_w = EDA;                       // the weights enter the (cx, cy) block of every waypoint: no band to rebuild
-            } else {
-                gram_bordered(c.w.Et, EDA, c.d, nm, nullptr, c.w.H, tid, MCQ_NT);
-                __syncthreads();
-            }
-            fs = timed_factor(c, c.w.H, SIG, any_fixed ? ST : nullptr);
+            c.kkt_w = EDA;                           // the weights enter the (cx, cy) block of every waypoint: nothing to form
+            fs = timed_factor(c, SIG, any_fixed ? ST : nullptr);
             c.kkt_w = nullptr;
             // With many curvature rows close to their bound the weights y / t reach 1e10 and more near the end; the band of
             // E' diag(1 + SK) E then carries rounding errors of that size against eigenvalues of order one, and the Cholesky can
@@ -2741,7 +561,7 @@ __device__ __noinline__ int ipm(SolveCtx& c, const McqBatch& B, bool with_kappa,
             // does not form this matrix.
             if (fs == MCQ_NOT_PD && mu < 1e-6 * mu_first) return MCQ_OK;
         } else {
-            fs = timed_factor(c, c.w.H, SIG, any_fixed ? ST : nullptr);
+            fs = timed_factor(c, SIG, any_fixed ? ST : nullptr);
         }
         if (fs != 0) return fs;
 
@@ -2761,8 +581,7 @@ __device__ __noinline__ int ipm(SolveCtx& c, const McqBatch& B, bool with_kappa,
         }
         timed_solve(c, RHS);
         if (with_kappa) {
-            band_matvec(c.w.Eb, c.d.bE, c.d.bR, n, nm, RHS, nullptr, 0.0, EDA);   // E dx_aff
-            __syncthreads();
+            tri_apply_E(c, RHS, nullptr, 0.0, EDA);   // E dx_aff
         }
         double ap = 1.0, ad = 1.0;
         for (int i = tid; i < n; i += MCQ_NT) {
@@ -2826,8 +645,7 @@ __device__ __noinline__ int ipm(SolveCtx& c, const McqBatch& B, bool with_kappa,
         }
         timed_solve(c, RHS);
         if (with_kappa) {
-            band_matvec(c.w.Eb, c.d.bE, c.d.bR, n, nm, RHS, nullptr, 0.0, Q);     // Q = E dx
-            __syncthreads();
+            tri_apply_E(c, RHS, nullptr, 0.0, Q);     // Q = E dx
         }
         double amax = 1.0 / 0.995;
         for (int i = tid; i < n; i += MCQ_NT) {
@@ -3036,13 +854,13 @@ __device__ __noinline__ int ipm_box(SolveCtx& c, const McqBatch& B, const SolveS
 
         // ---- factorisation, predictor solve -----------------------------------------------------------------------------
         // the predictor's right-hand side (written in pass 1) rides through the factorisation: its forward substitution is done
-        // when the factor is (MCQ_FUSE_FWD = 0: the plain sequence)
-        const int fs = timed_factor(c, c.w.H, VEC(c.w, c.nm, V_SIG), any_fixed ? c.w.state : nullptr,
-                                    MCQ_FUSE_FWD ? VEC(c.w, c.nm, V_RHS) : nullptr);
+        // when the factor is
+        const int fs = timed_factor(c, VEC(c.w, c.nm, V_SIG), any_fixed ? c.w.state : nullptr,
+                                    VEC(c.w, c.nm, V_RHS));
         // resumed attempt (complementarity already below 1e-10): an iterate that sits ON a bound in floating point (slack 0, sig = inf) ends
         // the attempt like a stalled complementarity does -- the pairs of the last completed iteration go to the active-set phase
         if (fs != 0) return (resume && fs == MCQ_NOT_PD) ? MCQ_OK : fs;
-        timed_solve(c, VEC(c.w, c.nm, V_RHS), MCQ_FUSE_FWD != 0);
+        timed_solve(c, VEC(c.w, c.nm, V_RHS), true);
 
         // ---- pass 2: affine step lengths, centring parameter, corrector right-hand side: ONE load phase (six arrays of eight entries stay in
         //      registers across the two block reductions; the affine multiplier steps are recomputed where they are needed) ----------
@@ -3169,19 +987,6 @@ __device__ __noinline__ int ipm_box(SolveCtx& c, const McqBatch& B, const SolveS
 // Working set = pinned box rows (masked banded Cholesky of H_FF) + at most MCQ_KMAX active curvature rows, the latter
 // through the Schur complement  S = E_K M^-1 E_K'  (|K| extra banded solves per iteration; rare path).
 // ---------------------------------------------------------------------------------------------------------------------
-__device__ __forceinline__ double erow_dot(const SolveCtx& c, int k, const gdouble* v)
-{
-    // (E v)_k, computed redundantly by every thread (short: ew terms)
-    const int n = c.d.n;
-    double acc = 0.0;
-    int j = cyc(k - c.d.bE, n);
-    for (int oo = 0; oo < c.d.ew; ++oo) {
-        acc += c.w.Eb[(size_t)oo * c.nm + k] * v[j];
-        j = (j + 1 == n) ? 0 : j + 1;
-    }
-    return acc;
-}
-
 // ---- curvature rows of the working set: the Schur complement  S = E_K M^-1 E_K'  (nk x nk) --------------------------------------
 // Where the working set's arrays live (KappaMem).  Up to MCQ_KMAX rows -- every case the reference's tracks produce -- the index /
 // sign / pivot lists and the three nk-vectors sit in LDS, S in HBM behind the scratch vector of McqWork.Z (row-major, leading
@@ -3439,32 +1244,30 @@ __device__ __noinline__ int active_set(SolveCtx& c, const McqBatch& B, bool with
         }
         gradient(c, T1, nullptr, T0, T2);       // T2 = H x_A + f
         for (int i = tid; i < n; i += MCQ_NT) RHS[i] = ST[i] == 0 ? -T2[i] : T1[i];
-        const int fs = timed_factor(c, c.w.H, nullptr, ST, MCQ_FUSE_FWD ? RHS : nullptr);
+        const int fs = timed_factor(c, nullptr, ST, RHS);
         if (fs != 0) return fs;
-        timed_solve(c, RHS, MCQ_FUSE_FWD != 0);   // x0 (pinned rows carry their bounds)
+        timed_solve(c, RHS, true);   // x0 (pinned rows carry their bounds)
         if (nk > 0) {
-            // column q of S = E_K (M^-1 E_kq' restricted to the free set): one banded solve per active row, nothing but one
-            // scratch vector kept (x = x0 - M^-1 E_K' mu costs one more solve afterwards instead of nk stored columns)
+            // column q of S = E_K (M^-1 E_kq' restricted to the free set): per active row one application of E' (to a unit vector), one
+            // solve, one application of E -- nothing but one scratch vector kept (x = x0 - M^-1 E_K' mu costs one more solve afterwards
+            // instead of nk stored columns).  (Rounds 1-3 read rows of a 65-wide band of E here; E is applied through the spline system
+            // now, untruncated, and no band exists.)
             gdouble* Zs = c.w.Z;
             gdouble* SG = K.sg;
             for (int q = 0; q < nk; ++q) {
                 const int k = KI[1 + q];
-                for (int i = tid; i < n; i += MCQ_NT) Zs[i] = 0.0;
-                __syncthreads();
-                for (int oo = tid; oo < c.d.ew; oo += MCQ_NT) {
-                    const int j = cyc(k + oo - c.d.bE, n);
-                    if (ST[j] == 0) Zs[j] = c.w.Eb[(size_t)oo * nm + k];
-                }
+                for (int i = tid; i < n; i += MCQ_NT) T2[i] = i == k ? 1.0 : 0.0;
+                apply_Et(c, T2, Zs);
+                for (int i = tid; i < n; i += MCQ_NT) if (ST[i] != 0) Zs[i] = 0.0;
                 __syncthreads();
                 timed_solve(c, Zs);
-                for (int q2 = tid; q2 < nk; q2 += MCQ_NT) SG[(size_t)q2 * K.ld + q] = erow_dot(c, KI[1 + q2], Zs);
+                tri_apply_E(c, Zs, nullptr, 0.0, T0);
+                for (int q2 = tid; q2 < nk; q2 += MCQ_NT) SG[(size_t)q2 * K.ld + q] = T0[KI[1 + q2]];
                 __syncthreads();
             }
             // rhs = E_K x0 + k_ref - s kb
-            for (int q = tid; q < nk; q += MCQ_NT) {
-                const int k = KI[1 + q];
-                KRH[q] = erow_dot(c, k, RHS) + KR[k] - KI[1 + kcap + q] * kb;
-            }
+            tri_apply_E(c, RHS, KR, 1.0, T0);
+            for (int q = tid; q < nk; q += MCQ_NT) KRH[q] = T0[KI[1 + q]] - KI[1 + kcap + q] * kb;
             kappa_lu_factor(K, nk);
             kappa_lu_solve(K, nk);
             kappa_apply(c, K, nk, Q, Zs);       // Q = multipliers on their rows, Zs = M^-1 E_K' mu
@@ -3473,10 +1276,7 @@ __device__ __noinline__ int active_set(SolveCtx& c, const McqBatch& B, bool with
         }
         for (int i = tid; i < n; i += MCQ_NT) X[i] = ST[i] == 0 ? RHS[i] : T1[i];
         gradient(c, X, nk > 0 ? Q : nullptr, T0, G);      // Lagrangian gradient  H x + f + E_K' mu
-        if (with_kappa) {
-            band_matvec(c.w.Eb, c.d.bE, c.d.bR, n, nm, X, KR, 1.0, T2);      // r = E x + k_ref
-            __syncthreads();
-        }
+        if (with_kappa) tri_apply_E(c, X, KR, 1.0, T2);      // r = E x + k_ref
         double nv = 0.0, imax = -1.0, kk = 0.0;
         for (int i = tid; i < n; i += MCQ_NT) {
             const signed char st = ST[i];
@@ -3516,9 +1316,10 @@ __device__ __noinline__ int active_set(SolveCtx& c, const McqBatch& B, bool with
                     // curvature rows in the working set: one step on the KKT system [M E_K'; E_K 0] through the factored Schur
                     // complement -- dx0 = M^-1(-g), S dmu = E_K dx0 + (E_K x + k_ref - s kb), dx = dx0 - M^-1 E_K' dmu
                     gdouble* Zs = c.w.Z;
+                    tri_apply_E(c, RHS, nullptr, 0.0, T0);
                     for (int q = tid; q < nk; q += MCQ_NT) {
                         const int k = KI[1 + q];
-                        KRH[q] = erow_dot(c, k, RHS) + T2[k] - KI[1 + kcap + q] * kb;
+                        KRH[q] = T0[k] + T2[k] - KI[1 + kcap + q] * kb;
                     }
                     kappa_lu_solve(K, nk);
                     for (int q = tid; q < nk; q += MCQ_NT) KRH[q] = KMU[q];       // dmu (kappa_apply reads KMU, Q is rebuilt below)
@@ -3533,10 +1334,7 @@ __device__ __noinline__ int active_set(SolveCtx& c, const McqBatch& B, bool with
                 for (int i = tid; i < n; i += MCQ_NT) if (ST[i] == 0) { X[i] += RHS[i]; dm = fmax(dm, fabs(RHS[i])); }
                 dm = block_reduce_(dm, 2, red);
                 gradient(c, X, nk > 0 ? Q : nullptr, T0, G);
-                if (nk > 0) {
-                    band_matvec(c.w.Eb, c.d.bE, c.d.bR, n, nm, X, KR, 1.0, T2);      // r = E x + k_ref
-                    __syncthreads();
-                }
+                if (nk > 0) tri_apply_E(c, X, KR, 1.0, T2);      // r = E x + k_ref
                 c.refine_rounds = r + 1;
                 if (!(dm > 1e-8)) break;
             }
@@ -3577,11 +1375,7 @@ __device__ __noinline__ int active_set(SolveCtx& c, const McqBatch& B, bool with
     return MCQ_ITER_CAP;
 }
 
-#if defined(MCQ_CORE_BAND)
-__global__ void __launch_bounds__(MCQ_NT) mcq_solve_kernel(McqBatch B)
-#else
 __global__ void __launch_bounds__(MCQ_NT, 2) mcq_solve_kernel(McqBatch B)
-#endif
 {
     const int tid = threadIdx.x;
     int n;
@@ -3590,19 +1384,20 @@ __global__ void __launch_bounds__(MCQ_NT, 2) mcq_solve_kernel(McqBatch B)
     c.w = mcq_work(B, blockIdx.x, n, kbound, wveh);
     if (*c.w.status != MCQ_OK) return;
     c.nm = B.nmax;
-    c.d = mcq_dims(n, B.band_e);
+    c.d = mcq_dims(n);
     for (int q = 0; q < 8; ++q) c.tk[q] = 0;
     c.last_step = 0.0;
     c.refine_rounds = c.second_attempt = 0;
     c.direct = B.objective == MCQ_OBJ_SHORTEST_PATH;
     c.kkt_w = nullptr;
+    c.sp_sig = nullptr;
+    c.sp_mk = nullptr;
     if (B.poison_lds) {      // debugging aid: whatever a phase reads from LDS without having written it shows up as NaN on every box
         for (int q = tid; q < SM_TOTAL; q += MCQ_NT) g_sm[q] = __longlong_as_double(-1LL);
         __syncthreads();
     }
     const long long t_kernel0 = TICK();
     const long long c_kernel0 = (long long)clock64();      // shader-clock counter (s_memtime): with ticks[3] the effective clock
-    if ((MCQ_WORKER_TIMERS || MCQ_SOLVE_TIMERS) && tid == 64) for (int q = 0; q < 8; ++q) ((long long*)c.w.Z)[q] = 0;
     double* red = g_sm + SM_RED;
     const int nm = B.nmax;
 
@@ -3618,21 +1413,12 @@ __global__ void __launch_bounds__(MCQ_NT, 2) mcq_solve_kernel(McqBatch B)
     gdouble* Q = VEC(c.w, nm, V_Q);
     gschar* ST = c.w.state;
 
-#if !defined(MCQ_CORE_BAND)
-    {   // f = F_SCALE E' k_ref: the Gram kernels that used to produce it together with the band of H are not launched for this core
+    if (!c.direct) {   // f = F_SCALE E' k_ref
         gdouble* Fw = VEC(c.w, nm, V_F);
-        __syncthreads();
-        if (tri_usable(c)) {
-            tri_prepare(c);
-            tri_apply_Et(c, VEC(c.w, nm, V_KREF), Fw);
-        } else {
-            band_matvec(c.w.Et, c.d.bR, c.d.bE, n, nm, VEC(c.w, nm, V_KREF), nullptr, 0.0, Fw);
-        }
-        __syncthreads();
+        tri_apply_Et(c, VEC(c.w, nm, V_KREF), Fw);        // (the pivots of T, V_IDL / V_TUC, are the assembly kernel's)
         for (int i = tid; i < n; i += MCQ_NT) Fw[i] *= MCQ_F_SCALE;
         __syncthreads();
     }
-#endif
     // ---- scalars: scales for the tolerances, initial gradient at the box centre -----------------------------------------
     SolveScalars sc;
     sc.kbound = kbound;
@@ -3687,10 +1473,8 @@ __global__ void __launch_bounds__(MCQ_NT, 2) mcq_solve_kernel(McqBatch B)
     int status = MCQ_OK;
     const long long t_ipm0 = TICK();
     if (!warm_done) status = small ? ipm_box(c, B, sc, ipm_iters, MCQ_IPM_TOL, false) : ipm(c, B, false, sc, ipm_iters);
-#if !defined(MCQ_CORE_BAND)
     c.tk[4] = TICK() - t_ipm0;          // wall time of the interior-point phase (ticks[4]; the band core reports its forward sweeps there)
     const long long t_as0 = TICK();
-#endif
     if (warm_done) {
     } else if (status == MCQ_OK && small) {
         // Two attempts.  The pairs at mu = 1e-10 identify the active set of all but the degenerate / extremely
@@ -3717,10 +1501,8 @@ __global__ void __launch_bounds__(MCQ_NT, 2) mcq_solve_kernel(McqBatch B)
         status = active_set(c, B, false, ipm_iters >= 1 && c.last_step >= 0.9, B.max_as_iter, sc, as_iters, kkt, nk_dummy, true, kappa_mem_lds(c));
     }
     as_iters += as_warm;        // rounds of an abandoned warm start are reported too
-#if !defined(MCQ_CORE_BAND)
     c.tk[5] = TICK() - t_as0;           // wall time of the active-set phase (ticks[5])
     const long long t_epi0 = TICK();
-#endif
 
     // kappa(alpha) = k_ref + E alpha
     for (int i = tid; i < n; i += MCQ_NT) X[i] = fmin(fmax(X[i], LO[i]), HI[i]);
@@ -3728,14 +1510,10 @@ __global__ void __launch_bounds__(MCQ_NT, 2) mcq_solve_kernel(McqBatch B)
     double km = 0.0;
     bool dd_valid = false;
     if (!c.direct) {
-#if !defined(MCQ_CORE_BAND)
         // (the second derivatives the post-check needs, D (n_x alpha) and D (n_y alpha), are by-products of this product: kept in two
         //  vectors only the curvature-row phase uses, so the post-check repeats the product only if that phase ran)
-        if (tri_usable(c)) { tri_apply_E(c, X, VEC(c.w, nm, V_KREF), 1.0, T0, VEC(c.w, nm, V_TL), VEC(c.w, nm, V_TU)); dd_valid = true; }
-        else
-#endif
-        band_matvec(c.w.Eb, c.d.bE, c.d.bR, n, nm, X, VEC(c.w, nm, V_KREF), 1.0, T0);
-        __syncthreads();
+        tri_apply_E(c, X, VEC(c.w, nm, V_KREF), 1.0, T0, VEC(c.w, nm, V_TL), VEC(c.w, nm, V_TU));
+        dd_valid = true;
         for (int i = tid; i < n; i += MCQ_NT) km = fmax(km, fabs(T0[i]));
         km = block_reduce_(km, 2, red);
     }
@@ -3744,16 +1522,9 @@ __global__ void __launch_bounds__(MCQ_NT, 2) mcq_solve_kernel(McqBatch B)
     //      then the box active-set polish with the curvature multipliers frozen ---------------------------------------------
     if (status == MCQ_OK && B.check_kappa && !c.direct && km > kbound * (1.0 + 1e-9)) {
         dd_valid = false;
-#if !defined(MCQ_CORE_BAND)
-        if (B.skip_eb) asm_e_band_lazy(c.w, nm, n, c.d.bE);      // the E band, first needed here
-#endif
         status = ipm(c, B, true, sc, it2);
         ipm_iters += it2;
         __syncthreads();
-#if defined(MCQ_CORE_BAND)
-        gram_bordered(c.w.Et, nullptr, c.d, nm, nullptr, c.w.H, tid, MCQ_NT);     // restore H = E'E
-        __syncthreads();
-#endif
         if (status == MCQ_OK) {
             status = active_set(c, B, true, false, B.max_as_iter, sc, it2, kkt, nact_kappa, true, kappa_mem_lds(c));
             as_iters += it2;
@@ -3777,8 +1548,7 @@ __global__ void __launch_bounds__(MCQ_NT, 2) mcq_solve_kernel(McqBatch B)
         }
         for (int i = tid; i < n; i += MCQ_NT) X[i] = fmin(fmax(X[i], LO[i]), HI[i]);
         __syncthreads();
-        band_matvec(c.w.Eb, c.d.bE, c.d.bR, n, nm, X, VEC(c.w, nm, V_KREF), 1.0, T0);
-        __syncthreads();
+        tri_apply_E(c, X, VEC(c.w, nm, V_KREF), 1.0, T0);
         double k2 = 0.0;
         for (int i = tid; i < n; i += MCQ_NT) k2 = fmax(k2, fabs(T0[i]));
         km = block_reduce_(k2, 2, red);
@@ -3802,20 +1572,12 @@ __global__ void __launch_bounds__(MCQ_NT, 2) mcq_solve_kernel(McqBatch B)
         if (!c.direct) {
             for (int i = tid; i < n; i += MCQ_NT) { T1[i] = VEC(c.w, nm, V_NX)[i] * X[i]; T2[i] = VEC(c.w, nm, V_NY)[i] * X[i]; }
             __syncthreads();
-#if !defined(MCQ_CORE_BAND)
-            if (tri_usable(c)) {
-                if (dd_valid) {
-                    const gdouble* D1 = VEC(c.w, nm, V_TL);
-                    const gdouble* D2 = VEC(c.w, nm, V_TU);
-                    for (int i = tid; i < n; i += MCQ_NT) { T0[i] = D1[i]; T3[i] = D2[i]; }
-                } else {
-                    tri_apply_E(c, X, nullptr, 0.0, Q, T0, T3);      // D (n_x alpha), D (n_y alpha) are by-products of E alpha
-                }
-            } else
-#endif
-            {
-            band_matvec(c.w.Db, c.d.bE, c.d.bR, n, nm, T1, nullptr, 0.0, T0);   // D (n_x alpha)
-            band_matvec(c.w.Db, c.d.bE, c.d.bR, n, nm, T2, nullptr, 0.0, T3);   // D (n_y alpha)
+            if (dd_valid) {
+                const gdouble* D1 = VEC(c.w, nm, V_TL);
+                const gdouble* D2 = VEC(c.w, nm, V_TU);
+                for (int i = tid; i < n; i += MCQ_NT) { T0[i] = D1[i]; T3[i] = D2[i]; }
+            } else {
+                tri_apply_E(c, X, nullptr, 0.0, Q, T0, T3);      // D (n_x alpha), D (n_y alpha) are by-products of E alpha
             }
             __syncthreads();
         }
@@ -3847,18 +1609,15 @@ __global__ void __launch_bounds__(MCQ_NT, 2) mcq_solve_kernel(McqBatch B)
                 o.refine_rounds = c.refine_rounds;
                 o.second_attempt = c.second_attempt;
                 c.tk[3] = TICK() - t_kernel0;
-#if !defined(MCQ_CORE_BAND)
                 c.tk[7] = TICK() - t_epi0;          // curvature check, (rare) curvature-row phase, outputs (ticks[7])
-#endif
-                if (!MCQ_FINE_TIMERS) c.tk[6] = (long long)clock64() - c_kernel0;
-                for (int q = 0; q < 8; ++q) o.ticks[q] = (MCQ_WORKER_TIMERS || MCQ_SOLVE_TIMERS) ? ((const long long*)c.w.Z)[q] : c.tk[q];
+                c.tk[6] = (long long)clock64() - c_kernel0;
+                for (int q = 0; q < 8; ++q) o.ticks[q] = c.tk[q];
                 *(mcq_info*)c.w.info = o;
             }
         }
     }
 }
 
-#if !defined(MCQ_CORE_BAND)
 // =====================================================================================================================
 // K4: IQP glue -- re-linearisation on the device
 // =====================================================================================================================
@@ -4438,8 +2197,4 @@ __global__ void __launch_bounds__(64) mcq_widen_rows_kernel(const float* rows, c
         y += (double)src[4 * i + 1] - cy;
     }
 }
-#endif   // !defined(MCQ_CORE_BAND)
 
-#if defined(MCQ_CORE_BAND)
-}   // namespace mcq_band
-#endif

@@ -4,25 +4,29 @@ Build guard: scans the gfx950 ISA of every non-kernel device function of mcq_ker
 s80-87, s96-103) that the function WRITES without having spilled them in its prologue.  hipcc 7.2 does this when a function grows past the
 range of a 16-bit branch offset: branch relaxation runs after prologue / epilogue insertion and scavenges s[98:99] for the
 s_getpc_b64 / s_setpc_b64 long branches (round 3: factor() with three factor_t bodies inlined -- active_set()'s loop stride lived in
-s[98:99]; found with rocgdb).  Exit code 1 if anything is found.     scripts/check_csr.py [extra hipcc flags]
+s[98:99]; found with rocgdb).  Exit code 1 if anything is found.     scripts/check_csr.py [kernels.s | extra hipcc flags]
 """
 import re, subprocess, sys, os, tempfile
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 src = os.path.join(ROOT, "global_racetrajectory_optimization_amd", "csrc", "mcq_kernels.hip")
-base = ["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-mllvm", "-amdgpu-mfma-vgpr-form", "-mllvm", "-enable-ipra=0",
-        "-S", "--cuda-device-only"]
+# The ISA comes from csrc/build.sh itself (ASM_OUT=<file>: the same flags as the library, no second recipe to keep in step); given a
+# file as first argument this script only scans it, otherwise it compiles the device side once with $HIPCC.
+if len(sys.argv) > 1 and os.path.exists(sys.argv[1]):
+    asm = sys.argv[1]
+else:
+    asm = os.path.join(tempfile.gettempdir(), "mcq_check_csr.s")
+    hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+    subprocess.run([hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-mllvm", "-enable-ipra=0", "--gpu-max-threads-per-block=512",
+                    "-S", "--cuda-device-only", "-o", asm, src] + sys.argv[1:], check=True, stderr=subprocess.DEVNULL)
 funcs, cur = {}, None
-for tag, extra in (("kkt", ["--gpu-max-threads-per-block=512"]), ("band", ["-DMCQ_CORE_BAND"])):      # the two translation units of csrc/build.sh
-    out = os.path.join(tempfile.gettempdir(), "mcq_check_csr_%s.s" % tag)
-    subprocess.run(base + extra + ["-o", out, src] + sys.argv[1:], check=True, stderr=subprocess.DEVNULL)
-    for ln in open(out):
-        m = re.match(r"^(_Z\w+):", ln)
-        if m:
-            cur = tag + ":" + m.group(1); funcs[cur] = []; continue
-        if ln.startswith(".Lfunc_end"):
-            cur = None; continue
-        if cur:
-            funcs[cur].append(ln)
+for ln in open(asm):
+    m = re.match(r"^(_Z\w+):", ln)
+    if m:
+        cur = m.group(1); funcs[cur] = []; continue
+    if ln.startswith(".Lfunc_end"):
+        cur = None; continue
+    if cur:
+        funcs[cur].append(ln)
 csr = set(range(34, 40)) | set(range(48, 56)) | set(range(64, 72)) | set(range(80, 88)) | set(range(96, 104))
 SKIP = ("s_cbranch", "s_branch", "s_waitcnt", "s_nop", "s_barrier", "s_setpc", "s_endpgm", "s_sleep", "s_cmp", "s_bitcmp")
 SECOND = ("v_div_scale", "v_add_co", "v_sub_co", "v_addc_co", "v_subb_co", "v_mad_u64", "v_mad_i64")

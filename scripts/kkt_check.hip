@@ -18,7 +18,7 @@ __global__ void __launch_bounds__(MCQ_NT, 2) kc_kernel(McqBatch B, int reps, con
     SolveCtx c;
     c.w = mcq_work(B, blockIdx.x, n, kb, wv);
     c.nm = B.nmax;
-    c.d = mcq_dims(n, B.band_e);
+    c.d = mcq_dims(n);
     for (int q = 0; q < 8; ++q) c.tk[q] = 0;
     c.last_step = 0.0;
     c.refine_rounds = c.second_attempt = 0;
@@ -100,8 +100,7 @@ int main(int argc, char** argv)
     memset(&B, 0, sizeof(B));
     B.batch = batch; B.n = n; B.nmax = n;
     B.L = L; B.vec = vecd; B.state = state; B.status = status;
-    B.band_e = 32;
-    B.Eb = B.Et = B.Db = B.H = L; B.Z = L;      // unused by the saddle-point path
+    B.Z = L;      // unused by the saddle-point path
     B.ref = L; B.kappa_bound = 1.0; B.w_veh = 0.0;
     hipLaunchKernelGGL(kc_kernel, dim3(batch), dim3(MCQ_NT), 0, 0, B, reps, rhsd, outd, fsd, fused, pin_frac > 0.0 ? 1 : 0, srange < -90.0 ? 1 : 0);
     CK(hipGetLastError());

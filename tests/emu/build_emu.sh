@@ -4,10 +4,13 @@
 set -e
 cd "$(dirname "$0")"
 SRC=../../global_racetrajectory_optimization_amd/csrc
-# mcq_kernels.hip twice, like csrc/build.sh: the library's kernels (saddle-point core) and namespace mcq_band (bordered-band core)
 F="-O2 -std=c++17 -fPIC -x c++ -I include -Wno-unused-result -Wno-attributes"
-g++ $F -c -o /tmp/mcq_emu_kkt.o $SRC/mcq_kernels.hip &
-g++ $F -DMCQ_CORE_BAND -c -o /tmp/mcq_emu_band.o $SRC/mcq_kernels.hip &
-g++ $F -c -o /tmp/mcq_emu_api.o $SRC/mcq_api.hip &
-wait
-g++ -shared -fPIC -o libmcq_emu.so /tmp/mcq_emu_kkt.o /tmp/mcq_emu_band.o /tmp/mcq_emu_api.o
+TMP=$(mktemp -d)
+trap 'rm -rf "$TMP"' EXIT
+g++ $F -c -o $TMP/kernels.o $SRC/mcq_kernels.hip &
+P1=$!
+g++ $F -c -o $TMP/api.o $SRC/mcq_api.hip &
+P2=$!
+wait $P1 || exit 1
+wait $P2 || exit 1
+g++ -shared -fPIC -o libmcq_emu.so $TMP/kernels.o $TMP/api.o

@@ -259,9 +259,9 @@ def test_velocity_profile_table_range_errors(emu, golden):
 
 @pytest.mark.parametrize("n", [7, 33, 70])
 def test_shortest_path_objective_matches_dense_oracle(emu, n):
-    """Row f-4 through the unchanged kernels: the cyclic tridiagonal H written straight into the bordered band (band,
-    wrap-around entries in the border, border block), the H x + f gradient, the 1 mm clipping of the deviations and a
-    ragged batch; against the dense Goldfarb-Idnani oracle."""
+    """Row f-4 through the unchanged kernels: the cyclic tridiagonal H as two vectors, its scalar elimination (Sherman-Morrison
+    for the ring, per-thread blocks + cyclic reduction of the separators; n = 7 / 33 / 70: blocks of one row, i.e. the reduction alone),
+    the H x + f gradient, the 1 mm clipping of the deviations and a ragged batch; against the dense Goldfarb-Idnani oracle."""
     ref, nv, _, _ = _small_track(n, seed=n)
     ref2, nv2, _, _ = _small_track(n + 3, seed=n + 100)
     ref2[: n // 2, 2] = 0.9                  # w_r - w_veh/2 < 0: clipped to 0.001
@@ -275,6 +275,54 @@ def test_shortest_path_objective_matches_dense_oracle(emu, n):
     assert np.max(np.abs(al[1] - a2)) < 1e-9
     assert np.all(al[1][: n // 2] <= 0.001 + 1e-15)
     assert info[0]["kkt_res"] < 1e-10 and info[0]["n_active_box"] > 0
+
+
+def _kkt_box_certificate(H_mul, f, lo, hi, x, tol):
+    """KKT conditions of  min 1/2 x'Hx + f'x, lo <= x <= hi  checked on the host from the problem data alone."""
+    g = H_mul(x) + f
+    assert np.all(x >= lo - 1e-9) and np.all(x <= hi + 1e-9)
+    free = (x > lo + 1e-7) & (x < hi - 1e-7)
+    assert np.max(np.abs(g[free])) < tol
+    assert np.all(g[x <= lo + 1e-7] > -tol) and np.all(g[x >= hi - 1e-7] < tol)
+
+
+@pytest.mark.parametrize("n", [300, 777, 2100])
+def test_shortest_path_blocks_and_long_rings(emu, n):
+    """The scalar tridiagonal route with real blocks (n = 300, 777: 2 / 4 rows per thread, a partial last block) and on workspace vectors
+    (n = 2100 > 2048: the LDS arrays do not hold the ring).  Checked by a KKT certificate computed on the host from H, f and the box
+    (the dense oracle needs minutes at these sizes); n = 300 also against the dense oracle."""
+    from global_racetrajectory_optimization_amd import synthetic
+    ref, nv, _ = synthetic.oval_batch(1, n=n, first=7000 + n, perturb_centreline=True)
+    ref, nv = ref[0], nv[0]
+    w_veh = 2.0
+    al, _, st, info = emu.solve_batch([dict(reftrack=ref, normvec=nv, scaling=None, kappa_bound=1.0, w_veh=w_veh)],
+                                      objective=engine.OBJ_SHORTEST_PATH)
+    assert st[0] == 0
+    x = al[0]
+    p = ref[:, :2]
+    hd = 4.0 * np.sum(nv * nv, axis=1)
+    hu = -2.0 * np.sum(nv * np.roll(nv, -1, axis=0), axis=1)
+    f = 2.0 * np.sum(nv * (2.0 * p - np.roll(p, 1, axis=0) - np.roll(p, -1, axis=0)), axis=1)
+    lo, hi = -np.maximum(ref[:, 3] - w_veh / 2, 0.001), np.maximum(ref[:, 2] - w_veh / 2, 0.001)
+    _kkt_box_certificate(lambda v: hd * v + hu * np.roll(v, -1) + np.roll(hu, 1) * np.roll(v, 1), f, lo, hi, x, 1e-8 * np.max(np.abs(f)))
+    assert 0 < info[0]["n_active_box"] < n
+    if n == 300:
+        assert np.max(np.abs(x - tph_ref.opt_shortest_path(ref, nv, w_veh))) < 1e-9
+
+
+def test_rings_between_2048_and_2208_waypoints(emu):
+    """Round-3 code ran rings of 2049 .. 2208 waypoints through a two-chunk LDS route whose second chunk read the first chunk's right-hand
+    sides where it needed its forward sweep (status 2 / metres of error; no test covered the range).  Round 4: every ring above 2048
+    waypoints takes the tridiagonal sweeps on workspace vectors.  Against CPU-B (independent assembly and solver)."""
+    from global_racetrajectory_optimization_amd import synthetic
+    from oracle import banded_ref
+    n = 2100
+    ref, nv, sc = synthetic.oval_batch(1, n=n, first=1000 + n, perturb_centreline=True)
+    a_cpu, c_cpu, st_cpu, _, _ = banded_ref.solve_batch(ref, nv, sc, 0.5, 3.0)
+    al, curv, st, info = emu.solve_batch([dict(reftrack=ref[0], normvec=nv[0], scaling=sc[0], kappa_bound=0.5, w_veh=3.0)])
+    assert st[0] == 0 and st_cpu[0] == 0
+    assert np.max(np.abs(al[0] - a_cpu[0])) < 1e-8
+    assert abs(curv[0] - c_cpu[0]) < 1e-9
 
 
 def test_shortest_path_golden_and_errors(emu, golden):

@@ -1,6 +1,7 @@
 """GPU fuzz against the banded CPU solver (oracle/banded_qp.c, "CPU-B": an independent restatement with its own assembly, band
-width and solver, pinned against the dense oracle in tests/test_oracle.py): ring sizes around every switch in the kernels (the
-all-rows Gram tile kernel from n = 256, odd / even n for the row-pair band products, partial last tiles and chunks), one centreline
+width and solver, pinned against the dense oracle in tests/test_oracle.py): ring sizes around every switch in the kernels (partial
+last chunks of the elimination, the interior point's register-resident passes up to n = 2048, the tridiagonal sweeps in LDS up to n = 2048
+and on workspace vectors beyond -- rings of 2049 .. 2208 waypoints were broken in round 3 and covered by no test), one centreline
 per problem, several vehicle widths.  The dense oracle needs a minute per N = 2000 problem; this route checks a few hundred
 full-size-class problems in seconds."""
 import numpy as np
@@ -11,7 +12,7 @@ from global_racetrajectory_optimization_amd import synthetic
 pytestmark = pytest.mark.gpu
 
 
-@pytest.mark.parametrize("n,w_veh", [(293, 2.0), (400, 3.4), (511, 1.6), (777, 3.0), (1001, 2.6), (1500, 3.4), (2000, 2.2), (2600, 3.6)])
+@pytest.mark.parametrize("n,w_veh", [(293, 2.0), (400, 3.4), (511, 1.6), (777, 3.0), (1001, 2.6), (1500, 3.4), (2000, 2.2), (2049, 2.4), (2100, 3.0), (2600, 3.6), (4100, 2.8)])
 def test_random_rings_against_banded_cpu_solver(gpu_engine, n, w_veh):
     from oracle import banded_ref
     bsz = 24

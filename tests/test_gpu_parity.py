@@ -676,6 +676,18 @@ def test_shortest_path_full_size_properties_and_oracle(gpu_engine):
                                                 w_veh=3.4)], objective=engine.OBJ_SHORTEST_PATH)
     assert st1[0] == 0
     assert np.max(np.abs(a[0] - a_ref)) < ALPHA_TOL
+    # ragged batch around the switches of the scalar tridiagonal route: one row per thread (n <= 256), partial last blocks, the
+    # workspace-vector route (n > 2048)
+    sizes = [100, 256, 257, 777, 2048, 2049, 2600, 4100]
+    probs = []
+    for k, n in enumerate(sizes):
+        r, v, _ = synthetic.oval_batch(1, n=n, first=300 + k, perturb_centreline=True)
+        probs.append(dict(reftrack=r[0], normvec=v[0], scaling=None, kappa_bound=1.0, w_veh=2.8))
+    al3, _, st3, info3 = gpu_engine.solve_batch(probs, objective=engine.OBJ_SHORTEST_PATH)
+    assert np.all(st3 == 0)
+    for k, pr in enumerate(probs):
+        viol, feas, nact = _sp_kkt(pr["reftrack"], pr["normvec"], 2.8, al3[k])
+        assert viol < 1e-8 and feas < 1e-12 and nact == info3[k]["n_active_box"]
 
 
 def test_mintime_reopt_corridor_config(gpu_engine, golden):
