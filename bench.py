@@ -46,7 +46,7 @@ if ROOT not in sys.path:
 
 INFO_DTYPE = np.dtype([("ipm_iters", "<i4"), ("as_iters", "<i4"), ("n_active_box", "<i4"), ("n_active_kappa", "<i4"),
                        ("kappa_max", "<f8"), ("kkt_res", "<f8"), ("ticks", "<i8", (8,)),
-                       ("refine_rounds", "<i4"), ("second_attempt", "<i4")])
+                       ("refine_rounds", "<i4"), ("second_attempt", "<i4"), ("f32_factorisations", "<i4"), ("reserved_", "<i4")])
 HBM_PEAK_GBS = 8000.0        # MI355X HBM3E spec peak, /opt/skills/guides/MI355X_MICROARCH.md
 FP64_PEAK_TFLOPS = 78.6      # MI355X fp64 vector = matrix peak (public spec; v_mfma_f64_16x16x4 runs at the fp64 VALU rate)
 KAPPA_BOUND, W_VEH = 0.12, 3.4
@@ -70,8 +70,12 @@ def work_model(n, info, band_e=32):
                                  spike correction: spikes (80) + the vector read and written (16)              -> 96 bytes
                  any other solve (corrector, refinement round): forward chain (160 + 8 + 40), backward chain (160 + 40 + 8),
                                  correction (80 + 16)                                                          -> 512 bytes
+                 float records (round 4; mcq_info.f32_factorisations of the interior-point factorisations -- the first four or five --
+                                 store their records as floats): D~^-1 | Lo 80, spike | y 112 (28 floats), alpha rows 40, the forward
+                                 chain's y 20:  factorisation 80 + 112 written, read back, 40 written + 65 + 16 -> 505 bytes; fused
+                                 solve 40 + 16 -> 56; solve with its own chains (80 + 8 + 20) + (80 + 20 + 8) + (40 + 16) -> 272
                  gradient      : E and E' through four solves with the tridiagonal spline matrix: 27 vector accesses -> 216 bytes
-                                 (the 65-wide bands of E and E' -- 1040 bytes -- are no longer read)
+                                 (the 65-wide bands of E and E' -- 1040 bytes -- no longer exist)
                  vector passes : one interior-point iteration reads / writes 33 vector entries (three passes of one load phase each;
                                  pass 1 in two halves), an active-set round ~30                                 -> 264 / 240 bytes
                interior-point iteration = 1 factorisation + predictor solve + corrector solve + passes (one exact gradient per problem
@@ -87,6 +91,7 @@ def work_model(n, info, band_e=32):
     ipm = info["ipm_iters"].astype(np.float64)
     act = info["as_iters"].astype(np.float64)
     ref = info["refine_rounds"].astype(np.float64)
+    f32 = info["f32_factorisations"].astype(np.float64) if "f32_factorisations" in info.dtype.names else 0.0 * ipm
     n_fac, n_sol = ipm + act, 2 * ipm + act + ref
     n_grad = 1.0 + 2 * act + ref + 1.0 + 1.0 + 1.0
     ew = 2 * band_e + 1
@@ -94,12 +99,15 @@ def work_model(n, info, band_e=32):
     b_fac, b_fused, b_solve = n * 897.0, n * 96.0, n * 512.0
     passes = ipm * n * 264.0 + act * n * 240.0
     plain = n_sol - n_fac                          # solves that run their own chains
-    streamed = float((n_fac * (b_fac + b_fused) + plain * b_solve + n_grad * grad + passes).sum())
+    # a float-record factorisation carries one fused solve (predictor) and one solve with its own chains (corrector)
+    saved = f32 * n * ((897.0 - 505.0) + (96.0 - 56.0) + (512.0 - 272.0))
+    streamed = float((n_fac * (b_fac + b_fused) + plain * b_solve + n_grad * grad + passes - saved).sum())
     banded = float((n_fac * n * (130.0 + 144.0) * 8.0 + n_sol * 2.0 * n * 144.0 * 8.0 + n_grad * 2.0 * n * ew * 8.0).sum())
     flops = float((n_fac * 2.0 * n * (640.0 + 275.0) + plain * 2.0 * 2.0 * n * 40.0 + n_grad * 2.0 * 16.0 * n).sum())
     return dict(streamed=streamed, declared=banded, flops=flops,
                 per_problem=dict(factorisations=float(n_fac.mean()), solves=float(n_sol.mean()), solves_with_own_chains=float(plain.mean()),
-                                 gradients=float(n_grad.mean()), bytes_factorisation=b_fac, bytes_fused_solve=b_fused, bytes_solve=b_solve,
+                                 gradients=float(n_grad.mean()), float_record_factorisations=float(np.mean(f32)), bytes_saved_by_float_records=float(np.mean(saved)),
+                                 bytes_factorisation=b_fac, bytes_fused_solve=b_fused, bytes_solve=b_solve,
                                  bytes_gradient=grad, bytes_vector_passes=float(passes.mean())))
 
 
@@ -194,16 +202,23 @@ def cpu_baseline(ref_b, nv_b, sc_b, alpha_gpu, curv_gpu, a_sample, b_sample):
     cores = os.cpu_count()
     n = ref_b.shape[1]
     out = {}
-    # CPU-B first (seconds)
+    # CPU-B first (seconds): built on THIS host with -O3 -march=native, one problem per hardware thread, every hardware thread
     kb = min(b_sample, ref_b.shape[0])
-    banded_ref.solve_batch(ref_b[:1], nv_b[:1], sc_b[:1], KAPPA_BOUND, W_VEH)            # builds / loads the library
+    banded_ref.solve_batch(ref_b[:1], nv_b[:1], sc_b[:1], KAPPA_BOUND, W_VEH, native=True)            # builds / loads the library
     t0 = time.perf_counter()
-    a_b, c_b, st_b, it_b, used = banded_ref.solve_batch(ref_b[:kb], nv_b[:kb], sc_b[:kb], KAPPA_BOUND, W_VEH)
+    a_b, c_b, st_b, it_b, used = banded_ref.solve_batch(ref_b[:kb], nv_b[:kb], sc_b[:kb], KAPPA_BOUND, W_VEH, nthreads=cores, native=True)
     t_b = time.perf_counter() - t0
     ok = st_b == 0
+    # ... and the portable build (no -march) on the runtime's default thread count, as rounds 1-3 quoted it
+    banded_ref.solve_batch(ref_b[:1], nv_b[:1], sc_b[:1], KAPPA_BOUND, W_VEH)
+    t0 = time.perf_counter()
+    _, _, st_p, _, used_p = banded_ref.solve_batch(ref_b[:kb], nv_b[:kb], sc_b[:kb], KAPPA_BOUND, W_VEH)
+    t_p = time.perf_counter() - t0
     out["cpu_b"] = {"value": kb / t_b, "unit": "solves/s", "cores": int(used), "kind": "port",
                     "sample": "%d of the %d N=%d problems, structure-exploiting scalar C (cyclic tridiagonal assembly, banded interior "
-                              "point + active set, oracle/banded_qp.c), one problem per thread, %d threads, %.2f s" % (kb, ref_b.shape[0], n, used, t_b),
+                              "point + active set, oracle/banded_qp.c built on this host with -O3 -march=native), one problem per thread, %d threads "
+                              "= every hardware thread, %.2f s" % (kb, ref_b.shape[0], n, used, t_b),
+                    "portable_build": {"value": kb / t_p, "cores": int(used_p), "what": "the same source without -march=native on OpenMP's default thread count"},
                     "failed": int(np.count_nonzero(~ok)),
                     "max_abs_alpha_diff_vs_gpu_m": float(np.max(np.abs(a_b[ok] - alpha_gpu[:kb][ok]))) if ok.any() else None,
                     "max_curv_err_diff_vs_gpu": float(np.max(np.abs(c_b[ok] - curv_gpu[:kb][ok]))) if ok.any() else None,
@@ -311,60 +326,66 @@ def main():
     if world != max(args.gpus, 1) and rank == 0:
         print("bench.py: --gpus %d but the launcher started %d ranks; reporting the ranks that exist" % (args.gpus, world), file=sys.stderr)
 
-    import torch
-    from global_racetrajectory_optimization_amd import engine, synthetic
+    from global_racetrajectory_optimization_amd import engine, parallel, synthetic
 
     emulate = args.emulate is not None
-    if emulate:
-        dev = torch.device("cpu")
-    else:
-        if not torch.cuda.is_available():
-            raise SystemExit("bench.py needs a GPU (the engine has no CPU path)")
-        if local_rank >= torch.cuda.device_count():
-            raise SystemExit("bench.py: rank %d has no GPU (%d visible): --gpus must not exceed the GPUs of the node"
-                             % (local_rank, torch.cuda.device_count()))
-        torch.cuda.set_device(local_rank)
-        dev = torch.device("cuda", local_rank)
-
-    def dev_sync():
-        if not emulate:
-            torch.cuda.synchronize()
+    # Nothing of torch touches the GPU (round 4): device memory, streams, events and the collective are the engine's (C ABI); torch is
+    # imported for torch.distributed alone -- the launcher's rendezvous (gloo), its barriers and the exchange of the ranks' wall times.
+    try:
+        eng = engine.Engine(0 if emulate else local_rank, lib_path=args.emulate)
+    except engine.EngineError as e:
+        raise SystemExit("bench.py needs a GPU for rank %d (the engine has no CPU path): %s" % (rank, e))
 
     dist = None
     collective = world > 1 or args.force_collective
     if collective:
+        import torch
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29531")
-        # RCCL prints its version banner (NCCL_DEBUG=VERSION is set on the GPU boxes) with printf on the first collective: keep it
-        # off stdout, where exactly ONE JSON line is expected -- file descriptor 1 points at stderr while RCCL comes up
+        # RCCL prints its version banner (NCCL_DEBUG=VERSION is set on the GPU boxes) with printf when it comes up: keep it
+        # off stdout, where exactly ONE JSON line is expected -- file descriptor 1 points at stderr meanwhile
         import ctypes
         sys.stdout.flush()
         saved_fd = os.dup(1)
         os.dup2(2, 1)
         try:
-            if emulate:
-                dist.init_process_group(backend="gloo", rank=rank, world_size=world)
-            else:
-                dist.init_process_group(backend="nccl", rank=rank, world_size=world, device_id=dev)
+            dist.init_process_group(backend="gloo", rank=rank, world_size=world)
+            if not emulate:
+                parallel.init_engine_comm(eng, dist)          # ncclCommInitRank behind the C ABI; the id travels over gloo
             dist.barrier()
-            dev_sync()
         finally:
             ctypes.CDLL(None).fflush(None)
             os.dup2(saved_fd, 1)
             os.close(saved_fd)
 
-    eng = engine.Engine(0 if emulate else local_rank, lib_path=args.emulate)
     B, n = args.batch, args.n
     f32 = args.io == "f32"
-    io_t = torch.float32 if f32 else torch.float64
+    io_np = np.float32 if f32 else np.float64
+    io_dt = eng.DT_F32 if f32 else eng.DT_F64
     solve_ms = []
-    ag_ev = []          # (start, end) CUDA events around every all-gather of the timed region
+    ag_ms_list = []     # device time of the gathers of the timed region (mcq_comm_wait)
+
+    def dbuf(arr=None, nbytes=0):
+        p = eng.alloc(arr.nbytes if arr is not None else nbytes)
+        if arr is not None:
+            eng.upload(p, arr)
+        return p
+
+    def gather(d_send, d_recv, count, np_dt, dt_code, record):
+        """The one collective of a step: RCCL through the C ABI (asynchronous, the engine's comm stream); emulated runs: gloo on host copies."""
+        if emulate:
+            local = torch.from_numpy(eng.download(d_send, (count,), np_dt))
+            full = torch.zeros((world * count,), dtype=local.dtype)
+            dist.all_gather_into_tensor(full, local)
+            eng.upload(d_recv, full.numpy())
+        else:
+            eng.comm_allgather(d_send, d_recv, count, dt_code)
 
     if args.config == 4:
         wl = config4_workload(rank, world, tuple(args.c4_tracks.split(",")), args.c4_widths, args.c4_vehicles)
-        d_lap = torch.zeros((wl["per_rank"],), dtype=torch.float64, device=dev)
-        d_all = torch.zeros((world * wl["per_rank"],), dtype=torch.float64, device=dev) if collective else None
+        d_lap = dbuf(nbytes=8 * wl["per_rank"])
+        d_all = dbuf(nbytes=8 * world * wl["per_rank"]) if collective else None
         lap_h = [None]
 
         def step(record):
@@ -375,66 +396,59 @@ def main():
             _, lap = eng.vel_profile_batch(race["kappa"], race["el_lengths"], wl["ggv"], wl["axm"], 0.75, 1200.0, wl["tops"], 1.0,
                                            track_of=wl["track_of"], n_of_track=race["m"])
             lap_h[0] = lap
-            d_lap[:lap.size] = torch.from_numpy(lap).to(dev)
             if collective:
-                dist.all_gather_into_tensor(d_all, d_lap)
+                if not emulate:
+                    ms = eng.comm_wait(0)          # the previous gather reads d_lap: done before it is overwritten
+                    if record and ms > 0.0:
+                        ag_ms_list.append(ms)
+                pad = np.zeros(wl["per_rank"])
+                pad[:lap.size] = lap
+                eng.upload(d_lap, pad)
+                gather(d_lap, d_all, wl["per_rank"], np.float64, eng.DT_F64, record)
     else:
         ref_h, nv_h, sc_h = synthetic.oval_batch(B, n=n, first=rank * B, perturb_centreline=args.perturb_centreline)
         d_org = None
         if f32 and args.f32_layout == "inc":
             rows32, org = engine.rows_to_increments(ref_h)           # float ring increments + fp64 origin per track
-            d_ref = torch.from_numpy(rows32).to(dev)
-            d_org = torch.from_numpy(org).to(dev)
+            d_ref = dbuf(rows32)
+            d_org = dbuf(org)
         else:
-            d_ref = torch.from_numpy(ref_h).to(dev).to(io_t)
-        d_nv = torch.from_numpy(nv_h).to(dev).to(io_t)
-        d_sc = torch.from_numpy(sc_h).to(dev).to(io_t)
-        # two result buffers, used in turn: the all-gather of step k (RCCL, torch's stream) runs while step k+1 solves into the other one
-        d_alpha2 = [torch.zeros((B, n), dtype=io_t, device=dev) for _ in range(2 if collective else 1)]
+            d_ref = dbuf(ref_h.astype(io_np))
+        d_nv = dbuf(nv_h.astype(io_np))
+        d_sc = dbuf(sc_h.astype(io_np))
+        # two result buffers, used in turn: the all-gather of step k (the engine's comm stream) runs while step k+1 solves into the other one
+        item = np.dtype(io_np).itemsize
+        d_alpha2 = [dbuf(nbytes=item * B * n) for _ in range(2 if collective else 1)]
         d_alpha = d_alpha2[0]
         step_no = [0]
-        gather_done = [None, None]
-        d_curv = torch.zeros((B,), dtype=torch.float64, device=dev)
-        d_status = torch.zeros((B,), dtype=torch.int32, device=dev)
-        d_info = torch.zeros((B, INFO_DTYPE.itemsize), dtype=torch.uint8, device=dev)
-        d_all = torch.zeros((world * B, n), dtype=io_t, device=dev) if collective else None
+        d_curv = dbuf(nbytes=8 * B)
+        d_status = dbuf(nbytes=4 * B)
+        d_info = dbuf(nbytes=INFO_DTYPE.itemsize * B)
+        d_all = dbuf(nbytes=item * world * B * n) if collective else None
 
         def step(record):
             slot = step_no[0] % len(d_alpha2)
             d_alpha = d_alpha2[slot]
             step_no[0] += 1
-            if gather_done[slot] is not None:
-                gather_done[slot].synchronize()      # the all-gather that last read this buffer (two steps ago) has finished
+            if collective and not emulate:
+                ms = eng.comm_wait(1)              # the gather that last read this buffer (two steps ago) has finished
+                if record and ms > 0.0:
+                    ag_ms_list.append(ms)
             if f32:     # float normals are unit vectors only to 6e-8: the engine derives them (and the scalings) in fp64
-                eng.solve_device_f32_rows(B, n, engine.F32_INCREMENTS if d_org is not None else engine.F32_ABSOLUTE, d_ref.data_ptr(),
-                                          d_org.data_ptr() if d_org is not None else None, KAPPA_BOUND, W_VEH,
-                                          d_alpha.data_ptr(), d_curv.data_ptr(), d_status.data_ptr(), d_info.data_ptr())
+                eng.solve_device_f32_rows(B, n, engine.F32_INCREMENTS if d_org is not None else engine.F32_ABSOLUTE, d_ref,
+                                          d_org, KAPPA_BOUND, W_VEH, d_alpha, d_curv, d_status, d_info)
             else:
-                eng.solve_device(B, n, d_ref.data_ptr(), d_nv.data_ptr(), d_sc.data_ptr(), KAPPA_BOUND, W_VEH,
-                                 d_alpha.data_ptr(), d_curv.data_ptr(), d_status.data_ptr(), d_info.data_ptr())
-            eng.sync()
+                eng.solve_device(B, n, d_ref, d_nv, d_sc, KAPPA_BOUND, W_VEH, d_alpha, d_curv, d_status, d_info)
             if record:
+                eng.sync()
                 solve_ms.append(eng.last_timing_ms())
             if collective:
-                if record and not emulate:
-                    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-                    e0.record()
-                    dist.all_gather_into_tensor(d_all, d_alpha)
-                    e1.record()
-                    ag_ev.append((e0, e1))
-                else:
-                    dist.all_gather_into_tensor(d_all, d_alpha)
-                if not emulate:
-                    ev = torch.cuda.Event()
-                    ev.record()
-                    gather_done[slot] = ev
+                gather(d_alpha, d_all, B * n, io_np, io_dt, record)
 
     def fence():
-        eng.sync()
-        dev_sync()
+        eng.sync()                  # the engine's stream AND its comm stream (the HIP device of this rank is idle afterwards)
         if collective:
             dist.barrier()
-            dev_sync()
 
     for _ in range(args.warmup):
         step(False)
@@ -452,16 +466,19 @@ def main():
     clocks = sampler.stop() if sampler else None
     dt, rank_ms = dt_local, [1e3 * dt_local / args.steps]
     if collective:
-        t = torch.tensor([dt_local], dtype=torch.float64, device=dev)
-        allt = torch.zeros((world,), dtype=torch.float64, device=dev)
+        t = torch.tensor([dt_local], dtype=torch.float64)
+        allt = torch.zeros((world,), dtype=torch.float64)
         dist.all_gather_into_tensor(allt, t)
-        rank_ms = [1e3 * float(v) / args.steps for v in allt.cpu()]
+        rank_ms = [1e3 * float(v) / args.steps for v in allt]
         dt = float(allt.max().item())
         if args.config != 4:
-            assert torch.equal(d_all[rank * B:(rank + 1) * B], d_alpha), "all-gather: own shard differs"
+            own = eng.download(d_all, (B, n), io_np, offset_bytes=rank * B * n * item)
+            assert np.array_equal(own, eng.download(d_alpha, (B, n), io_np)), "all-gather: own shard differs"
     ranks_seen = dist.get_world_size() if collective else 1
     assert ranks_seen == world, "process group has %d ranks, the launcher announced %d" % (ranks_seen, world)
-    ag_ms = float(np.mean([a.elapsed_time(b) for a, b in ag_ev])) if ag_ev else None
+    if collective and not emulate:
+        assert eng.comm_world() == (rank, world), "the engine's RCCL communicator is %s, the launcher announced rank %d of %d" % (eng.comm_world(), rank, world)
+    ag_ms = float(np.mean(ag_ms_list)) if ag_ms_list else None
 
     out = None
     if args.config == 4:
@@ -470,8 +487,8 @@ def main():
         gathered_laps = None
         if wl["n_total"] <= 256:
             if collective:
-                allv = d_all.cpu().numpy().reshape(world, wl["per_rank"])
-                from global_racetrajectory_optimization_amd import parallel as _par
+                allv = eng.download(d_all, (world, wl["per_rank"]), np.float64)
+                _par = parallel
                 nq = wl["n_total"] // args.c4_vehicles
                 gathered_laps = [float(v) for r in range(world)
                                  for v in allv[r, :(_par.shard_bounds(nq, world, r)[1] - _par.shard_bounds(nq, world, r)[0]) * args.c4_vehicles]]
@@ -492,10 +509,10 @@ def main():
                               "rank_ms_per_step": {"min": min(rank_ms), "max": max(rank_ms)},
                               "lap_time_range_s": [float(lap.min()), float(lap.max())]}}
     elif rank == 0:
-        status = d_status.cpu().numpy()
-        info = d_info.cpu().numpy().view(INFO_DTYPE).reshape(B)
-        alpha_gpu = d_alpha.cpu().numpy().astype(np.float64)
-        curv_gpu = d_curv.cpu().numpy()
+        status = eng.download(d_status, (B,), np.int32)
+        info = eng.download(d_info, (B,), INFO_DTYPE)
+        alpha_gpu = eng.download(d_alpha, (B, n), io_np).astype(np.float64)
+        curv_gpu = eng.download(d_curv, (B,), np.float64)
         value = world * B * args.steps / dt
         k_ms = float(np.mean([m["solve"] for m in solve_ms]))
         wm = work_model(n, info)
@@ -516,9 +533,10 @@ def main():
                        "batch_per_gpu": B, "n_waypoints": n,
                        "io": args.io + ((" rows (%s) / float alpha in HBM, fp64 arithmetic" % ("ring increments + fp64 origin" if args.f32_layout == "inc" else "absolute coordinates")) if f32 else ""),
                        "centrelines": "perturbed per track" if args.perturb_centreline else "shared",
-                       "collective": "1 all-gather of alpha per step" if collective else "none",
+                       "collective": ("1 all-gather of alpha per step: ncclAllGather (RCCL) through the C ABI, mcq_comm_allgather, on the engine's comm stream"
+                                      if collective and not emulate else "1 all-gather of alpha per step (gloo, emulated run)" if collective else "none"),
                        "ranks_seen": ranks_seen, "rank_ms_per_step": {"min": min(rank_ms), "max": max(rank_ms)},
-                       "allgather_ms": ag_ms, "allgather_dtype": str(io_t).replace("torch.", ""),
+                       "allgather_ms": ag_ms, "allgather_dtype": np.dtype(io_np).name,
                        "failed_problems": int(np.count_nonzero(status)),
                        "mean_ipm_iters": float(info["ipm_iters"].mean()), "mean_as_iters": float(info["as_iters"].mean()),
                        "mean_active_box_rows": float(info["n_active_box"].mean()),

@@ -10,7 +10,7 @@ HIPCC=${HIPCC:-/opt/rocm/bin/hipcc}
 # --gpu-max-threads-per-block=512: every device function of mcq_kernels.hip stays within 256 VGPRs (two workgroups of the solver kernel
 #   per CU).
 # ASM_OUT=<file>: also keep the device ISA of mcq_kernels.hip there (scripts/check_csr.py reads it instead of compiling a second time).
-FLAGS="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -mllvm -enable-ipra=0"
+FLAGS="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -mllvm -enable-ipra=${IPRA:-0}"
 OUT=${OUT:-libmcq.so}
 TMP=$(mktemp -d)
 trap 'rm -rf "$TMP"' EXIT

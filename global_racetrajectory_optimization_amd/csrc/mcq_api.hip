@@ -5,6 +5,7 @@
 // engine.py); a multi-GPU job is N such processes, each solving a contiguous shard of the batch.
 #include <hip/hip_runtime.h>
 
+#include <dlfcn.h>
 #include <stddef.h>
 #include <stdio.h>
 #include <stdlib.h>
@@ -61,6 +62,11 @@ struct mcq_handle {
     long long ws_bytes = 0;
     bool smem_attr_set = false;
     double* vel_scratch = nullptr;      // lap-doubled profiles of mcq_vel_profile_device, [2 nmax][batch]
+    void* comm = nullptr;               // ncclComm_t of mcq_comm_init (RCCL, loaded with dlopen)
+    int comm_rank = 0, comm_world = 0;
+    hipStream_t comm_stream = nullptr;  // the gathers run here: ordered behind the solves by an event, overlapping the NEXT solve
+    hipEvent_t comm_ready = nullptr, comm_t0[4] = {nullptr, nullptr, nullptr, nullptr}, comm_done[4] = {nullptr, nullptr, nullptr, nullptr};
+    unsigned comm_seq = 0;              // gathers enqueued so far (event ring index)
     size_t vel_scratch_bytes = 0;
     double* kbig = nullptr;             // overflow slots of the curvature-row working set (MCQ_KBIG_SLOTS x MCQ_KBIG_SLOT doubles)
     int* kbig_count = nullptr;          // slots claimed by the launch in flight
@@ -105,6 +111,7 @@ static mcq_opts resolve_opts(const mcq_opts* in)
 }
 
 extern "C" void mcq_destroy(mcq_handle* h);
+extern "C" int mcq_comm_destroy(mcq_handle* h);
 
 extern "C" int mcq_create(int device_id, mcq_handle** out)
 {
@@ -174,6 +181,7 @@ extern "C" void mcq_destroy(mcq_handle* h)
     if (h->stream) (void)hipStreamSynchronize(h->stream);
     if (h->cs_in) (void)hipStreamSynchronize(h->cs_in);
     if (h->cs_out) (void)hipStreamSynchronize(h->cs_out);
+    (void)mcq_comm_destroy(h);
     free_ws(h);
     free_stage(h);
     free_pipe(h);
@@ -281,9 +289,12 @@ static int launch(mcq_handle* h, McqBatch& B, const mcq_opts& o)
         return 0;
     }
     HIP_TRY(hipEventRecord(h->ev[0], h->stream));
-    hipLaunchKernelGGL(mcq_assemble_kernel, dim3(B.batch), dim3(256), 0, h->stream, B);
-    HIP_TRY(hipGetLastError());
-    if (B.prep_only) return 0;
+    if (B.prep_only) {
+        hipLaunchKernelGGL(mcq_assemble_kernel, dim3(B.batch), dim3(256), 0, h->stream, B);
+        HIP_TRY(hipGetLastError());
+        return 0;
+    }
+    // (no assembly launch: the solver kernel assembles its problem itself -- assemble_problem() -- since round 4)
     HIP_TRY(hipEventRecord(h->ev[1], h->stream));
     HIP_TRY(hipEventRecord(h->ev[2], h->stream));
     hipLaunchKernelGGL(mcq_solve_kernel, dim3(B.batch), dim3(256), 0, h->stream, B);
@@ -692,6 +703,7 @@ extern "C" int mcq_sync(mcq_handle* h)
     if (!h) { g_err = "mcq_sync: NULL handle"; return MCQ_E_ARG; }
     HIP_TRY(hipSetDevice(h->device));
     HIP_TRY(hipStreamSynchronize(h->stream));
+    if (h->comm_stream) HIP_TRY(hipStreamSynchronize(h->comm_stream));      // gathers in flight (mcq_comm_allgather) are work of the handle too
     return 0;
 }
 
@@ -1318,4 +1330,159 @@ extern "C" int mcq_iqp_batch(mcq_handle* h, const mcq_problem* probs, int batch,
         memcpy(normvec_out + (size_t)b * nmax * 2, nv_h[q] + (size_t)b * nmax * 2, n * 2 * sizeof(double));
     }
     return 0;
+}
+
+
+// =====================================================================================================================
+// The one collective of a multi-GPU job (include/mcq.h): ncclAllGather of RCCL on the handle's stream.  RCCL is loaded with dlopen on
+// first use -- libmcq.so has no link-time dependency on it, and a single-GPU process never maps its 570 MB.  Only the five entry
+// points below are bound; their types are restated here (rccl.h: ncclUniqueId = 128 opaque bytes, ncclComm_t an opaque pointer,
+// ncclDataType_t: ncclInt32 = 2, ncclFloat32 = 7, ncclFloat64 = 8; ncclSuccess = 0).
+// =====================================================================================================================
+namespace {
+struct RcclId { char internal[MCQ_COMM_ID_BYTES]; };
+struct Rccl {
+    void* lib = nullptr;
+    int (*GetUniqueId)(RcclId*) = nullptr;
+    int (*CommInitRank)(void**, int, RcclId, int) = nullptr;
+    int (*AllGather)(const void*, void*, size_t, int, void*, hipStream_t) = nullptr;
+    int (*CommDestroy)(void*) = nullptr;
+    const char* (*GetErrorString)(int) = nullptr;
+    std::string path;
+};
+Rccl g_rccl;
+
+int rccl_load()
+{
+    if (g_rccl.lib) return 0;
+    std::vector<std::string> cand;
+    if (const char* e = getenv("MCQ_RCCL_LIB")) cand.push_back(e);
+    if (const char* e = getenv("ROCM_PATH")) cand.push_back(std::string(e) + "/lib/librccl.so.1");
+    cand.push_back("/opt/rocm/lib/librccl.so.1");
+    cand.push_back("librccl.so.1");
+    std::string tried;
+    for (const std::string& p : cand) {
+        void* lib = dlopen(p.c_str(), RTLD_NOW | RTLD_LOCAL);
+        if (!lib) { tried += p + " (" + (dlerror() ? dlerror() : "?") + "); "; continue; }
+        g_rccl.GetUniqueId = (int (*)(RcclId*))dlsym(lib, "ncclGetUniqueId");
+        g_rccl.CommInitRank = (int (*)(void**, int, RcclId, int))dlsym(lib, "ncclCommInitRank");
+        g_rccl.AllGather = (int (*)(const void*, void*, size_t, int, void*, hipStream_t))dlsym(lib, "ncclAllGather");
+        g_rccl.CommDestroy = (int (*)(void*))dlsym(lib, "ncclCommDestroy");
+        g_rccl.GetErrorString = (const char* (*)(int))dlsym(lib, "ncclGetErrorString");
+        if (!g_rccl.GetUniqueId || !g_rccl.CommInitRank || !g_rccl.AllGather || !g_rccl.CommDestroy) {
+            tried += p + " (symbols missing); ";
+            dlclose(lib);
+            continue;
+        }
+        g_rccl.lib = lib;
+        g_rccl.path = p;
+        return 0;
+    }
+    g_err = "mcq_comm: RCCL could not be loaded: " + tried;
+    return MCQ_E_DEVICE;
+}
+
+int rccl_fail(const char* what, int rc)
+{
+    g_err = std::string(what) + " failed: " + (g_rccl.GetErrorString ? g_rccl.GetErrorString(rc) : "?") + " (" + g_rccl.path + ")";
+    return MCQ_E_DEVICE;
+}
+}   // namespace
+
+extern "C" int mcq_comm_unique_id(unsigned char id_out[MCQ_COMM_ID_BYTES])
+{
+    if (!id_out) { g_err = "mcq_comm_unique_id: id_out is NULL"; return MCQ_E_ARG; }
+    int rc = rccl_load();
+    if (rc) return rc;
+    RcclId id;
+    const int r = g_rccl.GetUniqueId(&id);
+    if (r != 0) return rccl_fail("ncclGetUniqueId", r);
+    memcpy(id_out, id.internal, MCQ_COMM_ID_BYTES);
+    return 0;
+}
+
+extern "C" int mcq_comm_init(mcq_handle* h, int rank, int world, const unsigned char id[MCQ_COMM_ID_BYTES])
+{
+    if (!h || !id || world < 1 || rank < 0 || rank >= world) { g_err = "mcq_comm_init: bad argument"; return MCQ_E_ARG; }
+    if (h->comm) { g_err = "mcq_comm_init: the handle already has a communicator"; return MCQ_E_ARG; }
+    int rc = rccl_load();
+    if (rc) return rc;
+    HIP_TRY(hipSetDevice(h->device));
+    if (!h->comm_stream) {
+        HIP_TRY(hipStreamCreate(&h->comm_stream));
+        HIP_TRY(hipEventCreate(&h->comm_ready));
+        for (int k = 0; k < 4; ++k) { HIP_TRY(hipEventCreate(&h->comm_t0[k])); HIP_TRY(hipEventCreate(&h->comm_done[k])); }
+    }
+    RcclId uid;
+    memcpy(uid.internal, id, MCQ_COMM_ID_BYTES);
+    void* comm = nullptr;
+    const int r = g_rccl.CommInitRank(&comm, world, uid, rank);
+    if (r != 0) return rccl_fail("ncclCommInitRank", r);
+    h->comm = comm;
+    h->comm_rank = rank;
+    h->comm_world = world;
+    h->comm_seq = 0;
+    return 0;
+}
+
+extern "C" int mcq_comm_allgather(mcq_handle* h, const void* send, void* recv, size_t count, int dtype)
+{
+    if (!h || !send || !recv || dtype < MCQ_DT_F64 || dtype > MCQ_DT_I32) { g_err = "mcq_comm_allgather: bad argument"; return MCQ_E_ARG; }
+    if (!h->comm) { g_err = "mcq_comm_allgather: mcq_comm_init has not been called on this handle"; return MCQ_E_ARG; }
+    if (count == 0) return 0;
+    HIP_TRY(hipSetDevice(h->device));
+    // behind everything enqueued on the handle's stream so far (the solve that filled `send`), on a stream of its own: the handle's
+    // stream goes on with the next solve while the gather runs
+    HIP_TRY(hipEventRecord(h->comm_ready, h->stream));
+    HIP_TRY(hipStreamWaitEvent(h->comm_stream, h->comm_ready, 0));
+    const unsigned slot = h->comm_seq & 3u;
+    HIP_TRY(hipEventRecord(h->comm_t0[slot], h->comm_stream));
+    const int nccl_t = dtype == MCQ_DT_F64 ? 8 : dtype == MCQ_DT_F32 ? 7 : 2;
+    const int r = g_rccl.AllGather(send, recv, count, nccl_t, h->comm, h->comm_stream);
+    if (r != 0) return rccl_fail("ncclAllGather", r);
+    HIP_TRY(hipEventRecord(h->comm_done[slot], h->comm_stream));
+    ++h->comm_seq;
+    return 0;
+}
+
+extern "C" int mcq_comm_wait(mcq_handle* h, int lag, float* ms_out)
+{
+    if (!h || lag < 0 || lag > 2) { g_err = "mcq_comm_wait: bad argument"; return MCQ_E_ARG; }
+    if (ms_out) *ms_out = 0.0f;
+    if (!h->comm || h->comm_seq <= (unsigned)lag) return 0;          // nothing (that old) in flight
+    HIP_TRY(hipSetDevice(h->device));
+    const unsigned slot = (h->comm_seq - 1u - (unsigned)lag) & 3u;
+    HIP_TRY(hipEventSynchronize(h->comm_done[slot]));
+    if (ms_out) HIP_TRY(hipEventElapsedTime(ms_out, h->comm_t0[slot], h->comm_done[slot]));
+    return 0;
+}
+
+extern "C" int mcq_comm_world(mcq_handle* h, int* rank_out, int* world_out)
+{
+    if (!h || !h->comm) { g_err = "mcq_comm_world: no communicator"; return MCQ_E_ARG; }
+    if (rank_out) *rank_out = h->comm_rank;
+    if (world_out) *world_out = h->comm_world;
+    return 0;
+}
+
+extern "C" int mcq_comm_destroy(mcq_handle* h)
+{
+    if (!h) return MCQ_E_ARG;
+    int ret = 0;
+    (void)hipSetDevice(h->device);
+    if (h->comm) {
+        if (h->stream) (void)hipStreamSynchronize(h->stream);
+        if (h->comm_stream) (void)hipStreamSynchronize(h->comm_stream);
+        const int r = g_rccl.CommDestroy(h->comm);
+        h->comm = nullptr;
+        h->comm_rank = h->comm_world = 0;
+        if (r != 0) ret = rccl_fail("ncclCommDestroy", r);
+    }
+    if (h->comm_stream) {
+        (void)hipEventDestroy(h->comm_ready);
+        for (int k = 0; k < 4; ++k) { (void)hipEventDestroy(h->comm_t0[k]); (void)hipEventDestroy(h->comm_done[k]); }
+        (void)hipStreamDestroy(h->comm_stream);
+        h->comm_stream = nullptr;
+    }
+    return ret;
 }

@@ -163,12 +163,13 @@ struct SolveCtx {
     McqWork w;
     int nm;
     mutable long long tk[8];   // phase timers (wall_clock64 ticks), meaningful on thread 0
-    mutable int refine_rounds, second_attempt;   // diagnostics for mcq_info
+    mutable int refine_rounds, second_attempt, f32_count;   // diagnostics for mcq_info
     mutable double last_step;  // length of the last interior-point step (the Tapia indicators are only trusted after a near-full one)
     int direct;                // 1: shortest-path objective -- H is a cyclic tridiagonal given entry by entry (V_SPD, V_SPU), V_F holds f
     mutable const gdouble* sp_sig;  // ... its current "factorisation": the diagonal shift and the working set (mcq_tri.inc, factor_sp)
     mutable const gschar* sp_mk;
     mutable const gdouble* kkt_w;   // saddle-point elimination: weights of the curvature rows (1 + y/t of the interior point) or nullptr
+    mutable int kkt_f32;            // ... its records are stored as floats (mcq_kkt.inc, KRec): set by factor(), read by the solves that follow
 };
 #define TICK() ((long long)wall_clock64())
 #include "mcq_kkt.inc"
@@ -177,13 +178,13 @@ struct SolveCtx {
 // =====================================================================================================================
 // K1: assembly
 // =====================================================================================================================
-__global__ void __launch_bounds__(MCQ_NT) mcq_assemble_kernel(McqBatch B)
+// Round 4: the assembly of a problem is a device function.  The solver kernel runs it as its prologue (one launch per QP pass; the
+// spline quantities go from the assembly to the solver through vectors that are still in the L2 of the same workgroup's XCD), and
+// mcq_assemble_kernel is the same function on its own for mcq_prep_device.  Returns the status it has written (uniform).
+__device__ __noinline__ int assemble_problem(const McqBatch& B, const McqWork& w, int n, double wveh)
 {
-    __shared__ double red[64];
+    double* red = g_sm + SM_RED;
     const int tid = threadIdx.x;
-    int n;
-    double kb, wveh;
-    const McqWork w = mcq_work(B, blockIdx.x, n, kb, wveh);
     const int nm = B.nmax;
     gdouble* LO = VEC(w, nm, V_LO);
     gdouble* HI = VEC(w, nm, V_HI);
@@ -235,14 +236,14 @@ __global__ void __launch_bounds__(MCQ_NT) mcq_assemble_kernel(McqBatch B)
             z.ipm_iters = z.as_iters = z.n_active_box = z.n_active_kappa = 0;
             z.kappa_max = 0.0;
             z.kkt_res = 0.0;
-            z.refine_rounds = z.second_attempt = 0;
+            z.refine_rounds = z.second_attempt = z.f32_factorisations = z.reserved_ = 0;
             for (int q = 0; q < 8; ++q) z.ticks[q] = 0;
             *(mcq_info*)w.info = z;
         }
     }
     if (st != MCQ_OK) {
         if (w.alpha) for (int i = tid; i < n; i += MCQ_NT) w.alpha[i] = 0.0;
-        return;
+        return st;
     }
     __syncthreads();
 
@@ -295,6 +296,15 @@ __global__ void __launch_bounds__(MCQ_NT) mcq_assemble_kernel(McqBatch B)
         if (B.sc_out) ((gdouble*)(B.sc_out + (size_t)blockIdx.x * nm))[i] = S[i];
     }
     __syncthreads();
+    return MCQ_OK;
+}
+
+__global__ void __launch_bounds__(MCQ_NT) mcq_assemble_kernel(McqBatch B)
+{
+    int n;
+    double kb, wveh;
+    const McqWork w = mcq_work(B, blockIdx.x, n, kb, wveh);
+    (void)assemble_problem(B, w, n, wveh);
 }
 
 // =====================================================================================================================
@@ -343,7 +353,7 @@ __global__ void __launch_bounds__(MCQ_NT) mcq_assemble_sp_kernel(McqBatch B)
             z.ipm_iters = z.as_iters = z.n_active_box = z.n_active_kappa = 0;
             z.kappa_max = 0.0;
             z.kkt_res = 0.0;
-            z.refine_rounds = z.second_attempt = 0;
+            z.refine_rounds = z.second_attempt = z.f32_factorisations = z.reserved_ = 0;
             for (int q = 0; q < 8; ++q) z.ticks[q] = 0;
             *(mcq_info*)w.info = z;
         }
@@ -367,17 +377,21 @@ __global__ void __launch_bounds__(MCQ_NT) mcq_assemble_sp_kernel(McqBatch B)
 }
 
 
-// fv: the right-hand side of the solve that follows rides through the elimination (solve(c, fv, true) then finishes it)
-__device__ __noinline__ int factor(const SolveCtx& c, const gdouble* sig, const gschar* mk, gdouble* fv)
+// fv: the right-hand side of the solve that follows rides through the elimination (solve(c, fv, true) then finishes it);
+// f32: the records of this factorisation may be stored as floats (interior-point iterations: inexact Newton directions, see KRec)
+__device__ __noinline__ int factor(const SolveCtx& c, const gdouble* sig, const gschar* mk, gdouble* fv, bool f32)
 {
     if (c.direct) return factor_sp(c, sig, mk);
-    return factor_kkt(c, sig, mk, c.kkt_w, fv);
+    c.kkt_f32 = f32 ? 1 : 0;
+    c.f32_count += f32 ? 1 : 0;
+    return f32 ? factor_kkt<true>(c, sig, mk, c.kkt_w, fv) : factor_kkt<false>(c, sig, mk, c.kkt_w, fv);
 }
 
 __device__ __noinline__ void solve(const SolveCtx& c, gdouble* v, bool fwd_done)
 {
     if (c.direct) { (void)sp_solve(c, v, v); return; }
-    solve_kkt(c, v, fwd_done);
+    if (c.kkt_f32) solve_kkt<true>(c, v, fwd_done);
+    else solve_kkt<false>(c, v, fwd_done);
 }
 
 // dst = E' src, through the spline system (mcq_tri.inc)
@@ -411,10 +425,10 @@ __device__ __noinline__ void gradient(SolveCtx& c, const gdouble* x, const gdoub
     c.tk[2] += TICK() - t0;
 }
 
-__device__ __forceinline__ int timed_factor(SolveCtx& c, const gdouble* sig, const gschar* mk, gdouble* fv = nullptr)
+__device__ __forceinline__ int timed_factor(SolveCtx& c, const gdouble* sig, const gschar* mk, gdouble* fv = nullptr, bool f32 = false)
 {
     const long long t0 = TICK();
-    const int r = factor(c, sig, mk, fv);
+    const int r = factor(c, sig, mk, fv, f32);
     c.tk[0] += TICK() - t0;
     return r;
 }
@@ -801,6 +815,19 @@ __device__ __noinline__ int ipm_box(SolveCtx& c, const McqBatch& B, const SolveS
     bool g_exact = true;
     double mu_prev = 1e300;
     int stalled = 0;
+    // Mixed precision (round 4): the FIRST factorisations of the cold interior point store their records as floats (mcq_kkt.inc, KRec).
+    // A direction from such records is exact to ~6e-8 of its own size: an inexact Newton step, which the iteration absorbs -- but on a row
+    // close to its bound, sig dx is of the size of the multiplier, so the residual of the solve is ~6e-8 z there: that is how much the carried
+    // gradient drifts per iteration, and as low as the dual residual can get on such records.  So they serve while the dual residual is
+    // far above that (MCQ_IPM_F32_RD, relative to the gradient scale: the first four or five of ~11 iterations); at the switch the gradient
+    // is recomputed exactly once, and the rest of the phase runs on fp64 records as before.
+#ifndef MCQ_IPM_F32
+#define MCQ_IPM_F32 1
+#endif
+#ifndef MCQ_IPM_F32_RD
+#define MCQ_IPM_F32_RD 1e-5
+#endif
+    bool f32 = MCQ_IPM_F32 && !resume;
     for (int it = 1; it <= B.max_ipm_iter; ++it) {
         // ---- pass 1: complementarity, dual residual, sig, predictor right-hand side ----------------------------------------
         double mu;
@@ -838,6 +865,14 @@ __device__ __noinline__ int ipm_box(SolveCtx& c, const McqBatch& B, const SolveS
 #ifdef IPM_TRACE
             if (threadIdx.x == 0) printf("ipmb it %d mu %.3e rdm %.3e exact %d resume %d\n", it, mu / (zscale * sc.wmean), rdm / zscale, (int)g_exact, (int)resume);
 #endif
+            if (f32 && it > 1 && rdm < MCQ_IPM_F32_RD * zscale) {      // float records have done their part
+                f32 = false;
+                if (!g_exact) {
+                    gradient(c, X, nullptr, VEC(c.w, nm, V_T0), G);
+                    g_exact = true;
+                    continue;
+                }
+            }
             if (conv && g_exact) return MCQ_OK;
             if (!conv) break;
             gradient(c, X, nullptr, VEC(c.w, nm, V_T0), G);     // looks converged on the carried gradient: confirm on the exact one
@@ -856,7 +891,7 @@ __device__ __noinline__ int ipm_box(SolveCtx& c, const McqBatch& B, const SolveS
         // the predictor's right-hand side (written in pass 1) rides through the factorisation: its forward substitution is done
         // when the factor is
         const int fs = timed_factor(c, VEC(c.w, c.nm, V_SIG), any_fixed ? c.w.state : nullptr,
-                                    VEC(c.w, c.nm, V_RHS));
+                                    VEC(c.w, c.nm, V_RHS), f32);
         // resumed attempt (complementarity already below 1e-10): an iterate that sits ON a bound in floating point (slack 0, sig = inf) ends
         // the attempt like a stalled complementarity does -- the pairs of the last completed iteration go to the active-set phase
         if (fs != 0) return (resume && fs == MCQ_NOT_PD) ? MCQ_OK : fs;
@@ -1382,22 +1417,25 @@ __global__ void __launch_bounds__(MCQ_NT, 2) mcq_solve_kernel(McqBatch B)
     double kbound, wveh;
     SolveCtx c;
     c.w = mcq_work(B, blockIdx.x, n, kbound, wveh);
-    if (*c.w.status != MCQ_OK) return;
-    c.nm = B.nmax;
-    c.d = mcq_dims(n);
-    for (int q = 0; q < 8; ++q) c.tk[q] = 0;
-    c.last_step = 0.0;
-    c.refine_rounds = c.second_attempt = 0;
-    c.direct = B.objective == MCQ_OBJ_SHORTEST_PATH;
-    c.kkt_w = nullptr;
-    c.sp_sig = nullptr;
-    c.sp_mk = nullptr;
     if (B.poison_lds) {      // debugging aid: whatever a phase reads from LDS without having written it shows up as NaN on every box
         for (int q = tid; q < SM_TOTAL; q += MCQ_NT) g_sm[q] = __longlong_as_double(-1LL);
         __syncthreads();
     }
     const long long t_kernel0 = TICK();
     const long long c_kernel0 = (long long)clock64();      // shader-clock counter (s_memtime): with ticks[3] the effective clock
+    if (B.objective == MCQ_OBJ_SHORTEST_PATH) {
+        if (*c.w.status != MCQ_OK) return;            // (written by mcq_assemble_sp_kernel)
+    } else if (assemble_problem(B, c.w, n, wveh) != MCQ_OK) return;
+    c.nm = B.nmax;
+    c.d = mcq_dims(n);
+    for (int q = 0; q < 8; ++q) c.tk[q] = 0;
+    c.last_step = 0.0;
+    c.refine_rounds = c.second_attempt = c.f32_count = 0;
+    c.direct = B.objective == MCQ_OBJ_SHORTEST_PATH;
+    c.kkt_w = nullptr;
+    c.kkt_f32 = 0;
+    c.sp_sig = nullptr;
+    c.sp_mk = nullptr;
     double* red = g_sm + SM_RED;
     const int nm = B.nmax;
 
@@ -1608,6 +1646,8 @@ __global__ void __launch_bounds__(MCQ_NT, 2) mcq_solve_kernel(McqBatch B)
                 o.kkt_res = sc.fscale > 0.0 ? kkt / sc.fscale : kkt;
                 o.refine_rounds = c.refine_rounds;
                 o.second_attempt = c.second_attempt;
+                o.f32_factorisations = c.f32_count;
+                o.reserved_ = 0;
                 c.tk[3] = TICK() - t_kernel0;
                 c.tk[7] = TICK() - t_epi0;          // curvature check, (rare) curvature-row phase, outputs (ticks[7])
                 c.tk[6] = (long long)clock64() - c_kernel0;

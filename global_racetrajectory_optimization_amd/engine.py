@@ -41,7 +41,8 @@ class McqOpts(ctypes.Structure):
 class McqInfo(ctypes.Structure):
     _fields_ = [("ipm_iters", ctypes.c_int), ("as_iters", ctypes.c_int), ("n_active_box", ctypes.c_int),
                 ("n_active_kappa", ctypes.c_int), ("kappa_max", ctypes.c_double), ("kkt_res", ctypes.c_double),
-                ("ticks", ctypes.c_longlong * 8), ("refine_rounds", ctypes.c_int), ("second_attempt", ctypes.c_int)]
+                ("ticks", ctypes.c_longlong * 8), ("refine_rounds", ctypes.c_int), ("second_attempt", ctypes.c_int),
+                ("f32_factorisations", ctypes.c_int), ("reserved_", ctypes.c_int)]
 
 
 class McqIqpStats(ctypes.Structure):
@@ -58,7 +59,8 @@ EXPORTED_SYMBOLS = ("mcq_create", "mcq_destroy", "mcq_last_error", "mcq_default_
                     "mcq_vel_profile_device", "mcq_vel_profile_device_ragged", "mcq_raceline_device", "mcq_normals_crossing_device",
                     "mcq_device_alloc",
                     "mcq_device_free", "mcq_copy_to_device", "mcq_copy_to_host", "mcq_sync", "mcq_stream",
-                    "mcq_last_timing", "mcq_workspace_bytes")
+                    "mcq_last_timing", "mcq_workspace_bytes",
+                    "mcq_comm_unique_id", "mcq_comm_init", "mcq_comm_allgather", "mcq_comm_wait", "mcq_comm_world", "mcq_comm_destroy")
 
 
 class EngineError(RuntimeError):
@@ -149,6 +151,18 @@ def load_library(path=None):
     lib.mcq_last_timing.restype = ctypes.c_int
     lib.mcq_workspace_bytes.argtypes = [vp]
     lib.mcq_workspace_bytes.restype = ctypes.c_longlong
+    lib.mcq_comm_unique_id.argtypes = [ctypes.c_char_p]
+    lib.mcq_comm_unique_id.restype = ctypes.c_int
+    lib.mcq_comm_init.argtypes = [vp, ctypes.c_int, ctypes.c_int, ctypes.c_char_p]
+    lib.mcq_comm_init.restype = ctypes.c_int
+    lib.mcq_comm_allgather.argtypes = [vp, vp, vp, ctypes.c_size_t, ctypes.c_int]
+    lib.mcq_comm_allgather.restype = ctypes.c_int
+    lib.mcq_comm_wait.argtypes = [vp, ctypes.c_int, ctypes.POINTER(ctypes.c_float)]
+    lib.mcq_comm_wait.restype = ctypes.c_int
+    lib.mcq_comm_world.argtypes = [vp, _ip, _ip]
+    lib.mcq_comm_world.restype = ctypes.c_int
+    lib.mcq_comm_destroy.argtypes = [vp]
+    lib.mcq_comm_destroy.restype = ctypes.c_int
     return lib
 
 
@@ -261,7 +275,8 @@ class Engine:
             off += ref.shape[0]
         infos = [dict(ipm_iters=i.ipm_iters, as_iters=i.as_iters, n_active_box=i.n_active_box,
                       n_active_kappa=i.n_active_kappa, kappa_max=i.kappa_max, kkt_res=i.kkt_res,
-                      ticks=list(i.ticks), refine_rounds=i.refine_rounds, second_attempt=i.second_attempt) for i in info]
+                      ticks=list(i.ticks), refine_rounds=i.refine_rounds, second_attempt=i.second_attempt,
+                      f32_factorisations=i.f32_factorisations) for i in info]
         return out, curv, status, infos
 
     # ------------------------------------------------------------------------------------------------------------------
@@ -711,6 +726,41 @@ class Engine:
 
     def workspace_bytes(self):
         return int(self.lib.mcq_workspace_bytes(self.h))
+
+    # ---- the one collective of a multi-GPU job: RCCL's all-gather through the C ABI, on the engine's own stream (include/mcq.h) -----
+    COMM_ID_BYTES = 128
+    DT_F64, DT_F32, DT_I32 = 0, 1, 2
+
+    def comm_unique_id(self):
+        """128 opaque bytes: created by rank 0, shipped to every rank by the launcher's rendezvous."""
+        buf = ctypes.create_string_buffer(self.COMM_ID_BYTES)
+        rc = self.lib.mcq_comm_unique_id(buf)
+        if rc != 0:
+            raise EngineError("mcq_comm_unique_id failed: %s" % self.lib.mcq_last_error().decode())
+        return buf.raw
+
+    def comm_init(self, rank, world, unique_id):
+        if len(unique_id) != self.COMM_ID_BYTES:
+            raise ValueError("comm_init: the unique id has %d bytes, not %d" % (len(unique_id), self.COMM_ID_BYTES))
+        self._check(self.lib.mcq_comm_init(self.h, int(rank), int(world), bytes(unique_id)), "mcq_comm_init")
+
+    def comm_allgather(self, d_send, d_recv, count, dtype=0):
+        """recv [world][count] <- send [count] of every rank (device pointers); asynchronous on the engine's stream."""
+        self._check(self.lib.mcq_comm_allgather(self.h, d_send, d_recv, int(count), int(dtype)), "mcq_comm_allgather")
+
+    def comm_wait(self, lag=0):
+        """Blocks until the gather enqueued `lag` gathers ago is done; returns its device time in ms (0.0 if there was none)."""
+        ms = ctypes.c_float(0.0)
+        self._check(self.lib.mcq_comm_wait(self.h, int(lag), ctypes.byref(ms)), "mcq_comm_wait")
+        return float(ms.value)
+
+    def comm_world(self):
+        r, w = ctypes.c_int(), ctypes.c_int()
+        self._check(self.lib.mcq_comm_world(self.h, ctypes.byref(r), ctypes.byref(w)), "mcq_comm_world")
+        return r.value, w.value
+
+    def comm_destroy(self):
+        self._check(self.lib.mcq_comm_destroy(self.h), "mcq_comm_destroy")
 
 
 _DEFAULT_ENGINE = None

@@ -1,14 +1,17 @@
 """
 Multi-GPU sharding of the batch axis: independent tracks / width sweeps / IQP re-linearisations are
 independent QPs, so the batch is block-partitioned over one-process-per-GPU ranks with NO data-path collective inside
-the solve; exactly one all-gather (RCCL over xGMI when the backend is "nccl") collects the alpha vectors afterwards.
+the solve; exactly one all-gather collects the alpha vectors afterwards.
 
-Device-resident since round 3: a rank's shard is packed once into padded tensors ON ITS DEVICE, solved there through the
-device entry of the C ABI (mcq_solve_device_ragged_params), and the result tensor the engine wrote is what the all-gather
-reads -- no numpy round trip between the solve and the collective.
+One process per GPU, one Engine per process.  Round 4: the gather is the ENGINE'S OWN -- RCCL's ncclAllGather behind the C ABI
+(mcq_comm_init / mcq_comm_allgather, include/mcq.h), enqueued on the engine's stream right behind the solve that filled the send
+buffer.  Nothing of torch touches the GPU: the shard lives in memory of the engine's HIP runtime (mcq_device_alloc), so there is
+no second runtime in the process, no stream of another runtime to order against and no initialisation order to get
+right.  The launcher's process group (torch.distributed, any backend -- gloo is enough) is only the rendezvous that carries rank
+0's 128-byte RCCL id to the other ranks (`init_engine_comm`).
 
-Order of initialisation on a GPU: create the process group / touch torch.cuda BEFORE the Engine (the engine's library links its
-own copy of the HIP runtime; torch's must be up first -- bench.py does the same).
+Without a communicator on the engine (the CPU tests: SIMT-interpreted library, gloo, world 2 and 4) the same packed buffers are
+gathered through `dist.all_gather_into_tensor` on host tensors -- test harness, not the product path.
 """
 import numpy as np
 
@@ -20,24 +23,47 @@ def shard_bounds(batch: int, world: int, rank: int) -> tuple:
     return lo, lo + base + (1 if rank < rem else 0)
 
 
-def solve_sharded(problems: list, engine, dist=None, device=None, **opt_kw):
+def init_engine_comm(engine, dist):
+    """Collective over the ranks of `dist` (an initialised torch.distributed, any backend): gives `engine` its RCCL communicator.
+    Rank 0 creates the id, one object broadcast ships it."""
+    rank, world = dist.get_rank(), dist.get_world_size()
+    box = [engine.comm_unique_id() if rank == 0 else None]
+    dist.broadcast_object_list(box, src=0)
+    engine.comm_init(rank, world, box[0])
+    return rank, world
+
+
+def _has_comm(engine):
+    try:
+        engine.comm_world()
+        return True
+    except Exception:
+        return False
+
+
+def solve_sharded(problems: list, engine, dist=None, **opt_kw):
     """Every rank solves its contiguous shard of `problems` on its own GPU; alpha (padded to the longest track),
     curvature errors and status words are all-gathered so that every rank returns the full batch.
 
-    problems: dicts {reftrack [n,4], normvec [n,2], scaling [n] or None, kappa_bound, w_veh} (normvec given for all).
-    dist: torch.distributed (initialised) or None for single-process.  device: torch device of this rank's tensors (the GPU the
-    engine runs on; None / "cpu" with the gloo backend and the SIMT-interpreted library of the tests).
+    problems: dicts {reftrack [n,4], normvec [n,2] or None (then for all: normals and scalings are derived on the device),
+    scaling [n] or None, kappa_bound, w_veh}.
+    dist: torch.distributed (initialised) or None for single-process.  The gather runs through the engine's RCCL communicator when it
+    has one (`init_engine_comm`), else through `dist` on host tensors (gloo: the CPU tests).
     Returns (alphas list, curv [B], status [B]).
     """
-    import torch
-
     bsz = len(problems)
     world = dist.get_world_size() if dist is not None else 1
     rank = dist.get_rank() if dist is not None else 0
-    dev = torch.device(device) if device is not None else torch.device("cpu")
+    use_rccl = _has_comm(engine)
+    if use_rccl and engine.comm_world() != (rank, world):
+        raise ValueError("solve_sharded: the engine's communicator is rank %d of %d, the process group says %d of %d"
+                         % (engine.comm_world() + (rank, world)))
     lo, hi = shard_bounds(bsz, world, rank)
     nmax = max(int(np.asarray(p["reftrack"]).shape[0]) for p in problems)
     per = max(shard_bounds(bsz, world, r)[1] - shard_bounds(bsz, world, r)[0] for r in range(world))
+    with_nv = [p.get("normvec") is not None for p in problems]
+    if any(with_nv) and not all(with_nv):
+        raise ValueError("solve_sharded: normvec must be given for all problems or for none")
     # ---- this rank's shard, padded to [per][nmax] (slots beyond the shard: n = 0, skipped by the kernels) -------------------------
     ref = np.zeros((per, nmax, 4))
     nv = np.zeros((per, nmax, 2))
@@ -48,41 +74,56 @@ def solve_sharded(problems: list, engine, dist=None, device=None, **opt_kw):
     for k, p in enumerate(problems[lo:hi]):
         r = np.asarray(p["reftrack"], dtype=np.float64)
         n = r.shape[0]
-        if p.get("normvec") is None:
-            raise ValueError("solve_sharded: normvec is required")
         ref[k, :n] = r
-        nv[k, :n] = p["normvec"]
+        if with_nv[0]:
+            nv[k, :n] = p["normvec"]
         if p.get("scaling") is not None:
             sc[k, :n] = p["scaling"]
         ns[k], kb[k], wv[k] = n, float(p["kappa_bound"]), float(p["w_veh"])
-    d_ref, d_nv, d_sc = (torch.from_numpy(a).to(dev) for a in (ref, nv, sc))
-    d_n, d_kb, d_wv = (torch.from_numpy(a).to(dev) for a in (ns, kb, wv))
-    # one result tensor per rank: [per][nmax + 2] = alpha | curv_error | status -- the engine writes alpha straight into its rows
-    # (row stride nmax + 2 is not what the entry expects, so alpha gets its own [per][nmax] tensor and is packed on the device)
-    d_alpha = torch.zeros((per, nmax), dtype=torch.float64, device=dev)
-    d_curv = torch.zeros((per,), dtype=torch.float64, device=dev)
-    d_status = torch.zeros((per,), dtype=torch.int32, device=dev)
-    if hi > lo:
-        engine.solve_device_ragged_params(per, nmax, d_n.data_ptr(), d_ref.data_ptr(), d_nv.data_ptr(), d_sc.data_ptr(), 0.0, 0.0,
-                                          d_kb.data_ptr(), d_wv.data_ptr(), d_alpha.data_ptr(), d_curv.data_ptr(), d_status.data_ptr(),
-                                          **opt_kw)
-        engine.sync()                                       # the engine's stream is not torch's: done before the collective reads
-    local = torch.cat((d_alpha, d_curv[:, None], d_status.to(torch.float64)[:, None]), dim=1).contiguous()
-    if dist is None or world == 1:
-        full = local[None]
-    else:
-        gathered = torch.zeros((world * per, nmax + 2), dtype=torch.float64, device=dev)
-        dist.all_gather_into_tensor(gathered, local)       # the single collective of the job
-        assert dist.get_world_size() == world
-        full = gathered.view(world, per, nmax + 2)
-    full = full.cpu().numpy()
+    # one send buffer per rank, [alpha per x nmax | curv per | status per (int32 in the first half of `per` doubles)]: the engine writes
+    # its outputs straight into it, the collective reads it
+    count = per * nmax + 2 * per
+    bufs = []
+
+    def dev(arr=None, nbytes=0):
+        p = engine.alloc(arr.nbytes if arr is not None else nbytes)
+        bufs.append(p)
+        if arr is not None:
+            engine.upload(p, arr)
+        return p
+
+    try:
+        d_ref, d_sc, d_n, d_kb, d_wv = dev(ref), dev(sc), dev(ns), dev(kb), dev(wv)
+        d_nv = dev(nv) if with_nv[0] else None
+        d_send = dev(nbytes=8 * count)                      # (mcq_device_alloc zero-fills: empty shards gather zeros)
+        d_alpha, d_curv, d_status = d_send, d_send + 8 * per * nmax, d_send + 8 * (per * nmax + per)
+        if hi > lo:
+            engine.solve_device_ragged_params(per, nmax, d_n, d_ref, d_nv, d_sc, 0.0, 0.0, d_kb, d_wv, d_alpha, d_curv, d_status,
+                                              **opt_kw)
+        if world == 1 and not use_rccl:
+            full = engine.download(d_send, (1, count), np.float64)
+        elif use_rccl:
+            d_recv = dev(nbytes=8 * count * world)
+            engine.comm_allgather(d_send, d_recv, count, engine.DT_F64)       # the single collective of the job (engine's stream)
+            full = engine.download(d_recv, (world, count), np.float64)        # (blocking copy on the same stream: waits for it)
+        else:
+            import torch
+            local = torch.from_numpy(engine.download(d_send, (count,), np.float64))
+            gathered = torch.zeros((world * count,), dtype=torch.float64)
+            dist.all_gather_into_tensor(gathered, local)                      # test harness (gloo)
+            full = gathered.numpy().reshape(world, count)
+    finally:
+        for p in bufs:
+            engine.free(p)
     out_a, out_c, out_s = [], np.zeros(bsz), np.zeros(bsz, dtype=np.int32)
     for r in range(world):
         rlo, rhi = shard_bounds(bsz, world, r)
+        al = full[r, :per * nmax].reshape(per, nmax)
+        cu = full[r, per * nmax:per * nmax + per]
+        st = np.ascontiguousarray(full[r, per * nmax + per:]).view(np.int32)[:per]
         for k in range(rhi - rlo):
             n = int(np.asarray(problems[rlo + k]["reftrack"]).shape[0])
-            row = full[r, k]
-            out_a.append(row[:n].copy())
-            out_c[rlo + k] = row[nmax]
-            out_s[rlo + k] = int(row[nmax + 1])
+            out_a.append(al[k, :n].copy())
+            out_c[rlo + k] = cu[k]
+            out_s[rlo + k] = int(st[k])
     return out_a, out_c, out_s

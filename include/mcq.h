@@ -94,22 +94,24 @@ typedef struct {
 
 /* per-problem diagnostics (optional output) */
 typedef struct {
-    int ipm_iters;      /* interior-point iterations (one banded factorisation each) */
-    int as_iters;       /* active-set (block pivoting) iterations (one banded factorisation each) */
+    int ipm_iters;      /* interior-point iterations (one factorisation each) */
+    int as_iters;       /* active-set (block pivoting) iterations (one factorisation each) */
     int n_active_box;   /* box rows active at the optimum */
     int n_active_kappa; /* curvature rows active at the optimum */
     double kappa_max;   /* max_i |k_ref_i + (E a)_i| at the returned a */
     double kkt_res;     /* max free-gradient magnitude relative to max |f| */
     /* device wall-clock (s_memrealtime, 100 MHz ticks) spent by this problem's workgroup in the phases of the solver
-     * kernel: [0] banded factorisations, [1] triangular solves, [2] gradient band products, [3] whole kernel,
-     * [4] / [5] forward / backward interior sweeps of the triangular solves as wave 0 sees them (part of [1]);
-     * [6] the same span as [3] in shader-clock cycles (s_memtime): [6] / [3] x 100 MHz = the clock the CU actually ran at;
-     * a -DMCQ_FINE_TIMERS build reports the inside of the factorisation in [4..6] instead (phase 1, phase 2, tail) */
+     * kernel: [0] factorisations, [1] solves, [2] gradients (E, E' through the spline system), [3] whole kernel (assembly included),
+     * [4] / [5] the interior-point / the active-set phase, [7] curvature check, (rare) curvature-row phase, outputs;
+     * [6] the same span as [3] in shader-clock cycles (s_memtime): [6] / [3] x 100 MHz = the clock the CU actually ran at */
     long long ticks[8];
     int refine_rounds;  /* fp64 refinement rounds run on the final working set (<= opts.refine_steps) */
     int second_attempt; /* bit 0: the active-set phase ran out of its first budget and the interior point was resumed to
                            mu = 1e-13 (degenerate / very ill-conditioned instance); bit 1: a warm start (mcq_opts.warm_start)
                            was abandoned for the cold path */
+    int f32_factorisations;  /* of ipm_iters: factorisations whose records were stored as floats (the first interior-point
+                                iterations, while the dual residual is far above what such records can resolve; round 4) */
+    int reserved_;
 } mcq_info;
 
 int mcq_create(int device_id, mcq_handle** out);
@@ -324,6 +326,35 @@ int mcq_last_timing(mcq_handle* h, float ms[5]);
 
 /* Bytes of device workspace the handle currently holds (for DESIGN.md / bench reporting). */
 long long mcq_workspace_bytes(mcq_handle* h);
+
+/* ---- the one collective of a multi-GPU job (north_star: "a single RCCL all-gather over xGMI to collect the alpha
+ *      vectors").  One process per GPU, one handle per process; independent QPs are block-partitioned over the ranks and every rank
+ *      solves its shard with the entries above -- no collective inside a solve.  The gather is the engine's own: ncclAllGather of RCCL
+ *      (loaded with dlopen on first use: $MCQ_RCCL_LIB, else $ROCM_PATH/lib/librccl.so.1, else /opt/rocm/lib/librccl.so.1, else
+ *      librccl.so.1 -- a process that never gathers never loads it), enqueued on the HANDLE'S stream, i.e. ordered after the solves that
+ *      produced the send buffer and overlapping nothing it should not; no torch, no second HIP runtime in the process.
+ *      Reference side: nothing to replace -- the reference is a single-process script; a caller that shards its sweeps
+ *      [REF main_globaltraj.py:441-505, the lap-time matrix loops] would call these three.
+ *   mcq_comm_unique_id   rank 0 creates the 128-byte id and ships it to the other ranks by whatever means the launcher offers
+ *                        (bench.py: one broadcast over the gloo rendezvous of torch.distributed.run; a file; MPI ...)
+ *   mcq_comm_init        collective over all ranks: ncclCommInitRank on the handle's device
+ *   mcq_comm_allgather   recv [world][count] <- send [count] of every rank, device pointers, dtype MCQ_DT_*.  Asynchronous: ordered behind
+ *                        everything enqueued on the handle's stream so far (the solve that filled `send`), but on a stream of its own,
+ *                        so the handle's stream goes on with the NEXT solve while the gather runs (keep two send buffers and alternate).
+ *                        `send` must not be overwritten and `recv` not read before mcq_comm_wait / mcq_sync.  world == 1: the same call
+ *                        path (RCCL is initialised and used).
+ *   mcq_comm_wait        blocks the host until the gather enqueued `lag` gathers ago has finished (0: the latest, 1: the one before:
+ *                        what a caller alternating two send buffers waits for before it reuses one); ms_out (optional): its duration
+ *                        on the device.  mcq_sync waits for all of them.
+ *   mcq_comm_destroy     also done by mcq_destroy */
+#define MCQ_COMM_ID_BYTES 128
+enum { MCQ_DT_F64 = 0, MCQ_DT_F32 = 1, MCQ_DT_I32 = 2 };
+int mcq_comm_unique_id(unsigned char id_out[MCQ_COMM_ID_BYTES]);
+int mcq_comm_init(mcq_handle* h, int rank, int world, const unsigned char id[MCQ_COMM_ID_BYTES]);
+int mcq_comm_allgather(mcq_handle* h, const void* send, void* recv, size_t count, int dtype);
+int mcq_comm_wait(mcq_handle* h, int lag, float* ms_out);
+int mcq_comm_world(mcq_handle* h, int* rank_out, int* world_out);      /* MCQ_E_ARG if no communicator was initialised */
+int mcq_comm_destroy(mcq_handle* h);
 
 #ifdef __cplusplus
 }

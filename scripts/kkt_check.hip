@@ -1,9 +1,12 @@
 // kkt_check.hip -- DIAGNOSTIC (not part of the library): the saddle-point elimination of mcq_kkt.inc in isolation.  One workgroup per problem
 // copy, `reps` factorisations + solves of the same system; every solution is compared with the first one (determinism: races show up as
 // differences between repetitions) and with a dense LU of the same saddle-point system on the host (correctness).
-//   hipcc --offload-arch=gfx950 -O3 -std=c++17 -mllvm -amdgpu-mfma-vgpr-form -mllvm -enable-ipra=0 -o kc scripts/kkt_check.hip ;  ./kc [n 333] [reps 50] [batch 4] [sigma exponent range 12] [host reference 1] [fused 0] [pinned fraction 0]
+//   hipcc --offload-arch=gfx950 -O3 -std=c++17 -mllvm -enable-ipra=0 --gpu-max-threads-per-block=512 [-DKKT_TIMERS=1] [-DKC_F32=1] -o kc scripts/kkt_check.hip ;  ./kc [n 333] [reps 50] [batch 4] [sigma exponent range 12] [host reference 1] [fused 0] [pinned fraction 0]
 // (also builds against tests/emu: g++ -O2 -std=c++17 -x c++ -I tests/emu/include scripts/kkt_check.hip)
 #include "../global_racetrajectory_optimization_amd/csrc/mcq_kernels.hip"
+#ifndef KC_F32
+#define KC_F32 0      /* 1: the records of the elimination stored as floats (KRec<true>): timing only -- the comparison with the dense LU then shows ~1e-7 */
+#endif
 
 #include <stdio.h>
 #include <string.h>
@@ -21,7 +24,7 @@ __global__ void __launch_bounds__(MCQ_NT, 2) kc_kernel(McqBatch B, int reps, con
     c.d = mcq_dims(n);
     for (int q = 0; q < 8; ++q) c.tk[q] = 0;
     c.last_step = 0.0;
-    c.refine_rounds = c.second_attempt = 0;
+    c.refine_rounds = c.second_attempt = c.f32_count = 0;
     c.direct = 0;
     c.kkt_w = nullptr;
     gdouble* SIG = VEC(c.w, c.nm, V_SIG);
@@ -32,9 +35,9 @@ __global__ void __launch_bounds__(MCQ_NT, 2) kc_kernel(McqBatch B, int reps, con
         for (int i = threadIdx.x; i < n; i += MCQ_NT) RHS[i] = rhs0[i];
         __syncthreads();
         const long long t0 = (long long)wall_clock64();
-        fs |= factor_kkt(c, nosig ? nullptr : SIG, masked ? c.w.state : nullptr, nullptr, fused ? RHS : nullptr);
+        fs |= factor_kkt<KC_F32 != 0>(c, nosig ? nullptr : SIG, masked ? c.w.state : nullptr, nullptr, fused ? RHS : nullptr);
         const long long t1 = (long long)wall_clock64();
-        solve_kkt(c, RHS, fused != 0);
+        solve_kkt<KC_F32 != 0>(c, RHS, fused != 0);
         const long long t2 = (long long)wall_clock64();
         tf += t1 - t0; ts += t2 - t1;
         for (int i = threadIdx.x; i < n; i += MCQ_NT) out[((size_t)blockIdx.x * reps + r) * n + i] = RHS[i];

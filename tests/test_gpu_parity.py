@@ -159,16 +159,21 @@ def test_full_size_oval_properties(gpu_engine):
 
 
 def test_long_ring_general_path_properties(gpu_engine):
-    """N = 3000 (> 2048 waypoints: the interior point's general vector passes instead of the register-resident ones): KKT
-    certificate, feasibility, start-index rotation."""
+    """N = 3000 (> 2048 waypoints: the interior point's general vector passes instead of the register-resident ones, the tridiagonal
+    sweeps on workspace vectors instead of LDS): against CPU-B (independent assembly and solver), feasibility, start-index rotation.
+    (The engine's self-reported KKT residual is only a sanity bound here: 1.2e-9 at this size since E is applied untruncated.)"""
+    from oracle import banded_ref
     ref, nv, sc = synthetic.oval_batch(2, n=3000)
     probs = [dict(reftrack=ref[b], normvec=nv[b], scaling=sc[b], kappa_bound=0.12, w_veh=3.4) for b in range(2)]
     al, curv, st, info = gpu_engine.solve_batch(probs)
     assert np.all(st == 0)
+    a_cpu, c_cpu, st_cpu, _, _ = banded_ref.solve_batch(ref, nv, sc, 0.12, 3.4)
+    assert np.all(st_cpu == 0)
     for b in range(2):
         lo, hi = -(ref[b, :, 3] - 1.7), ref[b, :, 2] - 1.7
         assert np.all(al[b] >= lo - 1e-12) and np.all(al[b] <= hi + 1e-12)
-        assert info[b]["kkt_res"] < 1e-9 and 0 < info[b]["n_active_box"] < 3000
+        assert np.max(np.abs(al[b] - a_cpu[b])) < 1e-7 and abs(curv[b] - c_cpu[b]) < 1e-8
+        assert info[b]["kkt_res"] < 5e-9 and 0 < info[b]["n_active_box"] < 3000
     r = 777
     pr = dict(reftrack=np.roll(ref[0], r, axis=0), normvec=np.roll(nv[0], r, axis=0), scaling=np.roll(sc[0], r),
               kappa_bound=0.12, w_veh=3.4)
@@ -910,9 +915,10 @@ def test_config4_full_size_lap_time_matrix(gpu_engine, golden):
 
 
 def test_bench_force_collective_initialises_rccl():
-    """The N > 1 path of bench.py on a 1-GPU box: `--force-collective` initialises RCCL (backend "nccl"), runs the
-    all-gather of alpha inside the timed region and checks the own shard -- so every round's GPU suite exercises the collective's
-    start-up, stream ordering against the engine's stream, and the line's multi-GPU fields."""
+    """The N > 1 path of bench.py on a 1-GPU box: `--force-collective` brings up RCCL THROUGH THE C ABI (mcq_comm_init: the id travels
+    over the gloo rendezvous; ncclAllGather on the engine's comm stream, round 4 -- no torch on the GPU), runs the all-gather of alpha
+    inside the timed region and checks the own shard -- so every round's GPU suite exercises the collective's start-up, its ordering
+    behind the solves, and the line's multi-GPU fields."""
     import json
     import os
     import subprocess
@@ -930,9 +936,47 @@ def test_bench_force_collective_initialises_rccl():
     assert len(lines) == 1, res.stdout
     rec = json.loads(lines[0])
     c = rec["config"]
-    assert c["collective"] == "1 all-gather of alpha per step" and c["ranks_seen"] == 1 and rec["n_gpus"] == 1
+    assert c["collective"].startswith("1 all-gather of alpha per step: ncclAllGather (RCCL) through the C ABI")
+    assert c["ranks_seen"] == 1 and rec["n_gpus"] == 1
     assert c["allgather_ms"] is not None and np.isfinite(c["allgather_ms"]) and 0.0 < c["allgather_ms"] < 50.0
     assert c["failed_problems"] == 0 and rec["value"] > 0
+
+
+def test_engine_collective_and_sharded_solve_on_one_rank(gpu_engine, golden):
+    """The C ABI's collective on its own (mcq_comm_*: RCCL loaded with dlopen, one rank) and parallel.solve_sharded's device-resident
+    path through it (that path had no GPU test): gathered buffers equal the send buffers bit for bit, for every dtype; the
+    sharded solve returns what the host-buffer entry returns; a batch without normals is accepted (derived on the device)."""
+    from global_racetrajectory_optimization_amd import parallel
+    eng = engine.Engine(0)           # a handle of its own: the session's engine keeps no communicator
+    try:
+        eng.comm_init(0, 1, eng.comm_unique_id())
+        assert eng.comm_world() == (0, 1)
+        rng = np.random.default_rng(5)
+        for np_dt, code in ((np.float64, eng.DT_F64), (np.float32, eng.DT_F32), (np.int32, eng.DT_I32)):
+            a = (rng.standard_normal(70001) * 1000).astype(np_dt)
+            d_s, d_r = eng.alloc(a.nbytes), eng.alloc(a.nbytes)
+            eng.upload(d_s, a)
+            eng.comm_allgather(d_s, d_r, a.size, code)
+            assert eng.comm_wait(0) >= 0.0
+            assert np.array_equal(eng.download(d_r, a.shape, np_dt), a)
+            eng.free(d_s)
+            eng.free(d_r)
+        probs = [dict(reftrack=golden[t]["reftrack"], normvec=golden[t]["normvec"], scaling=golden[t]["scaling"], kappa_bound=0.12, w_veh=3.4)
+                 for t in ("rounded_rectangle", "handling_track", "modena_2019")]
+        a_s, c_s, s_s = parallel.solve_sharded(probs, eng)
+        a_h, c_h, s_h, _ = gpu_engine.solve_batch(probs)
+        assert list(s_s) == list(s_h) == [0, 0, 0] and np.array_equal(c_s, c_h)
+        assert all(np.array_equal(x, y) for x, y in zip(a_s, a_h))
+        bare = [dict(p, normvec=None, scaling=None) for p in probs]
+        a_b, _, s_b = parallel.solve_sharded(bare, eng)
+        assert list(s_b) == [0, 0, 0] and max(float(np.max(np.abs(x - y))) for x, y in zip(a_b, a_h)) < 1e-6
+        with pytest.raises(ValueError, match="for all problems or for none"):
+            parallel.solve_sharded([probs[0], bare[1]], eng)
+        eng.comm_destroy()
+        with pytest.raises(engine.EngineError):
+            eng.comm_world()
+    finally:
+        eng.close()
 
 
 def test_curvature_row_overflow_slots_against_dense_gi(gpu_engine):
