@@ -11,6 +11,7 @@
 #include <stdlib.h>
 #include <string.h>
 
+#include <algorithm>
 #include <string>
 #include <vector>
 
@@ -62,6 +63,8 @@ struct mcq_handle {
     long long ws_bytes = 0;
     bool smem_attr_set = false;
     double* vel_scratch = nullptr;      // lap-doubled profiles of mcq_vel_profile_device, [2 nmax][batch]
+    mcq_iqp_round_cb iqp_cb = nullptr;  // mcq_iqp_set_round_callback
+    void* iqp_cb_user = nullptr;
     void* comm = nullptr;               // ncclComm_t of mcq_comm_init (RCCL, loaded with dlopen)
     int comm_rank = 0, comm_world = 0;
     hipStream_t comm_stream = nullptr;  // the gathers run here: ordered behind the solves by an event, overlapping the NEXT solve
@@ -808,6 +811,14 @@ extern "C" int mcq_solve_host(mcq_handle* h, int batch, int n, const double* ref
     HIP_TRY_SYNC(hipMemcpyAsync(status_out, h->d_status, batch * sizeof(int), hipMemcpyDeviceToHost, h->stream));
     if (info_out) HIP_TRY_SYNC(hipMemcpyAsync(info_out, h->d_info, batch * sizeof(mcq_info), hipMemcpyDeviceToHost, h->stream));
     HIP_TRY(hipStreamSynchronize(h->stream));
+    // problems that found every overflow slot of the launch taken (MCQ_KAPPA_NO_SLOT): each again in a launch of its own
+    for (int b = 0; batch > 1 && b < batch; ++b)
+        if (status_out[b] == MCQ_KAPPA_NO_SLOT) {
+            const size_t o1 = (size_t)b * n;
+            rc = mcq_solve_host(h, 1, n, reftrack + 4 * o1, normvec ? normvec + 2 * o1 : nullptr, scaling ? scaling + o1 : nullptr, kappa_bound,
+                                w_veh, opts, alpha_out + o1, curv_err_out + b, status_out + b, info_out ? info_out + b : nullptr);
+            if (rc) return rc;
+        }
     return 0;
 }
 
@@ -842,6 +853,13 @@ extern "C" int mcq_solve_batch_f32(mcq_handle* h, int batch, int n, int layout, 
     HIP_TRY_SYNC(hipMemcpyAsync(status_out, h->d_status, batch * sizeof(int), hipMemcpyDeviceToHost, h->stream));
     if (info_out) HIP_TRY_SYNC(hipMemcpyAsync(info_out, h->d_info, batch * sizeof(mcq_info), hipMemcpyDeviceToHost, h->stream));
     HIP_TRY(hipStreamSynchronize(h->stream));
+    for (int b = 0; batch > 1 && b < batch; ++b)          // MCQ_KAPPA_NO_SLOT: again in a launch of its own (see mcq_solve_host)
+        if (status_out[b] == MCQ_KAPPA_NO_SLOT) {
+            const size_t o1 = (size_t)b * n;
+            rc = mcq_solve_batch_f32(h, 1, n, layout, reftrack + 4 * o1, origin ? origin + 2 * (size_t)b : nullptr, kappa_bound, w_veh, opts,
+                                     alpha_out + o1, curv_err_out + b, status_out + b, info_out ? info_out + b : nullptr);
+            if (rc) return rc;
+        }
     return 0;
 }
 
@@ -1083,6 +1101,14 @@ extern "C" int mcq_iqp_device(mcq_handle* h, int batch, int nmax, int* n_io, dou
                 stats->fallbacks[it - 1] = fb;
             }
         }
+        if (h->iqp_cb) {        // print_debug: the pass's curvature errors and who ran it, before the termination test decides
+            std::vector<double> cv((size_t)batch);
+            std::vector<int> lv((size_t)batch);
+            if (hipMemcpyAsync(cv.data(), pass_curv, batch * sizeof(double), hipMemcpyDeviceToHost, h->stream) != hipSuccess ||
+                hipMemcpyAsync(lv.data(), live, batch * sizeof(int), hipMemcpyDeviceToHost, h->stream) != hipSuccess ||
+                hipStreamSynchronize(h->stream) != hipSuccess) { err = MCQ_E_DEVICE; break; }
+            h->iqp_cb(h->iqp_cb_user, it, batch, cv.data(), lv.data());
+        }
         if (hipMemsetAsync(live_count, 0, sizeof(int), h->stream) != hipSuccess) { err = MCQ_E_DEVICE; break; }
         S.phase = 0;
         S.round = it;
@@ -1110,9 +1136,12 @@ extern "C" int mcq_iqp_device(mcq_handle* h, int batch, int nmax, int* n_io, dou
     if (stats) {
         // QP passes summed over the tracks = sum of the rounds every track ran (the live count is only read back from round
         // iters_min on: counting launches x live tracks over-counted tracks that failed in an early round)
-        std::vector<int> rv((size_t)batch);
-        HIP_TRY(hipMemcpy(rv.data(), rounds_out, batch * sizeof(int), hipMemcpyDeviceToHost));
-        for (int k = 0; k < batch; ++k) solves += rv[k];
+        // (a statistic: a failed read-back must not discard the run -- qp_solves = -1 then; tracks that came in empty ran no QP)
+        std::vector<int> rv((size_t)batch), nf((size_t)batch);
+        if (hipMemcpy(rv.data(), rounds_out, batch * sizeof(int), hipMemcpyDeviceToHost) == hipSuccess &&
+            hipMemcpy(nf.data(), n_io, batch * sizeof(int), hipMemcpyDeviceToHost) == hipSuccess) {
+            for (int k = 0; k < batch; ++k) if (nf[k] > 0) solves += rv[k];
+        } else solves = -1;
         stats->rounds = rounds;
         stats->qp_solves = (int)solves;
     }
@@ -1225,12 +1254,47 @@ extern "C" int mcq_solve_batch(mcq_handle* h, const mcq_problem* probs, int batc
     HIP_TRY_SYNC(hipMemcpyAsync(P.info, h->d_info, batch * sizeof(mcq_info), hipMemcpyDeviceToHost, h->stream));
     HIP_TRY(hipStreamSynchronize(h->stream));
     size_t off = 0;
+    std::vector<size_t> offs((size_t)batch);
+    std::vector<int> retry;
     for (int b = 0; b < batch; ++b) {
         const size_t n = (size_t)probs[b].n;
         memcpy(alpha_out + off, P.alpha + (size_t)b * nmax, n * sizeof(double));
+        offs[(size_t)b] = off;
         off += n;
         if (info_out) info_out[b] = P.info[b];
+        if (status_out[b] == MCQ_KAPPA_NO_SLOT) retry.push_back(b);
     }
+    // Problems that found every overflow slot of the launch taken: again, MCQ_KBIG_SLOTS at a time -- a launch of at most that many
+    // problems cannot run out of slots, so the result of every problem is what a launch of its own gives, whatever order the
+    // workgroups of the big launch were scheduled in.
+    for (size_t g0 = 0; g0 < retry.size(); g0 += MCQ_KBIG_SLOTS) {
+        const int cnt = (int)std::min<size_t>(MCQ_KBIG_SLOTS, retry.size() - g0);
+        std::vector<mcq_problem> sub((size_t)cnt);
+        size_t tot = 0;
+        for (int k = 0; k < cnt; ++k) { sub[(size_t)k] = probs[retry[g0 + k]]; tot += (size_t)sub[(size_t)k].n; }
+        std::vector<double> a(tot), cu((size_t)cnt);
+        std::vector<int> st((size_t)cnt);
+        std::vector<mcq_info> inf((size_t)cnt);
+        rc = mcq_solve_batch(h, sub.data(), cnt, opts, a.data(), cu.data(), st.data(), inf.data());
+        if (rc) return rc;
+        size_t o2 = 0;
+        for (int k = 0; k < cnt; ++k) {
+            const int b = retry[g0 + k];
+            memcpy(alpha_out + offs[(size_t)b], a.data() + o2, (size_t)sub[(size_t)k].n * sizeof(double));
+            o2 += (size_t)sub[(size_t)k].n;
+            curv_err_out[b] = cu[(size_t)k];
+            status_out[b] = st[(size_t)k];
+            if (info_out) info_out[b] = inf[(size_t)k];
+        }
+    }
+    return 0;
+}
+
+extern "C" int mcq_iqp_set_round_callback(mcq_handle* h, mcq_iqp_round_cb cb, void* user)
+{
+    if (!h) { g_err = "mcq_iqp_set_round_callback: NULL handle"; return MCQ_E_ARG; }
+    h->iqp_cb = cb;
+    h->iqp_cb_user = cb ? user : nullptr;
     return 0;
 }
 

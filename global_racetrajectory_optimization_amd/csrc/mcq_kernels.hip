@@ -1581,7 +1581,7 @@ __global__ void __launch_bounds__(MCQ_NT, 2) mcq_solve_kernel(McqBatch B)
                     status = active_set(c, B, true, false, B.max_as_iter, sc, it2, kkt, nact_kappa, false,
                                         kappa_mem_slot(B.kbig + (size_t)slot * MCQ_KBIG_SLOT));
                     as_iters += it2;
-                }
+                } else status = MCQ_KAPPA_NO_SLOT;        // not a verdict on the problem: the host entries re-launch it (mcq_api.hip)
             }
         }
         for (int i = tid; i < n; i += MCQ_NT) X[i] = fmin(fmax(X[i], LO[i]), HI[i]);

@@ -18,7 +18,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 DEFAULT_LIB = os.path.join(_HERE, "csrc", "libmcq.so")
 
 STATUS_OK, STATUS_INFEASIBLE, STATUS_NOT_PD, STATUS_ITER_CAP, STATUS_BAD_INPUT, STATUS_KAPPA_INFEASIBLE, \
-    STATUS_KAPPA_ACTIVE, STATUS_RING_OVERFLOW = range(8)
+    STATUS_KAPPA_ACTIVE, STATUS_RING_OVERFLOW, STATUS_KAPPA_NO_SLOT = range(9)
 
 _dp = ctypes.POINTER(ctypes.c_double)
 _ip = ctypes.POINTER(ctypes.c_int)
@@ -53,7 +53,7 @@ class McqIqpStats(ctypes.Structure):
 IQP_TRACE = 16      # MCQ_IQP_TRACE
 
 EXPORTED_SYMBOLS = ("mcq_create", "mcq_destroy", "mcq_last_error", "mcq_default_opts", "mcq_solve_batch", "mcq_solve_host",
-                    "mcq_iqp_device", "mcq_iqp_batch", "mcq_host_alloc", "mcq_host_free",
+                    "mcq_iqp_device", "mcq_iqp_batch", "mcq_iqp_set_round_callback", "mcq_host_alloc", "mcq_host_free",
                     "mcq_solve_device", "mcq_solve_device_f32", "mcq_solve_device_f32_rows", "mcq_solve_batch_f32",
                     "mcq_solve_host_pipelined", "mcq_solve_device_ragged", "mcq_solve_device_ragged_params", "mcq_prep_device", "mcq_relinearise_device",
                     "mcq_vel_profile_device", "mcq_vel_profile_device_ragged", "mcq_raceline_device", "mcq_normals_crossing_device",
@@ -61,6 +61,9 @@ EXPORTED_SYMBOLS = ("mcq_create", "mcq_destroy", "mcq_last_error", "mcq_default_
                     "mcq_device_free", "mcq_copy_to_device", "mcq_copy_to_host", "mcq_sync", "mcq_stream",
                     "mcq_last_timing", "mcq_workspace_bytes",
                     "mcq_comm_unique_id", "mcq_comm_init", "mcq_comm_allgather", "mcq_comm_wait", "mcq_comm_world", "mcq_comm_destroy")
+
+
+IQP_ROUND_CB = ctypes.CFUNCTYPE(None, ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.POINTER(ctypes.c_double), ctypes.POINTER(ctypes.c_int))
 
 
 class EngineError(RuntimeError):
@@ -99,6 +102,8 @@ def load_library(path=None):
                                   ctypes.c_int, ctypes.POINTER(McqOpts), ctypes.c_int, _dp, _dp, _dp, _ip, _dp, _ip, _ip, _dp,
                                   ctypes.POINTER(McqIqpStats)]
     lib.mcq_iqp_batch.restype = ctypes.c_int
+    lib.mcq_iqp_set_round_callback.argtypes = [vp, IQP_ROUND_CB, vp]
+    lib.mcq_iqp_set_round_callback.restype = ctypes.c_int
     lib.mcq_host_alloc.argtypes = [vp, ctypes.c_size_t, ctypes.POINTER(vp)]
     lib.mcq_host_alloc.restype = ctypes.c_int
     lib.mcq_host_free.argtypes = [vp, vp]
@@ -692,6 +697,19 @@ class Engine:
                                              d_live or None, float(alpha_scale), float(stepsize), d_ref_out, d_nv_out,
                                              d_n_out, d_status)
         self._check(rc, "mcq_relinearise_device")
+
+    def set_iqp_round_callback(self, fn):
+        """fn(round, curv_err [batch] ndarray, live [batch] ndarray) after every QP pass of mcq_iqp_batch / mcq_iqp_device, or None to remove
+        it (the per-iteration print_debug lines of tph.iqp_handler, as they happen)."""
+        if fn is None:
+            self._iqp_cb = None
+            self._check(self.lib.mcq_iqp_set_round_callback(self.h, ctypes.cast(None, IQP_ROUND_CB), None), "mcq_iqp_set_round_callback")
+            return
+
+        def tramp(_user, rnd, batch, curv, live):
+            fn(int(rnd), np.ctypeslib.as_array(curv, shape=(batch,)).copy(), np.ctypeslib.as_array(live, shape=(batch,)).copy())
+        self._iqp_cb = IQP_ROUND_CB(tramp)          # kept alive while registered
+        self._check(self.lib.mcq_iqp_set_round_callback(self.h, self._iqp_cb, None), "mcq_iqp_set_round_callback")
 
     # ---- device memory plumbing (mcq_device_alloc & co): numpy in, numpy out, raw device pointers as ints ----------------
     def alloc(self, nbytes):

@@ -43,17 +43,20 @@ def _iqp_batch_device(eng, tracks, kappa_bound, w_veh, stepsize_interp, iters_mi
     between the passes all run on the device; the host packs the tracks, waits, and unpacks the
     end states.  The per-round curvature errors come back as a trace, for the print_debug lines upstream prints per round."""
     t_start = time.perf_counter()
-    out = eng.iqp_batch(tracks, kappa_bound, w_veh, stepsize_interp, iters_min, curv_error_allowed, max_rounds,
-                        timed=bool(stats is not None and stats.get("timed")), warm_start=0 if warm_start else -1)
-    for k in range(len(tracks)):
+    if print_debug:
+        # upstream prints one line per iteration AS IT GOES [REF main_globaltraj.py:270,280]: the engine calls back after every QP pass
+        # (mcq_iqp_set_round_callback), however many rounds there are
+        def on_round(rnd, curv, live):
+            for k in np.nonzero(live)[0]:
+                print("Minimum curvature IQP: iteration %i, curv_error_max: %.4frad/m" % (rnd, curv[k]), flush=True)
+        eng.set_iqp_round_callback(on_round)
+    try:
+        out = eng.iqp_batch(tracks, kappa_bound, w_veh, stepsize_interp, iters_min, curv_error_allowed, max_rounds,
+                            timed=bool(stats is not None and stats.get("timed")), warm_start=0 if warm_start else -1)
+    finally:
         if print_debug:
-            # (the engine runs the whole loop as one call: the per-round lines upstream prints as it goes come out together here)
-            for it in range(int(out["rounds"][k])):
-                if it < out["curv_trace"].shape[1]:
-                    print("Minimum curvature IQP: iteration %i, curv_error_max: %.4frad/m" % (it + 1, out["curv_trace"][k, it]))
-            if int(out["rounds"][k]) > out["curv_trace"].shape[1]:
-                print("Minimum curvature IQP: ... %d more iterations (the engine records the first %d)"
-                      % (int(out["rounds"][k]) - out["curv_trace"].shape[1], out["curv_trace"].shape[1]))
+            eng.set_iqp_round_callback(None)
+    for k in range(len(tracks)):
         if int(out["status"][k]) == _engine.STATUS_ITER_CAP and int(out["rounds"][k]) >= max_rounds:
             raise RuntimeError("iqp_handler: no convergence within %d rounds" % max_rounds)
         if int(out["status"][k]) == _engine.STATUS_RING_OVERFLOW:

@@ -47,10 +47,15 @@ enum {
     MCQ_BAD_INPUT = 4,       /* n < 3, non-finite input */
     MCQ_KAPPA_INFEASIBLE = 5, /* curvature rows cannot be satisfied -> quadprog raises ValueError("constraints are inconsistent, no solution") */
     MCQ_KAPPA_ACTIVE = 6,     /* box-only optimum violates a curvature row and the curvature-row phase is disabled (check_kappa < 0); or
-                               * more curvature rows are active than the engine carries: up to 120 in LDS, up to 512 through one of
-                               * the handle's 8 overflow slots per launch (round 3) -- beyond either, this status */
-    MCQ_RING_OVERFLOW = 7     /* mcq_iqp_device / mcq_iqp_batch only: the re-sampled raceline of an IQP round needs more waypoints than
+                               * more than 512 curvature rows are active (up to 120 are carried in LDS, up to 512 through one of the
+                               * handle's 8 overflow slots) */
+    MCQ_RING_OVERFLOW = 7,    /* mcq_iqp_device / mcq_iqp_batch only: the re-sampled raceline of an IQP round needs more waypoints than
                                * the buffers hold (nmax / nmax_out) -- not an input error of the QP (that stays MCQ_BAD_INPUT) */
+    MCQ_KAPPA_NO_SLOT = 8     /* device entries only: more than 8 problems of ONE launch had more than 120 active curvature rows and this
+                               * one did not get an overflow slot (which ones do depends on the order the GPU schedules workgroups in):
+                               * not a property of the problem -- solve it again in a launch with at most 8 such problems.  The
+                               * host-buffer entries (mcq_solve_batch, mcq_solve_host, mcq_solve_batch_f32) do that themselves and never
+                               * return this status: their results do not depend on scheduling. */
 };
 
 /* library-level error codes (negative return values) */
@@ -304,6 +309,13 @@ int mcq_iqp_batch(mcq_handle* h, const mcq_problem* probs, int batch, double ste
                   double curv_error_allowed, int max_rounds, const mcq_opts* opts, int nmax_out, double* alpha_out,
                   double* reftrack_out, double* normvec_out, int* n_out, double* curv_err_out, int* status_out,
                   int* rounds_out, double* curv_trace_out, mcq_iqp_stats* stats);
+
+/* Optional per-round callback of mcq_iqp_device / mcq_iqp_batch (what tph.iqp_handler prints per iteration with print_debug
+ * [REF main_globaltraj.py:270,280]): called on the host after the QP pass of every round, before its termination test, with the
+ * curvature errors of the pass and the tracks that ran it (live[k] != 0).  Costs one small device-to-host copy and a synchronisation per
+ * round while set; cb == NULL removes it. */
+typedef void (*mcq_iqp_round_cb)(void* user, int round, int batch, const double* curv_err, const int* live);
+int mcq_iqp_set_round_callback(mcq_handle* h, mcq_iqp_round_cb cb, void* user);
 
 /* Pinned (page-locked) host memory for callers that want their buffers copied at PCIe speed (mcq_solve_host, mcq_solve_batch,
  * mcq_copy_*). */

@@ -1,8 +1,9 @@
 #!/bin/bash
-# Final GPU call of round 3: the whole -m gpu suite (plain and with poisoned workspaces / LDS), the full bench line, the counter
-# passes (scripts/profile_round.sh), BASELINE config 4 and one rank's shard of config 5 on one GPU, the RCCL self-test line.
+# Round 4 evidence call: the whole -m gpu suite (plain and with poisoned workspaces / LDS; harness tests included when the reference tree
+# was shipped by scripts/gpu_with_reference.sh), the bench line, shortest path, force-collective, config 4 and config 5 shard on one GPU,
+# the elimination in isolation, the counter passes (scripts/profile_round.sh).
 R=${GRAFT_REPO_ROOT:-$(pwd)}
-T=${1:-r03}
+T=${1:-r04}
 mkdir -p $R/gpurun_out
 cd $R
 timeout 1500 python -m pytest tests -m gpu -q --durations=8 > gpurun_out/${T}_pytest_gpu.log 2>&1
@@ -13,11 +14,14 @@ echo "poison pytest rc $?" >> gpurun_out/${T}_pytest_gpu_poison.log
 tail -3 gpurun_out/${T}_pytest_gpu_poison.log
 timeout 900 python bench.py --steps 10 --warmup 2 > gpurun_out/${T}_bench.json 2> gpurun_out/${T}_bench.err
 echo "bench rc $?"; cut -c1-300 gpurun_out/${T}_bench.json
+timeout 300 python scripts/bench_shortest_path.py > gpurun_out/${T}_shortest_path.json 2> gpurun_out/${T}_shortest_path.err
+echo "shortest path rc $?"
 timeout 600 python bench.py --config 4 --steps 3 --warmup 1 > gpurun_out/${T}_bench_config4_1gpu.json 2> gpurun_out/${T}_bench_config4.err
-echo "config4 rc $?"; cut -c1-300 gpurun_out/${T}_bench_config4_1gpu.json
+echo "config4 rc $?"; cut -c1-200 gpurun_out/${T}_bench_config4_1gpu.json
 timeout 600 python bench.py --force-collective --steps 5 --warmup 2 --no-extras > gpurun_out/${T}_bench_force_collective_1gpu.json 2> gpurun_out/${T}_bench_fc.err
 echo "force-collective rc $?"
 timeout 900 python bench.py --config 5 --steps 2 --warmup 1 --no-extras > gpurun_out/${T}_config5_shard_1gpu.json 2> gpurun_out/${T}_config5.err
-echo "config5 rc $?"; cut -c1-300 gpurun_out/${T}_config5_shard_1gpu.json
+echo "config5 rc $?"; cut -c1-200 gpurun_out/${T}_config5_shard_1gpu.json
+for k in kc kc_f32; do for fused in 1 0; do timeout 120 ./build/kc/$k 2000 6 2048 12 0 $fused > gpurun_out/${T}_${k}_fused${fused}.txt 2>&1; done; done
+timeout 300 ./build/kc/kc 333 20 8 14 1 0 > gpurun_out/${T}_kkt_check_n333_reference.txt 2>&1
 scripts/profile_round.sh $T 2>&1 | grep "pmc\|calib" | tr '\n' ' '
-timeout 120 ./build/kc/kc 2000 6 2048 12 0 1 > gpurun_out/${T}_kkt_check_fused.txt 2>&1; timeout 120 ./build/kc/kc 2000 6 2048 12 0 0 > gpurun_out/${T}_kkt_check_plain.txt 2>&1; timeout 300 ./build/kc/kc 333 20 8 14 1 0 > gpurun_out/${T}_kkt_check_n333_reference.txt 2>&1

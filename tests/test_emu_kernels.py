@@ -467,6 +467,36 @@ def test_iqp_device_resident_with_warm_started_passes(emu, golden):
     assert np.max(np.abs(r - g["iqp_reftrack"])) < 1e-8 and np.max(np.abs(nv - g["iqp_normvec"])) < 1e-8
 
 
+def test_iqp_print_debug_lines_stream_per_round(emu, golden, capsys):
+    """tph.iqp_handler prints one line per iteration as it goes [REF main_globaltraj.py:270,280].  The engine runs the whole handler as
+    one call; with print_debug it calls back after every QP pass (mcq_iqp_set_round_callback), so the lines appear per round -- and for
+    as many rounds as there are (round 3 printed them after the run, the first 16 only).  iters_min = 20 forces 20 damped rounds."""
+    from global_racetrajectory_optimization_amd.trajectory_planning_helpers import iqp_handler as iq
+    g = golden["rounded_rectangle"]
+    seen = []
+    orig = emu.set_iqp_round_callback
+
+    def spy(fn):                                   # records WHEN the handler's callback fires relative to the engine call
+        if fn is None:
+            return orig(None)
+        return orig(lambda rnd, curv, live: (seen.append((rnd, float(curv[0]), int(live[0]))), fn(rnd, curv, live)))
+    emu.set_iqp_round_callback = spy
+    try:
+        out = iq.iqp_handler_batch([dict(reftrack=g["reftrack"].copy(), normvectors=g["normvec"], scaling=g["scaling"])], 0.12, 3.4,
+                                   3.0, 20, 0.01, print_debug=True, engine=emu, device_resident=True)
+    finally:
+        emu.set_iqp_round_callback = orig
+    lines = [l for l in capsys.readouterr().out.splitlines() if l.startswith("Minimum curvature IQP")]
+    assert [r for r, _, _ in seen] == list(range(1, 21)) and all(l == 1 for _, _, l in seen)
+    assert len(lines) == 20 and lines[0].startswith("Minimum curvature IQP: iteration 1, curv_error_max: ")
+    assert lines[19].startswith("Minimum curvature IQP: iteration 20, curv_error_max: %.4frad/m" % seen[19][1])
+    assert out[0][0].shape[0] == out[0][1].shape[0]
+    # ... and the callback is gone afterwards: a run without print_debug prints nothing
+    iq.iqp_handler_batch([dict(reftrack=g["reftrack"].copy(), normvectors=g["normvec"], scaling=g["scaling"])], 0.12, 3.4, 3.0, 3, 0.01,
+                         engine=emu)
+    assert "Minimum curvature IQP" not in capsys.readouterr().out
+
+
 def test_solve_host_entry_and_reopt_corridor(emu, golden):
     """mcq_solve_host (uniform batch straight from / to host arrays, the wall bench.py reports as host_to_host) returns what
     mcq_solve_batch returns, bitwise; the problems are the reference's re-optimisation consumer [REF main_globaltraj.py:337-350]

@@ -25,3 +25,30 @@ def test_random_rings_against_banded_cpu_solver(gpu_engine, n, w_veh):
     assert err < 1e-7, err                      # two independent solvers on cond ~ 1e10 problems: observed ~1e-10
     assert np.max(np.abs(np.asarray(curv) - c_cpu)) < 1e-8
     assert max(i["kkt_res"] for i in info) < 1e-9
+
+
+@pytest.mark.parametrize("n,w_veh", [(293, 2.0), (511, 1.6), (777, 3.0), (1001, 2.6)])
+def test_kkt_certificate_from_the_dense_oracle_assembly(gpu_engine, n, w_veh):
+    """`kkt_res` is self-reported by the engine.  Here the KKT conditions of the QP are checked ON THE
+    HOST from the dense-faithful assembly (oracle/tph_ref.assemble_dense: dense 4N x 4N inverse, dense E; H = E'E, f = 2 E'k_ref) --
+    stationarity on the free rows, multiplier signs on the active ones, feasibility -- for alpha as the engine returned it."""
+    from oracle import tph_ref
+    from global_racetrajectory_optimization_amd.trajectory_planning_helpers import calc_splines as cs
+    bsz = 3
+    ref, nv, sc = synthetic.oval_batch(bsz, n=n, first=5000 + n, perturb_centreline=True)
+    al, curv, st, info = gpu_engine.solve_batch([dict(reftrack=ref[k], normvec=nv[k], scaling=sc[k], kappa_bound=0.5, w_veh=w_veh)
+                                                 for k in range(bsz)])
+    assert np.all(np.asarray(st) == 0)
+    for k in range(bsz):
+        H, f, E, k_ref, _ = tph_ref.assemble_dense(ref[k], nv[k], cs.build_les_matrix(n, sc[k]))
+        x = al[k]
+        g = H @ x + f                                     # gradient of 1/2 x'Hx + f'x: the QP exactly as it is handed to quadprog
+        lo, hi = -(ref[k, :, 3] - w_veh / 2), ref[k, :, 2] - w_veh / 2
+        scale = np.max(np.abs(f))
+        assert np.all(x >= lo - 1e-10) and np.all(x <= hi + 1e-10)
+        at_lo, at_hi = x <= lo + 1e-9, x >= hi - 1e-9
+        free = ~(at_lo | at_hi)
+        assert np.max(np.abs(g[free])) < 1e-8 * scale, float(np.max(np.abs(g[free])) / scale)
+        assert np.all(g[at_lo] > -1e-8 * scale) and np.all(g[at_hi] < 1e-8 * scale)
+        assert np.max(np.abs(k_ref + E @ x)) < 0.5
+        assert int(np.count_nonzero(at_lo | at_hi)) == info[k]["n_active_box"]

@@ -234,6 +234,43 @@ def test_fp32_boundary_full_size(gpu_engine):
     assert np.all(st_o == 0) and np.array_equal(a_old, a_abs)
 
 
+def test_config5_shard_shape_against_cpu_b_and_dense_goldens(gpu_engine):
+    """BASELINE config 5 at one rank's shard SHAPE: 512 synthetic reference tracks, N = 2000, per-track
+    centrelines (generator indices 0 .. 511 of config 5's generator), float increment rows in / float alpha out through the host-buffer
+    entry mcq_solve_batch_f32.  Checked three ways: (i) every track against CPU-B (independent assembly and solver) run on the fp64 rows
+    the device rebuilds from the float increments -- what is left is one rounding of alpha; (ii) the four tracks that have dense-oracle
+    goldens (indices 5, 9: round 3; 13, 21: round 4) against those, within config 5's stated tolerance 1e-4 m (the goldens were solved on
+    the fp64 rows); (iii) feasibility in the rebuilt box."""
+    import os
+    from oracle import banded_ref
+    B, n = 512, 2000
+    ref, nv, sc = synthetic.oval_batch(B, n=n, first=0, perturb_centreline=True)
+    rows32, org = engine.rows_to_increments(ref)
+    a32, curv, st, info = gpu_engine.solve_batch_f32(rows32, org, 0.12, 3.4, layout=engine.F32_INCREMENTS)
+    assert a32.dtype == np.float32 and a32.shape == (B, n) and np.all(st == 0)
+    r64 = engine.increments_to_rows(rows32, org)
+    nv64 = np.empty((B, n, 2))
+    sc64 = np.empty((B, n))
+    for k in range(B):
+        nv64[k], sc64[k] = synthetic.prepared_track(r64[k, :, :2])
+    a_cpu, c_cpu, st_cpu, _, _ = banded_ref.solve_batch(r64, nv64, sc64, 0.12, 3.4)
+    assert np.all(st_cpu == 0)
+    err = np.max(np.abs(a32.astype(np.float64) - a_cpu), axis=1)
+    assert err.max() < 1e-6, (int(np.argmax(err)), float(err.max()))          # one float rounding of |alpha| <= 4 m is 2.4e-7
+    assert np.max(np.abs(curv - c_cpu)) < 1e-8
+    lo, hi = -(r64[:, :, 3] - 1.7), r64[:, :, 2] - 1.7
+    assert np.all(a32 >= lo - 3e-7) and np.all(a32 <= hi + 3e-7)
+    gdir = os.path.join(os.path.dirname(__file__), "golden")
+    worst = 0.0
+    for idx in (5, 9, 13, 21):
+        g = np.load(os.path.join(gdir, "oval_n2000_c%d.npz" % idx))
+        assert np.array_equal(g["reftrack"], ref[idx])
+        worst = max(worst, float(np.max(np.abs(a32[idx].astype(np.float64) - g["alpha"]))))
+    assert worst <= 1e-4 and worst < 5e-5, worst
+    print("config 5 shard shape: 512 tracks, max |alpha_f32 - CPU-B(rebuilt rows)| = %.2e m, max |alpha_f32 - dense golden (fp64 rows)| = %.2e m"
+          % (float(err.max()), worst))
+
+
 def test_random_rings_against_dense_oracle(gpu_engine):
     """96 random star-shaped rings (n = 24 ... 160, widths between barely feasible and generous, so anything from a handful to
     most of the rows ends up on a bound) in one ragged launch, every one against the live dense oracle."""
@@ -782,6 +819,31 @@ def test_oval_n2000_more_width_seeds_and_config5_tracks_against_golden(gpu_engin
     print("N=2000 goldens (2 width seeds, 2 config-5 tracks): max |alpha - dense oracle| = %.2e m" % worst)
 
 
+def test_round4_dense_goldens_at_bench_size(gpu_engine):
+    """Eight more N = 2000 problems through the dense oracle (scripts/make_golden_r4.py, tests/golden/SUMMARY_r4.json):
+    three width seeds of the bench workload, two config-5 tracks, the QPs of an IQP second pass (oval 5) and third pass (oval 9) -- rings
+    of 2003 / 2002 waypoints with unit scalings and dozens of barely active bounds --, and a ring whose CURVATURE bound is active at the
+    optimum at this size (box rows and curvature rows in one working set, 0.93 of the box optimum's curvature maximum)."""
+    from conftest import load_golden
+    worst = {}
+    for name in ("oval_n2000_w3", "oval_n2000_w7", "oval_n2000_w11", "oval_n2000_c13", "oval_n2000_c21", "iqp_pass2_oval5", "iqp_pass3_oval9",
+                 "oval_n2000_kappa"):
+        g = load_golden(name)
+        sc = g["scaling"] if "scaling" in g else None
+        kb = float(g["kappa_bound"])
+        if name.startswith("oval_n2000_") and name != "oval_n2000_kappa":
+            ref, nv, sc_g = synthetic.oval_batch(1, n=2000, first=int(g["generator_index"]), perturb_centreline=bool(g["perturb_centreline"]))
+            assert np.array_equal(ref[0], g["reftrack"]) and np.array_equal(nv[0], g["normvec"]) and np.array_equal(sc_g[0], sc), name
+        al, curv, st, info = gpu_engine.solve_batch([dict(reftrack=g["reftrack"], normvec=g["normvec"], scaling=sc, kappa_bound=kb, w_veh=3.4)])
+        assert st[0] == 0, (name, st[0])
+        worst[name] = float(np.max(np.abs(al[0] - g["alpha"])))
+        assert worst[name] < ALPHA_TOL, (name, worst[name])
+        assert abs(curv[0] - float(g["curv_error_max"])) < CURV_TOL, name
+        if name == "oval_n2000_kappa":
+            assert info[0]["n_active_kappa"] > 0 and abs(info[0]["kappa_max"] - kb) < 1e-9
+    print("round-4 N=2000 dense goldens: max |alpha - dense oracle| per fixture: %s" % {k: "%.1e" % v for k, v in worst.items()})
+
+
 def test_oval_n2000_iqp_end_state_against_golden(gpu_engine):
     """BASELINE config 3 IS mincurv_iqp: the END STATE of the whole iqp_handler chain at N = 2000 (three passes, N = 2000 ->
     2003 -> 2002: re-sampling, width carry-over, re-spline, damping 1/3 and 2/3) against the committed output of the oracle's
@@ -1004,4 +1066,24 @@ def test_curvature_row_overflow_slots_against_dense_gi(gpu_engine):
         assert abs(curv[k] - err_ref) < CURV_TOL
     print("curvature-row overflow: %s active rows, max |alpha - dense GI| = %.2e m"
           % ([w[2] for w in want], max(float(np.max(np.abs(al[k] - w[0]))) for k, w in enumerate(want))))
+    # more such problems in ONE launch than the handle has overflow slots (8): which of them get a slot depends on the order the GPU
+    # schedules workgroups in -- the host-buffer entries re-launch the ones left out (MCQ_KAPPA_NO_SLOT), so every copy comes back as the
+    # single solve does (a width sweep of such a track used to fail on most problems); the device entry reports them
+    many = [probs[0]] * 11 + [dict(reftrack=probs[0]["reftrack"], normvec=probs[0]["normvec"], scaling=probs[0]["scaling"], kappa_bound=0.5,
+                                  w_veh=2.0)]
+    al2, curv2, st2, info2 = gpu_engine.solve_batch(many)
+    assert np.all(st2 == 0)
+    for k in range(11):
+        assert np.array_equal(al2[k], al[0]) and curv2[k] == curv[0] and info2[k]["n_active_kappa"] == want[0][2]
+    n0 = probs[0]["reftrack"].shape[0]
+    d_ref, d_nv, d_sc = (gpu_engine.alloc(8 * 11 * n0 * w) for w in (4, 2, 1))
+    d_al, d_cu, d_st = gpu_engine.alloc(8 * 11 * n0), gpu_engine.alloc(8 * 11), gpu_engine.alloc(4 * 11)
+    gpu_engine.upload(d_ref, np.tile(probs[0]["reftrack"], (11, 1, 1)))
+    gpu_engine.upload(d_nv, np.tile(probs[0]["normvec"], (11, 1, 1)))
+    gpu_engine.upload(d_sc, np.tile(probs[0]["scaling"], (11, 1)))
+    gpu_engine.solve_device(11, n0, d_ref, d_nv, d_sc, probs[0]["kappa_bound"], 2.0, d_al, d_cu, d_st)
+    st3 = gpu_engine.download(d_st, (11,), np.int32)
+    assert np.count_nonzero(st3 == 0) == 8 and np.count_nonzero(st3 == engine.STATUS_KAPPA_NO_SLOT) == 3, st3
+    for p_ in (d_ref, d_nv, d_sc, d_al, d_cu, d_st):
+        gpu_engine.free(p_)
 

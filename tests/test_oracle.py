@@ -173,3 +173,26 @@ def test_cpu_b_banded_solver_matches_dense_oracle(golden):
     assert banded_ref.solve_batch(h["reftrack"][None], h["normvec"][None], h["scaling"][None], 0.12, 3.4)[2][0] == 4
     # curvature rows are checked: a bound below the curvature at the box optimum is reported (status 6)
     assert banded_ref.solve_batch(g["reftrack"][None], g["normvec"][None], g["scaling"][None], 0.05, 3.4)[2][0] == 6
+
+
+def test_round4_goldens_are_consistent_with_cpu_b():
+    """The dense-oracle fixtures of round 4 (N = 2000, scripts/make_golden_r4.py) against a THIRD route at full size: CPU-B
+    (oracle/banded_qp.c -- its own cyclic-tridiagonal assembly, a truncated band of E, bordered-band interior point + active set), which
+    shares no code with oracle/tph_ref.py + gi_dense.c.  Also: the stored KKT stationarity of every fixture (tests/golden/SUMMARY_r4.json)."""
+    import json
+    import os
+    from conftest import GOLDEN_DIR, load_golden
+    from oracle import banded_ref
+    summ = json.load(open(os.path.join(GOLDEN_DIR, "SUMMARY_r4.json")))
+    names = ("oval_n2000_w3", "oval_n2000_w7", "oval_n2000_w11", "oval_n2000_c13", "oval_n2000_c21", "iqp_pass2_oval5", "iqp_pass3_oval9")
+    for name in names + ("oval_n2000_kappa",):
+        assert summ[name]["kkt_stationarity"] < 1e-10, name
+    assert summ["oval_n2000_kappa"]["n_active_kappa"] >= 5
+    for name in names:
+        g = load_golden(name)
+        n = g["reftrack"].shape[0]
+        sc = g["scaling"] if "scaling" in g else np.ones(n)
+        a, c, st, _, _ = banded_ref.solve_batch(g["reftrack"][None], g["normvec"][None], sc[None], float(g["kappa_bound"]), float(g["w_veh"]))
+        assert st[0] == 0, name
+        assert np.max(np.abs(a[0] - g["alpha"])) < 2e-8, (name, float(np.max(np.abs(a[0] - g["alpha"]))))
+        assert abs(c[0] - float(g["curv_error_max"])) < 1e-9, name
