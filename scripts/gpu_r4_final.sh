@@ -12,6 +12,10 @@ tail -14 gpurun_out/${T}_pytest_gpu.log
 MCQ_POISON=1 timeout 1500 python -m pytest tests/test_gpu_parity.py tests/test_gpu_fuzz.py -m gpu -q > gpurun_out/${T}_pytest_gpu_poison.log 2>&1
 echo "poison pytest rc $?" >> gpurun_out/${T}_pytest_gpu_poison.log
 tail -3 gpurun_out/${T}_pytest_gpu_poison.log
+# config 1 on the real library, with the script's own output: the untouched main_globaltraj.py (mincurv, mincurv_iqp), stamped with the
+# SHA-256 of the engine sources it ran on
+(echo "engine sources sha256: $(python -c 'import bench; print(bench.source_sha())')"; timeout 600 python -m pytest tests/test_harness.py -m gpu -q -s 2>&1) > gpurun_out/${T}_harness_berlin.log
+echo "harness rc $?"; grep -c "Estimated laptime" gpurun_out/${T}_harness_berlin.log
 timeout 900 python bench.py --steps 10 --warmup 2 > gpurun_out/${T}_bench.json 2> gpurun_out/${T}_bench.err
 echo "bench rc $?"; cut -c1-300 gpurun_out/${T}_bench.json
 timeout 300 python scripts/bench_shortest_path.py > gpurun_out/${T}_shortest_path.json 2> gpurun_out/${T}_shortest_path.err
