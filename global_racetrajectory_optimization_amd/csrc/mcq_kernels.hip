@@ -126,7 +126,7 @@ __device__ void block_reduce2_(double& a, int opa, double& b, int opb, double* r
     b = rb;
 }
 
-__device__ McqWork mcq_work(const McqBatch& B, int pb, int& n, double& kb, double& wv)
+__device__ __forceinline__ McqWork mcq_work(const McqBatch& B, int pb, int& n, double& kb, double& wv)
 {
     McqWork w;
     const size_t nm = (size_t)B.nmax;
@@ -158,19 +158,31 @@ template <int N> __device__ __forceinline__ double bcast_row16(double v)
 #ifndef MCQ_IPM_TOL
 #define MCQ_IPM_TOL 1e-10
 #endif
+// Everything a problem's workgroup shares that is not a vector: ONE instance in LDS (round 4).  Rounds 1-3 kept it as a private
+// variable of the kernel and handed references to the non-inlined device functions: it then lives in scratch memory, every field access
+// in a callee is a FLAT load (268 of them in the round-3 ISA), and with it went the kernel's arguments and the scalars of the solve.  As
+// an LDS object -- the callees take `const LCtx&`, a reference that carries the address space -- a field is one ds_read.  Written by
+// thread 0 (or by every thread with the same value) and published by the barriers that follow; the timers are thread 0's.
 struct SolveCtx {
     McqDims d;
     McqWork w;
     int nm;
-    mutable long long tk[8];   // phase timers (wall_clock64 ticks), meaningful on thread 0
+    int direct;                // 1: shortest-path objective -- H is a cyclic tridiagonal given entry by entry (V_SPD, V_SPU), V_F holds f
+    int max_ipm_iter, max_as_iter, refine_steps;      // mcq_opts, as resolved by the host
+    double zscale, fscale, wmean, nfree, kbound;      // scales of the tolerances (set by the kernel's prologue)
+    mutable long long tk[8];   // phase timers (wall_clock64 ticks), thread 0's
     mutable int refine_rounds, second_attempt, f32_count;   // diagnostics for mcq_info
     mutable double last_step;  // length of the last interior-point step (the Tapia indicators are only trusted after a near-full one)
-    int direct;                // 1: shortest-path objective -- H is a cyclic tridiagonal given entry by entry (V_SPD, V_SPU), V_F holds f
-    mutable const gdouble* sp_sig;  // ... its current "factorisation": the diagonal shift and the working set (mcq_tri.inc, factor_sp)
+    mutable const gdouble* sp_sig;  // shortest path: the current "factorisation" = the diagonal shift and the working set (mcq_tri.inc, factor_sp)
     mutable const gschar* sp_mk;
     mutable const gdouble* kkt_w;   // saddle-point elimination: weights of the curvature rows (1 + y/t of the interior point) or nullptr
     mutable int kkt_f32;            // ... its records are stored as floats (mcq_kkt.inc, KRec): set by factor(), read by the solves that follow
+    mutable int out_iters, out_nk;  // results of ipm / ipm_box / active_set besides their status (uniform: every thread writes the same)
+    mutable double out_kkt;
 };
+typedef __attribute__((address_space(3))) SolveCtx LCtx;
+__shared__ SolveCtx g_ctx;
+#define G_CTX (*(const LCtx*)&g_ctx)
 #define TICK() ((long long)wall_clock64())
 #include "mcq_kkt.inc"
 #include "mcq_tri.inc"
@@ -181,11 +193,14 @@ struct SolveCtx {
 // Round 4: the assembly of a problem is a device function.  The solver kernel runs it as its prologue (one launch per QP pass; the
 // spline quantities go from the assembly to the solver through vectors that are still in the L2 of the same workgroup's XCD), and
 // mcq_assemble_kernel is the same function on its own for mcq_prep_device.  Returns the status it has written (uniform).
-__device__ __noinline__ int assemble_problem(const McqBatch& B, const McqWork& w, int n, double wveh)
+__device__ __noinline__ int assemble_problem(const LCtx& c, double wveh, gdouble* nv_out, gdouble* sc_out)
 {
     double* red = g_sm + SM_RED;
     const int tid = threadIdx.x;
-    const int nm = B.nmax;
+    McqWork w;                    // (member by member: a struct in LDS has no implicit copy into a private one)
+    w.ref = c.w.ref; w.nv = c.w.nv; w.sc = c.w.sc; w.L = c.w.L; w.vec = c.w.vec; w.state = c.w.state; w.Z = c.w.Z;
+    w.alpha = c.w.alpha; w.curv_err = c.w.curv_err; w.status = c.w.status; w.info = c.w.info;
+    const int nm = c.nm, n = c.d.n;
     gdouble* LO = VEC(w, nm, V_LO);
     gdouble* HI = VEC(w, nm, V_HI);
     gdouble* S = VEC(w, nm, V_SC);    // spline scalings
@@ -252,10 +267,6 @@ __device__ __noinline__ int assemble_problem(const McqBatch& B, const McqWork& w
     //      (SURVEY.md App. A.1); x'' = 2 c.  Solved by the periodic-pivot sweeps of mcq_tri.inc, whose factors (V_IDL, V_TUC) the solver
     //      kernel goes on using.  (Rounds 1-3 built rows of T^-1 here -- with image folding for short rings -- and, from them, the bands
     //      of E, E' and D; nothing reads a band any more.)
-    SolveCtx c;
-    c.w = w;
-    c.nm = nm;
-    c.d = mcq_dims(n);
     tri_prepare(c);
     gdouble* RX = VEC(w, nm, V_SK);
     gdouble* RY = VEC(w, nm, V_EDA);
@@ -288,23 +299,37 @@ __device__ __noinline__ int assemble_problem(const McqBatch& B, const McqWork& w
             NX[i] = yp / nrm;
             NY[i] = -xp / nrm;
         }
-        if (B.nv_out) {
-            gdouble* no = (gdouble*)(B.nv_out + ((size_t)blockIdx.x * nm + i) * 2);
-            no[0] = NX[i];
-            no[1] = NY[i];
+        if (nv_out) {
+            nv_out[2 * i] = NX[i];
+            nv_out[2 * i + 1] = NY[i];
         }
-        if (B.sc_out) ((gdouble*)(B.sc_out + (size_t)blockIdx.x * nm))[i] = S[i];
+        if (sc_out) sc_out[i] = S[i];
     }
     __syncthreads();
     return MCQ_OK;
+}
+
+// what the assembly needs of the context: the problem's pointers and size (thread 0 writes, the barrier publishes)
+__device__ __forceinline__ void ctx_set_problem(const McqBatch& B, int& n, double& kb, double& wveh)
+{
+    const McqWork w = mcq_work(B, blockIdx.x, n, kb, wveh);
+    __syncthreads();                                  // (a previous use of the context by this workgroup -- none today -- is over)
+    if (threadIdx.x == 0) {
+        g_ctx.w = w;
+        g_ctx.nm = B.nmax;
+        g_ctx.d = mcq_dims(n);
+    }
+    __syncthreads();
 }
 
 __global__ void __launch_bounds__(MCQ_NT) mcq_assemble_kernel(McqBatch B)
 {
     int n;
     double kb, wveh;
-    const McqWork w = mcq_work(B, blockIdx.x, n, kb, wveh);
-    (void)assemble_problem(B, w, n, wveh);
+    ctx_set_problem(B, n, kb, wveh);
+    const size_t nm = (size_t)B.nmax;
+    (void)assemble_problem(G_CTX, wveh, B.nv_out ? (gdouble*)(B.nv_out + (size_t)blockIdx.x * nm * 2) : nullptr,
+                           B.sc_out ? (gdouble*)(B.sc_out + (size_t)blockIdx.x * nm) : nullptr);
 }
 
 // =====================================================================================================================
@@ -379,15 +404,15 @@ __global__ void __launch_bounds__(MCQ_NT) mcq_assemble_sp_kernel(McqBatch B)
 
 // fv: the right-hand side of the solve that follows rides through the elimination (solve(c, fv, true) then finishes it);
 // f32: the records of this factorisation may be stored as floats (interior-point iterations: inexact Newton directions, see KRec)
-__device__ __noinline__ int factor(const SolveCtx& c, const gdouble* sig, const gschar* mk, gdouble* fv, bool f32)
+__device__ __noinline__ int factor(const LCtx& c, const gdouble* sig, const gschar* mk, gdouble* fv, bool f32)
 {
     if (c.direct) return factor_sp(c, sig, mk);
     c.kkt_f32 = f32 ? 1 : 0;
-    c.f32_count += f32 ? 1 : 0;
+    if (threadIdx.x == 0) c.f32_count += f32 ? 1 : 0;
     return f32 ? factor_kkt<true>(c, sig, mk, c.kkt_w, fv) : factor_kkt<false>(c, sig, mk, c.kkt_w, fv);
 }
 
-__device__ __noinline__ void solve(const SolveCtx& c, gdouble* v, bool fwd_done)
+__device__ __noinline__ void solve(const LCtx& c, gdouble* v, bool fwd_done)
 {
     if (c.direct) { (void)sp_solve(c, v, v); return; }
     if (c.kkt_f32) solve_kkt<true>(c, v, fwd_done);
@@ -395,10 +420,10 @@ __device__ __noinline__ void solve(const SolveCtx& c, gdouble* v, bool fwd_done)
 }
 
 // dst = E' src, through the spline system (mcq_tri.inc)
-__device__ __forceinline__ void apply_Et(SolveCtx& c, const gdouble* src, gdouble* dst) { tri_apply_Et(c, src, dst); }
+__device__ __forceinline__ void apply_Et(const LCtx& c, const gdouble* src, gdouble* dst) { tri_apply_Et(c, src, dst); }
 
 // g = E'(E x + F_SCALE k_ref + extra)      (tmp: scratch vector; extra may be nullptr)
-__device__ __noinline__ void gradient(SolveCtx& c, const gdouble* x, const gdouble* extra, gdouble* tmp, gdouble* g)
+__device__ __noinline__ void gradient(const LCtx& c, const gdouble* x, const gdouble* extra, gdouble* tmp, gdouble* g)
 {
     const int n = c.d.n;
     const long long t0 = TICK();
@@ -412,7 +437,7 @@ __device__ __noinline__ void gradient(SolveCtx& c, const gdouble* x, const gdoub
             g[i] = F[i] + HU[im] * x[im] + HD[i] * x[i] + HU[i] * x[ip];
         }
         __syncthreads();
-        c.tk[2] += TICK() - t0;
+        if (threadIdx.x == 0) c.tk[2] += TICK() - t0;
         return;
     }
     // E and E' through the spline system itself (mcq_tri.inc): no band is read
@@ -422,26 +447,23 @@ __device__ __noinline__ void gradient(SolveCtx& c, const gdouble* x, const gdoub
         __syncthreads();
     }
     tri_apply_Et(c, tmp, g);
-    c.tk[2] += TICK() - t0;
+    if (threadIdx.x == 0) c.tk[2] += TICK() - t0;
 }
 
-__device__ __forceinline__ int timed_factor(SolveCtx& c, const gdouble* sig, const gschar* mk, gdouble* fv = nullptr, bool f32 = false)
+__device__ __forceinline__ int timed_factor(const LCtx& c, const gdouble* sig, const gschar* mk, gdouble* fv = nullptr, bool f32 = false)
 {
     const long long t0 = TICK();
     const int r = factor(c, sig, mk, fv, f32);
-    c.tk[0] += TICK() - t0;
+    if (threadIdx.x == 0) c.tk[0] += TICK() - t0;
     return r;
 }
-__device__ __forceinline__ void timed_solve(SolveCtx& c, gdouble* v, bool fwd_done = false)
+__device__ __forceinline__ void timed_solve(const LCtx& c, gdouble* v, bool fwd_done = false)
 {
     const long long t0 = TICK();
     solve(c, v, fwd_done);
-    c.tk[1] += TICK() - t0;
+    if (threadIdx.x == 0) c.tk[1] += TICK() - t0;
 }
 
-struct SolveScalars {
-    double zscale, fscale, wmean, nfree, kbound;
-};
 
 // ---------------------------------------------------------------------------------------------------------------------
 // Mehrotra predictor-corrector interior point on
@@ -451,7 +473,7 @@ struct SolveScalars {
 //     (H + diag(zl/sl + zu/su) + E' diag(yl/tl + yu/tu) E) dx = rhs
 // i.e. the same bordered band as H: one banded Cholesky per iteration, two solves.
 // ---------------------------------------------------------------------------------------------------------------------
-__device__ __noinline__ int ipm(SolveCtx& c, const McqBatch& B, bool with_kappa, const SolveScalars& sc, int& iters)
+__device__ __noinline__ int ipm(const LCtx& c, bool with_kappa)
 {
     const int tid = threadIdx.x, n = c.d.n, nm = c.nm;
     double* red = g_sm + SM_RED;
@@ -476,9 +498,9 @@ __device__ __noinline__ int ipm(SolveCtx& c, const McqBatch& B, bool with_kappa,
     gdouble* EDA = VEC(c.w, nm, V_EDA);
     gdouble* Q = VEC(c.w, nm, V_Q);
     gschar* ST = c.w.state;
-    const double kb = sc.kbound, zscale = sc.zscale;
+    const double kb = c.kbound, zscale = c.zscale;
     const double IPM_TOL = 1e-10;
-    iters = 0;
+    c.out_iters = 0;
 
     for (int i = tid; i < n; i += MCQ_NT) {
         const bool fixed = !(HI[i] - LO[i] > 1e-12);
@@ -490,7 +512,7 @@ __device__ __noinline__ int ipm(SolveCtx& c, const McqBatch& B, bool with_kappa,
     __syncthreads();
     if (with_kappa) {
         tri_apply_E(c, X, KR, 1.0, T0);     // r = E x + k_ref
-        const double mu0 = 0.5 * zscale * sc.wmean;
+        const double mu0 = 0.5 * zscale * c.wmean;
         for (int i = tid; i < n; i += MCQ_NT) {
             const double r = T0[i];
             const double tl = fmax(kb + r, 0.1 * kb), tu = fmax(kb - r, 0.1 * kb);
@@ -499,9 +521,9 @@ __device__ __noinline__ int ipm(SolveCtx& c, const McqBatch& B, bool with_kappa,
         }
         __syncthreads();
     }
-    const double npairs = 2.0 * sc.nfree + (with_kappa ? 2.0 * n : 0.0);
+    const double npairs = 2.0 * c.nfree + (with_kappa ? 2.0 * n : 0.0);
     const gschar* const no_mask = nullptr;
-    const bool any_fixed = sc.nfree < (double)n;
+    const bool any_fixed = c.nfree < (double)n;
     (void)no_mask;
     if (!(npairs > 0.0)) return MCQ_OK;
 
@@ -512,7 +534,7 @@ __device__ __noinline__ int ipm(SolveCtx& c, const McqBatch& B, bool with_kappa,
     // On entry G holds the exact gradient at the box centre (computed by the caller for the scaling).
     bool g_exact = true;
     double mu_first = 0.0, rdm_best = 1e300;
-    for (int it = 1; it <= B.max_ipm_iter; ++it) {
+    for (int it = 1; it <= c.max_ipm_iter; ++it) {
         // ---- residuals: g = H x + f;  with kappa also r, rho and the dual residual needs E'(yu - yl) ---------------------
         if (with_kappa) {
             for (int i = tid; i < n; i += MCQ_NT) Q[i] = YU[i] - YL[i];
@@ -539,7 +561,7 @@ __device__ __noinline__ int ipm(SolveCtx& c, const McqBatch& B, bool with_kappa,
             mu = block_reduce_(mu, 0, red) / npairs;
             rdm = block_reduce_(rdm, 2, red);
             rhom = block_reduce_(rhom, 2, red);
-            const bool conv = mu < IPM_TOL * zscale * sc.wmean && rdm < IPM_TOL * zscale && rhom <= 1e-9 * kb;
+            const bool conv = mu < IPM_TOL * zscale * c.wmean && rdm < IPM_TOL * zscale && rhom <= 1e-9 * kb;
             // Curvature rows, late in the path: the weights 1 + y / t of rows close to their bound reach 1e10 and more, and the dual residual
             // stops following the complementarity down -- rounding in the weighted system, whichever way it is solved (the band of
             // E' diag(1 + y/t) E met a non-positive pivot at this point; the saddle-point form carries the weights in its (cx, cy) blocks and
@@ -548,14 +570,14 @@ __device__ __noinline__ int ipm(SolveCtx& c, const McqBatch& B, bool with_kappa,
             if (with_kappa && it > 1 && mu < 1e-6 * mu_first && rdm > 10.0 * rdm_best) return MCQ_OK;
             rdm_best = fmin(rdm_best, rdm);
 #ifdef IPM_TRACE
-            if (tid == 0) printf("ipm%d it %d mu %.3e rdm %.3e rhom %.3e step %.3e\n", (int)with_kappa, it, mu / (zscale * sc.wmean), rdm / zscale, rhom / kb, c.last_step);
+            if (tid == 0) printf("ipm%d it %d mu %.3e rdm %.3e rhom %.3e step %.3e\n", (int)with_kappa, it, mu / (zscale * c.wmean), rdm / zscale, rhom / kb, c.last_step);
 #endif
             if (conv && (with_kappa || g_exact)) return MCQ_OK;
             if (!conv) break;
             gradient(c, X, nullptr, T0, G);          // looks converged on the carried gradient: confirm on the exact one
             g_exact = true;
         }
-        iters = it;
+        c.out_iters = it;
         if (it == 1) mu_first = mu;
 
         // ---- factorisation of the reduced system ---------------------------------------------------------------------
@@ -739,7 +761,7 @@ __device__ __noinline__ int ipm(SolveCtx& c, const McqBatch& B, bool with_kappa,
 #define IPB_H 4     /* entries a pass keeps in registers at a time: two halves per pass (round 3: at 256 VGPRs -- two workgroups per CU -- eight entries of a pass's arrays spilled) */
 // `resume`: continue from the pairs (X, ZL, ZU) already in memory to the tighter tolerance `tol` -- the second attempt on
 // degenerate / very ill-conditioned instances (see the driver in mcq_solve_kernel).
-__device__ __noinline__ int ipm_box(SolveCtx& c, const McqBatch& B, const SolveScalars& sc, int& iters, double tol, bool resume)
+__device__ __noinline__ int ipm_box(const LCtx& c, double tol, bool resume)
 {
     // Pointers and the per-thread index set are re-derived at the top of every pass: nothing but a few scalars is live
     // across the (non-inlined) factorisation / solve calls, so nothing is spilled to scratch and reloaded around them.
@@ -787,9 +809,9 @@ __device__ __noinline__ int ipm_box(SolveCtx& c, const McqBatch& B, const SolveS
     gschar* ST = c.w.state;                                                                                            \
     gdouble* IND = VEC(c.w, nm, V_T3);                                                                                 \
     (void)IND; (void)red; (void)LO; (void)HI; (void)X; (void)G; (void)ZL; (void)ZU; (void)SIG; (void)RHS; (void)DXA; (void)ST;
-    const double zscale = sc.zscale;
+    const double zscale = c.zscale;
     const double IPM_TOL = tol;
-    iters = 0;
+    c.out_iters = 0;
     {
     IPB_SETUP
 #pragma unroll
@@ -807,8 +829,8 @@ __device__ __noinline__ int ipm_box(SolveCtx& c, const McqBatch& B, const SolveS
     }
     __syncthreads();
     if (resume) gradient(c, VEC(c.w, c.nm, V_X), nullptr, VEC(c.w, c.nm, V_T0), VEC(c.w, c.nm, V_G));
-    const double npairs = 2.0 * sc.nfree;
-    const bool any_fixed = sc.nfree < (double)c.d.n;
+    const double npairs = 2.0 * c.nfree;
+    const bool any_fixed = c.nfree < (double)c.d.n;
     if (!(npairs > 0.0)) return MCQ_OK;
 
     // g = H x + f is carried along (see ipm()): exact on entry, exact again before convergence is declared
@@ -828,7 +850,7 @@ __device__ __noinline__ int ipm_box(SolveCtx& c, const McqBatch& B, const SolveS
 #define MCQ_IPM_F32_RD 1e-5
 #endif
     bool f32 = MCQ_IPM_F32 && !resume;
-    for (int it = 1; it <= B.max_ipm_iter; ++it) {
+    for (int it = 1; it <= c.max_ipm_iter; ++it) {
         // ---- pass 1: complementarity, dual residual, sig, predictor right-hand side ----------------------------------------
         double mu;
         for (;;) {
@@ -861,9 +883,9 @@ __device__ __noinline__ int ipm_box(SolveCtx& c, const McqBatch& B, const SolveS
             block_reduce2_(mu, 0, rdm, 2, red);
             mu /= npairs;
             }
-            const bool conv = mu < IPM_TOL * zscale * sc.wmean && rdm < IPM_TOL * zscale;
+            const bool conv = mu < IPM_TOL * zscale * c.wmean && rdm < IPM_TOL * zscale;
 #ifdef IPM_TRACE
-            if (threadIdx.x == 0) printf("ipmb it %d mu %.3e rdm %.3e exact %d resume %d\n", it, mu / (zscale * sc.wmean), rdm / zscale, (int)g_exact, (int)resume);
+            if (threadIdx.x == 0) printf("ipmb it %d mu %.3e rdm %.3e exact %d resume %d\n", it, mu / (zscale * c.wmean), rdm / zscale, (int)g_exact, (int)resume);
 #endif
             if (f32 && it > 1 && rdm < MCQ_IPM_F32_RD * zscale) {      // float records have done their part
                 f32 = false;
@@ -878,7 +900,7 @@ __device__ __noinline__ int ipm_box(SolveCtx& c, const McqBatch& B, const SolveS
             gradient(c, X, nullptr, VEC(c.w, nm, V_T0), G);     // looks converged on the carried gradient: confirm on the exact one
             g_exact = true;
         }
-        iters = it;
+        c.out_iters = it;
         if (resume) {
             // at the tighter tolerance round-off can stop the complementarity from shrinking: three rounds without a 10 %
             // reduction end the attempt (the active-set phase then decides)
@@ -958,7 +980,7 @@ __device__ __noinline__ int ipm_box(SolveCtx& c, const McqBatch& B, const SolveS
 #ifdef MCQ_IPM_FIXED_STEP
             const double gm = 0.995;
 #else
-            const double gm = fmin(fmax(MCQ_IPM_GM_MIN, 1.0 - MCQ_IPM_GM_C * mu / (zscale * sc.wmean)), 1.0 - 1e-9);
+            const double gm = fmin(fmax(MCQ_IPM_GM_MIN, 1.0 - MCQ_IPM_GM_C * mu / (zscale * c.wmean)), 1.0 - 1e-9);
 #endif
             double amax = 1.0 / gm;
             double dx[IPB_E], da[IPB_E], x[IPB_E], lo[IPB_E], hi[IPB_E], zl[IPB_E], zu[IPB_E], g[IPB_E], sg[IPB_E];
@@ -1039,7 +1061,7 @@ struct KappaMem {
     int cap, ld;     // rows the arrays hold, leading dimension of sg
     bool in_lds;     // S is factored on a copy in the LDS overlay
 };
-__device__ __forceinline__ KappaMem kappa_mem_lds(const SolveCtx& c)
+__device__ __forceinline__ KappaMem kappa_mem_lds(const LCtx& c)
 {
     KappaMem k;
     k.kmu = g_sm + SM_KV;
@@ -1169,7 +1191,7 @@ __device__ void kappa_lu_solve(const KappaMem& K, int nk)
 }
 
 // v <- M^-1 (E_K' KMU restricted to the free set):  the multipliers scattered onto their rows (Q), one band product, one solve
-__device__ void kappa_apply(SolveCtx& c, const KappaMem& K, int nk, gdouble* Q, gdouble* v)
+__device__ void kappa_apply(const LCtx& c, const KappaMem& K, int nk, gdouble* Q, gdouble* v)
 {
     const int tid = threadIdx.x, n = c.d.n;
     const double* KMU = K.kmu;
@@ -1186,8 +1208,7 @@ __device__ void kappa_apply(SolveCtx& c, const KappaMem& K, int nk, gdouble* Q, 
     timed_solve(c, v);
 }
 
-__device__ __noinline__ int active_set(SolveCtx& c, const McqBatch& B, bool with_kappa, bool tapia, int cap, const SolveScalars& sc, int& iters,
-                                       double& kkt, int& nk_out, bool identify, const KappaMem& K)
+__device__ __noinline__ int active_set(const LCtx& c, bool with_kappa, bool tapia, int cap, bool identify, const KappaMem K)
 {
     const int tid = threadIdx.x, n = c.d.n, nm = c.nm;
     double* red = g_sm + SM_RED;
@@ -1211,11 +1232,11 @@ __device__ __noinline__ int active_set(SolveCtx& c, const McqBatch& B, bool with
     gdouble* KF = VEC(c.w, nm, V_SK);      // per-row flag of the curvature working set: 0, +1 (upper), -1 (lower)
     gdouble* PV = VEC(c.w, nm, V_DXA);     // by how much a free row leaves its box in this round (0 elsewhere)
     gschar* ST = c.w.state;
-    const double zscale = sc.zscale, fscale = sc.fscale, kb = sc.kbound;
+    const double zscale = c.zscale, fscale = c.fscale, kb = c.kbound;
     const int win = MCQ_AS_WINDOW < (n - 1) / 2 ? MCQ_AS_WINDOW : (n - 1) / 2;
-    iters = 0;
-    kkt = 0.0;
-    nk_out = 0;
+    c.out_iters = 0;
+    c.out_kkt = 0.0;
+    c.out_nk = 0;
 
     // ---- identification ---------------------------------------------------------------------------------------------------
     // (identify == false: the working set is given -- carried over from the previous IQP pass -- and the pairs are not read)
@@ -1243,7 +1264,7 @@ __device__ __noinline__ int active_set(SolveCtx& c, const McqBatch& B, bool with
             const gdouble* TU = VEC(c.w, nm, V_TU);
             const gdouble* YL = VEC(c.w, nm, V_YL);
             const gdouble* YU = VEC(c.w, nm, V_YU);
-            const double mu0 = 0.5 * zscale * sc.wmean;
+            const double mu0 = 0.5 * zscale * c.wmean;
             if (TL[i] * mu0 < YL[i] * kb * kb) kf = -1.0;
             else if (TU[i] * mu0 < YU[i] * kb * kb) kf = 1.0;
         }
@@ -1255,7 +1276,7 @@ __device__ __noinline__ int active_set(SolveCtx& c, const McqBatch& B, bool with
     const double tolk = 1e-10 * kb;
     int best = 2 * n + 1, pcnt = 3;
     for (int it = 1; it <= cap; ++it) {
-        iters = it;
+        c.out_iters = it;
         // ---- compact list of the curvature working set (thread 0; n is small relative to everything else here) ------------
         if (tid == 0) {
             int nk = 0;
@@ -1271,7 +1292,7 @@ __device__ __noinline__ int active_set(SolveCtx& c, const McqBatch& B, bool with
         const int nk = KI[0];
         if (nk > kcap) return MCQ_KAPPA_ACTIVE;          // more active curvature rows than these arrays hold (the caller may retry
                                                          // with an overflow slot)
-        nk_out = nk;
+        c.out_nk = nk;
 
         for (int i = tid; i < n; i += MCQ_NT) {
             const signed char st = ST[i];
@@ -1338,13 +1359,13 @@ __device__ __noinline__ int active_set(SolveCtx& c, const McqBatch& B, bool with
         }
         nv = block_reduce_(nv, 0, red);
         imax = block_reduce_(imax, 2, red);
-        kkt = block_reduce_(kk, 2, red);
+        c.out_kkt = block_reduce_(kk, 2, red);
         const int nvi = (int)nv;
         if (nvi == 0) {
             // fp64 residual refinement through E on the final working set (same factor); box-only working sets
             // A round whose correction is already below 1e-8 m is the last one: the next would move alpha by (cond * eps)
             // times that, i.e. far below the 1e-9 m at which the dense oracle itself is known.
-            for (int r = 0; r < B.refine_steps; ++r) {
+            for (int r = 0; r < c.refine_steps; ++r) {
                 for (int i = tid; i < n; i += MCQ_NT) RHS[i] = ST[i] == 0 ? -G[i] : 0.0;
                 timed_solve(c, RHS);
                 if (nk > 0) {
@@ -1375,7 +1396,7 @@ __device__ __noinline__ int active_set(SolveCtx& c, const McqBatch& B, bool with
             }
             double k2 = 0.0;
             for (int i = tid; i < n; i += MCQ_NT) if (ST[i] == 0) k2 = fmax(k2, fabs(G[i]));
-            kkt = block_reduce_(k2, 2, red);
+            c.out_kkt = block_reduce_(k2, 2, red);
             return MCQ_OK;
         }
         bool full;
@@ -1415,27 +1436,34 @@ __global__ void __launch_bounds__(MCQ_NT, 2) mcq_solve_kernel(McqBatch B)
     const int tid = threadIdx.x;
     int n;
     double kbound, wveh;
-    SolveCtx c;
-    c.w = mcq_work(B, blockIdx.x, n, kbound, wveh);
     if (B.poison_lds) {      // debugging aid: whatever a phase reads from LDS without having written it shows up as NaN on every box
         for (int q = tid; q < SM_TOTAL; q += MCQ_NT) g_sm[q] = __longlong_as_double(-1LL);
         __syncthreads();
     }
     const long long t_kernel0 = TICK();
     const long long c_kernel0 = (long long)clock64();      // shader-clock counter (s_memtime): with ticks[3] the effective clock
+    ctx_set_problem(B, n, kbound, wveh);
+    const LCtx& c = G_CTX;
+    if (tid == 0) {
+        for (int q = 0; q < 8; ++q) g_ctx.tk[q] = 0;
+        g_ctx.last_step = 0.0;
+        g_ctx.refine_rounds = g_ctx.second_attempt = g_ctx.f32_count = 0;
+        g_ctx.direct = B.objective == MCQ_OBJ_SHORTEST_PATH;
+        g_ctx.max_ipm_iter = B.max_ipm_iter;
+        g_ctx.max_as_iter = B.max_as_iter;
+        g_ctx.refine_steps = B.refine_steps;
+        g_ctx.kbound = kbound;
+        g_ctx.kkt_w = nullptr;
+        g_ctx.kkt_f32 = 0;
+        g_ctx.sp_sig = nullptr;
+        g_ctx.sp_mk = nullptr;
+        g_ctx.out_iters = g_ctx.out_nk = 0;
+        g_ctx.out_kkt = 0.0;
+    }
+    __syncthreads();
     if (B.objective == MCQ_OBJ_SHORTEST_PATH) {
         if (*c.w.status != MCQ_OK) return;            // (written by mcq_assemble_sp_kernel)
-    } else if (assemble_problem(B, c.w, n, wveh) != MCQ_OK) return;
-    c.nm = B.nmax;
-    c.d = mcq_dims(n);
-    for (int q = 0; q < 8; ++q) c.tk[q] = 0;
-    c.last_step = 0.0;
-    c.refine_rounds = c.second_attempt = c.f32_count = 0;
-    c.direct = B.objective == MCQ_OBJ_SHORTEST_PATH;
-    c.kkt_w = nullptr;
-    c.kkt_f32 = 0;
-    c.sp_sig = nullptr;
-    c.sp_mk = nullptr;
+    } else if (assemble_problem(c, wveh, nullptr, nullptr) != MCQ_OK) return;
     double* red = g_sm + SM_RED;
     const int nm = B.nmax;
 
@@ -1458,8 +1486,6 @@ __global__ void __launch_bounds__(MCQ_NT, 2) mcq_solve_kernel(McqBatch B)
         __syncthreads();
     }
     // ---- scalars: scales for the tolerances, initial gradient at the box centre -----------------------------------------
-    SolveScalars sc;
-    sc.kbound = kbound;
     double wsum = 0.0, nfree_d = 0.0, fmaxl = 0.0;
     for (int i = tid; i < n; i += MCQ_NT) {
         const double wdt = HI[i] - LO[i];
@@ -1470,20 +1496,24 @@ __global__ void __launch_bounds__(MCQ_NT, 2) mcq_solve_kernel(McqBatch B)
         fmaxl = fmax(fmaxl, fabs(F[i]));
     }
     wsum = block_reduce_(wsum, 0, red);
-    sc.nfree = block_reduce_(nfree_d, 0, red);
-    sc.fscale = block_reduce_(fmaxl, 2, red);
-    sc.wmean = sc.nfree > 0.0 ? wsum / sc.nfree : 1.0;
+    const double nfree_s = block_reduce_(nfree_d, 0, red), fscale_s = block_reduce_(fmaxl, 2, red);
     gradient(c, X, nullptr, T0, G);
     double gm = 0.0;
     for (int i = tid; i < n; i += MCQ_NT) if (ST[i] == 0) gm = fmax(gm, fabs(G[i]));
-    sc.zscale = block_reduce_(gm, 2, red);
-    if (!(sc.zscale > 0.0)) sc.zscale = sc.fscale > 0.0 ? sc.fscale : 1.0;
+    double zscale_s = block_reduce_(gm, 2, red);
+    if (!(zscale_s > 0.0)) zscale_s = fscale_s > 0.0 ? fscale_s : 1.0;
+    if (tid == 0) {
+        g_ctx.nfree = nfree_s;
+        g_ctx.fscale = fscale_s;
+        g_ctx.wmean = nfree_s > 0.0 ? wsum / nfree_s : 1.0;
+        g_ctx.zscale = zscale_s;
+    }
+    __syncthreads();
 
     // ---- phase 1: box-constrained QP ---------------------------------------------------------------------------------------
-    int ipm_iters = 0, as_iters = 0, it2 = 0, nact_kappa = 0;
+    int ipm_iters = 0, as_iters = 0, nact_kappa = 0;
     double kkt = 0.0;
     const bool small = n <= IPB_E * MCQ_NT;
-    int nk_dummy = 0;
     // ---- warm start (IQP passes 2+): the working set of the previous pass, carried through the re-sampling by the glue kernel, is
     //      off by a few dozen rows; the one-row-per-neighbourhood exchange settles from it in a handful of rounds (each one
     //      factorisation + one solve) -- a third to two thirds of what interior point + exchange cost.  The vertex returned is an
@@ -1495,7 +1525,9 @@ __global__ void __launch_bounds__(MCQ_NT, 2) mcq_solve_kernel(McqBatch B)
             if (ST[i] == 0) { const signed char s = WS[i]; ST[i] = (s == 1 || s == -1) ? s : (signed char)0; }
         __syncthreads();
         const int capw = B.max_as_iter < MCQ_WARM_ROUNDS ? B.max_as_iter : MCQ_WARM_ROUNDS;
-        const int sw = active_set(c, B, false, false, capw, sc, as_iters, kkt, nk_dummy, false, kappa_mem_lds(c));
+        const int sw = active_set(c, false, false, capw, false, kappa_mem_lds(c));
+        as_iters = c.out_iters;
+        kkt = c.out_kkt;
         if (sw == MCQ_OK) warm_done = true;
         else {
             c.second_attempt = 2;       // reported: warm start abandoned
@@ -1510,8 +1542,11 @@ __global__ void __launch_bounds__(MCQ_NT, 2) mcq_solve_kernel(McqBatch B)
     const int as_warm = warm_done ? 0 : as_iters;
     int status = MCQ_OK;
     const long long t_ipm0 = TICK();
-    if (!warm_done) status = small ? ipm_box(c, B, sc, ipm_iters, MCQ_IPM_TOL, false) : ipm(c, B, false, sc, ipm_iters);
-    c.tk[4] = TICK() - t_ipm0;          // wall time of the interior-point phase (ticks[4]; the band core reports its forward sweeps there)
+    if (!warm_done) {
+        status = small ? ipm_box(c, MCQ_IPM_TOL, false) : ipm(c, false);
+        ipm_iters = c.out_iters;
+    }
+    if (tid == 0) c.tk[4] = TICK() - t_ipm0;          // wall time of the interior-point phase (ticks[4])
     const long long t_as0 = TICK();
     if (warm_done) {
     } else if (status == MCQ_OK && small) {
@@ -1524,22 +1559,28 @@ __global__ void __launch_bounds__(MCQ_NT, 2) mcq_solve_kernel(McqBatch B)
         gdouble* XS = VEC(c.w, nm, V_TL);
         for (int i = tid; i < n; i += MCQ_NT) XS[i] = X[i];
         const int cap1 = B.max_as_iter < 6 ? B.max_as_iter : 6;
-        status = active_set(c, B, false, ipm_iters >= 1 && c.last_step >= 0.9, cap1, sc, as_iters, kkt, nk_dummy, true, kappa_mem_lds(c));
+        status = active_set(c, false, ipm_iters >= 1 && c.last_step >= 0.9, cap1, true, kappa_mem_lds(c));
+        as_iters = c.out_iters;
+        kkt = c.out_kkt;
         if (status == MCQ_ITER_CAP && B.max_as_iter > cap1) {
             c.second_attempt |= 1;
             for (int i = tid; i < n; i += MCQ_NT) X[i] = XS[i];
             __syncthreads();
-            int it_more = 0, as_more = 0;
-            status = ipm_box(c, B, sc, it_more, 1e-13, true);
-            ipm_iters += it_more;
-            if (status == MCQ_OK) status = active_set(c, B, false, false, B.max_as_iter, sc, as_more, kkt, nk_dummy, true, kappa_mem_lds(c));
-            as_iters += as_more;
+            status = ipm_box(c, 1e-13, true);
+            ipm_iters += c.out_iters;
+            if (status == MCQ_OK) {
+                status = active_set(c, false, false, B.max_as_iter, true, kappa_mem_lds(c));
+                as_iters += c.out_iters;
+                kkt = c.out_kkt;
+            }
         }
     } else if (status == MCQ_OK) {
-        status = active_set(c, B, false, ipm_iters >= 1 && c.last_step >= 0.9, B.max_as_iter, sc, as_iters, kkt, nk_dummy, true, kappa_mem_lds(c));
+        status = active_set(c, false, ipm_iters >= 1 && c.last_step >= 0.9, B.max_as_iter, true, kappa_mem_lds(c));
+        as_iters = c.out_iters;
+        kkt = c.out_kkt;
     }
     as_iters += as_warm;        // rounds of an abandoned warm start are reported too
-    c.tk[5] = TICK() - t_as0;           // wall time of the active-set phase (ticks[5])
+    if (tid == 0) c.tk[5] = TICK() - t_as0;           // wall time of the active-set phase (ticks[5])
     const long long t_epi0 = TICK();
 
     // kappa(alpha) = k_ref + E alpha
@@ -1560,12 +1601,14 @@ __global__ void __launch_bounds__(MCQ_NT, 2) mcq_solve_kernel(McqBatch B)
     //      then the box active-set polish with the curvature multipliers frozen ---------------------------------------------
     if (status == MCQ_OK && B.check_kappa && !c.direct && km > kbound * (1.0 + 1e-9)) {
         dd_valid = false;
-        status = ipm(c, B, true, sc, it2);
-        ipm_iters += it2;
+        status = ipm(c, true);
+        ipm_iters += c.out_iters;
         __syncthreads();
         if (status == MCQ_OK) {
-            status = active_set(c, B, true, false, B.max_as_iter, sc, it2, kkt, nact_kappa, true, kappa_mem_lds(c));
-            as_iters += it2;
+            status = active_set(c, true, false, B.max_as_iter, true, kappa_mem_lds(c));
+            as_iters += c.out_iters;
+            kkt = c.out_kkt;
+            nact_kappa = c.out_nk;
             if (status == MCQ_KAPPA_ACTIVE && B.kbig && B.kbig_slots > 0) {
                 // More curvature rows in the working set than the LDS-resident arrays hold (MCQ_KMAX): quadprog has no such limit
                 // [REF params/racecar.ini:49 curvlim].  The problem claims one of the handle's overflow slots -- MCQ_KBIG rows, the
@@ -1578,9 +1621,10 @@ __global__ void __launch_bounds__(MCQ_NT, 2) mcq_solve_kernel(McqBatch B)
                 const int slot = sslot[0];
                 __syncthreads();
                 if (slot < B.kbig_slots) {
-                    status = active_set(c, B, true, false, B.max_as_iter, sc, it2, kkt, nact_kappa, false,
-                                        kappa_mem_slot(B.kbig + (size_t)slot * MCQ_KBIG_SLOT));
-                    as_iters += it2;
+                    status = active_set(c, true, false, B.max_as_iter, false, kappa_mem_slot(B.kbig + (size_t)slot * MCQ_KBIG_SLOT));
+                    as_iters += c.out_iters;
+                    kkt = c.out_kkt;
+                    nact_kappa = c.out_nk;
                 } else status = MCQ_KAPPA_NO_SLOT;        // not a verdict on the problem: the host entries re-launch it (mcq_api.hip)
             }
         }
@@ -1643,7 +1687,7 @@ __global__ void __launch_bounds__(MCQ_NT, 2) mcq_solve_kernel(McqBatch B)
                 o.n_active_box = (int)nact;
                 o.n_active_kappa = nact_kappa;
                 o.kappa_max = km;
-                o.kkt_res = sc.fscale > 0.0 ? kkt / sc.fscale : kkt;
+                o.kkt_res = c.fscale > 0.0 ? kkt / c.fscale : kkt;
                 o.refine_rounds = c.refine_rounds;
                 o.second_attempt = c.second_attempt;
                 o.f32_factorisations = c.f32_count;

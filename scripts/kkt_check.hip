@@ -18,15 +18,17 @@ __global__ void __launch_bounds__(MCQ_NT, 2) kc_kernel(McqBatch B, int reps, con
 {
     int n;
     double kb, wv;
-    SolveCtx c;
-    c.w = mcq_work(B, blockIdx.x, n, kb, wv);
-    c.nm = B.nmax;
-    c.d = mcq_dims(n);
-    for (int q = 0; q < 8; ++q) c.tk[q] = 0;
-    c.last_step = 0.0;
-    c.refine_rounds = c.second_attempt = c.f32_count = 0;
-    c.direct = 0;
-    c.kkt_w = nullptr;
+    ctx_set_problem(B, n, kb, wv);
+    const LCtx& c = G_CTX;
+    if (threadIdx.x == 0) {
+        for (int q = 0; q < 8; ++q) g_ctx.tk[q] = 0;
+        g_ctx.last_step = 0.0;
+        g_ctx.refine_rounds = g_ctx.second_attempt = g_ctx.f32_count = 0;
+        g_ctx.direct = 0;
+        g_ctx.kkt_w = nullptr;
+        g_ctx.kkt_f32 = 0;
+    }
+    __syncthreads();
     gdouble* SIG = VEC(c.w, c.nm, V_SIG);
     gdouble* RHS = VEC(c.w, c.nm, V_RHS);
     int fs = 0;
