@@ -104,6 +104,53 @@ template <bool SM> __device__ __forceinline__ void writerec_lc_body(double* a, s
 }
 __global__ void __launch_bounds__(256, 2) k_writerec_lc(double* a, size_t per) { writerec_lc_body<false>(a, per); }
 __global__ void __launch_bounds__(256, 2) k_writerec_lc_sm(double* a, size_t per) { writerec_lc_body<true>(a, per); }
+// writerec with the records of TWO consecutive steps interleaved entry by entry (entry e of steps 2j, 2j + 1 adjacent): every lane keeps the
+// values of the even step in registers and writes 16 bytes every second step -- half the store instructions and half the write requests
+// for the same bytes, no LDS staging.  ROWS: the y lane's five values are the fifth column of the spike record (five lanes x 16 bytes per
+// instruction) instead of five separate 16-byte stores
+template <bool ROWS> __device__ __forceinline__ void writerec_pair_body(double* a, size_t per)
+{
+    double* base = a + (size_t)blockIdx.x * per;
+    const int g = threadIdx.x >> 4, cl = threadIdx.x & 15;
+    const size_t steps = per / (16 * 46);
+    double* AD = base + (size_t)g * steps * 20;
+    double* AY = base + (size_t)16 * steps * 20 + (size_t)g * steps * 26;
+    for (size_t k = 0; k + 1 < steps; k += 2) {
+        const d2u v = {(double)k, 1.0};
+        const size_t j = k >> 1;
+        if (cl < 5) {
+            for (int r = cl; r < 5; ++r) *(d2u*)(AD + j * 40 + (r * (r + 1) / 2 + cl) * 2) = v;
+            *(d2u*)(AD + j * 40 + (15 + cl) * 2) = v;
+        } else if (ROWS && cl >= 11) {
+            for (int r = 0; r < 5; ++r) *(d2u*)(AY + j * 52 + (r * 5 + (cl - 11)) * 2) = v;
+        } else if (!ROWS && cl >= 11 && cl < 15) {
+            for (int r = 0; r < 5; ++r) *(d2u*)(AY + j * 52 + (r * 4 + (cl - 11)) * 2) = v;
+        } else if (!ROWS && cl == 15) {
+            for (int r = 0; r < 5; ++r) *(d2u*)(AY + j * 52 + (20 + r) * 2) = v;
+        }
+    }
+}
+__global__ void __launch_bounds__(256, 2) k_writerec_pair(double* a, size_t per) { writerec_pair_body<false>(a, per); }
+__global__ void __launch_bounds__(256, 2) k_writerec_pair_rows(double* a, size_t per) { writerec_pair_body<true>(a, per); }
+// the same with FOUR steps interleaved (two 16-byte stores per entry and lane every fourth step, 32 bytes per lane contiguous)
+__global__ void __launch_bounds__(256, 2) k_writerec_quad_rows(double* a, size_t per)
+{
+    double* base = a + (size_t)blockIdx.x * per;
+    const int g = threadIdx.x >> 4, cl = threadIdx.x & 15;
+    const size_t steps = per / (16 * 46);
+    double* AD = base + (size_t)g * steps * 20;
+    double* AY = base + (size_t)16 * steps * 20 + (size_t)g * steps * 26;
+    for (size_t k = 0; k + 3 < steps; k += 4) {
+        const d2u v = {(double)k, 1.0};
+        const size_t j = k >> 2;
+        if (cl < 5) {
+            for (int r = cl; r < 5; ++r) { double* o = AD + j * 80 + (r * (r + 1) / 2 + cl) * 4; *(d2u*)o = v; *(d2u*)(o + 2) = v; }
+            double* o = AD + j * 80 + (15 + cl) * 4; *(d2u*)o = v; *(d2u*)(o + 2) = v;
+        } else if (cl >= 11) {
+            for (int r = 0; r < 5; ++r) { double* o = AY + j * 104 + (r * 5 + (cl - 11)) * 4; *(d2u*)o = v; *(d2u*)(o + 2) = v; }
+        }
+    }
+}
 // per-group streams as in writerec, but every store instruction writes contiguous 16-byte items (what staging the records of two steps in
 // LDS produces: 46 items per pair of steps and group)
 __global__ void __launch_bounds__(256, 2) k_writerec_staged(double* a, size_t per)
@@ -143,8 +190,8 @@ int main(int argc, char** argv)
     hipEvent_t e0, e1;
     CK(hipEventCreate(&e0));
     CK(hipEventCreate(&e1));
-    const char* names[] = {"read16", "write8", "write16", "writerec", "mix_writerec_read16", "writerec_stepmajor", "writerec_staged", "writerec_lanecontig", "writerec_lanecontig_stepmajor"};
-    for (int t = 0; t < 9; ++t) {
+    const char* names[] = {"read16", "write8", "write16", "writerec", "mix_writerec_read16", "writerec_stepmajor", "writerec_staged", "writerec_lanecontig", "writerec_lanecontig_stepmajor", "writerec_pair", "writerec_pair_rows", "writerec_quad_rows"};
+    for (int t = 0; t < 12; ++t) {
         float best = 1e30f;
         for (int r = 0; r < reps + 1; ++r) {
             CK(hipEventRecord(e0, 0));
@@ -157,6 +204,9 @@ int main(int argc, char** argv)
             if (t == 6) hipLaunchKernelGGL(k_writerec_staged, dim3(wgs), dim3(256), 0, 0, a, per_bytes / 8);
             if (t == 7) hipLaunchKernelGGL(k_writerec_lc, dim3(wgs), dim3(256), 0, 0, a, per_bytes / 8);
             if (t == 8) hipLaunchKernelGGL(k_writerec_lc_sm, dim3(wgs), dim3(256), 0, 0, a, per_bytes / 8);
+            if (t == 9) hipLaunchKernelGGL(k_writerec_pair, dim3(wgs), dim3(256), 0, 0, a, per_bytes / 8);
+            if (t == 10) hipLaunchKernelGGL(k_writerec_pair_rows, dim3(wgs), dim3(256), 0, 0, a, per_bytes / 8);
+            if (t == 11) hipLaunchKernelGGL(k_writerec_quad_rows, dim3(wgs), dim3(256), 0, 0, a, per_bytes / 8);
             CK(hipEventRecord(e1, 0));
             CK(hipEventSynchronize(e1));
             float ms;
@@ -164,7 +214,7 @@ int main(int argc, char** argv)
             if (r > 0 && ms < best) best = ms;
         }
         const double rec = (double)(per_bytes / 8 / (16 * 46)) * 16 * 45 * 8;          // bytes one workgroup writes in the record pattern
-        const double moved = (t == 3 || t == 5 || t == 7 || t == 8) ? rec * wgs : t == 4 ? (rec + (double)per_bytes) * (wgs / 2)
+        const double moved = (t == 3 || t == 5 || t == 7 || t >= 8) ? rec * wgs : t == 4 ? (rec + (double)per_bytes) * (wgs / 2)
                              : t == 6 ? (double)(per_bytes / 8 / (16 * 46) / 2) * 2 * 16 * 46 * 8 * wgs : (double)total;
         printf("{\"pattern\": \"%s\", \"workgroups\": %d, \"KB_per_workgroup\": %zu, \"best_ms\": %.3f, \"GBps\": %.0f}\n", names[t], wgs, kb, best,
                moved / (best * 1e-3) / 1e9);
