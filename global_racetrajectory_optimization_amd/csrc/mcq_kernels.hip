@@ -154,6 +154,17 @@ template <int N> __device__ __forceinline__ double bcast_row16(double v)
 {
     return __builtin_amdgcn_update_dpp(0.0, v, 0x150 + N, 0xf, 0xf, true);
 }
+// c - (a of lane N of the 16-lane row) * b  as ONE instruction: the broadcast rides on the multiply-add as its DPP operand (fp64 VALU
+// operations take row_newbcast).  hipcc 7.2 folds only 32-bit DPP moves into their users, hence the instruction by name; s_nop 1 = the two
+// wait states a DPP read needs after a VALU write of the same register, which nobody checks inside an asm statement.  (The SIMT
+// interpreter of tests/emu supplies this primitive itself, as it supplies the builtins.)
+#ifndef MCQ_HAVE_FNMA_BCAST_ROW16
+template <int N> __device__ __forceinline__ double fnma_bcast_row16(double a, double b, double c)
+{
+    asm("s_nop 1\n\tv_fmac_f64_dpp %0, %1, -%2 row_newbcast:%3 row_mask:0xf bank_mask:0xf" : "+v"(c) : "v"(a), "v"(b), "n"(N));
+    return c;
+}
+#endif
 
 #ifndef MCQ_IPM_TOL
 #define MCQ_IPM_TOL 1e-10

@@ -270,6 +270,9 @@ inline double hipemu_update_dpp(double old, double src, int ctrl, int rm, int bm
 #define __builtin_amdgcn_rcp(x) (1.0 / (double)(x))              /* v_rcp_f64: the kernels refine it */
 #define __builtin_amdgcn_rsq(x) (1.0 / sqrt((double)(x)))      /* v_rsq_f64: the kernels refine it */
 #define __builtin_amdgcn_update_dpp(old, src, ctrl, rm, bm, bc) hipemu_update_dpp((old), (src), (ctrl), (rm), (bm), (bc))
+// v_fmac_f64_dpp ... -b row_newbcast:N, which the kernels emit by name (mcq_kernels.hip: fnma_bcast_row16)
+#define MCQ_HAVE_FNMA_BCAST_ROW16 1
+template <int N> inline double fnma_bcast_row16(double a, double b, double c) { return fma(-hipemu_update_dpp(0.0, a, 0x150 + N, 0xf, 0xf, true), b, c); }
 inline int hipemu_readlane(int v, int src) { return (int)__shfl((double)v, src); }
 #define __builtin_amdgcn_readlane(v, l) hipemu_readlane((v), (l))
 #define __builtin_amdgcn_s_barrier() hipemu::block_barrier()
