@@ -1,5 +1,6 @@
 #!/bin/bash
-# GPU box: same-box A/B of the build variants + the elimination in isolation
+# GPU box: same-box A/B of the build variants, twice (run-to-run spread)
 R=${GRAFT_REPO_ROOT:-$(pwd)}
 cd $R; mkdir -p gpurun_out
-scripts/gpu_variants.sh r04d "n2000_first_pass or reference_tracks_match_golden"
+scripts/gpu_variants.sh r04d "n2000_first_pass"
+scripts/gpu_variants.sh r04e "n2000_first_pass"

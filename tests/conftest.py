@@ -34,8 +34,16 @@ def emu_lib():
     src = [os.path.join(ROOT, "global_racetrajectory_optimization_amd", "csrc", f)
            for f in ("mcq_kernels.hip", "mcq_kernels.h", "mcq_api.hip", "mcq_kkt.inc", "mcq_tri.inc")]
     src.append(os.path.join(ROOT, "tests", "emu", "include", "hip", "hip_runtime.h"))
-    if not os.path.exists(path) or any(os.path.getmtime(s) > os.path.getmtime(path) for s in src):
-        subprocess.run([os.path.join(ROOT, "tests", "emu", "build_emu.sh")], check=True)
+    def stale():
+        return not os.path.exists(path) or any(os.path.getmtime(s) > os.path.getmtime(path) for s in src)
+
+    if stale():
+        # several pytest-xdist workers may get here at once: one builds (build_emu.sh publishes the library with a rename), the others wait
+        import fcntl
+        with open(path + ".lock", "w") as lock:
+            fcntl.flock(lock, fcntl.LOCK_EX)
+            if stale():
+                subprocess.run([os.path.join(ROOT, "tests", "emu", "build_emu.sh")], check=True)
     return path
 
 
