@@ -452,11 +452,6 @@ __device__ __noinline__ void gradient(const LCtx& c, const gdouble* x, const gdo
         return;
     }
     // E and E' through the spline system itself (mcq_tri.inc): no band is read
-    if (n <= TRI_MAXN) {
-        tri_gradient_lds(c, x, VEC(c.w, c.nm, V_KREF), MCQ_F_SCALE, extra, tmp, g);
-        if (threadIdx.x == 0) c.tk[2] += TICK() - t0;
-        return;
-    }
     tri_apply_E(c, x, VEC(c.w, c.nm, V_KREF), MCQ_F_SCALE, tmp);
     if (extra) {
         for (int i = threadIdx.x; i < n; i += MCQ_NT) tmp[i] += extra[i];
