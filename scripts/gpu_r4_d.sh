@@ -1,6 +1,6 @@
 #!/bin/bash
+# GPU box: same-box A/B of the build variants, twice (run-to-run spread)
 R=${GRAFT_REPO_ROOT:-$(pwd)}
 cd $R; mkdir -p gpurun_out
-timeout 300 python scripts/diag_stadium.py 2>&1 | grep status | cut -c1-250
-timeout 900 python -m pytest tests -m gpu -q -x 2>&1 | tail -3
-scripts/gpu_variants.sh r04d "n2000_first_pass"
+scripts/gpu_variants.sh r04d "n2000_first_pass or reference_tracks_match_golden"
+scripts/gpu_variants.sh r04e "n2000_first_pass"
