@@ -586,7 +586,8 @@ extern "C" int mcq_relinearise_device(mcq_handle* h, int batch, int nmax, const 
 static int vel_profile_launch(mcq_handle* h, int batch, int n, int nmax, const int* n_of_track, const int* track_of,
                               const double* kappa, const double* el_lengths, const double* ggv, int n_ggv,
                               const double* ax_max_machines, int n_machines, const double* drag_coeff, const double* m_veh,
-                              const double* v_max, double dyn_model_exp, double* vx_out, double* lap_time_out)
+                              const double* v_max, double dyn_model_exp, double* vx_out, double* lap_time_out,
+                              const double* mu = nullptr, int filt_window = 0)
 {
     if (!h || batch <= 0 || (!n_of_track && n < 2) || nmax < n || nmax < 2 || !kappa || !el_lengths || !ggv || n_ggv < 1 ||
         !ax_max_machines || n_machines < 1 || !drag_coeff || !m_veh || !v_max || !vx_out || !lap_time_out ||
@@ -611,6 +612,7 @@ static int vel_profile_launch(mcq_handle* h, int batch, int n, int nmax, const i
     V.track_of = track_of; V.kappa = kappa; V.el = el_lengths;
     V.ggv = ggv; V.ng = n_ggv; V.axm = ax_max_machines; V.nam = n_machines;
     V.drag = drag_coeff; V.mass = m_veh; V.vmax = v_max; V.dyn_exp = dyn_model_exp;
+    V.mu = mu; V.filt_window = filt_window;
     V.scratch = h->vel_scratch; V.vx_out = vx_out; V.lap_time = lap_time_out;
     hipLaunchKernelGGL(mcq_vel_profile_kernel, dim3((batch + 63) / 64), dim3(64), 0, h->stream, V);
     HIP_TRY(hipGetLastError());
@@ -635,6 +637,19 @@ extern "C" int mcq_vel_profile_device_ragged(mcq_handle* h, int batch, int nmax,
     if (!n_of_track) { g_err = "mcq_vel_profile_device_ragged: n_of_track is NULL"; return MCQ_E_ARG; }
     return vel_profile_launch(h, batch, 0, nmax, n_of_track, track_of, kappa, el_lengths, ggv, n_ggv, ax_max_machines,
                               n_machines, drag_coeff, m_veh, v_max, dyn_model_exp, vx_out, lap_time_out);
+}
+
+extern "C" int mcq_vel_profile_device_opts(mcq_handle* h, int batch, int n, int nmax, const int* n_of_track, const int* track_of,
+                                           const double* kappa, const double* el_lengths, const double* ggv, int n_ggv,
+                                           const double* ax_max_machines, int n_machines, const double* drag_coeff,
+                                           const double* m_veh, const double* v_max, const mcq_vel_opts* opts, double* vx_out,
+                                           double* lap_time_out)
+{
+    if (!opts) { g_err = "mcq_vel_profile_device_opts: opts is NULL"; return MCQ_E_ARG; }
+    if (opts->filt_window < 0) { g_err = "mcq_vel_profile_device_opts: negative filt_window"; return MCQ_E_ARG; }
+    return vel_profile_launch(h, batch, n_of_track ? 0 : n, nmax, n_of_track, track_of, kappa, el_lengths, ggv, n_ggv, ax_max_machines,
+                              n_machines, drag_coeff, m_veh, v_max, opts->dyn_model_exp, vx_out, lap_time_out, opts->mu,
+                              opts->filt_window);
 }
 
 extern "C" int mcq_raceline_device(mcq_handle* h, int batch, int nmax, const int* n_in, const double* reftrack,

@@ -198,6 +198,8 @@ struct McqVel {
     const double* mass;      // [batch]
     const double* vmax;      // [batch]
     double dyn_exp;
+    const double* mu;        // [tracks][nmax] friction coefficient per waypoint, or nullptr (1 everywhere)
+    int filt_window;         // odd width of the closed moving-average filter on the finished profile (tph.conv_filt); <= 1: none
     double* scratch;         // [2 nmax][batch]: the lap-doubled profile, variant-minor (coalesced across threads)
     double* vx_out;          // [batch][nmax]
     double* lap_time;        // [batch]

@@ -1967,13 +1967,13 @@ __device__ __forceinline__ double vp_interp(double x, const gdouble* tab, int cn
     return y0 + (y1 - y0) * (x - x0) / (x1 - x0);
 }
 
-// longitudinal acceleration still available at speed v on radius `rad` (tph.calc_vel_profile.calc_ax_poss, mu = 1: tyre
-// potential shared with the lateral acceleration through the friction ellipse of exponent e, machine limit when accelerating,
+// longitudinal acceleration still available at speed v on radius `rad` with friction coefficient mu (tph.calc_vel_profile.calc_ax_poss:
+// tyre potential shared with the lateral acceleration through the friction ellipse of exponent e, machine limit when accelerating,
 // drag -- which helps when the deceleration is integrated backwards)
-__device__ __forceinline__ double vp_ax_possible(double v, double rad, const gdouble* ggv, int ng, const gdouble* axm, int nam,
+__device__ __forceinline__ double vp_ax_possible(double v, double rad, double mu, const gdouble* ggv, int ng, const gdouble* axm, int nam,
                                                  bool accel, double e, double drag_over_m)
 {
-    const double ax_t = fabs(vp_interp(v, ggv, ng, 3, 1)), ay_t = vp_interp(v, ggv, ng, 3, 2);
+    const double ax_t = fabs(mu * vp_interp(v, ggv, ng, 3, 1)), ay_t = mu * vp_interp(v, ggv, ng, 3, 2);
     const double ay_used = v * v / rad;
     const double radicand = 1.0 - pow(ay_used / ay_t, e);
     const double ax_tires = radicand > 0.0 ? ax_t * pow(radicand, 1.0 / e) : 0.0;
@@ -1990,8 +1990,13 @@ __device__ __forceinline__ double vp_ax_possible(double v, double rad, const gdo
 //   a sweep is switched on at the first point of every acceleration phase of the profile it starts from (v[i+1] > v[i] and not
 //     v[i] > v[i-1], both on the values before the sweep touched them) and switched off where the attainable speed exceeds v_max;
 //   the backward sweep re-evaluates the deceleration one point ahead at the attainable speed and keeps the smaller speed;
-//   backward, step p -> p-1 uses el[p] (upstream flips its arrays as a whole).
-// A ggv / machine table that ends below v_max (upstream raises RuntimeError) gives lap_time = NaN.
+//   backward, step p -> p-1 uses el[p] (upstream flips its arrays as a whole);
+//   optional: a friction coefficient per waypoint (V.mu: scales both tyre limits; the first estimate of the lateral limit uses its MEAN, as
+//     upstream -- the fixed point stops on a 0.5 % change, so the start matters at that level) and tph.conv_filt's closed moving average
+//     of odd width V.filt_window over the finished profile [REF main_globaltraj.py:407, params/racecar.ini:54-57], lap time from the
+//     filtered profile.
+// A ggv / machine table that ends below v_max (upstream raises RuntimeError) gives lap_time = NaN; so does a filter window that is even
+// or wider than the ring.
 __global__ void __launch_bounds__(64) mcq_vel_profile_kernel(McqVel V)
 {
     const int v = blockIdx.x * 64 + threadIdx.x;
@@ -2011,10 +2016,12 @@ __global__ void __launch_bounds__(64) mcq_vel_profile_kernel(McqVel V)
     const gdouble* el = (const gdouble*)(V.el + row);
     const gdouble* ggv = (const gdouble*)(V.ggv + (size_t)v * V.ng * 3);
     const gdouble* axm = (const gdouble*)(V.axm + (size_t)v * V.nam * 2);
+    const gdouble* muv = V.mu ? (const gdouble*)(V.mu + row) : nullptr;
+    const int fw = V.filt_window > 1 ? V.filt_window : 0;
     gdouble* S = (gdouble*)V.scratch + v;       // S[j * bt]
     const double vmax = V.vmax[v], e = V.dyn_exp, dom = V.drag[v] / V.mass[v];
     const int ng = V.ng, nam = V.nam;
-    if (ggv[(size_t)(ng - 1) * 3] < vmax || axm[(size_t)(nam - 1) * 2] < vmax) {
+    if (ggv[(size_t)(ng - 1) * 3] < vmax || axm[(size_t)(nam - 1) * 2] < vmax || (fw && (fw % 2 == 0 || fw > n))) {
         V.lap_time[v] = NAN;
         for (int i = 0; i < n; ++i) V.vx_out[(size_t)v * V.nmax + i] = NAN;
         return;
@@ -2022,15 +2029,22 @@ __global__ void __launch_bounds__(64) mcq_vel_profile_kernel(McqVel V)
     double aymin = ggv[2];
     for (int k = 1; k < ng; ++k) aymin = fmin(aymin, ggv[(size_t)k * 3 + 2]);
 #define VP_RAD(i_) ((kap[(i_)] != 0.0) ? fabs(1.0 / kap[(i_)]) : (double)INFINITY)
+#define VP_MU(i_) (muv ? muv[(i_)] : 1.0)
 
     // ---- lateral limit ------------------------------------------------------------------------------------------------------------
-    for (int i = 0; i < n; ++i) S[(size_t)i * bt] = sqrt(aymin * VP_RAD(i));
+    double mu_mean = 1.0;
+    if (muv) {
+        mu_mean = 0.0;
+        for (int i = 0; i < n; ++i) mu_mean += muv[i];
+        mu_mean /= (double)n;
+    }
+    for (int i = 0; i < n; ++i) S[(size_t)i * bt] = sqrt(mu_mean * aymin * VP_RAD(i));
     for (int it = 0; it < 100; ++it) {
         double worst = 0.0;
         bool any_nan = false;
         for (int i = 0; i < n; ++i) {
             const double vx = S[(size_t)i * bt];
-            const double vn = sqrt(vp_interp(vx, ggv, ng, 3, 2) * VP_RAD(i));
+            const double vn = sqrt(VP_MU(i) * vp_interp(vx, ggv, ng, 3, 2) * VP_RAD(i));
             const double ch = fabs(vn / vx - 1.0);
             if (ch != ch) any_nan = true;
             worst = fmax(worst, ch);
@@ -2058,7 +2072,7 @@ __global__ void __launch_bounds__(64) mcq_vel_profile_kernel(McqVel V)
             prev_rising = rising;
             o_cur = nxt;
             if (active) {
-                const double ax = vp_ax_possible(cur, VP_RAD(i), ggv, ng, axm, nam, true, e, dom);
+                const double ax = vp_ax_possible(cur, VP_RAD(i), VP_MU(i), ggv, ng, axm, nam, true, e, dom);
                 const double vnext = sqrt(cur * cur + 2.0 * ax * el[i]);
                 if (vnext < nxt) { nxt = vnext; S[(size_t)(j + 1) * bt] = nxt; }
                 if (vnext > vmax) active = false;
@@ -2083,9 +2097,9 @@ __global__ void __launch_bounds__(64) mcq_vel_profile_kernel(McqVel V)
             o_cur = prv;
             if (active) {
                 const double c2 = cur * cur, l2 = 2.0 * el[i];
-                const double ax = vp_ax_possible(cur, VP_RAD(i), ggv, ng, axm, nam, false, e, dom);
+                const double ax = vp_ax_possible(cur, VP_RAD(i), VP_MU(i), ggv, ng, axm, nam, false, e, dom);
                 double vprev = sqrt(c2 + ax * l2);
-                const double ax2 = vp_ax_possible(vprev, VP_RAD(im), ggv, ng, axm, nam, false, e, dom);
+                const double ax2 = vp_ax_possible(vprev, VP_RAD(im), VP_MU(im), ggv, ng, axm, nam, false, e, dom);
                 const double vtmp = sqrt(c2 + ax2 * l2);
                 if (vtmp < vprev) vprev = vtmp;
                 if (vprev < prv) { prv = vprev; S[(size_t)(j - 1) * bt] = prv; }
@@ -2095,13 +2109,31 @@ __global__ void __launch_bounds__(64) mcq_vel_profile_kernel(McqVel V)
         }
     }
 #undef VP_RAD
-    // ---- second lap out; lap time from the piecewise-constant accelerations (tph.calc_ax_profile / calc_t_profile) -----------
+#undef VP_MU
+    // ---- tph.conv_filt, closed: the mean over fw consecutive points of the ring, products summed in numpy.convolve's order; from the
+    //      second lap into the first (done with), which then is the profile ------------------------------------------------------------
+    size_t lap = (size_t)n;
+    if (fw) {
+        const int hw = (fw - 1) / 2;
+        const double ker = 1.0 / (double)fw;
+        for (int i = 0; i < n; ++i) {
+            double acc = 0.0;
+            for (int d = hw; d >= -hw; --d) {
+                int j = i + d;
+                j = j < 0 ? j + n : j >= n ? j - n : j;
+                acc += S[(size_t)(n + j) * bt] * ker;
+            }
+            S[(size_t)i * bt] = acc;
+        }
+        lap = 0;
+    }
+    // ---- the profile out; lap time from the piecewise-constant accelerations (tph.calc_ax_profile / calc_t_profile) -----------
     gdouble* out = (gdouble*)(V.vx_out + (size_t)v * V.nmax);
     double t = 0.0;
-    const double v0 = S[(size_t)n * bt];
+    const double v0 = S[lap * bt];
     double va = v0;
     for (int i = 0; i < n; ++i) {
-        const double vb = i + 1 < n ? S[(size_t)(n + i + 1) * bt] : v0;
+        const double vb = i + 1 < n ? S[(lap + i + 1) * bt] : v0;
         out[i] = va;
         // constant acceleration over the element: t = 2 l / (v_a + v_b).  Algebraically tph.calc_t_profile's
         // (-v_a + sqrt(v_a^2 + 2 a l)) / a with a = (v_b^2 - v_a^2) / (2 l), which cancels catastrophically as a -> 0 (a 1e-15

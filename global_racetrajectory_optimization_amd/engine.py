@@ -38,6 +38,10 @@ class McqOpts(ctypes.Structure):
                 ("warm_start", ctypes.c_int)]
 
 
+class McqVelOpts(ctypes.Structure):
+    _fields_ = [("dyn_model_exp", ctypes.c_double), ("filt_window", ctypes.c_int), ("reserved_", ctypes.c_int), ("mu", ctypes.c_void_p)]
+
+
 class McqInfo(ctypes.Structure):
     _fields_ = [("ipm_iters", ctypes.c_int), ("as_iters", ctypes.c_int), ("n_active_box", ctypes.c_int),
                 ("n_active_kappa", ctypes.c_int), ("kappa_max", ctypes.c_double), ("kkt_res", ctypes.c_double),
@@ -56,7 +60,7 @@ EXPORTED_SYMBOLS = ("mcq_create", "mcq_destroy", "mcq_last_error", "mcq_default_
                     "mcq_iqp_device", "mcq_iqp_batch", "mcq_iqp_set_round_callback", "mcq_host_alloc", "mcq_host_free",
                     "mcq_solve_device", "mcq_solve_device_f32", "mcq_solve_device_f32_rows", "mcq_solve_batch_f32",
                     "mcq_solve_host_pipelined", "mcq_solve_device_ragged", "mcq_solve_device_ragged_params", "mcq_prep_device", "mcq_relinearise_device",
-                    "mcq_vel_profile_device", "mcq_vel_profile_device_ragged", "mcq_raceline_device", "mcq_normals_crossing_device",
+                    "mcq_vel_profile_device", "mcq_vel_profile_device_ragged", "mcq_vel_profile_device_opts", "mcq_raceline_device", "mcq_normals_crossing_device",
                     "mcq_device_alloc",
                     "mcq_device_free", "mcq_copy_to_device", "mcq_copy_to_host", "mcq_sync", "mcq_stream",
                     "mcq_last_timing", "mcq_workspace_bytes",
@@ -135,6 +139,9 @@ def load_library(path=None):
     lib.mcq_vel_profile_device_ragged.argtypes = [vp, ctypes.c_int, ctypes.c_int, vp, vp, vp, vp, vp, ctypes.c_int, vp,
                                                   ctypes.c_int, vp, vp, vp, ctypes.c_double, vp, vp]
     lib.mcq_vel_profile_device_ragged.restype = ctypes.c_int
+    lib.mcq_vel_profile_device_opts.argtypes = [vp, ctypes.c_int, ctypes.c_int, ctypes.c_int, vp, vp, vp, vp, vp, ctypes.c_int, vp,
+                                                ctypes.c_int, vp, vp, vp, ctypes.POINTER(McqVelOpts), vp, vp]
+    lib.mcq_vel_profile_device_opts.restype = ctypes.c_int
     lib.mcq_raceline_device.argtypes = [vp, ctypes.c_int, ctypes.c_int, vp, vp, vp, vp, ctypes.c_double, ctypes.c_int, vp, vp,
                                         vp, vp, vp, vp]
     lib.mcq_raceline_device.restype = ctypes.c_int
@@ -574,8 +581,10 @@ class Engine:
         return [nv[k, :ns[k]].copy() for k in range(bsz)], [sc[k, :ns[k]].copy() for k in range(bsz)]
 
     def vel_profile_batch(self, kappa, el_lengths, ggv, ax_max_machines, drag_coeff, m_veh, v_max, dyn_model_exp=1.0,
-                          track_of=None, n_of_track=None):
-        """ggv velocity profiles and lap times of a batch of variants on the device (mcq_vel_profile_device).
+                          track_of=None, n_of_track=None, mu=None, filt_window=None):
+        """ggv velocity profiles and lap times of a batch of variants on the device (mcq_vel_profile_device; with mu -- friction
+        coefficient per waypoint, [tracks, n] -- or filt_window -- tph.conv_filt's odd moving-average width over the finished profile --
+        mcq_vel_profile_device_opts).
 
         kappa, el_lengths: [tracks, n]; ggv: [batch, g, 3]; ax_max_machines: [batch, m, 2]; drag_coeff, m_veh, v_max: [batch];
         track_of: [batch] ints (row of kappa / el per variant) or None when tracks == batch; n_of_track: [tracks] valid entries
@@ -592,6 +601,12 @@ class Engine:
             raise RuntimeError("ggv has to cover the entire velocity range of the car (i.e. >= v_max)!")
         if np.any(axm[:, -1, 0] < scal[2]):
             raise RuntimeError("ax_max_machines has to cover the entire velocity range of the car (i.e. >= v_max)!")
+        if filt_window is not None and int(filt_window) % 2 == 0:
+            raise RuntimeError("Window width of moving average filter must be odd!")
+        if mu is not None:
+            mu = np.ascontiguousarray(mu, dtype=np.float64)
+            if mu.shape != kappa.shape:
+                raise RuntimeError("kappa and mu must have the same length!")
         tr = None if track_of is None else np.ascontiguousarray(track_of, dtype=np.int32)
         nt = None if n_of_track is None else np.ascontiguousarray(n_of_track, dtype=np.int32)
         ptrs = []
@@ -607,7 +622,12 @@ class Engine:
             d_t = up(tr) if tr is not None else None
             d_vx = self.alloc(bsz * n * 8); ptrs.append(d_vx)
             d_lt = self.alloc(bsz * 8); ptrs.append(d_lt)
-            if nt is not None:
+            if mu is not None or filt_window is not None:
+                vo = McqVelOpts(float(dyn_model_exp), int(filt_window or 0), 0, up(mu) if mu is not None else None)
+                rc = self.lib.mcq_vel_profile_device_opts(self.h, bsz, n, n, up(nt) if nt is not None else None, d_t, d_k, d_e, d_g,
+                                                          ggv.shape[1], d_a, axm.shape[1], d_s[0], d_s[1], d_s[2], ctypes.byref(vo),
+                                                          d_vx, d_lt)
+            elif nt is not None:
                 rc = self.lib.mcq_vel_profile_device_ragged(self.h, bsz, n, up(nt), d_t, d_k, d_e, d_g, ggv.shape[1], d_a,
                                                             axm.shape[1], d_s[0], d_s[1], d_s[2], float(dyn_model_exp),
                                                             d_vx, d_lt)

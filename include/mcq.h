@@ -216,7 +216,7 @@ int mcq_relinearise_device(mcq_handle* h, int batch, int nmax, const int* n_in, 
                            double stepsize, double* reftrack_out, double* normvec_out, int* n_out, int* status_out);
 /* ggv velocity profile and lap time of a batch of (track, vehicle) variants -- what the lap-time-matrix sweep of the
  * reference runs per cell [REF main_globaltraj.py:400-422, 460-493]: tph.calc_vel_profile (closed track, global ggv, no
- * filter; every step of upstream's solver: fixed-point lateral limit over all ggv rows, sweeps gated on the acceleration-phase
+ * filter, mu = 1 -- mcq_vel_profile_device_opts below takes both; every step of upstream's solver: fixed-point lateral limit over all ggv rows, sweeps gated on the acceleration-phase
  * starts and on v_max, one look-ahead round in the backward sweep) followed by calc_ax_profile / calc_t_profile (lap time as
  * the sum of 2 l / (v_a + v_b)).  One device thread per variant.  A variant whose ggv or machine table ends below its v_max
  * (tph raises RuntimeError) gets lap_time NaN and a vx_out row of NaNs (never stale buffer contents).  All pointers DEVICE pointers:
@@ -237,6 +237,23 @@ int mcq_vel_profile_device_ragged(mcq_handle* h, int batch, int nmax, const int*
                                   const double* ax_max_machines, int n_machines, const double* drag_coeff,
                                   const double* m_veh, const double* v_max, double dyn_model_exp, double* vx_out,
                                   double* lap_time_out);
+
+/* The same two entries with the options of tph.calc_vel_profile that main_globaltraj.py reads from its parameter file
+ * [REF main_globaltraj.py:400-410, params/racecar.ini:53-57: vel_calc_opts] or leaves at their defaults: dyn_model_exp; filt_window --
+ * tph.conv_filt's closed moving average of that (odd) width over the finished profile, lap time from the filtered profile (0 or 1:
+ * none; an even width, where tph raises RuntimeError, or one wider than the ring gives lap_time NaN); mu -- a friction coefficient per
+ * waypoint, DEVICE pointer [tracks][nmax] like kappa, or NULL for 1 everywhere (tph's `mu` argument; the reference passes none).
+ * n_of_track NULL: every row has n entries (mcq_vel_profile_device); otherwise n is ignored (.._ragged). */
+typedef struct mcq_vel_opts {
+    double dyn_model_exp;
+    int filt_window;
+    int reserved_;
+    const double* mu;
+} mcq_vel_opts;
+int mcq_vel_profile_device_opts(mcq_handle* h, int batch, int n, int nmax, const int* n_of_track, const int* track_of,
+                                const double* kappa, const double* el_lengths, const double* ggv, int n_ggv,
+                                const double* ax_max_machines, int n_machines, const double* drag_coeff, const double* m_veh,
+                                const double* v_max, const mcq_vel_opts* opts, double* vx_out, double* lap_time_out);
 
 /* What main_globaltraj.py runs between the QP and the velocity profile [REF main_globaltraj.py:371-387], batched on the device:
  * tph.create_raceline (raceline = refline + alpha * normal, closed cubic spline through it with unit scalings, re-sampled at

@@ -1,6 +1,4 @@
 #!/bin/bash
-# GPU box: same-box A/B of the build variants, twice (run-to-run spread)
 R=${GRAFT_REPO_ROOT:-$(pwd)}
 cd $R; mkdir -p gpurun_out
-scripts/gpu_variants.sh r04d "n2000_first_pass or reference_tracks_match_golden"
-scripts/gpu_variants.sh r04e "n2000_first_pass"
+timeout 600 python -m pytest tests/test_gpu_parity.py -m gpu -q -x -k "velocity_profile or lap_time" 2>&1 | grep -v "^Hostname\|^Librccl\|^RCCL\|^HIP ver\|^ROCm" | tail -5

@@ -529,6 +529,20 @@ def test_prep_on_device_and_solve_without_normals(gpu_engine, golden):
         assert abs(curv[k] - float(golden[name]["curv_error_max"])) < CURV_TOL, name
 
 
+def test_velocity_profile_filter_window_and_friction_map(gpu_engine, golden):
+    """mcq_vel_profile_device_opts on the GPU: tph.calc_vel_profile's filt_window [REF params/racecar.ini:54-57,
+    main_globaltraj.py:407] and per-waypoint friction coefficients against oracle/vel_ref.py and the host shim (the helper of the
+    emulator suite, here through the real library)."""
+    from test_emu_kernels import _check_vel_profiles, _raceline_kappa_el, _vehicle_variants, _vehicle_variants_speed_dependent
+    for name in ("rounded_rectangle", "modena_2019"):
+        kappa, el = _raceline_kappa_el(golden[name])
+        n = kappa.size
+        mu = 0.9 + 0.2 * np.cos(2.0 * np.pi * np.arange(n) / n * 3.0)
+        _check_vel_profiles(gpu_engine, kappa, el, _vehicle_variants(), 1.0, filt_window=5)
+        _check_vel_profiles(gpu_engine, kappa, el, _vehicle_variants_speed_dependent(), 2.0, mu=mu)
+        _check_vel_profiles(gpu_engine, kappa, el, _vehicle_variants_speed_dependent(), 1.0, mu=mu, filt_window=7)
+
+
 def test_velocity_profile_lap_time_sweep(gpu_engine, golden):
     """Row f-3: a (gg-scale x top-speed) grid of vehicle variants over the racelines of two reference tracks in ONE launch
     (what the reference's lap-time matrix loops over [REF main_globaltraj.py:442-496]) against the ORACLE's restatement of
