@@ -348,7 +348,13 @@ def main():
     try:
         eng = engine.Engine(0 if emulate else local_rank, lib_path=args.emulate)
     except engine.EngineError as e:
-        raise SystemExit("bench.py needs a GPU for rank %d (the engine has no CPU path): %s" % (rank, e))
+        # a launcher that hands every rank ONE visible device (HIP_VISIBLE_DEVICES / ROCR_VISIBLE_DEVICES per process): that device is 0
+        if emulate or local_rank == 0 or "no such device" not in str(e):
+            raise SystemExit("bench.py needs a GPU for rank %d (the engine has no CPU path): %s" % (rank, e))
+        try:
+            eng = engine.Engine(0, lib_path=args.emulate)
+        except engine.EngineError as e2:
+            raise SystemExit("bench.py needs a GPU for rank %d (the engine has no CPU path): %s" % (rank, e2))
 
     dist = None
     collective = world > 1 or args.force_collective
