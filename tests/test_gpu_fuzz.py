@@ -12,7 +12,7 @@ from global_racetrajectory_optimization_amd import synthetic
 pytestmark = pytest.mark.gpu
 
 
-@pytest.mark.parametrize("n,w_veh", [(293, 2.0), (400, 3.4), (511, 1.6), (777, 3.0), (1001, 2.6), (1500, 3.4), (2000, 2.2), (2049, 2.4), (2100, 3.0), (2600, 3.6), (4100, 2.8)])
+@pytest.mark.parametrize("n,w_veh", [(293, 2.0), (400, 3.4), (511, 1.6), (777, 3.0), (1001, 2.6), (1500, 3.4), (2000, 2.2), (2047, 3.0), (2048, 2.6), (2049, 2.4), (2100, 3.0), (2600, 3.6), (4100, 2.8)])
 def test_random_rings_against_banded_cpu_solver(gpu_engine, n, w_veh):
     from oracle import banded_ref
     bsz = 24
@@ -52,3 +52,23 @@ def test_kkt_certificate_from_the_dense_oracle_assembly(gpu_engine, n, w_veh):
         assert np.all(g[at_lo] > -1e-8 * scale) and np.all(g[at_hi] < 1e-8 * scale)
         assert np.max(np.abs(k_ref + E @ x)) < 0.5
         assert int(np.count_nonzero(at_lo | at_hi)) == info[k]["n_active_box"]
+
+
+@pytest.mark.parametrize("n", [48, 71, 72, 73, 100, 143, 144, 145, 200])
+def test_rings_around_the_halo_widths_against_the_dense_oracle(gpu_engine, n):
+    """The sweeps' LDS arrays carry a halo of 72 waypoints either side (mcq_tri.inc): rings shorter than one halo wrap several times
+    inside it, rings below two halos have both copies of a waypoint written by the same few threads.  Dense oracle (these sizes cost
+    it nothing), two tracks per size in one ragged launch."""
+    from oracle import tph_ref
+    from test_emu_kernels import _small_track
+    probs, want = [], []
+    for m, seed in ((n, n), (n + 5, n + 300)):
+        ref, nv, A, sc = _small_track(m, seed=seed)
+        a_ref, err_ref = tph_ref.opt_min_curv(ref, nv, A, 0.5, 2.0)
+        probs.append(dict(reftrack=ref, normvec=nv, scaling=sc, kappa_bound=0.5, w_veh=2.0))
+        want.append((a_ref, err_ref))
+    al, curv, st, info = gpu_engine.solve_batch(probs)
+    assert list(st) == [0, 0]
+    for k, (a_ref, err_ref) in enumerate(want):
+        assert np.max(np.abs(al[k] - a_ref)) < 1e-8, (k, float(np.max(np.abs(al[k] - a_ref))))
+        assert abs(curv[k] - err_ref) < 1e-9
