@@ -12,7 +12,7 @@ from global_racetrajectory_optimization_amd import synthetic
 pytestmark = pytest.mark.gpu
 
 
-@pytest.mark.parametrize("n,w_veh", [(293, 2.0), (400, 3.4), (511, 1.6), (777, 3.0), (1001, 2.6), (1500, 3.4), (2000, 2.2), (2047, 3.0), (2048, 2.6), (2049, 2.4), (2100, 3.0), (2600, 3.6), (4100, 2.8)])
+@pytest.mark.parametrize("n,w_veh", [(293, 2.0), (400, 3.4), (511, 1.6), (777, 3.0), (1001, 2.6), (1500, 3.4), (2000, 2.2), (2047, 3.0), (2048, 2.6), (2049, 2.4), (2100, 3.0), (2600, 3.6), (4100, 2.8), (5000, 3.2)])
 def test_random_rings_against_banded_cpu_solver(gpu_engine, n, w_veh):
     from oracle import banded_ref
     bsz = 24
