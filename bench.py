@@ -64,16 +64,16 @@ def work_model(n, info, band_e=32):
                                  forward-eliminated left spike | y (208: four of the spike's five columns, the fifth is a combination of
                                  two of them) -- G = D~^-1 Up is not stored: Up_k is Lo_(k+1)', the consumers
                                  rebuild G x from the two records -- ; the spike pass reads both back and writes the alpha rows of
-                                 the spikes (80); inputs: 8 per-waypoint vectors + the mask byte (65); the right-hand side of the
-                                 solve that follows rides through both passes (16)                             -> 897 bytes
+                                 the spikes (64: both have rank 4, columns 1..4 each); inputs: 8 per-waypoint vectors + the mask byte (65);
+                                 the right-hand side of the solve that follows rides through both passes (16)   -> 881 bytes
                  solve after a factorisation (interior-point predictor, active-set round): the separators' system (LDS) and the
-                                 spike correction: spikes (80) + the vector read and written (16)              -> 96 bytes
+                                 spike correction: spikes (64) + the vector read and written (16)              -> 80 bytes
                  any other solve (corrector, refinement round): forward chain (160 + 8 + 40), backward chain (160 + 40 + 8),
-                                 correction (80 + 16)                                                          -> 512 bytes
+                                 correction (64 + 16)                                                          -> 496 bytes
                  float records (round 4; mcq_info.f32_factorisations of the interior-point factorisations -- the first four or five --
-                                 store their records as floats): D~^-1 | Lo 80, spike | y 112 (28 floats), alpha rows 40, the forward
-                                 chain's y 20:  factorisation 80 + 112 written, read back, 40 written + 65 + 16 -> 505 bytes; fused
-                                 solve 40 + 16 -> 56; solve with its own chains (80 + 8 + 20) + (80 + 20 + 8) + (40 + 16) -> 272
+                                 store their records as floats): D~^-1 | Lo 80, spike | y 112 (28 floats), alpha rows 32, the forward
+                                 chain's y 20:  factorisation 80 + 112 written, read back, 32 written + 65 + 16 -> 497 bytes; fused
+                                 solve 32 + 16 -> 48; solve with its own chains (80 + 8 + 20) + (80 + 20 + 8) + (32 + 16) -> 264
                  gradient      : E and E' through four solves with the tridiagonal spline matrix: 27 vector accesses -> 216 bytes
                                  (the 65-wide bands of E and E' -- 1040 bytes -- no longer exist)
                  vector passes : one interior-point iteration reads / writes 33 vector entries (three passes of one load phase each;
@@ -100,11 +100,11 @@ def work_model(n, info, band_e=32):
     n_grad = 1.0 + 2 * act + ref + 1.0 + 1.0 + 1.0 + (f32 > 0)
     ew = 2 * band_e + 1
     grad = n * 216.0
-    b_fac, b_fused, b_solve = n * 897.0, n * 96.0, n * 512.0
+    b_fac, b_fused, b_solve = n * 881.0, n * 80.0, n * 496.0
     passes = ipm * n * 264.0 + act * n * 240.0
     plain = n_sol - n_fac                          # solves that run their own chains
     # a float-record factorisation carries one fused solve (predictor) and one solve with its own chains (corrector)
-    saved = f32 * n * ((897.0 - 505.0) + (96.0 - 56.0) + (512.0 - 272.0))
+    saved = f32 * n * ((881.0 - 497.0) + (80.0 - 48.0) + (496.0 - 264.0))
     assembly = n * 256.0
     streamed = float((n_fac * (b_fac + b_fused) + plain * b_solve + n_grad * grad + passes - saved + assembly).sum())
     banded = float((n_fac * n * (130.0 + 144.0) * 8.0 + n_sol * 2.0 * n * 144.0 * 8.0 + n_grad * 2.0 * n * ew * 8.0).sum())
