@@ -7,7 +7,7 @@ R=$(cd "$(dirname "$0")/.." && pwd)
 T=${1:-r04}
 cd $R
 # gpurun MERGES into gpurun_out/: counter / stats files of earlier runs of the same tag stay next to the new ones -- drop everything older
-# than half an hour before the newest file, so that the summary is of ONE run
+# than seven minutes before the newest file (a run of the counter passes takes four), so that the summary is of ONE run
 python - "$T" <<'PY'
 import glob, os, sys
 dirs = [d for d in glob.glob("gpurun_out/%s_*" % sys.argv[1]) if os.path.isdir(d)]
@@ -15,7 +15,7 @@ files = [f for d in dirs for f in glob.glob(d + "/**/*", recursive=True) if os.p
 if files:
     newest = max(os.path.getmtime(f) for f in files)
     for f in files:
-        if os.path.getmtime(f) < newest - 1800:
+        if os.path.getmtime(f) < newest - 420:
             os.remove(f)
 PY
 for f in bench.json bench_config4_1gpu.json bench_force_collective_1gpu.json config5_shard_1gpu.json shortest_path.json harness_berlin.log \
