@@ -8,7 +8,7 @@ R=$(cd "$(dirname "$0")/.." && pwd)
 SRC=$R/global_racetrajectory_optimization_amd/csrc
 OUT=$R/build/variants
 HIPCC=${HIPCC:-/opt/rocm/bin/hipcc}
-FLAGS="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -shared -mllvm -amdgpu-mfma-vgpr-form -mllvm -enable-ipra=0"
+FLAGS="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -shared -mllvm -amdgpu-mfma-vgpr-form -mllvm -enable-ipra=0 -mllvm -amdgpu-schedule-metric-bias=0"
 mkdir -p $OUT /tmp/mcq_base/csrc /tmp/mcq_base/include_dir
 rm -f $OUT/*.so
 BASE_REV=${BASE_REV:-436904a}

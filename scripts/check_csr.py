@@ -16,7 +16,7 @@ if len(sys.argv) > 1 and os.path.exists(sys.argv[1]):
 else:
     asm = os.path.join(tempfile.gettempdir(), "mcq_check_csr.s")
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
-    subprocess.run([hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-mllvm", "-enable-ipra=0", "--gpu-max-threads-per-block=512",
+    subprocess.run([hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-mllvm", "-enable-ipra=0", "-mllvm", "-amdgpu-schedule-metric-bias=0", "--gpu-max-threads-per-block=512",
                     "-S", "--cuda-device-only", "-o", asm, src] + sys.argv[1:], check=True, stderr=subprocess.DEVNULL)
 funcs, cur = {}, None
 for ln in open(asm):
