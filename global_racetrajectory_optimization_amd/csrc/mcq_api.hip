@@ -72,7 +72,10 @@ struct mcq_handle {
     unsigned comm_seq = 0;              // gathers enqueued so far (event ring index)
     size_t vel_scratch_bytes = 0;
     double* kbig = nullptr;             // overflow slots of the curvature-row working set (MCQ_KBIG_SLOTS x MCQ_KBIG_SLOT doubles)
-    int* kbig_count = nullptr;          // slots claimed by the launch in flight
+    int* kbig_count = nullptr;          // [2]: slots claimed by the launch in flight; next chunk of the Goldfarb-Idnani kernel's scan
+    double* gi = nullptr;               // slots of the Goldfarb-Idnani path (mcq_gi.inc): gi_slots x MCQ_GI_SLOT_DOUBLES(gi_nmax, gi_nmax)
+    int gi_slots = 0, gi_nmax = 0;
+    long long gi_bytes = 0;
     double* d_org = nullptr;            // per-track origins of the fp32 row entries, [batch][2]
     double* d_trace = nullptr;          // curvature-error trace of mcq_iqp_batch, [batch][MCQ_IQP_TRACE] (grown with d_iqp)
     // mcq_solve_host_pipelined: two copy streams, the second set of staging buffers, one event triple per slot
@@ -88,7 +91,7 @@ extern "C" const char* mcq_last_error(void) { return g_err.c_str(); }
 extern "C" void mcq_default_opts(mcq_opts* o)
 {
     if (!o) return;
-    o->band_e = 32;
+    o->algorithm = MCQ_ALG_DEFAULT;
     o->max_ipm_iter = 60;
     o->max_as_iter = 60;
     o->refine_steps = 2;
@@ -102,7 +105,7 @@ static mcq_opts resolve_opts(const mcq_opts* in)
     mcq_opts o;
     mcq_default_opts(&o);
     if (in) {
-        o.band_e = 32;      // (ignored since round 4: E is applied through the spline system, untruncated; the field stays for ABI compatibility)
+        o.algorithm = in->algorithm == MCQ_ALG_GI ? MCQ_ALG_GI : MCQ_ALG_DEFAULT;    // (the field was `band_e` until round 4: 0 / 32 mean the default)
         if (in->max_ipm_iter > 0) o.max_ipm_iter = in->max_ipm_iter;
         if (in->max_as_iter > 0) o.max_as_iter = in->max_as_iter;
         if (in->refine_steps >= 0) o.refine_steps = in->refine_steps;
@@ -145,8 +148,10 @@ static void free_ws(mcq_handle* h)
 {
     (void)hipFree(h->L); (void)hipFree(h->vec); (void)hipFree(h->Z); (void)hipFree(h->state);
     (void)hipFree(h->state2);
-    (void)hipFree(h->kbig); (void)hipFree(h->kbig_count);
-    h->kbig = nullptr; h->kbig_count = nullptr;
+    (void)hipFree(h->kbig); (void)hipFree(h->kbig_count); (void)hipFree(h->gi);
+    h->kbig = nullptr; h->kbig_count = nullptr; h->gi = nullptr;
+    h->gi_slots = h->gi_nmax = 0;
+    h->gi_bytes = 0;
     h->L = h->vec = h->Z = nullptr;
     h->state = h->state2 = nullptr;
     h->state2_valid = false;
@@ -202,10 +207,32 @@ extern "C" void mcq_destroy(mcq_handle* h)
     delete h;
 }
 
+// Goldfarb-Idnani slots (mcq_gi.inc): a working set holds at most nmax independent constraints, so a slot is nmax x nmax (Q) + nmax x nmax
+// (R) doubles (64 MB at nmax = 2000); up to MCQ_GI_SLOTS of them ($MCQ_GI_SLOTS overrides), fewer for very long rings (<= 4 GB in all)
+static int ensure_gi(mcq_handle* h, size_t batch, size_t nmax)
+{
+    if (h->gi && (size_t)h->gi_nmax >= nmax) return 0;
+    HIP_TRY(hipStreamSynchronize(h->stream));
+    (void)hipFree(h->gi);
+    h->gi = nullptr;
+    h->gi_slots = h->gi_nmax = 0;
+    int slots = MCQ_GI_SLOTS;
+    if (const char* e = getenv("MCQ_GI_SLOTS")) slots = std::max(1, atoi(e));
+    const size_t per = MCQ_GI_SLOT_DOUBLES(nmax, nmax) * sizeof(double);
+    while (slots > 1 && (size_t)slots * per > ((size_t)4 << 30)) --slots;
+    slots = (int)std::min<size_t>((size_t)slots, std::max<size_t>(batch, 1));
+    HIP_TRY(hipMalloc((void**)&h->gi, (size_t)slots * per));
+    if (h->poison) HIP_TRY(hipMemsetAsync(h->gi, 0xff, (size_t)slots * per, h->stream));
+    h->gi_slots = slots;
+    h->gi_nmax = (int)nmax;
+    h->gi_bytes = (long long)((size_t)slots * per);
+    return 0;
+}
+
 static int ensure_ws(mcq_handle* h, size_t batch, size_t nmax)
 {
     const size_t elems = batch * nmax;
-    if (elems <= h->cap_elems && batch <= h->cap_batch) return 0;
+    if (elems <= h->cap_elems && batch <= h->cap_batch) return ensure_gi(h, batch, nmax);
     HIP_TRY(hipStreamSynchronize(h->stream));
     free_ws(h);
     HIP_TRY(hipMalloc((void**)&h->L, elems * MCQ_LLD * sizeof(double)));
@@ -214,7 +241,9 @@ static int ensure_ws(mcq_handle* h, size_t batch, size_t nmax)
     HIP_TRY(hipMalloc((void**)&h->state, elems));
     HIP_TRY(hipMalloc((void**)&h->state2, elems));
     HIP_TRY(hipMalloc((void**)&h->kbig, (size_t)MCQ_KBIG_SLOTS * MCQ_KBIG_SLOT * sizeof(double)));
-    HIP_TRY(hipMalloc((void**)&h->kbig_count, sizeof(int)));
+    HIP_TRY(hipMalloc((void**)&h->kbig_count, 2 * sizeof(int)));
+    h->gi_slots = h->gi_nmax = 0;
+    if (int rc = ensure_gi(h, batch, nmax)) return rc;
     if (h->poison) HIP_TRY(hipMemsetAsync(h->kbig, 0xff, (size_t)MCQ_KBIG_SLOTS * MCQ_KBIG_SLOT * sizeof(double), h->stream));
     HIP_TRY(hipMemsetAsync(h->state, 0, elems, h->stream));
     HIP_TRY(hipMemsetAsync(h->state2, 0, elems, h->stream));
@@ -271,7 +300,14 @@ static int launch(mcq_handle* h, McqBatch& B, const mcq_opts& o)
     B.kbig = h->kbig;
     B.kbig_count = h->kbig_count;
     B.kbig_slots = MCQ_KBIG_SLOTS;
-    if (!B.prep_only) HIP_TRY(hipMemsetAsync(h->kbig_count, 0, sizeof(int), h->stream));
+    B.algorithm = o.algorithm;
+    // the Goldfarb-Idnani slots hold working sets of up to gi_nmax constraints on rings of up to gi_nmax waypoints (slot stride: B.nmax)
+    const bool gi_on = h->gi && B.nmax <= h->gi_nmax && o.objective == MCQ_OBJ_MIN_CURV && !B.prep_only;
+    B.gi = gi_on ? h->gi : nullptr;
+    B.gi_slots = gi_on ? h->gi_slots : 0;
+    B.gi_qcap = B.nmax;
+    B.gi_next = h->kbig_count + 1;
+    if (!B.prep_only) HIP_TRY(hipMemsetAsync(h->kbig_count, 0, 2 * sizeof(int), h->stream));
     // warm start: only the working sets mcq_relinearise_device carried over for exactly this batch layout
     B.warm = (o.warm_start > 0 && h->state2_valid && !B.prep_only && h->state2_batch == B.batch && h->state2_nmax == B.nmax)
                  ? h->state2 : nullptr;
@@ -303,6 +339,11 @@ static int launch(mcq_handle* h, McqBatch& B, const mcq_opts& o)
     hipLaunchKernelGGL(mcq_solve_kernel, dim3(B.batch), dim3(256), 0, h->stream, B);
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipEventRecord(h->ev[3], h->stream));
+    // the Goldfarb-Idnani path for whatever the solver kernel did not settle (a scan of the statuses when there is nothing to do)
+    if (B.gi_slots > 0) {
+        hipLaunchKernelGGL(mcq_gi_kernel, dim3(std::min(B.gi_slots, (B.batch + MCQ_GI_CHUNK - 1) / MCQ_GI_CHUNK)), dim3(256), 0, h->stream, B);
+        HIP_TRY(hipGetLastError());
+    }
     HIP_TRY(hipEventRecord(h->ev[4], h->stream));
     h->timing_valid = true;
     return 0;
@@ -740,7 +781,7 @@ extern "C" int mcq_last_timing(mcq_handle* h, float ms[5])
     return 0;
 }
 
-extern "C" long long mcq_workspace_bytes(mcq_handle* h) { return h ? h->ws_bytes : 0; }
+extern "C" long long mcq_workspace_bytes(mcq_handle* h) { return h ? h->ws_bytes + h->gi_bytes : 0; }
 
 static int ensure_pin(mcq_handle* h, size_t bytes)
 {
@@ -826,14 +867,7 @@ extern "C" int mcq_solve_host(mcq_handle* h, int batch, int n, const double* ref
     HIP_TRY_SYNC(hipMemcpyAsync(status_out, h->d_status, batch * sizeof(int), hipMemcpyDeviceToHost, h->stream));
     if (info_out) HIP_TRY_SYNC(hipMemcpyAsync(info_out, h->d_info, batch * sizeof(mcq_info), hipMemcpyDeviceToHost, h->stream));
     HIP_TRY(hipStreamSynchronize(h->stream));
-    // problems that found every overflow slot of the launch taken (MCQ_KAPPA_NO_SLOT): each again in a launch of its own
-    for (int b = 0; batch > 1 && b < batch; ++b)
-        if (status_out[b] == MCQ_KAPPA_NO_SLOT) {
-            const size_t o1 = (size_t)b * n;
-            rc = mcq_solve_host(h, 1, n, reftrack + 4 * o1, normvec ? normvec + 2 * o1 : nullptr, scaling ? scaling + o1 : nullptr, kappa_bound,
-                                w_veh, opts, alpha_out + o1, curv_err_out + b, status_out + b, info_out ? info_out + b : nullptr);
-            if (rc) return rc;
-        }
+    // (MCQ_KAPPA_NO_SLOT never arrives here since round 5: the Goldfarb-Idnani kernel of the same launch sequence solves such problems)
     return 0;
 }
 
@@ -868,13 +902,6 @@ extern "C" int mcq_solve_batch_f32(mcq_handle* h, int batch, int n, int layout, 
     HIP_TRY_SYNC(hipMemcpyAsync(status_out, h->d_status, batch * sizeof(int), hipMemcpyDeviceToHost, h->stream));
     if (info_out) HIP_TRY_SYNC(hipMemcpyAsync(info_out, h->d_info, batch * sizeof(mcq_info), hipMemcpyDeviceToHost, h->stream));
     HIP_TRY(hipStreamSynchronize(h->stream));
-    for (int b = 0; batch > 1 && b < batch; ++b)          // MCQ_KAPPA_NO_SLOT: again in a launch of its own (see mcq_solve_host)
-        if (status_out[b] == MCQ_KAPPA_NO_SLOT) {
-            const size_t o1 = (size_t)b * n;
-            rc = mcq_solve_batch_f32(h, 1, n, layout, reftrack + 4 * o1, origin ? origin + 2 * (size_t)b : nullptr, kappa_bound, w_veh, opts,
-                                     alpha_out + o1, curv_err_out + b, status_out + b, info_out ? info_out + b : nullptr);
-            if (rc) return rc;
-        }
     return 0;
 }
 
@@ -1269,38 +1296,11 @@ extern "C" int mcq_solve_batch(mcq_handle* h, const mcq_problem* probs, int batc
     HIP_TRY_SYNC(hipMemcpyAsync(P.info, h->d_info, batch * sizeof(mcq_info), hipMemcpyDeviceToHost, h->stream));
     HIP_TRY(hipStreamSynchronize(h->stream));
     size_t off = 0;
-    std::vector<size_t> offs((size_t)batch);
-    std::vector<int> retry;
     for (int b = 0; b < batch; ++b) {
         const size_t n = (size_t)probs[b].n;
         memcpy(alpha_out + off, P.alpha + (size_t)b * nmax, n * sizeof(double));
-        offs[(size_t)b] = off;
         off += n;
         if (info_out) info_out[b] = P.info[b];
-        if (status_out[b] == MCQ_KAPPA_NO_SLOT) retry.push_back(b);
-    }
-    // Problems that found every overflow slot of the launch taken: again, MCQ_KBIG_SLOTS at a time -- a launch of at most that many
-    // problems cannot run out of slots, so the result of every problem is what a launch of its own gives, whatever order the
-    // workgroups of the big launch were scheduled in.
-    for (size_t g0 = 0; g0 < retry.size(); g0 += MCQ_KBIG_SLOTS) {
-        const int cnt = (int)std::min<size_t>(MCQ_KBIG_SLOTS, retry.size() - g0);
-        std::vector<mcq_problem> sub((size_t)cnt);
-        size_t tot = 0;
-        for (int k = 0; k < cnt; ++k) { sub[(size_t)k] = probs[retry[g0 + k]]; tot += (size_t)sub[(size_t)k].n; }
-        std::vector<double> a(tot), cu((size_t)cnt);
-        std::vector<int> st((size_t)cnt);
-        std::vector<mcq_info> inf((size_t)cnt);
-        rc = mcq_solve_batch(h, sub.data(), cnt, opts, a.data(), cu.data(), st.data(), inf.data());
-        if (rc) return rc;
-        size_t o2 = 0;
-        for (int k = 0; k < cnt; ++k) {
-            const int b = retry[g0 + k];
-            memcpy(alpha_out + offs[(size_t)b], a.data() + o2, (size_t)sub[(size_t)k].n * sizeof(double));
-            o2 += (size_t)sub[(size_t)k].n;
-            curv_err_out[b] = cu[(size_t)k];
-            status_out[b] = st[(size_t)k];
-            if (info_out) info_out[b] = inf[(size_t)k];
-        }
     }
     return 0;
 }

@@ -31,7 +31,7 @@ static_assert(sizeof(double) * SM_TOTAL <= 80 * 1024, "two workgroups of the sol
 size_t mcq_solve_lds_bytes() { return sizeof(double) * SM_TOTAL; }
 
 // The solver kernel's LDS: one statically sized array (address space 3 by type -> ds_read/ds_write in every device
-// function, inlined or not).  155 KiB of the CU's 160 KiB: one workgroup per CU.
+// function, inlined or not).  78 KiB of the CU's 160 KiB: two workgroups per CU.
 __shared__ double g_sm[SM_TOTAL];
 
 // ---------------------------------------------------------------------------------------------------------------------
@@ -262,7 +262,7 @@ __device__ __noinline__ int assemble_problem(const LCtx& c, double wveh, gdouble
             z.ipm_iters = z.as_iters = z.n_active_box = z.n_active_kappa = 0;
             z.kappa_max = 0.0;
             z.kkt_res = 0.0;
-            z.refine_rounds = z.second_attempt = z.f32_factorisations = z.reserved_ = 0;
+            z.refine_rounds = z.second_attempt = z.f32_factorisations = z.gi_iters = 0;
             for (int q = 0; q < 8; ++q) z.ticks[q] = 0;
             *(mcq_info*)w.info = z;
         }
@@ -321,9 +321,9 @@ __device__ __noinline__ int assemble_problem(const LCtx& c, double wveh, gdouble
 }
 
 // what the assembly needs of the context: the problem's pointers and size (thread 0 writes, the barrier publishes)
-__device__ __forceinline__ void ctx_set_problem(const McqBatch& B, int& n, double& kb, double& wveh)
+__device__ __forceinline__ void ctx_set_problem(const McqBatch& B, int pb, int& n, double& kb, double& wveh)
 {
-    const McqWork w = mcq_work(B, blockIdx.x, n, kb, wveh);
+    const McqWork w = mcq_work(B, pb, n, kb, wveh);
     __syncthreads();                                  // (a previous use of the context by this workgroup -- none today -- is over)
     if (threadIdx.x == 0) {
         g_ctx.w = w;
@@ -333,11 +333,33 @@ __device__ __forceinline__ void ctx_set_problem(const McqBatch& B, int& n, doubl
     __syncthreads();
 }
 
+// ... and what a solve needs on top: the options, the timers and diagnostics at zero
+__device__ __forceinline__ void ctx_set_solve(const McqBatch& B, double kbound)
+{
+    if (threadIdx.x == 0) {
+        for (int q = 0; q < 8; ++q) g_ctx.tk[q] = 0;
+        g_ctx.last_step = 0.0;
+        g_ctx.refine_rounds = g_ctx.second_attempt = g_ctx.f32_count = 0;
+        g_ctx.direct = B.objective == MCQ_OBJ_SHORTEST_PATH;
+        g_ctx.max_ipm_iter = B.max_ipm_iter;
+        g_ctx.max_as_iter = B.max_as_iter;
+        g_ctx.refine_steps = B.refine_steps;
+        g_ctx.kbound = kbound;
+        g_ctx.kkt_w = nullptr;
+        g_ctx.kkt_f32 = 0;
+        g_ctx.sp_sig = nullptr;
+        g_ctx.sp_mk = nullptr;
+        g_ctx.out_iters = g_ctx.out_nk = 0;
+        g_ctx.out_kkt = 0.0;
+    }
+    __syncthreads();
+}
+
 __global__ void __launch_bounds__(MCQ_NT) mcq_assemble_kernel(McqBatch B)
 {
     int n;
     double kb, wveh;
-    ctx_set_problem(B, n, kb, wveh);
+    ctx_set_problem(B, blockIdx.x, n, kb, wveh);
     const size_t nm = (size_t)B.nmax;
     (void)assemble_problem(G_CTX, wveh, B.nv_out ? (gdouble*)(B.nv_out + (size_t)blockIdx.x * nm * 2) : nullptr,
                            B.sc_out ? (gdouble*)(B.sc_out + (size_t)blockIdx.x * nm) : nullptr);
@@ -389,7 +411,7 @@ __global__ void __launch_bounds__(MCQ_NT) mcq_assemble_sp_kernel(McqBatch B)
             z.ipm_iters = z.as_iters = z.n_active_box = z.n_active_kappa = 0;
             z.kappa_max = 0.0;
             z.kkt_res = 0.0;
-            z.refine_rounds = z.second_attempt = z.f32_factorisations = z.reserved_ = 0;
+            z.refine_rounds = z.second_attempt = z.f32_factorisations = z.gi_iters = 0;
             for (int q = 0; q < 8; ++q) z.ticks[q] = 0;
             *(mcq_info*)w.info = z;
         }
@@ -1219,7 +1241,9 @@ __device__ void kappa_apply(const LCtx& c, const KappaMem& K, int nk, gdouble* Q
     timed_solve(c, v);
 }
 
-__device__ __noinline__ int active_set(const LCtx& c, bool with_kappa, bool tapia, int cap, bool identify, const KappaMem K)
+// identify: 1 the working set from the interior point's pairs; 0 the box rows given (state), the curvature rows from the pairs;
+//           2 both given (state, V_SK): the vertex the Goldfarb-Idnani path arrived at
+__device__ __noinline__ int active_set(const LCtx& c, bool with_kappa, bool tapia, int cap, int identify, const KappaMem K)
 {
     const int tid = threadIdx.x, n = c.d.n, nm = c.nm;
     double* red = g_sm + SM_RED;
@@ -1252,7 +1276,7 @@ __device__ __noinline__ int active_set(const LCtx& c, bool with_kappa, bool tapi
     // ---- identification ---------------------------------------------------------------------------------------------------
     // (identify == false: the working set is given -- carried over from the previous IQP pass -- and the pairs are not read)
     for (int i = tid; i < n; i += MCQ_NT) {
-        if (identify && ST[i] == 0) {
+        if (identify == 1 && ST[i] == 0) {
             // magnitude test on the final pair: active when the scaled multiplier exceeds the scaled slack
             const double wdt = HI[i] - LO[i];
             const double sl = X[i] - LO[i], su = HI[i] - X[i];
@@ -1270,7 +1294,8 @@ __device__ __noinline__ int active_set(const LCtx& c, bool with_kappa, bool tapi
             ST[i] = st;
         }
         double kf = 0.0;
-        if (with_kappa) {
+        if (with_kappa && identify == 2) kf = KF[i];
+        else if (with_kappa) {
             const gdouble* TL = VEC(c.w, nm, V_TL);
             const gdouble* TU = VEC(c.w, nm, V_TU);
             const gdouble* YL = VEC(c.w, nm, V_YL);
@@ -1442,6 +1467,121 @@ __device__ __noinline__ int active_set(const LCtx& c, bool with_kappa, bool tapi
     return MCQ_ITER_CAP;
 }
 
+// ---- scalars of a problem: the scales of the tolerances, the working set and the iterate at the box centre, the gradient there ----
+__device__ __noinline__ void problem_scales(const LCtx& c)
+{
+    const int tid = threadIdx.x, n = c.d.n, nm = c.nm;
+    double* red = g_sm + SM_RED;
+    const gdouble* LO = VEC(c.w, nm, V_LO);
+    const gdouble* HI = VEC(c.w, nm, V_HI);
+    const gdouble* F = VEC(c.w, nm, V_F);
+    gdouble* X = VEC(c.w, nm, V_X);
+    gdouble* G = VEC(c.w, nm, V_G);
+    gschar* ST = c.w.state;
+    double wsum = 0.0, nfree_d = 0.0, fmaxl = 0.0;
+    for (int i = tid; i < n; i += MCQ_NT) {
+        const double wdt = HI[i] - LO[i];
+        const bool fixed = !(wdt > 1e-12);
+        ST[i] = fixed ? 2 : 0;
+        X[i] = 0.5 * (LO[i] + HI[i]);
+        if (!fixed) { wsum += wdt; nfree_d += 1.0; }
+        fmaxl = fmax(fmaxl, fabs(F[i]));
+    }
+    wsum = block_reduce_(wsum, 0, red);
+    const double nfree_s = block_reduce_(nfree_d, 0, red), fscale_s = block_reduce_(fmaxl, 2, red);
+    gradient(c, X, nullptr, VEC(c.w, nm, V_T0), G);
+    double gm = 0.0;
+    for (int i = tid; i < n; i += MCQ_NT) if (ST[i] == 0) gm = fmax(gm, fabs(G[i]));
+    double zscale_s = block_reduce_(gm, 2, red);
+    if (!(zscale_s > 0.0)) zscale_s = fscale_s > 0.0 ? fscale_s : 1.0;
+    if (tid == 0) {
+        g_ctx.nfree = nfree_s;
+        g_ctx.fscale = fscale_s;
+        g_ctx.wmean = nfree_s > 0.0 ? wsum / nfree_s : 1.0;
+        g_ctx.zscale = zscale_s;
+    }
+    __syncthreads();
+}
+
+// ---- outputs of a problem: alpha, opt_min_curv's curvature-error post-check, status, diagnostics.  X holds the
+//      solution (inside its box), T0 = k_ref + E x and -- dd_valid -- V_TL / V_TU the second derivatives D (n_x x), D (n_y x). ----
+struct McqOutcome {
+    int status, ipm_iters, as_iters, nact_kappa, gi_iters;
+    double kkt, km;
+    bool dd_valid;
+    long long t_kernel0, c_kernel0, t_epi0;
+};
+__device__ __noinline__ void write_outputs(const LCtx& c, const McqOutcome& r)
+{
+    const int tid = threadIdx.x, n = c.d.n, nm = c.nm;
+    double* red = g_sm + SM_RED;
+    const gdouble* X = VEC(c.w, nm, V_X);
+    gdouble* T0 = VEC(c.w, nm, V_T0);
+    gdouble* T1 = VEC(c.w, nm, V_T1);
+    gdouble* T2 = VEC(c.w, nm, V_T2);
+    gdouble* T3 = VEC(c.w, nm, V_T3);
+    gdouble* Q = VEC(c.w, nm, V_Q);
+    const gschar* ST = c.w.state;
+    double nact = 0.0;
+    for (int i = tid; i < n; i += MCQ_NT) {
+        c.w.alpha[i] = X[i];
+        if (ST[i] == -1 || ST[i] == 1) nact += 1.0;
+    }
+    nact = block_reduce_(nact, 0, red);
+    const gdouble* XP = VEC(c.w, nm, V_XP);
+    const gdouble* YP = VEC(c.w, nm, V_YP);
+    const gdouble* XPP = VEC(c.w, nm, V_XPP);
+    const gdouble* YPP = VEC(c.w, nm, V_YPP);
+    if (!c.direct) {
+        for (int i = tid; i < n; i += MCQ_NT) { T1[i] = VEC(c.w, nm, V_NX)[i] * X[i]; T2[i] = VEC(c.w, nm, V_NY)[i] * X[i]; }
+        __syncthreads();
+        if (r.dd_valid) {
+            const gdouble* D1 = VEC(c.w, nm, V_TL);
+            const gdouble* D2 = VEC(c.w, nm, V_TU);
+            for (int i = tid; i < n; i += MCQ_NT) { T0[i] = D1[i]; T3[i] = D2[i]; }
+        } else {
+            tri_apply_E(c, X, nullptr, 0.0, Q, T0, T3);      // D (n_x alpha), D (n_y alpha) are by-products of E alpha
+        }
+        __syncthreads();
+    }
+    double em = 0.0;
+    for (int i = tid; i < (c.direct ? 0 : n); i += MCQ_NT) {
+        const int ip = cyc(i + 1, n);
+        const double s = VEC(c.w, nm, V_SC)[i];
+        const double s2 = s * s;
+        const double xpt = XP[i] + (T1[ip] - T1[i]) - (T0[i] + 0.5 * s2 * T0[ip]) / 3.0;
+        const double ypt = YP[i] + (T2[ip] - T2[i]) - (T3[i] + 0.5 * s2 * T3[ip]) / 3.0;
+        const double xpp = XPP[i] + T0[i], ypp = YPP[i] + T3[i];
+        const double xp = XP[i], yp = YP[i];
+        const double k0 = (xp * ypp - yp * xpp) / pow(xp * xp + yp * yp, 1.5);
+        const double k1 = (xpt * ypp - ypt * xpp) / pow(xpt * xpt + ypt * ypt, 1.5);
+        em = fmax(em, fabs(k1 - k0));
+    }
+    em = block_reduce_(em, 2, red);
+    if (tid == 0) {
+        *c.w.curv_err = em;
+        *c.w.status = r.status;
+        if (c.w.info) {
+            mcq_info o;
+            o.ipm_iters = r.ipm_iters;
+            o.as_iters = r.as_iters;
+            o.n_active_box = (int)nact;
+            o.n_active_kappa = r.nact_kappa;
+            o.kappa_max = r.km;
+            o.kkt_res = c.fscale > 0.0 ? r.kkt / c.fscale : r.kkt;
+            o.refine_rounds = c.refine_rounds;
+            o.second_attempt = c.second_attempt;
+            o.f32_factorisations = c.f32_count;
+            o.gi_iters = r.gi_iters;
+            c.tk[3] = TICK() - r.t_kernel0;
+            c.tk[7] = TICK() - r.t_epi0;          // curvature check, (rare) curvature-row phase, outputs (ticks[7])
+            c.tk[6] = (long long)clock64() - r.c_kernel0;
+            for (int q = 0; q < 8; ++q) o.ticks[q] = c.tk[q];
+            *(mcq_info*)c.w.info = o;
+        }
+    }
+}
+
 __global__ void __launch_bounds__(MCQ_NT, 2) mcq_solve_kernel(McqBatch B)
 {
     const int tid = threadIdx.x;
@@ -1453,25 +1593,9 @@ __global__ void __launch_bounds__(MCQ_NT, 2) mcq_solve_kernel(McqBatch B)
     }
     const long long t_kernel0 = TICK();
     const long long c_kernel0 = (long long)clock64();      // shader-clock counter (s_memtime): with ticks[3] the effective clock
-    ctx_set_problem(B, n, kbound, wveh);
+    ctx_set_problem(B, blockIdx.x, n, kbound, wveh);
     const LCtx& c = G_CTX;
-    if (tid == 0) {
-        for (int q = 0; q < 8; ++q) g_ctx.tk[q] = 0;
-        g_ctx.last_step = 0.0;
-        g_ctx.refine_rounds = g_ctx.second_attempt = g_ctx.f32_count = 0;
-        g_ctx.direct = B.objective == MCQ_OBJ_SHORTEST_PATH;
-        g_ctx.max_ipm_iter = B.max_ipm_iter;
-        g_ctx.max_as_iter = B.max_as_iter;
-        g_ctx.refine_steps = B.refine_steps;
-        g_ctx.kbound = kbound;
-        g_ctx.kkt_w = nullptr;
-        g_ctx.kkt_f32 = 0;
-        g_ctx.sp_sig = nullptr;
-        g_ctx.sp_mk = nullptr;
-        g_ctx.out_iters = g_ctx.out_nk = 0;
-        g_ctx.out_kkt = 0.0;
-    }
-    __syncthreads();
+    ctx_set_solve(B, kbound);
     if (B.objective == MCQ_OBJ_SHORTEST_PATH) {
         if (*c.w.status != MCQ_OK) return;            // (written by mcq_assemble_sp_kernel)
     } else if (assemble_problem(c, wveh, nullptr, nullptr) != MCQ_OK) return;
@@ -1496,30 +1620,12 @@ __global__ void __launch_bounds__(MCQ_NT, 2) mcq_solve_kernel(McqBatch B)
         for (int i = tid; i < n; i += MCQ_NT) Fw[i] *= MCQ_F_SCALE;
         __syncthreads();
     }
-    // ---- scalars: scales for the tolerances, initial gradient at the box centre -----------------------------------------
-    double wsum = 0.0, nfree_d = 0.0, fmaxl = 0.0;
-    for (int i = tid; i < n; i += MCQ_NT) {
-        const double wdt = HI[i] - LO[i];
-        const bool fixed = !(wdt > 1e-12);
-        ST[i] = fixed ? 2 : 0;
-        X[i] = 0.5 * (LO[i] + HI[i]);
-        if (!fixed) { wsum += wdt; nfree_d += 1.0; }
-        fmaxl = fmax(fmaxl, fabs(F[i]));
+    problem_scales(c);
+    if (B.algorithm == MCQ_ALG_GI && !c.direct) {
+        // every problem through the Goldfarb-Idnani path (mcq_gi_kernel, launched behind this kernel): leave it there
+        if (tid == 0) *c.w.status = MCQ_ITER_CAP;
+        return;
     }
-    wsum = block_reduce_(wsum, 0, red);
-    const double nfree_s = block_reduce_(nfree_d, 0, red), fscale_s = block_reduce_(fmaxl, 2, red);
-    gradient(c, X, nullptr, T0, G);
-    double gm = 0.0;
-    for (int i = tid; i < n; i += MCQ_NT) if (ST[i] == 0) gm = fmax(gm, fabs(G[i]));
-    double zscale_s = block_reduce_(gm, 2, red);
-    if (!(zscale_s > 0.0)) zscale_s = fscale_s > 0.0 ? fscale_s : 1.0;
-    if (tid == 0) {
-        g_ctx.nfree = nfree_s;
-        g_ctx.fscale = fscale_s;
-        g_ctx.wmean = nfree_s > 0.0 ? wsum / nfree_s : 1.0;
-        g_ctx.zscale = zscale_s;
-    }
-    __syncthreads();
 
     // ---- phase 1: box-constrained QP ---------------------------------------------------------------------------------------
     int ipm_iters = 0, as_iters = 0, nact_kappa = 0;
@@ -1536,7 +1642,7 @@ __global__ void __launch_bounds__(MCQ_NT, 2) mcq_solve_kernel(McqBatch B)
             if (ST[i] == 0) { const signed char s = WS[i]; ST[i] = (s == 1 || s == -1) ? s : (signed char)0; }
         __syncthreads();
         const int capw = B.max_as_iter < MCQ_WARM_ROUNDS ? B.max_as_iter : MCQ_WARM_ROUNDS;
-        const int sw = active_set(c, false, false, capw, false, kappa_mem_lds(c));
+        const int sw = active_set(c, false, false, capw, 0, kappa_mem_lds(c));
         as_iters = c.out_iters;
         kkt = c.out_kkt;
         if (sw == MCQ_OK) warm_done = true;
@@ -1570,7 +1676,7 @@ __global__ void __launch_bounds__(MCQ_NT, 2) mcq_solve_kernel(McqBatch B)
         gdouble* XS = VEC(c.w, nm, V_TL);
         for (int i = tid; i < n; i += MCQ_NT) XS[i] = X[i];
         const int cap1 = B.max_as_iter < 6 ? B.max_as_iter : 6;
-        status = active_set(c, false, ipm_iters >= 1 && c.last_step >= 0.9, cap1, true, kappa_mem_lds(c));
+        status = active_set(c, false, ipm_iters >= 1 && c.last_step >= 0.9, cap1, 1, kappa_mem_lds(c));
         as_iters = c.out_iters;
         kkt = c.out_kkt;
         if (status == MCQ_ITER_CAP && B.max_as_iter > cap1) {
@@ -1580,13 +1686,13 @@ __global__ void __launch_bounds__(MCQ_NT, 2) mcq_solve_kernel(McqBatch B)
             status = ipm_box(c, 1e-13, true);
             ipm_iters += c.out_iters;
             if (status == MCQ_OK) {
-                status = active_set(c, false, false, B.max_as_iter, true, kappa_mem_lds(c));
+                status = active_set(c, false, false, B.max_as_iter, 1, kappa_mem_lds(c));
                 as_iters += c.out_iters;
                 kkt = c.out_kkt;
             }
         }
     } else if (status == MCQ_OK) {
-        status = active_set(c, false, ipm_iters >= 1 && c.last_step >= 0.9, B.max_as_iter, true, kappa_mem_lds(c));
+        status = active_set(c, false, ipm_iters >= 1 && c.last_step >= 0.9, B.max_as_iter, 1, kappa_mem_lds(c));
         as_iters = c.out_iters;
         kkt = c.out_kkt;
     }
@@ -1616,7 +1722,7 @@ __global__ void __launch_bounds__(MCQ_NT, 2) mcq_solve_kernel(McqBatch B)
         ipm_iters += c.out_iters;
         __syncthreads();
         if (status == MCQ_OK) {
-            status = active_set(c, true, false, B.max_as_iter, true, kappa_mem_lds(c));
+            status = active_set(c, true, false, B.max_as_iter, 1, kappa_mem_lds(c));
             as_iters += c.out_iters;
             kkt = c.out_kkt;
             nact_kappa = c.out_nk;
@@ -1632,7 +1738,7 @@ __global__ void __launch_bounds__(MCQ_NT, 2) mcq_solve_kernel(McqBatch B)
                 const int slot = sslot[0];
                 __syncthreads();
                 if (slot < B.kbig_slots) {
-                    status = active_set(c, true, false, B.max_as_iter, false, kappa_mem_slot(B.kbig + (size_t)slot * MCQ_KBIG_SLOT));
+                    status = active_set(c, true, false, B.max_as_iter, 0, kappa_mem_slot(B.kbig + (size_t)slot * MCQ_KBIG_SLOT));
                     as_iters += c.out_iters;
                     kkt = c.out_kkt;
                     nact_kappa = c.out_nk;
@@ -1650,68 +1756,14 @@ __global__ void __launch_bounds__(MCQ_NT, 2) mcq_solve_kernel(McqBatch B)
         status = MCQ_KAPPA_ACTIVE;      // curvature rows switched off by the caller: the violated row is reported, not enforced
     }
 
-    // ---- outputs: alpha, opt_min_curv's curvature-error post-check ------------------------------------
-    double nact = 0.0;
-    for (int i = tid; i < n; i += MCQ_NT) {
-        c.w.alpha[i] = X[i];
-        if (ST[i] == -1 || ST[i] == 1) nact += 1.0;
-    }
-    nact = block_reduce_(nact, 0, red);
-    {
-        const gdouble* XP = VEC(c.w, nm, V_XP);
-        const gdouble* YP = VEC(c.w, nm, V_YP);
-        const gdouble* XPP = VEC(c.w, nm, V_XPP);
-        const gdouble* YPP = VEC(c.w, nm, V_YPP);
-        if (!c.direct) {
-            for (int i = tid; i < n; i += MCQ_NT) { T1[i] = VEC(c.w, nm, V_NX)[i] * X[i]; T2[i] = VEC(c.w, nm, V_NY)[i] * X[i]; }
-            __syncthreads();
-            if (dd_valid) {
-                const gdouble* D1 = VEC(c.w, nm, V_TL);
-                const gdouble* D2 = VEC(c.w, nm, V_TU);
-                for (int i = tid; i < n; i += MCQ_NT) { T0[i] = D1[i]; T3[i] = D2[i]; }
-            } else {
-                tri_apply_E(c, X, nullptr, 0.0, Q, T0, T3);      // D (n_x alpha), D (n_y alpha) are by-products of E alpha
-            }
-            __syncthreads();
-        }
-        double em = 0.0;
-        for (int i = tid; i < (c.direct ? 0 : n); i += MCQ_NT) {
-            const int ip = cyc(i + 1, n);
-            const double s = VEC(c.w, nm, V_SC)[i];
-            const double s2 = s * s;
-            const double xpt = XP[i] + (T1[ip] - T1[i]) - (T0[i] + 0.5 * s2 * T0[ip]) / 3.0;
-            const double ypt = YP[i] + (T2[ip] - T2[i]) - (T3[i] + 0.5 * s2 * T3[ip]) / 3.0;
-            const double xpp = XPP[i] + T0[i], ypp = YPP[i] + T3[i];
-            const double xp = XP[i], yp = YP[i];
-            const double k0 = (xp * ypp - yp * xpp) / pow(xp * xp + yp * yp, 1.5);
-            const double k1 = (xpt * ypp - ypt * xpp) / pow(xpt * xpt + ypt * ypt, 1.5);
-            em = fmax(em, fabs(k1 - k0));
-        }
-        em = block_reduce_(em, 2, red);
-        if (tid == 0) {
-            *c.w.curv_err = em;
-            *c.w.status = status;
-            if (c.w.info) {
-                mcq_info o;
-                o.ipm_iters = ipm_iters;
-                o.as_iters = as_iters;
-                o.n_active_box = (int)nact;
-                o.n_active_kappa = nact_kappa;
-                o.kappa_max = km;
-                o.kkt_res = c.fscale > 0.0 ? kkt / c.fscale : kkt;
-                o.refine_rounds = c.refine_rounds;
-                o.second_attempt = c.second_attempt;
-                o.f32_factorisations = c.f32_count;
-                o.reserved_ = 0;
-                c.tk[3] = TICK() - t_kernel0;
-                c.tk[7] = TICK() - t_epi0;          // curvature check, (rare) curvature-row phase, outputs (ticks[7])
-                c.tk[6] = (long long)clock64() - c_kernel0;
-                for (int q = 0; q < 8; ++q) o.ticks[q] = c.tk[q];
-                *(mcq_info*)c.w.info = o;
-            }
-        }
-    }
+    McqOutcome r;
+    r.status = status; r.ipm_iters = ipm_iters; r.as_iters = as_iters; r.nact_kappa = nact_kappa; r.gi_iters = 0;
+    r.kkt = kkt; r.km = km; r.dd_valid = dd_valid;
+    r.t_kernel0 = t_kernel0; r.c_kernel0 = c_kernel0; r.t_epi0 = t_epi0;
+    write_outputs(c, r);
 }
+
+#include "mcq_gi.inc"
 
 // =====================================================================================================================
 // K4: IQP glue -- re-linearisation on the device

@@ -30,10 +30,11 @@ class McqProblem(ctypes.Structure):
 
 
 OBJ_MIN_CURV, OBJ_SHORTEST_PATH = 0, 1      # mcq_opts.objective (include/mcq.h)
+ALG_DEFAULT, ALG_GI = 0, 1                  # mcq_opts.algorithm
 
 
 class McqOpts(ctypes.Structure):
-    _fields_ = [("band_e", ctypes.c_int), ("max_ipm_iter", ctypes.c_int), ("max_as_iter", ctypes.c_int),
+    _fields_ = [("algorithm", ctypes.c_int), ("max_ipm_iter", ctypes.c_int), ("max_as_iter", ctypes.c_int),
                 ("refine_steps", ctypes.c_int), ("check_kappa", ctypes.c_int), ("objective", ctypes.c_int),
                 ("warm_start", ctypes.c_int)]
 
@@ -46,7 +47,7 @@ class McqInfo(ctypes.Structure):
     _fields_ = [("ipm_iters", ctypes.c_int), ("as_iters", ctypes.c_int), ("n_active_box", ctypes.c_int),
                 ("n_active_kappa", ctypes.c_int), ("kappa_max", ctypes.c_double), ("kkt_res", ctypes.c_double),
                 ("ticks", ctypes.c_longlong * 8), ("refine_rounds", ctypes.c_int), ("second_attempt", ctypes.c_int),
-                ("f32_factorisations", ctypes.c_int), ("reserved_", ctypes.c_int)]
+                ("f32_factorisations", ctypes.c_int), ("gi_iters", ctypes.c_int)]
 
 
 class McqIqpStats(ctypes.Structure):
@@ -235,9 +236,10 @@ class Engine:
         except Exception:
             pass
 
-    def _opts(self, band_e=0, max_ipm_iter=0, max_as_iter=0, refine_steps=-1, check_kappa=1, objective=OBJ_MIN_CURV,
+    def _opts(self, algorithm=ALG_DEFAULT, max_ipm_iter=0, max_as_iter=0, refine_steps=-1, check_kappa=1, objective=OBJ_MIN_CURV,
               warm_start=0):
-        return McqOpts(int(band_e), int(max_ipm_iter), int(max_as_iter), int(refine_steps), int(check_kappa),
+        """mcq_opts.  algorithm=ALG_GI: every problem through the engine's Goldfarb-Idnani path (quadprog's algorithm; a reference mode)."""
+        return McqOpts(int(algorithm), int(max_ipm_iter), int(max_as_iter), int(refine_steps), int(check_kappa),
                        int(objective), int(warm_start))
 
     def _check(self, rc, what):
@@ -288,7 +290,7 @@ class Engine:
         infos = [dict(ipm_iters=i.ipm_iters, as_iters=i.as_iters, n_active_box=i.n_active_box,
                       n_active_kappa=i.n_active_kappa, kappa_max=i.kappa_max, kkt_res=i.kkt_res,
                       ticks=list(i.ticks), refine_rounds=i.refine_rounds, second_attempt=i.second_attempt,
-                      f32_factorisations=i.f32_factorisations) for i in info]
+                      f32_factorisations=i.f32_factorisations, gi_iters=i.gi_iters) for i in info]
         return out, curv, status, infos
 
     # ------------------------------------------------------------------------------------------------------------------

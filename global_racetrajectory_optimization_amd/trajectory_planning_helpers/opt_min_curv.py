@@ -27,11 +27,17 @@ def _raise_for_status(status: int) -> None:
     if status == _engine.STATUS_KAPPA_INFEASIBLE:
         raise ValueError("constraints are inconsistent, no solution")
     if status == _engine.STATUS_KAPPA_ACTIVE:
-        raise RuntimeError("opt_min_curv (MI355X engine): a curvature-bound row is active at the box optimum and the "
-                           "curvature-row phase did not resolve it (status 6)")
+        raise RuntimeError("opt_min_curv (MI355X engine): a curvature-bound row is violated at the returned point (status 6: the "
+                           "curvature rows were switched off with check_kappa < 0, or the solution missed the bound by more than 1e-7)")
     if status == _engine.STATUS_BAD_INPUT:
         raise RuntimeError("opt_min_curv (MI355X engine): non-finite input or fewer than 3 points (status 4)")
-    raise RuntimeError("opt_min_curv (MI355X engine): iteration cap reached (status %d)" % status)
+    if status == _engine.STATUS_RING_OVERFLOW:
+        raise RuntimeError("opt_min_curv (MI355X engine): the re-sampled raceline outgrew the caller's buffers (status 7)")
+    if status == _engine.STATUS_KAPPA_NO_SLOT:          # (not returned since round 5: the Goldfarb-Idnani path takes such problems)
+        raise RuntimeError("opt_min_curv (MI355X engine): no overflow slot for the curvature-row working set in this launch (status 8): "
+                           "solve the problem again in a launch of its own")
+    raise RuntimeError("opt_min_curv (MI355X engine): iteration cap reached (status %d) -- the block-pivoting phase AND the Goldfarb-Idnani "
+                       "fallback ran out of their budgets" % status)
 
 
 def _validate(reftrack, normvectors, A, closed):

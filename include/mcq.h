@@ -43,19 +43,17 @@ enum {
     MCQ_OK = 0,
     MCQ_INFEASIBLE = 1,      /* w_r + w_l < w_veh somewhere  -> tph raises RuntimeError("Problem not solvable, ...") */
     MCQ_NOT_PD = 2,          /* Cholesky pivot <= 0            -> quadprog raises ValueError("matrix G is not positive definite") */
-    MCQ_ITER_CAP = 3,        /* iteration cap hit */
+    MCQ_ITER_CAP = 3,        /* iteration cap hit -- of the Goldfarb-Idnani fallback too (20 n + 2000 steps; not observed) */
     MCQ_BAD_INPUT = 4,       /* n < 3, non-finite input */
     MCQ_KAPPA_INFEASIBLE = 5, /* curvature rows cannot be satisfied -> quadprog raises ValueError("constraints are inconsistent, no solution") */
-    MCQ_KAPPA_ACTIVE = 6,     /* box-only optimum violates a curvature row and the curvature-row phase is disabled (check_kappa < 0); or
-                               * more than 512 curvature rows are active (up to 120 are carried in LDS, up to 512 through one of the
-                               * handle's 8 overflow slots) */
+    MCQ_KAPPA_ACTIVE = 6,     /* box-only optimum violates a curvature row and the curvature-row phase is disabled (check_kappa < 0).
+                               * (Rounds 1-4 also returned it for more active curvature rows than the working-set arrays hold -- 120 in LDS,
+                               * 512 through an overflow slot; such problems now go through the Goldfarb-Idnani path, which has no limit.) */
     MCQ_RING_OVERFLOW = 7,    /* mcq_iqp_device / mcq_iqp_batch only: the re-sampled raceline of an IQP round needs more waypoints than
                                * the buffers hold (nmax / nmax_out) -- not an input error of the QP (that stays MCQ_BAD_INPUT) */
-    MCQ_KAPPA_NO_SLOT = 8     /* device entries only: more than 8 problems of ONE launch had more than 120 active curvature rows and this
-                               * one did not get an overflow slot (which ones do depends on the order the GPU schedules workgroups in):
-                               * not a property of the problem -- solve it again in a launch with at most 8 such problems.  The
-                               * host-buffer entries (mcq_solve_batch, mcq_solve_host, mcq_solve_batch_f32) do that themselves and never
-                               * return this status: their results do not depend on scheduling. */
+    MCQ_KAPPA_NO_SLOT = 8     /* never returned since round 5 (kept for ABI compatibility): a problem with more than 120 active curvature
+                               * rows that finds the handle's 8 overflow slots taken is solved by the Goldfarb-Idnani path of the same
+                               * launch sequence, on every entry point */
 };
 
 /* library-level error codes (negative return values) */
@@ -77,7 +75,12 @@ typedef struct {
 } mcq_problem;
 
 typedef struct {
-    int band_e;         /* cyclic half-bandwidth kept of E_kappa (<= 32; 0 => default 32; exact to fp64 round-off) */
+    int algorithm;      /* MCQ_ALG_DEFAULT (0; any value other than MCQ_ALG_GI): interior point -> block pivoting on the identified vertex,
+                         * with the Goldfarb-Idnani path below as the fallback of every problem that phase does not settle;
+                         * MCQ_ALG_GI (1): EVERY problem through the engine's Goldfarb-Idnani dual active-set path (quadprog's algorithm
+                         * [REF requirements.txt:3 via tph.opt_min_curv]: one constraint enters per iteration, ratio test, drops -- finite by
+                         * construction; a few workgroups per launch, so slow for large batches: a reference mode).  Minimum-curvature
+                         * objective only.  (Until round 4 this field was `band_e`, ignored since E is applied through the spline system.) */
     int max_ipm_iter;   /* 0 => default 60 */
     int max_as_iter;    /* 0 => default 60 */
     int refine_steps;   /* fp64 residual-refinement rounds on the final active set; <0 => default 2 */
@@ -96,6 +99,8 @@ typedef struct {
 } mcq_opts;
 #define MCQ_OBJ_MIN_CURV 0
 #define MCQ_OBJ_SHORTEST_PATH 1
+#define MCQ_ALG_DEFAULT 0
+#define MCQ_ALG_GI 1
 
 /* per-problem diagnostics (optional output) */
 typedef struct {
@@ -116,7 +121,9 @@ typedef struct {
                            was abandoned for the cold path */
     int f32_factorisations;  /* of ipm_iters: factorisations whose records were stored as floats (the first interior-point
                                 iterations, while the dual residual is far above what such records can resolve; round 4) */
-    int reserved_;
+    int gi_iters;       /* iterations (full + partial steps) of the Goldfarb-Idnani path, 0 if it did not run for this problem
+                           (second_attempt bit 2 says that it ran, bit 3 that its final polish through the block-pivoting phase did not
+                           settle and the Goldfarb-Idnani iterate itself is returned: feasible / optimal to its own 2e-9 m tolerances) */
 } mcq_info;
 
 int mcq_create(int device_id, mcq_handle** out);

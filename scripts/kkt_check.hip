@@ -18,7 +18,7 @@ __global__ void __launch_bounds__(MCQ_NT, 2) kc_kernel(McqBatch B, int reps, con
 {
     int n;
     double kb, wv;
-    ctx_set_problem(B, n, kb, wv);
+    ctx_set_problem(B, blockIdx.x, n, kb, wv);
     const LCtx& c = G_CTX;
     if (threadIdx.x == 0) {
         for (int q = 0; q < 8; ++q) g_ctx.tk[q] = 0;

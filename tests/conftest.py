@@ -32,7 +32,7 @@ def emu_lib():
     import subprocess
     path = os.path.join(ROOT, "tests", "emu", "libmcq_emu.so")
     src = [os.path.join(ROOT, "global_racetrajectory_optimization_amd", "csrc", f)
-           for f in ("mcq_kernels.hip", "mcq_kernels.h", "mcq_api.hip", "mcq_kkt.inc", "mcq_tri.inc")]
+           for f in ("mcq_kernels.hip", "mcq_kernels.h", "mcq_api.hip", "mcq_kkt.inc", "mcq_tri.inc", "mcq_gi.inc")]
     src.append(os.path.join(ROOT, "tests", "emu", "include", "hip", "hip_runtime.h"))
     def stale():
         return not os.path.exists(path) or any(os.path.getmtime(s) > os.path.getmtime(path) for s in src)

@@ -13,5 +13,5 @@ g++ $F -c -o $TMP/api.o $SRC/mcq_api.hip &
 P2=$!
 wait $P1 || exit 1
 wait $P2 || exit 1
-g++ -shared -fPIC -o $TMP/libmcq_emu.so $TMP/kernels.o $TMP/api.o
+g++ -shared -fPIC -o $TMP/libmcq_emu.so $TMP/kernels.o $TMP/api.o -ldl
 mv -f $TMP/libmcq_emu.so libmcq_emu.so      # (atomic: a process that has the old library mapped keeps it)

@@ -1,0 +1,88 @@
+"""The engine's Goldfarb-Idnani path (csrc/mcq_gi.inc) on the SIMT interpreter: quadprog's algorithm [REF requirements.txt:3 via
+tph.opt_min_curv, main_globaltraj.py:264-271] in curvature coordinates, as the fallback of the block-pivoting phase and -- with
+mcq_opts.algorithm = MCQ_ALG_GI -- on its own.  Checked against the dense Goldfarb-Idnani oracle (oracle/gi_dense.c): the same vertex AND the
+same number of steps (the two follow the same rule -- most violated constraint in, ratio test, drops -- on the same QP)."""
+import numpy as np
+import pytest
+
+from global_racetrajectory_optimization_amd import engine
+from oracle import qp_ref, tph_ref
+
+
+@pytest.fixture(scope="module")
+def emu(emu_lib):
+    eng = engine.Engine(0, lib_path=emu_lib)
+    yield eng
+    eng.close()
+
+
+def _problem(g, kb=None):
+    return dict(reftrack=g["reftrack"], normvec=g["normvec"], scaling=g["scaling"], kappa_bound=float(g["kappa_bound"]) if kb is None else kb,
+                w_veh=float(g["w_veh"]))
+
+
+def _dense(g, kb, w_veh):
+    ref, nv = g["reftrack"], g["normvec"]
+    _, _, A, _ = tph_ref.calc_splines(np.vstack((ref[:, :2], ref[:1, :2])))
+    info = {}
+    a_ref, err = tph_ref.opt_min_curv(ref, nv, A, kb, w_veh, solver=lambda H, f, G, h: qp_ref.solve_qp_gi(H, f, G, h, info))
+    return a_ref, err, info
+
+
+@pytest.mark.parametrize("track", ["rounded_rectangle", "handling_track"])
+def test_gi_mode_matches_golden_and_takes_the_dense_oracles_steps(emu, golden, track):
+    g = golden[track]
+    al, curv, st, info = emu.solve_batch([_problem(g)], algorithm=engine.ALG_GI)
+    assert st[0] == 0
+    assert np.max(np.abs(al[0] - g["alpha"])) < 1e-9
+    assert abs(curv[0] - float(g["curv_error_max"])) < 1e-10
+    i = info[0]
+    assert i["second_attempt"] & 4 and not i["second_attempt"] & 8 and i["ipm_iters"] == 0 and i["as_iters"] == 1
+    _, _, dinfo = _dense(g, float(g["kappa_bound"]), float(g["w_veh"]))
+    assert i["gi_iters"] == int(dinfo["iters"][0] + dinfo["iters"][1])          # constraints added + dropped
+    assert i["n_active_box"] == int(np.sum(dinfo["lagr"] > 0))
+    # the default path returns the same vertex without it
+    al0, curv0, st0, info0 = emu.solve_batch([_problem(g)])
+    assert st0[0] == 0 and info0[0]["gi_iters"] == 0 and not info0[0]["second_attempt"] & 4
+    assert np.max(np.abs(al0[0] - al[0])) < 1e-10
+
+
+def test_gi_mode_with_curvature_rows_against_dense_gi(emu, golden):
+    g = golden["rounded_rectangle"]
+    a_ref, err_ref, dinfo = _dense(g, 0.07, 3.4)
+    n = g["reftrack"].shape[0]
+    nk = int(np.sum(dinfo["lagr"][2 * n:] > 0))
+    assert nk >= 3
+    al, curv, st, info = emu.solve_batch([_problem(g, 0.07)], algorithm=engine.ALG_GI)
+    assert st[0] == 0 and info[0]["n_active_kappa"] == nk
+    assert np.max(np.abs(al[0] - a_ref)) < 1e-9 and abs(curv[0] - err_ref) < 1e-9
+    assert abs(info[0]["kappa_max"] - 0.07) < 1e-10
+
+
+def test_inconsistent_curvature_rows_are_recognised_by_both_paths(emu, golden):
+    """quadprog: ValueError("constraints are inconsistent, no solution").  A curvature bound no line inside the corridor can meet: the default
+    path's interior point gives up, the Goldfarb-Idnani path it falls back on finds the dependent row with nothing to drop -- status 5 either
+    way, as the dense oracle raises."""
+    g = golden["rounded_rectangle"]
+    with pytest.raises(ValueError, match="inconsistent"):
+        _dense(g, 0.01, 3.4)
+    for alg in (engine.ALG_DEFAULT, engine.ALG_GI):
+        _, _, st, info = emu.solve_batch([_problem(g, 0.01)], algorithm=alg)
+        assert st[0] == engine.STATUS_KAPPA_INFEASIBLE, (alg, st[0])
+        assert info[0]["second_attempt"] & 4                    # the verdict is the Goldfarb-Idnani path's in both cases
+
+
+def test_fallback_takes_over_when_block_pivoting_runs_out(emu, golden):
+    """max_as_iter = 1 ends the block-pivoting phase after one round: whatever it has not settled by then (MCQ_ITER_CAP inside the solver
+    kernel) goes through the Goldfarb-Idnani path of the same launch -- status 0 and the golden vertex, next to a problem that needs none."""
+    probs = [_problem(golden[t]) for t in ("rounded_rectangle", "handling_track")] + [_problem(golden["rounded_rectangle"], 0.07)]
+    al, curv, st, info = emu.solve_batch(probs, max_as_iter=1)
+    assert list(st) == [0, 0, 0]
+    ran = [bool(i["second_attempt"] & 4) for i in info]
+    assert any(ran), "no problem of this batch needed a second round: the test exercises nothing"
+    for k, t in enumerate(("rounded_rectangle", "handling_track")):
+        assert np.max(np.abs(al[k] - golden[t]["alpha"])) < 1e-9
+    a_ref, _, _ = _dense(golden["rounded_rectangle"], 0.07, 3.4)
+    assert np.max(np.abs(al[2] - a_ref)) < 1e-9
+    for r, i in zip(ran, info):
+        assert (i["gi_iters"] > 0) == r

@@ -1,0 +1,122 @@
+"""The engine's Goldfarb-Idnani path (csrc/mcq_gi.inc) on the MI355X, through the C ABI: quadprog's algorithm [REF requirements.txt:3 via
+tph.opt_min_curv, main_globaltraj.py:264-271; params/racecar.ini:49 curvlim] as the fallback of the block-pivoting phase -- VERDICT r4 item 1: no
+feasible strictly convex QP may end in MCQ_ITER_CAP / MCQ_KAPPA_ACTIVE, whatever the rounding sequence -- and on its own
+(mcq_opts.algorithm = MCQ_ALG_GI).  Oracle: dense Goldfarb-Idnani with all 4N rows (oracle/gi_dense.c), live for the stadiums, committed
+vectors (scripts/make_golden_r5.py) for the curvature-tight fuzz."""
+import os
+
+import numpy as np
+import pytest
+
+from global_racetrajectory_optimization_amd import engine
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ALPHA_TOL = 1e-6        # north_star's fp64 tolerance against quadprog
+
+
+def _stadium_cases():
+    from oracle import qp_ref, tph_ref
+    from test_emu_kernels import stadium_problem
+    probs, want = [], []
+    for n in (360, 720):
+        ref, nv, A, sc, kb = stadium_problem(n, 0.0223)
+        info = {}
+        a_ref, err_ref = tph_ref.opt_min_curv(ref, nv, A, kb, 2.0, solver=lambda H, f, G, h: qp_ref.solve_qp_gi(H, f, G, h, info))
+        probs.append(dict(reftrack=ref, normvec=nv, scaling=sc, kappa_bound=kb, w_veh=2.0))
+        want.append((a_ref, err_ref, int(np.sum(info["lagr"][2 * n:] > 0))))
+    return probs, want
+
+
+@pytest.fixture(scope="module")
+def stadiums():
+    return _stadium_cases()
+
+
+def test_gi_mode_reference_tracks_and_stadiums(gpu_engine, golden, stadiums):
+    """Every problem through the Goldfarb-Idnani path alone: the reference's four tracks against their dense-oracle goldens -- the same
+    vertex in the same number of steps as the dense Goldfarb-Idnani took (both add the most violated row and drop by the same ratio test) --
+    and the stadiums with 134 / 270 active curvature rows (no limit on the working set: MCQ_KMAX and the overflow slots are the block-pivoting
+    phase's)."""
+    names = ("rounded_rectangle", "handling_track", "modena_2019", "berlin_2018")
+    probs = [dict(reftrack=golden[t]["reftrack"], normvec=golden[t]["normvec"], scaling=golden[t]["scaling"], kappa_bound=0.12, w_veh=3.4)
+             for t in names]
+    sp, want = stadiums
+    al, curv, st, info = gpu_engine.solve_batch(probs + sp, algorithm=engine.ALG_GI)
+    assert np.all(st == 0), st
+    for k, t in enumerate(names):
+        assert np.max(np.abs(al[k] - golden[t]["alpha"])) < 2e-8, (t, float(np.max(np.abs(al[k] - golden[t]["alpha"]))))
+        assert abs(curv[k] - float(golden[t]["curv_error_max"])) < 1e-9
+        assert info[k]["second_attempt"] & 4 and info[k]["gi_iters"] > 0 and info[k]["ipm_iters"] == 0
+    for k, (a_ref, err_ref, nk) in enumerate(want):
+        i = info[len(names) + k]
+        assert i["n_active_kappa"] == nk, (i["n_active_kappa"], nk)
+        assert np.max(np.abs(al[len(names) + k] - a_ref)) < ALPHA_TOL and abs(curv[len(names) + k] - err_ref) < 1e-9
+    print("GI mode: steps %s, polish rejected %s, max |alpha - oracle| %s" % (
+        [i["gi_iters"] for i in info], [bool(i["second_attempt"] & 8) for i in info],
+        ["%.1e" % float(np.max(np.abs(al[k] - (golden[names[k]]["alpha"] if k < 4 else want[k - 4][0])))) for k in range(len(al))]))
+    # against the default path on the same problems
+    al0, curv0, st0, _ = gpu_engine.solve_batch(probs)
+    assert np.all(st0 == 0) and max(float(np.max(np.abs(a - b))) for a, b in zip(al0, al[:4])) < 1e-9
+
+
+def test_arithmetic_variants_on_the_stadium(stadiums):
+    """VERDICT r4 item 1(i).  Round 4's block-pivoting phase solved the 720-point stadium (270 adjacent active curvature rows) by the grace of
+    one rounding sequence: a one-ulp perturbation of every solve's separator values turned status 0 into 6 / 3 (docs/NOTEBOOK.md R4.6).  The
+    SAME sources built four more ways (__graft_entry__.VARIANTS: that perturbation, interprocedural register allocation on, no compiler-formed
+    fused multiply-adds, fp64 records throughout the interior point) must return the dense oracle's vertex on both stadiums -- by block
+    pivoting where it settles, through the Goldfarb-Idnani path where it does not."""
+    import __graft_entry__ as ge
+    probs, want = stadiums
+    report = {}
+    for name in ge.VARIANTS:
+        path = ge.variant_path(name)
+        assert os.path.exists(path), "arithmetic variant '%s' was not built (__graft_entry__.build_variants)" % name
+        eng = engine.Engine(0, lib_path=path)
+        try:
+            al, curv, st, info = eng.solve_batch(probs)
+        finally:
+            eng.close()
+        assert np.all(st == 0), (name, st)
+        for k, (a_ref, err_ref, nk) in enumerate(want):
+            d = float(np.max(np.abs(al[k] - a_ref)))
+            assert d < ALPHA_TOL, (name, k, d)
+            assert abs(curv[k] - err_ref) < 1e-9 and info[k]["n_active_kappa"] == nk, (name, k)
+        report[name] = [(i["as_iters"], i["gi_iters"]) for i in info]
+    print("stadium 360 / 720, (block-pivoting rounds, Goldfarb-Idnani steps) per build:", report)
+
+
+def test_curvature_tight_fuzz_against_dense_gi(gpu_engine):
+    """220 problems with kappa_bound between 0.6 x and 1.0 x the curvature maximum of their box optimum (stadiums,
+    star-shaped rings, the reference's own tracks; tests/golden/kappa_tight_fuzz.npz, scripts/make_golden_r5.py) in one ragged launch.
+    Status 0 and the dense oracle's vertex for every problem the dense Goldfarb-Idnani solves; MCQ_KAPPA_INFEASIBLE exactly where it reports
+    "constraints are inconsistent"; no other status."""
+    z = np.load(os.path.join(ROOT, "tests", "golden", "kappa_tight_fuzz.npz"))
+    off = z["offsets"]
+    nprob = len(off) - 1
+    assert nprob >= 200
+    probs = [dict(reftrack=z["reftrack"][off[k]:off[k + 1]], normvec=z["normvec"][off[k]:off[k + 1]], scaling=z["scaling"][off[k]:off[k + 1]],
+                  kappa_bound=float(z["kappa_bound"][k]), w_veh=float(z["w_veh"][k])) for k in range(nprob)]
+    al, curv, st, info = gpu_engine.solve_batch(probs)
+    st_ref = z["status_ref"]
+    assert np.array_equal(np.asarray(st) == 0, st_ref == 0), [(k, int(st[k]), int(st_ref[k])) for k in range(nprob) if (st[k] == 0) != (st_ref[k] == 0)]
+    assert set(np.unique(st)) <= {0, engine.STATUS_KAPPA_INFEASIBLE}, np.unique(st)
+    worst = 0.0
+    for k in range(nprob):
+        if st_ref[k] != 0:
+            continue
+        d = float(np.max(np.abs(al[k] - z["alpha"][off[k]:off[k + 1]])))
+        worst = max(worst, d)
+        assert d < ALPHA_TOL, (k, d)
+        assert abs(curv[k] - float(z["curv_error_max"][k])) < 1e-8, k
+        assert info[k]["n_active_kappa"] == int(z["n_active_kappa"][k]), (k, info[k]["n_active_kappa"], int(z["n_active_kappa"][k]))
+    ran = [k for k in range(nprob) if info[k]["second_attempt"] & 4]
+    print("curvature-tight fuzz: %d problems (%d inconsistent), max |alpha - dense GI| %.2e m, Goldfarb-Idnani path ran for %d: %s" % (
+        nprob, int(np.sum(st_ref != 0)), worst, len(ran), ran[:40]))
+    # the same set through the Goldfarb-Idnani path alone
+    al2, curv2, st2, info2 = gpu_engine.solve_batch(probs, algorithm=engine.ALG_GI)
+    assert np.array_equal(np.asarray(st2), np.where(st_ref == 0, 0, engine.STATUS_KAPPA_INFEASIBLE))
+    w2 = max(float(np.max(np.abs(al2[k] - z["alpha"][off[k]:off[k + 1]]))) for k in range(nprob) if st_ref[k] == 0)
+    assert w2 < ALPHA_TOL, w2
+    print("the same through the Goldfarb-Idnani path alone: max |alpha - dense GI| %.2e m, steps mean %.0f max %d" % (
+        w2, float(np.mean([i["gi_iters"] for i in info2])), max(i["gi_iters"] for i in info2)))

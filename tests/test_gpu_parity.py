@@ -1081,14 +1081,17 @@ def test_curvature_row_overflow_slots_against_dense_gi(gpu_engine):
     print("curvature-row overflow: %s active rows, max |alpha - dense GI| = %.2e m"
           % ([w[2] for w in want], max(float(np.max(np.abs(al[k] - w[0]))) for k, w in enumerate(want))))
     # more such problems in ONE launch than the handle has overflow slots (8): which of them get a slot depends on the order the GPU
-    # schedules workgroups in -- the host-buffer entries re-launch the ones left out (MCQ_KAPPA_NO_SLOT), so every copy comes back as the
-    # single solve does (a width sweep of such a track used to fail on most problems); the device entry reports them
+    # schedules workgroups in -- the ones left out go through the Goldfarb-Idnani kernel of the same launch sequence (round 5; rounds 3-4:
+    # MCQ_KAPPA_NO_SLOT, re-launched by the host-buffer entries only), whose final round from the same working set is the block-pivoting
+    # phase's own: every copy comes back with status 0 and the same vertex, on the host-buffer entry and on the device entry alike
     many = [probs[0]] * 11 + [dict(reftrack=probs[0]["reftrack"], normvec=probs[0]["normvec"], scaling=probs[0]["scaling"], kappa_bound=0.5,
                                   w_veh=2.0)]
     al2, curv2, st2, info2 = gpu_engine.solve_batch(many)
     assert np.all(st2 == 0)
     for k in range(11):
-        assert np.array_equal(al2[k], al[0]) and curv2[k] == curv[0] and info2[k]["n_active_kappa"] == want[0][2]
+        assert np.max(np.abs(al2[k] - al[0])) < 1e-9 and abs(curv2[k] - curv[0]) < 1e-12 and info2[k]["n_active_kappa"] == want[0][2]
+    print("11 copies, 8 overflow slots: Goldfarb-Idnani path for %d of them, bitwise equal to the single solve: %d of 11" % (
+        sum(1 for i in info2[:11] if i["second_attempt"] & 4), sum(1 for k in range(11) if np.array_equal(al2[k], al[0]))))
     n0 = probs[0]["reftrack"].shape[0]
     d_ref, d_nv, d_sc = (gpu_engine.alloc(8 * 11 * n0 * w) for w in (4, 2, 1))
     d_al, d_cu, d_st = gpu_engine.alloc(8 * 11 * n0), gpu_engine.alloc(8 * 11), gpu_engine.alloc(4 * 11)
@@ -1097,7 +1100,9 @@ def test_curvature_row_overflow_slots_against_dense_gi(gpu_engine):
     gpu_engine.upload(d_sc, np.tile(probs[0]["scaling"], (11, 1)))
     gpu_engine.solve_device(11, n0, d_ref, d_nv, d_sc, probs[0]["kappa_bound"], 2.0, d_al, d_cu, d_st)
     st3 = gpu_engine.download(d_st, (11,), np.int32)
-    assert np.count_nonzero(st3 == 0) == 8 and np.count_nonzero(st3 == engine.STATUS_KAPPA_NO_SLOT) == 3, st3
+    assert np.all(st3 == 0), st3
+    al3 = gpu_engine.download(d_al, (11, n0), np.float64)
+    assert np.max(np.abs(al3 - al[0][None, :])) < 1e-9
     for p_ in (d_ref, d_nv, d_sc, d_al, d_cu, d_st):
         gpu_engine.free(p_)
 
