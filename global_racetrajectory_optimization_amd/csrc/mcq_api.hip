@@ -735,6 +735,7 @@ extern "C" int mcq_device_free(mcq_handle* h, void* ptr)
     if (!ptr) return 0;
     HIP_TRY(hipSetDevice(h->device));
     HIP_TRY(hipStreamSynchronize(h->stream));
+    if (h->comm_stream) HIP_TRY(hipStreamSynchronize(h->comm_stream));      // (a gather in flight may read or write the buffer)
     HIP_TRY(hipFree(ptr));
     return 0;
 }
@@ -752,6 +753,9 @@ extern "C" int mcq_copy_to_host(mcq_handle* h, void* dst, const void* src, size_
 {
     if (!h || !dst || !src) { g_err = "mcq_copy_to_host: bad argument"; return MCQ_E_ARG; }
     HIP_TRY(hipSetDevice(h->device));
+    // a gather enqueued before this copy may be writing `src` on the comm stream: the copy is ordered behind the latest one (ADVICE r4:
+    // parallel.solve_sharded read its receive buffer before the gather had finished)
+    if (h->comm_seq > 0) HIP_TRY(hipStreamWaitEvent(h->stream, h->comm_done[(h->comm_seq - 1) & 3u], 0));
     HIP_TRY(hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToHost, h->stream));
     HIP_TRY(hipStreamSynchronize(h->stream));
     return 0;
@@ -1413,7 +1417,7 @@ extern "C" int mcq_iqp_batch(mcq_handle* h, const mcq_problem* probs, int batch,
 
 
 // =====================================================================================================================
-// The one collective of a multi-GPU job (include/mcq.h): ncclAllGather of RCCL on the handle's stream.  RCCL is loaded with dlopen on
+// The one collective of a multi-GPU job (include/mcq.h): ncclAllGather of RCCL on the handle's COMM stream, ordered behind its compute stream by an event.  RCCL is loaded with dlopen on
 // first use -- libmcq.so has no link-time dependency on it, and a single-GPU process never maps its 570 MB.  Only the five entry
 // points below are bound; their types are restated here (rccl.h: ncclUniqueId = 128 opaque bytes, ncclComm_t an opaque pointer,
 // ncclDataType_t: ncclInt32 = 2, ncclFloat32 = 7, ncclFloat64 = 8; ncclSuccess = 0).

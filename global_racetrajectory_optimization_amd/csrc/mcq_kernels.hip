@@ -1468,7 +1468,12 @@ __device__ __noinline__ int active_set(const LCtx& c, bool with_kappa, bool tapi
 }
 
 // ---- scalars of a problem: the scales of the tolerances, the working set and the iterate at the box centre, the gradient there ----
-__device__ __noinline__ void problem_scales(const LCtx& c)
+#ifdef MCQ_OUTLINE_PROLOGUE     /* A/B switch: as calls they cost the solver kernel 64 bytes of scratch per lane and ~0.5 % (round 5) */
+#define MCQ_FN_PROLOGUE __device__ __noinline__
+#else
+#define MCQ_FN_PROLOGUE __device__ __forceinline__
+#endif
+MCQ_FN_PROLOGUE void problem_scales(const LCtx& c)
 {
     const int tid = threadIdx.x, n = c.d.n, nm = c.nm;
     double* red = g_sm + SM_RED;
@@ -1511,7 +1516,7 @@ struct McqOutcome {
     bool dd_valid;
     long long t_kernel0, c_kernel0, t_epi0;
 };
-__device__ __noinline__ void write_outputs(const LCtx& c, const McqOutcome& r)
+MCQ_FN_PROLOGUE void write_outputs(const LCtx& c, const McqOutcome& r)
 {
     const int tid = threadIdx.x, n = c.d.n, nm = c.nm;
     double* red = g_sm + SM_RED;

@@ -4,8 +4,8 @@ independent QPs, so the batch is block-partitioned over one-process-per-GPU rank
 the solve; exactly one all-gather collects the alpha vectors afterwards.
 
 One process per GPU, one Engine per process.  Round 4: the gather is the ENGINE'S OWN -- RCCL's ncclAllGather behind the C ABI
-(mcq_comm_init / mcq_comm_allgather, include/mcq.h), enqueued on the engine's stream right behind the solve that filled the send
-buffer.  Nothing of torch touches the GPU: the shard lives in memory of the engine's HIP runtime (mcq_device_alloc), so there is
+(mcq_comm_init / mcq_comm_allgather, include/mcq.h), on a comm stream of the engine ordered behind the solve that filled the send
+buffer; the receive buffer is read after mcq_comm_wait.  Nothing of torch touches the GPU: the shard lives in memory of the engine's HIP runtime (mcq_device_alloc), so there is
 no second runtime in the process, no stream of another runtime to order against and no initialisation order to get
 right.  The launcher's process group (torch.distributed, any backend -- gloo is enough) is only the rendezvous that carries rank
 0's 128-byte RCCL id to the other ranks (`init_engine_comm`).
@@ -104,8 +104,9 @@ def solve_sharded(problems: list, engine, dist=None, **opt_kw):
             full = engine.download(d_send, (1, count), np.float64)
         elif use_rccl:
             d_recv = dev(nbytes=8 * count * world)
-            engine.comm_allgather(d_send, d_recv, count, engine.DT_F64)       # the single collective of the job (engine's stream)
-            full = engine.download(d_recv, (world, count), np.float64)        # (blocking copy on the same stream: waits for it)
+            engine.comm_allgather(d_send, d_recv, count, engine.DT_F64)       # the single collective of the job: on the handle's COMM stream,
+            engine.comm_wait(0)                                               # behind the solve; the receive buffer is complete after this
+            full = engine.download(d_recv, (world, count), np.float64)
         else:
             import torch
             local = torch.from_numpy(engine.download(d_send, (count,), np.float64))

@@ -123,7 +123,8 @@ typedef struct {
                                 iterations, while the dual residual is far above what such records can resolve; round 4) */
     int gi_iters;       /* iterations (full + partial steps) of the Goldfarb-Idnani path, 0 if it did not run for this problem
                            (second_attempt bit 2 says that it ran, bit 3 that its final polish through the block-pivoting phase did not
-                           settle and the Goldfarb-Idnani iterate itself is returned: feasible / optimal to its own 2e-9 m tolerances) */
+                           settle and the Goldfarb-Idnani iterate itself is returned: feasible / optimal to its own 2e-9 m tolerances;
+                           bits 4-7: the status the solver kernel had left for the problem -- why this path ran) */
 } mcq_info;
 
 int mcq_create(int device_id, mcq_handle** out);
@@ -367,8 +368,12 @@ long long mcq_workspace_bytes(mcq_handle* h);
  *      vectors").  One process per GPU, one handle per process; independent QPs are block-partitioned over the ranks and every rank
  *      solves its shard with the entries above -- no collective inside a solve.  The gather is the engine's own: ncclAllGather of RCCL
  *      (loaded with dlopen on first use: $MCQ_RCCL_LIB, else $ROCM_PATH/lib/librccl.so.1, else /opt/rocm/lib/librccl.so.1, else
- *      librccl.so.1 -- a process that never gathers never loads it), enqueued on the HANDLE'S stream, i.e. ordered after the solves that
- *      produced the send buffer and overlapping nothing it should not; no torch, no second HIP runtime in the process.
+ *      librccl.so.1 -- a process that never gathers never loads it).  ORDERING, stated once: a gather runs on a COMM STREAM of the handle,
+ *      ordered behind everything enqueued on the handle's compute stream at the time of the call (an event) -- so after the solve that
+ *      filled `send` -- and concurrent with whatever is enqueued on the compute stream afterwards (the next solve).  Work on the compute
+ *      stream is NOT ordered behind a gather; a caller waits with mcq_comm_wait or mcq_sync before it reads `recv` or overwrites `send`.
+ *      (The blocking helpers mcq_copy_to_host and mcq_device_free do wait for the gathers enqueued before them, since round 5.)
+ *      No torch, no second HIP runtime in the process.
  *      Reference side: nothing to replace -- the reference is a single-process script; a caller that shards its sweeps
  *      [REF main_globaltraj.py:441-505, the lap-time matrix loops] would call these three.
  *   mcq_comm_unique_id   rank 0 creates the 128-byte id and ships it to the other ranks by whatever means the launcher offers

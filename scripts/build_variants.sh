@@ -8,14 +8,14 @@ R=$(cd "$(dirname "$0")/.." && pwd)
 SRC=$R/global_racetrajectory_optimization_amd/csrc
 OUT=$R/build/variants
 HIPCC=${HIPCC:-/opt/rocm/bin/hipcc}
-FLAGS="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -shared -mllvm -amdgpu-mfma-vgpr-form -mllvm -enable-ipra=0 -mllvm -amdgpu-schedule-metric-bias=0"
+FLAGS="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -shared -mllvm -enable-ipra=0 -mllvm -amdgpu-schedule-metric-bias=0 --gpu-max-threads-per-block=512"
 mkdir -p $OUT /tmp/mcq_base/csrc /tmp/mcq_base/include_dir
 rm -f $OUT/*.so
-BASE_REV=${BASE_REV:-436904a}
+BASE_REV=${BASE_REV:-3b86c49}
 if [ "$BASE_REV" != "none" ]; then
   # the whole csrc of BASE_REV (its own C ABI: entries added since are missing -- variants scripts only call what round 2 had)
   rm -rf /tmp/mcq_base && mkdir -p /tmp/mcq_base/csrc /tmp/mcq_base/include
-  for f in mcq_kernels.hip mcq_kernels.h mcq_api.hip; do git -C $R show $BASE_REV:global_racetrajectory_optimization_amd/csrc/$f > /tmp/mcq_base/csrc/$f; done
+  for f in $(git -C $R ls-tree --name-only $BASE_REV:global_racetrajectory_optimization_amd/csrc | grep -E "\.(hip|h|inc)$"); do git -C $R show $BASE_REV:global_racetrajectory_optimization_amd/csrc/$f > /tmp/mcq_base/csrc/$f; done
   git -C $R show $BASE_REV:include/mcq.h > /tmp/mcq_base/include/mcq.h
   sed -i 's#"../../include/mcq.h"#"../include/mcq.h"#' /tmp/mcq_base/csrc/mcq_kernels.h
   (cd /tmp/mcq_base/csrc && $HIPCC $FLAGS -o $OUT/libmcq_00base.so mcq_kernels.hip mcq_api.hip) || echo "base build failed"

@@ -52,8 +52,8 @@ def test_gi_mode_reference_tracks_and_stadiums(gpu_engine, golden, stadiums):
         i = info[len(names) + k]
         assert i["n_active_kappa"] == nk, (i["n_active_kappa"], nk)
         assert np.max(np.abs(al[len(names) + k] - a_ref)) < ALPHA_TOL and abs(curv[len(names) + k] - err_ref) < 1e-9
-    print("GI mode: steps %s, polish rejected %s, max |alpha - oracle| %s" % (
-        [i["gi_iters"] for i in info], [bool(i["second_attempt"] & 8) for i in info],
+    print("GI mode: steps %s, ms per problem %s, polish rejected %s, max |alpha - oracle| %s" % (
+        [i["gi_iters"] for i in info], ["%.1f" % (i["ticks"][3] / 1e5) for i in info], [bool(i["second_attempt"] & 8) for i in info],
         ["%.1e" % float(np.max(np.abs(al[k] - (golden[names[k]]["alpha"] if k < 4 else want[k - 4][0])))) for k in range(len(al))]))
     # against the default path on the same problems
     al0, curv0, st0, _ = gpu_engine.solve_batch(probs)
@@ -111,8 +111,10 @@ def test_curvature_tight_fuzz_against_dense_gi(gpu_engine):
         assert abs(curv[k] - float(z["curv_error_max"][k])) < 1e-8, k
         assert info[k]["n_active_kappa"] == int(z["n_active_kappa"][k]), (k, info[k]["n_active_kappa"], int(z["n_active_kappa"][k]))
     ran = [k for k in range(nprob) if info[k]["second_attempt"] & 4]
-    print("curvature-tight fuzz: %d problems (%d inconsistent), max |alpha - dense GI| %.2e m, Goldfarb-Idnani path ran for %d: %s" % (
-        nprob, int(np.sum(st_ref != 0)), worst, len(ran), ran[:40]))
+    print("curvature-tight fuzz: %d problems (%d inconsistent), max |alpha - dense GI| %.2e m, Goldfarb-Idnani path ran for %d; for feasible "
+          "problems (index, status the block-pivoting phase had left, active curvature rows, steps): %s" % (
+              nprob, int(np.sum(st_ref != 0)), worst, len(ran),
+              [(k, (info[k]["second_attempt"] >> 4) & 15, info[k]["n_active_kappa"], info[k]["gi_iters"]) for k in ran if st_ref[k] == 0]))
     # the same set through the Goldfarb-Idnani path alone
     al2, curv2, st2, info2 = gpu_engine.solve_batch(probs, algorithm=engine.ALG_GI)
     assert np.array_equal(np.asarray(st2), np.where(st_ref == 0, 0, engine.STATUS_KAPPA_INFEASIBLE))
