@@ -27,14 +27,15 @@ def test_random_rings_against_banded_cpu_solver(gpu_engine, n, w_veh):
     assert max(i["kkt_res"] for i in info) < 1e-9
 
 
-@pytest.mark.parametrize("n,w_veh", [(293, 2.0), (511, 1.6), (777, 3.0), (1001, 2.6)])
+@pytest.mark.parametrize("n,w_veh", [(293, 2.0), (511, 1.6), (777, 3.0), (1001, 2.6), (2047, 3.0), (2049, 2.4)])
 def test_kkt_certificate_from_the_dense_oracle_assembly(gpu_engine, n, w_veh):
     """`kkt_res` is self-reported by the engine.  Here the KKT conditions of the QP are checked ON THE
     HOST from the dense-faithful assembly (oracle/tph_ref.assemble_dense: dense 4N x 4N inverse, dense E; H = E'E, f = 2 E'k_ref) --
     stationarity on the free rows, multiplier signs on the active ones, feasibility -- for alpha as the engine returned it."""
     from oracle import tph_ref
     from global_racetrajectory_optimization_amd.trajectory_planning_helpers import calc_splines as cs
-    bsz = 3
+    bsz = 3 if n < 1500 else 1          # (the dense 4N x 4N inverse of the assembly: about 20 s per problem at N = 2049 -- either side of the
+                                        #  switch between the LDS sweeps and the long-ring route, round 5)
     ref, nv, sc = synthetic.oval_batch(bsz, n=n, first=5000 + n, perturb_centreline=True)
     al, curv, st, info = gpu_engine.solve_batch([dict(reftrack=ref[k], normvec=nv[k], scaling=sc[k], kappa_bound=0.5, w_veh=w_veh)
                                                  for k in range(bsz)])

@@ -122,3 +122,34 @@ def test_curvature_tight_fuzz_against_dense_gi(gpu_engine):
     assert w2 < ALPHA_TOL, w2
     print("the same through the Goldfarb-Idnani path alone: max |alpha - dense GI| %.2e m, steps mean %.0f max %d" % (
         w2, float(np.mean([i["gi_iters"] for i in info2])), max(i["gi_iters"] for i in info2)))
+
+
+def test_long_rings_against_dense_goldens(gpu_engine):
+    """the dense oracle ABOVE 2048 waypoints (scripts/make_golden_r5.py: N = 2100 and 2600 through the dense
+    10 400 x 10 400 inverse and the dense Goldfarb-Idnani with all 4N rows; one with the curvature bound active; tph.opt_shortest_path's QP
+    at N = 2100).  This is the range of the long-ring route -- tridiagonal sweeps on workspace vectors, the general interior point -- that was
+    silently wrong for a whole round (2049 .. 2208 waypoints, metres of error) while every test was green, because only CPU-B looked at it.
+    Reference behaviour: any N [REF helper_funcs_glob/src/prep_track.py:39-51 sets N from stepsize_reg]."""
+    from conftest import load_golden
+    names = ("oval_n2100", "oval_n2600", "oval_n2600_kappa")
+    gs = [load_golden(t) for t in names]
+    probs = [dict(reftrack=g["reftrack"], normvec=g["normvec"], scaling=g["scaling"], kappa_bound=float(g["kappa_bound"]), w_veh=float(g["w_veh"]))
+             for g in gs]
+    al, curv, st, info = gpu_engine.solve_batch(probs)
+    assert np.all(st == 0), st
+    d = [float(np.max(np.abs(al[k] - gs[k]["alpha"]))) for k in range(3)]
+    assert max(d) < ALPHA_TOL, d
+    assert max(abs(curv[k] - float(gs[k]["curv_error_max"])) for k in range(3)) < 1e-9
+    assert info[2]["n_active_kappa"] >= 3 and abs(info[2]["kappa_max"] - float(gs[2]["kappa_bound"])) < 1e-10
+    # the same three through the Goldfarb-Idnani path alone (its solves and E / E' on the long-ring route)
+    al2, curv2, st2, info2 = gpu_engine.solve_batch(probs, algorithm=engine.ALG_GI)
+    assert np.all(st2 == 0), st2
+    d2 = [float(np.max(np.abs(al2[k] - gs[k]["alpha"]))) for k in range(3)]
+    assert max(d2) < ALPHA_TOL, d2
+    g = load_golden("shortest_path_n2100")
+    al3, _, st3, _ = gpu_engine.solve_batch([dict(reftrack=g["reftrack"], normvec=g["normvec"], scaling=None, kappa_bound=1.0, w_veh=float(g["w_veh"]))],
+                                            objective=engine.OBJ_SHORTEST_PATH)
+    d3 = float(np.max(np.abs(al3[0] - g["alpha"])))
+    assert st3[0] == 0 and d3 < ALPHA_TOL, (st3[0], d3)
+    print("rings above 2048 waypoints, max |alpha - dense oracle|: default path %s, Goldfarb-Idnani path %s (steps %s), shortest path %.1e" % (
+        ["%.1e" % v for v in d], ["%.1e" % v for v in d2], [i["gi_iters"] for i in info2], d3))

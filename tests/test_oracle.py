@@ -196,3 +196,35 @@ def test_round4_goldens_are_consistent_with_cpu_b():
         assert st[0] == 0, name
         assert np.max(np.abs(a[0] - g["alpha"])) < 2e-8, (name, float(np.max(np.abs(a[0] - g["alpha"]))))
         assert abs(c[0] - float(g["curv_error_max"])) < 1e-9, name
+
+
+def test_round5_goldens_above_2048_waypoints_are_consistent_with_cpu_b():
+    """above 2048 waypoints the engine's long-ring route had only CPU-B (the same author's interior point + block pivoting
+    design) to be compared with, and CPU-B was tied to the dense oracle at N <= 2003 only.  scripts/make_golden_r5.py puts the dense oracle
+    (10 400 x 10 400 inverse, dense Goldfarb-Idnani with all 4N rows) at N = 2100 and N = 2600: CPU-B agrees with it there too, the stored KKT
+    stationarity is at rounding level, and the curvature-bound fixture has curvature rows in its working set."""
+    import json
+    import os
+    from conftest import GOLDEN_DIR, load_golden
+    from oracle import banded_ref
+    summ = json.load(open(os.path.join(GOLDEN_DIR, "SUMMARY_r5.json")))
+    for name in ("oval_n2100", "oval_n2600", "oval_n2600_kappa"):
+        assert summ[name]["kkt_stationarity"] < 1e-10, name
+    assert summ["oval_n2600_kappa"]["n_active_kappa"] >= 3
+    for name in ("oval_n2100", "oval_n2600"):
+        g = load_golden(name)
+        assert g["reftrack"].shape[0] > 2048
+        a, c, st, _, _ = banded_ref.solve_batch(g["reftrack"][None], g["normvec"][None], g["scaling"][None], float(g["kappa_bound"]), float(g["w_veh"]))
+        assert st[0] == 0, name
+        assert np.max(np.abs(a[0] - g["alpha"])) < 2e-8, (name, float(np.max(np.abs(a[0] - g["alpha"]))))
+        assert abs(c[0] - float(g["curv_error_max"])) < 1e-9, name
+    # the curvature-tight fuzz fixture: every stored solution is feasible for its own (tight) bound and box
+    z = np.load(os.path.join(GOLDEN_DIR, "kappa_tight_fuzz.npz"))
+    off = z["offsets"]
+    assert len(off) - 1 >= 200 and int(np.sum(z["status_ref"] == 5)) >= 10 and int(np.max(z["n_active_kappa"])) > 120
+    for k in (0, 17, 95, 200):
+        if z["status_ref"][k] != 0:
+            continue
+        ref, al = z["reftrack"][off[k]:off[k + 1]], z["alpha"][off[k]:off[k + 1]]
+        w = float(z["w_veh"][k])
+        assert np.all(al <= ref[:, 2] - w / 2 + 1e-9) and np.all(al >= -(ref[:, 3] - w / 2) - 1e-9)
