@@ -371,8 +371,7 @@ def main():
         os.dup2(2, 1)
         try:
             dist.init_process_group(backend="gloo", rank=rank, world_size=world)
-            if not emulate:
-                parallel.init_engine_comm(eng, dist)          # ncclCommInitRank behind the C ABI; the id travels over gloo
+            parallel.init_engine_comm(eng, dist)              # ncclCommInitRank behind the C ABI; the id travels over gloo
             dist.barrier()
         finally:
             ctypes.CDLL(None).fflush(None)
@@ -393,14 +392,9 @@ def main():
         return p
 
     def gather(d_send, d_recv, count, np_dt, dt_code, record):
-        """The one collective of a step: RCCL through the C ABI (asynchronous, the engine's comm stream); emulated runs: gloo on host copies."""
-        if emulate:
-            local = torch.from_numpy(eng.download(d_send, (count,), np_dt))
-            full = torch.zeros((world * count,), dtype=local.dtype)
-            dist.all_gather_into_tensor(full, local)
-            eng.upload(d_recv, full.numpy())
-        else:
-            eng.comm_allgather(d_send, d_recv, count, dt_code)
+        """The one collective of a step: RCCL through the C ABI (asynchronous, the engine's comm stream).  (The CPU tests run this very
+        path: the SIMT-interpreted library loads tests/stub/librccl_stub_sync.so through $MCQ_RCCL_LIB.)"""
+        eng.comm_allgather(d_send, d_recv, count, dt_code)
 
     if args.config == 4:
         wl = config4_workload(rank, world, tuple(args.c4_tracks.split(",")), args.c4_widths, args.c4_vehicles)
@@ -417,10 +411,9 @@ def main():
                                            track_of=wl["track_of"], n_of_track=race["m"])
             lap_h[0] = lap
             if collective:
-                if not emulate:
-                    ms = eng.comm_wait(0)          # the previous gather reads d_lap: done before it is overwritten
-                    if record and ms > 0.0:
-                        ag_ms_list.append(ms)
+                ms = eng.comm_wait(0)              # the previous gather reads d_lap: done before it is overwritten
+                if record and ms > 0.0:
+                    ag_ms_list.append(ms)
                 pad = np.zeros(wl["per_rank"])
                 pad[:lap.size] = lap
                 eng.upload(d_lap, pad)
@@ -450,7 +443,7 @@ def main():
             slot = step_no[0] % len(d_alpha2)
             d_alpha = d_alpha2[slot]
             step_no[0] += 1
-            if collective and not emulate:
+            if collective:
                 ms = eng.comm_wait(1)              # the gather that last read this buffer (two steps ago) has finished
                 if record and ms > 0.0:
                     ag_ms_list.append(ms)
@@ -496,7 +489,7 @@ def main():
             assert np.array_equal(own, eng.download(d_alpha, (B, n), io_np)), "all-gather: own shard differs"
     ranks_seen = dist.get_world_size() if collective else 1
     assert ranks_seen == world, "process group has %d ranks, the launcher announced %d" % (ranks_seen, world)
-    if collective and not emulate:
+    if collective:
         assert eng.comm_world() == (rank, world), "the engine's RCCL communicator is %s, the launcher announced rank %d of %d" % (eng.comm_world(), rank, world)
     ag_ms = float(np.mean(ag_ms_list)) if ag_ms_list else None
 
@@ -554,7 +547,8 @@ def main():
                        "io": args.io + ((" rows (%s) / float alpha in HBM, fp64 arithmetic" % ("ring increments + fp64 origin" if args.f32_layout == "inc" else "absolute coordinates")) if f32 else ""),
                        "centrelines": "perturbed per track" if args.perturb_centreline else "shared",
                        "collective": ("1 all-gather of alpha per step: ncclAllGather (RCCL) through the C ABI, mcq_comm_allgather, on the engine's comm stream"
-                                      if collective and not emulate else "1 all-gather of alpha per step (gloo, emulated run)" if collective else "none"),
+                                      + (" [EMULATED RUN: librccl stand-in " + os.path.basename(os.environ.get("MCQ_RCCL_LIB", "?")) + "]" if emulate else "")
+                                      if collective else "none"),
                        "ranks_seen": ranks_seen, "rank_ms_per_step": {"min": min(rank_ms), "max": max(rank_ms)},
                        "allgather_ms": ag_ms, "allgather_dtype": np.dtype(io_np).name,
                        "failed_problems": int(np.count_nonzero(status)),

@@ -10,8 +10,8 @@ no second runtime in the process, no stream of another runtime to order against 
 right.  The launcher's process group (torch.distributed, any backend -- gloo is enough) is only the rendezvous that carries rank
 0's 128-byte RCCL id to the other ranks (`init_engine_comm`).
 
-Without a communicator on the engine (the CPU tests: SIMT-interpreted library, gloo, world 2 and 4) the same packed buffers are
-gathered through `dist.all_gather_into_tensor` on host tensors -- test harness, not the product path.
+The CPU tests (SIMT-interpreted library, world 2 and 4) run this very path: $MCQ_RCCL_LIB points the engine at tests/stub/librccl_stub_sync.so,
+a shared-memory stand-in for the five RCCL entry points it binds (round 5; until then a gloo branch in this file served them).
 """
 import numpy as np
 
@@ -47,14 +47,16 @@ def solve_sharded(problems: list, engine, dist=None, **opt_kw):
 
     problems: dicts {reftrack [n,4], normvec [n,2] or None (then for all: normals and scalings are derived on the device),
     scaling [n] or None, kappa_bound, w_veh}.
-    dist: torch.distributed (initialised) or None for single-process.  The gather runs through the engine's RCCL communicator when it
-    has one (`init_engine_comm`), else through `dist` on host tensors (gloo: the CPU tests).
+    dist: torch.distributed (initialised) or None for single-process.  The gather runs through the engine's RCCL communicator
+    (`init_engine_comm`; required for more than one rank).
     Returns (alphas list, curv [B], status [B]).
     """
     bsz = len(problems)
     world = dist.get_world_size() if dist is not None else 1
     rank = dist.get_rank() if dist is not None else 0
     use_rccl = _has_comm(engine)
+    if world > 1 and not use_rccl:
+        raise ValueError("solve_sharded: %d ranks but the engine has no communicator -- call parallel.init_engine_comm(engine, dist) first" % world)
     if use_rccl and engine.comm_world() != (rank, world):
         raise ValueError("solve_sharded: the engine's communicator is rank %d of %d, the process group says %d of %d"
                          % (engine.comm_world() + (rank, world)))
@@ -102,17 +104,11 @@ def solve_sharded(problems: list, engine, dist=None, **opt_kw):
                                               **opt_kw)
         if world == 1 and not use_rccl:
             full = engine.download(d_send, (1, count), np.float64)
-        elif use_rccl:
+        else:
             d_recv = dev(nbytes=8 * count * world)
             engine.comm_allgather(d_send, d_recv, count, engine.DT_F64)       # the single collective of the job: on the handle's COMM stream,
             engine.comm_wait(0)                                               # behind the solve; the receive buffer is complete after this
             full = engine.download(d_recv, (world, count), np.float64)
-        else:
-            import torch
-            local = torch.from_numpy(engine.download(d_send, (count,), np.float64))
-            gathered = torch.zeros((world * count,), dtype=torch.float64)
-            dist.all_gather_into_tensor(gathered, local)                      # test harness (gloo)
-            full = gathered.numpy().reshape(world, count)
     finally:
         for p in bufs:
             engine.free(p)

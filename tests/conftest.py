@@ -53,3 +53,20 @@ def gpu_engine():
     eng = engine.Engine(0)
     yield eng
     eng.close()
+
+
+@pytest.fixture(scope="session")
+def rccl_stub():
+    """TEST-ONLY: the shared-memory stand-in for librccl.so.1 (tests/stub/rccl_stub.cpp, synchronous build) that lets the engine's collective
+    path run with several ranks on the SIMT-interpreted library; tests hand its path to the engine through $MCQ_RCCL_LIB."""
+    import fcntl
+    import subprocess
+    d = os.path.join(ROOT, "tests", "stub")
+    path = os.path.join(d, "librccl_stub_sync.so")
+    src = os.path.join(d, "rccl_stub.cpp")
+    if not os.path.exists(path) or os.path.getmtime(src) > os.path.getmtime(path):
+        with open(path + ".lock", "w") as lock:
+            fcntl.flock(lock, fcntl.LOCK_EX)
+            if not os.path.exists(path) or os.path.getmtime(src) > os.path.getmtime(path):
+                subprocess.run([os.path.join(d, "build_stub.sh"), "sync-only"], check=True)
+    return path

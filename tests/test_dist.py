@@ -1,5 +1,7 @@
-"""world_size = 2 gloo run of the sharded batch path on CPU (the per-rank solver is the SIMT-interpreted kernel library,
-test infrastructure only): ragged shards, one all-gather, every rank ends with the full batch."""
+"""world_size = 2 run of the sharded batch path on CPU (the per-rank solver is the SIMT-interpreted kernel library, test infrastructure
+only): ragged shards, ONE all-gather -- the engine's own (mcq_comm_allgather behind the C ABI, round 5: on tests/stub/librccl_stub_sync.so, a
+shared-memory stand-in for the five RCCL entry points the engine binds; gloo carries the 128-byte id, as on the GPU box) --, every rank
+ends with the full batch."""
 import os
 import socket
 
@@ -33,13 +35,31 @@ def _problems():
     return out
 
 
-def _worker(rank, world, port, lib, q):
+def _worker(rank, world, port, lib, stub, q):
     import torch.distributed as dist
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
+    os.environ["MCQ_RCCL_LIB"] = stub
     dist.init_process_group("gloo", rank=rank, world_size=world)
     from global_racetrajectory_optimization_amd import engine
     eng = engine.Engine(0, lib_path=lib)
+    with pytest.raises(ValueError, match="init_engine_comm"):
+        parallel.solve_sharded(_problems(), eng, dist=dist)          # more than one rank and no communicator: refused, not emulated
+    assert parallel.init_engine_comm(eng, dist) == (rank, world) and eng.comm_world() == (rank, world)
+    # the collective on its own: two gathers in flight on alternating buffers, waited for with lag 1 and lag 0 (what bench.py's steps do)
+    vals = [np.arange(5, dtype=np.float64) + 10.0 * rank + 100.0 * k for k in range(3)]
+    d_s = [eng.alloc(40) for _ in range(2)]
+    d_r = [eng.alloc(40 * world) for _ in range(2)]
+    for k in range(3):
+        if k >= 2:
+            eng.comm_wait(1)
+        eng.upload(d_s[k % 2], vals[k])
+        eng.comm_allgather(d_s[k % 2], d_r[k % 2], 5, eng.DT_F64)
+    eng.comm_wait(0)
+    got = eng.download(d_r[0], (world, 5), np.float64)
+    assert np.array_equal(got, np.stack([np.arange(5) + 10.0 * r + 200.0 for r in range(world)]))
+    for p_ in d_s + d_r:
+        eng.free(p_)
     a, c, s = parallel.solve_sharded(_problems(), eng, dist=dist)
     q.put((rank, [x.tolist() for x in a], c.tolist(), s.tolist()))
     dist.barrier()
@@ -47,7 +67,7 @@ def _worker(rank, world, port, lib, q):
 
 
 @pytest.mark.timeout(600)
-def test_two_rank_gloo_matches_single_process(emu_lib):
+def test_two_rank_gloo_matches_single_process(emu_lib, rccl_stub):
     import torch.multiprocessing as mp
     from global_racetrajectory_optimization_amd import engine
     eng = engine.Engine(0, lib_path=emu_lib)
@@ -61,7 +81,7 @@ def test_two_rank_gloo_matches_single_process(emu_lib):
         port = sk.getsockname()[1]
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
-    procs = [ctx.Process(target=_worker, args=(r, 2, port, emu_lib, q)) for r in range(2)]
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, emu_lib, rccl_stub, q)) for r in range(2)]
     for p in procs:
         p.start()
     res = [q.get(timeout=500) for _ in range(2)]

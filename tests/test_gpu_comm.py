@@ -1,0 +1,107 @@
+"""The engine's collective path with MORE THAN ONE RANK on the one GPU a test box has (until round 5 every ordering
+of that path -- the comm stream behind the compute stream, the event ring, mcq_comm_wait(h, 1) guarding two alternating send buffers -- had only
+ever run with world = 1, where no ordering bug can show).  Two processes share GPU 0; the fabric is tests/stub/librccl_stub.so, an ASYNCHRONOUS
+shared-memory stand-in for the five RCCL entry points the engine binds (stream-ordered copies and host functions; $MCQ_RCCL_LIB).  Real RCCL
+with more than one rank needs more than one GPU: that is the driver's SCALE run."""
+import json
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _stub():
+    d = os.path.join(ROOT, "tests", "stub")
+    path = os.path.join(d, "librccl_stub.so")
+    if not os.path.exists(path) or os.path.getmtime(os.path.join(d, "rccl_stub.cpp")) > os.path.getmtime(path):
+        subprocess.run([os.path.join(d, "build_stub.sh")], check=True)
+    assert os.path.exists(path), "tests/stub/build_stub.sh did not produce librccl_stub.so (hipcc?)"
+    return path
+
+
+def _env():
+    env = dict(os.environ)
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    env["MCQ_RCCL_LIB"] = _stub()
+    return env
+
+
+def test_bench_two_ranks_on_one_gpu_through_the_engines_collective():
+    """bench.py --gpus 2 as the driver's SCALE run starts it, both ranks on GPU 0 (the one-visible-device fallback): four timed steps behind a
+    warm-up step, the all-gather of step k on the comm stream while step k + 1 solves into the other buffer.  bench.py itself asserts that the
+    gathered tensor holds this rank's shard bitwise and that the communicator is (rank, world); here: one JSON line, both ranks seen, no failed
+    problem, a gather time measured by mcq_comm_wait."""
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "4", "--warmup", "1", "--batch", "64", "--no-extras"]
+    res = subprocess.run(cmd, env=_env(), capture_output=True, text=True, timeout=600, cwd=ROOT)
+    assert res.returncode == 0, res.stderr[-3000:]
+    lines = [l for l in res.stdout.splitlines() if l.strip().startswith("{")]
+    assert len(lines) == 1, res.stdout
+    rec = json.loads(lines[0])
+    assert rec["n_gpus"] == 2 and rec["config"]["ranks_seen"] == 2 and rec["config"]["failed_problems"] == 0
+    assert rec["config"]["collective"].startswith("1 all-gather of alpha per step: ncclAllGather (RCCL) through the C ABI")
+    assert rec["config"]["allgather_ms"] is not None and rec["config"]["allgather_ms"] > 0.0
+    print("two ranks on one GPU: %.0f solves/s aggregate, gather %.3f ms (shared-memory stand-in: not a fabric measurement)" % (
+        rec["value"], rec["config"]["allgather_ms"]))
+
+
+_WORKER = r'''
+import os, sys
+import numpy as np
+sys.path.insert(0, {root!r})
+import torch.distributed as dist
+from global_racetrajectory_optimization_amd import engine, parallel, synthetic
+rank, world = int(sys.argv[1]), 2
+os.environ["MASTER_ADDR"] = "127.0.0.1"; os.environ["MASTER_PORT"] = sys.argv[2]
+dist.init_process_group("gloo", rank=rank, world_size=world)
+eng = engine.Engine(0)
+assert parallel.init_engine_comm(eng, dist) == (rank, world)
+# alternating send buffers, lag-1 waits: six gathers of 4 MB, every one checked after the fact
+n = 1 << 19
+d_s = [eng.alloc(8 * n) for _ in range(2)]
+d_r = [eng.alloc(8 * n * world) for _ in range(6)]
+for k in range(6):
+    if k >= 2:
+        eng.comm_wait(1)                      # the gather that last read this send buffer
+    eng.upload(d_s[k % 2], np.full(n, 1000.0 * k + rank))
+    eng.comm_allgather(d_s[k % 2], d_r[k], n, eng.DT_F64)
+eng.comm_wait(0)
+for k in range(6):
+    got = eng.download(d_r[k], (world, n), np.float64)
+    assert np.all(got[0] == 1000.0 * k) and np.all(got[1] == 1000.0 * k + 1), (rank, k, got[:, :2])
+# the sharded solve: 5 ragged problems over 2 ranks, every rank ends with the full batch
+probs = [dict(reftrack=synthetic.oval_batch(1, n=400 - 7 * k, first=40 + k, perturb_centreline=True)[0][0], normvec=None, scaling=None,
+              kappa_bound=0.5, w_veh=2.0 + 0.2 * k) for k in range(5)]
+a, c, s = parallel.solve_sharded(probs, eng, dist=dist)
+np.savez(sys.argv[3], status=s, curv=c, **{{"a%d" % k: a[k] for k in range(5)}})
+dist.barrier()
+eng.close()
+'''
+
+
+def test_two_ranks_sharded_solve_and_lagged_gathers(gpu_engine, tmp_path):
+    import socket
+    from global_racetrajectory_optimization_amd import synthetic
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    script = tmp_path / "worker.py"
+    script.write_text(_WORKER.format(root=ROOT))
+    outs = [str(tmp_path / ("out%d.npz" % r)) for r in range(2)]
+    procs = [subprocess.Popen([sys.executable, str(script), str(r), str(port), outs[r]], env=_env(), stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
+             for r in range(2)]
+    logs = [p.communicate(timeout=600)[0] for p in procs]
+    assert all(p.returncode == 0 for p in procs), "\n".join(l[-2000:] for l in logs)
+    probs = [dict(reftrack=synthetic.oval_batch(1, n=400 - 7 * k, first=40 + k, perturb_centreline=True)[0][0], normvec=None, scaling=None,
+                  kappa_bound=0.5, w_veh=2.0 + 0.2 * k) for k in range(5)]
+    a1, c1, s1, _ = gpu_engine.solve_batch(probs)
+    for r in range(2):
+        z = np.load(outs[r])
+        assert list(z["status"]) == list(s1) == [0] * 5 and np.array_equal(z["curv"], c1)
+        for k in range(5):
+            assert np.array_equal(z["a%d" % k], a1[k]), (r, k)
