@@ -10,6 +10,7 @@
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
+#include <time.h>
 
 #include <algorithm>
 #include <string>
@@ -72,10 +73,19 @@ struct mcq_handle {
     unsigned comm_seq = 0;              // gathers enqueued so far (event ring index)
     size_t vel_scratch_bytes = 0;
     double* kbig = nullptr;             // overflow slots of the curvature-row working set (MCQ_KBIG_SLOTS x MCQ_KBIG_SLOT doubles)
-    int* kbig_count = nullptr;          // [2]: slots claimed by the launch in flight; next chunk of the Goldfarb-Idnani kernel's scan
+    int* slot_flags = nullptr;          // [MCQ_KBIG_SLOTS + 64]: 0 free / 1 taken, claimed and released by the workgroups (never reset by the host)
     double* gi = nullptr;               // slots of the Goldfarb-Idnani path (mcq_gi.inc): gi_slots x MCQ_GI_SLOT_DOUBLES(gi_nmax, gi_nmax)
     int gi_slots = 0, gi_nmax = 0;
     long long gi_bytes = 0;
+    // mcq_solve_host_pipelined: a SECOND compute stream with a workspace of its own -- the kernels of consecutive steps run on alternating
+    // streams, so the tail of one launch (its slowest problems, on CUs the others have left) overlaps the start of the next (round 5)
+    hipStream_t stream2 = nullptr;
+    double *L2 = nullptr, *vec2 = nullptr, *Z2 = nullptr, *kbig2 = nullptr, *gi2 = nullptr;
+    signed char* state_alt = nullptr;
+    int* slot_flags2 = nullptr;
+    size_t alt_elems = 0, alt_batch = 0;
+    int gi2_slots = 0, gi2_nmax = 0;
+    long long alt_bytes = 0;
     double* d_org = nullptr;            // per-track origins of the fp32 row entries, [batch][2]
     double* d_trace = nullptr;          // curvature-error trace of mcq_iqp_batch, [batch][MCQ_IQP_TRACE] (grown with d_iqp)
     // mcq_solve_host_pipelined: two copy streams, the second set of staging buffers, one event triple per slot
@@ -148,14 +158,26 @@ static void free_ws(mcq_handle* h)
 {
     (void)hipFree(h->L); (void)hipFree(h->vec); (void)hipFree(h->Z); (void)hipFree(h->state);
     (void)hipFree(h->state2);
-    (void)hipFree(h->kbig); (void)hipFree(h->kbig_count); (void)hipFree(h->gi);
-    h->kbig = nullptr; h->kbig_count = nullptr; h->gi = nullptr;
+    (void)hipFree(h->kbig); (void)hipFree(h->slot_flags); (void)hipFree(h->gi);
+    h->kbig = nullptr; h->slot_flags = nullptr; h->gi = nullptr;
     h->gi_slots = h->gi_nmax = 0;
     h->gi_bytes = 0;
     h->L = h->vec = h->Z = nullptr;
     h->state = h->state2 = nullptr;
     h->state2_valid = false;
     h->cap_elems = h->cap_batch = 0;
+}
+
+static void free_alt(mcq_handle* h)
+{
+    (void)hipFree(h->L2); (void)hipFree(h->vec2); (void)hipFree(h->Z2); (void)hipFree(h->state_alt); (void)hipFree(h->kbig2);
+    (void)hipFree(h->slot_flags2); (void)hipFree(h->gi2);
+    h->L2 = h->vec2 = h->Z2 = h->kbig2 = h->gi2 = nullptr;
+    h->state_alt = nullptr;
+    h->slot_flags2 = nullptr;
+    h->alt_elems = h->alt_batch = 0;
+    h->gi2_slots = h->gi2_nmax = 0;
+    h->alt_bytes = 0;
 }
 
 static void free_stage(mcq_handle* h)
@@ -190,9 +212,12 @@ extern "C" void mcq_destroy(mcq_handle* h)
     if (h->cs_in) (void)hipStreamSynchronize(h->cs_in);
     if (h->cs_out) (void)hipStreamSynchronize(h->cs_out);
     (void)mcq_comm_destroy(h);
+    if (h->stream2) (void)hipStreamSynchronize(h->stream2);
     free_ws(h);
+    free_alt(h);
     free_stage(h);
     free_pipe(h);
+    if (h->stream2) (void)hipStreamDestroy(h->stream2);
     for (int k = 0; k < 2; ++k) {
         if (h->ev_up[k]) (void)hipEventDestroy(h->ev_up[k]);
         if (h->ev_done[k]) (void)hipEventDestroy(h->ev_done[k]);
@@ -217,7 +242,7 @@ static int ensure_gi(mcq_handle* h, size_t batch, size_t nmax)
     h->gi = nullptr;
     h->gi_slots = h->gi_nmax = 0;
     int slots = MCQ_GI_SLOTS;
-    if (const char* e = getenv("MCQ_GI_SLOTS")) slots = std::max(1, atoi(e));
+    if (const char* e = getenv("MCQ_GI_SLOTS")) slots = std::min(64, std::max(1, atoi(e)));
     const size_t per = MCQ_GI_SLOT_DOUBLES(nmax, nmax) * sizeof(double);
     while (slots > 1 && (size_t)slots * per > ((size_t)4 << 30)) --slots;
     slots = (int)std::min<size_t>((size_t)slots, std::max<size_t>(batch, 1));
@@ -241,7 +266,8 @@ static int ensure_ws(mcq_handle* h, size_t batch, size_t nmax)
     HIP_TRY(hipMalloc((void**)&h->state, elems));
     HIP_TRY(hipMalloc((void**)&h->state2, elems));
     HIP_TRY(hipMalloc((void**)&h->kbig, (size_t)MCQ_KBIG_SLOTS * MCQ_KBIG_SLOT * sizeof(double)));
-    HIP_TRY(hipMalloc((void**)&h->kbig_count, 2 * sizeof(int)));
+    HIP_TRY(hipMalloc((void**)&h->slot_flags, (MCQ_KBIG_SLOTS + 64) * sizeof(int)));
+    HIP_TRY(hipMemsetAsync(h->slot_flags, 0, (MCQ_KBIG_SLOTS + 64) * sizeof(int), h->stream));
     h->gi_slots = h->gi_nmax = 0;
     if (int rc = ensure_gi(h, batch, nmax)) return rc;
     if (h->poison) HIP_TRY(hipMemsetAsync(h->kbig, 0xff, (size_t)MCQ_KBIG_SLOTS * MCQ_KBIG_SLOT * sizeof(double), h->stream));
@@ -257,6 +283,41 @@ static int ensure_ws(mcq_handle* h, size_t batch, size_t nmax)
     h->ws_bytes = (long long)(elems * ((MCQ_LLD + MCQ_NVEC + 1) * sizeof(double) + 2) +
                               batch * (size_t)MCQ_KMAX * MCQ_KMAX * sizeof(double) +
                               (size_t)MCQ_KBIG_SLOTS * MCQ_KBIG_SLOT * sizeof(double));
+    return 0;
+}
+
+// the second workspace of the pipelined host entry (same slabs as ensure_ws, half the Goldfarb-Idnani slots)
+static int ensure_alt(mcq_handle* h, size_t batch, size_t nmax)
+{
+    if (!h->stream2) HIP_TRY(hipStreamCreate(&h->stream2));
+    const size_t elems = batch * nmax;
+    if (elems <= h->alt_elems && batch <= h->alt_batch && (size_t)h->gi2_nmax >= nmax) return 0;
+    HIP_TRY(hipStreamSynchronize(h->stream2));
+    free_alt(h);
+    HIP_TRY(hipMalloc((void**)&h->L2, elems * MCQ_LLD * sizeof(double)));
+    HIP_TRY(hipMalloc((void**)&h->vec2, elems * MCQ_NVEC * sizeof(double)));
+    HIP_TRY(hipMalloc((void**)&h->Z2, (elems + batch * (size_t)MCQ_KMAX * MCQ_KMAX) * sizeof(double)));
+    HIP_TRY(hipMalloc((void**)&h->state_alt, elems));
+    HIP_TRY(hipMalloc((void**)&h->kbig2, (size_t)MCQ_KBIG_SLOTS * MCQ_KBIG_SLOT * sizeof(double)));
+    HIP_TRY(hipMalloc((void**)&h->slot_flags2, (MCQ_KBIG_SLOTS + 64) * sizeof(int)));
+    HIP_TRY(hipMemsetAsync(h->slot_flags2, 0, (MCQ_KBIG_SLOTS + 64) * sizeof(int), h->stream2));
+    const size_t per = MCQ_GI_SLOT_DOUBLES(nmax, nmax) * sizeof(double);
+    int slots = std::max(1, h->gi_slots / 2);
+    HIP_TRY(hipMalloc((void**)&h->gi2, (size_t)slots * per));
+    HIP_TRY(hipMemsetAsync(h->state_alt, 0, elems, h->stream2));
+    if (h->poison) {
+        HIP_TRY(hipMemsetAsync(h->L2, 0xff, elems * MCQ_LLD * sizeof(double), h->stream2));
+        HIP_TRY(hipMemsetAsync(h->vec2, 0xff, elems * MCQ_NVEC * sizeof(double), h->stream2));
+        HIP_TRY(hipMemsetAsync(h->Z2, 0xff, (elems + batch * (size_t)MCQ_KMAX * MCQ_KMAX) * sizeof(double), h->stream2));
+        HIP_TRY(hipMemsetAsync(h->kbig2, 0xff, (size_t)MCQ_KBIG_SLOTS * MCQ_KBIG_SLOT * sizeof(double), h->stream2));
+        HIP_TRY(hipMemsetAsync(h->gi2, 0xff, (size_t)slots * per, h->stream2));
+    }
+    h->alt_elems = elems;
+    h->alt_batch = batch;
+    h->gi2_slots = slots;
+    h->gi2_nmax = (int)nmax;
+    h->alt_bytes = (long long)(elems * ((MCQ_LLD + MCQ_NVEC + 1) * sizeof(double) + 1) + batch * (size_t)MCQ_KMAX * MCQ_KMAX * sizeof(double) +
+                               (size_t)MCQ_KBIG_SLOTS * MCQ_KBIG_SLOT * sizeof(double) + (size_t)slots * per);
     return 0;
 }
 
@@ -288,64 +349,60 @@ static int ensure_stage(mcq_handle* h, size_t batch, size_t nmax)
     return 0;
 }
 
-static int launch(mcq_handle* h, McqBatch& B, const mcq_opts& o)
+// alt: on the handle's second compute stream and workspace (ensure_alt; mcq_solve_host_pipelined's odd steps) -- no event timing there
+static int launch(mcq_handle* h, McqBatch& B, const mcq_opts& o, bool alt = false)
 {
-    B.L = h->L; B.vec = h->vec; B.Z = h->Z; B.state = h->state;
+    hipStream_t st = alt ? h->stream2 : h->stream;
+    B.L = alt ? h->L2 : h->L; B.vec = alt ? h->vec2 : h->vec; B.Z = alt ? h->Z2 : h->Z; B.state = alt ? h->state_alt : h->state;
     B.max_ipm_iter = o.max_ipm_iter;
     B.max_as_iter = o.max_as_iter;
     B.refine_steps = o.refine_steps;
     B.check_kappa = o.check_kappa;
     B.objective = o.objective;
     B.poison_lds = h->poison ? 1 : 0;
-    B.kbig = h->kbig;
-    B.kbig_count = h->kbig_count;
+    B.kbig = alt ? h->kbig2 : h->kbig;
+    B.slot_flags = alt ? h->slot_flags2 : h->slot_flags;      // (zero between launches: the workgroups release what they claim)
     B.kbig_slots = MCQ_KBIG_SLOTS;
     B.algorithm = o.algorithm;
     // the Goldfarb-Idnani slots hold working sets of up to gi_nmax constraints on rings of up to gi_nmax waypoints (slot stride: B.nmax)
-    const bool gi_on = h->gi && B.nmax <= h->gi_nmax && o.objective == MCQ_OBJ_MIN_CURV && !B.prep_only;
-    B.gi = gi_on ? h->gi : nullptr;
-    B.gi_slots = gi_on ? h->gi_slots : 0;
+    double* gi_mem = alt ? h->gi2 : h->gi;
+    const bool gi_on = gi_mem && B.nmax <= (alt ? h->gi2_nmax : h->gi_nmax) && o.objective == MCQ_OBJ_MIN_CURV && !B.prep_only;
+    B.gi = gi_on ? gi_mem : nullptr;
+    B.gi_slots = gi_on ? (alt ? h->gi2_slots : h->gi_slots) : 0;
     B.gi_qcap = B.nmax;
-    B.gi_next = h->kbig_count + 1;
-    if (!B.prep_only) HIP_TRY(hipMemsetAsync(h->kbig_count, 0, 2 * sizeof(int), h->stream));
     // warm start: only the working sets mcq_relinearise_device carried over for exactly this batch layout
-    B.warm = (o.warm_start > 0 && h->state2_valid && !B.prep_only && h->state2_batch == B.batch && h->state2_nmax == B.nmax)
+    B.warm = (!alt && o.warm_start > 0 && h->state2_valid && !B.prep_only && h->state2_batch == B.batch && h->state2_nmax == B.nmax)
                  ? h->state2 : nullptr;
-    if (!B.prep_only) h->state2_valid = false;
+    if (!B.prep_only && !alt) h->state2_valid = false;
     if (B.objective == MCQ_OBJ_SHORTEST_PATH && !B.prep_only) {
         if (!B.nv) { g_err = "shortest-path objective: normvec is required"; return MCQ_E_ARG; }
         B.check_kappa = 0;
-        HIP_TRY(hipEventRecord(h->ev[0], h->stream));
-        hipLaunchKernelGGL(mcq_assemble_sp_kernel, dim3(B.batch), dim3(256), 0, h->stream, B);
+        if (!alt) HIP_TRY(hipEventRecord(h->ev[0], st));
+        hipLaunchKernelGGL(mcq_assemble_sp_kernel, dim3(B.batch), dim3(256), 0, st, B);
         HIP_TRY(hipGetLastError());
-        HIP_TRY(hipEventRecord(h->ev[1], h->stream));
-        HIP_TRY(hipEventRecord(h->ev[2], h->stream));
-        hipLaunchKernelGGL(mcq_solve_kernel, dim3(B.batch), dim3(256), 0, h->stream, B);
+        if (!alt) HIP_TRY(hipEventRecord(h->ev[1], st));
+        if (!alt) HIP_TRY(hipEventRecord(h->ev[2], st));
+        hipLaunchKernelGGL(mcq_solve_kernel, dim3(B.batch), dim3(256), 0, st, B);
         HIP_TRY(hipGetLastError());
-        HIP_TRY(hipEventRecord(h->ev[3], h->stream));
-        HIP_TRY(hipEventRecord(h->ev[4], h->stream));
-        h->timing_valid = true;
+        if (!alt) HIP_TRY(hipEventRecord(h->ev[3], st));
+        if (!alt) HIP_TRY(hipEventRecord(h->ev[4], st));
+        if (!alt) h->timing_valid = true;
         return 0;
     }
-    HIP_TRY(hipEventRecord(h->ev[0], h->stream));
+    if (!alt) HIP_TRY(hipEventRecord(h->ev[0], st));
     if (B.prep_only) {
-        hipLaunchKernelGGL(mcq_assemble_kernel, dim3(B.batch), dim3(256), 0, h->stream, B);
+        hipLaunchKernelGGL(mcq_assemble_kernel, dim3(B.batch), dim3(256), 0, st, B);
         HIP_TRY(hipGetLastError());
         return 0;
     }
     // (no assembly launch: the solver kernel assembles its problem itself -- assemble_problem() -- since round 4)
-    HIP_TRY(hipEventRecord(h->ev[1], h->stream));
-    HIP_TRY(hipEventRecord(h->ev[2], h->stream));
-    hipLaunchKernelGGL(mcq_solve_kernel, dim3(B.batch), dim3(256), 0, h->stream, B);
+    if (!alt) HIP_TRY(hipEventRecord(h->ev[1], st));
+    if (!alt) HIP_TRY(hipEventRecord(h->ev[2], st));
+    hipLaunchKernelGGL(mcq_solve_kernel, dim3(B.batch), dim3(256), 0, st, B);
     HIP_TRY(hipGetLastError());
-    HIP_TRY(hipEventRecord(h->ev[3], h->stream));
-    // the Goldfarb-Idnani path for whatever the solver kernel did not settle (a scan of the statuses when there is nothing to do)
-    if (B.gi_slots > 0) {
-        hipLaunchKernelGGL(mcq_gi_kernel, dim3(std::min(B.gi_slots, (B.batch + MCQ_GI_CHUNK - 1) / MCQ_GI_CHUNK)), dim3(256), 0, h->stream, B);
-        HIP_TRY(hipGetLastError());
-    }
-    HIP_TRY(hipEventRecord(h->ev[4], h->stream));
-    h->timing_valid = true;
+    if (!alt) HIP_TRY(hipEventRecord(h->ev[3], st));
+    if (!alt) HIP_TRY(hipEventRecord(h->ev[4], st));
+    if (!alt) h->timing_valid = true;
     return 0;
 }
 
@@ -767,6 +824,7 @@ extern "C" int mcq_sync(mcq_handle* h)
     HIP_TRY(hipSetDevice(h->device));
     HIP_TRY(hipStreamSynchronize(h->stream));
     if (h->comm_stream) HIP_TRY(hipStreamSynchronize(h->comm_stream));      // gathers in flight (mcq_comm_allgather) are work of the handle too
+    if (h->stream2) HIP_TRY(hipStreamSynchronize(h->stream2));
     return 0;
 }
 
@@ -785,7 +843,7 @@ extern "C" int mcq_last_timing(mcq_handle* h, float ms[5])
     return 0;
 }
 
-extern "C" long long mcq_workspace_bytes(mcq_handle* h) { return h ? h->ws_bytes + h->gi_bytes : 0; }
+extern "C" long long mcq_workspace_bytes(mcq_handle* h) { return h ? h->ws_bytes + h->gi_bytes + h->alt_bytes : 0; }
 
 static int ensure_pin(mcq_handle* h, size_t bytes)
 {
@@ -949,6 +1007,7 @@ static int ensure_pipe(mcq_handle* h, size_t batch, size_t nmax)
             g_err = buf_;                                                                                 \
             (void)hipStreamSynchronize(h->cs_in);                                                         \
             (void)hipStreamSynchronize(h->stream);                                                        \
+            if (h->stream2) (void)hipStreamSynchronize(h->stream2);                                       \
             (void)hipStreamSynchronize(h->cs_out);                                                        \
             return MCQ_E_DEVICE;                                                                          \
         }                                                                                                 \
@@ -974,6 +1033,15 @@ extern "C" int mcq_solve_host_pipelined(mcq_handle* h, int steps, int batch, int
     if (rc) return rc;
     rc = ensure_pipe(h, (size_t)batch, (size_t)n);
     if (rc) return rc;
+    // curv_error / status of every step land in PINNED memory of the handle and reach the caller's arrays at the end: a device-to-host copy into
+    // pageable memory -- what these two small arrays usually are -- blocks the host until the step's kernels have finished, i.e. the host could
+    // not enqueue step k + 1 before step k was over (round 5: this was the 0.5 ms per step that rounds 3-4 reported as "not hidden")
+    rc = ensure_pin(h, (size_t)steps * batch * (sizeof(double) + sizeof(int)));
+    if (rc) return rc;
+    double* pin_cu = (double*)h->pin;
+    int* pin_st = (int*)(pin_cu + (size_t)steps * batch);
+    const bool two = steps > 1 && !getenv("MCQ_PIPE_ONE_STREAM");      // kernels of odd steps on the second compute stream / workspace (the variable: A/B knob)
+    if (two) { rc = ensure_alt(h, (size_t)batch, (size_t)n); if (rc) return rc; }
     HIP_TRY(hipStreamSynchronize(h->stream));          // whatever ran before on the handle's stream is done with the staging buffers
     const size_t elems = (size_t)batch * n;
     double* s_ref[2] = {h->d_ref, h->p_ref};
@@ -1000,13 +1068,19 @@ extern "C" int mcq_solve_host_pipelined(mcq_handle* h, int steps, int batch, int
     };
     rc = upload(0);
     if (rc) return rc;
+    const bool trace = getenv("MCQ_PIPE_TRACE") != nullptr;
+    struct timespec ts0;
+    clock_gettime(CLOCK_MONOTONIC, &ts0);
     for (int k = 0; k < steps; ++k) {
         const int s = k & 1;
+        if (trace) { struct timespec t1; clock_gettime(CLOCK_MONOTONIC, &t1); fprintf(stderr, "pipe: step %d enqueued from %.3f ms\n", k, (t1.tv_sec - ts0.tv_sec) * 1e3 + (t1.tv_nsec - ts0.tv_nsec) * 1e-6); }
         const double* nv_k = normvec ? normvec[k] : nullptr;
         const double* sc_k = scaling ? scaling[k] : nullptr;
         // kernels of step k: after its upload, and after the download of step k - 2 has left the slot's result buffers
-        HIP_TRY_PIPE(hipStreamWaitEvent(h->stream, h->ev_up[s], 0));
-        if (k >= 2) HIP_TRY_PIPE(hipStreamWaitEvent(h->stream, h->ev_down[s], 0));
+        // (slot s's kernels always run on compute stream s: step k - 2, the last user of this slot's workspace and buffers, precedes in stream order)
+        hipStream_t cst = (two && s) ? h->stream2 : h->stream;
+        HIP_TRY_PIPE(hipStreamWaitEvent(cst, h->ev_up[s], 0));
+        if (k >= 2) HIP_TRY_PIPE(hipStreamWaitEvent(cst, h->ev_down[s], 0));
         McqBatch B;
         memset(&B, 0, sizeof(B));
         B.batch = batch;
@@ -1020,20 +1094,25 @@ extern "C" int mcq_solve_host_pipelined(mcq_handle* h, int steps, int batch, int
         B.status = s_st[s];
         B.kappa_bound = kappa_bound;
         B.w_veh = w_veh;
-        rc = launch(h, B, o);
-        if (rc) { (void)hipStreamSynchronize(h->cs_in); (void)hipStreamSynchronize(h->stream); (void)hipStreamSynchronize(h->cs_out); return rc; }
-        HIP_TRY_PIPE(hipEventRecord(h->ev_done[s], h->stream));
+        rc = launch(h, B, o, two && s);
+        if (rc) { (void)hipStreamSynchronize(h->cs_in); (void)hipStreamSynchronize(h->stream); if (h->stream2) (void)hipStreamSynchronize(h->stream2); (void)hipStreamSynchronize(h->cs_out); return rc; }
+        HIP_TRY_PIPE(hipEventRecord(h->ev_done[s], cst));
         if (k + 1 < steps) { rc = upload(k + 1); if (rc) return rc; }
         // download of step k
         HIP_TRY_PIPE(hipStreamWaitEvent(h->cs_out, h->ev_done[s], 0));
         HIP_TRY_PIPE(hipMemcpyAsync(alpha_out[k], s_al[s], elems * sizeof(double), hipMemcpyDeviceToHost, h->cs_out));
-        HIP_TRY_PIPE(hipMemcpyAsync(curv_err_out[k], s_cu[s], batch * sizeof(double), hipMemcpyDeviceToHost, h->cs_out));
-        HIP_TRY_PIPE(hipMemcpyAsync(status_out[k], s_st[s], batch * sizeof(int), hipMemcpyDeviceToHost, h->cs_out));
+        HIP_TRY_PIPE(hipMemcpyAsync(pin_cu + (size_t)k * batch, s_cu[s], batch * sizeof(double), hipMemcpyDeviceToHost, h->cs_out));
+        HIP_TRY_PIPE(hipMemcpyAsync(pin_st + (size_t)k * batch, s_st[s], batch * sizeof(int), hipMemcpyDeviceToHost, h->cs_out));
         HIP_TRY_PIPE(hipEventRecord(h->ev_down[s], h->cs_out));
     }
     HIP_TRY_PIPE(hipStreamSynchronize(h->cs_in));
     HIP_TRY_PIPE(hipStreamSynchronize(h->stream));
+    if (two) HIP_TRY_PIPE(hipStreamSynchronize(h->stream2));
     HIP_TRY_PIPE(hipStreamSynchronize(h->cs_out));
+    for (int k = 0; k < steps; ++k) {
+        memcpy(curv_err_out[k], pin_cu + (size_t)k * batch, batch * sizeof(double));
+        memcpy(status_out[k], pin_st + (size_t)k * batch, batch * sizeof(int));
+    }
     return 0;
 }
 

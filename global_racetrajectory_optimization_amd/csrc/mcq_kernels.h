@@ -96,24 +96,23 @@ struct McqBatch {
     const signed char* warm; // [batch][nmax] working set to start the exchange from (IQP passes 2+), or nullptr (cold: interior point)
     int poison_lds;         // MCQ_POISON=1 (debugging aid): the solver kernel starts from an LDS full of NaNs, like the workspaces
     double* kbig;           // overflow slots of the curvature-row working set (MCQ_KBIG_SLOT doubles each), kbig_slots of them;
-    int* kbig_count;        // slots claimed in this launch (zeroed by the host before it)
+    int* slot_flags;        // [kbig_slots + gi_slots] 0 = free, 1 = taken: a workgroup claims a slot by compare-and-swap and releases it when it is
+                            // done (zero whenever no launch is in flight: nothing for the host to reset between launches)
     int kbig_slots;
     int objective;          // MCQ_OBJ_*: shortest path = H (a cyclic tridiagonal: two vectors) and f written directly by
                             // mcq_assemble_sp_kernel, the gradient is H x + f; no curvature rows, no curvature-error post-check
-    int algorithm;          // MCQ_ALG_GI: the solver kernel stops after its prologue and leaves every problem to mcq_gi_kernel
-    double* gi;             // slots of the Goldfarb-Idnani path (mcq_gi.inc), MCQ_GI_SLOT_DOUBLES(nmax, gi_qcap) doubles each: one per workgroup
-    int gi_slots, gi_qcap;  // of mcq_gi_kernel; gi_qcap = constraints a working set can hold (= nmax: no more can be independent)
-    int* gi_next;           // [1] next chunk of the batch to scan (zeroed by the host before the launch)
+    int algorithm;          // MCQ_ALG_GI: interior point and block pivoting are skipped, every problem goes through the Goldfarb-Idnani path
+    double* gi;             // slots of the Goldfarb-Idnani path (mcq_gi.inc), MCQ_GI_SLOT_DOUBLES(nmax, gi_qcap) doubles each: a workgroup whose
+    int gi_slots, gi_qcap;  // problem needs the path claims one (and waits for one if all are taken); gi_qcap = constraints a working set can
+                            // hold (= nmax: no more can be independent)
 };
 
 __global__ void mcq_assemble_kernel(McqBatch B);
 __global__ void mcq_assemble_sp_kernel(McqBatch B);
 __global__ void mcq_solve_kernel(McqBatch B);      // saddle-point elimination (mcq_kkt.inc) / scalar cyclic tridiagonal (shortest path, mcq_tri.inc); two workgroups per CU
-/* Goldfarb-Idnani dual active-set path (mcq_gi.inc): grid = B.gi_slots persistent workgroups that scan the statuses the solver kernel left and
- * solve again, from scratch and by quadprog's algorithm, whatever it did not settle (iteration cap, working set beyond its arrays, ...) */
-__global__ void mcq_gi_kernel(McqBatch B);
+/* Goldfarb-Idnani dual active-set path (mcq_gi.inc): inside mcq_solve_kernel, for whatever its interior point + block pivoting did not
+ * settle (iteration cap, working set beyond its arrays, ...) -- solved again from scratch by quadprog's algorithm, in an HBM slot of the handle */
 #define MCQ_GI_SLOTS 8
-#define MCQ_GI_CHUNK 16            /* problems per claim of the scan */
 #define MCQ_GI_SLOT_DOUBLES(nm, qcap) ((size_t)(qcap) * (size_t)(nm) + (size_t)(qcap) * (size_t)(qcap) + 9 * (size_t)(qcap) + 8)
 
 /* tph.check_normals_crossing [REF helper_funcs_glob/src/prep_track.py:57-59], one workgroup per track: crossing_out [batch] =

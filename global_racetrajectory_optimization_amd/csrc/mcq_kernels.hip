@@ -1467,6 +1467,34 @@ __device__ __noinline__ int active_set(const LCtx& c, bool with_kappa, bool tapi
     return MCQ_ITER_CAP;
 }
 
+// ---- slots of the handle (overflow slots of the curvature-row working set, slots of the Goldfarb-Idnani path): flags[s] 0 = free, 1 = taken.
+//      Claimed by compare-and-swap, released by the holder: zero whenever no launch is in flight.  wait: spin until one is free -- the holders
+//      are resident workgroups that wait for nobody, so they finish.  Uniform over the block; returns the slot or -1. ----
+__device__ int claim_slot(int* flags, int nslots, bool wait)
+{
+    int* sh = (int*)(g_sm + SM_RED);
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        int got = -1;
+        for (;;) {
+            for (int s = 0; s < nslots && got < 0; ++s)
+                if (atomicCAS(flags + s, 0, 1) == 0) got = s;
+            if (got >= 0 || !wait) break;
+            __builtin_amdgcn_s_sleep(127);
+        }
+        sh[0] = got;
+    }
+    __syncthreads();
+    const int slot = sh[0];
+    __syncthreads();
+    return slot;
+}
+__device__ void release_slot(int* flags, int slot)
+{
+    __syncthreads();
+    if (threadIdx.x == 0) { __threadfence(); atomicExch(flags + slot, 0); }
+}
+
 // ---- scalars of a problem: the scales of the tolerances, the working set and the iterate at the box centre, the gradient there ----
 #ifdef MCQ_OUTLINE_PROLOGUE     /* A/B switch: as calls they cost the solver kernel 64 bytes of scratch per lane and ~0.5 % (round 5) */
 #define MCQ_FN_PROLOGUE __device__ __noinline__
@@ -1587,6 +1615,8 @@ MCQ_FN_PROLOGUE void write_outputs(const LCtx& c, const McqOutcome& r)
     }
 }
 
+#include "mcq_gi.inc"
+
 __global__ void __launch_bounds__(MCQ_NT, 2) mcq_solve_kernel(McqBatch B)
 {
     const int tid = threadIdx.x;
@@ -1626,11 +1656,8 @@ __global__ void __launch_bounds__(MCQ_NT, 2) mcq_solve_kernel(McqBatch B)
         __syncthreads();
     }
     problem_scales(c);
-    if (B.algorithm == MCQ_ALG_GI && !c.direct) {
-        // every problem through the Goldfarb-Idnani path (mcq_gi_kernel, launched behind this kernel): leave it there
-        if (tid == 0) *c.w.status = MCQ_ITER_CAP;
-        return;
-    }
+    // mcq_opts.algorithm = MCQ_ALG_GI: every problem through the Goldfarb-Idnani path at the end of this kernel, nothing else
+    const bool gi_only = B.algorithm == MCQ_ALG_GI && !c.direct && B.gi != nullptr;
 
     // ---- phase 1: box-constrained QP ---------------------------------------------------------------------------------------
     int ipm_iters = 0, as_iters = 0, nact_kappa = 0;
@@ -1641,7 +1668,7 @@ __global__ void __launch_bounds__(MCQ_NT, 2) mcq_solve_kernel(McqBatch B)
     //      factorisation + one solve) -- a third to two thirds of what interior point + exchange cost.  The vertex returned is an
     //      exact KKT point either way; if the exchange runs out of its rounds the cold path below takes over. ----
     bool warm_done = false;
-    if (B.warm && small) {
+    if (B.warm && small && !gi_only) {
         const gschar* WS = (const gschar*)(B.warm + (size_t)blockIdx.x * nm);
         for (int i = tid; i < n; i += MCQ_NT)
             if (ST[i] == 0) { const signed char s = WS[i]; ST[i] = (s == 1 || s == -1) ? s : (signed char)0; }
@@ -1664,7 +1691,8 @@ __global__ void __launch_bounds__(MCQ_NT, 2) mcq_solve_kernel(McqBatch B)
     const int as_warm = warm_done ? 0 : as_iters;
     int status = MCQ_OK;
     const long long t_ipm0 = TICK();
-    if (!warm_done) {
+    if (gi_only) status = MCQ_ITER_CAP;
+    else if (!warm_done) {
         status = small ? ipm_box(c, MCQ_IPM_TOL, false) : ipm(c, false);
         ipm_iters = c.out_iters;
     }
@@ -1736,18 +1764,15 @@ __global__ void __launch_bounds__(MCQ_NT, 2) mcq_solve_kernel(McqBatch B)
                 // [REF params/racecar.ini:49 curvlim].  The problem claims one of the handle's overflow slots -- MCQ_KBIG rows, the
                 // Schur matrix and its elimination in HBM -- and the exchange goes on from the box working set the first
                 // attempt left (its curvature flags are rebuilt from the interior point's pairs).  No
-                // slot free (more than kbig_slots such problems in one launch): the status stays MCQ_KAPPA_ACTIVE.
-                int* sslot = (int*)(g_sm + SM_RED);
-                if (tid == 0) sslot[0] = atomicAdd(B.kbig_count, 1);
-                __syncthreads();
-                const int slot = sslot[0];
-                __syncthreads();
-                if (slot < B.kbig_slots) {
+                // slot free (more than kbig_slots such problems at this moment): MCQ_KAPPA_NO_SLOT, taken up below.
+                const int slot = claim_slot(B.slot_flags, B.kbig_slots, false);
+                if (slot >= 0) {
                     status = active_set(c, true, false, B.max_as_iter, 0, kappa_mem_slot(B.kbig + (size_t)slot * MCQ_KBIG_SLOT));
                     as_iters += c.out_iters;
                     kkt = c.out_kkt;
                     nact_kappa = c.out_nk;
-                } else status = MCQ_KAPPA_NO_SLOT;        // not a verdict on the problem: the host entries re-launch it (mcq_api.hip)
+                    release_slot(B.slot_flags, slot);
+                } else status = MCQ_KAPPA_NO_SLOT;        // not a verdict on the problem: the Goldfarb-Idnani path below takes it
             }
         }
         for (int i = tid; i < n; i += MCQ_NT) X[i] = fmin(fmax(X[i], LO[i]), HI[i]);
@@ -1761,14 +1786,18 @@ __global__ void __launch_bounds__(MCQ_NT, 2) mcq_solve_kernel(McqBatch B)
         status = MCQ_KAPPA_ACTIVE;      // curvature rows switched off by the caller: the violated row is reported, not enforced
     }
 
+    // ---- the Goldfarb-Idnani path for whatever the phases above did not settle (mcq_gi.inc): quadprog's algorithm, finite by construction ----
+    int gi_iters = 0;
+    if (!c.direct && B.gi && gi_eligible(status, B.check_kappa)) {
+        status = gi_rescue(c, B.gi, B.gi_slots, B.gi_qcap, B.slot_flags + B.kbig_slots, B.check_kappa != 0, status, as_iters, nact_kappa, kkt, km, gi_iters);
+        dd_valid = true;
+    }
     McqOutcome r;
-    r.status = status; r.ipm_iters = ipm_iters; r.as_iters = as_iters; r.nact_kappa = nact_kappa; r.gi_iters = 0;
+    r.status = status; r.ipm_iters = ipm_iters; r.as_iters = as_iters; r.nact_kappa = nact_kappa; r.gi_iters = gi_iters;
     r.kkt = kkt; r.km = km; r.dd_valid = dd_valid;
     r.t_kernel0 = t_kernel0; r.c_kernel0 = c_kernel0; r.t_epi0 = t_epi0;
     write_outputs(c, r);
 }
-
-#include "mcq_gi.inc"
 
 // =====================================================================================================================
 // K4: IQP glue -- re-linearisation on the device

@@ -285,7 +285,9 @@ int mcq_solve_host(mcq_handle* h, int batch, int n, const double* reftrack, cons
 
 /* A STREAM of uniform batches from / to host memory with the PCIe hidden behind the kernels (SURVEY.md section 8d defines the
  * metric "inputs resident in host pinned memory -> alpha resident in host memory"): step k's kernels run while step k+1's rows are
- * uploaded and step k-1's results are downloaded, on two copy streams and two sets of device staging buffers.  Arrays of `steps`
+ * uploaded and step k-1's results are downloaded, on two copy streams and two sets of device staging buffers -- and, since round 5, on TWO
+ * COMPUTE STREAMS with a workspace each (a second 1.8 MB per problem while the entry is in use): consecutive steps are independent, so the
+ * kernels of step k+1 start on the compute units step k's launch has already left instead of waiting for its slowest problems.  Arrays of `steps`
  * host pointers (pinned memory from mcq_host_alloc for full PCIe speed): reftrack[k] [batch][n][4], normvec[k] [batch][n][2] (array or
  * entries may be NULL: derived on the device), scaling[k] [batch][n] (may be NULL), alpha_out[k] [batch][n], curv_err_out[k] [batch],
  * status_out[k] [batch].  Results of step k are bitwise those of mcq_solve_host on the same buffers.  Blocking; returns when

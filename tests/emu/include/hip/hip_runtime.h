@@ -296,6 +296,8 @@ inline double __hiloint2double(int hi, int lo)
 inline int __shfl_xor(int v, int m) { return (int)__shfl_xor((double)v, m); }
 inline int atomicAdd(int* p, int v) { const int o = *p; *p = o + v; return o; }    /* one work-item runs at a time */
 inline int atomicCAS(int* p, int cmp, int v) { const int o = *p; if (o == cmp) *p = v; return o; }
+inline int atomicExch(int* p, int v) { const int o = *p; *p = v; return o; }
+inline void __threadfence() {}
 
 // ---- host runtime subset -------------------------------------------------------------------------------------------
 typedef int hipError_t;
