@@ -46,14 +46,14 @@ if ROOT not in sys.path:
 
 INFO_DTYPE = np.dtype([("ipm_iters", "<i4"), ("as_iters", "<i4"), ("n_active_box", "<i4"), ("n_active_kappa", "<i4"),
                        ("kappa_max", "<f8"), ("kkt_res", "<f8"), ("ticks", "<i8", (8,)),
-                       ("refine_rounds", "<i4"), ("second_attempt", "<i4"), ("f32_factorisations", "<i4"), ("reserved_", "<i4")])
+                       ("refine_rounds", "<i4"), ("second_attempt", "<i4"), ("f32_factorisations", "<i4"), ("gi_iters", "<i4")])
 HBM_PEAK_GBS = 8000.0        # MI355X HBM3E spec peak, /opt/skills/guides/MI355X_MICROARCH.md
 FP64_PEAK_TFLOPS = 78.6      # MI355X fp64 vector = matrix peak (public spec; v_mfma_f64_16x16x4 runs at the fp64 VALU rate)
 KAPPA_BOUND, W_VEH = 0.12, 3.4
 
 
 # ----------------------------------------------------------------------------------------------------------------------
-# roofline model of mcq_solve_kernel ('banded-exact' mode)
+# roofline model of mcq_solve_kernel (the streamed-byte model of the saddle-point core)
 # ----------------------------------------------------------------------------------------------------------------------
 def work_model(n, info, band_e=32):
     """HBM bytes and fp64 flops of mcq_solve_kernel for one launch, from the iteration counts the solver reports (mcq_info).
@@ -555,8 +555,9 @@ def main():
                        "mean_ipm_iters": float(info["ipm_iters"].mean()), "mean_as_iters": float(info["as_iters"].mean()),
                        "mean_active_box_rows": float(info["n_active_box"].mean()),
                        "mean_refine_rounds": float(info["refine_rounds"].mean()),
-                       "second_attempts": int(info["second_attempt"].sum()),
-                       "kernel_ms": {k: float(np.mean([m[k] for m in solve_ms])) for k in ("assemble", "gram", "solve", "total")},
+                       "second_attempts": int(np.count_nonzero(info["second_attempt"] & 1)), "warm_start_fallbacks": int(np.count_nonzero(info["second_attempt"] & 2)),
+                       "kernel_ms": {k: float(np.mean([m[k] for m in solve_ms])) for k in ("solve", "total")},
+                       "goldfarb_idnani_fallbacks": int(np.count_nonzero(info["gi_iters"] > 0)),
                        "workspace_GB": eng.workspace_bytes() / 1e9,
                        "solver_phase_ms_per_problem": {k: float(info["ticks"][:, j].mean()) / 1e5 for j, k in
                                                        enumerate(("factor", "solve", "gradient", "kernel", "interior_point_phase", "active_set_phase"))},
@@ -604,7 +605,9 @@ def main():
             out["host_to_host"] = {"value": B * hs / t_pipe, "unit": "solves/s", "ms_per_step": 1e3 * t_pipe / hs, "steps": hs,
                                    "what": "mcq_solve_host_pipelined: a stream of %d batches, rows / normals / scalings in pinned host memory -> alpha, "
                                            "curv_error, status in pinned host memory; uploads, kernels and downloads of consecutive batches overlap "
-                                           "(two copy streams, two staging slots)" % hs,
+                                           "(two copy streams, two staging slots) and -- round 5 -- so do the KERNELS of consecutive batches (two compute "
+                                           "streams, two workspaces: the next launch starts on the compute units the previous one has left), which is why "
+                                           "this rate can exceed `value`, measured launch by launch on one stream" % hs,
                                    "ratio_to_device_resident": (B * hs / t_pipe) / value,
                                    "blocking_single_batch": {"value": B / float(np.mean(hh)), "ms_per_step": 1e3 * float(np.mean(hh)),
                                                              "what": "mcq_solve_host: H2D -> kernels -> D2H, blocking; %d calls" % len(hh)},

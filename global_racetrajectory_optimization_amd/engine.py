@@ -762,7 +762,7 @@ class Engine:
     def last_timing_ms(self):
         ms = (ctypes.c_float * 5)()
         self._check(self.lib.mcq_last_timing(self.h, ctypes.byref(ms)), "mcq_last_timing")
-        return dict(assemble=ms[0], gram=ms[1], solve=ms[2], post=ms[3], total=ms[4])
+        return dict(solve=ms[2], total=ms[4], assemble_sp=ms[0])      # (ms[1], ms[3]: kernels that no longer exist -- include/mcq.h)
 
     def workspace_bytes(self):
         return int(self.lib.mcq_workspace_bytes(self.h))

@@ -47,7 +47,7 @@ def main():
     info = eng.download(d_info, (B,), INFO_DTYPE)
     print(json.dumps({"objective": "shortest_path", "batch": B, "n": n, "steps": args.steps,
                       "solves_per_s": B * args.steps / dt, "failed": int(np.count_nonzero(st)),
-                      "kernel_ms": {k: float(np.mean([m[k] for m in ms])) for k in ("assemble", "solve", "total")},
+                      "kernel_ms": {k: float(np.mean([m[k] for m in ms])) for k in ("assemble_sp", "solve", "total")},
                       "mean_ipm_iters": float(info["ipm_iters"].mean()), "mean_as_iters": float(info["as_iters"].mean()),
                       "max_as_iters": int(info["as_iters"].max()), "second_attempts": int(info["second_attempt"].sum()),
                       "mean_active_box_rows": float(info["n_active_box"].mean()),

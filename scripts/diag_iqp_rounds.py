@@ -18,7 +18,7 @@ from global_racetrajectory_optimization_amd import engine, synthetic            
 
 INFO_DTYPE = np.dtype([("ipm_iters", "<i4"), ("as_iters", "<i4"), ("n_active_box", "<i4"), ("n_active_kappa", "<i4"),
                        ("kappa_max", "<f8"), ("kkt_res", "<f8"), ("ticks", "<i8", (8,)),
-                       ("refine_rounds", "<i4"), ("second_attempt", "<i4"), ("f32_factorisations", "<i4"), ("reserved_", "<i4")])
+                       ("refine_rounds", "<i4"), ("second_attempt", "<i4"), ("f32_factorisations", "<i4"), ("gi_iters", "<i4")])
 
 
 def main():

@@ -17,7 +17,7 @@ import json
 try:
     d=json.load(open("gpurun_out/${T}_${name}.json"))
     c=d["config"]
-    print("${name}: %.0f solves/s, kernels asm %.2f gram %.2f solve %.2f ms, phases %s, iters ipm %.2f as %.2f 2nd %d failed %d, ticks %s" % (d["value"], c["kernel_ms"]["assemble"], c["kernel_ms"]["gram"], c["kernel_ms"]["solve"], {k: round(v,3) for k,v in c["solver_phase_ms_per_problem"].items()}, c["mean_ipm_iters"], c["mean_as_iters"], c["second_attempts"], c["failed_problems"], [int(v) for v in c.get("ticks_mean", [])]))
+    print("${name}: %.0f solves/s, kernel solve %.2f ms, phases %s, iters ipm %.2f as %.2f 2nd %d failed %d, ticks %s" % (d["value"], c["kernel_ms"]["solve"], {k: round(v,3) for k,v in c["solver_phase_ms_per_problem"].items()}, c["mean_ipm_iters"], c["mean_as_iters"], c["second_attempts"], c["failed_problems"], [int(v) for v in c.get("ticks_mean", [])]))
 except Exception as e:
     print("${name}: no result", e)
 PY
