@@ -605,6 +605,12 @@ class Engine:
             raise RuntimeError("ax_max_machines has to cover the entire velocity range of the car (i.e. >= v_max)!")
         if filt_window is not None and int(filt_window) % 2 == 0:
             raise RuntimeError("Window width of moving average filter must be odd!")
+        if filt_window is not None and int(filt_window) > 1:
+            # a window wider than the ring: the kernel flags the variant with lap_time = NaN (tph.conv_filt wraps the ring more than once
+            # and returns something of another length) -- refused here instead of handed back as NaNs
+            n_min = int(np.min(n_of_track)) if n_of_track is not None else n
+            if int(filt_window) > n_min:
+                raise ValueError("vel_profile_batch: filt_window %d is wider than the shortest profile (%d points)" % (int(filt_window), n_min))
         if mu is not None:
             mu = np.ascontiguousarray(mu, dtype=np.float64)
             if mu.shape != kappa.shape:

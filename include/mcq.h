@@ -361,7 +361,7 @@ void* mcq_stream(mcq_handle* h);
 
 /* Timing of the last mcq_solve_device / mcq_solve_batch call, measured with HIP events on the handle's stream:
  * ms[2] the solver kernel (since round 4 the whole QP pass: assembly, solve, post-check -- and, round 5, the Goldfarb-Idnani path of the
- * problems that need it), ms[4] the whole launch sequence; ms[0] mcq_assemble_sp_kernel (shortest-path objective only, else ~0);
+ * problems that need it), ms[4] the whole launch sequence; ms[0] the assembly kernel of the shortest-path objective (else ~0);
  * ms[1], ms[3] are 0 (the kernels they timed until round 3 no longer exist; the slots stay for ABI compatibility). */
 int mcq_last_timing(mcq_handle* h, float ms[5]);
 

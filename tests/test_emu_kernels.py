@@ -260,6 +260,9 @@ def test_velocity_profile_filter_window_and_friction_map(emu, golden):
     with pytest.raises(RuntimeError, match="must be odd"):
         emu.vel_profile_batch(kappa[None, :], el[None, :], np.stack([v[0] for v in var]), np.stack([v[1] for v in var]),
                               [v[2] for v in var], [v[3] for v in var], [v[4] for v in var], filt_window=4)
+    with pytest.raises(ValueError, match="wider than the shortest profile"):       # (the kernel's NaN flag used to come back silently)
+        emu.vel_profile_batch(kappa[None, :], el[None, :], np.stack([v[0] for v in var]), np.stack([v[1] for v in var]),
+                              [v[2] for v in var], [v[3] for v in var], [v[4] for v in var], filt_window=2 * (n // 2) + 3)
 
 
 def test_velocity_profile_table_range_errors(emu, golden):
