@@ -86,3 +86,16 @@ def test_fallback_takes_over_when_block_pivoting_runs_out(emu, golden):
     assert np.max(np.abs(al[2] - a_ref)) < 1e-9
     for r, i in zip(ran, info):
         assert (i["gi_iters"] > 0) == r
+
+
+def test_iqp_rounds_with_the_fallback_inside(emu, golden):
+    """The whole iqp_handler chain as one engine call with the block-pivoting phase cut to ONE round per attempt (max_as_iter = 1): whatever a
+    round leaves unsettled goes through the Goldfarb-Idnani path inside the same launch, warm-started passes included -- the end state is the
+    golden one of the unrestricted chain."""
+    g = golden["rounded_rectangle"]
+    trk = [dict(reftrack=g["reftrack"].copy(), normvectors=g["normvec"], scaling=g["scaling"])]
+    ref = emu.iqp_batch(trk, 0.12, 3.4, 3.0, iters_min=3, curv_error_allowed=0.01)
+    out = emu.iqp_batch(trk, 0.12, 3.4, 3.0, iters_min=3, curv_error_allowed=0.01, max_as_iter=1)
+    assert out["status"][0] == 0 and ref["status"][0] == 0 and out["rounds"][0] == ref["rounds"][0]
+    assert out["alpha"][0].shape == ref["alpha"][0].shape == g["iqp_alpha"].shape
+    assert np.max(np.abs(out["alpha"][0] - g["iqp_alpha"])) < 1e-8 and np.max(np.abs(out["alpha"][0] - ref["alpha"][0])) < 1e-9
