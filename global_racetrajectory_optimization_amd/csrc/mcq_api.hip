@@ -929,7 +929,7 @@ extern "C" int mcq_solve_host(mcq_handle* h, int batch, int n, const double* ref
     HIP_TRY_SYNC(hipMemcpyAsync(status_out, h->d_status, batch * sizeof(int), hipMemcpyDeviceToHost, h->stream));
     if (info_out) HIP_TRY_SYNC(hipMemcpyAsync(info_out, h->d_info, batch * sizeof(mcq_info), hipMemcpyDeviceToHost, h->stream));
     HIP_TRY(hipStreamSynchronize(h->stream));
-    // (MCQ_KAPPA_NO_SLOT never arrives here since round 5: the Goldfarb-Idnani kernel of the same launch sequence solves such problems)
+    // (MCQ_KAPPA_NO_SLOT never arrives here since round 5: the Goldfarb-Idnani path inside the solver kernel takes such problems)
     return 0;
 }
 

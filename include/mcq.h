@@ -52,8 +52,8 @@ enum {
     MCQ_RING_OVERFLOW = 7,    /* mcq_iqp_device / mcq_iqp_batch only: the re-sampled raceline of an IQP round needs more waypoints than
                                * the buffers hold (nmax / nmax_out) -- not an input error of the QP (that stays MCQ_BAD_INPUT) */
     MCQ_KAPPA_NO_SLOT = 8     /* never returned since round 5 (kept for ABI compatibility): a problem with more than 120 active curvature
-                               * rows that finds the handle's 8 overflow slots taken is solved by the Goldfarb-Idnani path of the same
-                               * launch sequence, on every entry point */
+                               * rows that finds the handle's 8 overflow slots taken is solved by the Goldfarb-Idnani path inside the same
+                               * kernel, on every entry point */
 };
 
 /* library-level error codes (negative return values) */
@@ -287,7 +287,10 @@ int mcq_solve_host(mcq_handle* h, int batch, int n, const double* reftrack, cons
  * metric "inputs resident in host pinned memory -> alpha resident in host memory"): step k's kernels run while step k+1's rows are
  * uploaded and step k-1's results are downloaded, on two copy streams and two sets of device staging buffers -- and, since round 5, on TWO
  * COMPUTE STREAMS with a workspace each (a second 1.8 MB per problem while the entry is in use): consecutive steps are independent, so the
- * kernels of step k+1 start on the compute units step k's launch has already left instead of waiting for its slowest problems.  Arrays of `steps`
+ * kernels of step k+1 start on the compute units step k's launch has already left instead of waiting for its slowest problems.
+ * curv_err_out / status_out may be pageable (they pass through pinned staging of the handle and are filled when the call returns); alpha_out and
+ * the inputs should be pinned (mcq_host_alloc).  Debugging knobs (environment): MCQ_PIPE_ONE_STREAM=1 keeps every step on the handle's first
+ * compute stream (round 4's behaviour, for A/B measurements), MCQ_PIPE_TRACE=1 prints when the host enqueued each step.  Arrays of `steps`
  * host pointers (pinned memory from mcq_host_alloc for full PCIe speed): reftrack[k] [batch][n][4], normvec[k] [batch][n][2] (array or
  * entries may be NULL: derived on the device), scaling[k] [batch][n] (may be NULL), alpha_out[k] [batch][n], curv_err_out[k] [batch],
  * status_out[k] [batch].  Results of step k are bitwise those of mcq_solve_host on the same buffers.  Blocking; returns when

@@ -1081,7 +1081,7 @@ def test_curvature_row_overflow_slots_against_dense_gi(gpu_engine):
     print("curvature-row overflow: %s active rows, max |alpha - dense GI| = %.2e m"
           % ([w[2] for w in want], max(float(np.max(np.abs(al[k] - w[0]))) for k, w in enumerate(want))))
     # more such problems in ONE launch than the handle has overflow slots (8): which of them get a slot depends on the order the GPU
-    # schedules workgroups in -- the ones left out go through the Goldfarb-Idnani kernel of the same launch sequence (round 5; rounds 3-4:
+    # schedules workgroups in -- the ones left out go through the Goldfarb-Idnani path inside the same kernel (round 5; rounds 3-4:
     # MCQ_KAPPA_NO_SLOT, re-launched by the host-buffer entries only), whose final round from the same working set is the block-pivoting
     # phase's own: every copy comes back with status 0 and the same vertex, on the host-buffer entry and on the device entry alike
     many = [probs[0]] * 11 + [dict(reftrack=probs[0]["reftrack"], normvec=probs[0]["normvec"], scaling=probs[0]["scaling"], kappa_bound=0.5,
