@@ -105,3 +105,35 @@ def test_two_ranks_sharded_solve_and_lagged_gathers(gpu_engine, tmp_path):
         assert list(z["status"]) == list(s1) == [0] * 5 and np.array_equal(z["curv"], c1)
         for k in range(5):
             assert np.array_equal(z["a%d" % k], a1[k]), (r, k)
+
+
+def test_pipelined_host_entry_on_two_compute_streams_is_bitwise_the_blocking_entry(gpu_engine):
+    """mcq_solve_host_pipelined (round 5: consecutive steps on two compute streams with a workspace each, curv / status through pinned staging):
+    seven steps of DIFFERENT tracks -- pinned and pageable buffers mixed, normals given / derived -- against mcq_solve_host step by step, bitwise;
+    one step holds a problem the block-pivoting phase is not allowed to finish (max_as_iter = 1), so that the second workspace's
+    Goldfarb-Idnani slots are used as well."""
+    from global_racetrajectory_optimization_amd import synthetic
+    eng = gpu_engine
+    B, n, K = 48, 600, 7
+    refs, nvs, scs, outs = [], [], [], []
+    for k in range(K):
+        ref, nv, sc = synthetic.oval_batch(B, n=n, first=300 + 50 * k, perturb_centreline=True)
+        if k % 2 == 0:          # pinned
+            pr, pn, ps = eng.host_array((B, n, 4)), eng.host_array((B, n, 2)), eng.host_array((B, n))
+            pr[...], pn[...], ps[...] = ref, nv, sc
+            refs.append(pr); nvs.append(pn if k % 4 == 0 else None); scs.append(ps if k % 4 == 0 else None)
+        else:                   # pageable
+            refs.append(ref); nvs.append(nv); scs.append(sc)
+        outs.append(eng.host_array((B, n)) if k % 3 else np.empty((B, n)))
+    for opt in (dict(), dict(max_as_iter=1)):
+        for o in outs:
+            o[...] = np.nan
+        curv, st = eng.solve_host_pipelined(refs, nvs, scs, 0.12, 3.4, outs, **opt)
+        assert np.all(st == 0), np.unique(st)
+        ran = 0
+        for k in range(K):
+            a1, c1, s1, inf = eng.solve_host(refs[k], nvs[k], scs[k], 0.12, 3.4, **opt)
+            assert np.array_equal(a1, outs[k]) and np.array_equal(c1, curv[k]) and np.array_equal(s1, st[k]), (opt, k)
+            ran += sum(1 for i in inf if i.gi_iters > 0)
+        if opt:
+            assert ran > 0, "max_as_iter = 1 sent no problem through the Goldfarb-Idnani path: the test exercises nothing"
