@@ -153,3 +153,30 @@ def test_long_rings_against_dense_goldens(gpu_engine):
     assert st3[0] == 0 and d3 < ALPHA_TOL, (st3[0], d3)
     print("rings above 2048 waypoints, max |alpha - dense oracle|: default path %s, Goldfarb-Idnani path %s (steps %s), shortest path %.1e" % (
         ["%.1e" % v for v in d], ["%.1e" % v for v in d2], [i["gi_iters"] for i in info2], d3))
+
+
+def test_gi_mode_on_every_full_size_golden(gpu_engine):
+    """Every dense-oracle fixture of the bench size through the Goldfarb-Idnani path alone (mcq_opts.algorithm = MCQ_ALG_GI): twelve first passes
+    of N = 2000 ovals, the QPs of IQP second / third passes (unit scalings, dozens of bounds touched with multipliers down to 1e-7 of the gradient
+    scale: the instances that made block pivoting need a second attempt), the ring with the curvature bound active at this size, Berlin at
+    N = 333 / 776 and Modena.  One ragged launch of 20 problems on 8 slots; the same vertex as the default path, the oracle's to 1e-6 m."""
+    from conftest import load_golden
+    names = ["oval_n2000", "oval_n2000_w1", "oval_n2000_w2", "oval_n2000_w3", "oval_n2000_w7", "oval_n2000_w11", "oval_n2000_c5", "oval_n2000_c9",
+             "oval_n2000_c13", "oval_n2000_c21", "oval_n2000_kappa", "iqp_pass2_oval5", "iqp_pass3_oval3", "iqp_pass3_oval9", "iqp_pass3_oval629",
+             "berlin_2018_n333", "berlin_2018", "modena_2019"]
+    gs = [load_golden(t) for t in names]
+    probs = [dict(reftrack=g["reftrack"], normvec=g["normvec"], scaling=g["scaling"] if "scaling" in g else None,
+                  kappa_bound=float(g["kappa_bound"]) if "kappa_bound" in g else 0.12, w_veh=float(g["w_veh"]) if "w_veh" in g else 3.4) for g in gs]
+    al, curv, st, info = gpu_engine.solve_batch(probs, algorithm=engine.ALG_GI)
+    assert np.all(st == 0), dict(zip(names, st))
+    al0, curv0, st0, info0 = gpu_engine.solve_batch(probs)
+    assert np.all(st0 == 0)
+    d = [float(np.max(np.abs(al[k] - gs[k]["alpha"]))) for k in range(len(names))]
+    d0 = [float(np.max(np.abs(al[k] - al0[k]))) for k in range(len(names))]
+    assert max(d) < ALPHA_TOL and max(d0) < ALPHA_TOL, (dict(zip(names, d)), dict(zip(names, d0)))
+    for k, g in enumerate(gs):
+        assert abs(curv[k] - float(g["curv_error_max"])) < 1e-8, names[k]
+        assert info[k]["n_active_box"] == info0[k]["n_active_box"] and info[k]["n_active_kappa"] == info0[k]["n_active_kappa"], names[k]
+    print("GI mode on %d full-size fixtures: steps %s, ms %s, polish rejected %d, max |alpha - oracle| %.1e, max |alpha - default path| %.1e" % (
+        len(names), [i["gi_iters"] for i in info], ["%.0f" % (i["ticks"][3] / 1e5) for i in info], sum(1 for i in info if i["second_attempt"] & 8),
+        max(d), max(d0)))
