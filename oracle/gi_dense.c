@@ -10,6 +10,11 @@
  * the first `meq` constraints being equalities; dense G, dense C (one COLUMN per constraint);
  * entering constraint = the most negative slack after normalising by the column norm.
  *
+ * KNOWN LIMITATION (found in round 5, tests/test_emu_gi.py::test_zero_width_rows_both_paths_against_the_second_route): a pair of exactly
+ * dependent rows that must BOTH be respected -- the two box rows of a waypoint with w_r + w_l = w_veh, lo = hi -- can end in the exclusion list
+ * (`excl`, the degenerate-full-step rule below) while still violated, and the solver then stops at a non-optimal point (stationarity 2e-4 in that
+ * test).  No fixture of tests/golden/ has such rows; the engine is checked against the least-squares second route there instead.
+ *
  * Dense on purpose: this is the "what the reference's CPU path costs" stand-in.  O(n^3) set-up
  * (Cholesky, J = L^-T), then per iteration O(n*m) slacks + O(n^2) Givens updates.  Single thread.
  *
