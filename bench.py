@@ -78,8 +78,9 @@ def work_model(n, info, band_e=32):
                                  (the 65-wide bands of E and E' -- 1040 bytes -- no longer exist)
                  vector passes : one interior-point iteration reads / writes 33 vector entries (three passes of one load phase each;
                                  pass 1 in two halves), an active-set round ~30                                 -> 264 / 240 bytes
-               interior-point iteration = 1 factorisation + predictor solve + corrector solve + passes (one exact gradient per problem
-               confirms convergence, one more is taken where the float records hand over to fp64 ones); active-set round = 1
+               interior-point iteration = 1 factorisation + predictor solve + corrector solve + passes (one exact gradient is taken where the
+               float records hand over to fp64 ones; since round 5 convergence is declared on the carried gradient when every step it has
+               absorbed since came from fp64 records -- rounds 2-4 confirmed with one more); active-set round = 1
                factorisation + 1 solve + 2 gradients + passes; refinement round = 1 solve + 1 gradient; + 1 initial gradient + 1 for f
                and the curvature check + 1 for the post-check.
                  assembly      : since round 4 the prologue of the same kernel (assemble_problem): rows, normals, scalings in (56 B), 13
@@ -97,7 +98,9 @@ def work_model(n, info, band_e=32):
     ref = info["refine_rounds"].astype(np.float64)
     f32 = info["f32_factorisations"].astype(np.float64) if "f32_factorisations" in info.dtype.names else 0.0 * ipm
     n_fac, n_sol = ipm + act, 2 * ipm + act + ref
-    n_grad = 1.0 + 2 * act + ref + 1.0 + 1.0 + 1.0 + (f32 > 0)
+    # initial gradient, f + curvature check, post-check; the hand-over from float to fp64 records takes an exact gradient; the confirming one at
+    # convergence is only taken when the carried gradient has absorbed float-record steps since (round 5: never, once a hand-over has happened)
+    n_grad = 3.0 + 2 * act + ref + (f32 > 0) + ((f32 >= ipm) & (ipm > 0))
     ew = 2 * band_e + 1
     grad = n * 216.0
     b_fac, b_fused, b_solve = n * 881.0, n * 80.0, n * 496.0
@@ -122,7 +125,7 @@ def source_sha():
     import hashlib
     h = hashlib.sha256()
     base = os.path.join(ROOT, "global_racetrajectory_optimization_amd", "csrc")
-    for name in ("build.sh", "mcq_api.hip", "mcq_kernels.h", "mcq_kernels.hip", "mcq_kkt.inc", "mcq_tri.inc"):
+    for name in ("build.sh", "mcq_api.hip", "mcq_kernels.h", "mcq_kernels.hip", "mcq_kkt.inc", "mcq_tri.inc", "mcq_gi.inc"):
         with open(os.path.join(base, name), "rb") as fh:
             h.update(name.encode() + b"\0" + fh.read())
     return h.hexdigest()
