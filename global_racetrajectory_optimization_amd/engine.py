@@ -238,7 +238,10 @@ class Engine:
 
     def _opts(self, algorithm=ALG_DEFAULT, max_ipm_iter=0, max_as_iter=0, refine_steps=-1, check_kappa=1, objective=OBJ_MIN_CURV,
               warm_start=0):
-        """mcq_opts.  algorithm=ALG_GI: every problem through the engine's Goldfarb-Idnani path (quadprog's algorithm; a reference mode)."""
+        """mcq_opts.  algorithm=ALG_GI: every problem through the engine's Goldfarb-Idnani path (quadprog's algorithm; a reference mode).
+        $MCQ_ALGORITHM=gi selects it for callers that cannot pass options -- the drop-in package under the untouched main_globaltraj.py."""
+        if int(algorithm) == ALG_DEFAULT and os.environ.get("MCQ_ALGORITHM", "").lower() in ("gi", "goldfarb-idnani", "quadprog"):
+            algorithm = ALG_GI
         return McqOpts(int(algorithm), int(max_ipm_iter), int(max_as_iter), int(refine_steps), int(check_kappa),
                        int(objective), int(warm_start))
 

@@ -51,6 +51,21 @@ def test_main_globaltraj_untouched(emu_lib, tmp_path, monkeypatch, opt_type):
 
 
 @pytest.mark.skipif(not os.path.exists(os.path.join(REF, "main_globaltraj.py")), reason="reference checkout not present")
+def test_main_globaltraj_untouched_on_the_goldfarb_idnani_path(emu_lib, tmp_path, monkeypatch):
+    """$MCQ_ALGORITHM=gi: the untouched script with EVERY QP of its mincurv_iqp flow solved by the engine's Goldfarb-Idnani path -- the algorithm of
+    the quadprog it replaces -- ends in the golden IQP state of the default path."""
+    from global_racetrajectory_optimization_amd import engine, harness
+    monkeypatch.setenv("MCQ_LIB", emu_lib)
+    monkeypatch.setenv("MCQ_ALGORITHM", "gi")
+    monkeypatch.setattr(engine, "_DEFAULT_ENGINE", None)
+    res = harness.run(REF, opt_type="mincurv_iqp", track_name="rounded_rectangle", scratch=str(tmp_path), quiet=True)
+    monkeypatch.setattr(engine, "_DEFAULT_ENGINE", None)
+    assert "INFO: Estimated laptime:" in res["stdout"] and "Minimum curvature IQP: iteration 3" in res["stdout"]
+    g = np.load(os.path.join(os.path.dirname(__file__), "golden", "rounded_rectangle.npz"))
+    assert np.max(np.abs(res["globals"]["alpha_opt"] - g["iqp_alpha"])) < 1e-7
+
+
+@pytest.mark.skipif(not os.path.exists(os.path.join(REF, "main_globaltraj.py")), reason="reference checkout not present")
 def test_main_globaltraj_untouched_berlin_config1(emu_lib, tmp_path, monkeypatch):
     """BASELINE config 1 as specified: berlin_2018 (N = 776 at the ini defaults), opt_type = 'mincurv', the untouched script end to
     end -- import_track, prep_track, opt_min_curv behind the boundary, create_raceline, velocity profile, lap time, export."""
