@@ -1706,6 +1706,9 @@ __global__ void __launch_bounds__(MCQ_NT, 2) mcq_solve_kernel(McqBatch B)
     else if (!warm_done) {
         status = small ? ipm_box(c, MCQ_IPM_TOL, false) : ipm(c, false);
         ipm_iters = c.out_iters;
+        __syncthreads();      // (every thread has read what the phase left in the context before the next phase -- whose first act is to reset it --
+                              //  starts: round 5, found on the SIMT interpreter, where a fibre that runs ahead made thread 0 report 0 iterations; on the
+                              //  GPU a wave that far ahead of another was never observed, but `ipm_iters >= 1` below decides the Tapia rule per thread)
     }
     if (tid == 0) c.tk[4] = TICK() - t_ipm0;          // wall time of the interior-point phase (ticks[4])
     const long long t_as0 = TICK();
@@ -1729,6 +1732,7 @@ __global__ void __launch_bounds__(MCQ_NT, 2) mcq_solve_kernel(McqBatch B)
             __syncthreads();
             status = ipm_box(c, 1e-13, true);
             ipm_iters += c.out_iters;
+            __syncthreads();
             if (status == MCQ_OK) {
                 status = active_set(c, false, false, B.max_as_iter, 1, kappa_mem_lds(c));
                 as_iters += c.out_iters;
