@@ -13,7 +13,10 @@ HIPCC=${HIPCC:-/opt/rocm/bin/hipcc}
 # -amdgpu-schedule-metric-bias=0: the machine scheduler weighs latency only, not occupancy (default bias 10) -- every function of this
 #   library runs at the occupancy its register budget fixes (two workgroups per CU) and most of its time in dependent chains: +1.1 % on
 #   the bench, same results bit for bit (max-ilp as the strategy: the tridiagonal sweeps 11 % faster, the elimination 2 % slower, +0.3 %).
-FLAGS="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -mllvm -enable-ipra=${IPRA:-0} -mllvm -amdgpu-schedule-metric-bias=0"
+# -O2, not -O3 (round 5): results bit for bit, factorisations 2.3 % faster, bench +1.6 % over four same-box pairs (101.2 / 99.4 / 101.3 / 100.8 k
+#   against 98.7 / 98.4 / 100.8 / 98.2 k) -- -O3's extra unrolling of the elimination's and the chains' loops costs more scratch moves than it saves
+#   (the tridiagonal sweeps lose 4 %: gradients 0.291 -> 0.303 ms per problem; they are a tenth of the factorisations).
+FLAGS="--offload-arch=gfx950 -O2 -std=c++17 -fPIC -mllvm -enable-ipra=${IPRA:-0} -mllvm -amdgpu-schedule-metric-bias=0"
 OUT=${OUT:-libmcq.so}
 TMP=$(mktemp -d)
 trap 'rm -rf "$TMP"' EXIT

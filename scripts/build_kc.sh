@@ -6,7 +6,7 @@
 set -e
 R=$(cd "$(dirname "$0")/.." && pwd)
 HIPCC=${HIPCC:-/opt/rocm/bin/hipcc}
-F="--offload-arch=gfx950 -O3 -std=c++17 -mllvm -enable-ipra=0 -mllvm -amdgpu-schedule-metric-bias=0 --gpu-max-threads-per-block=512 -DKKT_TIMERS=1"
+F="--offload-arch=gfx950 -O2 -std=c++17 -mllvm -enable-ipra=0 -mllvm -amdgpu-schedule-metric-bias=0 --gpu-max-threads-per-block=512 -DKKT_TIMERS=1"
 mkdir -p $R/build/kc
 $HIPCC $F -o $R/build/kc/kc $R/scripts/kkt_check.hip &
 $HIPCC $F -DKC_F32=1 -o $R/build/kc/kc_f32 $R/scripts/kkt_check.hip &

@@ -8,7 +8,7 @@ R=$(cd "$(dirname "$0")/.." && pwd)
 SRC=$R/global_racetrajectory_optimization_amd/csrc
 OUT=$R/build/variants
 HIPCC=${HIPCC:-/opt/rocm/bin/hipcc}
-FLAGS="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -shared -mllvm -enable-ipra=0 -mllvm -amdgpu-schedule-metric-bias=0 --gpu-max-threads-per-block=512"
+FLAGS="--offload-arch=gfx950 -O2 -std=c++17 -fPIC -shared -mllvm -enable-ipra=0 -mllvm -amdgpu-schedule-metric-bias=0 --gpu-max-threads-per-block=512"
 mkdir -p $OUT /tmp/mcq_base/csrc /tmp/mcq_base/include_dir
 rm -f $OUT/*.so
 BASE_REV=${BASE_REV:-3b86c49}
