@@ -37,6 +37,9 @@ struct mcq_handle {
     hipStream_t stream = nullptr;
     hipEvent_t ev[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};
     bool timing_valid = false;
+    hipEvent_t ev_span[2] = {nullptr, nullptr};     // mcq_timing_begin / mcq_timing_end: a span of launches on the compute stream
+    int span_launches = 0;
+    bool span_open = false;
     // workspace slabs
     size_t cap_elems = 0;   // batch * nmax the slabs are sized for
     size_t cap_batch = 0;
@@ -228,6 +231,7 @@ extern "C" void mcq_destroy(mcq_handle* h)
     (void)hipFree(h->vel_scratch);
     if (h->pin) (void)hipHostFree(h->pin);
     for (int k = 0; k < 5; ++k) if (h->ev[k]) (void)hipEventDestroy(h->ev[k]);
+    for (int k = 0; k < 2; ++k) if (h->ev_span[k]) (void)hipEventDestroy(h->ev_span[k]);
     if (h->stream) (void)hipStreamDestroy(h->stream);
     delete h;
 }
@@ -403,6 +407,7 @@ static int launch(mcq_handle* h, McqBatch& B, const mcq_opts& o, bool alt = fals
     if (!alt) HIP_TRY(hipEventRecord(h->ev[3], st));
     if (!alt) HIP_TRY(hipEventRecord(h->ev[4], st));
     if (!alt) h->timing_valid = true;
+    if (!alt && h->span_open) ++h->span_launches;
     return 0;
 }
 
@@ -840,6 +845,31 @@ extern "C" int mcq_last_timing(mcq_handle* h, float ms[5])
     HIP_TRY(hipEventElapsedTime(&ms[2], h->ev[2], h->ev[3]));
     ms[3] = 0.0f;
     HIP_TRY(hipEventElapsedTime(&ms[4], h->ev[0], h->ev[4]));
+    return 0;
+}
+
+// A span of launches on the handle's compute stream, timed on the device (include/mcq.h)
+extern "C" int mcq_timing_begin(mcq_handle* h)
+{
+    if (!h) { g_err = "mcq_timing_begin: NULL handle"; return MCQ_E_ARG; }
+    HIP_TRY(hipSetDevice(h->device));
+    for (int k = 0; k < 2; ++k) if (!h->ev_span[k]) HIP_TRY(hipEventCreate(&h->ev_span[k]));
+    HIP_TRY(hipEventRecord(h->ev_span[0], h->stream));
+    h->span_launches = 0;
+    h->span_open = true;
+    return 0;
+}
+
+extern "C" int mcq_timing_end(mcq_handle* h, float* ms_out, int* launches_out)
+{
+    if (!h || !ms_out || !launches_out) { g_err = "mcq_timing_end: bad argument"; return MCQ_E_ARG; }
+    if (!h->span_open) { g_err = "mcq_timing_end: no span open (mcq_timing_begin)"; return MCQ_E_ARG; }
+    HIP_TRY(hipSetDevice(h->device));
+    HIP_TRY(hipEventRecord(h->ev_span[1], h->stream));
+    HIP_TRY(hipEventSynchronize(h->ev_span[1]));
+    HIP_TRY(hipEventElapsedTime(ms_out, h->ev_span[0], h->ev_span[1]));
+    *launches_out = h->span_launches;
+    h->span_open = false;
     return 0;
 }
 

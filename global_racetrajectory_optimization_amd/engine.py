@@ -64,7 +64,7 @@ EXPORTED_SYMBOLS = ("mcq_create", "mcq_destroy", "mcq_last_error", "mcq_default_
                     "mcq_vel_profile_device", "mcq_vel_profile_device_ragged", "mcq_vel_profile_device_opts", "mcq_raceline_device", "mcq_normals_crossing_device",
                     "mcq_device_alloc",
                     "mcq_device_free", "mcq_copy_to_device", "mcq_copy_to_host", "mcq_sync", "mcq_stream",
-                    "mcq_last_timing", "mcq_workspace_bytes",
+                    "mcq_last_timing", "mcq_timing_begin", "mcq_timing_end", "mcq_workspace_bytes",
                     "mcq_comm_unique_id", "mcq_comm_init", "mcq_comm_allgather", "mcq_comm_wait", "mcq_comm_world", "mcq_comm_destroy")
 
 
@@ -162,6 +162,10 @@ def load_library(path=None):
     lib.mcq_stream.restype = vp
     lib.mcq_last_timing.argtypes = [vp, ctypes.POINTER(ctypes.c_float * 5)]
     lib.mcq_last_timing.restype = ctypes.c_int
+    lib.mcq_timing_begin.argtypes = [vp]
+    lib.mcq_timing_begin.restype = ctypes.c_int
+    lib.mcq_timing_end.argtypes = [vp, ctypes.POINTER(ctypes.c_float), ctypes.POINTER(ctypes.c_int)]
+    lib.mcq_timing_end.restype = ctypes.c_int
     lib.mcq_workspace_bytes.argtypes = [vp]
     lib.mcq_workspace_bytes.restype = ctypes.c_longlong
     lib.mcq_comm_unique_id.argtypes = [ctypes.c_char_p]
@@ -772,6 +776,16 @@ class Engine:
         ms = (ctypes.c_float * 5)()
         self._check(self.lib.mcq_last_timing(self.h, ctypes.byref(ms)), "mcq_last_timing")
         return dict(solve=ms[2], total=ms[4], assemble_sp=ms[0])      # (ms[1], ms[3]: kernels that no longer exist -- include/mcq.h)
+
+    def timing_begin(self):
+        """Opens a span of launches timed on the device (mcq_timing_begin)."""
+        self._check(self.lib.mcq_timing_begin(self.h), "mcq_timing_begin")
+
+    def timing_end(self):
+        """Closes the span: (milliseconds on the device between begin and end, solver launches enqueued in between).  Blocks until the span's last launch is done."""
+        ms, cnt = ctypes.c_float(), ctypes.c_int()
+        self._check(self.lib.mcq_timing_end(self.h, ctypes.byref(ms), ctypes.byref(cnt)), "mcq_timing_end")
+        return float(ms.value), int(cnt.value)
 
     def workspace_bytes(self):
         return int(self.lib.mcq_workspace_bytes(self.h))

@@ -368,6 +368,14 @@ void* mcq_stream(mcq_handle* h);
  * ms[1], ms[3] are 0 (the kernels they timed until round 3 no longer exist; the slots stay for ABI compatibility). */
 int mcq_last_timing(mcq_handle* h, float ms[5]);
 
+/* A SPAN of launches timed on the device: mcq_timing_begin records an event on the handle's compute stream, mcq_timing_end records a second one,
+ * waits for it and returns the milliseconds between the two and the number of solver launches the handle enqueued on that stream in between
+ * (mcq_solve_device* / the QP passes of the IQP entries; not the second stream of mcq_solve_host_pipelined).  With launches enqueued back to back
+ * -- no host synchronisation inside the span -- ms / launches is the average duration of a launch, launch gaps included: what bench.py's
+ * `roofline.kernel_ms` is (round 5; until then it synchronised after every step to read mcq_last_timing, and a slow host showed up in `value`). */
+int mcq_timing_begin(mcq_handle* h);
+int mcq_timing_end(mcq_handle* h, float* ms_out, int* launches_out);
+
 /* Bytes of device workspace the handle currently holds (for DESIGN.md / bench reporting). */
 long long mcq_workspace_bytes(mcq_handle* h);
 
