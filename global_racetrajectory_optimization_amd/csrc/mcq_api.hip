@@ -76,7 +76,7 @@ struct mcq_handle {
     unsigned comm_seq = 0;              // gathers enqueued so far (event ring index)
     size_t vel_scratch_bytes = 0;
     double* kbig = nullptr;             // overflow slots of the curvature-row working set (MCQ_KBIG_SLOTS x MCQ_KBIG_SLOT doubles)
-    int* slot_flags = nullptr;          // [MCQ_KBIG_SLOTS + 64]: 0 free / 1 taken, claimed and released by the workgroups (never reset by the host)
+    int* slot_flags = nullptr;          // [MCQ_KBIG_SLOTS + MCQ_GI_SLOTS_MAX]: 0 free / 1 taken, claimed and released by the workgroups (never reset by the host)
     double* gi = nullptr;               // slots of the Goldfarb-Idnani path (mcq_gi.inc): gi_slots x MCQ_GI_SLOT_DOUBLES(gi_nmax, gi_nmax)
     int gi_slots = 0, gi_nmax = 0;
     long long gi_bytes = 0;
@@ -237,24 +237,31 @@ extern "C" void mcq_destroy(mcq_handle* h)
 }
 
 // Goldfarb-Idnani slots (mcq_gi.inc): a working set holds at most nmax independent constraints, so a slot is nmax x nmax (Q) + nmax x nmax
-// (R) doubles (64 MB at nmax = 2000); up to MCQ_GI_SLOTS of them ($MCQ_GI_SLOTS overrides), fewer for very long rings (<= 4 GB in all)
-static int ensure_gi(mcq_handle* h, size_t batch, size_t nmax)
+// (R) doubles (64 MB at nmax = 2000); MCQ_GI_SLOTS of them for the fallback ($MCQ_GI_SLOTS asks for more), fewer for very long rings.
+// want: slots asked for -- MCQ_GI_SLOTS for the fallback (<= 4 GB in all), up to MCQ_GI_SLOTS_MAX when EVERY problem takes this path
+// (mcq_opts.algorithm = MCQ_ALG_GI: one slot per resident workgroup, <= 48 GB in all: 33 GB for 512 slots at nmax = 2000)
+static int ensure_gi(mcq_handle* h, size_t batch, size_t nmax, int want = MCQ_GI_SLOTS)
 {
-    if (h->gi && (size_t)h->gi_nmax >= nmax) return 0;
+    if (const char* e = getenv("MCQ_GI_SLOTS")) want = std::max(want, atoi(e));
+    const size_t per = MCQ_GI_SLOT_DOUBLES(nmax, nmax) * sizeof(double);
+    const size_t cap_bytes = want > MCQ_GI_SLOTS ? ((size_t)48 << 30) : ((size_t)4 << 30);
+    int slots = std::min(std::max(want, 1), MCQ_GI_SLOTS_MAX);
+    while (slots > 1 && (size_t)slots * per > cap_bytes) --slots;
+    slots = (int)std::min<size_t>((size_t)slots, std::max<size_t>(batch, 1));
+    if (h->gi && (size_t)h->gi_nmax >= nmax && h->gi_slots >= slots) return 0;
+    nmax = std::max(nmax, (size_t)h->gi_nmax);
+    slots = std::max(slots, std::min(h->gi_slots, MCQ_GI_SLOTS));
+    const size_t per2 = MCQ_GI_SLOT_DOUBLES(nmax, nmax) * sizeof(double);
+    while (slots > 1 && (size_t)slots * per2 > cap_bytes) --slots;
     HIP_TRY(hipStreamSynchronize(h->stream));
     (void)hipFree(h->gi);
     h->gi = nullptr;
     h->gi_slots = h->gi_nmax = 0;
-    int slots = MCQ_GI_SLOTS;
-    if (const char* e = getenv("MCQ_GI_SLOTS")) slots = std::min(64, std::max(1, atoi(e)));
-    const size_t per = MCQ_GI_SLOT_DOUBLES(nmax, nmax) * sizeof(double);
-    while (slots > 1 && (size_t)slots * per > ((size_t)4 << 30)) --slots;
-    slots = (int)std::min<size_t>((size_t)slots, std::max<size_t>(batch, 1));
-    HIP_TRY(hipMalloc((void**)&h->gi, (size_t)slots * per));
-    if (h->poison) HIP_TRY(hipMemsetAsync(h->gi, 0xff, (size_t)slots * per, h->stream));
+    HIP_TRY(hipMalloc((void**)&h->gi, (size_t)slots * per2));
+    if (h->poison) HIP_TRY(hipMemsetAsync(h->gi, 0xff, (size_t)slots * per2, h->stream));
     h->gi_slots = slots;
     h->gi_nmax = (int)nmax;
-    h->gi_bytes = (long long)((size_t)slots * per);
+    h->gi_bytes = (long long)((size_t)slots * per2);
     return 0;
 }
 
@@ -270,8 +277,8 @@ static int ensure_ws(mcq_handle* h, size_t batch, size_t nmax)
     HIP_TRY(hipMalloc((void**)&h->state, elems));
     HIP_TRY(hipMalloc((void**)&h->state2, elems));
     HIP_TRY(hipMalloc((void**)&h->kbig, (size_t)MCQ_KBIG_SLOTS * MCQ_KBIG_SLOT * sizeof(double)));
-    HIP_TRY(hipMalloc((void**)&h->slot_flags, (MCQ_KBIG_SLOTS + 64) * sizeof(int)));
-    HIP_TRY(hipMemsetAsync(h->slot_flags, 0, (MCQ_KBIG_SLOTS + 64) * sizeof(int), h->stream));
+    HIP_TRY(hipMalloc((void**)&h->slot_flags, (MCQ_KBIG_SLOTS + MCQ_GI_SLOTS_MAX) * sizeof(int)));
+    HIP_TRY(hipMemsetAsync(h->slot_flags, 0, (MCQ_KBIG_SLOTS + MCQ_GI_SLOTS_MAX) * sizeof(int), h->stream));
     h->gi_slots = h->gi_nmax = 0;
     if (int rc = ensure_gi(h, batch, nmax)) return rc;
     if (h->poison) HIP_TRY(hipMemsetAsync(h->kbig, 0xff, (size_t)MCQ_KBIG_SLOTS * MCQ_KBIG_SLOT * sizeof(double), h->stream));
@@ -303,8 +310,8 @@ static int ensure_alt(mcq_handle* h, size_t batch, size_t nmax)
     HIP_TRY(hipMalloc((void**)&h->Z2, (elems + batch * (size_t)MCQ_KMAX * MCQ_KMAX) * sizeof(double)));
     HIP_TRY(hipMalloc((void**)&h->state_alt, elems));
     HIP_TRY(hipMalloc((void**)&h->kbig2, (size_t)MCQ_KBIG_SLOTS * MCQ_KBIG_SLOT * sizeof(double)));
-    HIP_TRY(hipMalloc((void**)&h->slot_flags2, (MCQ_KBIG_SLOTS + 64) * sizeof(int)));
-    HIP_TRY(hipMemsetAsync(h->slot_flags2, 0, (MCQ_KBIG_SLOTS + 64) * sizeof(int), h->stream2));
+    HIP_TRY(hipMalloc((void**)&h->slot_flags2, (MCQ_KBIG_SLOTS + MCQ_GI_SLOTS_MAX) * sizeof(int)));
+    HIP_TRY(hipMemsetAsync(h->slot_flags2, 0, (MCQ_KBIG_SLOTS + MCQ_GI_SLOTS_MAX) * sizeof(int), h->stream2));
     const size_t per = MCQ_GI_SLOT_DOUBLES(nmax, nmax) * sizeof(double);
     int slots = std::max(1, h->gi_slots / 2);
     HIP_TRY(hipMalloc((void**)&h->gi2, (size_t)slots * per));
@@ -369,6 +376,10 @@ static int launch(mcq_handle* h, McqBatch& B, const mcq_opts& o, bool alt = fals
     B.kbig_slots = MCQ_KBIG_SLOTS;
     B.algorithm = o.algorithm;
     // the Goldfarb-Idnani slots hold working sets of up to gi_nmax constraints on rings of up to gi_nmax waypoints (slot stride: B.nmax)
+    if (!alt && o.algorithm == MCQ_ALG_GI && o.objective == MCQ_OBJ_MIN_CURV && !B.prep_only) {
+        // every problem takes the Goldfarb-Idnani path: a slot per resident workgroup, so that they run side by side instead of eight at a time
+        if (int rc = ensure_gi(h, (size_t)B.batch, (size_t)B.nmax, std::min(B.batch, MCQ_GI_SLOTS_MAX))) return rc;
+    }
     double* gi_mem = alt ? h->gi2 : h->gi;
     const bool gi_on = gi_mem && B.nmax <= (alt ? h->gi2_nmax : h->gi_nmax) && o.objective == MCQ_OBJ_MIN_CURV && !B.prep_only;
     B.gi = gi_on ? gi_mem : nullptr;

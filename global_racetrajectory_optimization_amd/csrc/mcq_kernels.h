@@ -113,6 +113,7 @@ __global__ void mcq_solve_kernel(McqBatch B);      // saddle-point elimination (
 /* Goldfarb-Idnani dual active-set path (mcq_gi.inc): inside mcq_solve_kernel, for whatever its interior point + block pivoting did not
  * settle (iteration cap, working set beyond its arrays, ...) -- solved again from scratch by quadprog's algorithm, in an HBM slot of the handle */
 #define MCQ_GI_SLOTS 8
+#define MCQ_GI_SLOTS_MAX 512       /* ... and when every problem takes the path (mcq_opts.algorithm = MCQ_ALG_GI): one per resident workgroup */
 #define MCQ_GI_SLOT_DOUBLES(nm, qcap) ((size_t)(qcap) * (size_t)(nm) + (size_t)(qcap) * (size_t)(qcap) + 9 * (size_t)(qcap) + 8)
 
 /* tph.check_normals_crossing [REF helper_funcs_glob/src/prep_track.py:57-59], one workgroup per track: crossing_out [batch] =

@@ -1488,8 +1488,11 @@ __device__ int claim_slot(int* flags, int nslots, bool wait)
     if (threadIdx.x == 0) {
         int got = -1;
         for (;;) {
-            for (int s = 0; s < nslots && got < 0; ++s)
+            const int s0 = (int)(blockIdx.x % (unsigned)nslots);       // (workgroups start their scans at different flags)
+            for (int k = 0; k < nslots && got < 0; ++k) {
+                const int s = s0 + k < nslots ? s0 + k : s0 + k - nslots;
                 if (atomicCAS(flags + s, 0, 1) == 0) got = s;
+            }
             if (got >= 0 || !wait) break;
             __builtin_amdgcn_s_sleep(127);
         }

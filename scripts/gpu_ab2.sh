@@ -17,7 +17,7 @@ for so in build/variants/*.so; do
 import json
 try:
     d=json.load(open("gpurun_out/${T}_${name}_${rep}.json")); c=d["config"]
-    print("${name} ${rep}: %.0f solves/s, kernel %.3f ms, ipm %.2f (f32 %s) as %.2f, failed %d 2nd %d, phases %s" % (d["value"], c["kernel_ms"]["solve"], c["mean_ipm_iters"], c.get("mean_f32_factorisations", c.get("f32_factorisations_mean")), c["mean_as_iters"], c["failed_problems"], c["second_attempts"], {k: round(v,3) for k,v in c["solver_phase_ms_per_problem"].items()}))
+    print("${name} ${rep}: %.0f solves/s, kernel %.3f ms, ipm %.2f (f32 %s) as %.2f, failed %d 2nd %d, phases %s" % (d["value"], c["kernel_ms"]["solve"], c["mean_ipm_iters"], d["roofline"]["model"][d["roofline"]["model"].find("float_record_factorisations"):][:36], c["mean_as_iters"], c["failed_problems"], c["second_attempts"], {k: round(v,3) for k,v in c["solver_phase_ms_per_problem"].items()}))
 except Exception as e:
     print("${name}: no result", e)
 PY
