@@ -245,12 +245,15 @@ static int ensure_gi(mcq_handle* h, size_t batch, size_t nmax, int want = MCQ_GI
     if (const char* e = getenv("MCQ_GI_SLOTS")) want = std::max(want, atoi(e));
     const size_t per = MCQ_GI_SLOT_DOUBLES(nmax, nmax) * sizeof(double);
     const size_t cap_bytes = want > MCQ_GI_SLOTS ? ((size_t)48 << 30) : ((size_t)4 << 30);
+    // the fallback's slots: as many as 4 GB hold, between MCQ_GI_SLOTS and 128 (64 at nmax = 2000) -- a sweep over tight curvature bounds can send
+    // hundreds of problems of one launch down this path
+    if (want <= MCQ_GI_SLOTS) want = (int)std::min<size_t>(128, std::max<size_t>(MCQ_GI_SLOTS, cap_bytes / std::max<size_t>(per, 1)));
     int slots = std::min(std::max(want, 1), MCQ_GI_SLOTS_MAX);
     while (slots > 1 && (size_t)slots * per > cap_bytes) --slots;
     slots = (int)std::min<size_t>((size_t)slots, std::max<size_t>(batch, 1));
     if (h->gi && (size_t)h->gi_nmax >= nmax && h->gi_slots >= slots) return 0;
     nmax = std::max(nmax, (size_t)h->gi_nmax);
-    slots = std::max(slots, std::min(h->gi_slots, MCQ_GI_SLOTS));
+    slots = std::max(slots, std::min(h->gi_slots, 128));
     const size_t per2 = MCQ_GI_SLOT_DOUBLES(nmax, nmax) * sizeof(double);
     while (slots > 1 && (size_t)slots * per2 > cap_bytes) --slots;
     HIP_TRY(hipStreamSynchronize(h->stream));

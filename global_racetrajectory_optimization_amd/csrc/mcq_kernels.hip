@@ -1494,7 +1494,9 @@ __device__ int claim_slot(int* flags, int nslots, bool wait)
                 if (atomicCAS(flags + s, 0, 1) == 0) got = s;
             }
             if (got >= 0 || !wait) break;
-            __builtin_amdgcn_s_sleep(127);
+            // back off: the holders work for milliseconds, and hundreds of waiting workgroups hammering the flags' cache line slow THEM down
+            // (round 5: a launch with 455 problems for 8 slots took 25 s; ~0.2 ms between two scans)
+            for (int r = 0; r < 64; ++r) __builtin_amdgcn_s_sleep(127);
         }
         sh[0] = got;
     }

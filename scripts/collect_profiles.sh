@@ -19,7 +19,7 @@ if files:
             os.remove(f)
 PY
 for f in bench.json bench_config4_1gpu.json bench_force_collective_1gpu.json config5_shard_1gpu.json shortest_path.json harness_berlin.log \
-         pytest_gpu.log pytest_gpu_poison.log kkt_check_n333_reference.txt write_bw.jsonl gi_and_comm_tests.txt pipeline_streams.txt gi_mode.json; do
+         pytest_gpu.log pytest_gpu_poison.log kkt_check_n333_reference.txt write_bw.jsonl gi_and_comm_tests.txt pipeline_streams.txt gi_mode.json stress_two_paths.json; do
   [ -f gpurun_out/${T}_$f ] && cp gpurun_out/${T}_$f profiles/${T}_$f
 done
 for k in kc_fused0 kc_fused1 kc_f32_fused0 kc_f32_fused1; do [ -f gpurun_out/${T}_$k.txt ] && cp gpurun_out/${T}_$k.txt profiles/${T}_kkt_check_$k.txt; done

@@ -18,6 +18,8 @@ tail -3 gpurun_out/${T}_pytest_gpu_poison.log
 echo "harness rc $?"; grep -c "Estimated laptime" gpurun_out/${T}_harness_berlin.log
 (timeout 300 python -m pytest tests/test_gpu_gi.py tests/test_gpu_comm.py -m gpu -q -s 2>&1 | grep -E "GI mode|stadium 360|curvature-tight|the same through|rings above|two ranks|passed|failed") > gpurun_out/${T}_gi_and_comm_tests.txt
 (timeout 120 python scripts/diag_pipe.py; MCQ_PIPE_ONE_STREAM=1 timeout 120 python scripts/diag_pipe.py) > gpurun_out/${T}_pipeline_streams.txt 2>&1
+timeout 600 python scripts/stress_two_paths.py 3000 11 > gpurun_out/${T}_stress_two_paths.json 2> gpurun_out/${T}_stress.err
+echo "stress rc $?"
 timeout 300 python scripts/bench_gi_mode.py > gpurun_out/${T}_gi_mode.json 2> gpurun_out/${T}_gi_mode.err
 echo "gi mode rc $?"
 timeout 300 python scripts/bench_shortest_path.py > gpurun_out/${T}_shortest_path.json 2> gpurun_out/${T}_shortest_path.err
