@@ -1,7 +1,7 @@
 """Stress (round 5): thousands of random problems through the engine's two independent algorithms -- interior point + block pivoting (default) and the
 Goldfarb-Idnani path alone (mcq_opts.algorithm = MCQ_ALG_GI) -- which must agree: the same vertex (1e-6 m) or the same verdict (inconsistent).
 Families: star-shaped rings, stadiums, ovals of the bench generator; n 40 .. 900; widths, vehicle widths and curvature bounds from loose to below
-feasibility.  One JSON line.   python scripts/stress_two_paths.py [count] [seed]"""
+feasibility.  One JSON line.   python scripts/stress_two_paths.py [count] [seed] [n_lo] [n_hi]"""
 import json, os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
@@ -22,7 +22,7 @@ rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 7)
 probs = []
 for k in range(count):
     fam = k % 3
-    n = int(rng.integers(40, 901))
+    n = int(rng.integers(int(sys.argv[3]) if len(sys.argv) > 3 else 40, (int(sys.argv[4]) if len(sys.argv) > 4 else 900) + 1))
     if fam == 0:
         th = np.linspace(0.0, 2 * np.pi, n, endpoint=False)
         r = rng.uniform(30, 80) * (1 + rng.uniform(0.05, 0.2) * np.sin(int(rng.integers(2, 6)) * th + rng.uniform(0, 6)) + rng.uniform(0.0, 0.08) * np.cos(int(rng.integers(5, 11)) * th + rng.uniform(0, 6)))
