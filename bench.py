@@ -629,32 +629,28 @@ def main():
             #      workspace each): step k + 1 starts on the compute units step k has left while its slowest problems finish -- what
             #      mcq_solve_host_pipelined does for batches from host memory.  A side record: `value` stays the launch-by-launch rate.
             try:
-                eng2 = engine.Engine(0 if emulate else local_rank)
-                d2 = {k: eng2.alloc(a.nbytes) for k, a in (("ref", ref_h), ("nv", nv_h), ("sc", sc_h))}
-                for k, a in (("ref", ref_h), ("nv", nv_h), ("sc", sc_h)):
-                    eng2.upload(d2[k], a)
-                d2.update(al=eng2.alloc(8 * B * n), cu=eng2.alloc(8 * B), st=eng2.alloc(4 * B))
-                pair = [(eng, d_ref, d_nv, d_sc, d_alpha, d_curv, d_status), (eng2, d2["ref"], d2["nv"], d2["sc"], d2["al"], d2["cu"], d2["st"])]
-                def two(steps2):
-                    for e_ in (eng, eng2):
-                        e_.sync()
-                    t2 = time.perf_counter()
-                    for k in range(steps2):
-                        e_, r_, v_, s_, a_, c_, t_ = pair[k & 1]
-                        e_.solve_device(B, n, r_, v_, s_, KAPPA_BOUND, W_VEH, a_, c_, t_)
-                    for e_ in (eng, eng2):
-                        e_.sync()
-                    return (time.perf_counter() - t2) / steps2
-                two(4)
-                t_two = two(2 * max(args.steps, 5))
+                hs2 = 2 * max(args.steps, 5)
+                d_al2 = [d_alpha, eng.alloc(8 * B * n)]
+                d_cu2 = [d_curv, eng.alloc(8 * B)]
+                d_st2 = [d_status, eng.alloc(4 * B)]
+                lists = lambda k_: ([d_ref] * k_, [d_nv] * k_, [d_sc] * k_, [d_al2[q & 1] for q in range(k_)], [d_cu2[q & 1] for q in range(k_)],
+                                    [d_st2[q & 1] for q in range(k_)])
+                r_, v_, s_, a_, c_, t_ = lists(4)
+                eng.solve_device_stream(B, n, r_, v_, s_, KAPPA_BOUND, W_VEH, a_, c_, t_)
+                eng.sync()
+                r_, v_, s_, a_, c_, t_ = lists(hs2)
+                t2 = time.perf_counter()
+                eng.solve_device_stream(B, n, r_, v_, s_, KAPPA_BOUND, W_VEH, a_, c_, t_)
+                eng.sync()
+                t_two = (time.perf_counter() - t2) / hs2
                 out["device_resident_two_streams"] = {
-                    "value": B / t_two, "unit": "solves/s", "ms_per_step": 1e3 * t_two, "steps": 2 * max(args.steps, 5),
-                    "ratio_to_value": (B / t_two) / value,
-                    "alpha_equal": bool(np.array_equal(eng2.download(d2["al"], (B, n), np.float64), alpha_gpu)),
-                    "what": "the timed loop of `value` with consecutive steps on two streams (two engine handles): the launches overlap, so a "
-                            "launch's tail -- 10.6 ms against ~9.4 ms of mean load -- is filled by the next one's workgroups.  Not the headline: "
-                            "with two launches in flight a kernel's own duration no longer measures a step"}
-                eng2.close()
+                    "value": B / t_two, "unit": "solves/s", "ms_per_step": 1e3 * t_two, "steps": hs2, "ratio_to_value": (B / t_two) / value,
+                    "alpha_equal": bool(np.array_equal(eng.download(d_al2[1], (B, n), np.float64), alpha_gpu)
+                                        and np.array_equal(eng.download(d_al2[0], (B, n), np.float64), alpha_gpu)),
+                    "what": "mcq_solve_device_stream: the timed loop of `value` as ONE call that alternates consecutive steps between the engine's two "
+                            "compute streams (a workspace each): the launches overlap, so a launch's tail -- 10.4 ms against ~9.4 ms of mean load -- is "
+                            "filled by the next one's workgroups.  Not the headline: with two launches in flight a kernel's own duration no longer "
+                            "measures a step"}
             except Exception as e:      # (a side record must not cost the line)
                 out["device_resident_two_streams"] = {"error": str(e)[:200]}
             # ---- config 3 is mincurv_iqp: the whole iqp_handler chain of the same tracks as one engine call ------------------------

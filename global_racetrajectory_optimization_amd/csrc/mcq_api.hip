@@ -37,6 +37,7 @@ struct mcq_handle {
     hipStream_t stream = nullptr;
     hipEvent_t ev[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};
     bool timing_valid = false;
+    hipEvent_t ev_st[2] = {nullptr, nullptr};       // mcq_solve_device_stream: joins the second compute stream to the first and back
     hipEvent_t ev_span[2] = {nullptr, nullptr};     // mcq_timing_begin / mcq_timing_end: a span of launches on the compute stream
     int span_launches = 0;
     bool span_open = false;
@@ -232,6 +233,7 @@ extern "C" void mcq_destroy(mcq_handle* h)
     if (h->pin) (void)hipHostFree(h->pin);
     for (int k = 0; k < 5; ++k) if (h->ev[k]) (void)hipEventDestroy(h->ev[k]);
     for (int k = 0; k < 2; ++k) if (h->ev_span[k]) (void)hipEventDestroy(h->ev_span[k]);
+    for (int k = 0; k < 2; ++k) if (h->ev_st[k]) (void)hipEventDestroy(h->ev_st[k]);
     if (h->stream) (void)hipStreamDestroy(h->stream);
     delete h;
 }
@@ -1428,6 +1430,54 @@ extern "C" int mcq_solve_batch(mcq_handle* h, const mcq_problem* probs, int batc
         memcpy(alpha_out + off, P.alpha + (size_t)b * nmax, n * sizeof(double));
         off += n;
         if (info_out) info_out[b] = P.info[b];
+    }
+    return 0;
+}
+
+// ---- a stream of RESIDENT uniform batches on the handle's two compute streams (include/mcq.h) ---------------------------------------------
+extern "C" int mcq_solve_device_stream(mcq_handle* h, int steps, int batch, int n, const double* const* reftrack, const double* const* normvec,
+                                       const double* const* scaling, double kappa_bound, double w_veh, const mcq_opts* opts,
+                                       double* const* alpha_out, double* const* curv_err_out, int* const* status_out)
+{
+    if (!h || steps <= 0 || batch <= 0 || n <= 0 || !reftrack || !alpha_out || !curv_err_out || !status_out) {
+        g_err = "mcq_solve_device_stream: bad argument";
+        return MCQ_E_ARG;
+    }
+    for (int k = 0; k < steps; ++k)
+        if (!reftrack[k] || !alpha_out[k] || !curv_err_out[k] || !status_out[k]) { g_err = "mcq_solve_device_stream: NULL buffer in step list"; return MCQ_E_ARG; }
+    HIP_TRY(hipSetDevice(h->device));
+    const mcq_opts o = resolve_opts(opts);
+    int rc = ensure_ws(h, (size_t)batch, (size_t)n);
+    if (rc) return rc;
+    const bool two = steps > 1 && !getenv("MCQ_PIPE_ONE_STREAM");
+    if (two) { rc = ensure_alt(h, (size_t)batch, (size_t)n); if (rc) return rc; }
+    // the second stream starts behind whatever the caller has enqueued on the first (uploads of the inputs, an earlier call)
+    if (two) {
+        for (int k = 0; k < 2; ++k) if (!h->ev_st[k]) HIP_TRY(hipEventCreate(&h->ev_st[k]));
+        HIP_TRY(hipEventRecord(h->ev_st[0], h->stream));
+        HIP_TRY(hipStreamWaitEvent(h->stream2, h->ev_st[0], 0));
+    }
+    for (int k = 0; k < steps; ++k) {
+        McqBatch B;
+        memset(&B, 0, sizeof(B));
+        B.batch = batch;
+        B.n = n;
+        B.nmax = n;
+        B.ref = reftrack[k];
+        B.nv = normvec ? normvec[k] : nullptr;
+        B.sc = (scaling && B.nv) ? scaling[k] : nullptr;
+        B.alpha = alpha_out[k];
+        B.curv_err = curv_err_out[k];
+        B.status = status_out[k];
+        B.kappa_bound = kappa_bound;
+        B.w_veh = w_veh;
+        rc = launch(h, B, o, two && (k & 1));
+        if (rc) { (void)hipStreamSynchronize(h->stream); if (h->stream2) (void)hipStreamSynchronize(h->stream2); return rc; }
+    }
+    // the handle's first stream ends behind the second one: mcq_sync / a later call on the handle sees every step done
+    if (two) {
+        HIP_TRY(hipEventRecord(h->ev_st[1], h->stream2));
+        HIP_TRY(hipStreamWaitEvent(h->stream, h->ev_st[1], 0));
     }
     return 0;
 }

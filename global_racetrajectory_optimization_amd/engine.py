@@ -60,7 +60,7 @@ IQP_TRACE = 16      # MCQ_IQP_TRACE
 EXPORTED_SYMBOLS = ("mcq_create", "mcq_destroy", "mcq_last_error", "mcq_default_opts", "mcq_solve_batch", "mcq_solve_host",
                     "mcq_iqp_device", "mcq_iqp_batch", "mcq_iqp_set_round_callback", "mcq_host_alloc", "mcq_host_free",
                     "mcq_solve_device", "mcq_solve_device_f32", "mcq_solve_device_f32_rows", "mcq_solve_batch_f32",
-                    "mcq_solve_host_pipelined", "mcq_solve_device_ragged", "mcq_solve_device_ragged_params", "mcq_prep_device", "mcq_relinearise_device",
+                    "mcq_solve_host_pipelined", "mcq_solve_device_stream", "mcq_solve_device_ragged", "mcq_solve_device_ragged_params", "mcq_prep_device", "mcq_relinearise_device",
                     "mcq_vel_profile_device", "mcq_vel_profile_device_ragged", "mcq_vel_profile_device_opts", "mcq_raceline_device", "mcq_normals_crossing_device",
                     "mcq_device_alloc",
                     "mcq_device_free", "mcq_copy_to_device", "mcq_copy_to_host", "mcq_sync", "mcq_stream",
@@ -123,6 +123,8 @@ def load_library(path=None):
     lib.mcq_solve_host_pipelined.argtypes = [vp, ctypes.c_int, ctypes.c_int, ctypes.c_int, vp, vp, vp, ctypes.c_double, ctypes.c_double,
                                              ctypes.POINTER(McqOpts), vp, vp, vp]
     lib.mcq_solve_host_pipelined.restype = ctypes.c_int
+    lib.mcq_solve_device_stream.argtypes = lib.mcq_solve_host_pipelined.argtypes
+    lib.mcq_solve_device_stream.restype = ctypes.c_int
     lib.mcq_solve_device_ragged.argtypes = [vp, ctypes.c_int, ctypes.c_int, vp, vp, vp, vp, ctypes.c_double,
                                             ctypes.c_double, ctypes.POINTER(McqOpts), vp, vp, vp, vp]
     lib.mcq_solve_device_ragged.restype = ctypes.c_int
@@ -345,6 +347,23 @@ class Engine:
                                      ctypes.addressof(info))
         self._check(rc, "mcq_solve_host")
         return alpha, curv, status, info
+
+    def solve_device_stream(self, batch, n, d_reftracks, d_normvecs, d_scalings, kappa_bound, w_veh, d_alphas, d_curvs, d_statuses, **opt_kw):
+        """A stream of resident uniform batches on the engine's two compute streams (mcq_solve_device_stream): lists of raw device pointers, one
+        entry per step (d_normvecs / d_scalings: None, or lists whose entries may be None).  Asynchronous: sync() waits for every step."""
+        steps = len(d_reftracks)
+
+        def arr(seq):
+            if seq is None:
+                return None
+            a = (ctypes.c_void_p * steps)()
+            for k, p in enumerate(seq):
+                a[k] = p
+            return a
+        opts = self._opts(**opt_kw)
+        rc = self.lib.mcq_solve_device_stream(self.h, steps, int(batch), int(n), arr(d_reftracks), arr(d_normvecs), arr(d_scalings),
+                                              float(kappa_bound), float(w_veh), ctypes.byref(opts), arr(d_alphas), arr(d_curvs), arr(d_statuses))
+        self._check(rc, "mcq_solve_device_stream")
 
     def host_array(self, shape, dtype=np.float64):
         """numpy array backed by pinned (page-locked) host memory of the engine (mcq_host_alloc).  LIFETIME: the memory belongs to

@@ -300,6 +300,16 @@ int mcq_solve_host_pipelined(mcq_handle* h, int steps, int batch, int n, const d
                              const double* const* scaling, double kappa_bound, double w_veh, const mcq_opts* opts,
                              double* const* alpha_out, double* const* curv_err_out, int* const* status_out);
 
+/* The same for batches already RESIDENT in device memory (round 5): arrays of `steps` DEVICE pointers, layouts as for mcq_solve_device; normvec / scaling
+ * arrays or entries may be NULL.  The launches of consecutive steps alternate between the handle's two compute streams (a workspace each), so a
+ * step's slowest problems finish while the next step's workgroups already fill the compute units the others have left: 113 k solves/s where
+ * launch-by-launch calls of mcq_solve_device give 98 k (1024 rings of 2000 waypoints).  The steps must be independent of each other (distinct
+ * output buffers; an input may repeat).  Asynchronous: ordered behind what the handle's stream holds when it is called; mcq_sync (or any later
+ * call on the handle) waits for every step.  Results of step k are bitwise those of mcq_solve_device on the same buffers. */
+int mcq_solve_device_stream(mcq_handle* h, int steps, int batch, int n, const double* const* reftrack, const double* const* normvec,
+                            const double* const* scaling, double kappa_bound, double w_veh, const mcq_opts* opts, double* const* alpha_out,
+                            double* const* curv_err_out, int* const* status_out);
+
 /* ---- tph.iqp_handler [REF main_globaltraj.py:273-284] as ONE call: the whole iterated re-linearisation of a batch of tracks.
  *
  * Every round is one batched QP pass (mcq_solve_device_ragged; passes 2+ warm-started from the working set the glue carried

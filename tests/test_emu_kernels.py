@@ -677,6 +677,31 @@ def test_solve_host_pipelined_equals_solve_host(emu, golden):
         emu.solve_host(refs[0], nvs[0], scs[0], 0.12, 3.4, alpha_out=np.zeros((2, n), dtype=np.float32))
 
 
+def test_resident_stream_entry_matches_single_launches(emu, golden):
+    """mcq_solve_device_stream on the interpreter (its second stream and workspace are ordinary memory there): three resident batches, bitwise the
+    launch-by-launch results."""
+    g = golden["rounded_rectangle"]
+    n = g["reftrack"].shape[0]
+    ptr, want = [], []
+    for k in range(3):
+        ref = np.stack((g["reftrack"], g["reftrack"]))
+        ref[:, :, 2:] += 0.04 * k
+        nv, sc = np.stack((g["normvec"],) * 2), np.stack((g["scaling"],) * 2)
+        d = [emu.alloc(a.nbytes) for a in (ref, nv, sc)] + [emu.alloc(8 * 2 * n), emu.alloc(16), emu.alloc(8)]
+        for q, a in zip(d, (ref, nv, sc)):
+            emu.upload(q, a)
+        emu.solve_device(2, n, d[0], d[1], d[2], 0.12, 3.4, d[3], d[4], d[5])
+        want.append(emu.download(d[3], (2, n), np.float64))
+        emu.upload(d[3], np.zeros((2, n)))
+        ptr.append(d)
+    emu.solve_device_stream(2, n, [d[0] for d in ptr], [d[1] for d in ptr], [d[2] for d in ptr], 0.12, 3.4, [d[3] for d in ptr], [d[4] for d in ptr],
+                            [d[5] for d in ptr])
+    emu.sync()
+    for k in range(3):
+        assert np.array_equal(emu.download(ptr[k][3], (2, n), np.float64), want[k])
+        assert list(emu.download(ptr[k][5], (2,), np.int32)) == [0, 0]
+
+
 def _stadium(n, ls=120.0, r=40.0):
     """Two straights and two semicircles, n points equidistant in arclength (counter-clockwise)."""
     per = 2 * ls + 2 * np.pi * r

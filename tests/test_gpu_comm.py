@@ -137,3 +137,30 @@ def test_pipelined_host_entry_on_two_compute_streams_is_bitwise_the_blocking_ent
             ran += sum(1 for i in inf if i.gi_iters > 0)
         if opt:
             assert ran > 0, "max_as_iter = 1 sent no problem through the Goldfarb-Idnani path: the test exercises nothing"
+
+
+def test_resident_stream_entry_on_two_compute_streams_is_bitwise_the_single_launches(gpu_engine):
+    """mcq_solve_device_stream: five resident batches of different tracks through one call that alternates the engine's two compute streams,
+    against mcq_solve_device launch by launch -- bitwise; the call is asynchronous and joins the second stream back into the first (a download
+    right behind it sees every step)."""
+    from global_racetrajectory_optimization_amd import synthetic
+    eng = gpu_engine
+    B, n, K = 64, 700, 5
+    d_ref, d_nv, d_sc, d_al, d_cu, d_st, want = [], [], [], [], [], [], []
+    for k in range(K):
+        ref, nv, sc = synthetic.oval_batch(B, n=n, first=900 + 64 * k, perturb_centreline=True)
+        p = [eng.alloc(a.nbytes) for a in (ref, nv, sc)]
+        for q, a in zip(p, (ref, nv, sc)):
+            eng.upload(q, a)
+        d_ref.append(p[0]); d_nv.append(p[1] if k != 2 else None); d_sc.append(p[2] if k != 2 else None)
+        d_al.append(eng.alloc(8 * B * n)); d_cu.append(eng.alloc(8 * B)); d_st.append(eng.alloc(4 * B))
+        eng.solve_device(B, n, p[0], d_nv[-1], d_sc[-1], 0.12, 3.4, d_al[-1], d_cu[-1], d_st[-1])
+        want.append((eng.download(d_al[-1], (B, n), np.float64), eng.download(d_cu[-1], (B,), np.float64), eng.download(d_st[-1], (B,), np.int32)))
+        eng.upload(d_al[-1], np.full((B, n), np.nan))
+    eng.solve_device_stream(B, n, d_ref, d_nv, d_sc, 0.12, 3.4, d_al, d_cu, d_st)
+    for k in range(K):          # (no sync() in between: the blocking download is ordered behind the call)
+        a = eng.download(d_al[k], (B, n), np.float64)
+        assert np.array_equal(a, want[k][0]) and np.array_equal(eng.download(d_cu[k], (B,), np.float64), want[k][1]), k
+        assert np.all(eng.download(d_st[k], (B,), np.int32) == 0)
+    for p in d_ref + [q for q in d_nv if q] + [q for q in d_sc if q] + d_al + d_cu + d_st:
+        eng.free(p)
