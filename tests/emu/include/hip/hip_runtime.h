@@ -49,9 +49,49 @@ inline Idx& bidx() { static Idx v; return v; }
 inline Idx& bdim() { static Idx v; return v; }
 inline Idx& gdim() { static Idx v; return v; }
 
+// Fiber switch.  glibc's swapcontext saves and restores the signal mask with one system call per switch -- hundreds of millions of them per test
+// run, half the interpreter's time.  On x86-64 the switch is done by hand instead (callee-saved registers, mxcsr and the x87 control word on the
+// fiber's own stack, then the stack pointer is exchanged); other hosts keep ucontext.
+#if defined(__x86_64__)
+#define HIPEMU_ASM_SWITCH 1
+extern "C" void hipemu_switch(void** save_sp, void* load_sp);
+__asm__(".text\n"
+        ".weak hipemu_switch\n"
+        ".hidden hipemu_switch\n"
+        ".type hipemu_switch,@function\n"
+        "hipemu_switch:\n"
+        "    pushq %rbp\n"
+        "    pushq %rbx\n"
+        "    pushq %r12\n"
+        "    pushq %r13\n"
+        "    pushq %r14\n"
+        "    pushq %r15\n"
+        "    subq $8, %rsp\n"
+        "    stmxcsr (%rsp)\n"
+        "    fnstcw 4(%rsp)\n"
+        "    movq %rsp, (%rdi)\n"
+        "    movq %rsi, %rsp\n"
+        "    ldmxcsr (%rsp)\n"
+        "    fldcw 4(%rsp)\n"
+        "    addq $8, %rsp\n"
+        "    popq %r15\n"
+        "    popq %r14\n"
+        "    popq %r13\n"
+        "    popq %r12\n"
+        "    popq %rbx\n"
+        "    popq %rbp\n"
+        "    ret\n"
+        ".size hipemu_switch, .-hipemu_switch\n");
+#endif
+
 struct State {
+#ifdef HIPEMU_ASM_SWITCH
+    void* main_sp = nullptr;
+    std::vector<void*> sp;
+#else
     ucontext_t main_ctx;
     std::vector<ucontext_t> ctx;
+#endif
     std::vector<char*> stacks;
     std::vector<char> done;
     int nt = 0, cur = 0, alive = 0;
@@ -68,11 +108,20 @@ struct State {
 };
 inline State& st() { static State s; return s; }
 
+inline void to_main(State& s)
+{
+#ifdef HIPEMU_ASM_SWITCH
+    hipemu_switch(&s.sp[s.cur], s.main_sp);
+#else
+    swapcontext(&s.ctx[s.cur], &s.main_ctx);
+#endif
+}
+
 inline void yield()
 {
     State& s = st();
     ++s.switches;
-    swapcontext(&s.ctx[s.cur], &s.main_ctx);
+    to_main(s);
 }
 
 inline void block_barrier()
@@ -100,7 +149,8 @@ inline void trampoline()
     s.body();
     s.done[s.cur] = 1;
     --s.alive;
-    swapcontext(&s.ctx[s.cur], &s.main_ctx);
+    to_main(s);          // (never resumed)
+    abort();
 }
 
 inline void* dyn_smem_ptr() { return st().dyn_smem.data(); }
@@ -113,7 +163,11 @@ inline void run_block(F&& f, unsigned nt, size_t smem)
     if ((int)s.stacks.size() < (int)nt) {
         for (size_t k = s.stacks.size(); k < nt; ++k) s.stacks.push_back((char*)malloc(STACK));
     }
+#ifdef HIPEMU_ASM_SWITCH
+    s.sp.resize(nt);
+#else
     s.ctx.resize(nt);
+#endif
     s.done.assign(nt, 0);
     s.nt = (int)nt;
     s.alive = (int)nt;
@@ -125,6 +179,24 @@ inline void run_block(F&& f, unsigned nt, size_t smem)
     s.slot_i.assign(nt, 0);
     if (s.dyn_smem.size() < smem + 64) s.dyn_smem.resize(smem + 64);
     s.body = f;
+#ifdef HIPEMU_ASM_SWITCH
+    unsigned int mxcsr;
+    unsigned short fpcw;
+    __asm__ volatile("stmxcsr %0" : "=m"(mxcsr));
+    __asm__ volatile("fnstcw %0" : "=m"(fpcw));
+    for (unsigned t = 0; t < nt; ++t) {
+        // the frame hipemu_switch pops on the first switch into this fiber: control words, r15 r14 r13 r12 rbx rbp, then `ret` into
+        // trampoline with the stack pointer where a call would have left it (16-byte boundary + 8)
+        void** p = (void**)((size_t)(s.stacks[t] + STACK) & ~(size_t)15);
+        *--p = nullptr;                            // the return address trampoline never uses
+        *--p = (void*)(void (*)())trampoline;
+        for (int k = 0; k < 6; ++k) *--p = nullptr;
+        --p;
+        ((unsigned int*)p)[0] = mxcsr;
+        ((unsigned int*)p)[1] = fpcw;
+        s.sp[t] = (void*)p;
+    }
+#else
     for (unsigned t = 0; t < nt; ++t) {
         getcontext(&s.ctx[t]);
         s.ctx[t].uc_stack.ss_sp = s.stacks[t];
@@ -132,6 +204,7 @@ inline void run_block(F&& f, unsigned nt, size_t smem)
         s.ctx[t].uc_link = &s.main_ctx;
         makecontext(&s.ctx[t], (void (*)())trampoline, 0);
     }
+#endif
     long long idle_rounds = 0;
     while (s.alive > 0) {
         const long long sw0 = s.switches;
@@ -145,7 +218,11 @@ inline void run_block(F&& f, unsigned nt, size_t smem)
             if (s.done[t]) continue;
             s.cur = (int)t;
             tidx().x = t;
+#ifdef HIPEMU_ASM_SWITCH
+            hipemu_switch(&s.main_sp, s.sp[t]);
+#else
             swapcontext(&s.main_ctx, &s.ctx[t]);
+#endif
         }
         (void)sw0;
         // progress detection: a full round in which nobody finished and no barrier generation advanced, repeated
