@@ -1452,10 +1452,11 @@ __device__ __noinline__ int active_set(const LCtx& c, bool with_kappa, bool tapi
         else if (with_kappa) return MCQ_ITER_CAP;
         else full = false;
         // (The single-pivot backup rule terminates on box rows alone -- the linear complementarity problem of a positive definite Hessian
-        //  with simple bounds -- and is kept for them.  With curvature rows in the exchange it has never been seen to end: of the 220
-        //  curvature-tight problems of tests/golden/kappa_tight_fuzz.npz every exchange that ends does so within 10 rounds without ever
-        //  reaching it, and the three that reach it cycle at ~80 rows until the cap, each round paying one solve per row.  The
-        //  Goldfarb-Idnani path takes over from here instead [docs/NOTEBOOK.md R5.6].)
+        //  with simple bounds -- and is kept for them.  With curvature rows in the exchange nothing promises that, and a round costs one
+        //  solve per curvature row: of the 220 curvature-tight problems of tests/golden/kappa_tight_fuzz.npz every exchange that ends
+        //  does so within 10 rounds without ever reaching the rule, and the three that reach it cycle at ~80 rows until the cap; the
+        //  720-point stadium (270 rows) did come back from it, after 19 more rounds -- no cheaper than the 370 steps of the
+        //  Goldfarb-Idnani path, which takes over from here instead [docs/NOTEBOOK.md R5.6].)
         for (int i = tid; i < n; i += MCQ_NT) {
             const int code = (int)T3[i];
             // decode v in {-1,0,1,2}, vk in {-1,0,1,2}:  code = v + 8 vk
