@@ -654,7 +654,7 @@ def main():
             except Exception as e:      # (a side record must not cost the line)
                 out["device_resident_two_streams"] = {"error": str(e)[:200]}
             # ---- config 3 is mincurv_iqp: the whole iqp_handler chain of the same tracks as one engine call ------------------------
-            trk = [dict(reftrack=ref_h[k], normvectors=nv_h[k], scaling=sc_h[k]) for k in range(B)]
+            trk = dict(reftrack=ref_h, normvectors=nv_h, scaling=sc_h)      # (stacked arrays: row k is track k)
             w0 = eng.iqp_batch(trk, KAPPA_BOUND, W_VEH, 3.0)  # first call: workspace + pinned staging of this size are allocated
             nmx = w0["stats"]["nmax"]
             # end states into page-locked arrays the caller keeps across calls (two calls timed: the fresh-array path is the one a
@@ -664,18 +664,29 @@ def main():
             iq0 = eng.iqp_batch(trk, KAPPA_BOUND, W_VEH, 3.0, iters_min=3, curv_error_allowed=0.01, nmax=nmx)
             t_iqp_fresh = time.perf_counter() - t1
             t1 = time.perf_counter()
-            iq = eng.iqp_batch(trk, KAPPA_BOUND, W_VEH, 3.0, iters_min=3, curv_error_allowed=0.01, timed=True, nmax=nmx, out=obuf)
+            iq = eng.iqp_batch(trk, KAPPA_BOUND, W_VEH, 3.0, iters_min=3, curv_error_allowed=0.01, nmax=nmx, out=obuf)
             t_iqp = time.perf_counter() - t1
             same = all(np.array_equal(a, b) for a, b in zip(iq0["alpha"], iq["alpha"]))
+            # per-pass figures need the host between the rounds: the same call with timed statistics (one launch per round over the whole
+            # batch, per-track records read back after every pass) -- its end states must be the same bit for bit
+            t1 = time.perf_counter()
+            iqt = eng.iqp_batch(trk, KAPPA_BOUND, W_VEH, 3.0, iters_min=3, curv_error_allowed=0.01, timed=True, nmax=nmx)
+            t_iqp_timed = time.perf_counter() - t1
+            same = same and all(np.array_equal(a, b) for a, b in zip(iq0["alpha"], iqt["alpha"]))
             out["iqp"] = {"value": iq["stats"]["qp_solves"] / t_iqp, "unit": "QP solves/s (end to end: host tracks in, end states out)",
                           "tracks": B, "seconds": t_iqp, "rounds": iq["stats"]["rounds"], "qp_solves": iq["stats"]["qp_solves"],
-                          "pass_ms": iq["stats"]["solver_ms"], "warm_start_fallbacks_per_pass": iq["stats"]["fallbacks"],
+                          "pass_ms": iqt["stats"]["solver_ms"], "warm_start_fallbacks_per_pass": iqt["stats"]["fallbacks"],
+                          "seconds_round_by_round_with_statistics": t_iqp_timed,
                           "failed_tracks": int(np.count_nonzero(iq["status"])), "n_final_range": [int(iq["n"].min()), int(iq["n"].max())],
-                          "seconds_fresh_output_arrays": t_iqp_fresh, "alpha_equal_between_the_two_calls": bool(same),
+                          "seconds_fresh_output_arrays": t_iqp_fresh, "alpha_equal_between_the_three_calls": bool(same),
+                          "groups": int(os.environ.get("MCQ_IQP_GROUPS", "2")),
                           "what": "mcq_iqp_batch: iqp_handler (stepsize_interp 3.0, iters_min 3, curv_error_allowed 0.01) of the %d tracks as one "
                                   "call -- QP passes, termination test, damping and re-linearisation glue on the device, passes 2+ warm-started; "
-                                  "pass_ms = launch sequence of each round's QP pass (HIP events); end states land in page-locked arrays kept by the caller "
-                                  "(seconds_fresh_output_arrays: the same call allocating and touching fresh numpy arrays)" % B}
+                                  "the first iters_min rounds run in `groups` groups of tracks, a stream each (a group waits for its own slowest "
+                                  "track only), the batch is packed into pinned staging by several host threads; end states land in page-locked "
+                                  "arrays kept by the caller (seconds_fresh_output_arrays: the same call allocating and touching fresh numpy "
+                                  "arrays).  pass_ms / fallbacks: from a third call with per-round statistics (one launch per round, HIP "
+                                  "events, records read back after every pass: seconds_round_by_round_with_statistics)" % B}
             if not args.no_cpu_baseline:
                 cb = cpu_baseline(ref_h, nv_h, sc_h, alpha_gpu, curv_gpu, args.cpu_a_sample, args.cpu_b_sample)
                 out["cpu_baseline"] = dict(cb["cpu_a"], also={"cpu_b": cb["cpu_b"]})

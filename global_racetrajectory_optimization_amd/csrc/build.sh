@@ -32,4 +32,4 @@ fi
 wait $P1 || { echo "build.sh: mcq_kernels.hip failed to compile" >&2; exit 1; }
 wait $P2 || { echo "build.sh: mcq_api.hip failed to compile" >&2; exit 1; }
 if [ -n "$P3" ]; then wait $P3 || { echo "build.sh: ISA dump failed" >&2; exit 1; }; fi
-$HIPCC --offload-arch=gfx950 -shared -fPIC -o $OUT $TMP/kernels.o $TMP/api.o -ldl      # (dlopen / dlsym of RCCL: glibc < 2.34 keeps them in libdl)
+$HIPCC --offload-arch=gfx950 -shared -fPIC -pthread -o $OUT $TMP/kernels.o $TMP/api.o -ldl      # (dlopen / dlsym of RCCL: glibc < 2.34 keeps them in libdl)

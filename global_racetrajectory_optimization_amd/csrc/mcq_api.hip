@@ -14,10 +14,15 @@
 
 #include <algorithm>
 #include <string>
+#include <thread>
 #include <vector>
 
 #include "mcq_kernels.h"
 
+#define MCQ_IQP_GROUPS_MAX 16
+#ifndef MCQ_IQP_GROUPS_DEFAULT
+#define MCQ_IQP_GROUPS_DEFAULT 2
+#endif
 static thread_local std::string g_err;
 
 #define HIP_TRY(expr)                                                                                     \
@@ -38,6 +43,10 @@ struct mcq_handle {
     hipEvent_t ev[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};
     bool timing_valid = false;
     hipEvent_t ev_st[2] = {nullptr, nullptr};       // mcq_solve_device_stream: joins the second compute stream to the first and back
+    // mcq_iqp_device: the batch in GROUPS of tracks, each with a stream of its own (a track's passes depend on nothing but its own previous
+    // pass: a group that waits for its slowest track holds up nobody else)
+    hipStream_t gs[MCQ_IQP_GROUPS_MAX] = {};
+    hipEvent_t gev[MCQ_IQP_GROUPS_MAX + 1] = {};
     hipEvent_t ev_span[2] = {nullptr, nullptr};     // mcq_timing_begin / mcq_timing_end: a span of launches on the compute stream
     int span_launches = 0;
     bool span_open = false;
@@ -234,6 +243,8 @@ extern "C" void mcq_destroy(mcq_handle* h)
     for (int k = 0; k < 5; ++k) if (h->ev[k]) (void)hipEventDestroy(h->ev[k]);
     for (int k = 0; k < 2; ++k) if (h->ev_span[k]) (void)hipEventDestroy(h->ev_span[k]);
     for (int k = 0; k < 2; ++k) if (h->ev_st[k]) (void)hipEventDestroy(h->ev_st[k]);
+    for (int k = 0; k < MCQ_IQP_GROUPS_MAX; ++k) if (h->gs[k]) { (void)hipStreamSynchronize(h->gs[k]); (void)hipStreamDestroy(h->gs[k]); }
+    for (int k = 0; k <= MCQ_IQP_GROUPS_MAX; ++k) if (h->gev[k]) (void)hipEventDestroy(h->gev[k]);
     if (h->stream) (void)hipStreamDestroy(h->stream);
     delete h;
 }
@@ -366,9 +377,12 @@ static int ensure_stage(mcq_handle* h, size_t batch, size_t nmax)
 }
 
 // alt: on the handle's second compute stream and workspace (ensure_alt; mcq_solve_host_pipelined's odd steps) -- no event timing there
-static int launch(mcq_handle* h, McqBatch& B, const mcq_opts& o, bool alt = false)
+// ov: the launch goes to THIS stream and covers the slice B.pb_base .. + B.pb_count of the batch (mcq_iqp_device's groups: the handle's
+// workspace and every per-problem array are indexed by the problem's number in the whole batch, so concurrent slices touch nothing in common
+// but the slot flags, which are claimed atomically); no timing events, and the warm start is the caller's call (ov_warm).
+static int launch(mcq_handle* h, McqBatch& B, const mcq_opts& o, bool alt = false, hipStream_t ov = nullptr, bool ov_warm = false)
 {
-    hipStream_t st = alt ? h->stream2 : h->stream;
+    hipStream_t st = ov ? ov : (alt ? h->stream2 : h->stream);
     B.L = alt ? h->L2 : h->L; B.vec = alt ? h->vec2 : h->vec; B.Z = alt ? h->Z2 : h->Z; B.state = alt ? h->state_alt : h->state;
     B.max_ipm_iter = o.max_ipm_iter;
     B.max_as_iter = o.max_as_iter;
@@ -391,6 +405,13 @@ static int launch(mcq_handle* h, McqBatch& B, const mcq_opts& o, bool alt = fals
     B.gi_slots = gi_on ? (alt ? h->gi2_slots : h->gi_slots) : 0;
     B.gi_qcap = B.nmax;
     // warm start: only the working sets mcq_relinearise_device carried over for exactly this batch layout
+    if (ov) {
+        if (alt || B.prep_only || B.objective == MCQ_OBJ_SHORTEST_PATH) { g_err = "launch: a slice launch is a plain solver launch on the first workspace"; return MCQ_E_ARG; }
+        B.warm = ov_warm ? h->state2 : nullptr;
+        hipLaunchKernelGGL(mcq_solve_kernel, dim3(B.pb_count > 0 ? B.pb_count : B.batch), dim3(256), 0, st, B);
+        HIP_TRY(hipGetLastError());
+        return 0;
+    }
     B.warm = (!alt && o.warm_start > 0 && h->state2_valid && !B.prep_only && h->state2_batch == B.batch && h->state2_nmax == B.nmax)
                  ? h->state2 : nullptr;
     if (!B.prep_only && !alt) h->state2_valid = false;
@@ -663,10 +684,12 @@ extern "C" int mcq_normals_crossing_device(mcq_handle* h, int batch, int nmax, c
     return 0;
 }
 
-extern "C" int mcq_relinearise_device(mcq_handle* h, int batch, int nmax, const int* n_in, const double* reftrack_in,
-                                      const double* normvec_in, const double* alpha, const int* live, double alpha_scale,
-                                      double stepsize, double* reftrack_out, double* normvec_out, int* n_out,
-                                      int* status_out)
+// st / base / count: the launch covers tracks base .. base + count - 1 on stream st (mcq_iqp_device's groups); the ABI entry passes the
+// handle's stream and the whole batch
+static int relinearise_launch(mcq_handle* h, int batch, int nmax, const int* n_in, const double* reftrack_in,
+                              const double* normvec_in, const double* alpha, const int* live, double alpha_scale,
+                              double stepsize, double* reftrack_out, double* normvec_out, int* n_out,
+                              int* status_out, hipStream_t st, int base, int count)
 {
     if (!h || batch <= 0 || nmax <= 0 || !n_in || !reftrack_in || !normvec_in || !alpha || !reftrack_out || !normvec_out ||
         !n_out || !status_out || !(stepsize > 0.0) || reftrack_in == reftrack_out || normvec_in == normvec_out) {
@@ -697,9 +720,20 @@ extern "C" int mcq_relinearise_device(mcq_handle* h, int batch, int nmax, const 
     h->state2_valid = true;
     h->state2_batch = batch;
     h->state2_nmax = nmax;
-    hipLaunchKernelGGL(mcq_relinearise_kernel, dim3(batch), dim3(256), 0, h->stream, R);
+    R.pb_base = base;
+    hipLaunchKernelGGL(mcq_relinearise_kernel, dim3(count), dim3(256), 0, st, R);
     HIP_TRY(hipGetLastError());
     return 0;
+}
+
+extern "C" int mcq_relinearise_device(mcq_handle* h, int batch, int nmax, const int* n_in, const double* reftrack_in,
+                                      const double* normvec_in, const double* alpha, const int* live, double alpha_scale,
+                                      double stepsize, double* reftrack_out, double* normvec_out, int* n_out,
+                                      int* status_out)
+{
+    if (!h) { g_err = "mcq_relinearise_device: bad argument"; return MCQ_E_ARG; }
+    return relinearise_launch(h, batch, nmax, n_in, reftrack_in, normvec_in, alpha, live, alpha_scale, stepsize, reftrack_out, normvec_out,
+                              n_out, status_out, h->stream, 0, batch);
 }
 
 static int vel_profile_launch(mcq_handle* h, int batch, int n, int nmax, const int* n_of_track, const int* track_of,
@@ -1240,7 +1274,91 @@ extern "C" int mcq_iqp_device(mcq_handle* h, int batch, int nmax, int* n_io, dou
     HIP_TRY(hipMemsetAsync(d_final_n, 0, batch * sizeof(int), h->stream));
     S.final_n = d_final_n;
     int err = 0;
-    for (int it = 1; it <= max_rounds && n_live > 0 && !err; ++it) {
+    int it0 = 1;
+    // ---- The first iters_min rounds in GROUPS of tracks, a stream each.  A track's passes depend on nothing but its own previous pass, and no
+    //      track can end before round iters_min, so nothing has to come back to the host in between; but run as ONE launch per round, every
+    //      round ends with its slowest track -- a warm start that falls back to the cold path takes 8.9 ms where the others take 2.5-4 -- and
+    //      the next round's launch waits for it with most compute units idle (third pass of the 1024 ovals: 6.5 ms of mean load, 11.5 ms of
+    //      launch).  A group waits for ITS slowest track only, and the other groups' launches fill the compute units meanwhile.  The arrays are
+    //      the same (a slice launch indexes them by the track's number in the whole batch), the results bitwise those of the round-by-round
+    //      loop below, which takes over after round iters_min (and runs everything when per-round data must reach the host: timed statistics,
+    //      the print_debug callback).  $MCQ_IQP_GROUPS: number of groups (default MCQ_IQP_GROUPS_DEFAULT; 1 = off); 64 tracks per group at least. ----
+    int G = 1;
+    {
+        const char* e = getenv("MCQ_IQP_GROUPS");
+        int want = e && *e ? atoi(e) : MCQ_IQP_GROUPS_DEFAULT;
+        if (want > MCQ_IQP_GROUPS_MAX) want = MCQ_IQP_GROUPS_MAX;
+        const int most = e && *e ? batch : batch / 64;          // (asked for explicitly: groups of any size -- the tests run three groups of two tracks)
+        G = want < most ? want : most;
+        if (G < 1) G = 1;
+    }
+    if (G > 1 && !timed && !h->iqp_cb) {
+        const int ra = iters_min < max_rounds ? iters_min : max_rounds;
+        int* gcount = h->d_iqp + (size_t)8 * batch;          // live tracks per group (ensure_iqp: 16 ints behind the bookkeeping arrays)
+        for (int g = 1; g < G; ++g) {          // (group 0 runs on the handle's own stream)
+            if (!h->gs[g]) HIP_TRY(hipStreamCreate(&h->gs[g]));
+            if (!h->gev[g]) HIP_TRY(hipEventCreate(&h->gev[g]));
+        }
+        if (!h->gev[MCQ_IQP_GROUPS_MAX]) HIP_TRY(hipEventCreate(&h->gev[MCQ_IQP_GROUPS_MAX]));
+        HIP_TRY(hipEventRecord(h->gev[MCQ_IQP_GROUPS_MAX], h->stream));       // the set-up above
+        for (int g = 0; g < G && !err; ++g) {
+            const int base = (int)((long long)batch * g / G), cnt = (int)((long long)batch * (g + 1) / G) - base;
+            hipStream_t st = g == 0 ? h->stream : h->gs[g];
+            if (g > 0 && hipStreamWaitEvent(st, h->gev[MCQ_IQP_GROUPS_MAX], 0) != hipSuccess) { err = MCQ_E_DEVICE; break; }
+            int cg = 0;
+            for (int it = 1; it <= ra && !err; ++it) {
+                McqBatch B;
+                memset(&B, 0, sizeof(B));
+                B.batch = batch;
+                B.n = nmax;
+                B.nmax = nmax;
+                B.n_list = n_set[cg];
+                B.ref = ref_set[cg];
+                B.nv = nv_set[cg];
+                B.sc = it == 1 ? scaling : nullptr;
+                B.alpha = alpha_out;
+                B.curv_err = pass_curv;
+                B.status = pass_status;
+                B.kappa_bound = kappa_bound;
+                B.w_veh = w_veh;
+                B.pb_base = base;
+                B.pb_count = cnt;
+                if ((err = launch(h, B, o, false, st, warm && it > 1)) != 0) break;
+                if (hipMemsetAsync(gcount + g, 0, sizeof(int), st) != hipSuccess) { err = MCQ_E_DEVICE; break; }
+                S.phase = 0;
+                S.round = it;
+                S.cur = cg;
+                S.n_ring = n_set[cg];
+                S.n_next = n_set[1 - cg];
+                S.k_base = base;
+                S.k_count = cnt;
+                S.live_count = gcount + g;
+                hipLaunchKernelGGL(mcq_iqp_step_kernel, dim3((unsigned)((cnt + 255) / 256)), sblock, 0, st, S);
+                const double scale = it < iters_min ? (double)it / (double)iters_min : 1.0;
+                if ((err = relinearise_launch(h, batch, nmax, n_set[cg], ref_set[cg], nv_set[cg], alpha_out, live, scale, stepsize_interp,
+                                              ref_set[1 - cg], nv_set[1 - cg], n_set[1 - cg], rst, st, base, cnt)) != 0) break;
+                S.phase = 1;
+                hipLaunchKernelGGL(mcq_iqp_step_kernel, dim3((unsigned)((cnt + 255) / 256)), sblock, 0, st, S);
+                if (hipGetLastError() != hipSuccess) { err = MCQ_E_DEVICE; break; }
+                cg = 1 - cg;
+            }
+            if (!err && g > 0 && (hipEventRecord(h->gev[g], st) != hipSuccess || hipStreamWaitEvent(h->stream, h->gev[g], 0) != hipSuccess)) err = MCQ_E_DEVICE;
+        }
+        if (err) { (void)hipStreamSynchronize(h->stream); for (int g = 1; g < G; ++g) (void)hipStreamSynchronize(h->gs[g]); }
+        S.k_base = 0;
+        S.k_count = 0;
+        S.live_count = live_count;
+        if (!err) {
+            int hc[MCQ_IQP_GROUPS_MAX];
+            if (hipMemcpyAsync(hc, gcount, G * sizeof(int), hipMemcpyDeviceToHost, h->stream) != hipSuccess ||
+                hipStreamSynchronize(h->stream) != hipSuccess) err = MCQ_E_DEVICE;
+            else { n_live = 0; for (int g = 0; g < G; ++g) n_live += hc[g]; }
+            cur = ra & 1;
+            rounds = ra;
+            it0 = ra + 1;
+        }
+    }
+    for (int it = it0; it <= max_rounds && n_live > 0 && !err; ++it) {
         rounds = it;
         McqBatch B;
         memset(&B, 0, sizeof(B));
@@ -1352,22 +1470,53 @@ static int pack_and_upload(mcq_handle* h, const mcq_problem* probs, int batch, s
     P.info = (mcq_info*)(P.wv + batch);
     P.n = (int*)(P.info + batch);
     // (the padding behind a track's n waypoints is never read by a kernel: no need to clear it)
-    for (int b = 0; b < batch; ++b) {
-        const size_t n = (size_t)probs[b].n;
-        memcpy(P.ref + (size_t)b * nmax * 4, probs[b].reftrack, n * 4 * sizeof(double));
-        if (with_nv) memcpy(P.nv + (size_t)b * nmax * 2, probs[b].normvec, n * 2 * sizeof(double));
-        if (any_sc) {
-            if (probs[b].scaling) memcpy(P.sc + (size_t)b * nmax, probs[b].scaling, n * sizeof(double));
-            else for (size_t q = 0; q < n; ++q) P.sc[(size_t)b * nmax + q] = 1.0;
+    auto pack_range = [&](int b0, int b1) {
+        for (int b = b0; b < b1; ++b) {
+            const size_t n = (size_t)probs[b].n;
+            memcpy(P.ref + (size_t)b * nmax * 4, probs[b].reftrack, n * 4 * sizeof(double));
+            if (with_nv) memcpy(P.nv + (size_t)b * nmax * 2, probs[b].normvec, n * 2 * sizeof(double));
+            if (any_sc) {
+                if (probs[b].scaling) memcpy(P.sc + (size_t)b * nmax, probs[b].scaling, n * sizeof(double));
+                else for (size_t q = 0; q < n; ++q) P.sc[(size_t)b * nmax + q] = 1.0;
+            }
+            P.kb[b] = probs[b].kappa_bound;
+            P.wv[b] = probs[b].w_veh;
+            P.n[b] = probs[b].n;
         }
-        P.kb[b] = probs[b].kappa_bound;
-        P.wv[b] = probs[b].w_veh;
-        P.n[b] = probs[b].n;
-    }
+    };
+    // A large batch (the 1024 N = 2000 tracks of the bench: 115 MB) is packed in four chunks of tracks by several host threads, and a
+    // chunk's uploads are queued as soon as it is packed: one thread copies at ~10 GB/s -- 11 ms, a quarter of the whole mcq_iqp_batch
+    // call -- and the DMA of chunk k runs while chunk k + 1 is packed.  $MCQ_PACK_THREADS: threads (default 8 for batches above 8 MB; 1 = the single loop).
+    const size_t row_doubles = 4 + (with_nv ? 2 : 0) + (any_sc ? 1 : 0);
+    const size_t payload = elems * row_doubles * sizeof(double);
+    const char* pt = getenv("MCQ_PACK_THREADS");
+    const bool forced = pt && *pt;          // (asked for explicitly: whatever the size of the batch -- the tests pack six small tracks on three threads)
+    int nthreads = forced ? atoi(pt) : (payload > ((size_t)8 << 20) && batch >= 16 ? 8 : 1);
+    const int hw = (int)std::thread::hardware_concurrency();
+    if (hw > 0 && nthreads > hw) nthreads = hw;
+    if (nthreads > batch) nthreads = batch;
+    if (nthreads < 1) nthreads = 1;
+    int nchunks = (forced && nthreads > 1) || (payload > ((size_t)32 << 20) && batch >= 16) ? 4 : 1;
+    if (nchunks > batch) nchunks = batch;
     (void)who;
-    HIP_TRY_SYNC(hipMemcpyAsync(h->d_ref, P.ref, elems * 4 * sizeof(double), hipMemcpyHostToDevice, h->stream));
-    if (with_nv) HIP_TRY_SYNC(hipMemcpyAsync(h->d_nv, P.nv, elems * 2 * sizeof(double), hipMemcpyHostToDevice, h->stream));
-    if (any_sc) HIP_TRY_SYNC(hipMemcpyAsync(h->d_sc, P.sc, elems * sizeof(double), hipMemcpyHostToDevice, h->stream));
+    for (int ck = 0; ck < nchunks; ++ck) {
+        const int b0 = (int)((long long)batch * ck / nchunks), b1 = (int)((long long)batch * (ck + 1) / nchunks);
+        if (nthreads > 1) {
+            auto sub = [&](int t) { return b0 + (int)((long long)(b1 - b0) * t / nthreads); };
+            std::vector<std::thread> th;
+            int taken = 1;          // sub-ranges 0 .. taken - 1 have a thread (0: this one)
+            try {
+                for (; taken < nthreads; ++taken) th.emplace_back(pack_range, sub(taken), sub(taken + 1));
+            } catch (...) {}        // (no more threads to be had: their sub-ranges are packed here)
+            pack_range(sub(0), sub(1));
+            for (int t = taken; t < nthreads; ++t) pack_range(sub(t), sub(t + 1));
+            for (auto& t : th) t.join();
+        } else pack_range(b0, b1);
+        const size_t off = (size_t)b0 * nmax, cnt = (size_t)(b1 - b0) * nmax;
+        HIP_TRY_SYNC(hipMemcpyAsync(h->d_ref + off * 4, P.ref + off * 4, cnt * 4 * sizeof(double), hipMemcpyHostToDevice, h->stream));
+        if (with_nv) HIP_TRY_SYNC(hipMemcpyAsync(h->d_nv + off * 2, P.nv + off * 2, cnt * 2 * sizeof(double), hipMemcpyHostToDevice, h->stream));
+        if (any_sc) HIP_TRY_SYNC(hipMemcpyAsync(h->d_sc + off, P.sc + off, cnt * sizeof(double), hipMemcpyHostToDevice, h->stream));
+    }
     HIP_TRY_SYNC(hipMemcpyAsync(h->d_kb, P.kb, batch * sizeof(double), hipMemcpyHostToDevice, h->stream));
     HIP_TRY_SYNC(hipMemcpyAsync(h->d_wv, P.wv, batch * sizeof(double), hipMemcpyHostToDevice, h->stream));
     HIP_TRY_SYNC(hipMemcpyAsync(h->d_n, P.n, batch * sizeof(int), hipMemcpyHostToDevice, h->stream));

@@ -105,6 +105,8 @@ struct McqBatch {
     double* gi;             // slots of the Goldfarb-Idnani path (mcq_gi.inc), MCQ_GI_SLOT_DOUBLES(nmax, gi_qcap) doubles each: a workgroup whose
     int gi_slots, gi_qcap;  // problem needs the path claims one (and waits for one if all are taken); gi_qcap = constraints a working set can
                             // hold (= nmax: no more can be independent)
+    int pb_base, pb_count;  // a launch over a SLICE of the batch (mcq_iqp_device's groups, each on a stream of its own): workgroup w works on problem
+                            // pb_base + w of the same arrays; pb_count = workgroups of the launch (0: the whole batch from 0)
 };
 
 __global__ void mcq_assemble_kernel(McqBatch B);
@@ -149,6 +151,7 @@ struct McqRelin {
     double* vec;            // workspace, [batch][MCQ_NVEC][nmax] (the solver's vector slab)
     const signed char* state_in;   // [batch][nmax] working set the solver left for these tracks (or nullptr)
     signed char* state_out;        // [batch][nmax] the same carried to the re-sampled rings (warm start of the next pass)
+    int pb_base;                   // a launch over a slice of the batch: workgroup w works on track pb_base + w
 };
 __global__ void mcq_relinearise_kernel(McqRelin R);
 
@@ -169,6 +172,7 @@ struct McqIqpStep {
     int* final_n; int* final_buf; double* final_curv; int* final_status; int* final_rounds;
     double* curv_trace;         // [batch][MCQ_IQP_TRACE] or nullptr
     int* live_count;
+    int k_base, k_count;        // a launch over a slice of the batch: tracks k_base .. k_base + k_count - 1 (k_count 0: all)
 };
 __global__ void mcq_iqp_step_kernel(McqIqpStep S);
 

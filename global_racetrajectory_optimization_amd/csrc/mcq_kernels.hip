@@ -1651,7 +1651,8 @@ __global__ void __launch_bounds__(MCQ_NT, 2) mcq_solve_kernel(McqBatch B)
     }
     const long long t_kernel0 = TICK();
     const long long c_kernel0 = (long long)clock64();      // shader-clock counter (s_memtime): with ticks[3] the effective clock
-    ctx_set_problem(B, blockIdx.x, n, kbound, wveh);
+    const int pb = (int)blockIdx.x + B.pb_base;          // (pb_base: a launch over a slice of the batch, see McqBatch)
+    ctx_set_problem(B, pb, n, kbound, wveh);
     const LCtx& c = G_CTX;
     ctx_set_solve(B, kbound);
     if (B.objective == MCQ_OBJ_SHORTEST_PATH) {
@@ -1692,7 +1693,7 @@ __global__ void __launch_bounds__(MCQ_NT, 2) mcq_solve_kernel(McqBatch B)
     //      exact KKT point either way; if the exchange runs out of its rounds the cold path below takes over. ----
     bool warm_done = false;
     if (B.warm && small && !gi_only) {
-        const gschar* WS = (const gschar*)(B.warm + (size_t)blockIdx.x * nm);
+        const gschar* WS = (const gschar*)(B.warm + (size_t)pb * nm);
         for (int i = tid; i < n; i += MCQ_NT)
             if (ST[i] == 0) { const signed char s = WS[i]; ST[i] = (s == 1 || s == -1) ? s : (signed char)0; }
         __syncthreads();
@@ -1962,7 +1963,7 @@ __device__ __forceinline__ int relin_front(const gdouble* ref, const gdouble* nv
 
 __global__ void __launch_bounds__(MCQ_NT) mcq_relinearise_kernel(McqRelin R)
 {
-    const int tid = threadIdx.x, pb = blockIdx.x;
+    const int tid = threadIdx.x, pb = (int)blockIdx.x + R.pb_base;
     if (R.live && R.live[pb] == 0) return;
     const size_t nm = (size_t)R.nmax;
     const int n = R.n_in[pb];
@@ -2040,8 +2041,8 @@ __global__ void __launch_bounds__(MCQ_NT) mcq_relinearise_kernel(McqRelin R)
 // ---- iqp_handler's bookkeeping between the passes (see McqIqpStep) -------------------------------------------------------------------
 __global__ void __launch_bounds__(256) mcq_iqp_step_kernel(McqIqpStep S)
 {
-    const int k = blockIdx.x * 256 + threadIdx.x;
-    if (k >= S.batch) return;
+    const int k = S.k_base + (int)blockIdx.x * 256 + (int)threadIdx.x;
+    if (k >= (S.k_count > 0 ? S.k_base + S.k_count : S.batch)) return;
     if (S.phase == 0) {
         if (S.live[k] == 0) return;
         const int st = S.status[k];

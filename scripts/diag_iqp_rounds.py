@@ -28,6 +28,7 @@ def main():
     ap.add_argument("--passes", type=int, default=3)
     ap.add_argument("--iters-min", type=int, default=3)
     ap.add_argument("--cold", action="store_true", help="no warm start of passes 2+")
+    ap.add_argument("--dump", default=None, help="write every pass's per-track mcq_info records to this .npz")
     args = ap.parse_args()
     assert INFO_DTYPE.itemsize == ctypes.sizeof(engine.McqInfo)
     eng = engine.Engine(0)
@@ -52,6 +53,7 @@ def main():
     d_rst = eng.alloc(bsz * 4)
     cur = 0
     eng.prep_batch([ref_h[0, :n]] * 2)          # HIP module load
+    dump = {}
     for it in range(1, args.passes + 1):
         # (a warm start is consumed by the launch that uses it: one timed launch per pass; the workspace is grown beforehand)
         eng.solve_device_ragged(bsz, nmax, d_n[cur], d_ref[cur], d_nv[cur], d_sc if it == 1 else None, 0.12, 3.4, d_alpha,
@@ -62,6 +64,9 @@ def main():
         status = eng.download(d_status, (bsz,), np.int32)
         curv = eng.download(d_curv, (bsz,), np.float64)
         t = info["ticks"].astype(np.float64) / 1e5
+        for key in ("ipm_iters", "as_iters", "n_active_box", "second_attempt"):
+            dump["pass%d_%s" % (it, key)] = np.array(info[key])
+        dump["pass%d_kernel_ms" % it] = t[:, 3].copy()
         print(json.dumps({"pass": it, "kernel_ms": ms, "status_nonzero": int(np.count_nonzero(status)),
                           "curv_err_max": float(curv.max()), "curv_err_mean": float(curv.mean()),
                           "ipm_iters": [float(info["ipm_iters"].mean()), int(info["ipm_iters"].max())],
@@ -80,6 +85,8 @@ def main():
                                d_n[1 - cur], d_rst)
         eng.sync()
         cur = 1 - cur
+    if args.dump:
+        np.savez_compressed(args.dump, **dump)
     eng.close()
 
 

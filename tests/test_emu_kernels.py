@@ -623,6 +623,62 @@ def test_iqp_batch_into_caller_kept_buffers(emu, golden):
         assert np.max(np.abs(b["alpha"][k] - g["iqp_alpha"])) < 1e-8
     with pytest.raises(ValueError):
         emu.iqp_batch(trk, 0.12, 3.4, 3.0, 3, 0.01, nmax=nmax, out=dict(alpha=np.zeros((2, nmax + 1))))
+    # a uniform batch as ONE dict of stacked arrays (no per-track Python work): the same end states
+    c = emu.iqp_batch(dict(reftrack=np.stack([g["reftrack"]] * 2), normvectors=np.stack([g["normvec"]] * 2), scaling=np.stack([g["scaling"]] * 2)),
+                      0.12, 3.4, 3.0, 3, 0.01)
+    for k in range(2):
+        assert np.array_equal(a["alpha"][k], c["alpha"][k]) and np.array_equal(a["normvectors"][k], c["normvectors"][k])
+    with pytest.raises(ValueError):
+        emu.iqp_batch(dict(reftrack=np.zeros((2, 50, 4)), normvectors=np.zeros((2, 49, 2))), 0.12, 3.4, 3.0)
+
+
+def test_iqp_groups_on_streams_of_their_own_equal_the_round_by_round_loop(emu, golden, monkeypatch):
+    """mcq_iqp_device runs the first iters_min rounds in groups of tracks, each group on a stream of its own with slice launches of the
+    solver / bookkeeping / glue kernels over the SAME arrays (round 5; a group waits for its own slowest track only).  Six tracks of three
+    shapes and sizes in three groups ($MCQ_IQP_GROUPS=3) against the one-launch-per-round loop ($MCQ_IQP_GROUPS=1): end states bitwise, round
+    counts and statuses equal -- one track that needs a fourth round (the loop takes over after round iters_min), one whose QP is infeasible
+    from the start (it stops in round 1 and must not hold up its group)."""
+    trk = []
+    for name, dw in (("rounded_rectangle", 0.0), ("handling_track", 0.0), ("rounded_rectangle", 0.4), ("handling_track", -0.2),
+                     ("rounded_rectangle", -0.3), ("handling_track", 0.3)):
+        g = golden[name]
+        r = g["reftrack"].copy()
+        r[:, 2:] += dw
+        trk.append(dict(reftrack=r, normvectors=g["normvec"], scaling=g["scaling"]))
+    trk[4]["reftrack"][:, 2:] = 1.0          # narrower than the vehicle: status 1 in the first pass
+    res = {}
+    for groups in ("1", "3"):
+        monkeypatch.setenv("MCQ_IQP_GROUPS", groups)
+        res[groups] = emu.iqp_batch(trk, 0.12, 3.4, 3.0, 3, 3e-3)          # (curv_error_allowed 0.003: these tracks need a fourth round)
+    a, b = res["1"], res["3"]
+    assert list(a["status"]) == list(b["status"]) and list(a["rounds"]) == list(b["rounds"]) and list(a["n"]) == list(b["n"])
+    assert a["status"][4] == engine.STATUS_INFEASIBLE and a["rounds"][4] == 1
+    assert max(a["rounds"]) > 3, list(a["rounds"])
+    for k in range(6):
+        for key in ("alpha", "reftrack", "normvectors"):
+            assert np.array_equal(a[key][k], b[key][k]), (k, key)
+        assert a["curv_err"][k] == b["curv_err"][k] and np.array_equal(a["curv_trace"][k], b["curv_trace"][k])
+    assert a["stats"]["qp_solves"] == b["stats"]["qp_solves"] == int(np.sum(a["rounds"]))
+
+
+def test_host_batches_packed_by_several_threads(emu, golden, monkeypatch):
+    """mcq_solve_batch / mcq_iqp_batch pack large batches into the pinned staging in chunks of tracks on several host threads, each chunk's
+    uploads queued as it is ready ($MCQ_PACK_THREADS forces it for a small batch): a ragged batch -- scalings given for some tracks only,
+    more threads than some chunks have tracks -- returns exactly what the single loop returns."""
+    probs = []
+    for k, name in enumerate(("rounded_rectangle", "handling_track", "rounded_rectangle", "handling_track", "rounded_rectangle", "rounded_rectangle", "handling_track")):
+        g = golden[name]
+        r = g["reftrack"].copy()
+        r[:, 2:] += 0.05 * k
+        probs.append(dict(reftrack=r, normvec=g["normvec"], scaling=g["scaling"] if k % 3 != 1 else None, kappa_bound=0.12, w_veh=3.4 - 0.1 * (k % 2)))
+    res = {}
+    for th in ("1", "3"):
+        monkeypatch.setenv("MCQ_PACK_THREADS", th)
+        res[th] = emu.solve_batch(probs)
+    for k in range(len(probs)):
+        assert np.array_equal(res["1"][0][k], res["3"][0][k]), k
+    assert np.array_equal(res["1"][1], res["3"][1]) and list(res["1"][2]) == list(res["3"][2])
+    assert res["1"][2][0] == 0 and np.max(np.abs(res["1"][0][0] - golden["rounded_rectangle"]["alpha"])) < 1e-8
 
 
 def test_fp32_increment_rows_keep_the_accuracy(emu, golden):

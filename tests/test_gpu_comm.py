@@ -164,3 +164,35 @@ def test_resident_stream_entry_on_two_compute_streams_is_bitwise_the_single_laun
         assert np.all(eng.download(d_st[k], (B,), np.int32) == 0)
     for p in d_ref + [q for q in d_nv if q] + [q for q in d_sc if q] + d_al + d_cu + d_st:
         eng.free(p)
+
+
+def test_iqp_groups_on_streams_of_their_own_are_bitwise_the_round_by_round_loop(gpu_engine, monkeypatch):
+    """mcq_iqp_batch with the first iters_min rounds in groups of tracks, a stream each (slice launches of the solver / bookkeeping / glue
+    kernels over the same arrays, really concurrent here), against the one-launch-per-round loop ($MCQ_IQP_GROUPS=1): 192 ovals of 600
+    waypoints with per-track centrelines -- some need a fourth round, which the loop runs after the groups have joined --, one track narrower
+    than the vehicle (it stops in round 1) -- in 2, 3 and 5 groups, the batch packed by 1 and by 5 host threads, as a list of tracks and as
+    one dict of stacked arrays: end states, round counts, curvature errors bitwise."""
+    from global_racetrajectory_optimization_amd import engine, synthetic
+    eng = gpu_engine
+    B, n = 192, 600
+    ref, nv, sc = synthetic.oval_batch(B, n=n, first=4000, perturb_centreline=True)
+    ref[77, :, 2:] = 1.0
+    trk = [dict(reftrack=ref[k], normvectors=nv[k], scaling=sc[k]) for k in range(B)]
+    res = {}
+    for groups, threads, form in (("1", "1", trk), ("2", "5", trk), ("3", "1", dict(reftrack=ref, normvectors=nv, scaling=sc)), ("5", "5", trk)):
+        monkeypatch.setenv("MCQ_IQP_GROUPS", groups)
+        monkeypatch.setenv("MCQ_PACK_THREADS", threads)
+        # (curv_error_allowed 4.5e-5: on these gentle ovals the third pass leaves 4e-5 .. 5.5e-5, the fourth 2.5e-5 .. 3.3e-5)
+        res[groups] = eng.iqp_batch(form, 0.12, 3.4, 3.0, iters_min=3, curv_error_allowed=4.5e-5, max_rounds=6)
+    a = res["1"]
+    assert a["status"][77] == engine.STATUS_INFEASIBLE and a["rounds"][77] == 1
+    assert np.count_nonzero(a["status"] == engine.STATUS_INFEASIBLE) == 1 and a["rounds"].max() > 3 and np.count_nonzero(a["rounds"] == 3) > 0, (
+        np.unique(a["status"], return_counts=True), np.unique(a["rounds"], return_counts=True))
+    for groups in ("2", "3", "5"):
+        b = res[groups]
+        assert np.array_equal(a["status"], b["status"]) and np.array_equal(a["rounds"], b["rounds"]) and np.array_equal(a["n"], b["n"])
+        assert np.array_equal(a["curv_err"], b["curv_err"]) and np.array_equal(a["curv_trace"], b["curv_trace"])
+        for k in range(B):
+            assert np.array_equal(a["alpha"][k], b["alpha"][k]) and np.array_equal(a["reftrack"][k], b["reftrack"][k]), (groups, k)
+            assert np.array_equal(a["normvectors"][k], b["normvectors"][k]), (groups, k)
+        assert a["stats"]["qp_solves"] == b["stats"]["qp_solves"]
