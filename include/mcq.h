@@ -317,6 +317,10 @@ int mcq_solve_device_stream(mcq_handle* h, int steps, int batch, int n, const do
  * curv_error_allowed), the damping of the early rounds (alpha * round / iters_min) and the glue of mcq_relinearise_device for
  * the tracks that go on.  The host enqueues the first iters_min rounds without looking and then reads ONE int per round (how
  * many tracks are still iterating).  A track whose QP fails keeps that status and stops; the others are not affected.
+ * Those first rounds run in GROUPS of tracks, each on a stream of its own (a track's passes depend on its own previous pass
+ * only: a group waits for its own slowest track, not for the batch's; slice launches over the same arrays, results bitwise
+ * those of one launch per round) -- $MCQ_IQP_GROUPS groups (default 2, at most 16; 1 = one launch per round), 64 tracks per
+ * group at least unless the variable asks for less; with `stats->timed` or a round callback the rounds run one by one.
  *
  * mcq_iqp_device: everything resident.  reftrack_a / normvec_a [batch][nmax][*] hold the tracks on entry (n_io [batch] their
  * waypoint counts), reftrack_b / normvec_b are the second set of the double buffer; scaling [batch][nmax] (first pass) or NULL.
@@ -341,7 +345,9 @@ int mcq_iqp_device(mcq_handle* h, int batch, int nmax, int* n_io, double* reftra
                    int iters_min, double curv_error_allowed, int max_rounds, const mcq_opts* opts, double* alpha_out,
                    int* buf_out, double* curv_err_out, int* status_out, int* rounds_out, double* curv_trace_out,
                    mcq_iqp_stats* stats);
-/* The same from / to host buffers -- what iqp_handler binds.  problems [batch] as for mcq_solve_batch (normvec required);
+/* The same from / to host buffers -- what iqp_handler binds.  problems [batch] as for mcq_solve_batch (normvec required; batches
+ * above 8 MB are packed into the pinned staging by $MCQ_PACK_THREADS host threads -- default 8 -- in chunks whose uploads overlap
+ * the packing of the next; mcq_solve_batch packs the same way);
  * outputs padded to nmax_out waypoints per track (caller's capacity for the re-sampled rings; MCQ_E_TOO_LARGE names nothing
  * partial: a track whose ring outgrows it gets status MCQ_BAD_INPUT): alpha_out [batch][nmax_out], reftrack_out
  * [batch][nmax_out][4], normvec_out [batch][nmax_out][2], n_out / status_out / rounds_out [batch], curv_err_out [batch],
