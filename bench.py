@@ -679,11 +679,10 @@ def main():
                           "seconds_round_by_round_with_statistics": t_iqp_timed,
                           "failed_tracks": int(np.count_nonzero(iq["status"])), "n_final_range": [int(iq["n"].min()), int(iq["n"].max())],
                           "seconds_fresh_output_arrays": t_iqp_fresh, "alpha_equal_between_the_three_calls": bool(same),
-                          "groups": int(os.environ.get("MCQ_IQP_GROUPS", "2")),
                           "what": "mcq_iqp_batch: iqp_handler (stepsize_interp 3.0, iters_min 3, curv_error_allowed 0.01) of the %d tracks as one "
                                   "call -- QP passes, termination test, damping and re-linearisation glue on the device, passes 2+ warm-started; "
-                                  "the first iters_min rounds run in `groups` groups of tracks, a stream each (a group waits for its own slowest "
-                                  "track only), the batch is packed into pinned staging by several host threads; end states land in page-locked "
+                                  "the first iters_min rounds are ONE launch in which every workgroup takes its track through the rounds on its "
+                                  "own (mcq_iqp_rounds_kernel), the batch is packed into pinned staging by several host threads; end states land in page-locked "
                                   "arrays kept by the caller (seconds_fresh_output_arrays: the same call allocating and touching fresh numpy "
                                   "arrays).  pass_ms / fallbacks: from a third call with per-round statistics (one launch per round, HIP "
                                   "events, records read back after every pass: seconds_round_by_round_with_statistics)" % B}

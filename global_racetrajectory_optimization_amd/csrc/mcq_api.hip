@@ -19,10 +19,6 @@
 
 #include "mcq_kernels.h"
 
-#define MCQ_IQP_GROUPS_MAX 16
-#ifndef MCQ_IQP_GROUPS_DEFAULT
-#define MCQ_IQP_GROUPS_DEFAULT 2
-#endif
 static thread_local std::string g_err;
 
 #define HIP_TRY(expr)                                                                                     \
@@ -43,10 +39,6 @@ struct mcq_handle {
     hipEvent_t ev[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};
     bool timing_valid = false;
     hipEvent_t ev_st[2] = {nullptr, nullptr};       // mcq_solve_device_stream: joins the second compute stream to the first and back
-    // mcq_iqp_device: the batch in GROUPS of tracks, each with a stream of its own (a track's passes depend on nothing but its own previous
-    // pass: a group that waits for its slowest track holds up nobody else)
-    hipStream_t gs[MCQ_IQP_GROUPS_MAX] = {};
-    hipEvent_t gev[MCQ_IQP_GROUPS_MAX + 1] = {};
     hipEvent_t ev_span[2] = {nullptr, nullptr};     // mcq_timing_begin / mcq_timing_end: a span of launches on the compute stream
     int span_launches = 0;
     bool span_open = false;
@@ -243,8 +235,6 @@ extern "C" void mcq_destroy(mcq_handle* h)
     for (int k = 0; k < 5; ++k) if (h->ev[k]) (void)hipEventDestroy(h->ev[k]);
     for (int k = 0; k < 2; ++k) if (h->ev_span[k]) (void)hipEventDestroy(h->ev_span[k]);
     for (int k = 0; k < 2; ++k) if (h->ev_st[k]) (void)hipEventDestroy(h->ev_st[k]);
-    for (int k = 0; k < MCQ_IQP_GROUPS_MAX; ++k) if (h->gs[k]) { (void)hipStreamSynchronize(h->gs[k]); (void)hipStreamDestroy(h->gs[k]); }
-    for (int k = 0; k <= MCQ_IQP_GROUPS_MAX; ++k) if (h->gev[k]) (void)hipEventDestroy(h->gev[k]);
     if (h->stream) (void)hipStreamDestroy(h->stream);
     delete h;
 }
@@ -377,12 +367,9 @@ static int ensure_stage(mcq_handle* h, size_t batch, size_t nmax)
 }
 
 // alt: on the handle's second compute stream and workspace (ensure_alt; mcq_solve_host_pipelined's odd steps) -- no event timing there
-// ov: the launch goes to THIS stream and covers the slice B.pb_base .. + B.pb_count of the batch (mcq_iqp_device's groups: the handle's
-// workspace and every per-problem array are indexed by the problem's number in the whole batch, so concurrent slices touch nothing in common
-// but the slot flags, which are claimed atomically); no timing events, and the warm start is the caller's call (ov_warm).
-static int launch(mcq_handle* h, McqBatch& B, const mcq_opts& o, bool alt = false, hipStream_t ov = nullptr, bool ov_warm = false)
+// workspace, options and slots of a solver launch (everything of McqBatch the caller does not set)
+static int fill_batch(mcq_handle* h, McqBatch& B, const mcq_opts& o, bool alt)
 {
-    hipStream_t st = ov ? ov : (alt ? h->stream2 : h->stream);
     B.L = alt ? h->L2 : h->L; B.vec = alt ? h->vec2 : h->vec; B.Z = alt ? h->Z2 : h->Z; B.state = alt ? h->state_alt : h->state;
     B.max_ipm_iter = o.max_ipm_iter;
     B.max_as_iter = o.max_as_iter;
@@ -404,14 +391,14 @@ static int launch(mcq_handle* h, McqBatch& B, const mcq_opts& o, bool alt = fals
     B.gi = gi_on ? gi_mem : nullptr;
     B.gi_slots = gi_on ? (alt ? h->gi2_slots : h->gi_slots) : 0;
     B.gi_qcap = B.nmax;
+    return 0;
+}
+
+static int launch(mcq_handle* h, McqBatch& B, const mcq_opts& o, bool alt = false)
+{
+    hipStream_t st = alt ? h->stream2 : h->stream;
+    if (int rc = fill_batch(h, B, o, alt)) return rc;
     // warm start: only the working sets mcq_relinearise_device carried over for exactly this batch layout
-    if (ov) {
-        if (alt || B.prep_only || B.objective == MCQ_OBJ_SHORTEST_PATH) { g_err = "launch: a slice launch is a plain solver launch on the first workspace"; return MCQ_E_ARG; }
-        B.warm = ov_warm ? h->state2 : nullptr;
-        hipLaunchKernelGGL(mcq_solve_kernel, dim3(B.pb_count > 0 ? B.pb_count : B.batch), dim3(256), 0, st, B);
-        HIP_TRY(hipGetLastError());
-        return 0;
-    }
     B.warm = (!alt && o.warm_start > 0 && h->state2_valid && !B.prep_only && h->state2_batch == B.batch && h->state2_nmax == B.nmax)
                  ? h->state2 : nullptr;
     if (!B.prep_only && !alt) h->state2_valid = false;
@@ -684,12 +671,10 @@ extern "C" int mcq_normals_crossing_device(mcq_handle* h, int batch, int nmax, c
     return 0;
 }
 
-// st / base / count: the launch covers tracks base .. base + count - 1 on stream st (mcq_iqp_device's groups); the ABI entry passes the
-// handle's stream and the whole batch
-static int relinearise_launch(mcq_handle* h, int batch, int nmax, const int* n_in, const double* reftrack_in,
-                              const double* normvec_in, const double* alpha, const int* live, double alpha_scale,
-                              double stepsize, double* reftrack_out, double* normvec_out, int* n_out,
-                              int* status_out, hipStream_t st, int base, int count)
+extern "C" int mcq_relinearise_device(mcq_handle* h, int batch, int nmax, const int* n_in, const double* reftrack_in,
+                                      const double* normvec_in, const double* alpha, const int* live, double alpha_scale,
+                                      double stepsize, double* reftrack_out, double* normvec_out, int* n_out,
+                                      int* status_out)
 {
     if (!h || batch <= 0 || nmax <= 0 || !n_in || !reftrack_in || !normvec_in || !alpha || !reftrack_out || !normvec_out ||
         !n_out || !status_out || !(stepsize > 0.0) || reftrack_in == reftrack_out || normvec_in == normvec_out) {
@@ -720,20 +705,9 @@ static int relinearise_launch(mcq_handle* h, int batch, int nmax, const int* n_i
     h->state2_valid = true;
     h->state2_batch = batch;
     h->state2_nmax = nmax;
-    R.pb_base = base;
-    hipLaunchKernelGGL(mcq_relinearise_kernel, dim3(count), dim3(256), 0, st, R);
+    hipLaunchKernelGGL(mcq_relinearise_kernel, dim3(batch), dim3(256), 0, h->stream, R);
     HIP_TRY(hipGetLastError());
     return 0;
-}
-
-extern "C" int mcq_relinearise_device(mcq_handle* h, int batch, int nmax, const int* n_in, const double* reftrack_in,
-                                      const double* normvec_in, const double* alpha, const int* live, double alpha_scale,
-                                      double stepsize, double* reftrack_out, double* normvec_out, int* n_out,
-                                      int* status_out)
-{
-    if (!h) { g_err = "mcq_relinearise_device: bad argument"; return MCQ_E_ARG; }
-    return relinearise_launch(h, batch, nmax, n_in, reftrack_in, normvec_in, alpha, live, alpha_scale, stepsize, reftrack_out, normvec_out,
-                              n_out, status_out, h->stream, 0, batch);
 }
 
 static int vel_profile_launch(mcq_handle* h, int batch, int n, int nmax, const int* n_of_track, const int* track_of,
@@ -1275,88 +1249,59 @@ extern "C" int mcq_iqp_device(mcq_handle* h, int batch, int nmax, int* n_io, dou
     S.final_n = d_final_n;
     int err = 0;
     int it0 = 1;
-    // ---- The first iters_min rounds in GROUPS of tracks, a stream each.  A track's passes depend on nothing but its own previous pass, and no
-    //      track can end before round iters_min, so nothing has to come back to the host in between; but run as ONE launch per round, every
-    //      round ends with its slowest track -- a warm start that falls back to the cold path takes 8.9 ms where the others take 2.5-4 -- and
-    //      the next round's launch waits for it with most compute units idle (third pass of the 1024 ovals: 6.5 ms of mean load, 11.5 ms of
-    //      launch).  A group waits for ITS slowest track only, and the other groups' launches fill the compute units meanwhile.  The arrays are
-    //      the same (a slice launch indexes them by the track's number in the whole batch), the results bitwise those of the round-by-round
-    //      loop below, which takes over after round iters_min (and runs everything when per-round data must reach the host: timed statistics,
-    //      the print_debug callback).  $MCQ_IQP_GROUPS: number of groups (default MCQ_IQP_GROUPS_DEFAULT; 1 = off); 64 tracks per group at least. ----
-    int G = 1;
-    {
-        const char* e = getenv("MCQ_IQP_GROUPS");
-        int want = e && *e ? atoi(e) : MCQ_IQP_GROUPS_DEFAULT;
-        if (want > MCQ_IQP_GROUPS_MAX) want = MCQ_IQP_GROUPS_MAX;
-        const int most = e && *e ? batch : batch / 64;          // (asked for explicitly: groups of any size -- the tests run three groups of two tracks)
-        G = want < most ? want : most;
-        if (G < 1) G = 1;
-    }
-    if (G > 1 && !timed && !h->iqp_cb) {
+    // ---- The first iters_min rounds as ONE launch.  A track's rounds depend on nothing but its own previous round, and no track can end before
+    //      round iters_min, so nothing has to come back to the host in between; but launched round by round, every round ends with its slowest
+    //      track -- a warm start that falls back to the cold path takes 8.7 ms where the median track takes 3 -- and the next round's launch
+    //      waits for it with most compute units idle (third pass of the 1024 ovals: 6.5 ms of mean load, 11.5 ms of launch; neither another cap
+    //      of the exchange nor the pass before says which tracks those will be: docs/NOTEBOOK.md R5.7).  In mcq_iqp_rounds_kernel every
+    //      workgroup takes its track through those rounds on its own -- the bodies of the solver, bookkeeping and glue kernels between workgroup
+    //      barriers, the same arrays --: nobody waits for anybody.  Results bitwise those of the round-by-round loop below, which takes over
+    //      after round iters_min (and runs everything when per-round data must reach the host: timed statistics, the print_debug callback;
+    //      $MCQ_IQP_FUSED=0: always). ----
+    const char* fe = getenv("MCQ_IQP_FUSED");
+    const bool fused = !(fe && fe[0] == '0') && !timed && !h->iqp_cb;
+    if (fused) {
         const int ra = iters_min < max_rounds ? iters_min : max_rounds;
-        int* gcount = h->d_iqp + (size_t)8 * batch;          // live tracks per group (ensure_iqp: 16 ints behind the bookkeeping arrays)
-        for (int g = 1; g < G; ++g) {          // (group 0 runs on the handle's own stream)
-            if (!h->gs[g]) HIP_TRY(hipStreamCreate(&h->gs[g]));
-            if (!h->gev[g]) HIP_TRY(hipEventCreate(&h->gev[g]));
-        }
-        if (!h->gev[MCQ_IQP_GROUPS_MAX]) HIP_TRY(hipEventCreate(&h->gev[MCQ_IQP_GROUPS_MAX]));
-        HIP_TRY(hipEventRecord(h->gev[MCQ_IQP_GROUPS_MAX], h->stream));       // the set-up above
-        for (int g = 0; g < G && !err; ++g) {
-            const int base = (int)((long long)batch * g / G), cnt = (int)((long long)batch * (g + 1) / G) - base;
-            hipStream_t st = g == 0 ? h->stream : h->gs[g];
-            if (g > 0 && hipStreamWaitEvent(st, h->gev[MCQ_IQP_GROUPS_MAX], 0) != hipSuccess) { err = MCQ_E_DEVICE; break; }
-            int cg = 0;
-            for (int it = 1; it <= ra && !err; ++it) {
-                McqBatch B;
-                memset(&B, 0, sizeof(B));
-                B.batch = batch;
-                B.n = nmax;
-                B.nmax = nmax;
-                B.n_list = n_set[cg];
-                B.ref = ref_set[cg];
-                B.nv = nv_set[cg];
-                B.sc = it == 1 ? scaling : nullptr;
-                B.alpha = alpha_out;
-                B.curv_err = pass_curv;
-                B.status = pass_status;
-                B.kappa_bound = kappa_bound;
-                B.w_veh = w_veh;
-                B.pb_base = base;
-                B.pb_count = cnt;
-                if ((err = launch(h, B, o, false, st, warm && it > 1)) != 0) break;
-                if (hipMemsetAsync(gcount + g, 0, sizeof(int), st) != hipSuccess) { err = MCQ_E_DEVICE; break; }
-                S.phase = 0;
-                S.round = it;
-                S.cur = cg;
-                S.n_ring = n_set[cg];
-                S.n_next = n_set[1 - cg];
-                S.k_base = base;
-                S.k_count = cnt;
-                S.live_count = gcount + g;
-                hipLaunchKernelGGL(mcq_iqp_step_kernel, dim3((unsigned)((cnt + 255) / 256)), sblock, 0, st, S);
-                const double scale = it < iters_min ? (double)it / (double)iters_min : 1.0;
-                if ((err = relinearise_launch(h, batch, nmax, n_set[cg], ref_set[cg], nv_set[cg], alpha_out, live, scale, stepsize_interp,
-                                              ref_set[1 - cg], nv_set[1 - cg], n_set[1 - cg], rst, st, base, cnt)) != 0) break;
-                S.phase = 1;
-                hipLaunchKernelGGL(mcq_iqp_step_kernel, dim3((unsigned)((cnt + 255) / 256)), sblock, 0, st, S);
-                if (hipGetLastError() != hipSuccess) { err = MCQ_E_DEVICE; break; }
-                cg = 1 - cg;
-            }
-            if (!err && g > 0 && (hipEventRecord(h->gev[g], st) != hipSuccess || hipStreamWaitEvent(h->stream, h->gev[g], 0) != hipSuccess)) err = MCQ_E_DEVICE;
-        }
-        if (err) { (void)hipStreamSynchronize(h->stream); for (int g = 1; g < G; ++g) (void)hipStreamSynchronize(h->gs[g]); }
-        S.k_base = 0;
-        S.k_count = 0;
-        S.live_count = live_count;
+        McqIqpRounds F;
+        memset(&F, 0, sizeof(F));
+        F.B.batch = batch;
+        F.B.n = nmax;
+        F.B.nmax = nmax;
+        F.B.alpha = alpha_out;
+        F.B.curv_err = pass_curv;
+        F.B.status = pass_status;
+        F.B.kappa_bound = kappa_bound;
+        F.B.w_veh = w_veh;
+        if ((err = fill_batch(h, F.B, o, false)) != 0) return err;
+        F.R.batch = batch;
+        F.R.nmax = nmax;
+        F.R.alpha = alpha_out;
+        F.R.live = live;
+        F.R.stepsize = stepsize_interp;
+        F.R.status = rst;
+        F.R.vec = h->vec;
+        F.R.state_in = h->state;
+        F.R.state_out = h->state2;
+        F.S = S;
+        F.S.live_count = live_count;
+        for (int q = 0; q < 2; ++q) { F.n_set[q] = n_set[q]; F.ref_set[q] = ref_set[q]; F.nv_set[q] = nv_set[q]; }
+        F.sc = scaling;
+        F.warm = warm ? h->state2 : nullptr;
+        F.rounds = ra;
+        if (hipMemsetAsync(live_count, 0, sizeof(int), h->stream) != hipSuccess) err = MCQ_E_DEVICE;
         if (!err) {
-            int hc[MCQ_IQP_GROUPS_MAX];
-            if (hipMemcpyAsync(hc, gcount, G * sizeof(int), hipMemcpyDeviceToHost, h->stream) != hipSuccess ||
-                hipStreamSynchronize(h->stream) != hipSuccess) err = MCQ_E_DEVICE;
-            else { n_live = 0; for (int g = 0; g < G; ++g) n_live += hc[g]; }
-            cur = ra & 1;
-            rounds = ra;
-            it0 = ra + 1;
+            hipLaunchKernelGGL(mcq_iqp_rounds_kernel, dim3((unsigned)batch), dim3(256), 0, h->stream, F);
+            if (hipGetLastError() != hipSuccess) err = MCQ_E_DEVICE;
         }
+        // (the loop below may go on from the working sets the last round's glue carried over)
+        h->state2_valid = true;
+        h->state2_batch = batch;
+        h->state2_nmax = nmax;
+        if (!err && (hipMemcpyAsync(&n_live, live_count, sizeof(int), hipMemcpyDeviceToHost, h->stream) != hipSuccess ||
+                     hipStreamSynchronize(h->stream) != hipSuccess)) err = MCQ_E_DEVICE;
+        cur = ra & 1;
+        rounds = ra;
+        it0 = ra + 1;
     }
     for (int it = it0; it <= max_rounds && n_live > 0 && !err; ++it) {
         rounds = it;
@@ -1650,6 +1595,15 @@ extern "C" int mcq_iqp_batch(mcq_handle* h, const mcq_problem* probs, int batch,
         return MCQ_E_ARG;
     }
     HIP_TRY(hipSetDevice(h->device));
+    const bool trace = getenv("MCQ_IQP_TRACE") != nullptr;          // host-side time stamps of this call on stderr
+    struct timespec ts0;
+    clock_gettime(CLOCK_MONOTONIC, &ts0);
+    auto stamp = [&](const char* what) {
+        if (!trace) return;
+        struct timespec t1;
+        clock_gettime(CLOCK_MONOTONIC, &t1);
+        fprintf(stderr, "iqp_batch: %-28s at %.3f ms\n", what, (t1.tv_sec - ts0.tv_sec) * 1e3 + (t1.tv_nsec - ts0.tv_nsec) * 1e-6);
+    };
     const size_t nmax = (size_t)nmax_out;
     bool any_sc = false;
     for (int b = 0; b < batch; ++b) {
@@ -1676,8 +1630,10 @@ extern "C" int mcq_iqp_batch(mcq_handle* h, const mcq_problem* probs, int batch,
     }
     PinLayout P;
     // results need room for both buffer sets' ref / nv in the worst case: one extra set
+    stamp("checked, buffers ready");
     rc = pack_and_upload(h, probs, batch, nmax, any_sc, true, elems * 6 * sizeof(double) + (size_t)batch * 3 * sizeof(int), P, "mcq_iqp_batch");
     if (rc) return rc;
+    stamp("packed, uploads queued");
     rc = ensure_iqp(h, (size_t)batch);                 // the trace staging lives in the handle (no allocation / hipFree -- an implicit
     if (rc) return rc;                                 // device-wide synchronisation -- per call)
     double* d_trace = curv_trace_out ? h->d_trace : nullptr;
@@ -1687,6 +1643,7 @@ extern "C" int mcq_iqp_batch(mcq_handle* h, const mcq_problem* probs, int batch,
     rc = mcq_iqp_device(h, batch, (int)nmax, h->d_n, h->d_ref, h->d_nv, h->d_ref2, h->d_nv2, any_sc ? h->d_sc : nullptr,
                         probs[0].kappa_bound, probs[0].w_veh, stepsize_interp, iters_min, curv_error_allowed, max_rounds, opts,
                         h->d_alpha, d_buf, h->d_curv, h->d_status, d_rounds, d_trace, stats);
+    stamp("rounds done");
     if (!rc && d_trace && hipMemcpy(curv_trace_out, d_trace, (size_t)batch * MCQ_IQP_TRACE * sizeof(double), hipMemcpyDeviceToHost) != hipSuccess) {
         g_err = "mcq_iqp_batch: read-back of the curvature-error trace failed";
         rc = MCQ_E_DEVICE;
@@ -1701,6 +1658,7 @@ extern "C" int mcq_iqp_batch(mcq_handle* h, const mcq_problem* probs, int batch,
     // alpha straight into the caller's [batch][nmax_out] array (its padding holds whatever the device buffer held)
     HIP_TRY_SYNC(hipMemcpyAsync(alpha_out, h->d_alpha, elems * sizeof(double), hipMemcpyDeviceToHost, h->stream));
     HIP_TRY(hipStreamSynchronize(h->stream));
+    stamp("alpha and per-track results down");
     bool use[2] = {false, false};
     for (int b = 0; b < batch; ++b) use[buf_h[b] ? 1 : 0] = true;
     const double* d_ref_set[2] = {h->d_ref, h->d_ref2};
@@ -1711,6 +1669,7 @@ extern "C" int mcq_iqp_batch(mcq_handle* h, const mcq_problem* probs, int batch,
         HIP_TRY_SYNC(hipMemcpyAsync(reftrack_out, d_ref_set[q], elems * 4 * sizeof(double), hipMemcpyDeviceToHost, h->stream));
         HIP_TRY_SYNC(hipMemcpyAsync(normvec_out, d_nv_set[q], elems * 2 * sizeof(double), hipMemcpyDeviceToHost, h->stream));
         HIP_TRY(hipStreamSynchronize(h->stream));
+        stamp("rings and normals down");
         return 0;
     }
     // tracks ended in different rounds: both sets through the pinned staging (set 0 into the now free input block, set 1 into

@@ -105,8 +105,6 @@ struct McqBatch {
     double* gi;             // slots of the Goldfarb-Idnani path (mcq_gi.inc), MCQ_GI_SLOT_DOUBLES(nmax, gi_qcap) doubles each: a workgroup whose
     int gi_slots, gi_qcap;  // problem needs the path claims one (and waits for one if all are taken); gi_qcap = constraints a working set can
                             // hold (= nmax: no more can be independent)
-    int pb_base, pb_count;  // a launch over a SLICE of the batch (mcq_iqp_device's groups, each on a stream of its own): workgroup w works on problem
-                            // pb_base + w of the same arrays; pb_count = workgroups of the launch (0: the whole batch from 0)
 };
 
 __global__ void mcq_assemble_kernel(McqBatch B);
@@ -151,7 +149,6 @@ struct McqRelin {
     double* vec;            // workspace, [batch][MCQ_NVEC][nmax] (the solver's vector slab)
     const signed char* state_in;   // [batch][nmax] working set the solver left for these tracks (or nullptr)
     signed char* state_out;        // [batch][nmax] the same carried to the re-sampled rings (warm start of the next pass)
-    int pb_base;                   // a launch over a slice of the batch: workgroup w works on track pb_base + w
 };
 __global__ void mcq_relinearise_kernel(McqRelin R);
 
@@ -172,9 +169,26 @@ struct McqIqpStep {
     int* final_n; int* final_buf; double* final_curv; int* final_status; int* final_rounds;
     double* curv_trace;         // [batch][MCQ_IQP_TRACE] or nullptr
     int* live_count;
-    int k_base, k_count;        // a launch over a slice of the batch: tracks k_base .. k_base + k_count - 1 (k_count 0: all)
 };
 __global__ void mcq_iqp_step_kernel(McqIqpStep S);
+
+/* ---- the first `rounds` rounds of iqp_handler as ONE launch, a workgroup per track (mcq_kernels.hip: mcq_iqp_rounds_kernel).  B: the QP pass's
+ *      launch parameters (outputs, options, workspace; its ref / nv / n_list / sc / warm are not read); n_set / ref_set / nv_set: the two ring
+ *      buffers (round r reads set (r - 1) & 1 and writes the other); sc: the first round's scalings or nullptr; warm: the carried working sets
+ *      (= R.state_out) or nullptr (cold passes); R: the glue's parameters (its n_in / ref_in / nv_in / *_out / alpha_scale are not read);
+ *      S: the bookkeeping's (phase / round / cur / n_ring / n_next are not read; live_count: zero on entry, tracks still iterating on return). ---- */
+struct McqIqpRounds {
+    McqBatch B;
+    McqRelin R;
+    McqIqpStep S;
+    int* n_set[2];
+    double* ref_set[2];
+    double* nv_set[2];
+    const double* sc;
+    const signed char* warm;
+    int rounds;
+};
+__global__ void mcq_iqp_rounds_kernel(McqIqpRounds F);
 
 /* ---- raceline at the output resolution + heading / curvature (what main_globaltraj.py runs between the QP and the velocity
  *      profile [REF main_globaltraj.py:371-387]: tph.create_raceline + tph.calc_head_curv_an).  One workgroup per track. ---- */

@@ -126,16 +126,32 @@ __device__ void block_reduce2_(double& a, int opa, double& b, int opb, double* r
     b = rb;
 }
 
-__device__ __forceinline__ McqWork mcq_work(const McqBatch& B, int pb, int& n, double& kb, double& wv)
+// The inputs of one QP pass: the launch's own (McqBatch) for every kernel but mcq_iqp_rounds_kernel, which alternates between the two ring
+// buffers of iqp_handler's rounds inside one launch.
+struct McqSet {
+    const int* n_list;
+    const double* ref;
+    const double* nv;
+    const double* sc;
+    const signed char* warm;
+};
+__device__ __forceinline__ McqSet mcq_set_of(const McqBatch& B)
+{
+    McqSet s;
+    s.n_list = B.n_list; s.ref = B.ref; s.nv = B.nv; s.sc = B.sc; s.warm = B.warm;
+    return s;
+}
+
+__device__ __forceinline__ McqWork mcq_work(const McqBatch& B, const McqSet& S, int pb, int& n, double& kb, double& wv)
 {
     McqWork w;
     const size_t nm = (size_t)B.nmax;
-    n = B.n_list ? B.n_list[pb] : B.n;
+    n = S.n_list ? S.n_list[pb] : B.n;
     kb = B.kappa_bound_list ? B.kappa_bound_list[pb] : B.kappa_bound;
     wv = B.w_veh_list ? B.w_veh_list[pb] : B.w_veh;
-    w.ref = (const gdouble*)(B.ref + (size_t)pb * nm * 4);
-    w.nv = B.nv ? (const gdouble*)(B.nv + (size_t)pb * nm * 2) : nullptr;
-    w.sc = B.sc ? (const gdouble*)(B.sc + (size_t)pb * nm) : nullptr;
+    w.ref = (const gdouble*)(S.ref + (size_t)pb * nm * 4);
+    w.nv = S.nv ? (const gdouble*)(S.nv + (size_t)pb * nm * 2) : nullptr;
+    w.sc = S.sc ? (const gdouble*)(S.sc + (size_t)pb * nm) : nullptr;
     w.L = (gdouble*)(B.L + (size_t)pb * nm * MCQ_LLD);
     w.vec = (gdouble*)(B.vec + (size_t)pb * nm * MCQ_NVEC);
     w.state = (gschar*)(B.state + (size_t)pb * nm);
@@ -145,6 +161,10 @@ __device__ __forceinline__ McqWork mcq_work(const McqBatch& B, int pb, int& n, d
     w.status = (gint*)(B.status + pb);
     w.info = B.info ? (ginfo*)(B.info + pb) : nullptr;
     return w;
+}
+__device__ __forceinline__ McqWork mcq_work(const McqBatch& B, int pb, int& n, double& kb, double& wv)
+{
+    return mcq_work(B, mcq_set_of(B), pb, n, kb, wv);
 }
 
 #define VEC(w, nmax, id) ((w).vec + (size_t)(id) * (size_t)(nmax))
@@ -321,9 +341,9 @@ __device__ __noinline__ int assemble_problem(const LCtx& c, double wveh, gdouble
 }
 
 // what the assembly needs of the context: the problem's pointers and size (thread 0 writes, the barrier publishes)
-__device__ __forceinline__ void ctx_set_problem(const McqBatch& B, int pb, int& n, double& kb, double& wveh)
+__device__ __forceinline__ void ctx_set_problem(const McqBatch& B, const McqSet& S, int pb, int& n, double& kb, double& wveh)
 {
-    const McqWork w = mcq_work(B, pb, n, kb, wveh);
+    const McqWork w = mcq_work(B, S, pb, n, kb, wveh);
     __syncthreads();                                  // (a previous use of the context by this workgroup -- none today -- is over)
     if (threadIdx.x == 0) {
         g_ctx.w = w;
@@ -331,6 +351,11 @@ __device__ __forceinline__ void ctx_set_problem(const McqBatch& B, int pb, int& 
         g_ctx.d = mcq_dims(n);
     }
     __syncthreads();
+}
+
+__device__ __forceinline__ void ctx_set_problem(const McqBatch& B, int pb, int& n, double& kb, double& wveh)
+{
+    ctx_set_problem(B, mcq_set_of(B), pb, n, kb, wveh);
 }
 
 // ... and what a solve needs on top: the options, the timers and diagnostics at zero
@@ -1640,7 +1665,8 @@ MCQ_FN_PROLOGUE void write_outputs(const LCtx& c, const McqOutcome& r)
 
 #include "mcq_gi.inc"
 
-__global__ void __launch_bounds__(MCQ_NT, 2) mcq_solve_kernel(McqBatch B)
+// One QP pass of problem pb, by its workgroup: the body of mcq_solve_kernel (and of every round of mcq_iqp_rounds_kernel).
+__device__ __forceinline__ void solve_body(const McqBatch& B, const McqSet& IN, const int pb)
 {
     const int tid = threadIdx.x;
     int n;
@@ -1651,8 +1677,7 @@ __global__ void __launch_bounds__(MCQ_NT, 2) mcq_solve_kernel(McqBatch B)
     }
     const long long t_kernel0 = TICK();
     const long long c_kernel0 = (long long)clock64();      // shader-clock counter (s_memtime): with ticks[3] the effective clock
-    const int pb = (int)blockIdx.x + B.pb_base;          // (pb_base: a launch over a slice of the batch, see McqBatch)
-    ctx_set_problem(B, pb, n, kbound, wveh);
+    ctx_set_problem(B, IN, pb, n, kbound, wveh);
     const LCtx& c = G_CTX;
     ctx_set_solve(B, kbound);
     if (B.objective == MCQ_OBJ_SHORTEST_PATH) {
@@ -1692,8 +1717,8 @@ __global__ void __launch_bounds__(MCQ_NT, 2) mcq_solve_kernel(McqBatch B)
     //      factorisation + one solve) -- a third to two thirds of what interior point + exchange cost.  The vertex returned is an
     //      exact KKT point either way; if the exchange runs out of its rounds the cold path below takes over. ----
     bool warm_done = false;
-    if (B.warm && small && !gi_only) {
-        const gschar* WS = (const gschar*)(B.warm + (size_t)pb * nm);
+    if (IN.warm && small && !gi_only) {
+        const gschar* WS = (const gschar*)(IN.warm + (size_t)pb * nm);
         for (int i = tid; i < n; i += MCQ_NT)
             if (ST[i] == 0) { const signed char s = WS[i]; ST[i] = (s == 1 || s == -1) ? s : (signed char)0; }
         __syncthreads();
@@ -1827,6 +1852,11 @@ __global__ void __launch_bounds__(MCQ_NT, 2) mcq_solve_kernel(McqBatch B)
     write_outputs(c, r);
 }
 
+__global__ void __launch_bounds__(MCQ_NT, 2) mcq_solve_kernel(McqBatch B)
+{
+    solve_body(B, mcq_set_of(B), (int)blockIdx.x);
+}
+
 // =====================================================================================================================
 // K4: IQP glue -- re-linearisation on the device
 // =====================================================================================================================
@@ -1889,12 +1919,14 @@ __device__ void relin_spline_rhs(const gdouble* PX, const gdouble* PY, int n, gd
 // widths), closed unit-scaling spline through it, spline lengths and their running sum, point count of the re-sampled ring.
 // vec slots: 0/1 raceline points (a-coefficients), 2/3 rhs, 4/5 c-coefficients, 6 lengths, 7 running sum, 8/9 widths.
 // Returns the number of points kept (tph.interp_splines, incl_last_point = False) or -1; `total` = length of the raceline.
+// lds: RELIN_LDS doubles of the caller's LDS (the glue kernels bring their own 16 KB; mcq_iqp_rounds_kernel lends the solver's array).
+#define RELIN_LDS 2050
 __device__ __forceinline__ int relin_front(const gdouble* ref, const gdouble* nv, const gdouble* al, int n, double alpha_scale,
-                                           double stepsize, gdouble* vec, size_t nm, double& total)
+                                           double stepsize, gdouble* vec, size_t nm, double& total, double* lds)
 {
-    __shared__ double sbuf[2048];
-    __shared__ double s_carry;
-    __shared__ int s_m;
+    double* sbuf = lds;
+    double& s_carry = lds[2048];
+    int& s_m = *(int*)(lds + 2049);
     const int tid = threadIdx.x;
     gdouble* PX = vec + 0 * nm;   gdouble* PY = vec + 1 * nm;    // raceline points (a-coefficients)
     gdouble* RX = vec + 2 * nm;   gdouble* RY = vec + 3 * nm;    // rhs, later the new points
@@ -1961,31 +1993,38 @@ __device__ __forceinline__ int relin_front(const gdouble* ref, const gdouble* nv
     return s_m;
 }
 
-__global__ void __launch_bounds__(MCQ_NT) mcq_relinearise_kernel(McqRelin R)
+// The glue of one track, by its workgroup: the body of mcq_relinearise_kernel (and of every round of mcq_iqp_rounds_kernel).  IO: the ring
+// buffers of this round (the launch's own -- R -- for the kernel); lds: RELIN_LDS doubles.
+struct McqRelinIO {
+    const int* n_in; const double* ref_in; const double* nv_in;
+    double* ref_out; double* nv_out; int* n_out;
+    double alpha_scale;
+};
+__device__ __forceinline__ void relin_body(const McqRelin& R, const McqRelinIO& IO, const int pb, double* lds)
 {
-    const int tid = threadIdx.x, pb = (int)blockIdx.x + R.pb_base;
+    const int tid = threadIdx.x;
     if (R.live && R.live[pb] == 0) return;
     const size_t nm = (size_t)R.nmax;
-    const int n = R.n_in[pb];
-    const gdouble* ref = (const gdouble*)(R.ref_in + (size_t)pb * nm * 4);
-    const gdouble* nv = (const gdouble*)(R.nv_in + (size_t)pb * nm * 2);
+    const int n = IO.n_in[pb];
+    const gdouble* ref = (const gdouble*)(IO.ref_in + (size_t)pb * nm * 4);
+    const gdouble* nv = (const gdouble*)(IO.nv_in + (size_t)pb * nm * 2);
     const gdouble* al = (const gdouble*)(R.alpha + (size_t)pb * nm);
-    gdouble* refo = (gdouble*)(R.ref_out + (size_t)pb * nm * 4);
-    gdouble* nvo = (gdouble*)(R.nv_out + (size_t)pb * nm * 2);
+    gdouble* refo = (gdouble*)(IO.ref_out + (size_t)pb * nm * 4);
+    gdouble* nvo = (gdouble*)(IO.nv_out + (size_t)pb * nm * 2);
     gdouble* vec = (gdouble*)(R.vec + (size_t)pb * nm * MCQ_NVEC);
     gdouble* PX = vec + 0 * nm;   gdouble* PY = vec + 1 * nm;    // raceline points (a-coefficients)
     gdouble* CX = vec + 4 * nm;   gdouble* CY = vec + 5 * nm;    // c-coefficients
     gdouble* LEN = vec + 6 * nm;  gdouble* CUM = vec + 7 * nm;   // spline lengths, their running sum
     gdouble* WR = vec + 8 * nm;   gdouble* WL = vec + 9 * nm;    // shifted track widths
     gdouble* QX = vec + 10 * nm;  gdouble* QY = vec + 11 * nm;   // re-sampled points
-    gint* n_out = (gint*)(R.n_out + pb);
+    gint* n_out = (gint*)(IO.n_out + pb);
     gint* status = (gint*)(R.status + pb);
     if (n < 3) {
         if (tid == 0) { *status = MCQ_BAD_INPUT; *n_out = n; }
         return;
     }
     double total;
-    const int m = relin_front(ref, nv, al, n, R.alpha_scale, R.stepsize, vec, nm, total);
+    const int m = relin_front(ref, nv, al, n, IO.alpha_scale, R.stepsize, vec, nm, total, lds);
     if (m < 3 || m > R.nmax) {
         if (tid == 0) { *status = MCQ_BAD_INPUT; *n_out = n; }
         return;
@@ -2038,31 +2077,82 @@ __global__ void __launch_bounds__(MCQ_NT) mcq_relinearise_kernel(McqRelin R)
     if (tid == 0) { *status = MCQ_OK; *n_out = m; }
 }
 
-// ---- iqp_handler's bookkeeping between the passes (see McqIqpStep) -------------------------------------------------------------------
-__global__ void __launch_bounds__(256) mcq_iqp_step_kernel(McqIqpStep S)
+__global__ void __launch_bounds__(MCQ_NT) mcq_relinearise_kernel(McqRelin R)
 {
-    const int k = S.k_base + (int)blockIdx.x * 256 + (int)threadIdx.x;
-    if (k >= (S.k_count > 0 ? S.k_base + S.k_count : S.batch)) return;
-    if (S.phase == 0) {
+    __shared__ double lds[RELIN_LDS];
+    McqRelinIO io;
+    io.n_in = R.n_in; io.ref_in = R.ref_in; io.nv_in = R.nv_in; io.ref_out = R.ref_out; io.nv_out = R.nv_out; io.n_out = R.n_out;
+    io.alpha_scale = R.alpha_scale;
+    relin_body(R, io, (int)blockIdx.x, lds);
+}
+
+// ---- iqp_handler's bookkeeping between the passes (see McqIqpStep), one track: phase, round, ring buffer in use and the two size arrays
+//      are the caller's (the kernel's launch parameters; the round loop of mcq_iqp_rounds_kernel); count: keep S.live_count ------------
+__device__ __forceinline__ void iqp_step_track(const McqIqpStep& S, int k, int phase, int round, int cur, const int* n_ring, int* n_next, bool count)
+{
+    if (phase == 0) {
         if (S.live[k] == 0) return;
         const int st = S.status[k];
         const double ce = S.curv[k];
-        S.final_n[k] = S.n_ring[k];
-        S.final_buf[k] = S.cur;
+        S.final_n[k] = n_ring[k];
+        S.final_buf[k] = cur;
         S.final_curv[k] = ce;
         S.final_status[k] = st;
-        S.final_rounds[k] = S.round;
-        if (S.curv_trace && S.round <= MCQ_IQP_TRACE) S.curv_trace[(size_t)k * MCQ_IQP_TRACE + S.round - 1] = ce;
-        const bool stop = st != MCQ_OK || (S.round >= S.iters_min && ce <= S.curv_allowed);
+        S.final_rounds[k] = round;
+        if (S.curv_trace && round <= MCQ_IQP_TRACE) S.curv_trace[(size_t)k * MCQ_IQP_TRACE + round - 1] = ce;
+        const bool stop = st != MCQ_OK || (round >= S.iters_min && ce <= S.curv_allowed);
         if (stop) S.live[k] = 0;
-        else atomicAdd(S.live_count, 1);
+        else if (count) atomicAdd(S.live_count, 1);
     } else {
         if (S.live[k] != 0 && S.relin_status[k] != MCQ_OK) {      // the re-sampled ring does not fit the buffers
             S.live[k] = 0;
             S.final_status[k] = MCQ_RING_OVERFLOW;
-            atomicAdd(S.live_count, -1);
+            if (count) atomicAdd(S.live_count, -1);
         }
-        if (S.live[k] == 0) S.n_next[k] = 0;
+        if (S.live[k] == 0) n_next[k] = 0;
+    }
+}
+
+__global__ void __launch_bounds__(256) mcq_iqp_step_kernel(McqIqpStep S)
+{
+    const int k = (int)blockIdx.x * 256 + (int)threadIdx.x;
+    if (k >= S.batch) return;
+    iqp_step_track(S, k, S.phase, S.round, S.cur, S.n_ring, S.n_next, true);
+}
+
+// ---- The first rounds of iqp_handler for a batch of tracks as ONE launch: a track's rounds -- QP pass, termination test, glue -- depend on
+//      nothing but its own previous round, and no track can end before round iters_min, so a workgroup takes its track through `rounds`
+//      rounds on its own (the bodies of mcq_solve_kernel, mcq_iqp_step_kernel and mcq_relinearise_kernel, between workgroup barriers) and
+//      nobody waits for anybody: launched round by round, every round ended with its slowest track (a warm start that falls back takes
+//      8.7 ms where the median track takes 3) while most compute units idled.  F.live_count: tracks still iterating after the last round. ----
+__global__ void __launch_bounds__(MCQ_NT, 2) mcq_iqp_rounds_kernel(McqIqpRounds F)
+{
+    const int pb = (int)blockIdx.x;
+    for (int it = 1; it <= F.rounds; ++it) {
+        const int cur = (it - 1) & 1;
+        if (F.S.live[pb] == 0) {
+            // (the track stopped: neither ring buffer holds a ring to solve any more -- the round-by-round loop that may follow skips it)
+            if (threadIdx.x == 0) { F.n_set[0][pb] = 0; F.n_set[1][pb] = 0; }
+            break;
+        }
+        McqSet in;
+        in.n_list = F.n_set[cur];
+        in.ref = F.ref_set[cur];
+        in.nv = F.nv_set[cur];
+        in.sc = it == 1 ? F.sc : nullptr;                       // the re-spline of passes 2+ uses unit scalings (upstream)
+        in.warm = it > 1 ? F.warm : nullptr;
+        solve_body(F.B, in, pb);
+        __syncthreads();
+        if (threadIdx.x == 0) iqp_step_track(F.S, pb, 0, it, cur, F.n_set[cur], F.n_set[1 - cur], it == F.rounds);
+        __syncthreads();
+        McqRelinIO io;
+        io.n_in = F.n_set[cur]; io.ref_in = F.ref_set[cur]; io.nv_in = F.nv_set[cur];
+        io.ref_out = F.ref_set[1 - cur]; io.nv_out = F.nv_set[1 - cur]; io.n_out = F.n_set[1 - cur];
+        io.alpha_scale = it < F.S.iters_min ? (double)it / (double)F.S.iters_min : 1.0;
+        relin_body(F.R, io, pb, g_sm);
+        __syncthreads();
+        if (threadIdx.x == 0) iqp_step_track(F.S, pb, 1, it, cur, F.n_set[cur], F.n_set[1 - cur], it == F.rounds);
+        __syncthreads();
     }
 }
 
@@ -2281,7 +2371,8 @@ __global__ void __launch_bounds__(MCQ_NT) mcq_raceline_kernel(McqRace Q)
         return;
     }
     double total;
-    const int m = relin_front(ref, nv, al, n, 1.0, Q.stepsize, vec, nm, total);
+    __shared__ double relin_lds[RELIN_LDS];
+    const int m = relin_front(ref, nv, al, n, 1.0, Q.stepsize, vec, nm, total, relin_lds);
     if (m < 2 || m > Q.mmax) {
         if (tid == 0) { *status = MCQ_BAD_INPUT; *m_out = m > 0 ? m : 0; }
         return;

@@ -317,10 +317,10 @@ int mcq_solve_device_stream(mcq_handle* h, int steps, int batch, int n, const do
  * curv_error_allowed), the damping of the early rounds (alpha * round / iters_min) and the glue of mcq_relinearise_device for
  * the tracks that go on.  The host enqueues the first iters_min rounds without looking and then reads ONE int per round (how
  * many tracks are still iterating).  A track whose QP fails keeps that status and stops; the others are not affected.
- * Those first rounds run in GROUPS of tracks, each on a stream of its own (a track's passes depend on its own previous pass
- * only: a group waits for its own slowest track, not for the batch's; slice launches over the same arrays, results bitwise
- * those of one launch per round) -- $MCQ_IQP_GROUPS groups (default 2, at most 16; 1 = one launch per round), 64 tracks per
- * group at least unless the variable asks for less; with `stats->timed` or a round callback the rounds run one by one.
+ * Those first rounds are ONE launch in which every workgroup takes its track through the rounds on its own (a track's passes
+ * depend on its own previous pass only: launched round by round, every round would wait for the batch's slowest track);
+ * results bitwise those of one launch per round, which is what runs with `stats->timed`, with a round callback, or with
+ * $MCQ_IQP_FUSED=0.
  *
  * mcq_iqp_device: everything resident.  reftrack_a / normvec_a [batch][nmax][*] hold the tracks on entry (n_io [batch] their
  * waypoint counts), reftrack_b / normvec_b are the second set of the double buffer; scaling [batch][nmax] (first pass) or NULL.

@@ -1,9 +1,9 @@
 #!/usr/bin/env python
-"""mcq_iqp_batch on the 1024 synthetic ovals of BASELINE config 3 with the first iters_min rounds in 1 / 2 / 4 / 8 / 16 groups of tracks, a
-stream each ($MCQ_IQP_GROUPS; 1 = the one-launch-per-round loop): end to end seconds (best of three, end states into page-locked arrays),
-and the end states of every setting bitwise against those of the loop.  One JSON line.
+"""mcq_iqp_batch on the 1024 synthetic ovals of BASELINE config 3, the first iters_min rounds one launch per round ($MCQ_IQP_FUSED=0) and
+as one launch (mcq_iqp_rounds_kernel, the default): end to end seconds (best of three, end states into page-locked arrays), and the end
+states of the second bitwise against those of the first.  One JSON line.
 
-  python scripts/diag_iqp_groups.py [--batch 1024] [--n 2000] [--groups 1,2,4,8,16]
+  python scripts/diag_iqp_modes.py [--batch 1024] [--n 2000]
 """
 import argparse
 import json
@@ -22,20 +22,19 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--batch", type=int, default=1024)
     ap.add_argument("--n", type=int, default=2000)
-    ap.add_argument("--groups", default="1,2,4,8,16")
     args = ap.parse_args()
     eng = engine.Engine(0)
     ref, nv, sc = synthetic.oval_batch(args.batch, n=args.n)
-    trk = [dict(reftrack=ref[k], normvectors=nv[k], scaling=sc[k]) for k in range(args.batch)]
-    os.environ["MCQ_IQP_GROUPS"] = "1"
+    trk = dict(reftrack=ref, normvectors=nv, scaling=sc)
+    os.environ["MCQ_IQP_FUSED"] = "0"
     w0 = eng.iqp_batch(trk, 0.12, 3.4, 3.0)
     nmx = w0["stats"]["nmax"]
     obuf = dict(alpha=eng.host_array((args.batch, nmx)), reftrack=eng.host_array((args.batch, nmx, 4)),
                 normvectors=eng.host_array((args.batch, nmx, 2)))
     base = None
     rec = {}
-    for g in [int(x) for x in args.groups.split(",")]:
-        os.environ["MCQ_IQP_GROUPS"] = str(g)
+    for mode, fused in (("one launch per round", "0"), ("one launch", "1")):
+        os.environ["MCQ_IQP_FUSED"] = fused
         ts = []
         for _ in range(3):
             t0 = time.perf_counter()
@@ -49,9 +48,9 @@ def main():
                 np.array_equal(state["rounds"], base["rounds"]) and np.array_equal(state["curv"], base["curv"]) and
                 all(np.array_equal(a, b) for a, b in zip(state["alpha"], base["alpha"])) and
                 all(np.array_equal(a, b) for a, b in zip(state["reftrack"], base["reftrack"])))
-        rec[str(g)] = {"seconds": [round(t, 5) for t in ts], "qp_solves_per_s": r["stats"]["qp_solves"] / min(ts),
-                       "rounds": r["stats"]["rounds"], "failed": int(np.count_nonzero(r["status"])), "bitwise_equal_to_groups_1": bool(same)}
-    print(json.dumps({"what": "mcq_iqp_batch, %d tracks, N = %d, by $MCQ_IQP_GROUPS" % (args.batch, args.n), "by_groups": rec}))
+        rec[mode] = {"seconds": [round(t, 5) for t in ts], "qp_solves_per_s": r["stats"]["qp_solves"] / min(ts),
+                     "rounds": r["stats"]["rounds"], "failed": int(np.count_nonzero(r["status"])), "bitwise_equal_to_the_loop": bool(same)}
+    print(json.dumps({"what": "mcq_iqp_batch, %d tracks, N = %d" % (args.batch, args.n), "by_mode": rec}))
     eng.close()
 
 

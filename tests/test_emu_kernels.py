@@ -632,12 +632,12 @@ def test_iqp_batch_into_caller_kept_buffers(emu, golden):
         emu.iqp_batch(dict(reftrack=np.zeros((2, 50, 4)), normvectors=np.zeros((2, 49, 2))), 0.12, 3.4, 3.0)
 
 
-def test_iqp_groups_on_streams_of_their_own_equal_the_round_by_round_loop(emu, golden, monkeypatch):
-    """mcq_iqp_device runs the first iters_min rounds in groups of tracks, each group on a stream of its own with slice launches of the
-    solver / bookkeeping / glue kernels over the SAME arrays (round 5; a group waits for its own slowest track only).  Six tracks of three
-    shapes and sizes in three groups ($MCQ_IQP_GROUPS=3) against the one-launch-per-round loop ($MCQ_IQP_GROUPS=1): end states bitwise, round
-    counts and statuses equal -- one track that needs a fourth round (the loop takes over after round iters_min), one whose QP is infeasible
-    from the start (it stops in round 1 and must not hold up its group)."""
+def test_iqp_rounds_in_one_launch_equal_the_round_by_round_loop(emu, golden, monkeypatch):
+    """mcq_iqp_device runs the first iters_min rounds as ONE launch in which every workgroup takes its track through the rounds on its own
+    (mcq_iqp_rounds_kernel: the bodies of the solver, bookkeeping and glue kernels between workgroup barriers, the same arrays; round 5).
+    Six tracks of two shapes against the one-launch-per-round loop ($MCQ_IQP_FUSED=0): end states bitwise, round counts and statuses equal --
+    tracks that need a fourth round (the loop takes over after round iters_min), one whose QP is infeasible from the start (it stops in
+    round 1: neither of its ring buffers may be solved again), cold passes (warm_start=-1) as well."""
     trk = []
     for name, dw in (("rounded_rectangle", 0.0), ("handling_track", 0.0), ("rounded_rectangle", 0.4), ("handling_track", -0.2),
                      ("rounded_rectangle", -0.3), ("handling_track", 0.3)):
@@ -646,19 +646,22 @@ def test_iqp_groups_on_streams_of_their_own_equal_the_round_by_round_loop(emu, g
         r[:, 2:] += dw
         trk.append(dict(reftrack=r, normvectors=g["normvec"], scaling=g["scaling"]))
     trk[4]["reftrack"][:, 2:] = 1.0          # narrower than the vehicle: status 1 in the first pass
-    res = {}
-    for groups in ("1", "3"):
-        monkeypatch.setenv("MCQ_IQP_GROUPS", groups)
-        res[groups] = emu.iqp_batch(trk, 0.12, 3.4, 3.0, 3, 3e-3)          # (curv_error_allowed 0.003: these tracks need a fourth round)
-    a, b = res["1"], res["3"]
-    assert list(a["status"]) == list(b["status"]) and list(a["rounds"]) == list(b["rounds"]) and list(a["n"]) == list(b["n"])
-    assert a["status"][4] == engine.STATUS_INFEASIBLE and a["rounds"][4] == 1
-    assert max(a["rounds"]) > 3, list(a["rounds"])
-    for k in range(6):
-        for key in ("alpha", "reftrack", "normvectors"):
-            assert np.array_equal(a[key][k], b[key][k]), (k, key)
-        assert a["curv_err"][k] == b["curv_err"][k] and np.array_equal(a["curv_trace"][k], b["curv_trace"][k])
-    assert a["stats"]["qp_solves"] == b["stats"]["qp_solves"] == int(np.sum(a["rounds"]))
+    for kw in (dict(), dict(warm_start=-1)):
+        res = {}
+        for mode, fused in (("loop", "0"), ("one launch", "1")):
+            monkeypatch.setenv("MCQ_IQP_FUSED", fused)
+            res[mode] = emu.iqp_batch(trk if not kw else trk[:2], 0.12, 3.4, 3.0, 3, 3e-3, **kw)   # (curv_error_allowed 0.003: a fourth round)
+        a, b = res["loop"], res["one launch"]
+        ntr = len(a["status"])
+        if not kw:
+            assert a["status"][4] == engine.STATUS_INFEASIBLE and a["rounds"][4] == 1
+        assert max(a["rounds"]) > 3, list(a["rounds"])
+        assert list(a["status"]) == list(b["status"]) and list(a["rounds"]) == list(b["rounds"]) and list(a["n"]) == list(b["n"])
+        for k in range(ntr):
+            for key in ("alpha", "reftrack", "normvectors"):
+                assert np.array_equal(a[key][k], b[key][k]), (kw, k, key)
+            assert a["curv_err"][k] == b["curv_err"][k] and np.array_equal(a["curv_trace"][k], b["curv_trace"][k]), (kw, k)
+        assert a["stats"]["qp_solves"] == b["stats"]["qp_solves"] == int(np.sum(a["rounds"]))
 
 
 def test_host_batches_packed_by_several_threads(emu, golden, monkeypatch):

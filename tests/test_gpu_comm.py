@@ -166,12 +166,11 @@ def test_resident_stream_entry_on_two_compute_streams_is_bitwise_the_single_laun
         eng.free(p)
 
 
-def test_iqp_groups_on_streams_of_their_own_are_bitwise_the_round_by_round_loop(gpu_engine, monkeypatch):
-    """mcq_iqp_batch with the first iters_min rounds in groups of tracks, a stream each (slice launches of the solver / bookkeeping / glue
-    kernels over the same arrays, really concurrent here), against the one-launch-per-round loop ($MCQ_IQP_GROUPS=1): 192 ovals of 600
-    waypoints with per-track centrelines -- some need a fourth round, which the loop runs after the groups have joined --, one track narrower
-    than the vehicle (it stops in round 1) -- in 2, 3 and 5 groups, the batch packed by 1 and by 5 host threads, as a list of tracks and as
-    one dict of stacked arrays: end states, round counts, curvature errors bitwise."""
+def test_iqp_rounds_in_one_launch_are_bitwise_the_round_by_round_loop(gpu_engine, monkeypatch):
+    """mcq_iqp_batch with the first iters_min rounds as ONE launch (mcq_iqp_rounds_kernel: a workgroup takes its track through the rounds on
+    its own; the default) against the one-launch-per-round loop ($MCQ_IQP_FUSED=0): 192 ovals of 600 waypoints with per-track centrelines --
+    some need a fourth round, which the loop runs afterwards --, one track narrower than the vehicle (it stops in round 1); the batch packed
+    by 1 and by 5 host threads, as a list of tracks and as one dict of stacked arrays: end states, round counts, curvature errors bitwise."""
     from global_racetrajectory_optimization_amd import engine, synthetic
     eng = gpu_engine
     B, n = 192, 600
@@ -179,20 +178,21 @@ def test_iqp_groups_on_streams_of_their_own_are_bitwise_the_round_by_round_loop(
     ref[77, :, 2:] = 1.0
     trk = [dict(reftrack=ref[k], normvectors=nv[k], scaling=sc[k]) for k in range(B)]
     res = {}
-    for groups, threads, form in (("1", "1", trk), ("2", "5", trk), ("3", "1", dict(reftrack=ref, normvectors=nv, scaling=sc)), ("5", "5", trk)):
-        monkeypatch.setenv("MCQ_IQP_GROUPS", groups)
+    for mode, fused, threads, form in (("loop", "0", "1", trk), ("one launch", "1", "5", trk),
+                                       ("one launch, stacked", "1", "1", dict(reftrack=ref, normvectors=nv, scaling=sc))):
+        monkeypatch.setenv("MCQ_IQP_FUSED", fused)
         monkeypatch.setenv("MCQ_PACK_THREADS", threads)
         # (curv_error_allowed 4.5e-5: on these gentle ovals the third pass leaves 4e-5 .. 5.5e-5, the fourth 2.5e-5 .. 3.3e-5)
-        res[groups] = eng.iqp_batch(form, 0.12, 3.4, 3.0, iters_min=3, curv_error_allowed=4.5e-5, max_rounds=6)
-    a = res["1"]
+        res[mode] = eng.iqp_batch(form, 0.12, 3.4, 3.0, iters_min=3, curv_error_allowed=4.5e-5, max_rounds=6)
+    a = res["loop"]
     assert a["status"][77] == engine.STATUS_INFEASIBLE and a["rounds"][77] == 1
     assert np.count_nonzero(a["status"] == engine.STATUS_INFEASIBLE) == 1 and a["rounds"].max() > 3 and np.count_nonzero(a["rounds"] == 3) > 0, (
         np.unique(a["status"], return_counts=True), np.unique(a["rounds"], return_counts=True))
-    for groups in ("2", "3", "5"):
-        b = res[groups]
+    for mode in ("one launch", "one launch, stacked"):
+        b = res[mode]
         assert np.array_equal(a["status"], b["status"]) and np.array_equal(a["rounds"], b["rounds"]) and np.array_equal(a["n"], b["n"])
         assert np.array_equal(a["curv_err"], b["curv_err"]) and np.array_equal(a["curv_trace"], b["curv_trace"])
         for k in range(B):
-            assert np.array_equal(a["alpha"][k], b["alpha"][k]) and np.array_equal(a["reftrack"][k], b["reftrack"][k]), (groups, k)
-            assert np.array_equal(a["normvectors"][k], b["normvectors"][k]), (groups, k)
+            assert np.array_equal(a["alpha"][k], b["alpha"][k]) and np.array_equal(a["reftrack"][k], b["reftrack"][k]), (mode, k)
+            assert np.array_equal(a["normvectors"][k], b["normvectors"][k]), (mode, k)
         assert a["stats"]["qp_solves"] == b["stats"]["qp_solves"]
