@@ -154,3 +154,31 @@ def test_a_slice_of_the_curvature_tight_fuzz_on_the_interpreter(emu):
         if alg == engine.ALG_DEFAULT:
             j = ks.index(18)
             assert info[j]["second_attempt"] & 4 and info[j]["as_iters"] <= 14 and info[j]["gi_iters"] > 0, info[j]
+
+
+def test_random_rings_against_the_live_dense_oracle_on_the_interpreter(emu):
+    """24 random star-shaped rings (n = 24 ... 160, widths between barely feasible and generous: anything from a handful to most of the rows ends
+    on a bound -- the generator of the GPU suite's 96-ring fuzz, other seeds) in one ragged launch of the interpreted kernel sources, every one
+    against the live dense oracle; every third one also through the Goldfarb-Idnani path alone, whose step count on these box-only problems is
+    the dense implementation's."""
+    from test_emu_kernels import _small_track
+    rng = np.random.default_rng(515)
+    probs, refs = [], []
+    for k in range(24):
+        n = int(rng.integers(24, 161))
+        ref, nv, A, sc = _small_track(n, seed=9100 + k)
+        w_veh = float(rng.choice([1.2, 2.0, 2.6]))
+        ref[:, 2:] = 0.5 * w_veh + rng.uniform(0.05, 2.5) * rng.uniform(0.2, 1.0, size=(n, 2))
+        probs.append(dict(reftrack=ref, normvec=nv, scaling=sc, kappa_bound=1.0, w_veh=w_veh))
+        refs.append(tph_ref.opt_min_curv(ref, nv, A, 1.0, w_veh))
+    al, curv, st, info = emu.solve_batch(probs)
+    for k, (a_ref, err_ref) in enumerate(refs):
+        assert st[k] == 0, (k, st[k])
+        assert np.max(np.abs(al[k] - a_ref)) < 1e-8, (k, info[k])
+        assert abs(curv[k] - err_ref) < 1e-9, k
+    assert min(i["n_active_box"] for i in info) < 30 and max(i["n_active_box"] for i in info) > 40, sorted(i["n_active_box"] for i in info)
+    sub = list(range(0, 24, 3))
+    al2, curv2, st2, info2 = emu.solve_batch([probs[k] for k in sub], algorithm=engine.ALG_GI)
+    for j, k in enumerate(sub):
+        assert st2[j] == 0 and np.max(np.abs(al2[j] - refs[k][0])) < 1e-8, (k, info2[j])
+        assert np.array_equal(al2[j], al[k]), k          # the polish from the same working set is the default path's last round
