@@ -1,7 +1,6 @@
 """DIAGNOSTIC (round 5): mcq_solve_host_pipelined, 20 steps of the bench workload, against the device-resident loop on the same box.  MCQ_PIPE_ONE_STREAM=1: round 4's form."""
 import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-import numpy as np
 from global_racetrajectory_optimization_amd import engine, synthetic
 B, n, K = 1024, 2000, 20
 ref, nv, sc = synthetic.oval_batch(B, n=n)

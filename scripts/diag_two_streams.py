@@ -2,7 +2,6 @@
 process, the bench workload on each, launches enqueued alternately; against one engine doing the same number of launches."""
 import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-import numpy as np
 from global_racetrajectory_optimization_amd import engine, synthetic
 B, n, K = 1024, 2000, 10
 ref, nv, sc = synthetic.oval_batch(B, n=n)
