@@ -848,3 +848,53 @@ def test_saddle_point_elimination_in_isolation(n, fused, pinned, tmp_path):
     assert m and m.group(1) == "0" and m.group(2) == "0" and m.group(3) == "0", out
     berr = float(re.search(r"backward error .*: ([0-9.e+-]+)", out).group(1))
     assert berr < 1e-13, out
+
+
+_REVERSE_SCRIPT = r'''
+import sys
+import numpy as np
+sys.path.insert(0, sys.argv[1])
+sys.path.insert(0, sys.argv[1] + "/tests")
+from conftest import load_golden
+from global_racetrajectory_optimization_amd import engine
+eng = engine.Engine(0, lib_path=sys.argv[2])
+g, h = load_golden("rounded_rectangle"), load_golden("handling_track")
+out = {}
+probs = [dict(reftrack=g["reftrack"], normvec=g["normvec"], scaling=g["scaling"], kappa_bound=0.12, w_veh=3.4),
+         dict(reftrack=h["reftrack"], normvec=h["normvec"], scaling=h["scaling"], kappa_bound=0.055, w_veh=2.0)]      # curvature rows active
+for alg in (engine.ALG_DEFAULT, engine.ALG_GI):
+    al, curv, st, info = eng.solve_batch(probs, algorithm=alg)
+    for k in range(2):
+        out["alpha_%d_%d" % (alg, k)] = al[k]
+    out["curv_%d" % alg], out["status_%d" % alg] = curv, st
+r = eng.iqp_batch([dict(reftrack=g["reftrack"].copy(), normvectors=g["normvec"], scaling=g["scaling"]),
+                   dict(reftrack=h["reftrack"].copy(), normvectors=h["normvec"], scaling=h["scaling"])], 0.12, 3.4, 3.0, 3, 0.01)
+for k in range(2):
+    out["iqp_alpha_%d" % k], out["iqp_ref_%d" % k] = r["alpha"][k], r["reftrack"][k]
+out["iqp_rounds"] = r["rounds"]
+np.savez(sys.argv[3], **out)
+'''
+
+
+def test_reversed_work_item_order_changes_nothing(emu_lib, tmp_path):
+    """The interpreter runs the work-items of a workgroup in their natural order between barriers; with HIPEMU_REVERSE=1 the LAST wave runs every
+    phase first.  A kernel without a missing barrier cannot tell the difference: a box problem, one with active curvature rows, both through
+    the default path and the Goldfarb-Idnani path, and iqp_handler's rounds in one launch (mcq_iqp_rounds_kernel) -- bitwise the same in
+    both orders (each order in a process of its own: the variable is read once)."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    script = tmp_path / "rev.py"
+    script.write_text(_REVERSE_SCRIPT)
+    res = {}
+    for rev in ("0", "1"):
+        env = dict(os.environ, HIPEMU_REVERSE=rev, OMP_NUM_THREADS="1")
+        env.pop("MCQ_LIB", None)
+        p = subprocess.run([sys.executable, str(script), root, emu_lib, str(tmp_path / ("out%s.npz" % rev))], env=env, capture_output=True,
+                           text=True, timeout=600)
+        assert p.returncode == 0, p.stderr[-2000:]
+        res[rev] = np.load(tmp_path / ("out%s.npz" % rev))
+    assert sorted(res["0"].files) == sorted(res["1"].files)
+    for key in res["0"].files:
+        assert np.array_equal(res["0"][key], res["1"][key]), key
+    assert list(res["0"]["status_0"]) == [0, 0] and list(res["0"]["iqp_rounds"]) == [3, 4]
