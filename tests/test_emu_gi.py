@@ -182,3 +182,29 @@ def test_random_rings_against_the_live_dense_oracle_on_the_interpreter(emu):
     for j, k in enumerate(sub):
         assert st2[j] == 0 and np.max(np.abs(al2[j] - refs[k][0])) < 1e-8, (k, info2[j])
         assert np.array_equal(al2[j], al[k]), k          # the polish from the same working set is the default path's last round
+
+
+def test_full_size_dense_goldens_on_the_interpreter(emu):
+    """BASELINE's size on the CPU suite: eleven of the dense-oracle goldens of N = 2000 ... 2600 waypoints (first passes of the synthetic ovals,
+    one with the curvature bound active; N = 2100 / 2600 / 2600 with the curvature bound active: the long-ring route; IQP second / third-pass
+    QPs with their unit scalings and barely active bounds) through the interpreted kernel sources in one ragged launch -- 1e-8 m from the
+    dense oracle, `curv_error_max` to 1e-9 --, and the two with active curvature rows through the Goldfarb-Idnani path alone as well, bitwise
+    the default path's alpha."""
+    import os
+    gdir = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+    names = ("oval_n2000_w1", "oval_n2000_w7", "oval_n2000_c5", "oval_n2000_c13", "oval_n2000_kappa", "oval_n2100", "oval_n2600",
+             "oval_n2600_kappa", "iqp_pass2_oval5", "iqp_pass3_oval3", "iqp_pass3_oval629")          # (the GPU suite takes all eighteen)
+    files = [os.path.join(gdir, nm + ".npz") for nm in names]
+    gs = [np.load(f) for f in files]
+    probs = [dict(reftrack=g["reftrack"], normvec=g["normvec"], scaling=g["scaling"] if "scaling" in g.files else None,
+                  kappa_bound=float(g["kappa_bound"]), w_veh=float(g["w_veh"])) for g in gs]
+    al, curv, st, info = emu.solve_batch(probs)
+    for k, g in enumerate(gs):
+        assert st[k] == 0, (files[k], st[k], info[k])
+        assert np.max(np.abs(al[k] - g["alpha"])) < 1e-8, (files[k], float(np.max(np.abs(al[k] - g["alpha"]))), info[k])
+        assert abs(curv[k] - float(g["curv_error_max"])) < 1e-9, files[k]
+    kap = [k for k in range(len(gs)) if info[k]["n_active_kappa"] > 0]
+    assert len(kap) >= 2, [os.path.basename(files[k]) for k in kap]
+    al2, _, st2, info2 = emu.solve_batch([probs[k] for k in kap], algorithm=engine.ALG_GI)
+    for j, k in enumerate(kap):
+        assert st2[j] == 0 and info2[j]["gi_iters"] > 0 and np.array_equal(al2[j], al[k]), (files[k], info2[j])
