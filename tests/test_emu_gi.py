@@ -208,3 +208,22 @@ def test_full_size_dense_goldens_on_the_interpreter(emu):
     al2, _, st2, info2 = emu.solve_batch([probs[k] for k in kap], algorithm=engine.ALG_GI)
     for j, k in enumerate(kap):
         assert st2[j] == 0 and info2[j]["gi_iters"] > 0 and np.array_equal(al2[j], al[k]), (files[k], info2[j])
+
+
+def test_iqp_end_state_at_full_size_on_the_interpreter(emu, monkeypatch):
+    """BASELINE config 3 IS mincurv_iqp: the END STATE of the whole iqp_handler chain at N = 2000 (three passes, N = 2000 -> 2003 -> 2002:
+    re-sampling, width carry-over, re-spline, damping 1/3 and 2/3) against the committed output of the dense oracle's chain, through the
+    interpreted kernel sources -- the rounds as one launch (mcq_iqp_rounds_kernel) and round by round, bitwise the same."""
+    import os
+    g = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "oval_n2000.npz"))
+    trk = [dict(reftrack=g["reftrack"].copy(), normvectors=g["normvec"], scaling=g["scaling"])]
+    res = {}
+    for fused in ("1", "0"):
+        monkeypatch.setenv("MCQ_IQP_FUSED", fused)
+        res[fused] = emu.iqp_batch(trk, 0.12, 3.4, float(g["stepsize_interp"]), 3, 0.01)
+    r = res["1"]
+    assert r["status"][0] == 0 and r["rounds"][0] == len(g["iqp_n"]) == 3 and r["n"][0] == int(g["iqp_n"][-1])
+    assert np.max(np.abs(r["alpha"][0] - g["iqp_alpha"])) < 1e-8, float(np.max(np.abs(r["alpha"][0] - g["iqp_alpha"])))
+    assert np.max(np.abs(r["reftrack"][0] - g["iqp_reftrack"])) < 1e-6 and np.max(np.abs(r["normvectors"][0] - g["iqp_normvec"])) < 1e-8
+    for key in ("alpha", "reftrack", "normvectors"):
+        assert np.array_equal(res["0"][key][0], r[key][0]), key
