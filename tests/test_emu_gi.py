@@ -129,20 +129,20 @@ def test_zero_width_rows_both_paths_against_the_second_route(emu):
 
 
 def test_a_slice_of_the_curvature_tight_fuzz_on_the_interpreter(emu):
-    """Every twelfth problem of tests/golden/kappa_tight_fuzz.npz (18 of the 220: stadium plateaus, star-shaped rings, the reference's tracks with
+    """Every twelfth problem of tests/golden/kappa_tight_fuzz.npz (16 of the 220: stadium plateaus, star-shaped rings, the reference's tracks with
     the curvature bound drawn between 0.6 x and 1.0 x the box optimum's curvature maximum; some INCONSISTENT) through the unchanged kernel sources
-    on the CPU in one ragged launch, and every third one of those through the Goldfarb-Idnani path alone: the dense Goldfarb-Idnani's verdict
+    on the CPU in one ragged launch, and three of those through the Goldfarb-Idnani path alone: the dense Goldfarb-Idnani's verdict
     and vertex from both.  Problem 18 is one of those whose block-pivoting phase starts to cycle: it must hand over to the Goldfarb-Idnani path
     when the single-pivot rule would begin (12 rounds at most), not at the cap of 60.  (The full set runs on the GPU: tests/test_gpu_gi.py.)"""
     import os
     z = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "kappa_tight_fuzz.npz"))
     off = z["offsets"]
-    sl = list(range(6, len(off) - 1, 12))
-    for alg, ks in ((engine.ALG_DEFAULT, sl), (engine.ALG_GI, sl[2::3])):
+    sl = [k for k in range(6, len(off) - 1, 12) if k not in (42, 78)]          # (two of the three inconsistent ones left to the GPU suite: 7 and 11 s here)
+    for alg, ks in ((engine.ALG_DEFAULT, sl), (engine.ALG_GI, [30, 66, 138])):
         probs = [dict(reftrack=z["reftrack"][off[k]:off[k + 1]], normvec=z["normvec"][off[k]:off[k + 1]], scaling=z["scaling"][off[k]:off[k + 1]],
                       kappa_bound=float(z["kappa_bound"][k]), w_veh=float(z["w_veh"][k])) for k in ks]
         st_ref = z["status_ref"][ks]
-        assert np.sum(st_ref != 0) >= 1 and np.sum(st_ref == 0) >= 4
+        assert np.sum(st_ref != 0) >= 1 and np.sum(st_ref == 0) >= 2
         al, curv, st, info = emu.solve_batch(probs, algorithm=alg)
         assert np.array_equal(np.asarray(st), np.where(st_ref == 0, 0, engine.STATUS_KAPPA_INFEASIBLE)), (alg, list(st), list(st_ref))
         for j, k in enumerate(ks):
@@ -188,8 +188,8 @@ def test_full_size_dense_goldens_on_the_interpreter(emu):
     """BASELINE's size on the CPU suite: eleven of the dense-oracle goldens of N = 2000 ... 2600 waypoints (first passes of the synthetic ovals,
     one with the curvature bound active; N = 2100 / 2600 / 2600 with the curvature bound active: the long-ring route; IQP second / third-pass
     QPs with their unit scalings and barely active bounds) through the interpreted kernel sources in one ragged launch -- 1e-8 m from the
-    dense oracle, `curv_error_max` to 1e-9 --, and the two with active curvature rows through the Goldfarb-Idnani path alone as well, bitwise
-    the default path's alpha."""
+    dense oracle, `curv_error_max` to 1e-9 --, and the N = 2000 one with active curvature rows through the Goldfarb-Idnani path alone as well,
+    bitwise the default path's alpha."""
     import os
     gdir = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
     names = ("oval_n2000_w1", "oval_n2000_w7", "oval_n2000_c5", "oval_n2000_c13", "oval_n2000_kappa", "oval_n2100", "oval_n2600",
@@ -205,9 +205,9 @@ def test_full_size_dense_goldens_on_the_interpreter(emu):
         assert abs(curv[k] - float(g["curv_error_max"])) < 1e-9, files[k]
     kap = [k for k in range(len(gs)) if info[k]["n_active_kappa"] > 0]
     assert len(kap) >= 2, [os.path.basename(files[k]) for k in kap]
-    al2, _, st2, info2 = emu.solve_batch([probs[k] for k in kap], algorithm=engine.ALG_GI)
-    for j, k in enumerate(kap):
-        assert st2[j] == 0 and info2[j]["gi_iters"] > 0 and np.array_equal(al2[j], al[k]), (files[k], info2[j])
+    k = names.index("oval_n2000_kappa")          # (the 2600-point one through that path: 18 s here, and part of the GPU suite)
+    al2, _, st2, info2 = emu.solve_batch([probs[k]], algorithm=engine.ALG_GI)
+    assert st2[0] == 0 and info2[0]["gi_iters"] > 0 and np.array_equal(al2[0], al[k]), info2[0]
 
 
 def test_iqp_end_state_at_full_size_on_the_interpreter(emu, monkeypatch):
