@@ -258,6 +258,74 @@ def cpu_baseline(ref_b, nv_b, sc_b, alpha_gpu, curv_gpu, a_sample, b_sample):
 
 
 # ----------------------------------------------------------------------------------------------------------------------
+# BASELINE config 2: ONE QP behind the drop-in boundary, the way the untouched script calls it [REF main_globaltraj.py:264-271]
+# ----------------------------------------------------------------------------------------------------------------------
+def latency_batch1(eng, reps=15):
+    """What a caller of `tph.opt_min_curv.opt_min_curv(reftrack=, normvectors=, A=, ...)` waits for, batch = 1: the drop-in's
+    wall in the steady state and on the first call of a fresh handle, its pieces -- the N scalings read from the dense 4N x 4N matrix the
+    reference passes, the engine call (pack + H2D + kernel + D2H), the kernel alone (HIP events) -- and, beside it on this host, the
+    structure-exploiting CPU solver (oracle/banded_qp.c, ONE thread) on the same problem.  Berlin at the N of BASELINE config 2 (333), at the
+    ini's default step (776), and the bench workload's N = 2000 oval; inputs from tests/golden."""
+    from global_racetrajectory_optimization_amd import engine
+    from global_racetrajectory_optimization_amd import trajectory_planning_helpers as tph
+    from oracle import banded_ref
+    root = os.path.dirname(os.path.abspath(__file__))
+    saved = engine._DEFAULT_ENGINE
+    out = {"what": "tph.opt_min_curv.opt_min_curv(reftrack, normvectors, A, 0.12, 3.4) through the drop-in package, one problem per call, median of "
+                   "%d calls after a warm-up (ms); first_call_fresh_handle: the first call on a new engine handle in this process (workspace + "
+                   "staging allocation; HIP and the code object are already loaded); cpu_b_1thread: oracle/banded_qp.c (-O3 -march=native) on one "
+                   "host thread, same problem" % reps}
+    try:
+        for key, fixture in (("berlin_n333", "berlin_2018_n333"), ("berlin_n776", "berlin_2018"), ("oval_n2000", "oval_n2000")):
+            g = np.load(os.path.join(root, "tests", "golden", fixture + ".npz"))
+            ref, nv = np.ascontiguousarray(g["reftrack"]), np.ascontiguousarray(g["normvec"])
+            n = ref.shape[0]
+            A = tph.calc_splines.calc_splines(path=np.vstack((ref[:, :2], ref[0, :2])))[2]      # what prep_track hands the script
+            fresh = engine.Engine(eng.device_id, lib_path=eng.lib_path)
+            engine._DEFAULT_ENGINE = fresh
+            t0 = time.perf_counter()
+            a_first, _ = tph.opt_min_curv.opt_min_curv(reftrack=ref, normvectors=nv, A=A, kappa_bound=KAPPA_BOUND, w_veh=W_VEH)
+            t_first = time.perf_counter() - t0
+            t_call, t_sc, t_eng, k_ms = [], [], [], []
+            for _ in range(reps):
+                t0 = time.perf_counter()
+                alpha, _ = tph.opt_min_curv.opt_min_curv(reftrack=ref, normvectors=nv, A=A, kappa_bound=KAPPA_BOUND, w_veh=W_VEH)
+                t_call.append(time.perf_counter() - t0)
+                k_ms.append(fresh.last_timing_ms()["solve"])
+                t0 = time.perf_counter()
+                sc = engine.les_scalings(A)
+                t_sc.append(time.perf_counter() - t0)
+                t0 = time.perf_counter()
+                fresh.solve_batch([dict(reftrack=ref, normvec=nv, scaling=sc, kappa_bound=KAPPA_BOUND, w_veh=W_VEH)])
+                t_eng.append(time.perf_counter() - t0)
+            fresh.close()
+            rec = {"n": int(n), "opt_min_curv_ms": 1e3 * float(np.median(t_call)), "first_call_fresh_handle_ms": 1e3 * t_first,
+                   "scalings_from_dense_A_ms": 1e3 * float(np.median(t_sc)), "engine_call_ms": 1e3 * float(np.median(t_eng)),
+                   "kernel_ms": float(np.median(k_ms)), "A_bytes": int(A.nbytes),
+                   "max_abs_alpha_diff_vs_golden_m": float(np.max(np.abs(alpha - g["alpha"]))),
+                   "first_call_bitwise_equal": bool(np.array_equal(a_first, alpha))}
+            rec["ratio_call_to_kernel"] = rec["opt_min_curv_ms"] / max(rec["kernel_ms"], 1e-9)
+            try:
+                scg = g["scaling"] if "scaling" in g.files else sc
+                banded_ref.solve_batch(ref[None], nv[None], scg[None], KAPPA_BOUND, W_VEH, nthreads=1, native=True)
+                tb = []
+                for _ in range(3):
+                    t0 = time.perf_counter()
+                    a_b, _, st_b, _, _ = banded_ref.solve_batch(ref[None], nv[None], scg[None], KAPPA_BOUND, W_VEH, nthreads=1, native=True)
+                    tb.append(time.perf_counter() - t0)
+                rec["cpu_b_1thread_ms"] = 1e3 * float(np.median(tb)) if st_b[0] == 0 else None
+                rec["cpu_b_status"] = int(st_b[0])
+                if st_b[0] == 0:
+                    rec["cpu_b_max_abs_alpha_diff_m"] = float(np.max(np.abs(a_b[0] - alpha)))
+            except Exception as e:      # (a side record must not cost the line)
+                rec["cpu_b_error"] = str(e)[:200]
+            out[key] = rec
+    finally:
+        engine._DEFAULT_ENGINE = saved
+    return out
+
+
+# ----------------------------------------------------------------------------------------------------------------------
 def self_launch(args):
     """--gpus N > 1 without a launcher: run N ranks of this script under torch.distributed.run (one process per GPU)."""
     s = socket.socket()
@@ -689,6 +757,10 @@ def main():
             if not args.no_cpu_baseline:
                 cb = cpu_baseline(ref_h, nv_h, sc_h, alpha_gpu, curv_gpu, args.cpu_a_sample, args.cpu_b_sample)
                 out["cpu_baseline"] = dict(cb["cpu_a"], also={"cpu_b": cb["cpu_b"]})
+                try:
+                    out["latency_batch1"] = latency_batch1(eng)
+                except Exception as e:      # (a side record must not cost the line)
+                    out["latency_batch1"] = {"error": str(e)[:300]}
         elif world == 1 and not args.no_cpu_baseline and not args.no_extras and not emulate:
             # f32 boundary: the baseline solves the rows the engine saw
             r32 = engine.increments_to_rows(rows32, org) if d_org is not None else ref_h.astype(np.float32).astype(np.float64)

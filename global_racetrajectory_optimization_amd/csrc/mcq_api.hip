@@ -13,6 +13,7 @@
 #include <time.h>
 
 #include <algorithm>
+#include <cmath>
 #include <string>
 #include <thread>
 #include <vector>
@@ -79,9 +80,13 @@ struct mcq_handle {
     size_t vel_scratch_bytes = 0;
     double* kbig = nullptr;             // overflow slots of the curvature-row working set (MCQ_KBIG_SLOTS x MCQ_KBIG_SLOT doubles)
     int* slot_flags = nullptr;          // [MCQ_KBIG_SLOTS + MCQ_GI_SLOTS_MAX]: 0 free / 1 taken, claimed and released by the workgroups (never reset by the host)
-    double* gi = nullptr;               // slots of the Goldfarb-Idnani path (mcq_gi.inc): gi_slots x MCQ_GI_SLOT_DOUBLES(gi_nmax, gi_nmax)
+    double* gi = nullptr;               // FULL slots of the Goldfarb-Idnani path (mcq_gi.inc): gi_slots x MCQ_GI_SLOT_DOUBLES(gi_nmax, gi_nmax)
     int gi_slots = 0, gi_nmax = 0;
     long long gi_bytes = 0;
+    size_t gi_none_nmax = 0;            // > 0: no full slot could be had for rings of this many waypoints (beyond the byte cap, or hipMalloc said no) -- not tried again
+    double* gis = nullptr;              // SMALL slots (MCQ_ALG_GI: one per resident workgroup): gis_slots x MCQ_GI_SLOT_DOUBLES(gis_nmax, gi_small_qcap(gis_nmax))
+    int gis_slots = 0, gis_nmax = 0;
+    long long gis_bytes = 0;
     // mcq_solve_host_pipelined: a SECOND compute stream with a workspace of its own -- the kernels of consecutive steps run on alternating
     // streams, so the tail of one launch (its slowest problems, on CUs the others have left) overlaps the start of the next (round 5)
     hipStream_t stream2 = nullptr;
@@ -163,10 +168,11 @@ static void free_ws(mcq_handle* h)
 {
     (void)hipFree(h->L); (void)hipFree(h->vec); (void)hipFree(h->Z); (void)hipFree(h->state);
     (void)hipFree(h->state2);
-    (void)hipFree(h->kbig); (void)hipFree(h->slot_flags); (void)hipFree(h->gi);
-    h->kbig = nullptr; h->slot_flags = nullptr; h->gi = nullptr;
+    (void)hipFree(h->kbig); (void)hipFree(h->slot_flags); (void)hipFree(h->gi); (void)hipFree(h->gis);
+    h->kbig = nullptr; h->slot_flags = nullptr; h->gi = nullptr; h->gis = nullptr;
     h->gi_slots = h->gi_nmax = 0;
-    h->gi_bytes = 0;
+    h->gis_slots = h->gis_nmax = 0;
+    h->gi_bytes = h->gis_bytes = 0;
     h->L = h->vec = h->Z = nullptr;
     h->state = h->state2 = nullptr;
     h->state2_valid = false;
@@ -239,42 +245,100 @@ extern "C" void mcq_destroy(mcq_handle* h)
     delete h;
 }
 
-// Goldfarb-Idnani slots (mcq_gi.inc): a working set holds at most nmax independent constraints, so a slot is nmax x nmax (Q) + nmax x nmax
-// (R) doubles (64 MB at nmax = 2000); MCQ_GI_SLOTS of them for the fallback ($MCQ_GI_SLOTS asks for more), fewer for very long rings.
-// want: slots asked for -- MCQ_GI_SLOTS for the fallback (<= 4 GB in all), up to MCQ_GI_SLOTS_MAX when EVERY problem takes this path
-// (mcq_opts.algorithm = MCQ_ALG_GI: one slot per resident workgroup, <= 48 GB in all: 33 GB for 512 slots at nmax = 2000)
-static int ensure_gi(mcq_handle* h, size_t batch, size_t nmax, int want = MCQ_GI_SLOTS)
+// Goldfarb-Idnani slots (mcq_gi.inc).  Two pools:
+//   FULL slots  -- a working set holds at most nmax independent constraints: nmax x nmax (Q) + nmax x nmax (R) doubles (64 MB at nmax = 2000).  The
+//                  fallback's pool: as many as $MCQ_GI_BYTES (4 GB) hold, at most MCQ_GI_FULL_MAX = 128 (64 at nmax = 2000: a sweep over tight curvature
+//                  bounds can send hundreds of problems of one launch down this path), never more than the batch.  A rare path must not cost the
+//                  common one its launch: a slot beyond the byte cap (rings above ~16 000 waypoints) or a refused hipMalloc leaves the handle
+//                  WITHOUT the pool -- the kernel then returns what its own phases left (MCQ_ITER_CAP, ...), as in round 4; not tried again for
+//                  rings that long.
+//   SMALL slots -- round 6, mcq_opts.algorithm = MCQ_ALG_GI (every problem takes the path: one slot per resident workgroup): working sets of up to
+//                  gi_small_qcap(nmax) = nmax / 8 constraints (rounded up to 64, at least 128), what the path's working sets measure on every workload
+//                  here (62 .. 90 active rows at nmax = 2000, 130 adds at most); 4.6 MB at nmax = 2000, 2.4 GB for 512 of them (round 5: full slots,
+//                  34.7 GB).  A problem that outgrows its small slot starts again in a full one (gi_rescue).
+static size_t gi_small_qcap(size_t nmax)
 {
-    if (const char* e = getenv("MCQ_GI_SLOTS")) want = std::max(want, atoi(e));
+    const size_t q = std::max<size_t>(128, ((nmax / 8 + 63) / 64) * 64);
+    return std::min(q, nmax);
+}
+
+static size_t gi_byte_cap()
+{
+    if (const char* e = getenv("MCQ_GI_BYTES")) { const long long v = atoll(e); if (v >= 0) return (size_t)v; }
+    return (size_t)4 << 30;
+}
+
+// hipMalloc of `slots` items of `per` bytes, halving the count until the allocation succeeds; returns the count had (0: none)
+static int alloc_slots(double** out, int slots, size_t per)
+{
+    *out = nullptr;
+    while (slots >= 1) {
+        if (hipMalloc((void**)out, (size_t)slots * per) == hipSuccess) return slots;
+        (void)hipGetLastError();        // (an out-of-memory is not sticky, but it stays in the last-error slot)
+        *out = nullptr;
+        slots /= 2;
+    }
+    return 0;
+}
+
+static void ensure_gi(mcq_handle* h, size_t batch, size_t nmax)
+{
+    if (h->gi_none_nmax && nmax >= h->gi_none_nmax) return;
+    const size_t cap_bytes = gi_byte_cap();
+    int want = MCQ_GI_FULL_MAX;
+    if (const char* e = getenv("MCQ_GI_SLOTS")) want = std::min(std::max(atoi(e), 1), MCQ_GI_FULL_MAX);
     const size_t per = MCQ_GI_SLOT_DOUBLES(nmax, nmax) * sizeof(double);
-    const size_t cap_bytes = want > MCQ_GI_SLOTS ? ((size_t)48 << 30) : ((size_t)4 << 30);
-    // the fallback's slots: as many as 4 GB hold, between MCQ_GI_SLOTS and 128 (64 at nmax = 2000) -- a sweep over tight curvature bounds can send
-    // hundreds of problems of one launch down this path
-    if (want <= MCQ_GI_SLOTS) want = (int)std::min<size_t>(128, std::max<size_t>(MCQ_GI_SLOTS, cap_bytes / std::max<size_t>(per, 1)));
-    int slots = std::min(std::max(want, 1), MCQ_GI_SLOTS_MAX);
-    while (slots > 1 && (size_t)slots * per > cap_bytes) --slots;
+    int slots = (int)std::min<size_t>((size_t)want, cap_bytes / per);
     slots = (int)std::min<size_t>((size_t)slots, std::max<size_t>(batch, 1));
-    if (h->gi && (size_t)h->gi_nmax >= nmax && h->gi_slots >= slots) return 0;
+    if (h->gi && (size_t)h->gi_nmax >= nmax && h->gi_slots >= slots) return;
     nmax = std::max(nmax, (size_t)h->gi_nmax);
-    slots = std::max(slots, std::min(h->gi_slots, 128));
     const size_t per2 = MCQ_GI_SLOT_DOUBLES(nmax, nmax) * sizeof(double);
-    while (slots > 1 && (size_t)slots * per2 > cap_bytes) --slots;
-    HIP_TRY(hipStreamSynchronize(h->stream));
+    slots = std::max(slots, h->gi_slots);
+    slots = (int)std::min<size_t>((size_t)slots, cap_bytes / per2);
+    (void)hipStreamSynchronize(h->stream);
     (void)hipFree(h->gi);
     h->gi = nullptr;
     h->gi_slots = h->gi_nmax = 0;
-    HIP_TRY(hipMalloc((void**)&h->gi, (size_t)slots * per2));
-    if (h->poison) HIP_TRY(hipMemsetAsync(h->gi, 0xff, (size_t)slots * per2, h->stream));
+    h->gi_bytes = 0;
+    slots = alloc_slots(&h->gi, slots, per2);
+    if (slots < 1) { h->gi_none_nmax = nmax; return; }
+    if (h->poison) (void)hipMemsetAsync(h->gi, 0xff, (size_t)slots * per2, h->stream);
     h->gi_slots = slots;
     h->gi_nmax = (int)nmax;
     h->gi_bytes = (long long)((size_t)slots * per2);
+}
+
+// the small pool of MCQ_ALG_GI; an error only if the handle ends up with no slot of either kind (the caller asked for this path by name)
+static int ensure_gi_small(mcq_handle* h, size_t batch, size_t nmax)
+{
+    int slots = (int)std::min<size_t>(std::max<size_t>(batch, 1), MCQ_GI_SLOTS_MAX);
+    if (!(h->gis && (size_t)h->gis_nmax >= nmax && h->gis_slots >= slots)) {
+        nmax = std::max(nmax, (size_t)h->gis_nmax);
+        slots = std::max(slots, h->gis_slots);
+        const size_t per = MCQ_GI_SLOT_DOUBLES(nmax, gi_small_qcap(nmax)) * sizeof(double);
+        const size_t cap_bytes = std::max(gi_byte_cap(), (size_t)8 << 30);
+        slots = (int)std::min<size_t>((size_t)slots, cap_bytes / per);
+        (void)hipStreamSynchronize(h->stream);
+        (void)hipFree(h->gis);
+        h->gis = nullptr;
+        h->gis_slots = h->gis_nmax = 0;
+        h->gis_bytes = 0;
+        slots = alloc_slots(&h->gis, slots, per);
+        if (slots >= 1) {
+            if (h->poison) (void)hipMemsetAsync(h->gis, 0xff, (size_t)slots * per, h->stream);
+            h->gis_slots = slots;
+            h->gis_nmax = (int)nmax;
+            h->gis_bytes = (long long)((size_t)slots * per);
+        }
+    }
+    if (!h->gis && !h->gi) { g_err = "MCQ_ALG_GI: no device memory for a Goldfarb-Idnani slot at this ring size"; return MCQ_E_DEVICE; }
     return 0;
 }
 
 static int ensure_ws(mcq_handle* h, size_t batch, size_t nmax)
 {
     const size_t elems = batch * nmax;
-    if (elems <= h->cap_elems && batch <= h->cap_batch) return ensure_gi(h, batch, nmax);
+    if (elems <= h->cap_elems && batch <= h->cap_batch) { ensure_gi(h, batch, nmax); return 0; }
     HIP_TRY(hipStreamSynchronize(h->stream));
     free_ws(h);
     HIP_TRY(hipMalloc((void**)&h->L, elems * MCQ_LLD * sizeof(double)));
@@ -283,10 +347,9 @@ static int ensure_ws(mcq_handle* h, size_t batch, size_t nmax)
     HIP_TRY(hipMalloc((void**)&h->state, elems));
     HIP_TRY(hipMalloc((void**)&h->state2, elems));
     HIP_TRY(hipMalloc((void**)&h->kbig, (size_t)MCQ_KBIG_SLOTS * MCQ_KBIG_SLOT * sizeof(double)));
-    HIP_TRY(hipMalloc((void**)&h->slot_flags, (MCQ_KBIG_SLOTS + MCQ_GI_SLOTS_MAX) * sizeof(int)));
-    HIP_TRY(hipMemsetAsync(h->slot_flags, 0, (MCQ_KBIG_SLOTS + MCQ_GI_SLOTS_MAX) * sizeof(int), h->stream));
-    h->gi_slots = h->gi_nmax = 0;
-    if (int rc = ensure_gi(h, batch, nmax)) return rc;
+    HIP_TRY(hipMalloc((void**)&h->slot_flags, MCQ_SLOT_FLAGS * sizeof(int)));
+    HIP_TRY(hipMemsetAsync(h->slot_flags, 0, MCQ_SLOT_FLAGS * sizeof(int), h->stream));
+    ensure_gi(h, batch, nmax);
     if (h->poison) HIP_TRY(hipMemsetAsync(h->kbig, 0xff, (size_t)MCQ_KBIG_SLOTS * MCQ_KBIG_SLOT * sizeof(double), h->stream));
     HIP_TRY(hipMemsetAsync(h->state, 0, elems, h->stream));
     HIP_TRY(hipMemsetAsync(h->state2, 0, elems, h->stream));
@@ -316,23 +379,23 @@ static int ensure_alt(mcq_handle* h, size_t batch, size_t nmax)
     HIP_TRY(hipMalloc((void**)&h->Z2, (elems + batch * (size_t)MCQ_KMAX * MCQ_KMAX) * sizeof(double)));
     HIP_TRY(hipMalloc((void**)&h->state_alt, elems));
     HIP_TRY(hipMalloc((void**)&h->kbig2, (size_t)MCQ_KBIG_SLOTS * MCQ_KBIG_SLOT * sizeof(double)));
-    HIP_TRY(hipMalloc((void**)&h->slot_flags2, (MCQ_KBIG_SLOTS + MCQ_GI_SLOTS_MAX) * sizeof(int)));
-    HIP_TRY(hipMemsetAsync(h->slot_flags2, 0, (MCQ_KBIG_SLOTS + MCQ_GI_SLOTS_MAX) * sizeof(int), h->stream2));
+    HIP_TRY(hipMalloc((void**)&h->slot_flags2, MCQ_SLOT_FLAGS * sizeof(int)));
+    HIP_TRY(hipMemsetAsync(h->slot_flags2, 0, MCQ_SLOT_FLAGS * sizeof(int), h->stream2));
     const size_t per = MCQ_GI_SLOT_DOUBLES(nmax, nmax) * sizeof(double);
-    int slots = std::max(1, h->gi_slots / 2);
-    HIP_TRY(hipMalloc((void**)&h->gi2, (size_t)slots * per));
+    // half the first workspace's full slots (none where it has none: the kernel then returns what its own phases left)
+    int slots = h->gi && (size_t)h->gi_nmax >= nmax ? alloc_slots(&h->gi2, std::max(1, h->gi_slots / 2), per) : 0;
     HIP_TRY(hipMemsetAsync(h->state_alt, 0, elems, h->stream2));
     if (h->poison) {
         HIP_TRY(hipMemsetAsync(h->L2, 0xff, elems * MCQ_LLD * sizeof(double), h->stream2));
         HIP_TRY(hipMemsetAsync(h->vec2, 0xff, elems * MCQ_NVEC * sizeof(double), h->stream2));
         HIP_TRY(hipMemsetAsync(h->Z2, 0xff, (elems + batch * (size_t)MCQ_KMAX * MCQ_KMAX) * sizeof(double), h->stream2));
         HIP_TRY(hipMemsetAsync(h->kbig2, 0xff, (size_t)MCQ_KBIG_SLOTS * MCQ_KBIG_SLOT * sizeof(double), h->stream2));
-        HIP_TRY(hipMemsetAsync(h->gi2, 0xff, (size_t)slots * per, h->stream2));
+        if (h->gi2) HIP_TRY(hipMemsetAsync(h->gi2, 0xff, (size_t)slots * per, h->stream2));
     }
     h->alt_elems = elems;
     h->alt_batch = batch;
     h->gi2_slots = slots;
-    h->gi2_nmax = (int)nmax;
+    h->gi2_nmax = (int)nmax;      // (the ring size this workspace was sized for, with or without slots)
     h->alt_bytes = (long long)(elems * ((MCQ_LLD + MCQ_NVEC + 1) * sizeof(double) + 1) + batch * (size_t)MCQ_KMAX * MCQ_KMAX * sizeof(double) +
                                (size_t)MCQ_KBIG_SLOTS * MCQ_KBIG_SLOT * sizeof(double) + (size_t)slots * per);
     return 0;
@@ -382,15 +445,28 @@ static int fill_batch(mcq_handle* h, McqBatch& B, const mcq_opts& o, bool alt)
     B.kbig_slots = MCQ_KBIG_SLOTS;
     B.algorithm = o.algorithm;
     // the Goldfarb-Idnani slots hold working sets of up to gi_nmax constraints on rings of up to gi_nmax waypoints (slot stride: B.nmax)
-    if (!alt && o.algorithm == MCQ_ALG_GI && o.objective == MCQ_OBJ_MIN_CURV && !B.prep_only) {
-        // every problem takes the Goldfarb-Idnani path: a slot per resident workgroup, so that they run side by side instead of eight at a time
-        if (int rc = ensure_gi(h, (size_t)B.batch, (size_t)B.nmax, std::min(B.batch, MCQ_GI_SLOTS_MAX))) return rc;
+    const bool gi_path = o.objective == MCQ_OBJ_MIN_CURV && !B.prep_only;
+    B.gis = nullptr;
+    B.gis_slots = B.gis_qcap = 0;
+    if (!alt && o.algorithm == MCQ_ALG_GI && gi_path) {
+        // every problem takes the Goldfarb-Idnani path: a (small) slot per resident workgroup, so that they run side by side
+        if (int rc = ensure_gi_small(h, (size_t)B.batch, (size_t)B.nmax)) return rc;
+        if (h->gis && B.nmax <= h->gis_nmax) {
+            B.gis = h->gis;
+            B.gis_slots = h->gis_slots;
+            B.gis_qcap = (int)gi_small_qcap((size_t)B.nmax);
+        }
     }
     double* gi_mem = alt ? h->gi2 : h->gi;
-    const bool gi_on = gi_mem && B.nmax <= (alt ? h->gi2_nmax : h->gi_nmax) && o.objective == MCQ_OBJ_MIN_CURV && !B.prep_only;
+    const bool gi_on = gi_mem && (alt ? h->gi2_slots : h->gi_slots) > 0 && B.nmax <= (alt ? h->gi2_nmax : h->gi_nmax) && gi_path;
     B.gi = gi_on ? gi_mem : nullptr;
     B.gi_slots = gi_on ? (alt ? h->gi2_slots : h->gi_slots) : 0;
     B.gi_qcap = B.nmax;
+    // The overflow slots of the curvature-row working set (rounds 3-4) serve only where no Goldfarb-Idnani slot exists: which of more than eight
+    // such problems of a launch got one depended on the order the GPU scheduled workgroups in, and so did the last bits of their results
+    // (ADVICE r5).  With a Goldfarb-Idnani pool every working set beyond MCQ_KMAX rows takes THAT path -- one route per problem, whatever else
+    // is in the launch.
+    if (B.gi || B.gis) B.kbig_slots = 0;
     return 0;
 }
 
@@ -841,7 +917,7 @@ extern "C" int mcq_copy_to_host(mcq_handle* h, void* dst, const void* src, size_
     HIP_TRY(hipSetDevice(h->device));
     // a gather enqueued before this copy may be writing `src` on the comm stream: the copy is ordered behind the latest one (ADVICE r4:
     // parallel.solve_sharded read its receive buffer before the gather had finished)
-    if (h->comm_seq > 0) HIP_TRY(hipStreamWaitEvent(h->stream, h->comm_done[(h->comm_seq - 1) & 3u], 0));
+    if (h->comm_stream && h->comm_seq > 0) HIP_TRY(hipStreamWaitEvent(h->stream, h->comm_done[(h->comm_seq - 1) & 3u], 0));
     HIP_TRY(hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToHost, h->stream));
     HIP_TRY(hipStreamSynchronize(h->stream));
     return 0;
@@ -897,7 +973,7 @@ extern "C" int mcq_timing_end(mcq_handle* h, float* ms_out, int* launches_out)
     return 0;
 }
 
-extern "C" long long mcq_workspace_bytes(mcq_handle* h) { return h ? h->ws_bytes + h->gi_bytes + h->alt_bytes : 0; }
+extern "C" long long mcq_workspace_bytes(mcq_handle* h) { return h ? h->ws_bytes + h->gi_bytes + h->gis_bytes + h->alt_bytes : 0; }
 
 static int ensure_pin(mcq_handle* h, size_t bytes)
 {
@@ -925,6 +1001,67 @@ static int ensure_pin(mcq_handle* h, size_t bytes)
             return MCQ_E_DEVICE;                                                                          \
         }                                                                                                 \
     } while (0)
+
+// ---- the n spline scalings out of the dense matrix the reference passes (include/mcq.h); host code, no GPU ----------------------------------
+extern "C" int mcq_les_scalings(const double* A, int n, double* s_out, int check)
+{
+    if (!A || !s_out || n < 3) { g_err = "mcq_les_scalings: bad argument"; return MCQ_E_ARG; }
+    const size_t m = (size_t)4 * n;
+    for (int i = 0; i + 1 < n; ++i) s_out[i] = -A[((size_t)4 * i + 2) * m + 4 * i + 5];
+    s_out[n - 1] = A[(m - 2) * m + 1];
+    if (!check) return 0;
+    // Row by row: the entries the closed-spline system has in that row, at their values (the wrap-around rows carry the
+    // opposite sign), and NOTHING else -- a row's non-zeros are counted while it streams through.
+    int nthreads = 8;
+    if (const char* e = getenv("MCQ_PACK_THREADS")) nthreads = atoi(e);
+    const int hw = (int)std::thread::hardware_concurrency();
+    if (hw > 0 && nthreads > hw) nthreads = hw;
+    if (nthreads > n) nthreads = n;
+    if (nthreads < 1 || m * m < ((size_t)1 << 21)) nthreads = 1;
+    std::vector<long long> bad((size_t)nthreads, -1);          // first offending (row * m + column) of a thread's blocks
+    auto rel = [](double a, double b) { return fabs(a - b) <= 1e-12 * fabs(b); };
+    auto scan = [&](int t) {
+        const int i0 = (int)((long long)n * t / nthreads), i1 = (int)((long long)n * (t + 1) / nthreads);
+        for (int i = i0; i < i1 && bad[t] < 0; ++i) {
+            const size_t j = (size_t)4 * i;
+            const bool last = i == n - 1;
+            const double s = s_out[i];
+            if (!(s > 0.0) || !std::isfinite(s)) { bad[t] = (long long)((j + 2) * m + (last ? 1 : j + 5)); break; }
+            for (int r = 0; r < 4; ++r) {
+                const double* row = A + (j + r) * m;
+                size_t nz = 0;
+                for (size_t c = 0; c < m; ++c) nz += row[c] != 0.0;
+                bool ok;
+                if (r == 0) ok = nz == 1 && row[j] == 1.0;
+                else if (r == 1) ok = nz == 4 && row[j] == 1.0 && row[j + 1] == 1.0 && row[j + 2] == 1.0 && row[j + 3] == 1.0;
+                else if (r == 2) ok = nz == 4 && (last ? (row[j + 1] == -1.0 && row[j + 2] == -2.0 && row[j + 3] == -3.0 && row[1] == s)
+                                                       : (row[j + 1] == 1.0 && row[j + 2] == 2.0 && row[j + 3] == 3.0 && row[j + 5] == -s));
+                else ok = nz == 3 && (last ? (row[j + 2] == -2.0 && row[j + 3] == -6.0 && rel(row[2], 2.0 * s * s))
+                                           : (row[j + 2] == 2.0 && row[j + 3] == 6.0 && rel(-row[j + 6], 2.0 * s * s)));
+                if (!ok) { bad[t] = (long long)((j + r) * m); break; }
+            }
+        }
+    };
+    if (nthreads > 1) {
+        std::vector<std::thread> th;
+        int taken = 1;
+        try {
+            for (; taken < nthreads; ++taken) th.emplace_back(scan, taken);
+        } catch (...) {}
+        scan(0);
+        for (int t = taken; t < nthreads; ++t) scan(t);
+        for (auto& t : th) t.join();
+    } else scan(0);
+    for (int t = 0; t < nthreads; ++t) {
+        if (bad[t] >= 0) {
+            char buf[160];
+            snprintf(buf, sizeof buf, "mcq_les_scalings: row %lld of A does not have the structure of calc_splines' closed-spline system", bad[t] / (long long)m);
+            g_err = buf;
+            return MCQ_E_ARG;
+        }
+    }
+    return 0;
+}
 
 extern "C" int mcq_host_alloc(mcq_handle* h, size_t bytes, void** out)
 {
@@ -1094,7 +1231,9 @@ extern "C" int mcq_solve_host_pipelined(mcq_handle* h, int steps, int batch, int
     if (rc) return rc;
     double* pin_cu = (double*)h->pin;
     int* pin_st = (int*)(pin_cu + (size_t)steps * batch);
-    const bool two = steps > 1 && !getenv("MCQ_PIPE_ONE_STREAM");      // kernels of odd steps on the second compute stream / workspace (the variable: A/B knob)
+    // kernels of odd steps on the second compute stream / workspace (the variable: A/B knob); MCQ_ALG_GI stays on one stream: its slots
+    // (one per resident workgroup) belong to the first workspace (the second one's few slots made odd steps run ~32 problems at a time)
+    const bool two = steps > 1 && !getenv("MCQ_PIPE_ONE_STREAM") && o.algorithm != MCQ_ALG_GI;
     if (two) { rc = ensure_alt(h, (size_t)batch, (size_t)n); if (rc) return rc; }
     HIP_TRY(hipStreamSynchronize(h->stream));          // whatever ran before on the handle's stream is done with the staging buffers
     const size_t elems = (size_t)batch * n;
@@ -1543,7 +1682,7 @@ extern "C" int mcq_solve_device_stream(mcq_handle* h, int steps, int batch, int 
     const mcq_opts o = resolve_opts(opts);
     int rc = ensure_ws(h, (size_t)batch, (size_t)n);
     if (rc) return rc;
-    const bool two = steps > 1 && !getenv("MCQ_PIPE_ONE_STREAM");
+    const bool two = steps > 1 && !getenv("MCQ_PIPE_ONE_STREAM") && o.algorithm != MCQ_ALG_GI;
     if (two) { rc = ensure_alt(h, (size_t)batch, (size_t)n); if (rc) return rc; }
     // the second stream starts behind whatever the caller has enqueued on the first (uploads of the inputs, an earlier call)
     if (two) {
@@ -1847,6 +1986,9 @@ extern "C" int mcq_comm_destroy(mcq_handle* h)
         for (int k = 0; k < 4; ++k) { (void)hipEventDestroy(h->comm_t0[k]); (void)hipEventDestroy(h->comm_done[k]); }
         (void)hipStreamDestroy(h->comm_stream);
         h->comm_stream = nullptr;
+        h->comm_ready = nullptr;
+        for (int k = 0; k < 4; ++k) h->comm_t0[k] = h->comm_done[k] = nullptr;
     }
+    h->comm_seq = 0;      // no gather in flight any more: mcq_copy_to_host / mcq_device_free must not wait on the destroyed events
     return ret;
 }

@@ -102,9 +102,12 @@ struct McqBatch {
     int objective;          // MCQ_OBJ_*: shortest path = H (a cyclic tridiagonal: two vectors) and f written directly by
                             // mcq_assemble_sp_kernel, the gradient is H x + f; no curvature rows, no curvature-error post-check
     int algorithm;          // MCQ_ALG_GI: interior point and block pivoting are skipped, every problem goes through the Goldfarb-Idnani path
-    double* gi;             // slots of the Goldfarb-Idnani path (mcq_gi.inc), MCQ_GI_SLOT_DOUBLES(nmax, gi_qcap) doubles each: a workgroup whose
+    double* gi;             // FULL slots of the Goldfarb-Idnani path (mcq_gi.inc), MCQ_GI_SLOT_DOUBLES(nmax, gi_qcap) doubles each: a workgroup whose
     int gi_slots, gi_qcap;  // problem needs the path claims one (and waits for one if all are taken); gi_qcap = constraints a working set can
                             // hold (= nmax: no more can be independent)
+    double* gis;            // SMALL slots (round 6; MCQ_ALG_GI: one per resident workgroup), working sets of up to gis_qcap < nmax constraints --
+    int gis_slots, gis_qcap; // what the observed working sets need; a problem that outgrows its small slot starts again in a full one.
+                            // Flags: slot_flags[kbig_slots + MCQ_GI_FULL_MAX + s]
 };
 
 __global__ void mcq_assemble_kernel(McqBatch B);
@@ -113,7 +116,10 @@ __global__ void mcq_solve_kernel(McqBatch B);      // saddle-point elimination (
 /* Goldfarb-Idnani dual active-set path (mcq_gi.inc): inside mcq_solve_kernel, for whatever its interior point + block pivoting did not
  * settle (iteration cap, working set beyond its arrays, ...) -- solved again from scratch by quadprog's algorithm, in an HBM slot of the handle */
 #define MCQ_GI_SLOTS 8
-#define MCQ_GI_SLOTS_MAX 512       /* ... and when every problem takes the path (mcq_opts.algorithm = MCQ_ALG_GI): one per resident workgroup */
+#define MCQ_GI_FULL_MAX 128        /* full slots (working sets of up to nmax constraints) a handle holds at most */
+#define MCQ_GI_SLOTS_MAX 512       /* small slots when every problem takes the path (mcq_opts.algorithm = MCQ_ALG_GI): one per resident workgroup */
+#define MCQ_SLOT_FLAGS (MCQ_KBIG_SLOTS + MCQ_GI_FULL_MAX + MCQ_GI_SLOTS_MAX)
+#define MCQ_GI_SLOT_FULL 100       /* gi_solve: the working set has outgrown the slot (internal: gi_rescue moves the problem to a full slot) */
 #define MCQ_GI_SLOT_DOUBLES(nm, qcap) ((size_t)(qcap) * (size_t)(nm) + (size_t)(qcap) * (size_t)(qcap) + 9 * (size_t)(qcap) + 8)
 
 /* tph.check_normals_crossing [REF helper_funcs_glob/src/prep_track.py:57-59], one workgroup per track: crossing_out [batch] =

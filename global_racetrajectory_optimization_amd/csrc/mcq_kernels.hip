@@ -1706,7 +1706,7 @@ __device__ __forceinline__ void solve_body(const McqBatch& B, const McqSet& IN, 
     }
     problem_scales(c);
     // mcq_opts.algorithm = MCQ_ALG_GI: every problem through the Goldfarb-Idnani path at the end of this kernel, nothing else
-    const bool gi_only = B.algorithm == MCQ_ALG_GI && !c.direct && B.gi != nullptr;
+    const bool gi_only = B.algorithm == MCQ_ALG_GI && !c.direct && (B.gi != nullptr || B.gis != nullptr);
 
     // ---- phase 1: box-constrained QP ---------------------------------------------------------------------------------------
     int ipm_iters = 0, as_iters = 0, nact_kappa = 0;
@@ -1841,8 +1841,8 @@ __device__ __forceinline__ void solve_body(const McqBatch& B, const McqSet& IN, 
 
     // ---- the Goldfarb-Idnani path for whatever the phases above did not settle (mcq_gi.inc): quadprog's algorithm, finite by construction ----
     int gi_iters = 0;
-    if (!c.direct && B.gi && gi_eligible(status, B.check_kappa)) {
-        status = gi_rescue(c, B.gi, B.gi_slots, B.gi_qcap, B.slot_flags + B.kbig_slots, B.check_kappa != 0, status, as_iters, nact_kappa, kkt, km, gi_iters);
+    if (!c.direct && (B.gi || B.gis) && gi_eligible(status, B.check_kappa)) {
+        status = gi_rescue(c, B, B.check_kappa != 0, status, as_iters, nact_kappa, kkt, km, gi_iters);
         dd_valid = true;
     }
     McqOutcome r;

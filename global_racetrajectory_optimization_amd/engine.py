@@ -101,7 +101,8 @@ EXPORTED_SYMBOLS = ("mcq_create", "mcq_destroy", "mcq_last_error", "mcq_default_
                     "mcq_device_alloc",
                     "mcq_device_free", "mcq_copy_to_device", "mcq_copy_to_host", "mcq_sync", "mcq_stream",
                     "mcq_last_timing", "mcq_timing_begin", "mcq_timing_end", "mcq_workspace_bytes",
-                    "mcq_comm_unique_id", "mcq_comm_init", "mcq_comm_allgather", "mcq_comm_wait", "mcq_comm_world", "mcq_comm_destroy")
+                    "mcq_comm_unique_id", "mcq_comm_init", "mcq_comm_allgather", "mcq_comm_wait", "mcq_comm_world", "mcq_comm_destroy",
+                    "mcq_les_scalings")
 
 
 IQP_ROUND_CB = ctypes.CFUNCTYPE(None, ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.POINTER(ctypes.c_double), ctypes.POINTER(ctypes.c_int))
@@ -145,6 +146,8 @@ def load_library(path=None):
     lib.mcq_iqp_batch.restype = ctypes.c_int
     lib.mcq_iqp_set_round_callback.argtypes = [vp, IQP_ROUND_CB, vp]
     lib.mcq_iqp_set_round_callback.restype = ctypes.c_int
+    lib.mcq_les_scalings.argtypes = [vp, ctypes.c_int, vp, ctypes.c_int]
+    lib.mcq_les_scalings.restype = ctypes.c_int
     lib.mcq_host_alloc.argtypes = [vp, ctypes.c_size_t, ctypes.POINTER(vp)]
     lib.mcq_host_alloc.restype = ctypes.c_int
     lib.mcq_host_free.argtypes = [vp, vp]
@@ -263,6 +266,7 @@ class Engine:
             raise EngineError("mcq_create(%d) failed: %s" % (device_id, self.lib.mcq_last_error().decode()))
         self.h = h
         self.device_id = int(device_id)
+        self.lib_path = lib_path
 
     def close(self):
         if getattr(self, "h", None):
@@ -879,6 +883,30 @@ class Engine:
 
     def comm_destroy(self):
         self._check(self.lib.mcq_comm_destroy(self.h), "mcq_comm_destroy")
+
+
+_LIB_FOR_HOST_HELPERS = None
+
+
+def les_scalings(A, check=True):
+    """The N spline scalings out of the dense [4N, 4N] matrix the reference passes as `A` (mcq_les_scalings: one threaded pass over the matrix in
+    C, no GPU, no handle) -- the structural check of trajectory_planning_helpers.calc_splines.scalings_from_les_matrix, which stays as its
+    numpy statement (and takes any array this entry cannot: other dtypes, non-contiguous views).  Raises RuntimeError with upstream-style
+    wording when `A` is not calc_splines' closed-spline system."""
+    global _LIB_FOR_HOST_HELPERS
+    if not (isinstance(A, np.ndarray) and A.dtype == np.float64 and A.ndim == 2 and A.shape[0] == A.shape[1] and A.shape[0] % 4 == 0
+            and A.shape[0] >= 12 and A.flags["C_CONTIGUOUS"]):
+        from .trajectory_planning_helpers import calc_splines as _cs
+        return _cs.scalings_from_les_matrix(A, check=check)
+    if _LIB_FOR_HOST_HELPERS is None:
+        _LIB_FOR_HOST_HELPERS = _DEFAULT_ENGINE.lib if _DEFAULT_ENGINE is not None else load_library()
+    n = A.shape[0] // 4
+    s = np.empty(n)
+    if _LIB_FOR_HOST_HELPERS.mcq_les_scalings(A.ctypes.data, n, s.ctypes.data, 1 if check else 0) != 0:
+        raise RuntimeError("Spline equation system matrix A does not have the structure of calc_splines' closed-spline "
+                           "system (the MI355X engine derives everything from the N spline scalings it encodes and "
+                           "cannot use an arbitrary matrix): " + _LIB_FOR_HOST_HELPERS.mcq_last_error().decode())
+    return s
 
 
 _DEFAULT_ENGINE = None

@@ -44,7 +44,33 @@ def _stub_casadi():
     return mod
 
 
-def run(reference_dir, opt_type="mincurv", track_name="berlin_2018", scratch=None, quiet=False):
+RECORDED_ENTRY_POINTS = (("opt_min_curv", "opt_min_curv"), ("iqp_handler", "iqp_handler"), ("opt_shortest_path", "opt_shortest_path"))
+
+
+def _install_recorder(tph, record):
+    """record (a list) receives one dict per call the script makes through the drop-in boundary [REF main_globaltraj.py:264-271, 273-284,
+    286-290, 344-350]: the entry point's name and a deep copy of its keyword arguments as they were BEFORE the call (iqp_handler works on
+    its arguments).  Returns the undo function."""
+    import copy
+    saved = []
+    for mod_name, fn_name in RECORDED_ENTRY_POINTS:
+        mod = getattr(tph, mod_name)
+        orig = getattr(mod, fn_name)
+
+        def wrapper(*args, _orig=orig, _name=mod_name + "." + fn_name, **kwargs):
+            record.append(dict(entry=_name, args=copy.deepcopy(args), kwargs=copy.deepcopy(kwargs)))
+            return _orig(*args, **kwargs)
+
+        setattr(mod, fn_name, wrapper)
+        saved.append((mod, fn_name, orig))
+
+    def undo():
+        for mod, fn_name, orig in saved:
+            setattr(mod, fn_name, orig)
+    return undo
+
+
+def run(reference_dir, opt_type="mincurv", track_name="berlin_2018", scratch=None, quiet=False, record=None):
     reference_dir = os.path.abspath(reference_dir)
     scratch = scratch or tempfile.mkdtemp(prefix="globaltraj_")
     work = os.path.join(scratch, "reference")
@@ -82,6 +108,7 @@ def run(reference_dir, opt_type="mincurv", track_name="berlin_2018", scratch=Non
         sys.modules["trajectory_planning_helpers"] = tph
         for sub in tph._SUBMODULES:
             sys.modules["trajectory_planning_helpers." + sub] = getattr(tph, sub)
+        undo_recorder = _install_recorder(tph, record) if record is not None else (lambda: None)
         if "casadi" not in sys.modules:
             sys.modules["casadi"] = _stub_casadi()
         import pkg_resources
@@ -101,6 +128,7 @@ def run(reference_dir, opt_type="mincurv", track_name="berlin_2018", scratch=Non
             sys.stdout = stdout
             os.chdir(cwd)
             pkg_resources.require = orig_require
+            undo_recorder()
     finally:
         sys.path[:] = saved_path
         for k, v in saved_modules.items():
@@ -117,7 +145,7 @@ def run(reference_dir, opt_type="mincurv", track_name="berlin_2018", scratch=Non
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--reference", default="/root/reference")
-    ap.add_argument("--opt-type", default="mincurv", choices=("mincurv", "mincurv_iqp"))
+    ap.add_argument("--opt-type", default="mincurv", choices=("mincurv", "mincurv_iqp", "shortest_path"))
     ap.add_argument("--track", default="berlin_2018")
     args = ap.parse_args()
     res = run(args.reference, args.opt_type, args.track)

@@ -127,11 +127,10 @@ def iqp_handler(reftrack: np.ndarray, normvectors: np.ndarray, A: np.ndarray, ka
                 print_debug: bool, plot_debug: bool, stepsize_interp: float, iters_min: int = 3,
                 curv_error_allowed: float = 0.01) -> tuple:
     """Returns (alpha_mincurv [N'], reftrack [N',4], normvectors [N',2]) of the last re-linearisation."""
-    from .calc_splines import scalings_from_les_matrix
     reftrack = np.asarray(reftrack, dtype=np.float64)
     normvectors = np.asarray(normvectors, dtype=np.float64)
     _omc._validate(reftrack, normvectors, A, True)
-    sc = scalings_from_les_matrix(A) if A is not None else None
+    sc = _engine.les_scalings(A) if A is not None else None
     # upstream aliases the caller's reftrack on the first pass and mutates its width columns in place; main rebinds the
     # name [REF main_globaltraj.py:274], so working on a copy is unobservable there and safer for other callers.
     return iqp_handler_batch([dict(reftrack=reftrack, normvectors=normvectors, scaling=sc)], kappa_bound, w_veh,

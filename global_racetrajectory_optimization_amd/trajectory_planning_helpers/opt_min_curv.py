@@ -12,7 +12,6 @@ import time
 import numpy as np
 
 from .. import engine as _engine
-from . import calc_splines as _cs
 
 _MSG_TOO_SMALL = "Problem not solvable, track might be too small to run with current safety distance!"
 
@@ -58,7 +57,7 @@ def opt_min_curv(reftrack: np.ndarray, normvectors: np.ndarray, A: np.ndarray, k
     reftrack = np.asarray(reftrack, dtype=np.float64)
     normvectors = np.asarray(normvectors, dtype=np.float64)
     _validate(reftrack, normvectors, A, closed)
-    scaling = _cs.scalings_from_les_matrix(A) if A is not None else None
+    scaling = _engine.les_scalings(A) if A is not None else None      # (threaded C pass over the dense matrix: engine.les_scalings)
 
     eng = _engine.default_engine()
     t_start = time.perf_counter()
@@ -85,7 +84,7 @@ def opt_min_curv_batch(problems: list, engine=None, **opt_kw) -> tuple:
         _validate(ref, nv, p.get("A"), True)
         sc = p.get("scaling")
         if sc is None and p.get("A") is not None:
-            sc = _cs.scalings_from_les_matrix(p["A"])
+            sc = _engine.les_scalings(p["A"])
         packed.append(dict(reftrack=ref, normvec=nv, scaling=sc, kappa_bound=p["kappa_bound"], w_veh=p["w_veh"]))
     return eng.solve_batch(packed, **opt_kw)
 

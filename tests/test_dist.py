@@ -63,6 +63,12 @@ def _worker(rank, world, port, lib, stub, q):
     a, c, s = parallel.solve_sharded(_problems(), eng, dist=dist)
     q.put((rank, [x.tolist() for x in a], c.tolist(), s.tolist()))
     dist.barrier()
+    # a download after comm_destroy must not wait on the destroyed events of the last gather
+    eng.comm_destroy()
+    d_x = eng.alloc(40)
+    eng.upload(d_x, vals[0])
+    assert np.array_equal(eng.download(d_x, (5,), np.float64), vals[0])
+    eng.free(d_x)
     dist.destroy_process_group()
 
 

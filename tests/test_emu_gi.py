@@ -39,7 +39,8 @@ def test_gi_mode_matches_golden_and_takes_the_dense_oracles_steps(emu, golden, t
     i = info[0]
     assert i["second_attempt"] & 4 and not i["second_attempt"] & 8 and i["ipm_iters"] == 0 and i["as_iters"] == 1
     _, _, dinfo = _dense(g, float(g["kappa_bound"]), float(g["w_veh"]))
-    assert i["gi_iters"] == int(dinfo["iters"][0] + dinfo["iters"][1])          # constraints added + dropped
+    # quadprog's `iters` pair (oracle/gi_dense.c follows qpgen2): main iterations = full steps + 1 (the last one finds nothing violated), drops
+    assert i["gi_iters"] == int(dinfo["iters"][0] - 1 + dinfo["iters"][1])      # constraints added + dropped
     assert i["n_active_box"] == int(np.sum(dinfo["lagr"] > 0))
     # the default path returns the same vertex without it
     al0, curv0, st0, info0 = emu.solve_batch([_problem(g)])
@@ -101,13 +102,14 @@ def test_iqp_rounds_with_the_fallback_inside(emu, golden):
     assert np.max(np.abs(out["alpha"][0] - g["iqp_alpha"])) < 1e-8 and np.max(np.abs(out["alpha"][0] - ref["alpha"][0])) < 1e-9
 
 
-def test_zero_width_rows_both_paths_against_the_second_route(emu):
+def test_zero_width_rows_both_paths_against_the_dense_oracle(emu):
     """Waypoints where the corridor is exactly as wide as the vehicle (w_r + w_l = w_veh: lo = hi) are equality constraints in disguise -- two
-    dependent rows of quadprog's G.  Both engine paths pin them and agree with the independent least-squares route (scipy BVLS on the dense E,
-    the zero-width boxes opened by 1e-9 m) to 1e-8 m, with stationarity at rounding level.  (Found in round 5: the dense Goldfarb-Idnani ORACLE
-    itself stops at a worse point here -- objective higher by 2.6e-5, stationarity 2e-4: its exclusion rule for a row that depends on the working
-    set gives up on a still-violated row.  quadprog's own behaviour on such input is not known to us; the oracle is not used for this case.)"""
+    exactly dependent rows of quadprog's G, which tph's `>` test lets through.  Both engine paths pin them and return the DENSE ORACLE's vertex
+    (oracle/gi_dense.c follows qpgen2's rule set since round 6: the second row of such a pair never enters, its slack is a rounding residue
+    below vsmall -- the QuadProg++-style exclusion list of rounds 1-5 stopped at a non-optimal point here, stationarity 2e-4); the independent
+    least-squares route (scipy BVLS on the dense E, the zero-width boxes opened by 1e-9 m) stays as the second opinion on all three."""
     from scipy.optimize import lsq_linear
+    from oracle import qp_ref
     from test_emu_kernels import _small_track
     ref, nv, A, sc = _small_track(40, seed=5)
     ref = ref.copy()
@@ -117,15 +119,45 @@ def test_zero_width_rows_both_paths_against_the_second_route(emu):
     hi2 = hi.copy()
     hi2[[3, 4, 17]] += 1e-9
     x2 = lsq_linear(E, -2.0 * k_ref, bounds=(lo, hi2), method="bvls", tol=1e-14).x
+    G, h = tph_ref.constraints_dense(ref, E, k_ref, 0.5, 2.0)
+    info_o = {}
+    xo = qp_ref.solve_qp_gi(H, f, G, h, info_o)
+    assert np.max(np.abs(xo[[3, 4, 17]])) < 1e-14 and np.max(np.abs(xo - x2)) < 1e-8
+    free_o = (xo > lo + 1e-9) & (xo < hi - 1e-9)
+    assert np.max(np.abs((H @ xo + f)[free_o])) < 1e-10 * np.max(np.abs(f))
     prob = dict(reftrack=ref, normvec=nv, scaling=sc, kappa_bound=0.5, w_veh=2.0)
     for alg in (engine.ALG_DEFAULT, engine.ALG_GI):
         al, _, st, info = emu.solve_batch([prob], algorithm=alg)
         x = al[0]
         assert st[0] == 0 and np.all(x[[3, 4, 17]] == 0.0)
+        assert np.max(np.abs(x - xo)) < 1e-9, (alg, float(np.max(np.abs(x - xo))))
         assert np.max(np.abs(x - x2)) < 1e-8, (alg, float(np.max(np.abs(x - x2))))
         g = H @ x + f
         free = (x > lo + 1e-9) & (x < hi - 1e-9)
         assert np.max(np.abs(g[free])) < 1e-10 * np.max(np.abs(f))
+
+
+def test_slot_pools_small_full_and_none(emu, emu_lib, monkeypatch):
+    """Round 6 (ADVICE r5 / VERDICT r5 item 7): the Goldfarb-Idnani path's memory.  MCQ_ALG_GI gives every resident workgroup a SMALL slot (working
+    sets of up to max(128, n / 8) constraints); the 360-point stadium's working set (134 curvature + 10 box rows) outgrows it, and the problem starts
+    again in one of the handle's FULL slots: status 0, the dense oracle's vertex.  A handle WITHOUT full slots ($MCQ_GI_BYTES = 0 here; in the
+    field: rings too long for the byte cap, or a refused allocation) still solves -- the default path through the overflow slots of the
+    curvature-row working set, as in rounds 3-4 -- and reports the outgrown small slot as MCQ_ITER_CAP instead of failing the launch."""
+    from test_emu_kernels import stadium_problem
+    ref, nv, A, sc, kb = stadium_problem()
+    prob = dict(reftrack=ref, normvec=nv, scaling=sc, kappa_bound=kb, w_veh=2.0)
+    a_ref, _ = tph_ref.opt_min_curv(ref, nv, A, kb, 2.0)
+    al, _, st, info = emu.solve_batch([prob], algorithm=engine.ALG_GI)
+    assert st[0] == 0 and info[0]["n_active_kappa"] > 128 and np.max(np.abs(al[0] - a_ref)) < 1e-8
+    monkeypatch.setenv("MCQ_GI_BYTES", "0")
+    bare = engine.Engine(0, lib_path=emu_lib)
+    try:
+        al0, _, st0, info0 = bare.solve_batch([prob])
+        assert st0[0] == 0 and not info0[0]["second_attempt"] & 4 and np.max(np.abs(al0[0] - a_ref)) < 1e-7
+        _, _, st1, info1 = bare.solve_batch([prob], algorithm=engine.ALG_GI)
+        assert st1[0] == engine.STATUS_ITER_CAP and info1[0]["second_attempt"] & 4, (st1[0], info1[0])
+    finally:
+        bare.close()
 
 
 def test_a_slice_of_the_curvature_tight_fuzz_on_the_interpreter(emu):

@@ -1051,6 +1051,20 @@ def test_engine_collective_and_sharded_solve_on_one_rank(gpu_engine, golden):
         eng.comm_destroy()
         with pytest.raises(engine.EngineError):
             eng.comm_world()
+        # the handle stays usable after comm_destroy -- a download must not wait on the destroyed events of the last gather --
+        # and takes a new communicator
+        d_x = eng.alloc(80)
+        eng.upload(d_x, np.arange(10.0))
+        assert np.array_equal(eng.download(d_x, (10,), np.float64), np.arange(10.0))
+        a_h2, _, s_h2, _ = eng.solve_batch(probs[:1])
+        assert s_h2[0] == 0 and np.array_equal(a_h2[0], a_h[0])
+        eng.comm_init(0, 1, eng.comm_unique_id())
+        d_y = eng.alloc(80)
+        eng.comm_allgather(d_x, d_y, 10, eng.DT_F64)
+        assert np.array_equal(eng.download(d_y, (10,), np.float64), np.arange(10.0))
+        eng.free(d_x)
+        eng.free(d_y)
+        eng.comm_destroy()
     finally:
         eng.close()
 

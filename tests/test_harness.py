@@ -95,6 +95,102 @@ def test_main_globaltraj_untouched_berlin_config1(emu_lib, tmp_path, monkeypatch
     assert abs(lap - vel_ref.lap_time_stable(vx, out[8])) < 0.02          # the script prints two decimals
 
 
+def _replay_recorded_calls(capsys, on_build_box, with_kappa_error=True):
+    """The calls the untouched main_globaltraj.py made at the drop-in boundary on berlin_2018 (captured once by
+    scripts/record_harness_calls.py -> tests/golden/harness_calls_berlin.npz: keyword arguments as the script passed them
+    [REF main_globaltraj.py:264-271, 273-284, 286-290; 337-350 constructed], the ORACLE's outputs for them, the print_debug lines), replayed
+    through the drop-in package on whatever library engine.default_engine() loads.  alpha within 1e-6 m of the oracle's (north_star's fp64
+    tolerance), upstream's debug lines, upstream's exception types and messages."""
+    import hashlib
+    import json
+    import re
+    from global_racetrajectory_optimization_amd import trajectory_planning_helpers as tph
+    z = np.load(os.path.join(ROOT, "tests", "golden", "harness_calls_berlin.npz"))
+
+    def matrix(key):
+        ref = z[key + "_reftrack"]
+        A = tph.calc_splines.calc_splines(path=np.vstack((ref[:, :2], ref[0, :2])))[2]       # what prep_track hands the script [REF prep_track.py:48-51]
+        assert np.max(np.abs(tph.calc_splines.scalings_from_les_matrix(A) - z[key + "_A_scalings"])) < 1e-13
+        if on_build_box:
+            assert hashlib.sha256(np.ascontiguousarray(A).tobytes()).hexdigest() == str(z[key + "_A_sha256"])
+        return A
+
+    capsys.readouterr()
+    # ---- opt_type = 'mincurv' [REF main_globaltraj.py:264-271] ----
+    kw = json.loads(str(z["mincurv_kwargs"]))
+    assert str(z["mincurv_entry"]) == "opt_min_curv.opt_min_curv" and kw["print_debug"] is True
+    alpha = tph.opt_min_curv.opt_min_curv(reftrack=z["mincurv_reftrack"].copy(), normvectors=z["mincurv_normvectors"].copy(), A=matrix("mincurv"), **kw)[0]
+    d_mc = float(np.max(np.abs(alpha - z["mincurv_oracle_alpha"])))
+    assert alpha.shape == (776,) and d_mc <= 1e-6
+    out = capsys.readouterr().out
+    assert re.search(r"^Solver runtime opt_min_curv: \d+\.\d{3}s$", out, re.M), out
+    # the second element of the tuple the script drops with [0]
+    curv = tph.opt_min_curv.opt_min_curv(reftrack=z["mincurv_reftrack"].copy(), normvectors=z["mincurv_normvectors"].copy(), A=matrix("mincurv"),
+                                         kappa_bound=kw["kappa_bound"], w_veh=kw["w_veh"])[1]
+    assert abs(curv - float(z["mincurv_oracle_curv_error_max"])) < 1e-9
+    # ---- opt_type = 'mincurv_iqp' [REF main_globaltraj.py:273-284] ----
+    kw = json.loads(str(z["iqp_kwargs"]))
+    capsys.readouterr()
+    a_iqp, rt, nv = tph.iqp_handler.iqp_handler(reftrack=z["iqp_reftrack"].copy(), normvectors=z["iqp_normvectors"].copy(), A=matrix("iqp"), **kw)
+    assert a_iqp.shape == z["iqp_oracle_alpha"].shape and rt.shape == z["iqp_oracle_reftrack"].shape and nv.shape == z["iqp_oracle_normvectors"].shape
+    d_iqp = float(np.max(np.abs(a_iqp - z["iqp_oracle_alpha"])))
+    assert d_iqp <= 1e-6 and np.max(np.abs(rt - z["iqp_oracle_reftrack"])) <= 1e-6 and np.max(np.abs(nv - z["iqp_oracle_normvectors"])) <= 1e-6
+    lines = [l for l in capsys.readouterr().out.splitlines() if l.startswith(("Minimum curvature IQP", "Finished IQP"))]
+    assert lines == json.loads(str(z["iqp_stdout"])) and len(lines) == 4              # the three iterations' lines and the closing one, digit for digit
+    assert lines[:3] == ["Minimum curvature IQP: iteration %i, curv_error_max: %.4frad/m" % (k + 1, c) for k, c in enumerate(z["iqp_oracle_curv_error_trace"])]
+    # ---- opt_type = 'shortest_path' [REF main_globaltraj.py:286-290] ----
+    kw = json.loads(str(z["shortest_kwargs"]))
+    a_sp = tph.opt_shortest_path.opt_shortest_path(reftrack=z["shortest_reftrack"].copy(), normvectors=z["shortest_normvectors"].copy(), **kw)
+    d_sp = float(np.max(np.abs(a_sp - z["shortest_oracle_alpha"])))
+    assert d_sp <= 1e-6
+    assert re.search(r"^Solver runtime opt_shortest_path: \d+\.\d{3}s$", capsys.readouterr().out, re.M)
+    # ---- the re-optimisation call of the mintime branch [REF main_globaltraj.py:337-350] ----
+    kw = json.loads(str(z["reopt_kwargs"]))
+    a_ro = tph.opt_min_curv.opt_min_curv(reftrack=z["reopt_reftrack"].copy(), normvectors=z["reopt_normvectors"].copy(), A=matrix("reopt"), **kw)[0]
+    d_ro = float(np.max(np.abs(a_ro - z["reopt_oracle_alpha"])))
+    assert d_ro <= 1e-6 and np.max(np.abs(a_ro)) <= 0.2 + 1e-9                      # corridor 1.0 either side, vehicle 1.6
+    # ---- what upstream's callers would see when the QP has no solution ----
+    kw = json.loads(str(z["mincurv_kwargs"]))
+    narrow = z["mincurv_reftrack"].copy()
+    narrow[z["error_narrow_rows"], 2:] = float(z["error_narrow_width"])
+    with pytest.raises(RuntimeError) as e1:
+        tph.opt_min_curv.opt_min_curv(reftrack=narrow, normvectors=z["mincurv_normvectors"].copy(), A=matrix("mincurv"), **kw)
+    assert str(e1.value) == str(z["error_narrow_message"])
+    if with_kappa_error:        # (79 s on the SIMT interpreter: the Goldfarb-Idnani path's several hundred steps at N = 776; milliseconds on the GPU)
+        with pytest.raises(ValueError) as e2:
+            tph.opt_min_curv.opt_min_curv(reftrack=z["mincurv_reftrack"].copy(), normvectors=z["mincurv_normvectors"].copy(), A=matrix("mincurv"),
+                                          kappa_bound=float(z["error_kappa_bound"]), w_veh=kw["w_veh"])
+        assert str(e2.value) == str(z["error_kappa_message"]) == "constraints are inconsistent, no solution"
+    with pytest.raises(RuntimeError, match="Array size of reftrack should be the same as normvectors"):
+        tph.opt_min_curv.opt_min_curv(reftrack=z["mincurv_reftrack"].copy(), normvectors=z["mincurv_normvectors"][:-1].copy(), A=matrix("mincurv"), **kw)
+    return dict(mincurv=d_mc, iqp=d_iqp, shortest_path=d_sp, reopt=d_ro)
+
+
+def test_replay_of_the_recorded_calls_on_the_interpreter(emu_lib, monkeypatch, capsys):
+    from global_racetrajectory_optimization_amd import engine
+    monkeypatch.setenv("MCQ_LIB", emu_lib)
+    monkeypatch.setattr(engine, "_DEFAULT_ENGINE", None)
+    # (the curvature-bound error case is left to the GPU replay; the mapping itself is covered here by
+    #  tests/test_emu_gi.py::test_inconsistent_curvature_rows_are_recognised_by_both_paths and tests/test_host.py)
+    d = _replay_recorded_calls(capsys, on_build_box=True, with_kappa_error=False)
+    monkeypatch.setattr(engine, "_DEFAULT_ENGINE", None)
+    assert max(d.values()) < 1e-7, d
+
+
+@pytest.mark.gpu
+def test_replay_of_the_recorded_calls_on_the_gpu(monkeypatch, capsys):
+    """BASELINE config 1 / 2 on the REAL library without the reference tree (the driver's GPU box has none, and the two
+    tests below are skipped there): every call main_globaltraj.py makes at the boundary, as recorded, through the drop-in package -> ctypes
+    -> C ABI -> libmcq.so on the MI355X."""
+    from global_racetrajectory_optimization_amd import engine
+    monkeypatch.delenv("MCQ_LIB", raising=False)
+    monkeypatch.setattr(engine, "_DEFAULT_ENGINE", None)
+    d = _replay_recorded_calls(capsys, on_build_box=False)
+    monkeypatch.setattr(engine, "_DEFAULT_ENGINE", None)
+    with capsys.disabled():
+        print("replay of main_globaltraj.py's recorded calls on libmcq.so: max |alpha - oracle| [m] = %s" % {k: "%.1e" % v for k, v in d.items()})
+
+
 @pytest.mark.gpu
 @pytest.mark.parametrize("opt_type", ["mincurv", "mincurv_iqp"])
 def test_main_globaltraj_untouched_on_the_gpu(tmp_path, monkeypatch, opt_type):

@@ -120,9 +120,33 @@ def test_les_matrix_structure_guard(golden):
         cs.scalings_from_les_matrix(np.eye(4 * n))
     with pytest.raises(RuntimeError, match="structure of calc_splines"):
         cs.scalings_from_les_matrix(A[::-1].copy())
-    # the drop-in entry points run the guard before anything reaches the engine (no library needed to see it)
+    # the drop-in entry points run the guard before anything reaches the engine
     with pytest.raises(RuntimeError, match="structure of calc_splines"):
         tph.opt_min_curv.opt_min_curv(ref, nv, np.eye(4 * n), 0.12, 3.4)
+    # round 6: the drop-in's guard is the C ABI's mcq_les_scalings (one threaded pass over the dense matrix; host code of libmcq.so, no GPU) --
+    # the same scalings bit for bit and the same verdicts as the numpy statement above, single- and multi-threaded (Berlin: 3104 x 3104)
+    from global_racetrajectory_optimization_amd import engine
+    assert np.array_equal(engine.les_scalings(A), cs.scalings_from_les_matrix(A))
+    assert np.array_equal(engine.les_scalings(np.asfortranarray(A)), cs.scalings_from_les_matrix(A))       # (not C-contiguous: the numpy statement serves)
+    for r, c, dv in ((7, 9, 0.5), (4 * n - 1, 0, 1e-3), (2, 2, -2.0), (0, 0, 0.25), (6, 9, 5.0), (40, 200, 1e-9), (7, 10, 1e-6), (4 * n - 2, 1, -50.0)):
+        B = A.copy()
+        B[r, c] += dv
+        with pytest.raises(RuntimeError, match="structure of calc_splines"):
+            engine.les_scalings(B)
+    for bad in (np.eye(4 * n), A[::-1].copy()):
+        with pytest.raises(RuntimeError, match="structure of calc_splines"):
+            engine.les_scalings(bad)
+    refb = golden["berlin_2018"]["reftrack"]
+    Ab = cs.calc_splines(np.vstack((refb[:, :2], refb[0, :2])))[2]
+    assert np.array_equal(engine.les_scalings(Ab), cs.scalings_from_les_matrix(Ab)) and np.array_equal(engine.les_scalings(Ab), golden["berlin_2018"]["scaling"])
+    rng = np.random.default_rng(3)
+    for _ in range(6):
+        B = Ab.copy()
+        B[rng.integers(0, B.shape[0]), rng.integers(0, B.shape[0])] += 1e-7
+        with pytest.raises(RuntimeError, match="structure of calc_splines"):
+            engine.les_scalings(B)
+        with pytest.raises(RuntimeError, match="structure of calc_splines"):
+            cs.scalings_from_les_matrix(B)
     with pytest.raises(RuntimeError, match="structure of calc_splines"):
         tph.iqp_handler.iqp_handler(ref, nv, np.eye(4 * n), 0.12, 3.4, False, False, 3.0)
 

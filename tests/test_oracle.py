@@ -104,6 +104,24 @@ def test_gi_reports_infeasible_and_not_pd():
         qp_ref.solve_qp_gi(np.array([[1.0, 2.0], [2.0, 1.0]]), f, G, np.array([1.0, 1.0]))
 
 
+def test_gi_dense_reproduces_the_example_of_quadprogs_own_documentation():
+    """The one published known answer of the solver the reference's path ends in: the example of R quadprog's `solve.QP` help page (the Fortran
+    `qpgen2` the Python package `quadprog` compiles [REF Readme.md:40,44]; also the case its own test-suite solves) --
+    Dmat = I3, dvec = (0, 5, 0), Amat = [[-4, 2, 0], [-3, 1, -2], [0, 0, 1]], bvec = (-8, 2, 0) -> solution (0.4761905, 1.0476190, 2.0952381),
+    value -2.380952, Lagrangian (0, 0.2380952, 2.0952381), iterations (3, 0), iact (3, 2) (1-based there).  oracle/gi_dense.c returns every
+    field of that tuple, the iteration pair and the ORDER of the active set included -- its rule set is qpgen2's."""
+    Amat = np.array([[-4.0, 2.0, 0.0], [-3.0, 1.0, -2.0], [0.0, 0.0, 1.0]])
+    x, fval, lagr, iact, iters = qp_ref.solve_qp_quadprog_convention(np.eye(3), np.array([0.0, 5.0, 0.0]), Amat, np.array([-8.0, 2.0, 0.0]))
+    assert np.max(np.abs(x - np.array([10.0, 22.0, 44.0]) / 21.0)) < 1e-15
+    assert abs(fval + 50.0 / 21.0) < 1e-15
+    assert np.max(np.abs(lagr - np.array([0.0, 5.0 / 21.0, 44.0 / 21.0]))) < 1e-15
+    assert list(iact) == [2, 1] and list(iters) == [3, 0]
+    # an equality row (meq = 1): x0 + x1 = 1 with the box x >= 0 -> the projection of (0, 5, 0) onto the plane
+    C = np.array([[1.0, 1.0, 0.0], [1.0, 0.0, 0.0], [0.0, 1.0, 0.0], [0.0, 0.0, 1.0]]).T
+    x, _, lagr, iact, iters = qp_ref.solve_qp_quadprog_convention(np.eye(3), np.array([0.0, 5.0, 0.0]), C, np.array([1.0, 0.0, 0.0, 0.0]), meq=1)
+    assert np.max(np.abs(x - np.array([0.0, 1.0, 0.0]))) < 1e-15 and sorted(iact) == [0, 1]
+
+
 def test_iqp_golden_shapes(golden):
     g = golden["rounded_rectangle"]
     assert list(g["iqp_n"]) == [105, 104, 103]
