@@ -596,7 +596,8 @@ def main():
                                           "partition over the ranks, one all-gather of the lap times" % wl["n_total"],
                               "tracks": wl["tracks"], "variants_total": wl["n_total"], "variants_this_rank": wl["nvar"], "ranks_seen": ranks_seen,
                               "lap_times_gathered_s": gathered_laps,
-                              "rank_ms_per_step": {"min": min(rank_ms), "max": max(rank_ms)},
+                              "rank_ms_per_step": {"min": min(rank_ms), "max": max(rank_ms), "by_rank": rank_ms},
+                              "allgather_ms": ag_ms,
                               "lap_time_range_s": [float(lap.min()), float(lap.max())]}}
     elif rank == 0:
         status = eng.download(d_status, (B,), np.int32)
@@ -626,7 +627,7 @@ def main():
                        "collective": ("1 all-gather of alpha per step: ncclAllGather (RCCL) through the C ABI, mcq_comm_allgather, on the engine's comm stream"
                                       + (" [EMULATED RUN: librccl stand-in " + os.path.basename(os.environ.get("MCQ_RCCL_LIB", "?")) + "]" if emulate else "")
                                       if collective else "none"),
-                       "ranks_seen": ranks_seen, "rank_ms_per_step": {"min": min(rank_ms), "max": max(rank_ms)},
+                       "ranks_seen": ranks_seen, "rank_ms_per_step": {"min": min(rank_ms), "max": max(rank_ms), "by_rank": rank_ms},
                        "allgather_ms": ag_ms, "allgather_dtype": np.dtype(io_np).name,
                        "failed_problems": int(np.count_nonzero(status)),
                        "mean_ipm_iters": float(info["ipm_iters"].mean()), "mean_as_iters": float(info["as_iters"].mean()),
@@ -657,6 +658,12 @@ def main():
                          # the bytes the banded-exact algorithm of rounds 1-3 would have moved for the same iteration
                          # counts: for reference, no fraction quoted -- the saddle-point core does not move them
                          "banded_model_bytes_per_launch": wm["declared"],
+                         "durations": "achieved / frac: kernel_ms of THIS run (device-side span over the timed region's launches); traffic: counters of "
+                                      "the profiled run named in traffic_source (its own kernel duration is in that summary; frac_of_measured_traffic "
+                                      "divides its bytes by THIS run's kernel_ms)",
+                         "mfma": "SQ_INSTS_MFMA = 0 by design (profiles/*_pmc.md): H = E'E is never formed since round 4 -- every linear system is the 5 x 5-block "
+                                 "saddle-point elimination or a scalar tridiagonal sweep, far below a 16 x 16 x 4 MFMA tile; north_star's 'MFMA for the dense "
+                                 "H = M'M contraction' has no contraction left to run on (DESIGN.md section 1); the bound that applies is HBM",
                          "fp64_flops_per_launch": wm["flops"], "fp64_tflops": wm["flops"] / (k_ms * 1e-3) / 1e12,
                          "fp64_frac_of_%.1f_tflops" % FP64_PEAK_TFLOPS: wm["flops"] / (k_ms * 1e-3) / 1e12 / FP64_PEAK_TFLOPS},
         }

@@ -1012,12 +1012,13 @@ extern "C" int mcq_les_scalings(const double* A, int n, double* s_out, int check
     if (!check) return 0;
     // Row by row: the entries the closed-spline system has in that row, at their values (the wrap-around rows carry the
     // opposite sign), and NOTHING else -- a row's non-zeros are counted while it streams through.
-    int nthreads = 8;
+    // one thread per 16 MB of matrix, 32 at most (512 MB at n = 2000: 3.4 ms on 8 threads of the bench host, memory-bound); $MCQ_PACK_THREADS overrides
+    int nthreads = (int)std::min<size_t>(32, std::max<size_t>(1, (m * m * sizeof(double)) >> 24));
     if (const char* e = getenv("MCQ_PACK_THREADS")) nthreads = atoi(e);
     const int hw = (int)std::thread::hardware_concurrency();
     if (hw > 0 && nthreads > hw) nthreads = hw;
     if (nthreads > n) nthreads = n;
-    if (nthreads < 1 || m * m < ((size_t)1 << 21)) nthreads = 1;
+    if (nthreads < 1) nthreads = 1;
     std::vector<long long> bad((size_t)nthreads, -1);          // first offending (row * m + column) of a thread's blocks
     auto rel = [](double a, double b) { return fabs(a - b) <= 1e-12 * fabs(b); };
     auto scan = [&](int t) {

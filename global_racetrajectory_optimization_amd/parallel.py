@@ -23,6 +23,19 @@ def shard_bounds(batch: int, world: int, rank: int) -> tuple:
     return lo, lo + base + (1 if rank < rem else 0)
 
 
+def shard_indices(batch: int, world: int, rank: int, partition: str = "block"):
+    """The batch indices rank `rank` solves.  "block": the contiguous range of shard_bounds (the default: a rank's alphas are one slab of the
+    gathered tensor).  "interleaved": b mod world == rank (ragged batches sorted by size, sweeps whose cost grows along the
+    batch axis -- neighbouring problems cost about the same, so dealing them out evens the ranks' loads; the gathered tensor is then rank-major
+    and solve_sharded puts the rows back in batch order).  Every rank holds ceil(batch / world) slots either way."""
+    if partition == "block":
+        lo, hi = shard_bounds(batch, world, rank)
+        return np.arange(lo, hi)
+    if partition == "interleaved":
+        return np.arange(rank, batch, world)
+    raise ValueError("partition must be 'block' or 'interleaved'")
+
+
 def init_engine_comm(engine, dist):
     """Collective over the ranks of `dist` (an initialised torch.distributed, any backend): gives `engine` its RCCL communicator.
     Rank 0 creates the id, one object broadcast ships it."""
@@ -41,9 +54,10 @@ def _has_comm(engine):
         return False
 
 
-def solve_sharded(problems: list, engine, dist=None, **opt_kw):
-    """Every rank solves its contiguous shard of `problems` on its own GPU; alpha (padded to the longest track),
-    curvature errors and status words are all-gathered so that every rank returns the full batch.
+def solve_sharded(problems: list, engine, dist=None, partition: str = "block", **opt_kw):
+    """Every rank solves its shard of `problems` on its own GPU -- a contiguous block of the batch axis, or with partition="interleaved" every
+    world-th problem (shard_indices) --; alpha (padded to the longest track), curvature errors and status words are all-gathered so that every
+    rank returns the full batch, in batch order.
 
     problems: dicts {reftrack [n,4], normvec [n,2] or None (then for all: normals and scalings are derived on the device),
     scaling [n] or None, kappa_bound, w_veh}.
@@ -60,9 +74,9 @@ def solve_sharded(problems: list, engine, dist=None, **opt_kw):
     if use_rccl and engine.comm_world() != (rank, world):
         raise ValueError("solve_sharded: the engine's communicator is rank %d of %d, the process group says %d of %d"
                          % (engine.comm_world() + (rank, world)))
-    lo, hi = shard_bounds(bsz, world, rank)
+    mine = shard_indices(bsz, world, rank, partition)
     nmax = max(int(np.asarray(p["reftrack"]).shape[0]) for p in problems)
-    per = max(shard_bounds(bsz, world, r)[1] - shard_bounds(bsz, world, r)[0] for r in range(world))
+    per = max(len(shard_indices(bsz, world, r, partition)) for r in range(world))
     with_nv = [p.get("normvec") is not None for p in problems]
     if any(with_nv) and not all(with_nv):
         raise ValueError("solve_sharded: normvec must be given for all problems or for none")
@@ -73,7 +87,7 @@ def solve_sharded(problems: list, engine, dist=None, **opt_kw):
     ns = np.zeros(per, dtype=np.int32)
     kb = np.ones(per)
     wv = np.zeros(per)
-    for k, p in enumerate(problems[lo:hi]):
+    for k, p in enumerate(problems[b] for b in mine):
         r = np.asarray(p["reftrack"], dtype=np.float64)
         n = r.shape[0]
         ref[k, :n] = r
@@ -99,7 +113,7 @@ def solve_sharded(problems: list, engine, dist=None, **opt_kw):
         d_nv = dev(nv) if with_nv[0] else None
         d_send = dev(nbytes=8 * count)                      # (mcq_device_alloc zero-fills: empty shards gather zeros)
         d_alpha, d_curv, d_status = d_send, d_send + 8 * per * nmax, d_send + 8 * (per * nmax + per)
-        if hi > lo:
+        if len(mine) > 0:
             engine.solve_device_ragged_params(per, nmax, d_n, d_ref, d_nv, d_sc, 0.0, 0.0, d_kb, d_wv, d_alpha, d_curv, d_status,
                                               **opt_kw)
         if world == 1 and not use_rccl:
@@ -112,15 +126,14 @@ def solve_sharded(problems: list, engine, dist=None, **opt_kw):
     finally:
         for p in bufs:
             engine.free(p)
-    out_a, out_c, out_s = [], np.zeros(bsz), np.zeros(bsz, dtype=np.int32)
+    out_a, out_c, out_s = [None] * bsz, np.zeros(bsz), np.zeros(bsz, dtype=np.int32)
     for r in range(world):
-        rlo, rhi = shard_bounds(bsz, world, r)
         al = full[r, :per * nmax].reshape(per, nmax)
         cu = full[r, per * nmax:per * nmax + per]
         st = np.ascontiguousarray(full[r, per * nmax + per:]).view(np.int32)[:per]
-        for k in range(rhi - rlo):
-            n = int(np.asarray(problems[rlo + k]["reftrack"]).shape[0])
-            out_a.append(al[k, :n].copy())
-            out_c[rlo + k] = cu[k]
-            out_s[rlo + k] = int(st[k])
+        for k, b in enumerate(shard_indices(bsz, world, r, partition)):
+            n = int(np.asarray(problems[b]["reftrack"]).shape[0])
+            out_a[b] = al[k, :n].copy()
+            out_c[b] = cu[k]
+            out_s[b] = int(st[k])
     return out_a, out_c, out_s

@@ -367,8 +367,8 @@ int mcq_iqp_set_round_callback(mcq_handle* h, mcq_iqp_round_cb cb, void* user);
 /* The one thing the engine reads from the dense spline matrix the reference passes [REF main_globaltraj.py:267 `A=a_interp`;
  * helper_funcs_glob/src/prep_track.py:48-51]: the n spline scalings s_i encoded in the [4n][4n] row-major matrix of tph.calc_splines' closed-spline
  * system (s_i = -A[4i+2][4i+5], s_(n-1) = A[4n-2][1]) -> s_out [n].  check != 0 verifies that A IS that matrix -- the 12 n structural entries at
- * their places and values, the four that mirror the scalings, and not one non-zero anywhere else -- in ONE pass over the matrix on $MCQ_PACK_THREADS
- * (8) host threads (512 MB at n = 2000: the numpy restatement of the same check in trajectory_planning_helpers/calc_splines.py took 100-200 ms of
+ * their places and values, the four that mirror the scalings, and not one non-zero anywhere else -- in ONE pass over the matrix on a host thread per 16 MB
+ * (32 at most; $MCQ_PACK_THREADS overrides) (512 MB at n = 2000: the numpy restatement of the same check in trajectory_planning_helpers/calc_splines.py took 100-200 ms of
  * a call whose kernel takes 3; round 6).  No GPU involved, no handle.  Returns 0, or MCQ_E_ARG when A does not have the structure (the message
  * names the first offending entry). */
 int mcq_les_scalings(const double* A, int n, double* s_out, int check);

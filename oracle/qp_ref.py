@@ -4,6 +4,7 @@ ORACLE -- TEST INFRASTRUCTURE ONLY (header of oracle/tph_ref.py applies).  PARIT
 QP routes used to pin the oracle against itself:
   solve_qp_gi      dense Goldfarb-Idnani (oracle/gi_dense.c), quadprog calling convention
                    quadprog.solve_qp(H, -f, -G.T, -h, 0)[0]  
+  solve_qp_gi_zero_width_as_equalities   the same solver with exactly dependent box pairs (lo = hi) stated as equalities (meq), see there
   solve_box_bvls   scipy.optimize.lsq_linear(E, -2 k_ref, bounds) -- valid when the kappa rows are inactive
   solve_box_second_route   the same least-squares form by the trust-region-reflective method (an interior method on the dense
                    E with exact SVD steps: neither an active-set method nor the normal equations) -- the independent route at
@@ -73,6 +74,31 @@ def solve_qp_gi(H, f, G, h, info=None):
     x, fv, lagr, iact, iters = solve_qp_quadprog_convention(H, -f, -G.T, -h, 0)
     if info is not None:
         info.update(f=fv, lagr=lagr, iact=iact, iters=iters)
+    return x
+
+
+def solve_qp_gi_zero_width_as_equalities(H, f, G, h, info=None):
+    """The same QP with every EXACTLY DEPENDENT box pair (rows i and n + i of upstream's G = [I; -I; E; -E] with h_i = -h_(n+i): a waypoint
+    whose corridor is exactly as wide as the vehicle, lo = hi) stated the way quadprog wants an equality stated -- one row, counted in `meq` --
+    instead of the two opposite inequalities tph builds.  Still oracle/gi_dense.c, i.e. qpgen2's algorithm.
+
+    Why it exists (round 6, found by tests/test_gpu_parity.py::test_pinned_variables_and_bad_input after gi_dense.c became qpgen2's rule set): on
+    the two-inequality form quadprog's outcome is decided by a rounding residue.  After one row of the pair has entered, later steps move x along
+    directions orthogonal to its normal only up to rounding; when the partner's slack drifts below -vsmall (1.4e-15; seen: -4.5e-15) the
+    partner is "violated", its normal is minus an active one, so z = 0, r = -1 for the active partner, a chain of dual steps drops every
+    constraint with r > 0 and the solve ends in "constraints are inconsistent, no solution" -- on a feasible QP.  When the residue stays below
+    vsmall the slack is set to zero and the solve ends at the optimum (tests/test_emu_gi.py's case).  The engine returns the optimum in both
+    cases: a stated deviation from what quadprog would do on such input, pinned by this form and by the BVLS route."""
+    n = H.shape[0]
+    pin = np.where(h[:n] + h[n:2 * n] == 0.0)[0]
+    keep = np.ones(G.shape[0], dtype=bool)
+    keep[pin] = False
+    keep[n + pin] = False
+    C = np.hstack((-G[pin].T, -G[keep].T))
+    b = np.concatenate((-h[pin], -h[keep]))
+    x, fv, lagr, iact, iters = solve_qp_quadprog_convention(H, -f, C, b, meq=int(pin.size))
+    if info is not None:
+        info.update(f=fv, lagr=lagr, iact=iact, iters=iters, pinned=pin)
     return x
 
 

@@ -25,5 +25,11 @@ abl() {   # abl <name> <sed script applied to the temporary copy of mcq_kkt.inc>
 abl nostore 's|if (st_en\[r\]) o\[st_off\[r\]\] = (RT)nvv\[r\];|if (st_en[r] \&\& k < 0) o[st_off[r]] = (RT)nvv[r];|; s|if (cl < 5) o\[15 + cl\] = (RT)lov;|if (cl < 5 \&\& k < 0) o[15 + cl] = (RT)lov;|' &
 abl noload 's|if (k0 + KCKF < Lmax) kkt_point_load(c, sig, mk, wgt, fv, KKT_REC_POINT(k0 + KCKF), raw);|/* ablation: no further loads */|' &
 abl noboth 's|if (st_en\[r\]) o\[st_off\[r\]\] = (RT)nvv\[r\];|if (st_en[r] \&\& k < 0) o[st_off[r]] = (RT)nvv[r];|; s|if (cl < 5) o\[15 + cl\] = (RT)lov;|if (cl < 5 \&\& k < 0) o[15 + cl] = (RT)lov;|; s|if (k0 + KCKF < Lmax) kkt_point_load(c, sig, mk, wgt, fv, KKT_REC_POINT(k0 + KCKF), raw);|/* ablation: no further loads */|' &
+# round 6, the checkpoint idea (docs/NOTEBOOK.md R6.3) as an UPPER BOUND before building it: the forward-eliminated spike | y records (208 of the
+# 368 B per waypoint the elimination writes and the spike pass reads back) not written / not read / neither -- what a spike pass that recomputes
+# them from one record in six would save at most (its extra arithmetic not included)
+abl noaystore 's|if (fl_on\[j\]) \*(gd2\*)(fl_dst\[j\] + (size_t)(k0 + kk) \* fl_rec\[j\]) = \*(const d2\*)fl_src\[j\];|if (fl_on[j] \&\& fl_rec[j] == KAD) *(gd2*)(fl_dst[j] + (size_t)(k0 + kk) * fl_rec[j]) = *(const d2*)fl_src[j];|' &
+abl noayload 's|kkt_stage_issue<F32, KCK2 \* KAYR>(AY + (size_t)(lo_pt + (nq - 1) \* KCK2) \* KAYR, cl, ry);|/* ablation */|; s|kkt_stage_issue<F32, KCK2 \* KAYR>(AY + (size_t)(lo_pt + (q - 1) \* KCK2) \* KAYR, cl, ry);|/* ablation */|' &
+abl noayboth 's|if (fl_on\[j\]) \*(gd2\*)(fl_dst\[j\] + (size_t)(k0 + kk) \* fl_rec\[j\]) = \*(const d2\*)fl_src\[j\];|if (fl_on[j] \&\& fl_rec[j] == KAD) *(gd2*)(fl_dst[j] + (size_t)(k0 + kk) * fl_rec[j]) = *(const d2*)fl_src[j];|; s|kkt_stage_issue<F32, KCK2 \* KAYR>(AY + (size_t)(lo_pt + (nq - 1) \* KCK2) \* KAYR, cl, ry);|/* ablation */|; s|kkt_stage_issue<F32, KCK2 \* KAYR>(AY + (size_t)(lo_pt + (q - 1) \* KCK2) \* KAYR, cl, ry);|/* ablation */|' &
 wait
 ls -la $R/build/kc

@@ -21,6 +21,15 @@ def test_shard_bounds_cover_batch():
             assert max(sizes) - min(sizes) <= 1
 
 
+def test_interleaved_partition_covers_batch():
+    for batch in (1, 2, 5, 1024):
+        for world in (1, 2, 3, 8):
+            idx = [parallel.shard_indices(batch, world, r, "interleaved") for r in range(world)]
+            assert sorted(int(i) for a in idx for i in a) == list(range(batch))
+            assert max(len(a) for a in idx) - min(len(a) for a in idx) <= 1
+            assert all(np.array_equal(parallel.shard_indices(batch, world, r), np.arange(*parallel.shard_bounds(batch, world, r))) for r in range(world))
+
+
 def _problems():
     from oracle import tph_ref
     out = []
@@ -61,6 +70,9 @@ def _worker(rank, world, port, lib, stub, q):
     for p_ in d_s + d_r:
         eng.free(p_)
     a, c, s = parallel.solve_sharded(_problems(), eng, dist=dist)
+    # the interleaved partition (b mod world) returns the same batch, in batch order, bit for bit
+    a_i, c_i, s_i = parallel.solve_sharded(_problems(), eng, dist=dist, partition="interleaved")
+    assert all(np.array_equal(x, y) for x, y in zip(a, a_i)) and np.array_equal(c, c_i) and np.array_equal(s, s_i)
     q.put((rank, [x.tolist() for x in a], c.tolist(), s.tolist()))
     dist.barrier()
     # a download after comm_destroy must not wait on the destroyed events of the last gather

@@ -105,9 +105,11 @@ def test_iqp_rounds_with_the_fallback_inside(emu, golden):
 def test_zero_width_rows_both_paths_against_the_dense_oracle(emu):
     """Waypoints where the corridor is exactly as wide as the vehicle (w_r + w_l = w_veh: lo = hi) are equality constraints in disguise -- two
     exactly dependent rows of quadprog's G, which tph's `>` test lets through.  Both engine paths pin them and return the DENSE ORACLE's vertex
-    (oracle/gi_dense.c follows qpgen2's rule set since round 6: the second row of such a pair never enters, its slack is a rounding residue
-    below vsmall -- the QuadProg++-style exclusion list of rounds 1-5 stopped at a non-optimal point here, stationarity 2e-4); the independent
-    least-squares route (scipy BVLS on the dense E, the zero-width boxes opened by 1e-9 m) stays as the second opinion on all three."""
+    (oracle/gi_dense.c follows qpgen2's rule set since round 6: here the second row of such a pair never enters, its slack is a rounding residue
+    below vsmall and is set to zero -- the QuadProg++-style exclusion list of rounds 1-5 stopped at a non-optimal point, stationarity 2e-4;
+    where the residue exceeds vsmall quadprog's rules end in a spurious "inconsistent", see oracle/qp_ref.solve_qp_gi_zero_width_as_equalities
+    and tests/test_gpu_parity.py::test_pinned_variables_and_bad_input); the equality form of the same oracle and the independent least-squares
+    route (scipy BVLS on the dense E, the zero-width boxes opened by 1e-9 m) are the second and third opinion."""
     from scipy.optimize import lsq_linear
     from oracle import qp_ref
     from test_emu_kernels import _small_track
@@ -120,8 +122,9 @@ def test_zero_width_rows_both_paths_against_the_dense_oracle(emu):
     hi2[[3, 4, 17]] += 1e-9
     x2 = lsq_linear(E, -2.0 * k_ref, bounds=(lo, hi2), method="bvls", tol=1e-14).x
     G, h = tph_ref.constraints_dense(ref, E, k_ref, 0.5, 2.0)
-    info_o = {}
-    xo = qp_ref.solve_qp_gi(H, f, G, h, info_o)
+    xo = qp_ref.solve_qp_gi(H, f, G, h)                     # tph's two-inequality form: ends at the optimum HERE (the partner rows' residues stay below vsmall) ...
+    xe = qp_ref.solve_qp_gi_zero_width_as_equalities(H, f, G, h)      # ... the equality form (meq = 3) does so whatever the residues are
+    assert np.max(np.abs(xo - xe)) < 1e-10 and np.max(np.abs(xe[[3, 4, 17]])) < 1e-13
     assert np.max(np.abs(xo[[3, 4, 17]])) < 1e-14 and np.max(np.abs(xo - x2)) < 1e-8
     free_o = (xo > lo + 1e-9) & (xo < hi - 1e-9)
     assert np.max(np.abs((H @ xo + f)[free_o])) < 1e-10 * np.max(np.abs(f))

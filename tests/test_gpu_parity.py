@@ -666,7 +666,13 @@ def test_pinned_variables_and_bad_input(gpu_engine, golden):
         ref[i, 3] = 1.7 - shift          # lo =  shift
     path_cl = np.vstack((ref[:, :2], ref[0, :2]))
     _, _, A, nv = tph_ref.calc_splines(path_cl)
-    a_ref, err_ref = tph_ref.opt_min_curv(ref, nv, A, 0.12, 3.4)
+    # the oracle with the three zero-width waypoints stated as EQUALITIES (meq = 3) -- on tph's two-inequality form quadprog's own rule set ends
+    # in a spurious "constraints are inconsistent" on this input (a rounding residue of -4.5e-15 on the partner row of an active one:
+    # oracle/qp_ref.solve_qp_gi_zero_width_as_equalities has the mechanism); the engine returns the vertex
+    from oracle import qp_ref
+    a_ref, err_ref = tph_ref.opt_min_curv(ref, nv, A, 0.12, 3.4, solver=qp_ref.solve_qp_gi_zero_width_as_equalities)
+    with pytest.raises(ValueError, match="inconsistent"):
+        tph_ref.opt_min_curv(ref, nv, A, 0.12, 3.4)
     bad = g["reftrack"].copy()
     bad[7, 0] = np.nan
     sc = tph.calc_splines.scalings_from_les_matrix(A)
