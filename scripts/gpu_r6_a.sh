@@ -14,9 +14,9 @@ timeout 300 python scripts/bench_gi_mode.py > gpurun_out/${T}_gi_mode.json 2> gp
 echo "gi mode rc $?"; cut -c1-400 gpurun_out/${T}_gi_mode.json
 timeout 900 python bench.py --steps 10 --warmup 2 > gpurun_out/${T}_bench.json 2> gpurun_out/${T}_bench.err
 echo "bench rc $?"; cut -c1-300 gpurun_out/${T}_bench.json
-python - <<'PY'
+python - $T <<'PY'
 import json
-d=json.load(open("gpurun_out/%s_bench.json" % "r06a"))
+d=json.load(open("gpurun_out/%s_bench.json" % __import__("sys").argv[1]))
 print(json.dumps(d.get("latency_batch1"), indent=1))
 print("value", d["value"], "frac", d["roofline"]["frac"], "iqp", d.get("iqp",{}).get("value"), "h2h", d.get("host_to_host",{}).get("value"))
 PY
