@@ -247,7 +247,7 @@ extern "C" void mcq_destroy(mcq_handle* h)
 
 // Goldfarb-Idnani slots (mcq_gi.inc).  Two pools:
 //   FULL slots  -- a working set holds at most nmax independent constraints: nmax x nmax (Q) + nmax x nmax (R) doubles (64 MB at nmax = 2000).  The
-//                  fallback's pool: as many as $MCQ_GI_BYTES (4 GB) hold, at most MCQ_GI_FULL_MAX = 128 (64 at nmax = 2000: a sweep over tight curvature
+//                  fallback's pool: as many as $MCQ_GI_BYTES (4 GB) hold, at most MCQ_GI_FULL_MAX = 512 (64 at nmax = 2000: a sweep over tight curvature
 //                  bounds can send hundreds of problems of one launch down this path), never more than the batch.  A rare path must not cost the
 //                  common one its launch: a slot beyond the byte cap (rings above ~16 000 waypoints) or a refused hipMalloc leaves the handle
 //                  WITHOUT the pool -- the kernel then returns what its own phases left (MCQ_ITER_CAP, ...), as in round 4; not tried again for

@@ -354,6 +354,18 @@ def test_shortest_path_golden_and_errors(emu, golden):
                                          w_veh=float(z["w_veh"]))], objective=engine.OBJ_SHORTEST_PATH)
     assert st[0] == 0
     assert np.max(np.abs(al[0] - z["rounded_rectangle_alpha"])) < 1e-9
+    # round 6: a shortest-path problem that runs out of the caller's round budget (one round here) goes on from its working set under the
+    # single-pivot backup rule, which terminates on box rows -- status 0 and the golden vertex, where rounds 1-5 returned MCQ_ITER_CAP (this
+    # objective has no Goldfarb-Idnani path behind it)
+    went_on = 0
+    for name in ("rounded_rectangle", "handling_track", "modena_2019", "berlin_2018"):
+        gg = golden[name]
+        al1, _, st1, info1 = emu.solve_batch([dict(reftrack=gg["reftrack"], normvec=gg["normvec"], scaling=None, kappa_bound=1.0,
+                                                   w_veh=float(z["w_veh"]))], objective=engine.OBJ_SHORTEST_PATH, max_as_iter=1)
+        assert st1[0] == 0 and info1[0]["gi_iters"] == 0, (name, st1[0], info1[0])
+        assert np.max(np.abs(al1[0] - z[name + "_alpha"])) < 1e-8, name
+        went_on += 1 if info1[0]["second_attempt"] & 4 else 0
+    assert went_on >= 1            # (at least one of them needs more than the one round it was given)
     bad = g["reftrack"].copy()
     bad[3, 0] = np.nan
     _, _, st, _ = emu.solve_batch([dict(reftrack=bad, normvec=g["normvec"], scaling=None, kappa_bound=1.0, w_veh=3.4)],
