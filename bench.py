@@ -681,6 +681,14 @@ def main():
                 t1 = time.perf_counter()
                 _, _, st_h, _ = eng.solve_host(p_ref, p_nv, p_sc, KAPPA_BOUND, W_VEH, alpha_out=p_al[0])
                 hh.append(time.perf_counter() - t1)
+            os.environ["MCQ_HOST_ONE_LAUNCH"] = "1"          # (A/B: the same entry as ONE upload -> launch -> download, as rounds 1-5 ran it)
+            hh1 = []
+            for _ in range(3):
+                t1 = time.perf_counter()
+                eng.solve_host(p_ref, p_nv, p_sc, KAPPA_BOUND, W_VEH, alpha_out=p_al[1])
+                hh1.append(time.perf_counter() - t1)
+            del os.environ["MCQ_HOST_ONE_LAUNCH"]
+            blocking_equal = bool(np.array_equal(p_al[0], p_al[1]))
             hs = max(args.host_steps, 2)
             eng.solve_host_pipelined([p_ref] * 2, [p_nv] * 2, [p_sc] * 2, KAPPA_BOUND, W_VEH, p_al)       # staging slots, streams
             p_al[0][...] = np.nan
@@ -696,7 +704,11 @@ def main():
                                            "this rate can exceed `value`, measured launch by launch on one stream" % hs,
                                    "ratio_to_device_resident": (B * hs / t_pipe) / value,
                                    "blocking_single_batch": {"value": B / float(np.mean(hh)), "ms_per_step": 1e3 * float(np.mean(hh)),
-                                                             "what": "mcq_solve_host: H2D -> kernels -> D2H, blocking; %d calls" % len(hh)},
+                                                             "what": "mcq_solve_host, ONE batch, blocking; round 6: in four slices -- upload k + 1 / kernel k / "
+                                                                     "download k - 1 overlapped, consecutive slices' kernels on the two compute streams; %d calls" % len(hh),
+                                                             "as_one_launch": {"value": B / float(np.mean(hh1)), "ms_per_step": 1e3 * float(np.mean(hh1)),
+                                                                               "what": "$MCQ_HOST_ONE_LAUNCH=1: H2D -> one launch -> D2H (rounds 1-5)"},
+                                                             "alpha_equal_between_the_two": blocking_equal},
                                    "bytes_h2d_per_step": int(p_ref.nbytes + p_nv.nbytes + p_sc.nbytes), "bytes_d2h_per_step": int(p_al[0].nbytes),
                                    "alpha_equal_to_device_resident_run": bool(np.array_equal(p_al[0], alpha_gpu) and np.array_equal(p_al[1], alpha_gpu)),
                                    "failed_problems": int(np.count_nonzero(st_h) + np.count_nonzero(st_p))}

@@ -14,6 +14,7 @@
 
 #include <algorithm>
 #include <cmath>
+#include <functional>
 #include <string>
 #include <thread>
 #include <vector>
@@ -101,6 +102,7 @@ struct mcq_handle {
     // mcq_solve_host_pipelined: two copy streams, the second set of staging buffers, one event triple per slot
     hipStream_t cs_in = nullptr, cs_out = nullptr;
     hipEvent_t ev_up[2] = {nullptr, nullptr}, ev_done[2] = {nullptr, nullptr}, ev_down[2] = {nullptr, nullptr};
+    hipEvent_t ev_slice[16] = {};      // mcq_solve_host in slices: upload / kernel done, per slice
     double *p_ref = nullptr, *p_nv = nullptr, *p_sc = nullptr, *p_alpha = nullptr, *p_curv = nullptr;
     int* p_status = nullptr;
     size_t pipe_elems = 0, pipe_batch = 0;
@@ -234,6 +236,7 @@ extern "C" void mcq_destroy(mcq_handle* h)
         if (h->ev_done[k]) (void)hipEventDestroy(h->ev_done[k]);
         if (h->ev_down[k]) (void)hipEventDestroy(h->ev_down[k]);
     }
+    for (int k = 0; k < 16; ++k) if (h->ev_slice[k]) (void)hipEventDestroy(h->ev_slice[k]);
     if (h->cs_in) (void)hipStreamDestroy(h->cs_in);
     if (h->cs_out) (void)hipStreamDestroy(h->cs_out);
     (void)hipFree(h->vel_scratch);
@@ -247,9 +250,9 @@ extern "C" void mcq_destroy(mcq_handle* h)
 
 // Goldfarb-Idnani slots (mcq_gi.inc).  Two pools:
 //   FULL slots  -- a working set holds at most nmax independent constraints: nmax x nmax (Q) + nmax x nmax (R) doubles (64 MB at nmax = 2000).  The
-//                  fallback's pool: as many as $MCQ_GI_BYTES (4 GB) hold, at most MCQ_GI_FULL_MAX = 512 (64 at nmax = 2000: a sweep over tight curvature
+//                  fallback's pool: as many as $MCQ_GI_BYTES (16 GB) hold, at most MCQ_GI_FULL_MAX = 512 (256 at nmax = 2000: a sweep over tight curvature
 //                  bounds can send hundreds of problems of one launch down this path), never more than the batch.  A rare path must not cost the
-//                  common one its launch: a slot beyond the byte cap (rings above ~16 000 waypoints) or a refused hipMalloc leaves the handle
+//                  common one its launch: a slot beyond the byte cap (rings above ~32 000 waypoints) or a refused hipMalloc leaves the handle
 //                  WITHOUT the pool -- the kernel then returns what its own phases left (MCQ_ITER_CAP, ...), as in round 4; not tried again for
 //                  rings that long.
 //   SMALL slots -- round 6, mcq_opts.algorithm = MCQ_ALG_GI (every problem takes the path: one slot per resident workgroup): working sets of up to
@@ -265,7 +268,7 @@ static size_t gi_small_qcap(size_t nmax)
 static size_t gi_byte_cap()
 {
     if (const char* e = getenv("MCQ_GI_BYTES")) { const long long v = atoll(e); if (v >= 0) return (size_t)v; }
-    return (size_t)4 << 30;
+    return (size_t)16 << 30;       // (288 GB of HBM: round 6 measured the 600-large-ring stress at 75 s with 4 GB of full slots and 44 s with 48 GB)
 }
 
 // hipMalloc of `slots` items of `per` bytes, halving the count until the allocation succeeds; returns the count had (0: none)
@@ -1082,6 +1085,42 @@ extern "C" int mcq_host_free(mcq_handle* h, void* ptr)
     return 0;
 }
 
+// the knobs of the sliced host entries (mcq_solve_host, mcq_solve_batch): slices for this batch / these options, or 1
+static int host_slices(int batch, const mcq_opts& o)
+{
+    int slice_min = 512;           // ($MCQ_HOST_SLICE_MIN: the tests slice a batch of eleven)
+    if (const char* e = getenv("MCQ_HOST_SLICE_MIN")) slice_min = std::max(atoi(e), 4);
+    int nsl = 4;                   // ($MCQ_HOST_SLICES: 2 .. 8; 4 measured best on 1024 x N = 2000, docs/NOTEBOOK.md R6.5)
+    if (const char* e = getenv("MCQ_HOST_SLICES")) nsl = std::min(std::max(atoi(e), 2), 8);
+    return (batch >= slice_min && o.objective == MCQ_OBJ_MIN_CURV && o.algorithm != MCQ_ALG_GI && !getenv("MCQ_HOST_ONE_LAUNCH")) ? nsl : 1;
+}
+static int ensure_slice_streams(mcq_handle* h)
+{
+    if (!h->cs_in) { HIP_TRY(hipStreamCreate(&h->cs_in)); HIP_TRY(hipStreamCreate(&h->cs_out)); }
+    if (!h->stream2) HIP_TRY(hipStreamCreate(&h->stream2));
+    for (int k = 0; k < 16; ++k) if (!h->ev_slice[k]) HIP_TRY(hipEventCreate(&h->ev_slice[k]));
+    HIP_TRY(hipStreamSynchronize(h->stream));          // whatever ran before on the handle is done with the staging buffers and the workspace
+    HIP_TRY(hipStreamSynchronize(h->stream2));
+    return 0;
+}
+
+// (the slices of mcq_solve_host: every stream that may hold copies from / into the caller's buffers is drained before an error is reported)
+#define HIP_TRY_SLICE(expr)                                                                               \
+    do {                                                                                                  \
+        hipError_t e_ = (expr);                                                                           \
+        if (e_ != hipSuccess) {                                                                           \
+            char buf_[512];                                                                               \
+            snprintf(buf_, sizeof(buf_), "%s failed: %s (%s:%d)", #expr, hipGetErrorString(e_), __FILE__, \
+                     __LINE__);                                                                           \
+            g_err = buf_;                                                                                 \
+            (void)hipStreamSynchronize(h->cs_in);                                                         \
+            (void)hipStreamSynchronize(h->stream);                                                        \
+            (void)hipStreamSynchronize(h->stream2);                                                       \
+            (void)hipStreamSynchronize(h->cs_out);                                                        \
+            return MCQ_E_DEVICE;                                                                          \
+        }                                                                                                 \
+    } while (0)
+
 extern "C" int mcq_solve_host(mcq_handle* h, int batch, int n, const double* reftrack, const double* normvec,
                               const double* scaling, double kappa_bound, double w_veh, const mcq_opts* opts, double* alpha_out,
                               double* curv_err_out, int* status_out, mcq_info* info_out)
@@ -1097,9 +1136,6 @@ extern "C" int mcq_solve_host(mcq_handle* h, int batch, int n, const double* ref
     rc = ensure_stage(h, (size_t)batch, (size_t)n);
     if (rc) return rc;
     const size_t elems = (size_t)batch * n;
-    HIP_TRY_SYNC(hipMemcpyAsync(h->d_ref, reftrack, elems * 4 * sizeof(double), hipMemcpyHostToDevice, h->stream));
-    if (normvec) HIP_TRY_SYNC(hipMemcpyAsync(h->d_nv, normvec, elems * 2 * sizeof(double), hipMemcpyHostToDevice, h->stream));
-    if (scaling) HIP_TRY_SYNC(hipMemcpyAsync(h->d_sc, scaling, elems * sizeof(double), hipMemcpyHostToDevice, h->stream));
     McqBatch B;
     memset(&B, 0, sizeof(B));
     B.batch = batch;
@@ -1114,6 +1150,48 @@ extern "C" int mcq_solve_host(mcq_handle* h, int batch, int n, const double* ref
     B.info = info_out ? h->d_info : nullptr;
     B.kappa_bound = kappa_bound;
     B.w_veh = w_veh;
+    // A large batch in SLICES (round 6): the upload of slice k + 1 and the download of slice k - 1 run while slice k's kernel does -- on a copy
+    // stream each way --, and the kernels of consecutive slices go to the handle's two compute streams, so that a slice's tail (its slowest
+    // problems, on compute units the others have left) is filled by the next slice's workgroups; all of them work on disjoint rows of the ONE
+    // workspace (McqBatch.pb0).  The blocking single-batch entry had paid its 115 MB of H2D and 16 MB of D2H in full next to the kernel: 13.3 ms
+    // for a 10.4 ms kernel at 1024 x N = 2000.  Results bitwise those of the one launch: the problems are independent.  $MCQ_HOST_ONE_LAUNCH=1:
+    // the one launch (A/B knob).
+    const int nsl = host_slices(batch, o);
+    if (nsl > 1) {
+        if (int src = ensure_slice_streams(h)) return src;
+        if (int frc = fill_batch(h, B, o, false)) return frc;
+        B.warm = nullptr;
+        h->state2_valid = false;
+        h->timing_valid = false;
+        for (int k = 0; k < nsl; ++k) {
+            const int b0 = (int)((long long)batch * k / nsl), b1 = (int)((long long)batch * (k + 1) / nsl);
+            const size_t off = (size_t)b0 * n, cnt = (size_t)(b1 - b0) * n;
+            HIP_TRY_SLICE(hipMemcpyAsync(h->d_ref + off * 4, reftrack + off * 4, cnt * 4 * sizeof(double), hipMemcpyHostToDevice, h->cs_in));
+            if (normvec) HIP_TRY_SLICE(hipMemcpyAsync(h->d_nv + off * 2, normvec + off * 2, cnt * 2 * sizeof(double), hipMemcpyHostToDevice, h->cs_in));
+            if (scaling) HIP_TRY_SLICE(hipMemcpyAsync(h->d_sc + off, scaling + off, cnt * sizeof(double), hipMemcpyHostToDevice, h->cs_in));
+            HIP_TRY_SLICE(hipEventRecord(h->ev_slice[k], h->cs_in));
+            hipStream_t st = (k & 1) ? h->stream2 : h->stream;
+            HIP_TRY_SLICE(hipStreamWaitEvent(st, h->ev_slice[k], 0));
+            McqBatch S = B;
+            S.pb0 = b0;
+            hipLaunchKernelGGL(mcq_solve_kernel, dim3(b1 - b0), dim3(256), 0, st, S);
+            HIP_TRY_SLICE(hipGetLastError());
+            HIP_TRY_SLICE(hipEventRecord(h->ev_slice[8 + k], st));
+            HIP_TRY_SLICE(hipStreamWaitEvent(h->cs_out, h->ev_slice[8 + k], 0));
+            HIP_TRY_SLICE(hipMemcpyAsync(alpha_out + off, h->d_alpha + off, cnt * sizeof(double), hipMemcpyDeviceToHost, h->cs_out));
+        }
+        // (cs_out is behind every slice's kernel now: the small arrays follow the last slice's alpha)
+        HIP_TRY_SLICE(hipMemcpyAsync(curv_err_out, h->d_curv, batch * sizeof(double), hipMemcpyDeviceToHost, h->cs_out));
+        HIP_TRY_SLICE(hipMemcpyAsync(status_out, h->d_status, batch * sizeof(int), hipMemcpyDeviceToHost, h->cs_out));
+        if (info_out) HIP_TRY_SLICE(hipMemcpyAsync(info_out, h->d_info, batch * sizeof(mcq_info), hipMemcpyDeviceToHost, h->cs_out));
+        HIP_TRY(hipStreamSynchronize(h->cs_out));
+        HIP_TRY(hipStreamSynchronize(h->stream));
+        HIP_TRY(hipStreamSynchronize(h->stream2));
+        return 0;
+    }
+    HIP_TRY_SYNC(hipMemcpyAsync(h->d_ref, reftrack, elems * 4 * sizeof(double), hipMemcpyHostToDevice, h->stream));
+    if (normvec) HIP_TRY_SYNC(hipMemcpyAsync(h->d_nv, normvec, elems * 2 * sizeof(double), hipMemcpyHostToDevice, h->stream));
+    if (scaling) HIP_TRY_SYNC(hipMemcpyAsync(h->d_sc, scaling, elems * sizeof(double), hipMemcpyHostToDevice, h->stream));
     rc = launch(h, B, o);
     if (rc) { (void)hipStreamSynchronize(h->stream); return rc; }
     HIP_TRY_SYNC(hipMemcpyAsync(alpha_out, h->d_alpha, elems * sizeof(double), hipMemcpyDeviceToHost, h->stream));
@@ -1162,9 +1240,11 @@ extern "C" int mcq_solve_batch_f32(mcq_handle* h, int batch, int n, int layout, 
 // ---- a stream of uniform host batches with the PCIe behind the kernels (include/mcq.h) ------------------------------------------
 static int ensure_pipe(mcq_handle* h, size_t batch, size_t nmax)
 {
-    if (!h->cs_in) {
+    if (!h->cs_in) {                    // (mcq_solve_host's slices may have created the two copy streams already)
         HIP_TRY(hipStreamCreate(&h->cs_in));
         HIP_TRY(hipStreamCreate(&h->cs_out));
+    }
+    if (!h->ev_up[0]) {
         for (int k = 0; k < 2; ++k) {
             HIP_TRY(hipEventCreate(&h->ev_up[k]));
             HIP_TRY(hipEventCreate(&h->ev_done[k]));
@@ -1538,8 +1618,12 @@ struct PinLayout {
     mcq_info* info;
 };
 
+// after_chunk (round 6, mcq_solve_batch in slices): the uploads go to the handle's copy stream h->cs_in instead of its compute stream, in exactly
+// `force_chunks` chunks of tracks, the per-problem scalars first, and after_chunk(k, b0, b1) is called as soon as chunk k's uploads are queued
+// (it queues that slice's kernel behind them while the next chunk is packed).
 static int pack_and_upload(mcq_handle* h, const mcq_problem* probs, int batch, size_t nmax, bool any_sc, bool with_nv,
-                           size_t extra_bytes, PinLayout& P, const char* who)
+                           size_t extra_bytes, PinLayout& P, const char* who, int force_chunks = 0,
+                           const std::function<int(int, int, int)>& after_chunk = nullptr)
 {
     const size_t elems = (size_t)batch * nmax;
     const size_t bytes = elems * (4 + 2 + 1 + 1) * sizeof(double) + (size_t)batch * (2 * sizeof(double) + sizeof(int) + sizeof(mcq_info)) + 64 + extra_bytes;
@@ -1582,8 +1666,16 @@ static int pack_and_upload(mcq_handle* h, const mcq_problem* probs, int batch, s
     if (nthreads > batch) nthreads = batch;
     if (nthreads < 1) nthreads = 1;
     int nchunks = (forced && nthreads > 1) || (payload > ((size_t)32 << 20) && batch >= 16) ? 4 : 1;
+    if (force_chunks > 0) nchunks = force_chunks;
     if (nchunks > batch) nchunks = batch;
     (void)who;
+    hipStream_t up = force_chunks > 0 ? h->cs_in : h->stream;
+    if (force_chunks > 0) {        // the slices' kernels read the per-problem scalars: first
+        for (int b = 0; b < batch; ++b) { P.kb[b] = probs[b].kappa_bound; P.wv[b] = probs[b].w_veh; P.n[b] = probs[b].n; }
+        HIP_TRY_SYNC(hipMemcpyAsync(h->d_kb, P.kb, batch * sizeof(double), hipMemcpyHostToDevice, up));
+        HIP_TRY_SYNC(hipMemcpyAsync(h->d_wv, P.wv, batch * sizeof(double), hipMemcpyHostToDevice, up));
+        HIP_TRY_SYNC(hipMemcpyAsync(h->d_n, P.n, batch * sizeof(int), hipMemcpyHostToDevice, up));
+    }
     for (int ck = 0; ck < nchunks; ++ck) {
         const int b0 = (int)((long long)batch * ck / nchunks), b1 = (int)((long long)batch * (ck + 1) / nchunks);
         if (nthreads > 1) {
@@ -1598,10 +1690,12 @@ static int pack_and_upload(mcq_handle* h, const mcq_problem* probs, int batch, s
             for (auto& t : th) t.join();
         } else pack_range(b0, b1);
         const size_t off = (size_t)b0 * nmax, cnt = (size_t)(b1 - b0) * nmax;
-        HIP_TRY_SYNC(hipMemcpyAsync(h->d_ref + off * 4, P.ref + off * 4, cnt * 4 * sizeof(double), hipMemcpyHostToDevice, h->stream));
-        if (with_nv) HIP_TRY_SYNC(hipMemcpyAsync(h->d_nv + off * 2, P.nv + off * 2, cnt * 2 * sizeof(double), hipMemcpyHostToDevice, h->stream));
-        if (any_sc) HIP_TRY_SYNC(hipMemcpyAsync(h->d_sc + off, P.sc + off, cnt * sizeof(double), hipMemcpyHostToDevice, h->stream));
+        HIP_TRY_SYNC(hipMemcpyAsync(h->d_ref + off * 4, P.ref + off * 4, cnt * 4 * sizeof(double), hipMemcpyHostToDevice, up));
+        if (with_nv) HIP_TRY_SYNC(hipMemcpyAsync(h->d_nv + off * 2, P.nv + off * 2, cnt * 2 * sizeof(double), hipMemcpyHostToDevice, up));
+        if (any_sc) HIP_TRY_SYNC(hipMemcpyAsync(h->d_sc + off, P.sc + off, cnt * sizeof(double), hipMemcpyHostToDevice, up));
+        if (after_chunk) { if (int rc2 = after_chunk(ck, b0, b1)) return rc2; }
     }
+    if (force_chunks > 0) return 0;
     HIP_TRY_SYNC(hipMemcpyAsync(h->d_kb, P.kb, batch * sizeof(double), hipMemcpyHostToDevice, h->stream));
     HIP_TRY_SYNC(hipMemcpyAsync(h->d_wv, P.wv, batch * sizeof(double), hipMemcpyHostToDevice, h->stream));
     HIP_TRY_SYNC(hipMemcpyAsync(h->d_n, P.n, batch * sizeof(int), hipMemcpyHostToDevice, h->stream));
@@ -1632,9 +1726,6 @@ extern "C" int mcq_solve_batch(mcq_handle* h, const mcq_problem* probs, int batc
     rc = ensure_stage(h, (size_t)batch, nmax);
     if (rc) return rc;
     PinLayout P;
-    rc = pack_and_upload(h, probs, batch, nmax, any_sc, probs[0].normvec != nullptr, 0, P, "mcq_solve_batch");
-    if (rc) return rc;
-
     McqBatch B;
     memset(&B, 0, sizeof(B));
     B.batch = batch;
@@ -1650,6 +1741,51 @@ extern "C" int mcq_solve_batch(mcq_handle* h, const mcq_problem* probs, int batc
     B.info = h->d_info;
     B.kappa_bound_list = h->d_kb;
     B.w_veh_list = h->d_wv;
+    const int nsl = host_slices(batch, o);
+    if (nsl > 1) {
+        // in slices, as mcq_solve_host (see there): chunk k's kernel is queued behind its uploads while chunk k + 1 is packed; the padded alpha
+        // rows come back slice by slice into the pinned staging
+        rc = ensure_slice_streams(h);
+        if (rc) return rc;
+        rc = fill_batch(h, B, o, false);
+        if (rc) return rc;
+        B.warm = nullptr;
+        h->state2_valid = false;
+        h->timing_valid = false;
+        PinLayout* Pp = &P;
+        rc = pack_and_upload(h, probs, batch, nmax, any_sc, probs[0].normvec != nullptr, 0, P, "mcq_solve_batch", nsl,
+                             [&](int k, int b0, int b1) -> int {
+                                 HIP_TRY_SLICE(hipEventRecord(h->ev_slice[k], h->cs_in));
+                                 hipStream_t st = (k & 1) ? h->stream2 : h->stream;
+                                 HIP_TRY_SLICE(hipStreamWaitEvent(st, h->ev_slice[k], 0));
+                                 McqBatch S = B;
+                                 S.pb0 = b0;
+                                 hipLaunchKernelGGL(mcq_solve_kernel, dim3(b1 - b0), dim3(256), 0, st, S);
+                                 HIP_TRY_SLICE(hipGetLastError());
+                                 HIP_TRY_SLICE(hipEventRecord(h->ev_slice[8 + k], st));
+                                 HIP_TRY_SLICE(hipStreamWaitEvent(h->cs_out, h->ev_slice[8 + k], 0));
+                                 const size_t off = (size_t)b0 * nmax, cnt = (size_t)(b1 - b0) * nmax;
+                                 HIP_TRY_SLICE(hipMemcpyAsync(Pp->alpha + off, h->d_alpha + off, cnt * sizeof(double), hipMemcpyDeviceToHost, h->cs_out));
+                                 return 0;
+                             });
+        if (rc) { (void)hipStreamSynchronize(h->cs_in); (void)hipStreamSynchronize(h->stream); (void)hipStreamSynchronize(h->stream2); (void)hipStreamSynchronize(h->cs_out); return rc; }
+        HIP_TRY_SLICE(hipMemcpyAsync(curv_err_out, h->d_curv, batch * sizeof(double), hipMemcpyDeviceToHost, h->cs_out));
+        HIP_TRY_SLICE(hipMemcpyAsync(status_out, h->d_status, batch * sizeof(int), hipMemcpyDeviceToHost, h->cs_out));
+        HIP_TRY_SLICE(hipMemcpyAsync(P.info, h->d_info, batch * sizeof(mcq_info), hipMemcpyDeviceToHost, h->cs_out));
+        HIP_TRY_SLICE(hipStreamSynchronize(h->cs_out));
+        HIP_TRY_SLICE(hipStreamSynchronize(h->stream));
+        HIP_TRY_SLICE(hipStreamSynchronize(h->stream2));
+        size_t off2 = 0;
+        for (int b = 0; b < batch; ++b) {
+            const size_t nb = (size_t)probs[b].n;
+            memcpy(alpha_out + off2, P.alpha + (size_t)b * nmax, nb * sizeof(double));
+            off2 += nb;
+            if (info_out) info_out[b] = P.info[b];
+        }
+        return 0;
+    }
+    rc = pack_and_upload(h, probs, batch, nmax, any_sc, probs[0].normvec != nullptr, 0, P, "mcq_solve_batch");
+    if (rc) return rc;
     rc = launch(h, B, o);
     if (rc) { (void)hipStreamSynchronize(h->stream); return rc; }
 

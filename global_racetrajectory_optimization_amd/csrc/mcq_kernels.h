@@ -74,6 +74,7 @@ enum {
 };
 
 struct McqBatch {
+    int pb0;        // slice launches (round 6, mcq_solve_host): workgroup w of the launch works on problem pb0 + w of the batch's arrays
     int batch;
     int n;          // uniform-n path (n_list == nullptr) or nmax
     int nmax;
@@ -116,7 +117,7 @@ __global__ void mcq_solve_kernel(McqBatch B);      // saddle-point elimination (
 /* Goldfarb-Idnani dual active-set path (mcq_gi.inc): inside mcq_solve_kernel, for whatever its interior point + block pivoting did not
  * settle (iteration cap, working set beyond its arrays, ...) -- solved again from scratch by quadprog's algorithm, in an HBM slot of the handle */
 #define MCQ_GI_SLOTS 8
-#define MCQ_GI_FULL_MAX 512        /* full slots (working sets of up to nmax constraints) a handle holds at most (the default byte cap, 4 GB, gives 64 at nmax = 2000; $MCQ_GI_BYTES raises it) */
+#define MCQ_GI_FULL_MAX 512        /* full slots (working sets of up to nmax constraints) a handle holds at most (the default byte cap, 16 GB, gives 256 at nmax = 2000; $MCQ_GI_BYTES moves it) */
 #define MCQ_GI_SLOTS_MAX 512       /* small slots when every problem takes the path (mcq_opts.algorithm = MCQ_ALG_GI): one per resident workgroup */
 #define MCQ_SLOT_FLAGS (MCQ_KBIG_SLOTS + MCQ_GI_FULL_MAX + MCQ_GI_SLOTS_MAX)
 #define MCQ_GI_SLOT_FULL 100       /* gi_solve: the working set has outgrown the slot (internal: gi_rescue moves the problem to a full slot) */

@@ -1866,7 +1866,7 @@ __device__ __forceinline__ void solve_body(const McqBatch& B, const McqSet& IN, 
 
 __global__ void __launch_bounds__(MCQ_NT, 2) mcq_solve_kernel(McqBatch B)
 {
-    solve_body(B, mcq_set_of(B), (int)blockIdx.x);
+    solve_body(B, mcq_set_of(B), B.pb0 + (int)blockIdx.x);
 }
 
 // =====================================================================================================================

@@ -43,17 +43,22 @@ enum {
     MCQ_OK = 0,
     MCQ_INFEASIBLE = 1,      /* w_r + w_l < w_veh somewhere  -> tph raises RuntimeError("Problem not solvable, ...") */
     MCQ_NOT_PD = 2,          /* Cholesky pivot <= 0            -> quadprog raises ValueError("matrix G is not positive definite") */
-    MCQ_ITER_CAP = 3,        /* iteration cap hit -- of the Goldfarb-Idnani fallback too (20 n + 2000 steps; not observed) */
+    MCQ_ITER_CAP = 3,        /* iteration cap hit -- of the Goldfarb-Idnani fallback too (20 n + 2000 steps; not observed) --, or of the interior
+                               * point + block pivoting on a handle that has no Goldfarb-Idnani slot for rings this long (see MCQ_ALG_GI below) */
     MCQ_BAD_INPUT = 4,       /* n < 3, non-finite input */
     MCQ_KAPPA_INFEASIBLE = 5, /* curvature rows cannot be satisfied -> quadprog raises ValueError("constraints are inconsistent, no solution") */
     MCQ_KAPPA_ACTIVE = 6,     /* box-only optimum violates a curvature row and the curvature-row phase is disabled (check_kappa < 0).
                                * (Rounds 1-4 also returned it for more active curvature rows than the working-set arrays hold -- 120 in LDS,
-                               * 512 through an overflow slot; such problems now go through the Goldfarb-Idnani path, which has no limit.) */
+                               * 512 through an overflow slot; such problems now go through the Goldfarb-Idnani path, which has no limit --
+                               * round 6: ALL of them, so that a problem's route and the last bits of its result do not depend on what else is in
+                               * the launch.  On a handle without a Goldfarb-Idnani slot -- rings beyond the byte cap below -- the overflow slots
+                               * serve as before and this status can come back for more than 512 rows.)  Also returned by that path when
+                               * check_kappa < 0 and the returned point violates a curvature row. */
     MCQ_RING_OVERFLOW = 7,    /* mcq_iqp_device / mcq_iqp_batch only: the re-sampled raceline of an IQP round needs more waypoints than
                                * the buffers hold (nmax / nmax_out) -- not an input error of the QP (that stays MCQ_BAD_INPUT) */
-    MCQ_KAPPA_NO_SLOT = 8     /* never returned since round 5 (kept for ABI compatibility): a problem with more than 120 active curvature
-                               * rows that finds the handle's 8 overflow slots taken is solved by the Goldfarb-Idnani path inside the same
-                               * kernel, on every entry point */
+    MCQ_KAPPA_NO_SLOT = 8     /* returned only on a handle WITHOUT Goldfarb-Idnani slots (rings beyond the byte cap): more than eight problems of
+                               * one launch with more than 120 active curvature rows each.  Everywhere else such problems are solved by the
+                               * Goldfarb-Idnani path inside the same kernel, on every entry point */
 };
 
 /* library-level error codes (negative return values) */
@@ -79,8 +84,14 @@ typedef struct {
                          * with the Goldfarb-Idnani path below as the fallback of every problem that phase does not settle;
                          * MCQ_ALG_GI (1): EVERY problem through the engine's Goldfarb-Idnani dual active-set path (quadprog's algorithm
                          * [REF requirements.txt:3 via tph.opt_min_curv]: one constraint enters per iteration, ratio test, drops -- finite by
-                         * construction; a reference mode -- the handle then holds an HBM slot of 2 nmax^2 doubles per resident workgroup, up to 512 of them and
-                         * 48 GB: 7.8 k solves/s on 1024 rings of 2000 waypoints, a twelfth of the default path's rate).  Minimum-curvature
+                         * construction; a reference mode: 8.1 k solves/s on 1024 rings of 2000 waypoints, a twelfth of the default path's rate).
+                         * Memory of that path (round 6): FULL slots (2 nmax^2 doubles: a working set of up to nmax constraints) for the fallback,
+                         * as many as $MCQ_GI_BYTES (default 16 GB) hold, at most 512, never more than the batch -- and NONE where one slot exceeds
+                         * the cap (rings above ~32 000 waypoints) or the allocation is refused: the launch then runs without the fallback and
+                         * reports what interior point + block pivoting left (MCQ_ITER_CAP ...), it does not fail; SMALL slots (working sets of up
+                         * to max(128, nmax / 8) constraints, 4.6 MB at nmax = 2000) for MCQ_ALG_GI, one per resident workgroup (2.4 GB for 512),
+                         * a problem that outgrows its small slot moving into a full one.  MCQ_ALG_GI without any slot to be had is MCQ_E_DEVICE.
+                         * mcq_solve_host_pipelined / mcq_solve_device_stream keep MCQ_ALG_GI on ONE compute stream.  Minimum-curvature
                          * objective only.  (Until round 4 this field was `band_e`, ignored since E is applied through the spline system.) */
     int max_ipm_iter;   /* 0 => default 60 */
     int max_as_iter;    /* 0 => default 60 */
@@ -279,7 +290,11 @@ int mcq_raceline_device(mcq_handle* h, int batch, int nmax, const int* n_in, con
  * scaling [batch][n] or NULL in host memory, results to host memory.  One asynchronous copy per array straight from / to the
  * caller's buffers -- no packing pass; buffers from mcq_host_alloc (pinned) are copied at PCIe speed, pageable ones go through
  * the runtime's staging.  This is the wall SURVEY.md section 8d defines the metric on ("inputs resident in host pinned memory
- * -> alpha resident in host memory"); bench.py reports it next to the device-resident rate.  Blocking. */
+ * -> alpha resident in host memory"); bench.py reports it next to the device-resident rate.  Blocking.  Round 6: a batch of 512 or more
+ * (minimum-curvature objective, default algorithm) goes in four SLICES -- the upload of slice k + 1 and the download of slice k - 1 overlap slice
+ * k's kernel, consecutive slices' kernels run on the handle's two compute streams (11.6 ms where the one launch took 13.0 for 1024 x N = 2000);
+ * results bitwise those of the one launch; mcq_last_timing is not valid after such a call.  mcq_solve_batch does the same behind its packing
+ * threads.  Knobs (environment): MCQ_HOST_ONE_LAUNCH=1, MCQ_HOST_SLICES (2 .. 8), MCQ_HOST_SLICE_MIN. */
 int mcq_solve_host(mcq_handle* h, int batch, int n, const double* reftrack, const double* normvec, const double* scaling,
                    double kappa_bound, double w_veh, const mcq_opts* opts, double* alpha_out, double* curv_err_out,
                    int* status_out, mcq_info* info_out);

@@ -724,6 +724,45 @@ def test_fp32_increment_rows_keep_the_accuracy(emu, golden):
     assert np.max(np.abs(a_no_org[0].astype(np.float64) - a_inc[0])) < 1e-6
 
 
+def test_solve_host_in_slices_is_bitwise_the_one_launch(emu, monkeypatch):
+    """Round 6: mcq_solve_host takes a batch of 512 or more (here: $MCQ_HOST_SLICE_MIN = 8) in four SLICES -- upload k + 1 / kernel k / download k - 1 overlapped, the kernels of
+    consecutive slices on the handle's two compute streams, all on disjoint rows of one workspace (McqBatch.pb0) -- and must return what the one
+    launch ($MCQ_HOST_ONE_LAUNCH=1) returns, bit for bit, info records included; a narrow corridor in slice 2 keeps its status."""
+    monkeypatch.setenv("MCQ_HOST_SLICE_MIN", "8")
+    n, bsz = 24, 11                         # (not a multiple of four: the slices differ in size)
+    base = [_small_track(n, seed=300 + k) for k in range(5)]
+    rng = np.random.default_rng(9)
+    refs = np.stack([base[k % 5][0] for k in range(bsz)])
+    refs[:, :, 2:] += rng.uniform(0.0, 0.8, size=(bsz, n, 2))
+    refs[7, 3, 2:] = 0.5                     # w_r + w_l < w_veh: MCQ_INFEASIBLE for this one
+    nvs = np.stack([base[k % 5][1] for k in range(bsz)])
+    scs = np.stack([base[k % 5][3] for k in range(bsz)])
+    al, cu, st, info = emu.solve_host(refs, nvs, scs, 0.5, 2.0)
+    monkeypatch.setenv("MCQ_HOST_ONE_LAUNCH", "1")
+    al1, cu1, st1, info1 = emu.solve_host(refs, nvs, scs, 0.5, 2.0)
+    assert st[7] == engine.STATUS_INFEASIBLE and np.count_nonzero(st) == 1 and np.array_equal(st, st1)
+    assert np.array_equal(al, al1) and np.array_equal(cu, cu1)
+    assert [i.ipm_iters for i in info] == [i.ipm_iters for i in info1] and [i.as_iters for i in info] == [i.as_iters for i in info1]
+    # ... and what the ragged host-buffer entry returns for three of them
+    probs = [dict(reftrack=refs[k], normvec=nvs[k], scaling=scs[k], kappa_bound=0.5, w_veh=2.0) for k in (0, 5, 10)]
+    al2, _, st2, _ = emu.solve_batch(probs)
+    assert all(np.array_equal(al2[j], al[k]) for j, k in enumerate((0, 5, 10)))
+    # the ragged host-buffer entry (mcq_solve_batch: what the drop-in's opt_min_curv_batch calls) slices the same way: eleven rings of three
+    # different sizes, per-problem vehicle widths, one of them infeasible -- sliced and in one launch, bit for bit
+    rag = []
+    for k in range(11):
+        r_, v_, _, s_ = _small_track(20 + 3 * (k % 3), seed=400 + k)
+        rag.append(dict(reftrack=r_, normvec=v_, scaling=s_, kappa_bound=0.5, w_veh=2.0 + 0.05 * k))
+    rag[6]["reftrack"] = rag[6]["reftrack"].copy()
+    rag[6]["reftrack"][2, 2:] = 0.4
+    a_one, c_one, s_one, i_one = emu.solve_batch(rag)           # (MCQ_HOST_ONE_LAUNCH is still set)
+    monkeypatch.delenv("MCQ_HOST_ONE_LAUNCH")
+    a_sl, c_sl, s_sl, i_sl = emu.solve_batch(rag)
+    assert list(s_sl) == list(s_one) and s_sl[6] == engine.STATUS_INFEASIBLE and np.count_nonzero(s_sl) == 1
+    assert all(np.array_equal(x, y) for x, y in zip(a_sl, a_one)) and np.array_equal(c_sl, c_one)
+    assert [i["ipm_iters"] for i in i_sl] == [i["ipm_iters"] for i in i_one]
+
+
 def test_solve_host_pipelined_equals_solve_host(emu, golden):
     """mcq_solve_host_pipelined (uploads / kernels / downloads of consecutive batches overlapped on three streams, two staging
     slots): every step's results are bitwise those of the blocking entry on the same buffers -- five steps, so both slots are
