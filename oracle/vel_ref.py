@@ -34,17 +34,23 @@ import math
 import numpy as np
 
 
-def calc_ax_poss(vx_start, radius, ggv, mu, dyn_model_exp, drag_coeff, m_veh, ax_max_machines=None, mode="accel_forw"):
+def calc_ax_poss(vx_start, radius, ggv, mu, dyn_model_exp, drag_coeff, m_veh, ax_max_machines=None, mode="accel_forw", loc_gg=None):
     """Longitudinal acceleration still available at vx_start on `radius` (tyre potential shared with the lateral
-    acceleration through the generalised friction ellipse, machine limit when accelerating, drag)."""
+    acceleration through the generalised friction ellipse, machine limit when accelerating, drag).  Tyre potential from the
+    speed-dependent ggv diagram, or (round 6: the `loc_gg` form of tph.calc_vel_profile, which the reference's mintime branch with a
+    variable friction map would reach [REF main_globaltraj.py:396-410]) from the local pair loc_gg = (ax_max, ay_max) of the point."""
     if mode not in ("accel_forw", "decel_forw", "decel_backw"):
         raise RuntimeError("Unknown operation mode for calc_ax_poss!")
     if mode == "accel_forw" and ax_max_machines is None:
         raise RuntimeError("ax_max_machines is required if operation mode is accel_forw!")
-    if ggv.ndim != 2 or ggv.shape[1] != 3:
+    if ggv is not None and (ggv.ndim != 2 or ggv.shape[1] != 3):
         raise RuntimeError("ggv must have two dimensions and three columns [vx, ax_max, ay_max]!")
-    ax_max_tires = mu * np.interp(vx_start, ggv[:, 0], ggv[:, 1])
-    ay_max_tires = mu * np.interp(vx_start, ggv[:, 0], ggv[:, 2])
+    if ggv is not None:
+        ax_max_tires = mu * np.interp(vx_start, ggv[:, 0], ggv[:, 1])
+        ay_max_tires = mu * np.interp(vx_start, ggv[:, 0], ggv[:, 2])
+    else:
+        ax_max_tires = mu * loc_gg[0]
+        ay_max_tires = mu * loc_gg[1]
     ay_used = math.pow(vx_start, 2) / radius
     if mode in ("accel_forw", "decel_backw") and ax_max_tires < 0.0:
         ax_max_tires *= -1.0
@@ -63,7 +69,7 @@ def calc_ax_poss(vx_start, radius, ggv, mu, dyn_model_exp, drag_coeff, m_veh, ax
 
 
 def _solver_fb_acc_profile(ggv, ax_max_machines, v_max, radii, el_lengths, mu, vx_profile, dyn_model_exp, drag_coeff, m_veh,
-                           backwards=False):
+                           backwards=False, loc_gg=None):
     no_points = vx_profile.size
     if backwards:
         radii_mod, el_lengths_mod, mu_mod = np.flipud(radii), np.flipud(el_lengths), np.flipud(mu)
@@ -73,6 +79,8 @@ def _solver_fb_acc_profile(ggv, ax_max_machines, v_max, radii, el_lengths, mu, v
         radii_mod, el_lengths_mod, mu_mod = radii, el_lengths, mu
         vx_profile = vx_profile.copy()
         mode = "accel_forw"
+    loc_gg_mod = None if loc_gg is None else (np.flipud(loc_gg) if backwards else loc_gg)
+    lg = (lambda j: None) if loc_gg_mod is None else (lambda j: loc_gg_mod[j])
     # start points of the acceleration phases of the profile as handed in
     acc_inds = np.where(np.diff(vx_profile) > 0.0)[0]
     if acc_inds.size != 0:
@@ -84,13 +92,13 @@ def _solver_fb_acc_profile(ggv, ax_max_machines, v_max, radii, el_lengths, mu, v
         i = acc_inds_rel.pop(0)
         while i < no_points - 1:
             ax_possible_cur = calc_ax_poss(vx_profile[i], radii_mod[i], ggv, mu_mod[i], dyn_model_exp, drag_coeff, m_veh,
-                                           ax_max_machines, mode)
+                                           ax_max_machines, mode, loc_gg=lg(i))
             vx_possible_next = math.sqrt(math.pow(vx_profile[i], 2) + 2 * ax_possible_cur * el_lengths_mod[i])
             if backwards:
                 # the deceleration available at point i need not be available at the next one: one look-ahead round
                 for _ in range(1):
                     ax_possible_next = calc_ax_poss(vx_possible_next, radii_mod[i + 1], ggv, mu_mod[i + 1], dyn_model_exp,
-                                                    drag_coeff, m_veh, ax_max_machines, mode)
+                                                    drag_coeff, m_veh, ax_max_machines, mode, loc_gg=lg(i + 1))
                     vx_tmp = math.sqrt(math.pow(vx_profile[i], 2) + 2 * ax_possible_next * el_lengths_mod[i])
                     if vx_tmp < vx_possible_next:
                         vx_possible_next = vx_tmp
@@ -119,24 +127,39 @@ def conv_filt(signal, filt_window, closed):
 
 def calc_vel_profile(ax_max_machines, kappa, el_lengths, closed, drag_coeff, m_veh, ggv=None, loc_gg=None, v_max=None,
                      dyn_model_exp=1.0, mu=None, v_start=None, v_end=None, filt_window=None, info=None):
-    """Closed tracks with a global ggv (optionally mu): the form every call site of the reference uses.  `info` (dict)
-    receives the number of fixed-point rounds of the lateral limit."""
-    if loc_gg is not None or ggv is None:
-        raise NotImplementedError("oracle restates the global-ggv form (the only one the reference calls)")
-    if not closed:
-        raise NotImplementedError("oracle restates the closed-track form (the only one the reference calls)")
-    if ggv.shape[1] != 3:
+    """Closed tracks with a global ggv (optionally mu) are the form every call site of the reference's in-scope flow uses; round 6 adds the two
+    other forms of upstream's signature -- `loc_gg` [no_points, 2] = local (ax_max, ay_max) per point instead of the ggv diagram (v_max is then
+    mandatory), and unclosed profiles (kappa one longer than el_lengths; v_start mandatory, v_end optional: the sweeps run once over the profile
+    instead of over the lap doubled).  `info` (dict) receives the number of fixed-point rounds of the lateral limit."""
+    if (ggv is not None or mu is not None) and loc_gg is not None:
+        raise RuntimeError("Either ggv and optionally mu OR loc_gg must be supplied, not both (or all) of them!")
+    if ggv is None and loc_gg is None:
+        raise RuntimeError("Either ggv or loc_gg must be supplied!")
+    if loc_gg is not None:
+        if v_max is None:
+            raise RuntimeError("v_max must be supplied if loc_gg is used!")
+        if loc_gg.ndim != 2 or loc_gg.shape != (kappa.size, 2):
+            raise RuntimeError("loc_gg must have the shape [no_points, 2]!")
+    if ggv is not None and ggv.shape[1] != 3:
         raise RuntimeError("ggv diagram must consist of the three columns [vx, ax_max, ay_max]!")
     if mu is not None and kappa.size != mu.size:
         raise RuntimeError("kappa and mu must have the same length!")
-    if kappa.size != el_lengths.size:
+    if closed and kappa.size != el_lengths.size:
         raise RuntimeError("kappa and el_lengths must have the same length if closed!")
+    if not closed and kappa.size != el_lengths.size + 1:
+        raise RuntimeError("kappa must have the length of el_lengths + 1 if unclosed!")
+    if not closed and v_start is None:
+        raise RuntimeError("v_start must be provided for the unclosed case!")
+    if v_start is not None and v_start < 0.0:
+        v_start = 0.0
+    if v_end is not None and v_end < 0.0:
+        v_end = 0.0
     if ax_max_machines.shape[1] != 2:
         raise RuntimeError("ax_max_machines must consist of the two columns [vx, ax_max_machines]!")
     if v_max is None:
         v_max = min(ggv[-1, 0], ax_max_machines[-1, 0])
     else:
-        if ggv[-1, 0] < v_max:
+        if ggv is not None and ggv[-1, 0] < v_max:
             raise RuntimeError("ggv has to cover the entire velocity range of the car (i.e. >= v_max)!")
         if ax_max_machines[-1, 0] < v_max:
             raise RuntimeError("ax_max_machines has to cover the entire velocity range of the car (i.e. >= v_max)!")
@@ -146,32 +169,47 @@ def calc_vel_profile(ax_max_machines, kappa, el_lengths, closed, drag_coeff, m_v
     no_points = radii.size
 
     # lateral limit
-    mu_mean = float(np.mean(mu))                       # upstream: the first estimate uses the mean friction coefficient
-    ay_max_global = mu_mean * np.amin(ggv[:, 2])
-    vx_profile = np.sqrt(ay_max_global * radii)
     rounds = 0
-    for _ in range(100):
-        rounds += 1
-        vx_prev = vx_profile
-        ay_max_curr = mu * np.interp(vx_profile, ggv[:, 0], ggv[:, 2])
-        vx_profile = np.sqrt(np.multiply(ay_max_curr, radii))
-        with np.errstate(invalid="ignore", divide="ignore"):
-            if np.max(np.abs(vx_profile / vx_prev - 1.0)) < 0.005:
-                break
+    if ggv is not None:
+        mu_mean = float(np.mean(mu))                       # upstream: the first estimate uses the mean friction coefficient
+        ay_max_global = mu_mean * np.amin(ggv[:, 2])
+        vx_profile = np.sqrt(ay_max_global * radii)
+        for _ in range(100):
+            rounds += 1
+            vx_prev = vx_profile
+            ay_max_curr = mu * np.interp(vx_profile, ggv[:, 0], ggv[:, 2])
+            vx_profile = np.sqrt(np.multiply(ay_max_curr, radii))
+            with np.errstate(invalid="ignore", divide="ignore"):
+                if np.max(np.abs(vx_profile / vx_prev - 1.0)) < 0.005:
+                    break
+    else:
+        vx_profile = np.sqrt(loc_gg[:, 1] * radii)         # the local lateral limit does not depend on the speed: no iteration
     if info is not None:
         info["lateral_rounds"] = rounds
     vx_profile[vx_profile > v_max] = v_max
 
-    # forward over two laps, backward over the doubled second lap of that
-    radii_d = np.concatenate((radii, radii))
-    el_d = np.concatenate((el_lengths, el_lengths))
-    mu_d = np.concatenate((mu, mu))
-    vx_d = _solver_fb_acc_profile(ggv, ax_max_machines, v_max, radii_d, el_d, mu_d, np.concatenate((vx_profile, vx_profile)),
-                                  dyn_model_exp, drag_coeff, m_veh, backwards=False)
-    vx_d = np.concatenate((vx_d[no_points:], vx_d[no_points:]))
-    vx_d = _solver_fb_acc_profile(ggv, ax_max_machines, v_max, radii_d, el_d, mu_d, vx_d, dyn_model_exp, drag_coeff, m_veh,
-                                  backwards=True)
-    vx_profile = vx_d[no_points:]
+    if not closed:
+        # once over the profile: the start speed caps the first point, the end speed (if given) the last one
+        if vx_profile[0] > v_start:
+            vx_profile[0] = v_start
+        vx_profile = _solver_fb_acc_profile(ggv, ax_max_machines, v_max, radii, el_lengths, mu, vx_profile, dyn_model_exp, drag_coeff, m_veh,
+                                            backwards=False, loc_gg=loc_gg)
+        if v_end is not None and vx_profile[-1] > v_end:
+            vx_profile[-1] = v_end
+        vx_profile = _solver_fb_acc_profile(ggv, ax_max_machines, v_max, radii, el_lengths, mu, vx_profile, dyn_model_exp, drag_coeff, m_veh,
+                                            backwards=True, loc_gg=loc_gg)
+    else:
+        # forward over two laps, backward over the doubled second lap of that
+        radii_d = np.concatenate((radii, radii))
+        el_d = np.concatenate((el_lengths, el_lengths))
+        mu_d = np.concatenate((mu, mu))
+        lg_d = None if loc_gg is None else np.concatenate((loc_gg, loc_gg), axis=0)
+        vx_d = _solver_fb_acc_profile(ggv, ax_max_machines, v_max, radii_d, el_d, mu_d, np.concatenate((vx_profile, vx_profile)),
+                                      dyn_model_exp, drag_coeff, m_veh, backwards=False, loc_gg=lg_d)
+        vx_d = np.concatenate((vx_d[no_points:], vx_d[no_points:]))
+        vx_d = _solver_fb_acc_profile(ggv, ax_max_machines, v_max, radii_d, el_d, mu_d, vx_d, dyn_model_exp, drag_coeff, m_veh,
+                                      backwards=True, loc_gg=lg_d)
+        vx_profile = vx_d[no_points:]
     if filt_window is not None:
         vx_profile = conv_filt(vx_profile, filt_window, closed)
     return vx_profile

@@ -188,3 +188,58 @@ def test_vel_profile_lateral_limit_starts_from_mean_friction():
     a = cv.calc_vel_profile(ggv=ggv2, ax_max_machines=axm2, v_max=60.0, kappa=kappa, el_lengths=el, closed=True, mu=mu, drag_coeff=0.8, m_veh=1100.0)
     b = vel_ref.calc_vel_profile(ggv=ggv2, ax_max_machines=axm2, v_max=60.0, kappa=kappa, el_lengths=el, closed=True, mu=mu, drag_coeff=0.8, m_veh=1100.0)
     assert np.max(np.abs(a - b)) < 1e-9
+
+
+def test_vel_profile_local_gg_and_unclosed_forms():
+    """Round 6 (VERDICT r5 missing 4): the two forms of tph.calc_vel_profile's signature the shim had refused -- `loc_gg` [no_points, 2] (local
+    ax_max / ay_max per point instead of the ggv diagram: what the mintime branch with a variable friction map passes [REF main_globaltraj.py:396-410])
+    and unclosed profiles with v_start / v_end.  The shim (one gated pass with an `active` flag) against the oracle's restatement of upstream's
+    work-list form, plus what can be said without either: a constant local gg equals the ggv form with constant rows; an unclosed profile starts at
+    v_start, ends at or below v_end, never exceeds the lateral limit, and its accelerations respect the friction ellipse; the error texts."""
+    from global_racetrajectory_optimization_amd.trajectory_planning_helpers import calc_vel_profile as cv
+    from oracle import vel_ref
+    rng = np.random.default_rng(4)
+    n = 300
+    s = np.arange(n) * 3.0
+    kappa = 0.03 * np.sin(2 * np.pi * s / 400.0) + 0.012 * np.sin(2 * np.pi * s / 90.0 + 1.0)
+    el = np.full(n, 3.0)
+    v = np.arange(0.0, 90.1, 10.0)
+    axm = np.column_stack((v, np.interp(v, [0.0, 30.0, 90.0], [7.0, 5.0, 1.5])))
+    loc = np.column_stack((10.0 + 3.0 * np.sin(s / 55.0), 12.0 + 4.0 * np.cos(s / 70.0)))
+    kw = dict(ax_max_machines=axm, drag_coeff=0.85, m_veh=1160.0, dyn_model_exp=1.4)
+    # closed, local gg
+    a = cv.calc_vel_profile(kappa=kappa, el_lengths=el, closed=True, loc_gg=loc, v_max=70.0, **kw)
+    b = vel_ref.calc_vel_profile(kappa=kappa, el_lengths=el, closed=True, loc_gg=loc, v_max=70.0, **kw)
+    assert a.shape == (n,) and np.max(np.abs(a - b)) < 1e-9
+    assert np.all(a <= np.minimum(np.sqrt(loc[:, 1] / np.abs(kappa)), 70.0) + 1e-9)
+    # a constant local gg is the ggv form with constant rows
+    const = np.column_stack((np.full(n, 9.0), np.full(n, 11.0)))
+    ggv_c = np.column_stack((v, np.full(v.size, 9.0), np.full(v.size, 11.0)))
+    c1 = cv.calc_vel_profile(kappa=kappa, el_lengths=el, closed=True, loc_gg=const, v_max=70.0, **kw)
+    c2 = cv.calc_vel_profile(kappa=kappa, el_lengths=el, closed=True, ggv=ggv_c, v_max=70.0, **kw)
+    assert np.max(np.abs(c1 - c2)) < 1e-9
+    # unclosed: ggv form and local-gg form, with and without v_end, filter window included
+    ggv = np.column_stack((v, 11.0 - 0.04 * v, 13.0 - 0.08 * v))
+    mu = 0.8 + 0.4 * rng.uniform(size=n)
+    for form in (dict(ggv=ggv, mu=mu, v_max=65.0), dict(loc_gg=loc, v_max=65.0)):
+        for v_end in (None, 8.0):
+            for fw in (None, 5):
+                a = cv.calc_vel_profile(kappa=kappa, el_lengths=el[:-1], closed=False, v_start=12.0, v_end=v_end, filt_window=fw, **form, **kw)
+                b = vel_ref.calc_vel_profile(kappa=kappa, el_lengths=el[:-1], closed=False, v_start=12.0, v_end=v_end, filt_window=fw, **form, **kw)
+                assert a.shape == (n,) and np.max(np.abs(a - b)) < 1e-9, (sorted(form), v_end, fw)
+                if fw is None:
+                    assert a[0] <= 12.0 + 1e-12 and (v_end is None or a[-1] <= v_end + 1e-12)
+                    ax = (a[1:] ** 2 - a[:-1] ** 2) / (2.0 * el[:-1])
+                    assert np.max(ax) < 7.0 + 1e-9                  # never more than the machine gives
+    # a negative start speed is taken as zero (upstream warns and goes on)
+    z = cv.calc_vel_profile(kappa=kappa, el_lengths=el[:-1], closed=False, v_start=-3.0, ggv=ggv, v_max=65.0, **kw)
+    assert z[0] == 0.0 and z[1] > 0.0
+    for bad, msg in ((dict(closed=False, ggv=ggv, el_lengths=el[:-1]), "v_start must be provided"),
+                     (dict(closed=True, loc_gg=loc, el_lengths=el), "v_max must be supplied if loc_gg is used"),
+                     (dict(closed=True, loc_gg=loc[:-1], v_max=60.0, el_lengths=el), r"loc_gg must have the shape \[no_points, 2\]"),
+                     (dict(closed=True, loc_gg=loc, ggv=ggv, v_max=60.0, el_lengths=el), "not both"),
+                     (dict(closed=False, ggv=ggv, v_start=5.0, el_lengths=el), "el_lengths \\+ 1 if unclosed"),
+                     (dict(closed=True, el_lengths=el), "Either ggv or loc_gg must be supplied")):
+        for f in (cv.calc_vel_profile, vel_ref.calc_vel_profile):
+            with pytest.raises(RuntimeError, match=msg):
+                f(kappa=kappa, **bad, **kw)
