@@ -1476,6 +1476,9 @@ __device__ __noinline__ int active_set(const LCtx& c, bool with_kappa, bool tapi
         else if (pcnt > 0) { --pcnt; full = true; }
         else if (with_kappa) return MCQ_ITER_CAP;
         else full = false;
+        // (round 6, tried: a warm-started exchange that is down to <= 3 / 6 / 12 violated rows after five rounds goes row by row from there -- the
+        //  third IQP pass of the bench workload then falls back to the cold path 41 / 178 / 328 times instead of 15: full exchanges with the
+        //  one-row-per-neighbourhood rule are what settles these, single pivots wander longer.  docs/NOTEBOOK.md R6.5)
         // (The single-pivot backup rule terminates on box rows alone -- the linear complementarity problem of a positive definite Hessian
         //  with simple bounds -- and is kept for them.  With curvature rows in the exchange nothing promises that, and a round costs one
         //  solve per curvature row: of the 220 curvature-tight problems of tests/golden/kappa_tight_fuzz.npz every exchange that ends
