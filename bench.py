@@ -704,8 +704,8 @@ def main():
                                            "this rate can exceed `value`, measured launch by launch on one stream" % hs,
                                    "ratio_to_device_resident": (B * hs / t_pipe) / value,
                                    "blocking_single_batch": {"value": B / float(np.mean(hh)), "ms_per_step": 1e3 * float(np.mean(hh)),
-                                                             "what": "mcq_solve_host, ONE batch, blocking; round 6: in four slices -- upload k + 1 / kernel k / "
-                                                                     "download k - 1 overlapped, consecutive slices' kernels on the two compute streams; %d calls" % len(hh),
+                                                             "what": "mcq_solve_host, ONE batch, blocking; round 6: in two slices, one per compute stream -- upload k + 1 / kernel k / "
+                                                                     "download k - 1 overlapped; %d calls" % len(hh),
                                                              "as_one_launch": {"value": B / float(np.mean(hh1)), "ms_per_step": 1e3 * float(np.mean(hh1)),
                                                                                "what": "$MCQ_HOST_ONE_LAUNCH=1: H2D -> one launch -> D2H (rounds 1-5)"},
                                                              "alpha_equal_between_the_two": blocking_equal},

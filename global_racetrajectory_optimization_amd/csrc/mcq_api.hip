@@ -102,7 +102,7 @@ struct mcq_handle {
     // mcq_solve_host_pipelined: two copy streams, the second set of staging buffers, one event triple per slot
     hipStream_t cs_in = nullptr, cs_out = nullptr;
     hipEvent_t ev_up[2] = {nullptr, nullptr}, ev_done[2] = {nullptr, nullptr}, ev_down[2] = {nullptr, nullptr};
-    hipEvent_t ev_slice[16] = {};      // mcq_solve_host in slices: upload / kernel done, per slice
+    hipEvent_t ev_slice[16] = {};      // mcq_solve_host / mcq_solve_batch in slices: upload / kernel done, per slice
     double *p_ref = nullptr, *p_nv = nullptr, *p_sc = nullptr, *p_alpha = nullptr, *p_curv = nullptr;
     int* p_status = nullptr;
     size_t pipe_elems = 0, pipe_batch = 0;
@@ -1090,10 +1090,18 @@ static int host_slices(int batch, const mcq_opts& o)
 {
     int slice_min = 512;           // ($MCQ_HOST_SLICE_MIN: the tests slice a batch of eleven)
     if (const char* e = getenv("MCQ_HOST_SLICE_MIN")) slice_min = std::max(atoi(e), 4);
-    int nsl = 4;                   // ($MCQ_HOST_SLICES: 2 .. 8; 4 measured best on 1024 x N = 2000, docs/NOTEBOOK.md R6.5)
+    // TWO slices, one per compute stream: both are in flight as soon as their uploads are, so a batch with a heavy tail -- a sweep over tight
+    // curvature bounds, where single problems take seconds in the Goldfarb-Idnani path -- loses nothing against the one launch.  Four slices
+    // gain 0.3 ms more on uniform batches (11.5 against 11.8 ms for 1024 x N = 2000; one launch: 13.0) but make slice k + 2 wait for the slowest
+    // problem of slice k on its stream: 600 curvature-tight long rings then take 76 s instead of 45 (docs/NOTEBOOK.md R6.5).  $MCQ_HOST_SLICES: 2 .. 8
+    int nsl = 2;
     if (const char* e = getenv("MCQ_HOST_SLICES")) nsl = std::min(std::max(atoi(e), 2), 8);
     return (batch >= slice_min && o.objective == MCQ_OBJ_MIN_CURV && o.algorithm != MCQ_ALG_GI && !getenv("MCQ_HOST_ONE_LAUNCH")) ? nsl : 1;
 }
+// the compute stream of slice k: the handle's two, in turn.  (Tried, round 6: a stream per slice -- 14.0 ms where two streams give 11.5 for four
+// slices of 256 problems, and the 600 curvature-tight long rings 105 s where the one launch takes 45: more than two queues of large workgroups
+// cost more in the hardware scheduler than they overlap.)
+static hipStream_t slice_stream(mcq_handle* h, int k) { return (k & 1) ? h->stream2 : h->stream; }
 static int ensure_slice_streams(mcq_handle* h)
 {
     if (!h->cs_in) { HIP_TRY(hipStreamCreate(&h->cs_in)); HIP_TRY(hipStreamCreate(&h->cs_out)); }
@@ -1150,10 +1158,9 @@ extern "C" int mcq_solve_host(mcq_handle* h, int batch, int n, const double* ref
     B.info = info_out ? h->d_info : nullptr;
     B.kappa_bound = kappa_bound;
     B.w_veh = w_veh;
-    // A large batch in SLICES (round 6): the upload of slice k + 1 and the download of slice k - 1 run while slice k's kernel does -- on a copy
-    // stream each way --, and the kernels of consecutive slices go to the handle's two compute streams, so that a slice's tail (its slowest
-    // problems, on compute units the others have left) is filled by the next slice's workgroups; all of them work on disjoint rows of the ONE
-    // workspace (McqBatch.pb0).  The blocking single-batch entry had paid its 115 MB of H2D and 16 MB of D2H in full next to the kernel: 13.3 ms
+    // A large batch in (two) SLICES (round 6): the upload of slice k + 1 and the download of slice k - 1 run while slice k's kernel does -- on a
+    // copy stream each way --, and the kernels of consecutive slices go to the handle's two compute streams; all of them work on disjoint rows of
+    // the ONE workspace (McqBatch.pb0).  The blocking single-batch entry had paid its 115 MB of H2D and 16 MB of D2H in full next to the kernel: 13.3 ms
     // for a 10.4 ms kernel at 1024 x N = 2000.  Results bitwise those of the one launch: the problems are independent.  $MCQ_HOST_ONE_LAUNCH=1:
     // the one launch (A/B knob).
     const int nsl = host_slices(batch, o);
@@ -1170,7 +1177,7 @@ extern "C" int mcq_solve_host(mcq_handle* h, int batch, int n, const double* ref
             if (normvec) HIP_TRY_SLICE(hipMemcpyAsync(h->d_nv + off * 2, normvec + off * 2, cnt * 2 * sizeof(double), hipMemcpyHostToDevice, h->cs_in));
             if (scaling) HIP_TRY_SLICE(hipMemcpyAsync(h->d_sc + off, scaling + off, cnt * sizeof(double), hipMemcpyHostToDevice, h->cs_in));
             HIP_TRY_SLICE(hipEventRecord(h->ev_slice[k], h->cs_in));
-            hipStream_t st = (k & 1) ? h->stream2 : h->stream;
+            hipStream_t st = slice_stream(h, k);
             HIP_TRY_SLICE(hipStreamWaitEvent(st, h->ev_slice[k], 0));
             McqBatch S = B;
             S.pb0 = b0;
@@ -1756,7 +1763,7 @@ extern "C" int mcq_solve_batch(mcq_handle* h, const mcq_problem* probs, int batc
         rc = pack_and_upload(h, probs, batch, nmax, any_sc, probs[0].normvec != nullptr, 0, P, "mcq_solve_batch", nsl,
                              [&](int k, int b0, int b1) -> int {
                                  HIP_TRY_SLICE(hipEventRecord(h->ev_slice[k], h->cs_in));
-                                 hipStream_t st = (k & 1) ? h->stream2 : h->stream;
+                                 hipStream_t st = slice_stream(h, k);
                                  HIP_TRY_SLICE(hipStreamWaitEvent(st, h->ev_slice[k], 0));
                                  McqBatch S = B;
                                  S.pb0 = b0;

@@ -291,8 +291,9 @@ int mcq_raceline_device(mcq_handle* h, int batch, int nmax, const int* n_in, con
  * caller's buffers -- no packing pass; buffers from mcq_host_alloc (pinned) are copied at PCIe speed, pageable ones go through
  * the runtime's staging.  This is the wall SURVEY.md section 8d defines the metric on ("inputs resident in host pinned memory
  * -> alpha resident in host memory"); bench.py reports it next to the device-resident rate.  Blocking.  Round 6: a batch of 512 or more
- * (minimum-curvature objective, default algorithm) goes in four SLICES -- the upload of slice k + 1 and the download of slice k - 1 overlap slice
- * k's kernel, consecutive slices' kernels run on the handle's two compute streams (11.6 ms where the one launch took 13.0 for 1024 x N = 2000);
+ * (minimum-curvature objective, default algorithm) goes in two SLICES, one per compute stream of the handle -- the second slice's upload and the
+ * first slice's download overlap the kernels (11.8 ms where the one launch took 13.0 for 1024 x N = 2000; four slices: 11.5, but then a heavy-tailed
+ * batch waits for its slowest problems slice by slice);
  * results bitwise those of the one launch; mcq_last_timing is not valid after such a call.  mcq_solve_batch does the same behind its packing
  * threads.  Knobs (environment): MCQ_HOST_ONE_LAUNCH=1, MCQ_HOST_SLICES (2 .. 8), MCQ_HOST_SLICE_MIN. */
 int mcq_solve_host(mcq_handle* h, int batch, int n, const double* reftrack, const double* normvec, const double* scaling,

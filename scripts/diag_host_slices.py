@@ -9,8 +9,8 @@ eng = engine.Engine(0)
 p_ref, p_nv, p_sc, p_al = eng.host_array((B, n, 4)), eng.host_array((B, n, 2)), eng.host_array((B, n)), eng.host_array((B, n))
 p_ref[...], p_nv[...], p_sc[...] = ref, nv, sc
 base = None
-for mode in ("one", "2", "4", "8", "one", "4"):
-    os.environ.pop("MCQ_HOST_ONE_LAUNCH", None); os.environ.pop("MCQ_HOST_SLICES", None)
+for mode in ("one", "2", "4", "8", "one", "2"):
+    os.environ.pop("MCQ_HOST_ONE_LAUNCH", None); os.environ.pop("MCQ_HOST_SLICES", None); 
     if mode == "one": os.environ["MCQ_HOST_ONE_LAUNCH"] = "1"
     else: os.environ["MCQ_HOST_SLICES"] = mode
     eng.solve_host(p_ref, p_nv, p_sc, 0.12, 3.4, alpha_out=p_al)

@@ -725,10 +725,11 @@ def test_fp32_increment_rows_keep_the_accuracy(emu, golden):
 
 
 def test_solve_host_in_slices_is_bitwise_the_one_launch(emu, monkeypatch):
-    """Round 6: mcq_solve_host takes a batch of 512 or more (here: $MCQ_HOST_SLICE_MIN = 8) in four SLICES -- upload k + 1 / kernel k / download k - 1 overlapped, the kernels of
+    """Round 6: mcq_solve_host takes a batch of 512 or more (here: $MCQ_HOST_SLICE_MIN = 8) in SLICES (two by default, four here) -- upload k + 1 / kernel k / download k - 1 overlapped, the kernels of
     consecutive slices on the handle's two compute streams, all on disjoint rows of one workspace (McqBatch.pb0) -- and must return what the one
     launch ($MCQ_HOST_ONE_LAUNCH=1) returns, bit for bit, info records included; a narrow corridor in slice 2 keeps its status."""
     monkeypatch.setenv("MCQ_HOST_SLICE_MIN", "8")
+    monkeypatch.setenv("MCQ_HOST_SLICES", "4")          # (the default is two; four exercises a stream's second slice)
     n, bsz = 24, 11                         # (not a multiple of four: the slices differ in size)
     base = [_small_track(n, seed=300 + k) for k in range(5)]
     rng = np.random.default_rng(9)
