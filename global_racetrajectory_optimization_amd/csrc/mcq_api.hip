@@ -80,7 +80,7 @@ struct mcq_handle {
     unsigned comm_seq = 0;              // gathers enqueued so far (event ring index)
     size_t vel_scratch_bytes = 0;
     double* kbig = nullptr;             // overflow slots of the curvature-row working set (MCQ_KBIG_SLOTS x MCQ_KBIG_SLOT doubles)
-    int* slot_flags = nullptr;          // [MCQ_KBIG_SLOTS + MCQ_GI_SLOTS_MAX]: 0 free / 1 taken, claimed and released by the workgroups (never reset by the host)
+    int* slot_flags = nullptr;          // [MCQ_SLOT_FLAGS] = overflow slots | full Goldfarb-Idnani slots | small ones: 0 free / 1 taken, claimed and released by the workgroups (never reset by the host)
     double* gi = nullptr;               // FULL slots of the Goldfarb-Idnani path (mcq_gi.inc): gi_slots x MCQ_GI_SLOT_DOUBLES(gi_nmax, gi_nmax)
     int gi_slots = 0, gi_nmax = 0;
     long long gi_bytes = 0;
@@ -257,8 +257,8 @@ extern "C" void mcq_destroy(mcq_handle* h)
 //                  rings that long.
 //   SMALL slots -- round 6, mcq_opts.algorithm = MCQ_ALG_GI (every problem takes the path: one slot per resident workgroup): working sets of up to
 //                  gi_small_qcap(nmax) = nmax / 8 constraints (rounded up to 64, at least 128), what the path's working sets measure on every workload
-//                  here (62 .. 90 active rows at nmax = 2000, 130 adds at most); 4.6 MB at nmax = 2000, 2.4 GB for 512 of them (round 5: full slots,
-//                  34.7 GB).  A problem that outgrows its small slot starts again in a full one (gi_rescue).
+//                  here (62 .. 100 active rows at nmax = 2000); 4.6 MB at nmax = 2000, 2.4 GB for 512 of them (round 5: full slots,
+//                  33 GB).  A problem that outgrows its small slot moves into a full one in place (gi_grow, mcq_gi.inc).
 static size_t gi_small_qcap(size_t nmax)
 {
     const size_t q = std::max<size_t>(128, ((nmax / 8 + 63) / 64) * 64);

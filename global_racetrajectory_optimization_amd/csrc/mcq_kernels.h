@@ -97,7 +97,7 @@ struct McqBatch {
     const signed char* warm; // [batch][nmax] working set to start the exchange from (IQP passes 2+), or nullptr (cold: interior point)
     int poison_lds;         // MCQ_POISON=1 (debugging aid): the solver kernel starts from an LDS full of NaNs, like the workspaces
     double* kbig;           // overflow slots of the curvature-row working set (MCQ_KBIG_SLOT doubles each), kbig_slots of them;
-    int* slot_flags;        // [kbig_slots + gi_slots] 0 = free, 1 = taken: a workgroup claims a slot by compare-and-swap and releases it when it is
+    int* slot_flags;        // [MCQ_SLOT_FLAGS: MCQ_KBIG_SLOTS overflow slots, MCQ_GI_FULL_MAX full, MCQ_GI_SLOTS_MAX small Goldfarb-Idnani slots] 0 = free, 1 = taken: a workgroup claims a slot by compare-and-swap and releases it when it is
                             // done (zero whenever no launch is in flight: nothing for the host to reset between launches)
     int kbig_slots;
     int objective;          // MCQ_OBJ_*: shortest path = H (a cyclic tridiagonal: two vectors) and f written directly by

@@ -164,7 +164,7 @@ def test_slot_pools_small_full_and_none(emu, emu_lib, monkeypatch):
 
 
 def test_a_slice_of_the_curvature_tight_fuzz_on_the_interpreter(emu):
-    """Every twelfth problem of tests/golden/kappa_tight_fuzz.npz (16 of the 220: stadium plateaus, star-shaped rings, the reference's tracks with
+    """Every twelfth problem of tests/golden/kappa_tight_fuzz.npz (13 of the 220: stadium plateaus, star-shaped rings, the reference's tracks with
     the curvature bound drawn between 0.6 x and 1.0 x the box optimum's curvature maximum; some INCONSISTENT) through the unchanged kernel sources
     on the CPU in one ragged launch, and three of those through the Goldfarb-Idnani path alone: the dense Goldfarb-Idnani's verdict
     and vertex from both.  Problem 18 is one of those whose block-pivoting phase starts to cycle: it must hand over to the Goldfarb-Idnani path
@@ -172,7 +172,8 @@ def test_a_slice_of_the_curvature_tight_fuzz_on_the_interpreter(emu):
     import os
     z = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "kappa_tight_fuzz.npz"))
     off = z["offsets"]
-    sl = [k for k in range(6, len(off) - 1, 12) if k not in (42, 78)]          # (two of the three inconsistent ones left to the GPU suite: 7 and 11 s here)
+    sl = [k for k in range(6, len(off) - 1, 12) if k not in (42, 78, 102, 150, 198)]      # (two of the three inconsistent ones left to the GPU suite: 7 and 11 s
+                                                                                          #  here; three more dropped in round 6: the serial suite's minutes)
     for alg, ks in ((engine.ALG_DEFAULT, sl), (engine.ALG_GI, [30, 66, 138])):
         probs = [dict(reftrack=z["reftrack"][off[k]:off[k + 1]], normvec=z["normvec"][off[k]:off[k + 1]], scaling=z["scaling"][off[k]:off[k + 1]],
                       kappa_bound=float(z["kappa_bound"][k]), w_veh=float(z["w_veh"][k])) for k in ks]
