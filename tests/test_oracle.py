@@ -122,6 +122,68 @@ def test_gi_dense_reproduces_the_example_of_quadprogs_own_documentation():
     assert np.max(np.abs(x - np.array([0.0, 1.0, 0.0]))) < 1e-15 and sorted(iact) == [0, 1]
 
 
+def test_gi_dense_against_brute_force_on_tiny_random_qps():
+    """The restated qpgen2 against an enumeration of active sets on 400 tiny strictly convex QPs (n <= 4, up to 7 inequality rows, some with an
+    equality, about a third infeasible): where a KKT point exists the solver returns it (x to 1e-9, multipliers non-negative and complementary, the
+    criterion value quadprog's tuple carries), where none does it reports "constraints are inconsistent" -- adds, drops, partial steps and the
+    z = 0 branch all occur at these sizes (iters[1] > 0 in a good part of them)."""
+    import itertools
+    rng = np.random.default_rng(11)
+    n_sol = n_inf = n_drop = 0
+    for trial in range(400):
+        n = int(rng.integers(2, 5))
+        m = int(rng.integers(1, 8))
+        meq = int(rng.integers(0, 2)) if m >= 2 else 0
+        Mx = rng.standard_normal((n, n))
+        Gm = Mx @ Mx.T + 0.1 * np.eye(n)
+        a = rng.standard_normal(n) * 2.0
+        C = rng.standard_normal((n, m))
+        b = rng.standard_normal(m) * (1.5 if trial % 3 == 0 else 0.5)
+        if trial % 7 == 0 and m >= 2:                       # an opposite pair that cannot both hold: C_1 = -C_0, b_0 + b_1 > 0
+            C[:, 1] = -C[:, 0]
+            b[0], b[1] = 0.5, 0.2
+        # brute force: every subset of inequality rows held as equalities (with the meq equality rows), KKT conditions checked
+        best = None
+        ineq = list(range(meq, m))
+        for r in range(0, min(len(ineq), n - meq) + 1):
+            for act in itertools.combinations(ineq, r):
+                rows = list(range(meq)) + list(act)
+                k = len(rows)
+                if k > n:
+                    continue
+                Ca = C[:, rows]
+                K = np.block([[Gm, -Ca], [Ca.T, np.zeros((k, k))]]) if k else Gm
+                rhs = np.concatenate((a, b[rows])) if k else a
+                try:
+                    sol = np.linalg.solve(K, rhs)
+                except np.linalg.LinAlgError:
+                    continue
+                x, lam = sol[:n], sol[n:]
+                if k and np.linalg.cond(K) > 1e10:
+                    continue
+                if np.all(C.T @ x - b >= -1e-9) and np.all(lam[meq:] >= -1e-9) and (meq == 0 or np.all(np.abs(C[:, :meq].T @ x - b[:meq]) < 1e-9)):
+                    f = 0.5 * x @ Gm @ x - a @ x
+                    if best is None or f < best[1] - 1e-12:
+                        best = (x, f)
+        try:
+            x, fval, lagr, iact, iters = qp_ref.solve_qp_quadprog_convention(Gm, a, C, b, meq=meq)
+        except ValueError as e:
+            assert "inconsistent" in str(e)
+            assert best is None, (trial, "the solver says inconsistent, enumeration found a KKT point")
+            n_inf += 1
+            continue
+        assert best is not None, (trial, "the solver returned a point, enumeration found none")
+        sc = 1.0 + float(np.max(np.abs(best[0])))
+        assert np.max(np.abs(x - best[0])) < 1e-8 * sc and abs(fval - best[1]) < 1e-9 * (1.0 + abs(best[1])), (trial, x, best[0])
+        s_ = C.T @ x - b
+        assert np.all(s_[meq:] >= -1e-9 * sc) and np.all(lagr[meq:] >= 0.0) and np.max(np.abs(lagr[meq:] * s_[meq:])) < 1e-8 * sc * (1.0 + float(np.max(lagr)))
+        if meq == 0:        # stationarity with quadprog's multipliers: G x - a = C lagr
+            assert np.max(np.abs(Gm @ x - a - C @ lagr)) < 1e-8 * (1.0 + float(np.max(np.abs(Gm @ x - a))))
+        n_sol += 1
+        n_drop += 1 if iters[1] > 0 else 0
+    assert n_sol > 150 and n_inf > 40 and n_drop > 20, (n_sol, n_inf, n_drop)
+
+
 def test_iqp_golden_shapes(golden):
     g = golden["rounded_rectangle"]
     assert list(g["iqp_n"]) == [105, 104, 103]
