@@ -181,6 +181,34 @@ def test_long_ring_general_path_properties(gpu_engine):
     assert st2[0] == 0 and np.max(np.abs(np.roll(al2[0], -r) - al[0])) < ALPHA_TOL
 
 
+def test_very_long_rings_run_with_few_or_no_goldfarb_idnani_slots(monkeypatch):
+    """the Goldfarb-Idnani slots -- a rare fallback -- were allocated eagerly and fatally: a ring of 20 000 waypoints needed
+    6.4 GB for ONE slot and failed the launch with MCQ_E_DEVICE before any kernel ran, although round 4 had solved such rings through the
+    long-ring route.  Round 6: full slots are capped by $MCQ_GI_BYTES and never fatal.  A ring of 20 000 waypoints with the default cap (two
+    slots) and one of 40 000 with a cap no slot fits under (the handle then has NO Goldfarb-Idnani pool): both solve, within 1e-7 m of CPU-B
+    (independent assembly and solver, O(n))."""
+    from oracle import banded_ref
+    for n, cap in ((20000, None), (40000, str(8 << 30))):
+        if cap is None:
+            monkeypatch.delenv("MCQ_GI_BYTES", raising=False)
+        else:
+            monkeypatch.setenv("MCQ_GI_BYTES", cap)           # 2 n^2 doubles = 25.6 GB per slot at n = 40 000: none fits
+        eng = engine.Engine(0)
+        try:
+            xy = synthetic.oval_centreline(n, perimeter=3.0 * n, k1=7 * n // 2000, k2=23 * n // 2000, fine=20)
+            nv, sc = synthetic.prepared_track(xy)
+            ref = np.column_stack((xy, synthetic.widths(n, 77)))
+            al, curv, st, info = eng.solve_batch([dict(reftrack=ref, normvec=nv, scaling=sc, kappa_bound=0.12, w_veh=3.4)])
+            assert st[0] == 0, (n, st[0], info[0])
+            a_cpu, c_cpu, st_cpu, _, _ = banded_ref.solve_batch(ref[None], nv[None], sc[None], 0.12, 3.4)
+            assert st_cpu[0] == 0 and np.max(np.abs(al[0] - a_cpu[0])) < 1e-7 and abs(curv[0] - c_cpu[0]) < 1e-8, (n, float(np.max(np.abs(al[0] - a_cpu[0]))))
+            assert 0 < info[0]["n_active_box"] < n and info[0]["gi_iters"] == 0
+            print("ring of %d waypoints: max |alpha - CPU-B| %.1e m, %d active rows, workspace %.2f GB" % (
+                n, float(np.max(np.abs(al[0] - a_cpu[0]))), info[0]["n_active_box"], eng.workspace_bytes() / 1e9))
+        finally:
+            eng.close()
+
+
 def test_oval_n1000_against_dense_gi_oracle(gpu_engine):
     """One N = 1000 oval against the LIVE dense oracle (dense inverse + dense Goldfarb-Idnani, about 10 s of CPU); the full
     size, N = 2000, is checked against the committed oracle output in test_oval_n2000_* below."""
