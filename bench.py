@@ -751,9 +751,17 @@ def main():
             iq0 = eng.iqp_batch(trk, KAPPA_BOUND, W_VEH, 3.0, iters_min=3, curv_error_allowed=0.01, nmax=nmx)
             t_iqp_fresh = time.perf_counter() - t1
             t1 = time.perf_counter()
-            iq = eng.iqp_batch(trk, KAPPA_BOUND, W_VEH, 3.0, iters_min=3, curv_error_allowed=0.01, nmax=nmx, out=obuf)
+            iq_pg = eng.iqp_batch(trk, KAPPA_BOUND, W_VEH, 3.0, iters_min=3, curv_error_allowed=0.01, nmax=nmx, out=obuf)
+            t_iqp_pageable = time.perf_counter() - t1
+            # the steady state of a batch service: its input arrays are page-locked too (the rows of p_ref / p_nv / p_sc, back to back) -- round 6: such
+            # a batch goes to the device without the packing pass (mcq_last_upload_was_direct)
+            trk_p = dict(reftrack=p_ref, normvectors=p_nv, scaling=p_sc)
+            eng.iqp_batch(trk_p, KAPPA_BOUND, W_VEH, 3.0, iters_min=3, curv_error_allowed=0.01, nmax=nmx, out=obuf)
+            t1 = time.perf_counter()
+            iq = eng.iqp_batch(trk_p, KAPPA_BOUND, W_VEH, 3.0, iters_min=3, curv_error_allowed=0.01, nmax=nmx, out=obuf)
             t_iqp = time.perf_counter() - t1
-            same = all(np.array_equal(a, b) for a, b in zip(iq0["alpha"], iq["alpha"]))
+            direct = eng.last_upload_was_direct()
+            same = all(np.array_equal(a, b) for a, b in zip(iq0["alpha"], iq["alpha"])) and all(np.array_equal(a, b) for a, b in zip(iq0["alpha"], iq_pg["alpha"]))
             # per-pass figures need the host between the rounds: the same call with timed statistics (one launch per round over the whole
             # batch, per-track records read back after every pass) -- its end states must be the same bit for bit
             t1 = time.perf_counter()
@@ -765,12 +773,14 @@ def main():
                           "pass_ms": iqt["stats"]["solver_ms"], "warm_start_fallbacks_per_pass": iqt["stats"]["fallbacks"],
                           "seconds_round_by_round_with_statistics": t_iqp_timed,
                           "failed_tracks": int(np.count_nonzero(iq["status"])), "n_final_range": [int(iq["n"].min()), int(iq["n"].max())],
-                          "seconds_fresh_output_arrays": t_iqp_fresh, "alpha_equal_between_the_three_calls": bool(same),
+                          "seconds_fresh_output_arrays": t_iqp_fresh, "seconds_pageable_inputs": t_iqp_pageable, "inputs_uploaded_without_packing": bool(direct),
+                          "alpha_equal_between_the_calls": bool(same),
                           "what": "mcq_iqp_batch: iqp_handler (stepsize_interp 3.0, iters_min 3, curv_error_allowed 0.01) of the %d tracks as one "
                                   "call -- QP passes, termination test, damping and re-linearisation glue on the device, passes 2+ warm-started; "
                                   "the first iters_min rounds are ONE launch in which every workgroup takes its track through the rounds on its "
-                                  "own (mcq_iqp_rounds_kernel), the batch is packed into pinned staging by several host threads; end states land in page-locked "
-                                  "arrays kept by the caller (seconds_fresh_output_arrays: the same call allocating and touching fresh numpy "
+                                  "own (mcq_iqp_rounds_kernel); inputs AND end states in page-locked arrays kept by the caller: the batch goes up straight "
+                                  "from them, no packing pass (round 6; seconds_pageable_inputs: the same call from pageable numpy inputs, packed into "
+                                  "pinned staging by several host threads; seconds_fresh_output_arrays: also allocating and touching fresh output "
                                   "arrays).  pass_ms / fallbacks: from a third call with per-round statistics (one launch per round, HIP "
                                   "events, records read back after every pass: seconds_round_by_round_with_statistics)" % B}
             if not args.no_cpu_baseline:

@@ -103,6 +103,7 @@ struct mcq_handle {
     hipStream_t cs_in = nullptr, cs_out = nullptr;
     hipEvent_t ev_up[2] = {nullptr, nullptr}, ev_done[2] = {nullptr, nullptr}, ev_down[2] = {nullptr, nullptr};
     hipEvent_t ev_slice[16] = {};      // mcq_solve_host / mcq_solve_batch in slices: upload / kernel done, per slice
+    int last_upload_direct = 0;         // the last host-buffer batch went up without the packing pass (mcq_last_upload_was_direct)
     double *p_ref = nullptr, *p_nv = nullptr, *p_sc = nullptr, *p_alpha = nullptr, *p_curv = nullptr;
     int* p_status = nullptr;
     size_t pipe_elems = 0, pipe_batch = 0;
@@ -976,6 +977,8 @@ extern "C" int mcq_timing_end(mcq_handle* h, float* ms_out, int* launches_out)
     return 0;
 }
 
+extern "C" int mcq_last_upload_was_direct(mcq_handle* h) { return h ? h->last_upload_direct : 0; }
+
 extern "C" long long mcq_workspace_bytes(mcq_handle* h) { return h ? h->ws_bytes + h->gi_bytes + h->gis_bytes + h->alt_bytes : 0; }
 
 static int ensure_pin(mcq_handle* h, size_t bytes)
@@ -1660,6 +1663,44 @@ static int pack_and_upload(mcq_handle* h, const mcq_problem* probs, int batch, s
             P.n[b] = probs[b].n;
         }
     };
+    // ---- no packing at all (round 6): a UNIFORM batch that lies in the caller's memory as one contiguous, page-locked block per array (what
+    //      engine.py hands over for stacked arrays from mcq_host_alloc) goes to the device straight from there -- one strided copy per array
+    //      (rows of n waypoints into rows of nmax) instead of a 115 MB memcpy into the staging first: that memcpy was 4-6 ms of a 36-42 ms
+    //      mcq_iqp_batch call and the part of it that differs from host to host.  $MCQ_PACK_ALWAYS=1: the packing pass (A/B knob). ----
+    {
+        const int n0 = probs[0].n;
+        bool direct = batch >= 2 && n0 > 0 && !getenv("MCQ_PACK_ALWAYS");
+        for (int b = 1; b < batch && direct; ++b) {
+            direct = probs[b].n == n0 && probs[b].reftrack == probs[0].reftrack + (size_t)b * n0 * 4
+                     && (!with_nv || probs[b].normvec == probs[0].normvec + (size_t)b * n0 * 2)
+                     && (probs[0].scaling ? probs[b].scaling == probs[0].scaling + (size_t)b * n0 : probs[b].scaling == nullptr);
+        }
+        auto pinned = [](const void* p) {
+            hipPointerAttribute_t a;
+            if (hipPointerGetAttributes(&a, p) != hipSuccess) { (void)hipGetLastError(); return false; }
+            return a.type == hipMemoryTypeHost;
+        };
+        direct = direct && pinned(probs[0].reftrack) && (!with_nv || pinned(probs[0].normvec)) && (!probs[0].scaling || pinned(probs[0].scaling));
+        h->last_upload_direct = direct ? 1 : 0;
+        if (direct) {
+            hipStream_t up = force_chunks > 0 ? h->cs_in : h->stream;
+            for (int b = 0; b < batch; ++b) { P.kb[b] = probs[b].kappa_bound; P.wv[b] = probs[b].w_veh; P.n[b] = probs[b].n; }
+            HIP_TRY_SYNC(hipMemcpyAsync(h->d_kb, P.kb, batch * sizeof(double), hipMemcpyHostToDevice, up));
+            HIP_TRY_SYNC(hipMemcpyAsync(h->d_wv, P.wv, batch * sizeof(double), hipMemcpyHostToDevice, up));
+            HIP_TRY_SYNC(hipMemcpyAsync(h->d_n, P.n, batch * sizeof(int), hipMemcpyHostToDevice, up));
+            const size_t w = (size_t)n0 * sizeof(double), pitch = nmax * sizeof(double);
+            const int nck = force_chunks > 0 ? std::min(force_chunks, batch) : 1;
+            for (int ck = 0; ck < nck; ++ck) {
+                const int b0 = (int)((long long)batch * ck / nck), b1 = (int)((long long)batch * (ck + 1) / nck);
+                const size_t rows = (size_t)(b1 - b0);
+                HIP_TRY_SYNC(hipMemcpy2DAsync(h->d_ref + (size_t)b0 * nmax * 4, pitch * 4, probs[b0].reftrack, w * 4, w * 4, rows, hipMemcpyHostToDevice, up));
+                if (with_nv) HIP_TRY_SYNC(hipMemcpy2DAsync(h->d_nv + (size_t)b0 * nmax * 2, pitch * 2, probs[b0].normvec, w * 2, w * 2, rows, hipMemcpyHostToDevice, up));
+                if (any_sc) HIP_TRY_SYNC(hipMemcpy2DAsync(h->d_sc + (size_t)b0 * nmax, pitch, probs[b0].scaling, w, w, rows, hipMemcpyHostToDevice, up));
+                if (after_chunk) { if (int rc2 = after_chunk(ck, b0, b1)) return rc2; }
+            }
+            return 0;
+        }
+    }
     // A large batch (the 1024 N = 2000 tracks of the bench: 115 MB) is packed in four chunks of tracks by several host threads, and a
     // chunk's uploads are queued as soon as it is packed: one thread copies at ~10 GB/s -- 11 ms, a quarter of the whole mcq_iqp_batch
     // call -- and the DMA of chunk k runs while chunk k + 1 is packed.  $MCQ_PACK_THREADS: threads (default 8 for batches above 8 MB; 1 = the single loop).

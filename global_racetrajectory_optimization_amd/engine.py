@@ -102,7 +102,7 @@ EXPORTED_SYMBOLS = ("mcq_create", "mcq_destroy", "mcq_last_error", "mcq_default_
                     "mcq_device_free", "mcq_copy_to_device", "mcq_copy_to_host", "mcq_sync", "mcq_stream",
                     "mcq_last_timing", "mcq_timing_begin", "mcq_timing_end", "mcq_workspace_bytes",
                     "mcq_comm_unique_id", "mcq_comm_init", "mcq_comm_allgather", "mcq_comm_wait", "mcq_comm_world", "mcq_comm_destroy",
-                    "mcq_les_scalings")
+                    "mcq_les_scalings", "mcq_last_upload_was_direct")
 
 
 IQP_ROUND_CB = ctypes.CFUNCTYPE(None, ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.POINTER(ctypes.c_double), ctypes.POINTER(ctypes.c_int))
@@ -146,6 +146,8 @@ def load_library(path=None):
     lib.mcq_iqp_batch.restype = ctypes.c_int
     lib.mcq_iqp_set_round_callback.argtypes = [vp, IQP_ROUND_CB, vp]
     lib.mcq_iqp_set_round_callback.restype = ctypes.c_int
+    lib.mcq_last_upload_was_direct.argtypes = [vp]
+    lib.mcq_last_upload_was_direct.restype = ctypes.c_int
     lib.mcq_les_scalings.argtypes = [vp, ctypes.c_int, vp, ctypes.c_int]
     lib.mcq_les_scalings.restype = ctypes.c_int
     lib.mcq_host_alloc.argtypes = [vp, ctypes.c_size_t, ctypes.POINTER(vp)]
@@ -267,6 +269,10 @@ class Engine:
         self.h = h
         self.device_id = int(device_id)
         self.lib_path = lib_path
+
+    def last_upload_was_direct(self):
+        """True if the last solve_batch / iqp_batch went to the device without the packing pass (uniform batch, rows back to back in host_array memory)."""
+        return bool(self.lib.mcq_last_upload_was_direct(self.h))
 
     def close(self):
         if getattr(self, "h", None):

@@ -421,6 +421,12 @@ int mcq_timing_end(mcq_handle* h, float* ms_out, int* launches_out);
 /* Bytes of device workspace the handle currently holds (for DESIGN.md / bench reporting). */
 long long mcq_workspace_bytes(mcq_handle* h);
 
+/* 1 if the last host-buffer batch of problem records (mcq_solve_batch, mcq_iqp_batch) was uploaded WITHOUT the packing pass (round 6): a
+ * uniform batch -- every track n waypoints -- whose reftrack / normvec / scaling rows lie back to back in page-locked memory (mcq_host_alloc) goes
+ * to the device straight from there, one strided copy per array; anything else (ragged, pageable, scattered) is packed into the handle's pinned
+ * staging first (several host threads, chunk by chunk).  $MCQ_PACK_ALWAYS=1 forces the packing pass.  Same results either way. */
+int mcq_last_upload_was_direct(mcq_handle* h);
+
 /* ---- the one collective of a multi-GPU job (north_star: "a single RCCL all-gather over xGMI to collect the alpha
  *      vectors").  One process per GPU, one handle per process; independent QPs are block-partitioned over the ranks and every rank
  *      solves its shard with the entries above -- no collective inside a solve.  The gather is the engine's own: ncclAllGather of RCCL

@@ -23,6 +23,7 @@ inline double hipemu_now() { return std::chrono::duration<double, std::milli>(st
 #include <cstdlib>
 #include <cstring>
 #include <functional>
+#include <mutex>
 #include <vector>
 
 using std::isfinite;
@@ -397,8 +398,42 @@ inline hipError_t hipMemset(void* p, int v, size_t n) { memset(p, v, n); return 
 inline hipError_t hipMalloc(void** p, size_t n) { *p = calloc(n ? n : 1, 1); return *p ? hipSuccess : hipErrorInvalidValue; }
 inline hipError_t hipFree(void* p) { free(p); return hipSuccess; }
 enum { hipHostMallocDefault = 0 };
-inline hipError_t hipHostMalloc(void** p, size_t n, unsigned) { *p = calloc(n ? n : 1, 1); return *p ? hipSuccess : hipErrorInvalidValue; }
-inline hipError_t hipHostFree(void* p) { free(p); return hipSuccess; }
+/* page-locked host memory: the interpreter keeps the ranges, so that hipPointerGetAttributes can tell them from pageable memory (the library
+ * uploads a uniform batch straight from pinned arrays, without its packing pass) */
+inline std::vector<std::pair<char*, size_t>>& hipemu_pinned_() { static std::vector<std::pair<char*, size_t>> v; return v; }
+inline std::mutex& hipemu_pinned_mutex_() { static std::mutex m; return m; }
+inline hipError_t hipHostMalloc(void** p, size_t n, unsigned)
+{
+    *p = calloc(n ? n : 1, 1);
+    if (!*p) return hipErrorInvalidValue;
+    std::lock_guard<std::mutex> g(hipemu_pinned_mutex_());
+    hipemu_pinned_().push_back({(char*)*p, n ? n : 1});
+    return hipSuccess;
+}
+inline hipError_t hipHostFree(void* p)
+{
+    {
+        std::lock_guard<std::mutex> g(hipemu_pinned_mutex_());
+        auto& v = hipemu_pinned_();
+        for (size_t i = 0; i < v.size(); ++i) if (v[i].first == (char*)p) { v.erase(v.begin() + i); break; }
+    }
+    free(p);
+    return hipSuccess;
+}
+enum hipMemoryType { hipMemoryTypeUnregistered = 0, hipMemoryTypeHost = 1, hipMemoryTypeDevice = 2 };
+struct hipPointerAttribute_t { hipMemoryType type; int device; void* devicePointer; void* hostPointer; };
+inline hipError_t hipPointerGetAttributes(hipPointerAttribute_t* a, const void* p)
+{
+    std::lock_guard<std::mutex> g(hipemu_pinned_mutex_());
+    for (auto& r : hipemu_pinned_())
+        if ((const char*)p >= r.first && (const char*)p < r.first + r.second) { a->type = hipMemoryTypeHost; a->device = 0; a->devicePointer = a->hostPointer = (void*)p; return hipSuccess; }
+    return hipErrorInvalidValue;       /* (as the runtime answers for pageable memory) */
+}
+inline hipError_t hipMemcpy2DAsync(void* d, size_t dpitch, const void* s, size_t spitch, size_t width, size_t height, hipMemcpyKind, hipStream_t)
+{
+    for (size_t r = 0; r < height; ++r) memcpy((char*)d + r * dpitch, (const char*)s + r * spitch, width);
+    return hipSuccess;
+}
 inline hipError_t hipMemcpyAsync(void* d, const void* s, size_t n, hipMemcpyKind, hipStream_t) { memcpy(d, s, n); return hipSuccess; }
 inline hipError_t hipMemsetAsync(void* d, int v, size_t n, hipStream_t) { memset(d, v, n); return hipSuccess; }
 inline hipError_t hipMemcpy(void* d, const void* s, size_t n, hipMemcpyKind) { memcpy(d, s, n); return hipSuccess; }

@@ -764,6 +764,48 @@ def test_solve_host_in_slices_is_bitwise_the_one_launch(emu, monkeypatch):
     assert [i["ipm_iters"] for i in i_sl] == [i["ipm_iters"] for i in i_one]
 
 
+def test_uniform_pinned_batches_skip_the_packing_pass(emu, golden, monkeypatch):
+    """Round 6: a uniform batch whose arrays lie in page-locked memory as one contiguous block each (rows of engine.host_array blocks; what a batch
+    service keeps between calls) is uploaded straight from there -- one strided copy per array, rows of n waypoints into rows of nmax -- instead
+    of being packed into the staging first.  mcq_solve_batch (one launch and in slices) and mcq_iqp_batch (whose device rows are LONGER than the
+    caller's: nmax > n) must return what the packing pass ($MCQ_PACK_ALWAYS=1) returns, bit for bit; pageable copies of the same arrays take the
+    packing pass by themselves."""
+    g = golden["rounded_rectangle"]
+    n, bsz = g["reftrack"].shape[0], 9
+    p_ref, p_nv, p_sc = emu.host_array((bsz, n, 4)), emu.host_array((bsz, n, 2)), emu.host_array((bsz, n))
+    rng = np.random.default_rng(2)
+    for k in range(bsz):
+        p_ref[k] = g["reftrack"]
+        p_ref[k, :, 2:] += rng.uniform(0.0, 0.6, size=(n, 2))
+        p_nv[k], p_sc[k] = g["normvec"], g["scaling"]
+    probs = [dict(reftrack=p_ref[k], normvec=p_nv[k], scaling=p_sc[k], kappa_bound=0.12, w_veh=3.4) for k in range(bsz)]
+    pageable = [dict(reftrack=p_ref[k].copy(), normvec=p_nv[k].copy(), scaling=p_sc[k].copy(), kappa_bound=0.12, w_veh=3.4) for k in range(bsz)]
+    a_dir, c_dir, s_dir, _ = emu.solve_batch(probs)
+    assert emu.last_upload_was_direct()
+    a_pg, c_pg, s_pg, _ = emu.solve_batch(pageable)
+    assert not emu.last_upload_was_direct()
+    monkeypatch.setenv("MCQ_HOST_SLICE_MIN", "8")
+    a_sl, c_sl, s_sl, _ = emu.solve_batch(probs)                   # direct uploads per slice
+    assert emu.last_upload_was_direct()
+    monkeypatch.setenv("MCQ_PACK_ALWAYS", "1")
+    a_pk, c_pk, s_pk, _ = emu.solve_batch(probs)
+    assert not emu.last_upload_was_direct()
+    assert np.all(s_dir == 0)
+    for other_a, other_c in ((a_pg, c_pg), (a_sl, c_sl), (a_pk, c_pk)):
+        assert all(np.array_equal(x, y) for x, y in zip(a_dir, other_a)) and np.array_equal(c_dir, other_c)
+    assert not np.array_equal(a_dir[0], a_dir[1])                    # (the widths differ: the rows did not all come from track 0)
+    # the IQP call: stacked pinned arrays, device rows of nmax > n waypoints
+    trk = dict(reftrack=p_ref[:4], normvectors=p_nv[:4], scaling=p_sc[:4])
+    iq_pk = emu.iqp_batch(trk, 0.12, 3.4, 3.0, iters_min=3, curv_error_allowed=0.01)
+    assert not emu.last_upload_was_direct()
+    monkeypatch.delenv("MCQ_PACK_ALWAYS")
+    iq_dir = emu.iqp_batch(trk, 0.12, 3.4, 3.0, iters_min=3, curv_error_allowed=0.01)
+    assert emu.last_upload_was_direct()
+    assert iq_dir["stats"]["nmax"] > n and np.all(iq_dir["status"] == 0)
+    assert all(np.array_equal(x, y) for x, y in zip(iq_dir["alpha"], iq_pk["alpha"]))
+    assert all(np.array_equal(x, y) for x, y in zip(iq_dir["reftrack"], iq_pk["reftrack"]))
+
+
 def test_solve_host_pipelined_equals_solve_host(emu, golden):
     """mcq_solve_host_pipelined (uploads / kernels / downloads of consecutive batches overlapped on three streams, two staging
     slots): every step's results are bitwise those of the blocking entry on the same buffers -- five steps, so both slots are
