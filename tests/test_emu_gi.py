@@ -164,7 +164,7 @@ def test_slot_pools_small_full_and_none(emu, emu_lib, monkeypatch):
 
 
 def test_a_slice_of_the_curvature_tight_fuzz_on_the_interpreter(emu):
-    """Every twelfth problem of tests/golden/kappa_tight_fuzz.npz (13 of the 220: stadium plateaus, star-shaped rings, the reference's tracks with
+    """Every twelfth problem of tests/golden/kappa_tight_fuzz.npz (11 of the 220: stadium plateaus, star-shaped rings, the reference's tracks with
     the curvature bound drawn between 0.6 x and 1.0 x the box optimum's curvature maximum; some INCONSISTENT) through the unchanged kernel sources
     on the CPU in one ragged launch, and three of those through the Goldfarb-Idnani path alone: the dense Goldfarb-Idnani's verdict
     and vertex from both.  Problem 18 is one of those whose block-pivoting phase starts to cycle: it must hand over to the Goldfarb-Idnani path
@@ -172,7 +172,7 @@ def test_a_slice_of_the_curvature_tight_fuzz_on_the_interpreter(emu):
     import os
     z = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "kappa_tight_fuzz.npz"))
     off = z["offsets"]
-    sl = [k for k in range(6, len(off) - 1, 12) if k not in (42, 78, 102, 150, 198)]      # (two of the three inconsistent ones left to the GPU suite: 7 and 11 s
+    sl = [k for k in range(6, len(off) - 1, 12) if k not in (42, 78, 54, 90, 102, 150, 198)]      # (two of the three inconsistent ones left to the GPU suite: 7 and 11 s
                                                                                           #  here; three more dropped in round 6: the serial suite's minutes)
     for alg, ks in ((engine.ALG_DEFAULT, sl), (engine.ALG_GI, [30, 66, 138])):
         probs = [dict(reftrack=z["reftrack"][off[k]:off[k + 1]], normvec=z["normvec"][off[k]:off[k + 1]], scaling=z["scaling"][off[k]:off[k + 1]],
@@ -221,15 +221,15 @@ def test_random_rings_against_the_live_dense_oracle_on_the_interpreter(emu):
 
 
 def test_full_size_dense_goldens_on_the_interpreter(emu):
-    """BASELINE's size on the CPU suite: eleven of the dense-oracle goldens of N = 2000 ... 2600 waypoints (first passes of the synthetic ovals,
+    """BASELINE's size on the CPU suite: nine of the dense-oracle goldens of N = 2000 ... 2600 waypoints (first passes of the synthetic ovals,
     one with the curvature bound active; N = 2100 / 2600 / 2600 with the curvature bound active: the long-ring route; IQP second / third-pass
     QPs with their unit scalings and barely active bounds) through the interpreted kernel sources in one ragged launch -- 1e-8 m from the
     dense oracle, `curv_error_max` to 1e-9 --, and the N = 2000 one with active curvature rows through the Goldfarb-Idnani path alone as well,
     bitwise the default path's alpha."""
     import os
     gdir = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
-    names = ("oval_n2000_w1", "oval_n2000_w7", "oval_n2000_c5", "oval_n2000_c13", "oval_n2000_kappa", "oval_n2100", "oval_n2600",
-             "oval_n2600_kappa", "iqp_pass2_oval5", "iqp_pass3_oval3", "iqp_pass3_oval629")          # (the GPU suite takes all eighteen)
+    names = ("oval_n2000_w1", "oval_n2000_c5", "oval_n2000_c13", "oval_n2000_kappa", "oval_n2100", "oval_n2600",
+             "oval_n2600_kappa", "iqp_pass2_oval5", "iqp_pass3_oval3")          # (the GPU suite takes all eighteen; round 6: two fewer here, the suite's minutes)
     files = [os.path.join(gdir, nm + ".npz") for nm in names]
     gs = [np.load(f) for f in files]
     probs = [dict(reftrack=g["reftrack"], normvec=g["normvec"], scaling=g["scaling"] if "scaling" in g.files else None,

@@ -728,38 +728,38 @@ def test_solve_host_in_slices_is_bitwise_the_one_launch(emu, monkeypatch):
     """Round 6: mcq_solve_host takes a batch of 512 or more (here: $MCQ_HOST_SLICE_MIN = 8) in SLICES (two by default, four here) -- upload k + 1 / kernel k / download k - 1 overlapped, the kernels of
     consecutive slices on the handle's two compute streams, all on disjoint rows of one workspace (McqBatch.pb0) -- and must return what the one
     launch ($MCQ_HOST_ONE_LAUNCH=1) returns, bit for bit, info records included; a narrow corridor in slice 2 keeps its status."""
-    monkeypatch.setenv("MCQ_HOST_SLICE_MIN", "8")
+    monkeypatch.setenv("MCQ_HOST_SLICE_MIN", "4")
     monkeypatch.setenv("MCQ_HOST_SLICES", "4")          # (the default is two; four exercises a stream's second slice)
-    n, bsz = 24, 11                         # (not a multiple of four: the slices differ in size)
+    n, bsz = 24, 7                          # (not a multiple of four: the slices differ in size)
     base = [_small_track(n, seed=300 + k) for k in range(5)]
     rng = np.random.default_rng(9)
     refs = np.stack([base[k % 5][0] for k in range(bsz)])
     refs[:, :, 2:] += rng.uniform(0.0, 0.8, size=(bsz, n, 2))
-    refs[7, 3, 2:] = 0.5                     # w_r + w_l < w_veh: MCQ_INFEASIBLE for this one
+    refs[5, 3, 2:] = 0.5                     # w_r + w_l < w_veh: MCQ_INFEASIBLE for this one
     nvs = np.stack([base[k % 5][1] for k in range(bsz)])
     scs = np.stack([base[k % 5][3] for k in range(bsz)])
     al, cu, st, info = emu.solve_host(refs, nvs, scs, 0.5, 2.0)
     monkeypatch.setenv("MCQ_HOST_ONE_LAUNCH", "1")
     al1, cu1, st1, info1 = emu.solve_host(refs, nvs, scs, 0.5, 2.0)
-    assert st[7] == engine.STATUS_INFEASIBLE and np.count_nonzero(st) == 1 and np.array_equal(st, st1)
+    assert st[5] == engine.STATUS_INFEASIBLE and np.count_nonzero(st) == 1 and np.array_equal(st, st1)
     assert np.array_equal(al, al1) and np.array_equal(cu, cu1)
     assert [i.ipm_iters for i in info] == [i.ipm_iters for i in info1] and [i.as_iters for i in info] == [i.as_iters for i in info1]
     # ... and what the ragged host-buffer entry returns for three of them
-    probs = [dict(reftrack=refs[k], normvec=nvs[k], scaling=scs[k], kappa_bound=0.5, w_veh=2.0) for k in (0, 5, 10)]
+    probs = [dict(reftrack=refs[k], normvec=nvs[k], scaling=scs[k], kappa_bound=0.5, w_veh=2.0) for k in (0, 4, 6)]
     al2, _, st2, _ = emu.solve_batch(probs)
-    assert all(np.array_equal(al2[j], al[k]) for j, k in enumerate((0, 5, 10)))
-    # the ragged host-buffer entry (mcq_solve_batch: what the drop-in's opt_min_curv_batch calls) slices the same way: eleven rings of three
+    assert all(np.array_equal(al2[j], al[k]) for j, k in enumerate((0, 4, 6)))
+    # the ragged host-buffer entry (mcq_solve_batch: what the drop-in's opt_min_curv_batch calls) slices the same way: seven rings of three
     # different sizes, per-problem vehicle widths, one of them infeasible -- sliced and in one launch, bit for bit
     rag = []
-    for k in range(11):
+    for k in range(7):
         r_, v_, _, s_ = _small_track(20 + 3 * (k % 3), seed=400 + k)
         rag.append(dict(reftrack=r_, normvec=v_, scaling=s_, kappa_bound=0.5, w_veh=2.0 + 0.05 * k))
-    rag[6]["reftrack"] = rag[6]["reftrack"].copy()
-    rag[6]["reftrack"][2, 2:] = 0.4
+    rag[3]["reftrack"] = rag[3]["reftrack"].copy()
+    rag[3]["reftrack"][2, 2:] = 0.4
     a_one, c_one, s_one, i_one = emu.solve_batch(rag)           # (MCQ_HOST_ONE_LAUNCH is still set)
     monkeypatch.delenv("MCQ_HOST_ONE_LAUNCH")
     a_sl, c_sl, s_sl, i_sl = emu.solve_batch(rag)
-    assert list(s_sl) == list(s_one) and s_sl[6] == engine.STATUS_INFEASIBLE and np.count_nonzero(s_sl) == 1
+    assert list(s_sl) == list(s_one) and s_sl[3] == engine.STATUS_INFEASIBLE and np.count_nonzero(s_sl) == 1
     assert all(np.array_equal(x, y) for x, y in zip(a_sl, a_one)) and np.array_equal(c_sl, c_one)
     assert [i["ipm_iters"] for i in i_sl] == [i["ipm_iters"] for i in i_one]
 
@@ -771,20 +771,21 @@ def test_uniform_pinned_batches_skip_the_packing_pass(emu, golden, monkeypatch):
     caller's: nmax > n) must return what the packing pass ($MCQ_PACK_ALWAYS=1) returns, bit for bit; pageable copies of the same arrays take the
     packing pass by themselves."""
     g = golden["rounded_rectangle"]
-    n, bsz = g["reftrack"].shape[0], 9
+    t_ref, t_nv, _, t_sc = _small_track(30, seed=77)
+    n, bsz = 30, 5
     p_ref, p_nv, p_sc = emu.host_array((bsz, n, 4)), emu.host_array((bsz, n, 2)), emu.host_array((bsz, n))
     rng = np.random.default_rng(2)
     for k in range(bsz):
-        p_ref[k] = g["reftrack"]
+        p_ref[k] = t_ref
         p_ref[k, :, 2:] += rng.uniform(0.0, 0.6, size=(n, 2))
-        p_nv[k], p_sc[k] = g["normvec"], g["scaling"]
-    probs = [dict(reftrack=p_ref[k], normvec=p_nv[k], scaling=p_sc[k], kappa_bound=0.12, w_veh=3.4) for k in range(bsz)]
-    pageable = [dict(reftrack=p_ref[k].copy(), normvec=p_nv[k].copy(), scaling=p_sc[k].copy(), kappa_bound=0.12, w_veh=3.4) for k in range(bsz)]
+        p_nv[k], p_sc[k] = t_nv, t_sc
+    probs = [dict(reftrack=p_ref[k], normvec=p_nv[k], scaling=p_sc[k], kappa_bound=0.5, w_veh=2.0) for k in range(bsz)]
+    pageable = [dict(reftrack=p_ref[k].copy(), normvec=p_nv[k].copy(), scaling=p_sc[k].copy(), kappa_bound=0.5, w_veh=2.0) for k in range(bsz)]
     a_dir, c_dir, s_dir, _ = emu.solve_batch(probs)
     assert emu.last_upload_was_direct()
     a_pg, c_pg, s_pg, _ = emu.solve_batch(pageable)
     assert not emu.last_upload_was_direct()
-    monkeypatch.setenv("MCQ_HOST_SLICE_MIN", "8")
+    monkeypatch.setenv("MCQ_HOST_SLICE_MIN", "4")
     a_sl, c_sl, s_sl, _ = emu.solve_batch(probs)                   # direct uploads per slice
     assert emu.last_upload_was_direct()
     monkeypatch.setenv("MCQ_PACK_ALWAYS", "1")
@@ -794,12 +795,17 @@ def test_uniform_pinned_batches_skip_the_packing_pass(emu, golden, monkeypatch):
     for other_a, other_c in ((a_pg, c_pg), (a_sl, c_sl), (a_pk, c_pk)):
         assert all(np.array_equal(x, y) for x, y in zip(a_dir, other_a)) and np.array_equal(c_dir, other_c)
     assert not np.array_equal(a_dir[0], a_dir[1])                    # (the widths differ: the rows did not all come from track 0)
-    # the IQP call: stacked pinned arrays, device rows of nmax > n waypoints
-    trk = dict(reftrack=p_ref[:4], normvectors=p_nv[:4], scaling=p_sc[:4])
-    iq_pk = emu.iqp_batch(trk, 0.12, 3.4, 3.0, iters_min=3, curv_error_allowed=0.01)
+    # the IQP call: stacked pinned arrays (two copies of the reference's smallest track), device rows of nmax > n waypoints
+    n = g["reftrack"].shape[0]
+    q_ref, q_nv, q_sc = emu.host_array((2, n, 4)), emu.host_array((2, n, 2)), emu.host_array((2, n))
+    for k in range(2):
+        q_ref[k], q_nv[k], q_sc[k] = g["reftrack"], g["normvec"], g["scaling"]
+    q_ref[1, :, 2:] += 0.2
+    trk = dict(reftrack=q_ref, normvectors=q_nv, scaling=q_sc)
+    iq_pk = emu.iqp_batch(trk, 0.12, 3.4, 3.0, iters_min=2, curv_error_allowed=1.0)          # (two rounds: the upload is what is compared)
     assert not emu.last_upload_was_direct()
     monkeypatch.delenv("MCQ_PACK_ALWAYS")
-    iq_dir = emu.iqp_batch(trk, 0.12, 3.4, 3.0, iters_min=3, curv_error_allowed=0.01)
+    iq_dir = emu.iqp_batch(trk, 0.12, 3.4, 3.0, iters_min=2, curv_error_allowed=1.0)
     assert emu.last_upload_was_direct()
     assert iq_dir["stats"]["nmax"] > n and np.all(iq_dir["status"] == 0)
     assert all(np.array_equal(x, y) for x, y in zip(iq_dir["alpha"], iq_pk["alpha"]))
