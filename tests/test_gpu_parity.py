@@ -158,6 +158,41 @@ def test_full_size_oval_properties(gpu_engine):
     assert np.max(np.abs(al3[1] + al[0])) < ALPHA_TOL
 
 
+def test_full_size_similarity_invariances(gpu_engine):
+    """BASELINE's full size (1024 x N = 2000, one launch) through three more size-independent properties of the QP (round 6): it sees the track only
+    through differences of neighbouring waypoints and through lengths, so (i) moving the whole track by kilometres leaves alpha where it is, (ii)
+    rotating it by an arbitrary angle (normals with it) too, and (iii) scaling every length by c -- waypoints, widths, vehicle width -- with the
+    curvature bound scaled by 1 / c scales alpha by c and the curvature error by 1 / c.  Every problem of the batch, against its own unmoved solve;
+    tolerance 1e-7 m (the moved / rotated coordinates differ from the originals in their last bits: what is checked is that kilometre-sized
+    offsets cost no more than that)."""
+    bsz, n = 1024, 2000
+    ref, nv, sc = synthetic.oval_batch(bsz, n=n)
+    p_al = np.empty((bsz, n))
+    al, curv, st, _ = gpu_engine.solve_host(ref, nv, sc, 0.12, 3.4, alpha_out=p_al)
+    al = al.copy()
+    assert np.all(st == 0)
+    # (i) translation
+    moved = ref.copy()
+    moved[:, :, 0] += 12345.678
+    moved[:, :, 1] -= 3210.987
+    al1, curv1, st1, _ = gpu_engine.solve_host(moved, nv, sc, 0.12, 3.4)
+    assert np.all(st1 == 0) and np.max(np.abs(al1 - al)) < 1e-7 and np.max(np.abs(curv1 - curv)) < 1e-9
+    # (ii) rotation by 0.7 rad about the origin
+    c_, s_ = np.cos(0.7), np.sin(0.7)
+    rot = ref.copy()
+    rot[:, :, 0] = c_ * ref[:, :, 0] - s_ * ref[:, :, 1]
+    rot[:, :, 1] = s_ * ref[:, :, 0] + c_ * ref[:, :, 1]
+    nvr = np.stack((c_ * nv[:, :, 0] - s_ * nv[:, :, 1], s_ * nv[:, :, 0] + c_ * nv[:, :, 1]), axis=2)
+    al2, curv2, st2, _ = gpu_engine.solve_host(rot, nvr, sc, 0.12, 3.4)
+    assert np.all(st2 == 0) and np.max(np.abs(al2 - al)) < 1e-7 and np.max(np.abs(curv2 - curv)) < 1e-9
+    # (iii) similarity: lengths x 2.5, curvature bound / 2.5
+    k = 2.5
+    al3, curv3, st3, _ = gpu_engine.solve_host(ref * k, nv, sc, 0.12 / k, 3.4 * k)
+    assert np.all(st3 == 0) and np.max(np.abs(al3 / k - al)) < 1e-7 and np.max(np.abs(curv3 * k - curv)) < 1e-9
+    print("1024 x N = 2000: max |d alpha| under translation %.1e, rotation %.1e, scaling %.1e m" % (
+        float(np.max(np.abs(al1 - al))), float(np.max(np.abs(al2 - al))), float(np.max(np.abs(al3 / k - al)))))
+
+
 def test_long_ring_general_path_properties(gpu_engine):
     """N = 3000 (> 2048 waypoints: the interior point's general vector passes instead of the register-resident ones, the tridiagonal
     sweeps on workspace vectors instead of LDS): against CPU-B (independent assembly and solver), feasibility, start-index rotation.
