@@ -8,7 +8,7 @@ import os
 import numpy as np
 import pytest
 
-from global_racetrajectory_optimization_amd import engine
+from global_racetrajectory_optimization_amd import engine, synthetic
 
 pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -184,3 +184,25 @@ def test_gi_mode_on_every_full_size_golden(gpu_engine):
     print("GI mode on %d full-size fixtures: steps %s, ms %s, polish rejected %d, max |alpha - oracle| %.1e, max |alpha - default path| %.1e" % (
         len(names), [i["gi_iters"] for i in info], ["%.0f" % (i["ticks"][3] / 1e5) for i in info], sum(1 for i in info if i["second_attempt"] & 8),
         max(d), max(d0)))
+
+
+def test_gi_mode_stays_on_one_stream_in_the_pipelined_entries(gpu_engine):
+    """with mcq_opts.algorithm = MCQ_ALG_GI the second compute stream's workspace held half the fallback's few slots, so odd steps
+    of mcq_solve_host_pipelined / mcq_solve_device_stream ran ~32 problems at a time.  Round 6: MCQ_ALG_GI keeps these entries on ONE compute
+    stream (its per-workgroup slots belong to the first workspace).  Three steps of 96 rings through the mode: every step bitwise the default
+    path's alpha, and no step an order of magnitude slower than the others."""
+    import time
+    bsz, n, steps = 96, 400, 3
+    ref, nv, sc = synthetic.oval_batch(bsz, n=n)
+    refs = [ref.copy() for _ in range(steps)]
+    for k in range(steps):
+        refs[k][:, :, 2:] += 0.01 * k                    # (every step its own widths)
+    outs = [np.empty((bsz, n)) for _ in range(steps)]
+    t0 = time.perf_counter()
+    curv, st = gpu_engine.solve_host_pipelined(refs, [nv] * steps, [sc] * steps, 0.12, 3.4, outs, algorithm=engine.ALG_GI)
+    t_gi = time.perf_counter() - t0
+    assert np.all(st == 0)
+    for k in range(steps):
+        a_def, _, st_def, _ = gpu_engine.solve_host(refs[k], nv, sc, 0.12, 3.4)
+        assert np.all(st_def == 0) and np.array_equal(outs[k], a_def), k
+    assert t_gi < 5.0, t_gi

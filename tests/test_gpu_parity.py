@@ -1172,7 +1172,10 @@ def test_curvature_row_overflow_slots_against_dense_gi(gpu_engine):
     al2, curv2, st2, info2 = gpu_engine.solve_batch(many)
     assert np.all(st2 == 0)
     for k in range(11):
-        assert np.max(np.abs(al2[k] - al[0])) < 1e-9 and abs(curv2[k] - curv[0]) < 1e-12 and info2[k]["n_active_kappa"] == want[0][2]
+        # round 6: ONE route per problem -- every working set beyond MCQ_KMAX rows goes through the Goldfarb-Idnani path, whatever
+        # else is in the launch -- so the copies are BITWISE the single solve again (rounds 3-5: 1e-9, eight of them through overflow slots)
+        assert np.array_equal(al2[k], al[0]) and curv2[k] == curv[0] and info2[k]["n_active_kappa"] == want[0][2], k
+        assert info2[k]["second_attempt"] & 4
     print("11 copies, 8 overflow slots: Goldfarb-Idnani path for %d of them, bitwise equal to the single solve: %d of 11" % (
         sum(1 for i in info2[:11] if i["second_attempt"] & 4), sum(1 for k in range(11) if np.array_equal(al2[k], al[0]))))
     n0 = probs[0]["reftrack"].shape[0]
@@ -1185,7 +1188,7 @@ def test_curvature_row_overflow_slots_against_dense_gi(gpu_engine):
     st3 = gpu_engine.download(d_st, (11,), np.int32)
     assert np.all(st3 == 0), st3
     al3 = gpu_engine.download(d_al, (11, n0), np.float64)
-    assert np.max(np.abs(al3 - al[0][None, :])) < 1e-9
+    assert np.array_equal(al3, np.tile(al[0], (11, 1)))            # ... on the device entry too
     for p_ in (d_ref, d_nv, d_sc, d_al, d_cu, d_st):
         gpu_engine.free(p_)
 
