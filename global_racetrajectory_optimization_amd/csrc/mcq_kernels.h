@@ -107,7 +107,7 @@ struct McqBatch {
     int gi_slots, gi_qcap;  // problem needs the path claims one (and waits for one if all are taken); gi_qcap = constraints a working set can
                             // hold (= nmax: no more can be independent)
     double* gis;            // SMALL slots (round 6; MCQ_ALG_GI: one per resident workgroup), working sets of up to gis_qcap < nmax constraints --
-    int gis_slots, gis_qcap; // what the observed working sets need; a problem that outgrows its small slot starts again in a full one.
+    int gis_slots, gis_qcap; // what the observed working sets need; a problem that outgrows its small slot moves into a full one in place (gi_grow).
                             // Flags: slot_flags[kbig_slots + MCQ_GI_FULL_MAX + s]
 };
 
